@@ -1,0 +1,404 @@
+"""CPU oracle for the ARCO stratified pixel-contrastive hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under arco_amd/ may import this module; only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only
+as the checker.  It is a restatement (plain PyTorch-CPU fp32 / numpy) of the
+reference algorithm, written in "flatten pixels + GEMM + gather" form; every
+function cites the reference file:line it follows (paths relative to
+/root/reference/code).  It is pinned against golden vectors produced by running
+the real reference in the build container (oracle/gen_golden.py ->
+tests/golden/*.npz); see tests/test_oracle_golden.py.
+
+The reference has two loss files that differ only in the number of spatial
+dims (loss_helper_3d.py = 4-D/2-D images, loss_helper.py = 5-D/3-D volumes);
+the restatement below is rank-generic and serves both.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# L3  memory bank                                   loss_helper_3d.py:12-32
+# --------------------------------------------------------------------------
+
+
+@torch.no_grad()
+def dequeue_and_enqueue(keys, queue, queue_ptr, queue_size):
+    """FIFO-by-truncation bank append (loss_helper_3d.py:12-32; loss_helper.py:142-162)."""
+    n = int(keys.shape[0])
+    grown = torch.cat((queue[0], keys.detach().clone().cpu()), dim=0)
+    if grown.shape[0] >= queue_size:
+        queue[0] = grown[grown.shape[0] - queue_size:, :]
+        queue_ptr[0] = queue_size
+    else:
+        queue[0] = grown
+        queue_ptr[0] = (int(queue_ptr) + n) % queue_size
+    return n
+
+
+# --------------------------------------------------------------------------
+# L4  samplers                                      loss_helper_3d.py:35-268
+# --------------------------------------------------------------------------
+
+
+def _strata_1d(high, shape, patch, antithetic):
+    """1-D stratified fallback (loss_helper_3d.py:35-80 asmc / :83-117 smc).
+
+    Uses python `random` for the picks and one torch.randperm for the shuffle.
+    """
+    if high // patch > shape or high < patch:
+        return torch.randint(high, size=(shape,))
+    blocks = (high - high % patch) // patch
+    per = shape // blocks
+    out = []
+    if high % patch != 0 and blocks > shape:          # :44-48 / :92-96 (unreachable: guarded above)
+        b = 0
+        while len(out) < shape:
+            out.append(random.randint(b * patch, (b + 1) * patch - 1))
+            b += 1
+    else:
+        for b in range(blocks):
+            lo, hi = b * patch, (b + 1) * patch - 1
+            if antithetic:
+                first = [random.randint(lo, hi) for _ in range(per // 2)]
+                out.extend(first)
+                out.extend([(2 * b + 1) * patch - 1 - v for v in first])
+            else:
+                out.extend([random.randint(lo, hi) for _ in range(per)])
+        while len(out) < shape:
+            out.append(random.randint(0, high - 1))
+    vals = torch.Tensor(out).reshape(shape,).long()      # float32 round trip, :74 / :111
+    return vals[torch.randperm(shape).long()]
+
+
+def monte_carlo_sample(high=5233, shape=256, patch=16):
+    return _strata_1d(high, shape, patch, antithetic=False)
+
+
+def as_monte_carlo_sample(high=5233, shape=256, patch=16):
+    return _strata_1d(high, shape, patch, antithetic=True)
+
+
+def _grid_blocks(edge, cut):
+    """Yield the row-major flattened pixel ids of each of the cut*cut blocks
+    (loss_helper_3d.py:140-155): block side edge//cut, last row/col absorb the rest."""
+    side = edge // cut
+    grid = np.arange(edge * edge).reshape(edge, edge)
+    for bi in range(cut):
+        r0 = bi * side
+        r1 = edge if bi == cut - 1 else (bi + 1) * side
+        for bj in range(cut):
+            c0 = bj * side
+            c1 = edge if bj == cut - 1 else (bj + 1) * side
+            yield grid[r0:r1, c0:c1].flatten()
+
+
+def _grid_sample(high, shape, cut, antithetic):
+    """2-D stratified sampler (loss_helper_3d.py:120-184 smc, :187-268 asmc).
+
+    RNG call order on the torch CPU default generator: per block randperm(n_blk)
+    then randint(n_blk, (k,)); then randperm(n_kept); then one randint(high,(1,1))
+    per missing element.  Any exception in the reference drops to the 1-D sampler.
+    Two are reachable, both at the FIRST block and before any generator draw
+    (randperm(0)/randperm(1) consume nothing): an empty block (edge < cut) makes
+    randint(0, ...) raise; a 1-element block is indexed by a 1-element tensor,
+    numpy returns a scalar, and `.shape[0]` raises.  So edge//cut <= 1
+    (high <= 56 at cut=4) always takes the 1-D path.
+    """
+    edge = round(math.sqrt(high))
+    per_block = shape * edge ** 2 // high // (cut ** 2)
+    take = per_block // 2 if antithetic else per_block
+    rows = []
+    for blk in _grid_blocks(edge, cut):
+        n = blk.shape[0]
+        if antithetic:
+            center = (2 * np.mean(blk)).astype(np.int64) if n > 0 else None
+        if n <= 1:
+            return None                                  # reference raises -> fallback
+        blk = blk[torch.randperm(n).numpy()]
+        pick = blk[torch.randint(n, (take,)).numpy()]
+        rows.append(pick)
+        if antithetic:
+            rows.append(center - pick)
+    vals = torch.from_numpy(np.array(rows)).to(torch.float32).flatten().long()   # :163 / :245-246
+    vals = vals[vals < high]
+    vals = vals[torch.randperm(vals.shape[0])]
+    if vals.shape[0] < shape:
+        pad = torch.cat([torch.randint(high, (1, 1)) for _ in range(shape - vals.shape[0])]).flatten()
+        vals = torch.cat([vals, pad])
+    return vals[:shape]
+
+
+@torch.no_grad()
+def grid_monte_carlo_sample(high=5233, shape=256, cut_count=4):
+    out = _grid_sample(high, shape, cut_count, antithetic=False)
+    return monte_carlo_sample(high, shape) if out is None else out
+
+
+@torch.no_grad()
+def grid_as_monte_carlo_sample(high=5233, shape=256, cut_count=4):
+    out = _grid_sample(high, shape, cut_count, antithetic=True)
+    return as_monte_carlo_sample(high, shape) if out is None else out
+
+
+# --------------------------------------------------------------------------
+# L1/L2/L5/L6  contrastive loss            loss_helper_3d.py:271-513 (2-D)
+#                                           loss_helper.py:442-686   (3-D)
+# --------------------------------------------------------------------------
+
+
+def class_rank(prob_rows):
+    """rank[p, c] = position of class c in a descending sort of prob_rows[p, :]
+    (loss_helper_3d.py:352-358).  torch's CPU sort is stable for <=16 classes:
+    ties keep the lower class index first."""
+    pi = prob_rows.unsqueeze(2)                # [n, C(i), 1]
+    pj = prob_rows.unsqueeze(1)                # [n, 1, C(j)]
+    C = prob_rows.shape[1]
+    earlier = torch.tril(torch.ones(C, C, dtype=torch.bool), -1)      # [i, j] : j < i
+    return ((pj > pi) | ((pj == pi) & earlier)).sum(2)
+
+
+def _rows(x):
+    """[B, K, *spatial] -> [B*prod(spatial), K] in (b, spatial...) row-major order
+    (the reference's permute(0,2,3,1) / (0,2,3,4,1), loss_helper_3d.py:344-345)."""
+    return x.movedim(1, -1).reshape(-1, x.shape[1])
+
+
+def compute_contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask,
+                                 memobank, queue_prtlis, queue_size, rep_teacher,
+                                 momentum_prototype=None, i_iter=0, delta_n=1.0, func='asmc',
+                                 num_queries=256, num_negatives=512, temp=0.5, trace=None):
+    """Restatement of compute_contra_memobank_loss (loss_helper_3d.py:271-513).
+
+    `trace`, if a dict, receives the per-class masks' row lists and the sampled
+    index tensors (test instrumentation; not in the reference).
+    """
+    delta_p, low_rank, high_rank = 0.3, 3, 20                     # :316-318
+    D = rep.shape[1]
+    C = label_l.shape[1]
+    n_lab_rows = label_l.shape[0] * int(np.prod(label_l.shape[2:]))
+
+    if func == 'asmc':                                             # :327-338
+        draw = grid_as_monte_carlo_sample
+        q_arg, n_arg = num_queries, num_queries * num_negatives
+    elif func == 'smc':
+        draw = grid_monte_carlo_sample
+        q_arg, n_arg = num_queries, num_queries * num_negatives
+    else:
+        draw = torch.randint
+        q_arg, n_arg = (num_queries,), (num_queries * num_negatives,)
+
+    R = _rows(rep)                                                 # student rows (grad)
+    T = _rows(rep_teacher).detach()
+    lab = _rows(torch.cat((label_l, label_u), 0))
+    prob = _rows(torch.cat((prob_l, prob_u), 0))
+    low_valid = lab * low_mask.reshape(-1, 1)                      # :341
+    high_valid = lab * high_mask.reshape(-1, 1)                    # :342
+    rank = class_rank(prob)
+    labeled_row = torch.arange(lab.shape[0]) < n_lab_rows
+
+    anchor_rows, protos, new_keys, seg_num, valid_classes = [], [], [], [], []
+    for c in range(C):                                             # :364-415
+        lv = low_valid[:, c].bool()
+        anchor_m = (prob[:, c] > delta_p) & lv
+        hard_m = (prob[:, c] < delta_n) & high_valid[:, c].bool()
+        anchor_rows.append(torch.nonzero(anchor_m).flatten())
+        protos.append(T[lv].mean(0, keepdim=True))
+        cls_u = (rank[:, c] >= low_rank) & (rank[:, c] < high_rank)
+        cls_l = (rank[:, c] < low_rank) & (lab[:, c] == 0)
+        neg_m = hard_m & torch.where(labeled_row, cls_l, cls_u)
+        new_keys.append(dequeue_and_enqueue(T[neg_m], memobank[c], queue_prtlis[c], queue_size[c]))
+        if low_valid[:, c].sum() > 0:
+            seg_num.append(int(low_valid[:, c].sum().item()))
+            valid_classes.append(c)
+        if trace is not None:
+            trace.setdefault('anchor_rows', []).append(anchor_rows[-1].clone())
+            trace.setdefault('neg_rows', []).append(torch.nonzero(neg_m).flatten())
+
+    if len(seg_num) <= 1:                                          # :417-424
+        zero = torch.tensor(0.0) * rep.sum()
+        return (new_keys, zero) if momentum_prototype is None else (momentum_prototype, new_keys, zero)
+
+    loss = torch.tensor(0.0)
+    proto = torch.cat(protos)                                      # indexed by LOOP COUNTER below (:481)
+    prototype = torch.zeros((C, num_queries, 1, D))
+    for k in range(len(seg_num)):                                  # :435-509  (k is the loop counter)
+        bank = memobank[valid_classes[k]][0]
+        if anchor_rows[k].shape[0] == 0 or bank.shape[0] == 0:     # :436-462
+            loss = loss + 0 * rep.sum()
+            continue
+        a_idx = draw(anchor_rows[k].shape[0], q_arg)
+        A = R[anchor_rows[k][a_idx]]                               # [Q, D], grad flows
+        with torch.no_grad():
+            n_idx = draw(bank.shape[0], n_arg)
+            pos = proto[k].view(1, 1, D).repeat(num_queries, 1, 1)
+            if momentum_prototype is not None:                     # :488-497
+                if not (momentum_prototype == 0).all():
+                    decay = min(1 - 1 / i_iter, 0.999)
+                    pos = (1 - decay) * pos + decay * momentum_prototype[valid_classes[k]]
+                prototype[valid_classes[k]] = pos.clone()
+        if trace is not None:
+            trace.setdefault('anchor_idx', []).append(a_idx.clone())
+            trace.setdefault('neg_idx', []).append(n_idx.clone())
+        # cosine similarity in GEMM + gather form (:503-505): each vector is divided
+        # by max(||x||, 1e-8) (torch>=2 cosine_similarity), then dotted.
+        eps = 1e-8
+        An = A / A.norm(dim=1, keepdim=True).clamp_min(eps)
+        Bn = bank / bank.norm(dim=1, keepdim=True).clamp_min(eps)
+        Pn = pos[:, 0] / pos[:, 0].norm(dim=1, keepdim=True).clamp_min(eps)
+        S = An @ Bn.t()                                            # [Q, len(bank)]
+        neg_logit = S.gather(1, n_idx.view(num_queries, num_negatives))
+        pos_logit = (An * Pn).sum(1, keepdim=True)
+        logits = torch.cat((pos_logit, neg_logit), 1)
+        loss = loss + F.cross_entropy(logits / temp, torch.zeros(num_queries).long())   # :507-509
+    loss = loss / len(seg_num)
+    return (new_keys, loss) if momentum_prototype is None else (prototype, new_keys, loss)
+
+
+# --------------------------------------------------------------------------
+# N1-N3  2-D network pieces (functional, parameters by reference state_dict key)
+# --------------------------------------------------------------------------
+
+
+def bn_train(x, w, b, rm=None, rv=None, momentum=0.1, eps=1e-5):
+    """Train-mode BatchNorm over all dims but channel (nn.BatchNorm2d/3d default)."""
+    return F.batch_norm(x, rm, rv, w, b, True, momentum, eps)
+
+
+def conv_block_2d(x, sd, pre, slope=0.01):
+    """networks/unetWithArgs.py:31-47 with Dropout disabled (p forced to 0)."""
+    for k in ("0", "4"):
+        x = F.conv2d(x, sd[f"{pre}.conv_conv.{k}.weight"], sd[f"{pre}.conv_conv.{k}.bias"], padding=1)
+        bnk = str(int(k) + 1)
+        x = bn_train(x, sd[f"{pre}.conv_conv.{bnk}.weight"], sd[f"{pre}.conv_conv.{bnk}.bias"])
+        x = F.leaky_relu(x, slope)
+    return x
+
+
+def unet_forward(x, sd):
+    """networks/unetWithArgs.py:109-116 (Encoder), :142-158 (Decoder), :345-348 (UNet);
+    dropout off.  NB the Decoder constructs UpBlock WITHOUT passing `bilinear`
+    (:130-137), so UpBlock's default bilinear=True applies (:66): the up-path is
+    conv1x1 (bias) -> x2 bilinear upsample align_corners=True (:72-75,80-83), not
+    ConvTranspose2d, whatever params['bilinear'] (:317) says."""
+    feats = [conv_block_2d(x, sd, "encoder.in_conv")]
+    for i in range(1, 5):
+        feats.append(conv_block_2d(F.max_pool2d(feats[-1], 2), sd, f"encoder.down{i}.maxpool_conv.1"))
+    x = feats[4]
+    fmap = [x]
+    for i, skip in zip(range(1, 5), (feats[3], feats[2], feats[1], feats[0])):
+        up = F.conv2d(x, sd[f"decoder.up{i}.conv1x1.weight"], sd[f"decoder.up{i}.conv1x1.bias"])
+        up = F.interpolate(up, scale_factor=2, mode='bilinear', align_corners=True)
+        x = conv_block_2d(torch.cat([skip, up], 1), sd, f"decoder.up{i}.conv")
+        fmap.append(x)
+    out = F.conv2d(x, sd["decoder.out_conv.weight"], sd["decoder.out_conv.bias"], padding=1)
+    return out, feats[4], fmap
+
+
+def feature_extractor_forward(fmap, sd, mode='bilinear'):
+    """model_2D.py:35-55 / model_3D.py:37-63: residual 1x1 convs + align_corners upsample + cat."""
+    conv = F.conv2d if mode == 'bilinear' else F.conv3d
+    x = conv(fmap[0], sd["fea0.weight"]) + fmap[0]
+    for i in range(1, 5):
+        x = F.interpolate(x, size=fmap[i].shape[2:], mode=mode, align_corners=True)
+        x = torch.cat((x, fmap[i]), 1)
+        y = conv(x, sd[f"fea{i}.weight"])
+        x = y + x if i < 4 else y
+    return x
+
+
+# --------------------------------------------------------------------------
+# V1  3-D V-Net (networks/vnetWithArgs.py:145-252), batchnorm, dropout off
+# --------------------------------------------------------------------------
+
+
+def _vnet_stage(x, sd, pre, n):
+    for s in range(n):
+        x = F.conv3d(x, sd[f"{pre}.conv.{3 * s}.weight"], sd[f"{pre}.conv.{3 * s}.bias"], padding=1)
+        x = bn_train(x, sd[f"{pre}.conv.{3 * s + 1}.weight"], sd[f"{pre}.conv.{3 * s + 1}.bias"])
+        x = F.relu(x)
+    return x
+
+
+def _vnet_down(x, sd, pre):
+    x = F.conv3d(x, sd[f"{pre}.conv.0.weight"], sd[f"{pre}.conv.0.bias"], stride=2)
+    return F.relu(bn_train(x, sd[f"{pre}.conv.1.weight"], sd[f"{pre}.conv.1.bias"]))
+
+
+def _vnet_up(x, sd, pre):
+    x = F.conv_transpose3d(x, sd[f"{pre}.conv.0.weight"], sd[f"{pre}.conv.0.bias"], stride=2)
+    return F.relu(bn_train(x, sd[f"{pre}.conv.1.weight"], sd[f"{pre}.conv.1.bias"]))
+
+
+def vnet_forward(x, sd):
+    x1 = _vnet_stage(x, sd, "block_one", 1)
+    x2 = _vnet_stage(_vnet_down(x1, sd, "block_one_dw"), sd, "block_two", 2)
+    x3 = _vnet_stage(_vnet_down(x2, sd, "block_two_dw"), sd, "block_three", 3)
+    x4 = _vnet_stage(_vnet_down(x3, sd, "block_three_dw"), sd, "block_four", 3)
+    x5 = _vnet_stage(_vnet_down(x4, sd, "block_four_dw"), sd, "block_five", 3)
+    u5 = _vnet_up(x5, sd, "block_five_up") + x4
+    u6 = _vnet_up(_vnet_stage(u5, sd, "block_six", 3), sd, "block_six_up") + x3
+    u7 = _vnet_up(_vnet_stage(u6, sd, "block_seven", 3), sd, "block_seven_up") + x2
+    u8 = _vnet_up(_vnet_stage(u7, sd, "block_eight", 2), sd, "block_eight_up") + x1
+    x9 = _vnet_stage(u8, sd, "block_nine", 1)
+    out = F.conv3d(x9, sd["out_conv.weight"], sd["out_conv.bias"])
+    fmap = [u5, u6, u7, u8, x9]
+    return out, fmap[0], fmap
+
+
+# --------------------------------------------------------------------------
+# T1 / O1 / N5  trainer glue (train_arco_2d.py:284-286,342-393,425-435,492-498)
+# --------------------------------------------------------------------------
+
+
+def label_onehot(inputs, num_segments):
+    """train_arco_2d.py:492-498 (3-D: train_arco_3d.py:463-469): negatives clamp to class 0."""
+    idx = inputs.clamp_min(0).to(torch.int64).unsqueeze(1)
+    out = torch.zeros([inputs.shape[0], num_segments, *inputs.shape[1:]])
+    return out.scatter_(1, idx, 1.0)
+
+
+def compute_unsupervised_loss(predict, target, logits, strong_threshold):
+    """train_arco_2d.py:482-489."""
+    b = predict.shape[0]
+    valid = (target >= 0).float().view(b, -1).sum(-1)
+    weight = logits.view(b, -1).ge(strong_threshold).sum(-1) / valid
+    ce = F.cross_entropy(predict, target, reduction='none', ignore_index=-1)
+    w = weight.view(b, *([1] * (ce.dim() - 1))) * ce
+    return torch.mean(torch.masked_select(w, ce > 0))
+
+
+def entropy_masks(pred_u, label_l_raw, label_u_raw, alpha_t):
+    """Entropy-percentile masks, train_arco_2d.py:352-393 (F.interpolate to the same
+    size is the identity and is omitted).  Returns (low_mask_all, high_mask_all, entropy)."""
+    prob = torch.softmax(pred_u, dim=1)
+    entropy = -torch.sum(prob * torch.log(prob + 1e-10), dim=1)
+    valid = label_u_raw >= 0
+    ent_valid = entropy[valid].cpu().numpy().flatten()
+    low_t = np.percentile(ent_valid, alpha_t)
+    high_t = np.percentile(ent_valid, 100 - alpha_t)
+    low_u = entropy.le(low_t).float() * valid
+    high_u = entropy.ge(high_t).float() * valid
+    lab_ok = (label_l_raw.unsqueeze(1) >= 0).float()
+    return (torch.cat((lab_ok, low_u.unsqueeze(1))), torch.cat((lab_ok, high_u.unsqueeze(1))), entropy)
+
+
+def ema_update(teacher_params, student_params, m=0.99):
+    """model_2D.py:176-182: k = m*k + (1-m)*q over parameters() (buffers untouched)."""
+    return [k * m + q * (1.0 - m) for k, q in zip(teacher_params, student_params)]
+
+
+def poly_lr(base_lr, it, max_it):
+    """train_arco_2d.py:433."""
+    return base_lr * (1.0 - it / max_it) ** 0.9
+
+
+def sgd_nesterov_step(p, g, buf, lr, momentum=0.9, wd=1e-4):
+    """torch.optim.SGD(nesterov=True, weight_decay) single-tensor step
+    (train_arco_2d.py:248). buf None on first step."""
+    g = g + wd * p
+    buf = g.clone() if buf is None else momentum * buf + g
+    return p - lr * (g + momentum * buf), buf

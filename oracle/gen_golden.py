@@ -1,0 +1,324 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) on CPU.
+
+TEST INFRASTRUCTURE — runs only in the build container (the reference never
+travels).  Usage:  python oracle/gen_golden.py
+Inputs come from tests/fixture_inputs.py (numpy RandomState), so the files hold
+only the reference's outputs.  Trainer-glue functions are pulled out of
+train_arco_2d.py with ast/exec at generation time (the trainer itself cannot be
+imported: argparse at import, tensorboardX/h5py/torchvision missing).
+"""
+import ast
+import hashlib
+import os
+import random
+import sys
+import textwrap
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ref_shim            # noqa: E402
+import fixture_inputs as fx  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(4)
+
+
+def seed_all(s):
+    random.seed(s); np.random.seed(s); torch.manual_seed(s)
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+
+
+def rng_probe():
+    """One draw after a call pins how much of the generator the call consumed."""
+    return int(torch.randint(1 << 30, (1,)))
+
+
+# ---------------------------------------------------------------- G1 samplers
+def gen_samplers(mods):
+    L = mods["loss_helper_3d"]
+    out = {}
+    for name, fn in (("smc", L.grid_monte_carlo_sample), ("asmc", L.grid_as_monte_carlo_sample),
+                     ("mc1d", L.monte_carlo_sample), ("asmc1d", L.as_monte_carlo_sample)):
+        for high in fx.SAMPLER_HIGHS:
+            for shape in fx.SAMPLER_SHAPES:
+                for seed in fx.SAMPLER_SEEDS:
+                    seed_all(seed)
+                    idx = fn(high, shape)
+                    key = f"{name}_h{high}_s{shape}_r{seed}"
+                    out[key] = idx.numpy().astype(np.int32)
+                    out[key + "_probe"] = np.array([rng_probe(), random.randint(0, 1 << 30)])
+    # production-size negative draws: keep hashes + head only
+    for name, fn in (("smc", L.grid_monte_carlo_sample), ("asmc", L.grid_as_monte_carlo_sample)):
+        for high in (1, 4096, 29999, 50000):
+            seed_all(3)
+            idx = fn(high, 131072)
+            key = f"{name}_h{high}_s131072_r3"
+            out[key + "_sha"] = np.frombuffer(bytes.fromhex(sha(idx)), dtype=np.uint8)
+            out[key + "_head"] = idx[:64].numpy().astype(np.int32)
+            out[key + "_probe"] = np.array([rng_probe(), random.randint(0, 1 << 30)])
+    np.savez_compressed(os.path.join(OUT, "g1_samplers.npz"), **out)
+    print("g1_samplers", len(out))
+
+
+# ---------------------------------------------------------------- G2 loss
+def gen_loss(mods):
+    out = {}
+    for case, (ikw, lkw, qsize, binit) in fx.LOSS_CASES.items():
+        nd3 = len(ikw["spatial"]) == 3
+        L = mods["loss_helper"] if nd3 else mods["loss_helper_3d"]
+        trace = []
+        orig = (L.grid_monte_carlo_sample, L.grid_as_monte_carlo_sample)
+
+        def rec(f):
+            def w(*a, **k):
+                r = f(*a, **k); trace.append(r.clone()); return r
+            return w
+        L.grid_monte_carlo_sample, L.grid_as_monte_carlo_sample = rec(orig[0]), rec(orig[1])
+        bank, ptr, qs = fx.fresh_bank(ikw["n_cls"], ikw["feat"], qsize, binit)
+        mom = None
+        if case == "proto_momentum":
+            mom = torch.zeros(ikw["n_cls"], lkw["num_queries"], 1, ikw["feat"])
+        seed_all(1337)
+        for step in range(fx.LOSS_STEPS):
+            inp = fx.loss_inputs(100 * step + 11, **ikw)
+            rep = inp["rep"].clone().requires_grad_(True)
+            del trace[:]
+            res = L.compute_contra_memobank_loss(
+                rep, inp["label_l"], inp["label_u"], inp["prob_l"], inp["prob_u"],
+                inp["low_mask"], inp["high_mask"], bank, ptr, qs, inp["rep_teacher"],
+                momentum_prototype=mom, i_iter=step + 1, **lkw)
+            if mom is not None:
+                mom, new_keys, loss = res
+                out[f"{case}_s{step}_prototype"] = mom.detach().numpy().copy()
+            else:
+                new_keys, loss = res
+            loss.backward()
+            p = f"{case}_s{step}_"
+            out[p + "loss"] = np.array(loss.item(), dtype=np.float64)
+            out[p + "grad"] = rep.grad.numpy().copy()
+            out[p + "new_keys"] = np.array(new_keys, dtype=np.int64)
+            out[p + "ptr"] = np.array([int(q) for q in ptr], dtype=np.int64)
+            out[p + "bank_len"] = np.array([b[0].shape[0] for b in bank], dtype=np.int64)
+            for c, b in enumerate(bank):
+                out[p + f"bank{c}"] = b[0].numpy().copy()
+            for k, t in enumerate(trace):
+                out[p + f"draw{k}"] = t.numpy().astype(np.int32)
+            out[p + "n_draws"] = np.array(len(trace))
+            out[p + "probe"] = np.array([rng_probe()])
+        L.grid_monte_carlo_sample, L.grid_as_monte_carlo_sample = orig
+    np.savez_compressed(os.path.join(OUT, "g2_loss.npz"), **out)
+    print("g2_loss", len(out))
+
+
+# ---------------------------------------------------------------- G3 nets
+def probe_like(t, seed):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.standard_normal(tuple(t.shape)).astype(np.float32))
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.Dropout, torch.nn.Dropout3d)):
+            mod.p = 0.0
+
+
+def gen_nets(mods):
+    out = {}
+    U = mods["networks.unetWithArgs"]
+    # --- whole U-Net at 32x32, b=2, one train-mode step (dropout off)
+    net = U.UNet(1, 4)
+    sd = fx.unet_state(21)
+    net.load_state_dict(sd, strict=True)
+    zero_dropout(net); net.train()
+    x = fx.image_batch(5, 2, 1, (32, 32)).requires_grad_(True)
+    logits, latent, fmap = net(x)
+    loss = (logits * probe_like(logits, 1)).sum()
+    for i, f in enumerate(fmap):
+        loss = loss + (f * probe_like(f, 10 + i)).sum()
+    loss.backward()
+    out["unet_logits"] = logits.detach().numpy()
+    out["unet_latent"] = latent.detach().numpy()
+    for i, f in enumerate(fmap):
+        out[f"unet_fmap{i}"] = f.detach().numpy()
+    out["unet_dx"] = x.grad.numpy()
+    names, gsum, gabs = [], [], []
+    for n, p in net.named_parameters():
+        names.append(n); gsum.append(p.grad.double().sum().item()); gabs.append(p.grad.double().abs().sum().item())
+    out["unet_grad_names"] = np.array(names)
+    out["unet_grad_sum"] = np.array(gsum); out["unet_grad_abs"] = np.array(gabs)
+    for n in ("encoder.in_conv.conv_conv.0.weight", "encoder.in_conv.conv_conv.1.weight",
+              "encoder.in_conv.conv_conv.1.bias", "encoder.down1.maxpool_conv.1.conv_conv.4.weight",
+              "decoder.up4.conv1x1.weight", "decoder.up4.conv1x1.bias", "decoder.up4.conv.conv_conv.0.weight",
+              "decoder.out_conv.weight", "decoder.out_conv.bias", "decoder.up1.conv.conv_conv.5.weight"):
+        out["unet_grad::" + n] = dict(net.named_parameters())[n].grad.numpy()
+    st = net.state_dict()
+    for n in ("encoder.in_conv.conv_conv.1.running_mean", "encoder.in_conv.conv_conv.1.running_var",
+              "encoder.down4.maxpool_conv.1.conv_conv.5.running_mean",
+              "encoder.down4.maxpool_conv.1.conv_conv.5.running_var",
+              "decoder.up4.conv.conv_conv.5.running_var", "encoder.in_conv.conv_conv.1.num_batches_tracked"):
+        out["unet_buf::" + n] = st[n].numpy()
+    out["unet_n_state_keys"] = np.array(len(st))
+
+    # --- ConvBlock / UpBlock alone (small channels)
+    cb = U.ConvBlock(3, 8, 0.0); cb.train()
+    rs = np.random.RandomState(3)
+    for n, p in cb.named_parameters():
+        p.data = torch.from_numpy((0.3 * rs.standard_normal(tuple(p.shape))).astype(np.float32))
+    xb = fx.image_batch(6, 2, 3, (12, 10)).requires_grad_(True)
+    yb = cb(xb); (yb * probe_like(yb, 2)).sum().backward()
+    out["cb_y"] = yb.detach().numpy(); out["cb_dx"] = xb.grad.numpy()
+    for n, p in cb.named_parameters():
+        out["cb_p::" + n] = p.detach().numpy(); out["cb_g::" + n] = p.grad.numpy()
+    for n, b in cb.named_buffers():
+        out["cb_b::" + n] = b.numpy()
+
+    # --- FeatureExtractor (2-D), small dims, and the production dims (checksums)
+    M2 = mods["model_2D"]
+    for tag, dims, od, sp in (("fe_small", (32, 16, 8, 8, 8), 24, 32), ("fe_full", (256, 128, 64, 32, 16), 496, 32)):
+        fe = M2.FeatureExtractor(fea_dim=list(dims), output_dim=od)
+        fsd = fx.fe_state(31, dims, od, nd=2)
+        fe.load_state_dict(fsd, strict=True)
+        fl = [fx.image_batch(40 + i, 2, c, (sp >> (4 - i), sp >> (4 - i))).requires_grad_(True) for i, c in enumerate(dims)]
+        y = fe(fl)
+        (y * probe_like(y, 3)).sum().backward()
+        if tag == "fe_small":
+            out[tag + "_y"] = y.detach().numpy()
+            for i, f in enumerate(fl):
+                out[tag + f"_dx{i}"] = f.grad.numpy()
+            for n, p in fe.named_parameters():
+                out[tag + "_g::" + n] = p.grad.numpy()
+        else:
+            out[tag + "_y_sub"] = y.detach()[:, ::31, ::5, ::7].numpy()
+            out[tag + "_y_sum"] = np.array([y.double().sum().item(), y.double().abs().sum().item()])
+            for i, f in enumerate(fl):
+                out[tag + f"_dx{i}_sum"] = np.array([f.grad.double().sum().item(), f.grad.double().abs().sum().item()])
+            for n, p in fe.named_parameters():
+                out[tag + "_g_sum::" + n] = np.array([p.grad.double().sum().item(), p.grad.double().abs().sum().item()])
+                out[tag + "_g_sub::" + n] = p.grad[::13, ::17].numpy()
+
+    # --- V-Net at 16^3 and FeatureExtractor_3d
+    V = mods["networks.vnetWithArgs"]
+    vnet = V.VNet(n_channels=1, n_classes=2, normalization='batchnorm', has_dropout=True)
+    vsd = fx.vnet_state(51)
+    vnet.load_state_dict(vsd, strict=True)
+    vnet.train()
+    xv = fx.image_batch(8, 2, 1, (16, 16, 16)).requires_grad_(True)
+    vo, v0, vf = vnet(xv, turnoff_drop=True)
+    lossv = (vo * probe_like(vo, 4)).sum()
+    for i, f in enumerate(vf):
+        lossv = lossv + (f * probe_like(f, 20 + i)).sum()
+    lossv.backward()
+    out["vnet_out"] = vo.detach().numpy()
+    for i, f in enumerate(vf):
+        out[f"vnet_fmap{i}"] = f.detach().numpy()
+    out["vnet_dx"] = xv.grad.numpy()
+    names, gsum, gabs = [], [], []
+    for n, p in vnet.named_parameters():
+        names.append(n); gsum.append(p.grad.double().sum().item()); gabs.append(p.grad.double().abs().sum().item())
+    out["vnet_grad_names"] = np.array(names); out["vnet_grad_sum"] = np.array(gsum); out["vnet_grad_abs"] = np.array(gabs)
+    vst = vnet.state_dict()
+    for n in ("block_one.conv.1.running_mean", "block_one.conv.1.running_var", "block_five_up.conv.1.running_var"):
+        out["vnet_buf::" + n] = vst[n].numpy()
+    M3 = mods["model_3D"]
+    fe3 = M3.FeatureExtractor_3d(fea_dim=[128, 64, 32, 16, 16], output_dim=16)
+    f3sd = fx.fe_state(61, (128, 64, 32, 16, 16), 16, nd=3)
+    fe3.load_state_dict(f3sd, strict=True)
+    fl3 = [f.detach().clone().requires_grad_(True) for f in vf]
+    y3 = fe3(fl3)
+    (y3 * probe_like(y3, 5)).sum().backward()
+    out["fe3d_y"] = y3.detach().numpy()
+    for i, f in enumerate(fl3):
+        out[f"fe3d_dx{i}_sum"] = np.array([f.grad.double().sum().item(), f.grad.double().abs().sum().item()])
+    for n, p in fe3.named_parameters():
+        out["fe3d_g_sum::" + n] = np.array([p.grad.double().sum().item(), p.grad.double().abs().sum().item()])
+    np.savez_compressed(os.path.join(OUT, "g3_nets.npz"), **out)
+    print("g3_nets", len(out))
+
+
+# ---------------------------------------------------------------- G4 trainer glue
+def _pull_functions(path, names):
+    """exec selected top-level functions of a reference script without importing it."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch, "np": np, "F": torch.nn.functional, "nn": torch.nn}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+    return ns, src.splitlines()
+
+
+def gen_glue():
+    out = {}
+    path = os.path.join(ref_shim.REF, "train_arco_2d.py")
+    ns, lines = _pull_functions(path, {"compute_unsupervised_loss", "label_onehot", "get_revisiting_loss",
+                                       "_dequeue_and_enqueue"})
+    rs = np.random.RandomState(77)
+    b, C, H, W = 2, 4, 24, 20
+    pred_l = torch.from_numpy(rs.standard_normal((b, C, H, W)).astype(np.float32) * 2)
+    pred_u = torch.from_numpy(rs.standard_normal((b, C, H, W)).astype(np.float32) * 2)
+    lab_l = torch.from_numpy(fx.blob_labels(rs, b, (H, W), C))
+    lab_u = torch.from_numpy(fx.blob_labels(rs, b, (H, W), C))
+    lab_u[0, :3, :4] = -1                                      # invalid (ignore) pixels
+    logits_u = torch.from_numpy(rs.uniform(0.3, 1.0, size=(b, H, W)).astype(np.float32))
+    out["onehot_u"] = ns["label_onehot"](lab_u, C).numpy()
+    out["unsup_loss"] = np.array(ns["compute_unsupervised_loss"](pred_u, lab_u, logits_u, 0.97).item())
+    # mask block train_arco_2d.py:342-393 executed from the reference text itself
+    block = textwrap.dedent("\n".join(lines[341:393]))
+    for epoch_num, max_epoch in ((0, 10), (3, 10)):
+        env = dict(ns)
+        env.update(dict(args=types.SimpleNamespace(weak_threshold=0.7, num_classes=C), epoch_num=epoch_num,
+                        max_epoch=max_epoch, train_u_aug_logits=logits_u, train_l_label=lab_l,
+                        train_u_aug_label=lab_u, pred_all=torch.cat((pred_l, pred_u)), pred_l=pred_l, pred_u=pred_u,
+                        pred_l_teacher=pred_l, pred_u_teacher=pred_u))
+        exec(block, env)
+        t = f"mask_e{epoch_num}_"
+        out[t + "low"] = env["low_mask_all"].numpy(); out[t + "high"] = env["high_mask_all"].numpy()
+        out[t + "entropy"] = env["entropy"].numpy()
+        out[t + "thr"] = np.array([env["low_thresh"], env["high_thresh"]], dtype=np.float64)
+        out[t + "label_l"] = env["label_l"].numpy(); out[t + "label_u"] = env["label_u"].numpy()
+        out[t + "alpha"] = np.array(env["alpha_t"])
+    # revisiting loss + pool enqueue (train_arco_2d.py:108-136)
+    K, feat = 6, 3 * 8 * 8
+    pool = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((K, feat)).astype(np.float32)), dim=1)
+    ru = torch.from_numpy(rs.standard_normal((2, 3, 8, 8)).astype(np.float32))
+    rt = torch.from_numpy(rs.standard_normal((2, 3, 8, 8)).astype(np.float32))
+    out["revisit_loss"] = np.array(ns["get_revisiting_loss"](pool, ru, rt, topk=3).item())
+    ns["args"] = types.SimpleNamespace(K=K)
+    ptr = torch.zeros(1, dtype=torch.long); pool2 = pool.clone()
+    keys = torch.nn.functional.normalize(rt.view(2, -1), dim=-1)
+    ns["_dequeue_and_enqueue"](keys, pool2, ptr)
+    out["pool_after"] = pool2.numpy(); out["pool_ptr"] = np.array(int(ptr))
+    # EMA (model_2D.py:176-182) and SGD-nesterov + poly LR through torch itself
+    q = torch.from_numpy(rs.standard_normal((5, 7)).astype(np.float32)); k = torch.from_numpy(rs.standard_normal((5, 7)).astype(np.float32))
+    out["ema_q"] = q.numpy(); out["ema_k"] = k.numpy(); out["ema_out"] = (k * 0.99 + q * (1. - 0.99)).numpy()
+    p = torch.nn.Parameter(q.clone())
+    opt = torch.optim.SGD([p], lr=0.01, weight_decay=0.0001, momentum=0.9, nesterov=True)
+    gs = []
+    for it in range(3):
+        g = torch.from_numpy(rs.standard_normal((5, 7)).astype(np.float32)); gs.append(g.numpy())
+        opt.zero_grad(); p.grad = g.clone(); opt.step()
+        lr_ = 0.01 * (1.0 - it / 30000) ** 0.9
+        for grp in opt.param_groups:
+            grp['lr'] = lr_
+        out[f"sgd_p{it}"] = p.detach().numpy().copy()
+    out["sgd_g"] = np.stack(gs)
+    np.savez_compressed(os.path.join(OUT, "g4_glue.npz"), **out)
+    print("g4_glue", len(out))
+
+
+if __name__ == "__main__":
+    mods = ref_shim.load()
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    if "g1" in which: gen_samplers(mods)
+    if "g2" in which: gen_loss(mods)
+    if "g3" in which: gen_nets(mods)
+    if "g4" in which: gen_glue()

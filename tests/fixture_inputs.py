@@ -1,0 +1,200 @@
+"""Deterministic synthetic inputs shared by oracle/gen_golden.py and the tests.
+
+Everything is drawn from numpy RandomState (bit-stable across numpy versions), so
+the golden files only need to hold the reference's OUTPUTS.
+"""
+import numpy as np
+import torch
+
+
+def blob_labels(rs, b, spatial, n_cls, absent=()):
+    """Piecewise-constant label maps: background 0 plus random boxes of the other
+    classes (ACDC-like imbalance).  Classes in `absent` never appear."""
+    lab = np.zeros((b, *spatial), dtype=np.int64)
+    present = [c for c in range(1, n_cls) if c not in absent]
+    for i in range(b):
+        for c in present:
+            lo = [rs.randint(0, max(1, s - 2)) for s in spatial]
+            sz = [rs.randint(max(1, s // 6), max(2, s // 2)) for s in spatial]
+            sl = tuple(slice(l, min(s, l + z)) for l, z, s in zip(lo, sz, spatial))
+            lab[(i, *sl)] = c
+    if 0 in absent:
+        # push background away: fill with the first present class
+        lab[lab == 0] = present[0]
+    return lab
+
+
+def onehot(lab, n_cls):
+    t = torch.from_numpy(lab)
+    out = torch.zeros(lab.shape[0], n_cls, *lab.shape[1:], dtype=torch.int64)
+    return out.scatter_(1, t.clamp_min(0).unsqueeze(1), 1)
+
+
+def loss_inputs(seed, b=2, n_cls=4, feat=16, spatial=(16, 16), absent=(), low_p=0.35, high_p=0.5,
+                single_class=False, tie_probs=False):
+    """Inputs of compute_contra_memobank_loss for one step (b labeled + b unlabeled)."""
+    rs = np.random.RandomState(seed)
+    B = 2 * b
+    rep = rs.standard_normal((B, feat, *spatial)).astype(np.float32)
+    rep_t = rs.standard_normal((B, feat, *spatial)).astype(np.float32)
+    if single_class:
+        lab_l = np.zeros((b, *spatial), dtype=np.int64)
+        lab_u = np.zeros((b, *spatial), dtype=np.int64)
+    else:
+        lab_l = blob_labels(rs, b, spatial, n_cls, absent)
+        lab_u = blob_labels(rs, b, spatial, n_cls, absent)
+    lab = np.concatenate([lab_l, lab_u])
+    logit = rs.standard_normal((B, n_cls, *spatial)).astype(np.float32)
+    logit += 0.8 * np.moveaxis(np.eye(n_cls, dtype=np.float32)[lab], -1, 1)
+    if tie_probs:
+        logit = np.round(logit)          # many exact ties between classes
+    prob = torch.softmax(torch.from_numpy(logit), 1)
+    low_u = (rs.uniform(size=(b, 1, *spatial)) < low_p).astype(np.float32)
+    high_u = (rs.uniform(size=(b, 1, *spatial)) < high_p).astype(np.float32)
+    ones = np.ones((b, 1, *spatial), dtype=np.float32)
+    return dict(
+        rep=torch.from_numpy(rep), rep_teacher=torch.from_numpy(rep_t),
+        label_l=onehot(lab_l, n_cls), label_u=onehot(lab_u, n_cls),
+        prob_l=prob[:b].contiguous(), prob_u=prob[b:].contiguous(),
+        low_mask=torch.from_numpy(np.concatenate([ones, low_u])),
+        high_mask=torch.from_numpy(np.concatenate([ones, high_u])),
+    )
+
+
+def fresh_bank(n_cls, feat, queue_size, init='zeros', seed=0):
+    """train_arco_2d.py:147-154 (zeros(1,D)) / train_arco_3d.py:144-151 (randn(1,D))."""
+    rs = np.random.RandomState(1000 + seed)
+    bank, ptr, qs = [], [], []
+    for c in range(n_cls):
+        row = np.zeros((1, feat), np.float32) if init == 'zeros' else rs.standard_normal((1, feat)).astype(np.float32)
+        bank.append([torch.from_numpy(row)])
+        ptr.append(torch.zeros(1, dtype=torch.long))
+        qs.append(queue_size[c] if isinstance(queue_size, (list, tuple)) else queue_size)
+    return bank, ptr, qs
+
+
+# loss cases: name -> (kwargs for loss_inputs, loss kwargs, queue_size, bank init)
+LOSS_CASES = {
+    "d16_smc": (dict(b=2, n_cls=4, feat=16, spatial=(16, 16)),
+                dict(func='smc', num_queries=32, num_negatives=16, delta_n=0.97), 96, 'zeros'),
+    "d16_asmc": (dict(b=2, n_cls=4, feat=16, spatial=(16, 16)),
+                 dict(func='asmc', num_queries=32, num_negatives=16, delta_n=0.97), 96, 'zeros'),
+    "d16_randint": (dict(b=2, n_cls=4, feat=16, spatial=(16, 16)),
+                    dict(func='rand', num_queries=32, num_negatives=16, delta_n=0.97), 96, 'zeros'),
+    "d64_smc_default_q": (dict(b=1, n_cls=4, feat=64, spatial=(24, 24)),
+                          dict(func='smc', delta_n=0.97), 512, 'zeros'),
+    "absent_class1": (dict(b=2, n_cls=4, feat=16, spatial=(16, 16), absent=(1,)),
+                      dict(func='smc', num_queries=32, num_negatives=16, delta_n=0.97), 96, 'zeros'),
+    "absent_class0": (dict(b=2, n_cls=4, feat=16, spatial=(16, 16), absent=(0,)),
+                      dict(func='asmc', num_queries=32, num_negatives=16, delta_n=0.97), 96, 'zeros'),
+    "single_class": (dict(b=2, n_cls=4, feat=16, spatial=(8, 8), single_class=True),
+                     dict(func='smc', num_queries=32, num_negatives=16, delta_n=0.97), 96, 'zeros'),
+    "binary_3d": (dict(b=1, n_cls=2, feat=16, spatial=(8, 8, 6)),
+                  dict(func='asmc', num_queries=32, num_negatives=16, delta_n=0.97), 64, 'randn'),
+    "c8_ties": (dict(b=1, n_cls=8, feat=16, spatial=(16, 16), tie_probs=True),
+                 dict(func='smc', num_queries=32, num_negatives=16, delta_n=0.97), 128, 'zeros'),
+    "tiny_queue_overflow": (dict(b=2, n_cls=4, feat=16, spatial=(16, 16)),
+                            dict(func='smc', num_queries=32, num_negatives=16, delta_n=1.0), 20, 'zeros'),
+    "proto_momentum": (dict(b=2, n_cls=4, feat=16, spatial=(16, 16)),
+                       dict(func='smc', num_queries=32, num_negatives=16, delta_n=0.97), 96, 'zeros'),
+}
+LOSS_STEPS = 3
+
+SAMPLER_HIGHS = [1, 3, 11, 12, 13, 15, 16, 17, 100, 257, 4096, 5233, 8179, 30000, 300000]
+SAMPLER_SHAPES = [256, 8192]
+SAMPLER_SEEDS = [0, 7]
+
+
+def unet_state(seed, in_chns=1, n_cls=4, ft=(16, 32, 64, 128, 256)):
+    """Random U-Net parameters keyed like the reference state_dict
+    (networks/unetWithArgs.py; 136 keys incl. BN buffers)."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+
+    def conv(name, co, ci, k):
+        fan = ci * k * k
+        sd[name + ".weight"] = torch.from_numpy((rs.standard_normal((co, ci, k, k)) / np.sqrt(fan)).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy((0.1 * rs.standard_normal(co)).astype(np.float32))
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.from_numpy((1 + 0.1 * rs.standard_normal(c)).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy((0.1 * rs.standard_normal(c)).astype(np.float32))
+        sd[name + ".running_mean"] = torch.zeros(c)
+        sd[name + ".running_var"] = torch.ones(c)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    def block(pre, ci, co):
+        conv(pre + ".conv_conv.0", co, ci, 3)
+        bn(pre + ".conv_conv.1", co)
+        conv(pre + ".conv_conv.4", co, co, 3)
+        bn(pre + ".conv_conv.5", co)
+
+    block("encoder.in_conv", in_chns, ft[0])
+    for i in range(1, 5):
+        block(f"encoder.down{i}.maxpool_conv.1", ft[i - 1], ft[i])
+    for i, (c1, c2) in zip(range(1, 5), ((ft[4], ft[3]), (ft[3], ft[2]), (ft[2], ft[1]), (ft[1], ft[0]))):
+        # Decoder builds UpBlock with its default bilinear=True (unetWithArgs.py:66,130-137):
+        # 1x1 conv (with bias) then x2 bilinear upsample, align_corners=True (:72-75)
+        conv(f"decoder.up{i}.conv1x1", c2, c1, 1)
+        block(f"decoder.up{i}.conv", 2 * c2, c2)
+    conv("decoder.out_conv", n_cls, ft[0], 3)
+    return sd
+
+
+def fe_state(seed, fea_dim=(256, 128, 64, 32, 16), out_dim=496, nd=2):
+    rs = np.random.RandomState(seed)
+    sd, cnt = {}, 0
+    for i, f in enumerate(fea_dim):
+        cnt += f
+        co = out_dim if i == 4 else cnt
+        w = (rs.standard_normal((co, cnt) + (1,) * nd) / np.sqrt(cnt)).astype(np.float32)
+        sd[f"fea{i}.weight"] = torch.from_numpy(w)
+    return sd
+
+
+def vnet_state(seed, in_chns=1, n_cls=2, nf=16):
+    """Random V-Net parameters keyed like networks/vnetWithArgs.py (batchnorm variant)."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+
+    def conv(name, co, ci, k, transpose=False):
+        shape = (ci, co, k, k, k) if transpose else (co, ci, k, k, k)
+        sd[name + ".weight"] = torch.from_numpy((rs.standard_normal(shape) / np.sqrt(ci * k ** 3)).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy((0.1 * rs.standard_normal(co)).astype(np.float32))
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.from_numpy((1 + 0.1 * rs.standard_normal(c)).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy((0.1 * rs.standard_normal(c)).astype(np.float32))
+        sd[name + ".running_mean"] = torch.zeros(c)
+        sd[name + ".running_var"] = torch.ones(c)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    def stage(pre, n, ci, co):
+        for s in range(n):
+            conv(f"{pre}.conv.{3 * s}", co, ci if s == 0 else co, 3)
+            bn(f"{pre}.conv.{3 * s + 1}", co)
+
+    def down(pre, ci, co):
+        conv(f"{pre}.conv.0", co, ci, 2)
+        bn(f"{pre}.conv.1", co)
+
+    def up(pre, ci, co):
+        conv(f"{pre}.conv.0", co, ci, 2, transpose=True)
+        bn(f"{pre}.conv.1", co)
+
+    stage("block_one", 1, in_chns, nf); down("block_one_dw", nf, 2 * nf)
+    stage("block_two", 2, 2 * nf, 2 * nf); down("block_two_dw", 2 * nf, 4 * nf)
+    stage("block_three", 3, 4 * nf, 4 * nf); down("block_three_dw", 4 * nf, 8 * nf)
+    stage("block_four", 3, 8 * nf, 8 * nf); down("block_four_dw", 8 * nf, 16 * nf)
+    stage("block_five", 3, 16 * nf, 16 * nf); up("block_five_up", 16 * nf, 8 * nf)
+    stage("block_six", 3, 8 * nf, 8 * nf); up("block_six_up", 8 * nf, 4 * nf)
+    stage("block_seven", 3, 4 * nf, 4 * nf); up("block_seven_up", 4 * nf, 2 * nf)
+    stage("block_eight", 2, 2 * nf, 2 * nf); up("block_eight_up", 2 * nf, nf)
+    stage("block_nine", 1, nf, nf)
+    conv("out_conv", n_cls, nf, 1)
+    return sd
+
+
+def image_batch(seed, b, c, spatial):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.uniform(size=(b, c, *spatial)).astype(np.float32))

@@ -1,0 +1,179 @@
+"""Pin the CPU oracle (oracle/arco_oracle.py) to golden vectors produced by the real
+reference (oracle/gen_golden.py).  CPU-only; no reference import at test time."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import arco_oracle as orc
+import fixture_inputs as fx
+
+
+def seed_all(s):
+    random.seed(s); np.random.seed(s); torch.manual_seed(s)
+
+
+def probe():
+    return [int(torch.randint(1 << 30, (1,))), random.randint(0, 1 << 30)]
+
+
+SAMPLERS = {"smc": orc.grid_monte_carlo_sample, "asmc": orc.grid_as_monte_carlo_sample,
+            "mc1d": orc.monte_carlo_sample, "asmc1d": orc.as_monte_carlo_sample}
+
+
+@pytest.mark.parametrize("name", list(SAMPLERS))
+def test_samplers_bit_exact(golden, name):
+    g = golden["g1_samplers"]
+    fn = SAMPLERS[name]
+    for high in fx.SAMPLER_HIGHS:
+        for shape in fx.SAMPLER_SHAPES:
+            for seed in fx.SAMPLER_SEEDS:
+                key = f"{name}_h{high}_s{shape}_r{seed}"
+                seed_all(seed)
+                idx = fn(high, shape)
+                assert idx.dtype == torch.int64 and idx.shape == (shape,)
+                np.testing.assert_array_equal(idx.numpy(), g[key].astype(np.int64), err_msg=key)
+                assert probe() == g[key + "_probe"].tolist(), key      # same RNG consumption
+
+
+@pytest.mark.parametrize("name", ["smc", "asmc"])
+def test_samplers_production_size(golden, name):
+    g = golden["g1_samplers"]
+    for high in (1, 4096, 29999, 50000):
+        key = f"{name}_h{high}_s131072_r3"
+        seed_all(3)
+        idx = SAMPLERS[name](high, 131072)
+        sha = hashlib.sha256(np.ascontiguousarray(idx.numpy()).tobytes()).digest()
+        assert sha == g[key + "_sha"].tobytes(), key
+        assert probe() == g[key + "_probe"].tolist()
+
+
+@pytest.mark.parametrize("case", list(fx.LOSS_CASES))
+def test_loss_chain(golden, case):
+    g = golden["g2_loss"]
+    ikw, lkw, qsize, binit = fx.LOSS_CASES[case]
+    bank, ptr, qs = fx.fresh_bank(ikw["n_cls"], ikw["feat"], qsize, binit)
+    mom = torch.zeros(ikw["n_cls"], lkw["num_queries"], 1, ikw["feat"]) if case == "proto_momentum" else None
+    seed_all(1337)
+    for step in range(fx.LOSS_STEPS):
+        inp = fx.loss_inputs(100 * step + 11, **ikw)
+        rep = inp["rep"].clone().requires_grad_(True)
+        trace = {}
+        res = orc.compute_contra_memobank_loss(
+            rep, inp["label_l"], inp["label_u"], inp["prob_l"], inp["prob_u"], inp["low_mask"],
+            inp["high_mask"], bank, ptr, qs, inp["rep_teacher"], momentum_prototype=mom,
+            i_iter=step + 1, trace=trace, **lkw)
+        p = f"{case}_s{step}_"
+        if mom is not None:
+            mom, new_keys, loss = res
+            np.testing.assert_allclose(mom.numpy(), g[p + "prototype"], rtol=1e-5, atol=1e-6)
+        else:
+            new_keys, loss = res
+        loss.backward()
+        assert new_keys == g[p + "new_keys"].tolist()
+        assert [int(q) for q in ptr] == g[p + "ptr"].tolist()
+        assert [b[0].shape[0] for b in bank] == g[p + "bank_len"].tolist()
+        for c, b in enumerate(bank):
+            np.testing.assert_array_equal(b[0].numpy(), g[p + f"bank{c}"])
+        draws = []
+        for a, n in zip(trace.get("anchor_idx", []), trace.get("neg_idx", [])):
+            draws += [a, n]
+        if lkw["func"] in ("smc", "asmc"):
+            assert len(draws) == int(g[p + "n_draws"])
+            for k, d in enumerate(draws):
+                np.testing.assert_array_equal(d.numpy(), g[p + f"draw{k}"].astype(np.int64))
+        np.testing.assert_allclose(loss.item(), float(g[p + "loss"]), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rep.grad.numpy(), g[p + "grad"], rtol=1e-4, atol=1e-6)
+        assert int(torch.randint(1 << 30, (1,))) == int(g[p + "probe"][0])
+
+
+def test_loss_cases_exercise_real_work(golden):
+    """At least the mainstream cases must have a non-trivial loss and gradient."""
+    g = golden["g2_loss"]
+    for case in ("d16_smc", "d16_asmc", "d64_smc_default_q", "binary_3d"):
+        assert any(abs(float(g[f"{case}_s{s}_loss"])) > 1e-3 for s in range(fx.LOSS_STEPS)), case
+        assert any(np.abs(g[f"{case}_s{s}_grad"]).sum() > 0 for s in range(fx.LOSS_STEPS)), case
+
+
+def probe_like(t, seed):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.standard_normal(tuple(t.shape)).astype(np.float32))
+
+
+def test_unet_forward_backward(golden):
+    g = golden["g3_nets"]
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in fx.unet_state(21).items()}
+    x = fx.image_batch(5, 2, 1, (32, 32)).requires_grad_(True)
+    logits, latent, fmap = orc.unet_forward(x, sd)
+    np.testing.assert_allclose(logits.detach().numpy(), g["unet_logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(latent.detach().numpy(), g["unet_latent"], rtol=1e-4, atol=1e-5)
+    for i, f in enumerate(fmap):
+        np.testing.assert_allclose(f.detach().numpy(), g[f"unet_fmap{i}"], rtol=1e-4, atol=1e-5)
+    loss = (logits * probe_like(logits, 1)).sum()
+    for i, f in enumerate(fmap):
+        loss = loss + (f * probe_like(f, 10 + i)).sum()
+    loss.backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["unet_dx"], rtol=1e-3, atol=1e-4)
+    for n in g.files:
+        if n.startswith("unet_grad::"):
+            np.testing.assert_allclose(sd[n.split("::")[1]].grad.numpy(), g[n], rtol=2e-3, atol=2e-4, err_msg=n)
+    assert int(g["unet_n_state_keys"]) == len(sd)
+
+
+def test_feature_extractor(golden):
+    g = golden["g3_nets"]
+    dims, od, sp = (32, 16, 8, 8, 8), 24, 32
+    sd = {k: v.clone().requires_grad_(True) for k, v in fx.fe_state(31, dims, od, nd=2).items()}
+    fl = [fx.image_batch(40 + i, 2, c, (sp >> (4 - i), sp >> (4 - i))).requires_grad_(True) for i, c in enumerate(dims)]
+    y = orc.feature_extractor_forward(fl, sd)
+    np.testing.assert_allclose(y.detach().numpy(), g["fe_small_y"], rtol=1e-4, atol=1e-5)
+    (y * probe_like(y, 3)).sum().backward()
+    for i, f in enumerate(fl):
+        np.testing.assert_allclose(f.grad.numpy(), g[f"fe_small_dx{i}"], rtol=1e-4, atol=1e-5)
+    for k in sd:
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["fe_small_g::" + k], rtol=1e-3, atol=1e-4)
+
+
+def test_vnet_and_fe3d(golden):
+    g = golden["g3_nets"]
+    sd = fx.vnet_state(51)
+    x = fx.image_batch(8, 2, 1, (16, 16, 16))
+    out, f0, fmap = orc.vnet_forward(x, sd)
+    np.testing.assert_allclose(out.numpy(), g["vnet_out"], rtol=1e-4, atol=1e-5)
+    for i, f in enumerate(fmap):
+        np.testing.assert_allclose(f.numpy(), g[f"vnet_fmap{i}"], rtol=1e-4, atol=1e-5)
+    f3 = fx.fe_state(61, (128, 64, 32, 16, 16), 16, nd=3)
+    y = orc.feature_extractor_forward(fmap, f3, mode='trilinear')
+    np.testing.assert_allclose(y.numpy(), g["fe3d_y"], rtol=1e-4, atol=1e-5)
+
+
+def test_trainer_glue(golden):
+    g = golden["g4_glue"]
+    rs = np.random.RandomState(77)
+    b, C, H, W = 2, 4, 24, 20
+    pred_l = torch.from_numpy(rs.standard_normal((b, C, H, W)).astype(np.float32) * 2)
+    pred_u = torch.from_numpy(rs.standard_normal((b, C, H, W)).astype(np.float32) * 2)
+    lab_l = torch.from_numpy(fx.blob_labels(rs, b, (H, W), C))
+    lab_u = torch.from_numpy(fx.blob_labels(rs, b, (H, W), C))
+    lab_u[0, :3, :4] = -1
+    logits_u = torch.from_numpy(rs.uniform(0.3, 1.0, size=(b, H, W)).astype(np.float32))
+    np.testing.assert_array_equal(orc.label_onehot(lab_u, C).numpy(), g["onehot_u"])
+    np.testing.assert_allclose(orc.compute_unsupervised_loss(pred_u, lab_u, logits_u, 0.97).item(),
+                               float(g["unsup_loss"]), rtol=1e-6)
+    for epoch, max_epoch in ((0, 10), (3, 10)):
+        alpha = 20 * (1 - epoch / max_epoch)
+        assert alpha == float(g[f"mask_e{epoch}_alpha"])
+        low, high, ent = orc.entropy_masks(pred_u, lab_l, lab_u, alpha)
+        np.testing.assert_array_equal(low.numpy(), g[f"mask_e{epoch}_low"])
+        np.testing.assert_array_equal(high.numpy(), g[f"mask_e{epoch}_high"])
+        np.testing.assert_allclose(ent.numpy(), g[f"mask_e{epoch}_entropy"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(orc.ema_update([torch.from_numpy(g["ema_k"])], [torch.from_numpy(g["ema_q"])])[0].numpy(),
+                                  g["ema_out"])
+    p, buf = torch.from_numpy(g["ema_q"]).clone(), None
+    lr = 0.01
+    for it in range(3):
+        p, buf = orc.sgd_nesterov_step(p, torch.from_numpy(g["sgd_g"][it]), buf, lr)
+        np.testing.assert_allclose(p.numpy(), g[f"sgd_p{it}"], rtol=1e-6, atol=1e-7)
+        lr = orc.poly_lr(0.01, it, 30000)
