@@ -1,0 +1,100 @@
+"""ctypes binding of the C-ABI library arco_amd/lib/libarco_hip.so (include/arco_hip.h).
+
+The product path has NO CPU fallback: every op below raises if the HIP extension
+is missing or a launch fails.  PyTorch only owns memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libarco_hip.so")
+_lib = None
+
+_P, _I, _L, _F, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
+
+# name -> argtypes  (all return int status unless noted)
+_SIGS = {
+    "arco_mask_codes": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _F, _F, _I, _I, _P, _P, _P, _P, _P],
+    "arco_compact_rows": [_P, _L, _I, _P, _P, _P],
+    "arco_masked_proto": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P],
+    "arco_gather_rows": [_P, _L, _I, _P, _P, _P, _L, _L, _P, _L, _P],
+    "arco_bank_append": [_P, _L, _P, _L, _L, _I, _P, _P],
+    "arco_normalize_rows": [_P, _L, _L, _I, _F, _P, _L, _P, _L, _P, _P],
+    "arco_neg_multiplicity": [_P, _I, _I, _L, _L, _P, _P],
+    "arco_infonce_fwd": [_P, _L, _P, _L, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P],
+    "arco_infonce_anchor_grad": [_P, _P, _P, _L, _P, _P, _I, _I, _F, _F, _P, _P],
+    "arco_scatter_add_rows": [_P, _L, _I, _P, _P, _L, _P, _F, _P, _L, _P],
+    "arco_sum_scale": [_P, _I, _F, _P, _I, _P],
+    "arco_pack_conv_weight": [_P, _I, _I, _I, _I, _P, _P],
+    "arco_conv_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _P],
+    "arco_conv_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "arco_colsum": [_P, _L, _L, _I, _P, _P, _I, _P],
+    "arco_transpose2d": [_P, _L, _I, _I, _P, _L, _P],
+    "arco_bn_finalize": [_P, _P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
+    "arco_chan_stats": [_P, _L, _L, _I, _P, _P, _P],
+    "arco_bn_act_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _L, _P],
+    "arco_bn_act_bwd": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _P, _P, _I, _P, _L, _P],
+    "arco_maxpool2_fwd": [_P, _L, _I, _I, _I, _I, _P, _L, _P],
+    "arco_maxpool2_bwd": [_P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    "arco_bilinear_fwd": [_P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "arco_bilinear_bwd": [_P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _I, _P],
+    "arco_copy_rows": [_P, _L, _L, _I, _P, _L, _I, _P],
+    "arco_nchw_to_nhwc": [_P, _I, _I, _L, _P, _L, _P],
+    "arco_nhwc_to_nchw": [_P, _L, _I, _I, _L, _P, _P],
+    "arco_sgd_nesterov": [_P, _P, _P, _L, _F, _F, _F, _I, _P],
+    "arco_ema": [_P, _P, _L, _F, _P],
+}
+_QUERIES = {   # plain host helpers returning sizes
+    "arco_proto_ws_floats": ([_L, _I, _I], _L),
+    "arco_conv_mblocks": ([_I, _I, _I, _I, _I], _I),
+    "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
+    "arco_chan_stats_blocks": ([_L], _I),
+}
+EXPORTS = sorted(list(_SIGS) + list(_QUERIES))
+
+
+def load():
+    """Load the shared library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"arco_amd: HIP extension {LIB_PATH} is missing - build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (make -C arco_amd/csrc). "
+                "There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, _I
+        for name, (args, res) in _QUERIES.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Invoke a kernel entry point on the current torch HIP stream; raise on error."""
+    rc = getattr(load(), name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"arco_amd: {name} failed with code {rc}")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("arco_amd: tensors must live on the GPU (no CPU fallback); got a CPU tensor")

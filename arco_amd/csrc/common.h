@@ -1,0 +1,45 @@
+// Shared helpers for the arco_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ARCO_OK 0
+#define ARCO_ERR_ARG (-1)
+#define ARCO_ERR_LAUNCH (-2)
+#define ARCO_ERR_UNSUPPORTED (-3)
+
+#define ARCO_CHECK_ARG(cond) \
+  do {                       \
+    if (!(cond)) return ARCO_ERR_ARG; \
+  } while (0)
+
+static inline int arco_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ARCO_OK : ARCO_ERR_LAUNCH;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// bit layout of the per-pixel class code (C <= 21)
+#define ARCO_MAXC 21
+#define ARCO_BIT_LV(c) (c)
+#define ARCO_BIT_ANCHOR(c) (21 + (c))
+#define ARCO_BIT_NEG(c) (42 + (c))
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

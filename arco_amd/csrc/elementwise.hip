@@ -1,0 +1,479 @@
+// HBM-bound channels-last passes around the convs: train-mode BatchNorm statistics /
+// apply / backward fused with (Leaky)ReLU and dropout (unetWithArgs.py:36-44,
+// vnetWithArgs.py:16-25), 2x2 max-pool, align_corners bilinear resize
+// (model_2D.py:43-52, unetWithArgs.py:74-75), channel-slice copies (the cat's),
+// flat-buffer SGD-Nesterov and EMA (train_arco_2d.py:248,306-308,432; model_2D.py:176-182).
+// All kernels: float4 per lane along the channel axis, grid-stride over pixels.
+#include "common.h"
+
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+  uint32_t s = v * 747796405u + 2891336453u;
+  uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+// keep-decision of the dropout mask for element index e (stateless: recomputed in backward)
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
+  const uint32_t h = pcg_hash((uint32_t)e ^ pcg_hash((uint32_t)(e >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+// ---- BN statistics finalize: block partial (sum, sumsq) -> mean, istd, running stats
+__global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
+                                   double count, float eps, float momentum, float* __restrict__ mean,
+                                   float* __restrict__ istd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += (double)ssum[(long)c * nblk + b]; q += (double)ssq[(long)c * nblk + b]; }
+  const double m = s / count;
+  double var = q / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  istd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+  }
+}
+
+// ---- generic per-channel (sum, sumsq) partials of a channels-last tensor (for
+//      tensors not produced by the conv kernel, e.g. the V-Net k2s2 convs)
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ X, long ldx, long M, int C,
+                                                        float* __restrict__ ssum, float* __restrict__ ssq, int nblk) {
+  const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
+  const long rpb = (M + nblk - 1) / nblk;
+  const long r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
+  f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  if (tr < rstep)
+    for (long r = r0 + tr; r < r1; r += rstep) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ldx + 4 * tq);
+      s += v; q += v * v;
+    }
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][256][4]
+  *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s;
+  *reinterpret_cast<f32x4*>(&red[1024 + threadIdx.x * 4]) = q;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int qq = c / 4, e = c % 4;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rstep; ++r) { a += red[(r * q4 + qq) * 4 + e]; b += red[1024 + (r * q4 + qq) * 4 + e]; }
+    ssum[(long)c * nblk + blockIdx.x] = a; ssq[(long)c * nblk + blockIdx.x] = b;
+  }
+}
+
+// ---- BN apply + LeakyReLU(slope) + dropout:  a = drop(lrelu((z-mean)*istd*gamma+beta))
+//      drop_mode 0: none, 1: per element (nn.Dropout), 2: per (image, channel) (nn.Dropout3d)
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Z, long ldz, long M, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ istd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float slope, int drop_mode, float p, uint64_t seed, long P,
+                                                        float* __restrict__ Aout, long lda) {
+  const int q4 = C / 4;
+  const long tot = M * q4;
+  const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const long r = i / q4; const int c = (int)(i - r * q4) * 4;
+    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float y = mean ? (z[e] - mean[c + e]) * istd[c + e] * gamma[c + e] + beta[c + e] : z[e];
+      y = y >= 0.f ? y : y * slope;
+      if (drop_mode == 1) y = drop_keep(seed, (uint64_t)(r * C + c + e), p) ? y * keep_scale : 0.f;
+      else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)((r / P) * C + c + e), p) ? y * keep_scale : 0.f;
+      o[e] = y;
+    }
+    *reinterpret_cast<f32x4*>(Aout + r * lda + c) = o;
+  }
+}
+
+// dy (gradient at the BN output) recomputed from z: dy = dA * dropmask * lrelu'(y)
+__device__ __forceinline__ float bn_dy(float dA, float y, float slope, int drop_mode, float p, float keep_scale,
+                                       uint64_t seed, uint64_t e) {
+  float d = y >= 0.f ? dA : dA * slope;
+  if (drop_mode) d = drop_keep(seed, e, p) ? d * keep_scale : 0.f;
+  return d;
+}
+
+// ---- BN backward pass 1: per-channel partial sums of dy and dy*xhat
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
+    const float* __restrict__ dA, long ldd, const float* __restrict__ Z, long ldz, long M, int C,
+    const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed, long P,
+    float* __restrict__ s_dy, float* __restrict__ s_dyx, int nblk) {
+  const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
+  const long rpb = (M + nblk - 1) / nblk;
+  const long r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
+  const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
+  f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  const int c = 4 * tq;
+  if (tr < rstep)
+    for (long r = r0 + tr; r < r1; r += rstep) {
+      const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dA + r * ldd + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (z[e] - mean[c + e]) * istd[c + e];
+        const float y = xh * gamma[c + e] + beta[c + e];
+        const uint64_t ei = drop_mode == 2 ? (uint64_t)((r / P) * C + c + e) : (uint64_t)(r * C + c + e);
+        const float dy = bn_dy(d[e], y, slope, drop_mode, p, keep_scale, seed, ei);
+        s[e] += dy; q[e] += dy * xh;
+      }
+    }
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s;
+  *reinterpret_cast<f32x4*>(&red[1024 + threadIdx.x * 4]) = q;
+  __syncthreads();
+  for (int cc = threadIdx.x; cc < C; cc += 256) {
+    const int qq = cc / 4, e = cc % 4;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rstep; ++r) { a += red[(r * q4 + qq) * 4 + e]; b += red[1024 + (r * q4 + qq) * 4 + e]; }
+    s_dy[(long)cc * nblk + blockIdx.x] = a; s_dyx[(long)cc * nblk + blockIdx.x] = b;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int nblk, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nblk; ++i) { a += (double)s_dy[(long)c * nblk + i]; b += (double)s_dyx[(long)c * nblk + i]; }
+  dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+  dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+}
+
+// ---- BN backward pass 2: dz = gamma*istd*(dy - sum_dy/n - xhat*sum_dyx/n)
+//      sums are read from `sums` = [dbeta_this_call | dgamma_this_call] (not the accumulated grads)
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const float* __restrict__ dA, long ldd, const float* __restrict__ Z, long ldz, long M, int C,
+    const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed, long P,
+    const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, float inv_count,
+    float* __restrict__ dZ, long ldo) {
+  const int q4 = C / 4;
+  const long tot = M * q4;
+  const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const long r = i / q4; const int c = (int)(i - r * q4) * 4;
+    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dA + r * ldd + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint64_t ei = drop_mode == 2 ? (uint64_t)((r / P) * C + c + e) : (uint64_t)(r * C + c + e);
+      if (mean) {
+        const float xh = (z[e] - mean[c + e]) * istd[c + e];
+        const float y = xh * gamma[c + e] + beta[c + e];
+        const float dy = bn_dy(d[e], y, slope, drop_mode, p, keep_scale, seed, ei);
+        o[e] = gamma[c + e] * istd[c + e] * (dy - sum_dy[c + e] * inv_count - xh * sum_dyx[c + e] * inv_count);
+      } else {
+        o[e] = bn_dy(d[e], z[e], slope, drop_mode, p, keep_scale, seed, ei);
+      }
+    }
+    *reinterpret_cast<f32x4*>(dZ + r * ldo + c) = o;
+  }
+}
+
+// ---- 2x2 max pool (nn.MaxPool2d(2), unetWithArgs.py:55-58), channels-last
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ X, long ldx, int NB, int H, int W,
+                                                          int C, float* __restrict__ Y, long ldy) {
+  const int q4 = C / 4, Ho = H / 2, Wo = W / 2;
+  const long tot = (long)NB * Ho * Wo * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q4) * 4; long r = i / q4;
+    const int xo = r % Wo; r /= Wo; const int yo = r % Ho; const long n = r / Ho;
+    const float* b = X + (((n * H) + 2 * yo) * W + 2 * xo) * ldx + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(b), v01 = *reinterpret_cast<const f32x4*>(b + ldx);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + (long)W * ldx), v11 = *reinterpret_cast<const f32x4*>(b + (long)W * ldx + ldx);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+    *reinterpret_cast<f32x4*>(Y + (((n * Ho) + yo) * Wo + xo) * ldy + c) = o;
+  }
+}
+// gradient goes to the first maximum in window scan order (torch's saved argmax)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ X, long ldx, int NB, int H, int W,
+                                                          int C, const float* __restrict__ dY, long ldy,
+                                                          float* __restrict__ dX, long ldo) {
+  const int q4 = C / 4, Ho = H / 2, Wo = W / 2;
+  const long tot = (long)NB * Ho * Wo * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q4) * 4; long r = i / q4;
+    const int xo = r % Wo; r /= Wo; const int yo = r % Ho; const long n = r / Ho;
+    const long p00 = ((n * H) + 2 * yo) * W + 2 * xo;
+    const long off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(X + off[k] * ldx + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dY + (((n * Ho) + yo) * Wo + xo) * ldy + c);
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int best = 0; float bv = v[0][e];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) if (v[k][e] > bv) { bv = v[k][e]; best = k; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][e] = k == best ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dX + off[k] * ldo + c) = o[k];
+  }
+}
+
+// ---- bilinear resize, align_corners=True (torch upsample_bilinear2d index math in fp32)
+__device__ __forceinline__ void ac_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+  const float src = scale * (float)o;
+  i0 = (int)src; if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 < in_size - 1 ? i0 + 1 : i0;
+  l1 = src - (float)i0;
+}
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ X, long ldx, int NB, int Hi, int Wi,
+                                                          int C, int Ho, int Wo, float* __restrict__ Y, long ldy) {
+  const int q4 = C / 4;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  const long tot = (long)NB * Ho * Wo * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q4) * 4; long r = i / q4;
+    const int xo = r % Wo; r /= Wo; const int yo = r % Ho; const long n = r / Ho;
+    int y0, y1, x0, x1; float ly, lx;
+    ac_src(yo, sh, Hi, y0, y1, ly); ac_src(xo, sw, Wi, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = X + (n * Hi) * (long)Wi * ldx + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((long)y0 * Wi + x0) * ldx);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((long)y0 * Wi + x1) * ldx);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((long)y1 * Wi + x0) * ldx);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((long)y1 * Wi + x1) * ldx);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(Y + (((n * Ho) + yo) * Wo + xo) * ldy + c) = o;
+  }
+}
+// adjoint as a gather (no atomics): input pixel (yi, xi) collects from the output pixels that
+// reference it; candidate output ranges are bounded by the scale and verified with ac_src.
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dY, long ldy, int NB, int Hi, int Wi,
+                                                          int C, int Ho, int Wo, float* __restrict__ dX, long ldx,
+                                                          int accumulate) {
+  const int q4 = C / 4;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  const float ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
+  const long tot = (long)NB * Hi * Wi * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q4) * 4; long r = i / q4;
+    const int xi = r % Wi; r /= Wi; const int yi = r % Hi; const long n = r / Hi;
+    int ya = sh > 0.f ? (int)floorf((float)(yi - 1) * ish) - 1 : 0, yb = sh > 0.f ? (int)ceilf((float)(yi + 1) * ish) + 1 : Ho - 1;
+    int xa = sw > 0.f ? (int)floorf((float)(xi - 1) * isw) - 1 : 0, xb = sw > 0.f ? (int)ceilf((float)(xi + 1) * isw) + 1 : Wo - 1;
+    ya = max(ya, 0); yb = min(yb, Ho - 1); xa = max(xa, 0); xb = min(xb, Wo - 1);
+    f32x4 acc = {0, 0, 0, 0};
+    for (int yo = ya; yo <= yb; ++yo) {
+      int y0, y1; float ly; ac_src(yo, sh, Hi, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == yi) wy += 1.f - ly;
+      if (y1 == yi) wy += ly;
+      if (wy == 0.f && !(y0 == yi || y1 == yi)) continue;
+      for (int xo = xa; xo <= xb; ++xo) {
+        int x0, x1; float lx; ac_src(xo, sw, Wi, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == xi) wx += 1.f - lx;
+        if (x1 == xi) wx += lx;
+        if (!(x0 == xi || x1 == xi)) continue;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dY + (((n * Ho) + yo) * Wo + xo) * ldy + c);
+        const float w = wy * wx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w * g[e];
+      }
+    }
+    float* dst = dX + (((n * Hi) + yi) * Wi + xi) * ldx + c;
+    if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(dst); acc += old; }
+    *reinterpret_cast<f32x4*>(dst) = acc;
+  }
+}
+
+// ---- strided channel-slice copy / add:  Y[r][0..C) (+)= X[r][0..C)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ X, long ldx, long M, int C,
+                                                       float* __restrict__ Y, long ldy, int accumulate) {
+  const int q4 = C / 4;
+  const long tot = M * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const long r = i / q4; const int c = (int)(i - r * q4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ldx + c);
+    float* d = Y + r * ldy + c;
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(d);
+    *reinterpret_cast<f32x4*>(d) = v;
+  }
+}
+
+// NCHW plane layout <-> channels-last rows (API boundary conversion)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ X, int NB, int C, long P, float* __restrict__ Y, long ldy) {
+  __shared__ float tile[32][33];
+  const long n = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {          // r: channel
+    const int c = c0 + r; const long p = p0 + threadIdx.x;
+    tile[r][threadIdx.x] = (c < C && p < P) ? X[(n * C + c) * P + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {          // r: pixel
+    const long p = p0 + r; const int c = c0 + threadIdx.x;
+    if (p < P && c < C) Y[(n * P + p) * ldy + c] = tile[threadIdx.x][r];
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ X, long ldx, int NB, int C, long P, float* __restrict__ Y) {
+  __shared__ float tile[32][33];
+  const long n = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {          // r: pixel
+    const long p = p0 + r; const int c = c0 + threadIdx.x;
+    tile[r][threadIdx.x] = (c < C && p < P) ? X[(n * P + p) * ldx + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {          // r: channel
+    const int c = c0 + r; const long p = p0 + threadIdx.x;
+    if (p < P && c < C) Y[(n * C + c) * P + p] = tile[threadIdx.x][r];
+  }
+}
+
+// ---- flat-buffer optimiser steps
+// torch.optim.SGD(momentum, weight_decay, nesterov=True): g += wd*p; buf = first ? g : mom*buf + g;
+// p -= lr * (g + mom*buf)
+__global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ buf, long n, float lr, float mom, float wd,
+                                                          int first) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pv = p[i];
+    const float gv = g[i] + wd * pv;
+    const float b = first ? gv : mom * buf[i] + gv;
+    buf[i] = b;
+    p[i] = pv - lr * (gv + mom * b);
+  }
+}
+// k = k*m + q*(1-m)
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ k, const float* __restrict__ q, long n, float m) {
+  const float om = 1.0f - m;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) k[i] = k[i] * m + q[i] * om;
+}
+
+static inline int ew_grid(long work) {
+  long g = (work + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" {
+
+int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
+                     float* mean, float* istd, float* running_mean, float* running_var, void* stream) {
+  ARCO_CHECK_ARG(C > 0 && nblk > 0 && count > 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), ssum, ssq, nblk, C,
+                     (double)count, eps, momentum, mean, istd, running_mean, running_var);
+  return arco_launch_status();
+}
+
+int arco_chan_stats_blocks(long M) { long b = (M + 2047) / 2048; if (b > 512) b = 512; if (b < 1) b = 1; return (int)b; }
+
+int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream) {
+  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldx & 3) == 0);
+  const int nblk = arco_chan_stats_blocks(M);
+  hipLaunchKernelGGL(chan_stats_kernel, dim3(nblk), dim3(256), 2048 * sizeof(float), as_stream(stream), X, ldx, M, C,
+                     ssum, ssq, nblk);
+  return arco_launch_status();
+}
+
+int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                    const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
+                    void* stream) {
+  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && p < 1.0f);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, as_stream(stream), Z, ldz, M, C, mean,
+                     istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda);
+  return arco_launch_status();
+}
+
+// ws: 2*C*nblk floats + 2*C floats (this call's sums);  nblk = arco_chan_stats_blocks(M)
+int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
+                    const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
+                    uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
+                    void* stream) {
+  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldz & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0);
+  const int dm = p > 0.f ? drop_mode : 0;
+  hipStream_t st = as_stream(stream);
+  if (mean) {
+    const int nblk = arco_chan_stats_blocks(M);
+    float* s_dy = ws; float* s_dyx = ws + (long)C * nblk; float* sums = ws + 2l * C * nblk;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, M,
+                       C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums + C,
+                       sums, 0);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
+                       mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)M, dZ, ldo);
+    // grads: dbeta = sum dy, dgamma = sum dy*xhat
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, s_dy, s_dyx, nblk, C, dgamma,
+                       dbeta, accumulate);
+  } else {
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
+                       nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo);
+  }
+  return arco_launch_status();
+}
+
+int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, float* Y, long ldy, void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (H & 1) == 0 && (W & 1) == 0);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid((long)NB * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     as_stream(stream), X, ldx, NB, H, W, C, Y, ldy);
+  return arco_launch_status();
+}
+int arco_maxpool2_bwd(const float* X, long ldx, int NB, int H, int W, int C, const float* dY, long ldy, float* dX,
+                      long ldo, void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (H & 1) == 0 && (W & 1) == 0);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid((long)NB * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     as_stream(stream), X, ldx, NB, H, W, C, dY, ldy, dX, ldo);
+  return arco_launch_status();
+}
+
+int arco_bilinear_fwd(const float* X, long ldx, int NB, int Hi, int Wi, int C, int Ho, int Wo, float* Y, long ldy,
+                      void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_grid((long)NB * Ho * Wo * (C / 4))), dim3(256), 0, as_stream(stream),
+                     X, ldx, NB, Hi, Wi, C, Ho, Wo, Y, ldy);
+  return arco_launch_status();
+}
+int arco_bilinear_bwd(const float* dY, long ldy, int NB, int Hi, int Wi, int C, int Ho, int Wo, float* dX, long ldx,
+                      int accumulate, void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_grid((long)NB * Hi * Wi * (C / 4))), dim3(256), 0, as_stream(stream),
+                     dY, ldy, NB, Hi, Wi, C, Ho, Wo, dX, ldx, accumulate);
+  return arco_launch_status();
+}
+
+int arco_copy_rows(const float* X, long ldx, long M, int C, float* Y, long ldy, int accumulate, void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, as_stream(stream), X, ldx, M, C, Y, ldy,
+                     accumulate);
+  return arco_launch_status();
+}
+
+int arco_nchw_to_nhwc(const float* X, int NB, int C, long P, float* Y, long ldy, void* stream) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((P + 31) / 32, (C + 31) / 32, NB), dim3(32, 8), 0, as_stream(stream), X,
+                     NB, C, P, Y, ldy);
+  return arco_launch_status();
+}
+int arco_nhwc_to_nchw(const float* X, long ldx, int NB, int C, long P, float* Y, void* stream) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((P + 31) / 32, (C + 31) / 32, NB), dim3(32, 8), 0, as_stream(stream), X,
+                     ldx, NB, C, P, Y);
+  return arco_launch_status();
+}
+
+int arco_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                      int first, void* stream) {
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), p, g, buf, n, lr, momentum,
+                     weight_decay, first);
+  return arco_launch_status();
+}
+int arco_ema(float* k, const float* q, long n, float m, void* stream) {
+  hipLaunchKernelGGL(ema_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), k, q, n, m);
+  return arco_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,511 @@
+// Implicit-GEMM convolution on the CDNA4 fp32 matrix cores (v_mfma_f32_16x16x4_f32):
+//   out[pix][n] = sum_{tap, k} in[pix + tap][k] * Wp[tap][n][k]  (+bias, +residual)
+// channels-last activations (rows of `ld` floats), packed weights [TAPS][Npad][Kpad].
+// One kernel family serves the 1x1 convs (FeatureExtractor / q_representation /
+// UpBlock.conv1x1: model_2D.py:20-55, train_arco_2d.py:231-234, unetWithArgs.py:72-83)
+// and the 3x3 convs of ConvBlock (unetWithArgs.py:31-47), forward and dgrad
+// (dgrad = same kernel with flipped+transposed packed weights).
+//
+// Tiling: 4 waves / workgroup; a wave owns A_T x C_T MFMA tiles of 16 pixels x 16
+// channels.  Per K-chunk (KC channels) the input patch (with halo for 3x3) and the
+// weight slab of every tap are staged in LDS with rows padded to KC+4 floats, so the
+// ds_read_b128 fragment reads (4 consecutive k per lane) are bank-conflict free.
+// A b128 fragment feeds 4 MFMAs: lane (i, g) holds k = 4g+j for j = 0..3.
+#include "common.h"
+
+struct IgemmArgs {
+  const float* A; long lda;
+  const float* Wp; int Npad, Kpad, N, K;
+  float* C; long ldc;
+  const float* bias;
+  const float* R; long ldr;
+  float* stat_sum; float* stat_sq;   // [N][n_mblocks] block partials (nullable)
+  int n_mblocks;
+  int NB, H, W;                      // images, rows, cols (TAPS==9); TAPS==1 uses M only
+  long M;                            // total pixels
+};
+
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+  constexpr int TH = BM / 16;
+  constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
+  constexpr int LDK = KC + 4;
+  constexpr int A_T = BM / 16 / WAVES_M;
+  constexpr int C_T = BN / 16 / WAVES_N;
+  constexpr int Q4 = KC / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + AROWS * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * BN;
+
+  // tile origin
+  long m0 = 0; int img = 0, y0 = 0, x0 = 0;
+  if (TAPS == 9) {
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; img = t / tiles_y;
+    y0 = ty * TH; x0 = tx * 16;
+  } else {
+    m0 = (long)blockIdx.x * BM;
+  }
+
+  f32x4 acc[A_T][C_T];
+#pragma unroll
+  for (int i = 0; i < A_T; ++i)
+#pragma unroll
+    for (int j = 0; j < C_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  const bool vecA = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
+
+  for (int kc0 = 0; kc0 < a.Kpad; kc0 += KC) {
+    // ---- stage A (input patch)
+    for (int idx = tid; idx < AROWS * Q4; idx += 256) {
+      const int row = idx / Q4, q = idx - row * Q4;
+      const int k = kc0 + 4 * q;
+      long pix = -1;
+      if (TAPS == 9) {
+        const int hy = row / 18, hx = row - hy * 18;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        if (y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
+      } else {
+        const long m = m0 + row;
+        if (m < a.M) pix = m;
+      }
+      f32x4 v = f32x4{0, 0, 0, 0};
+      if (pix >= 0) {
+        const float* src = a.A + pix * a.lda + k;
+        if (vecA) {
+          if (k < a.K) v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < a.K) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&As[row * LDK + 4 * q]) = v;
+    }
+    // ---- stage B (weights of every tap for this K-chunk)
+    for (int idx = tid; idx < TAPS * BN * Q4; idx += 256) {
+      const int row = idx / Q4, q = idx - row * Q4;
+      const int tap = row / BN, n = row - tap * BN;
+      f32x4 v = f32x4{0, 0, 0, 0};
+      if (n0 + n < a.Npad)
+        v = *reinterpret_cast<const f32x4*>(a.Wp + ((long)tap * a.Npad + n0 + n) * a.Kpad + kc0 + 4 * q);
+      *reinterpret_cast<f32x4*>(&Bs[row * LDK + 4 * q]) = v;
+    }
+    __syncthreads();
+    // ---- MFMA
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk) {
+        f32x4 af[A_T], bf[C_T];
+#pragma unroll
+        for (int at = 0; at < A_T; ++at) {
+          const int s = wm * A_T + at;
+          const int row = TAPS == 9 ? (s + dy) * 18 + li + dx : s * 16 + li;
+          af[at] = *reinterpret_cast<const f32x4*>(&As[row * LDK + kk * 16 + 4 * g]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < C_T; ++ct) {
+          const int row = tap * BN + (wn * C_T + ct) * 16 + li;
+          bf[ct] = *reinterpret_cast<const f32x4*>(&Bs[row * LDK + kk * 16 + 4 * g]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int at = 0; at < A_T; ++at)
+#pragma unroll
+            for (int ct = 0; ct < C_T; ++ct)
+              acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[at][j], bf[ct][j], acc[at][ct], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, residual, store, BN partial statistics
+  float s1[C_T], s2[C_T];
+#pragma unroll
+  for (int ct = 0; ct < C_T; ++ct) { s1[ct] = 0.f; s2[ct] = 0.f; }
+#pragma unroll
+  for (int ct = 0; ct < C_T; ++ct) {
+    const int n = n0 + (wn * C_T + ct) * 16 + li;
+    const bool nok = n < a.N;
+    const float bv = (a.bias && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int at = 0; at < A_T; ++at) {
+      const int s = wm * A_T + at;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        long pix = -1;
+        if (TAPS == 9) {
+          const int y = y0 + s, x = x0 + i;
+          if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
+        } else {
+          const long m = m0 + s * 16 + i;
+          if (m < a.M) pix = m;
+        }
+        if (pix >= 0 && nok) {
+          float v = acc[at][ct][r] + bv;
+          if (a.R) v += a.R[pix * a.ldr + n];
+          a.C[pix * a.ldc + n] = v;
+          s1[ct] += v; s2[ct] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stat_sum) {
+    float* red = smem;   // reuse: [2][WAVES_M][BN]
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < C_T; ++ct) {
+      float v1 = s1[ct], v2 = s2[ct];
+      v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
+      v2 += __shfl_xor(v2, 16, 64); v2 += __shfl_xor(v2, 32, 64);
+      if (g == 0) {
+        const int nl = (wn * C_T + ct) * 16 + li;
+        red[(0 * WAVES_M + wm) * BN + nl] = v1;
+        red[(1 * WAVES_M + wm) * BN + nl] = v2;
+      }
+    }
+    __syncthreads();
+    for (int nl = tid; nl < BN; nl += 256) {
+      const int n = n0 + nl;
+      if (n < a.N) {
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) { v1 += red[(0 * WAVES_M + w) * BN + nl]; v2 += red[(1 * WAVES_M + w) * BN + nl]; }
+        a.stat_sum[(long)n * a.n_mblocks + blockIdx.x] = v1;
+        a.stat_sq[(long)n * a.n_mblocks + blockIdx.x] = v2;
+      }
+    }
+  }
+}
+
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC>
+static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
+  constexpr int TH = BM / 16;
+  constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
+  int mblocks;
+  if (TAPS == 9) mblocks = a.NB * ((a.H + TH - 1) / TH) * ((a.W + 15) / 16);
+  else mblocks = (int)((a.M + BM - 1) / BM);
+  if (n_mblocks_out) { *n_mblocks_out = mblocks; return ARCO_OK; }
+  size_t sh = (size_t)(AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
+  const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
+  if (sh < red) sh = red;
+  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC>;
+  if (sh > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  IgemmArgs b = a;
+  b.n_mblocks = mblocks;
+  dim3 grid(mblocks, (a.Npad + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, b);
+  return arco_launch_status();
+}
+
+// config choice shared by the launch and the "how many M-blocks" query
+static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb) {
+  if (taps == 1) {
+    if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16>(a, st, nmb);
+    if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 16>(a, st, nmb);
+    if (a.M * (long)a.Npad <= 4096l * 1024) return launch_igemm<1, 64, 64, 2, 2, 16>(a, st, nmb);
+    return launch_igemm<1, 128, 128, 2, 2, 16>(a, st, nmb);
+  }
+  if (taps == 9) {
+    if (a.Npad <= 16) return launch_igemm<9, 256, 16, 4, 1, 16>(a, st, nmb);
+    if (a.Npad <= 32) return launch_igemm<9, 128, 32, 4, 1, 16>(a, st, nmb);
+    if ((long)a.NB * a.H * a.W <= 16384) return launch_igemm<9, 64, 64, 2, 2, 16>(a, st, nmb);
+    return launch_igemm<9, 128, 64, 4, 1, 16>(a, st, nmb);
+  }
+  return ARCO_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------
+// weight packing: torch [Cout][Cin][kh][kw] -> Wp[tap][Npad][Kpad]
+//   mode 0 (forward):  Wp[tap][co][ci] = W[co][ci][tap]
+//   mode 1 (dgrad):    Wp[tap][ci][co] = W[co][ci][TAPS-1-tap]   (flipped, transposed)
+// ---------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int Cin, int taps, int mode, int Npad,
+                                   int Kpad, float* __restrict__ Wp) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tot = (long)taps * Npad * Kpad;
+  if (i >= tot) return;
+  const int k = i % Kpad; const long r = i / Kpad; const int n = r % Npad; const int tap = r / Npad;
+  float v = 0.f;
+  if (mode == 0) { if (n < Cout && k < Cin) v = W[((long)n * Cin + k) * taps + tap]; }
+  else { if (n < Cin && k < Cout) v = W[((long)k * Cin + n) * taps + (taps - 1 - tap)]; }
+  Wp[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient:  dW[co][ci][tap] = sum_pix dZ[pix][co] * Ain[pix + tap][ci]
+// M = co, N = ci, K = pixels.  grid.x = pixel chunk, grid.y = co tile,
+// grid.z = tap * ci_tiles + ci tile.  Tiles of 128 pixels (8x16) are staged channels-last in
+// LDS (row stride = 16 mod 32 dwords -> conflict-free ds_read_b32 of 16 channels x 4
+// pixels); each wave reduces 32 pixels per tile; partial slabs are summed in fixed
+// order by wgrad_reduce_kernel (deterministic).
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dZ; long ldz; int Cout;
+  const float* Ain; long lda; int Cin;
+  int taps, NB, H, W; long M;
+  float* partial;      // [chunks][taps][CoutPad][CinPad]
+  int CoutPad, CinPad, n_tiles;
+};
+
+template <int CO_B, int CI_B>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  constexpr int LDZ = (CO_B % 32 == 0) ? CO_B + 16 : CO_B;
+  constexpr int LDA = (CI_B % 32 == 0) ? CI_B + 16 : CI_B;
+  constexpr int CO_T = CO_B / 16, CI_T = CI_B / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zs = smem;                 // [128][LDZ]
+  float* Xs = smem + 128 * LDZ;     // [128][LDA]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int ci_tiles = a.CinPad / CI_B;
+  const int tap = blockIdx.z / ci_tiles, cit = blockIdx.z % ci_tiles;
+  const int co0 = blockIdx.y * CO_B, ci0 = cit * CI_B;
+  const int dy = a.taps == 9 ? tap / 3 - 1 : 0, dx = a.taps == 9 ? tap % 3 - 1 : 0;
+  const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
+
+  f32x4 acc[CO_T][CI_T];
+#pragma unroll
+  for (int i = 0; i < CO_T; ++i)
+#pragma unroll
+    for (int j = 0; j < CI_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    int img = 0, y0 = 0, x0 = 0; long m0 = 0;
+    if (a.taps == 9) {
+      int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; img = tt / tiles_y;
+      y0 = ty * 8; x0 = tx * 16;
+    } else {
+      m0 = (long)t * 128;
+    }
+    __syncthreads();
+    // stage dZ tile and (shifted) input tile; 128 pixels each
+    for (int idx = tid; idx < 128 * (CO_B / 4); idx += 256) {
+      const int p = idx / (CO_B / 4), q = idx % (CO_B / 4);
+      long pix = -1;
+      if (a.taps == 9) { const int y = y0 + p / 16, x = x0 + p % 16; if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x; }
+      else { const long m = m0 + p; if (m < a.M) pix = m; }
+      f32x4 v = f32x4{0, 0, 0, 0};
+      if (pix >= 0) {
+        const int c = co0 + 4 * q;
+        const float* src = a.dZ + pix * a.ldz + c;
+        if (((a.Cout & 3) == 0) && ((a.ldz & 3) == 0)) { if (c < a.Cout) v = *reinterpret_cast<const f32x4*>(src); }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c + e < a.Cout) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Zs[p * LDZ + 4 * q]) = v;
+    }
+    for (int idx = tid; idx < 128 * (CI_B / 4); idx += 256) {
+      const int p = idx / (CI_B / 4), q = idx % (CI_B / 4);
+      long pix = -1;
+      if (a.taps == 9) {
+        const int yo = y0 + p / 16, xo = x0 + p % 16;
+        const int y = yo + dy, x = xo + dx;
+        if (yo < a.H && xo < a.W && y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
+      } else { const long m = m0 + p; if (m < a.M) pix = m; }
+      f32x4 v = f32x4{0, 0, 0, 0};
+      if (pix >= 0) {
+        const int c = ci0 + 4 * q;
+        const float* src = a.Ain + pix * a.lda + c;
+        if (((a.Cin & 3) == 0) && ((a.lda & 3) == 0)) { if (c < a.Cin) v = *reinterpret_cast<const f32x4*>(src); }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c + e < a.Cin) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Xs[p * LDA + 4 * q]) = v;
+    }
+    __syncthreads();
+    const int pw = wid * 32;
+#pragma unroll 4
+    for (int ks = 0; ks < 8; ++ks) {
+      const int p = pw + ks * 4 + g;
+      float zf[CO_T], xf[CI_T];
+#pragma unroll
+      for (int i = 0; i < CO_T; ++i) zf[i] = Zs[p * LDZ + i * 16 + li];
+#pragma unroll
+      for (int j = 0; j < CI_T; ++j) xf[j] = Xs[p * LDA + j * 16 + li];
+#pragma unroll
+      for (int i = 0; i < CO_T; ++i)
+#pragma unroll
+        for (int j = 0; j < CI_T; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // cross-wave reduction through LDS, then slab store
+  __syncthreads();
+  float* red = smem;   // [4][CO_B][CI_B]
+#pragma unroll
+  for (int i = 0; i < CO_T; ++i)
+#pragma unroll
+    for (int j = 0; j < CI_T; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[((wid * CO_B) + i * 16 + 4 * g + r) * CI_B + j * 16 + li] = acc[i][j][r];
+  __syncthreads();
+  float* out = a.partial + (((long)blockIdx.x * a.taps + tap) * a.CoutPad) * a.CinPad;
+  for (int idx = tid; idx < CO_B * CI_B; idx += 256) {
+    const int co = idx / CI_B, ci = idx % CI_B;
+    const float v = (red[(0 * CO_B + co) * CI_B + ci] + red[(1 * CO_B + co) * CI_B + ci]) +
+                    (red[(2 * CO_B + co) * CI_B + ci] + red[(3 * CO_B + co) * CI_B + ci]);
+    out[(long)(co0 + co) * a.CinPad + ci0 + ci] = v;
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int taps, int CoutPad, int CinPad,
+                                    int Cout, int Cin, float* __restrict__ dW, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tot = (long)Cout * Cin * taps;
+  if (i >= tot) return;
+  const int tap = i % taps; const long r = i / taps; const int ci = r % Cin; const int co = r / Cin;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[(((long)c * taps + tap) * CoutPad + co) * CinPad + ci];
+  dW[i] = accumulate ? dW[i] + s : s;
+}
+
+// column sums (bias gradient): out[c] = sum_pix X[pix][c]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, long M, int C,
+                                                            float* __restrict__ partial) {
+  // block handles a pixel range; thread t handles channel t % C for rows t / C + k*(256/C)
+  const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+  const long r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += X[r * ldx + c];
+    partial[(long)blockIdx.x * C + c] = s;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+__global__ void transpose2d_kernel(const float* __restrict__ x, long ldx, int rows, int cols, float* __restrict__ y, long ldy) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int rr = by + r, cc = bx + threadIdx.x;
+    tile[r][threadIdx.x] = (rr < rows && cc < cols) ? x[(long)rr * ldx + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int cc = bx + r, rr = by + threadIdx.x;   // output row = input col
+    if (cc < cols && rr < rows) y[(long)cc * ldy + rr] = tile[threadIdx.x][r];
+  }
+}
+
+extern "C" {
+
+// Query: number of M-blocks (= BN-stat partial slabs per channel) the conv launch will use.
+int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout) {
+  IgemmArgs a{};
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16;
+  int nmb = 0;
+  if (dispatch_igemm(a, taps, nullptr, &nmb) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
+  return nmb;
+}
+
+int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream) {
+  ARCO_CHECK_ARG(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9 || taps == 27) && (mode == 0 || mode == 1));
+  const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+  const int Npad = (N + 15) / 16 * 16, Kpad = (K + 15) / 16 * 16;
+  const long tot = (long)taps * Npad * Kpad;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), W, Cout, Cin, taps,
+                     mode, Npad, Kpad, Wp);
+  return arco_launch_status();
+}
+
+// out[pix][0..N) = conv(in)[pix] (+bias) (+residual); channels-last; taps in {1, 9}
+int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                  const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                  int NB, int H, int W, void* stream) {
+  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0);
+  IgemmArgs a{};
+  a.A = in; a.lda = ld_in; a.Wp = Wp; a.N = N; a.K = K;
+  a.Npad = (N + 15) / 16 * 16; a.Kpad = (K + 15) / 16 * 16;
+  a.C = out; a.ldc = ld_out; a.bias = bias; a.R = residual; a.ldr = ld_res;
+  a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W;
+  return dispatch_igemm(a, taps, as_stream(stream), nullptr);
+}
+
+long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M) {
+  const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
+  const int CoutPad = (Cout + co_b - 1) / co_b * co_b, CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
+  const long n_tiles = (M + 127) / 128 + 64;   // upper bound incl. ragged 2-D tiles
+  const long yz = (long)(CoutPad / co_b) * (CinPad / ci_b) * taps;
+  long chunks = 2048 / yz; if (chunks < 1) chunks = 1; if (chunks > n_tiles) chunks = n_tiles;
+  return chunks * taps * CoutPad * CinPad;
+}
+
+int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NB,
+                    int H, int W, float* ws, float* dW, int accumulate, void* stream) {
+  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9));
+  WgradArgs a{};
+  a.dZ = dZ; a.ldz = ld_dz; a.Cout = Cout; a.Ain = in; a.lda = ld_in; a.Cin = Cin; a.taps = taps;
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.partial = ws;
+  const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
+  a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
+  a.n_tiles = taps == 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
+  const long yz = (long)(a.CoutPad / co_b) * (a.CinPad / ci_b) * taps;
+  long chunks = 2048 / yz; if (chunks < 1) chunks = 1; if (chunks > a.n_tiles) chunks = a.n_tiles;
+  dim3 grid((unsigned)chunks, a.CoutPad / co_b, (a.CinPad / ci_b) * taps);
+  hipStream_t st = as_stream(stream);
+#define WG(COB, CIB)                                                                              \
+  do {                                                                                            \
+    constexpr int LZ = (COB % 32 == 0) ? COB + 16 : COB, LA = (CIB % 32 == 0) ? CIB + 16 : CIB;   \
+    size_t sh = (size_t)128 * (LZ + LA) * 4; const size_t rd = (size_t)4 * COB * CIB * 4;         \
+    if (sh < rd) sh = rd;                                                                         \
+    auto kern = wgrad_kernel<COB, CIB>;                                                           \
+    if (sh > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, a);                                         \
+  } while (0)
+  if (co_b == 64 && ci_b == 64) WG(64, 64);
+  else if (co_b == 64 && ci_b == 32) WG(64, 32);
+  else if (co_b == 64 && ci_b == 16) WG(64, 16);
+  else if (co_b == 32 && ci_b == 64) WG(32, 64);
+  else if (co_b == 32 && ci_b == 32) WG(32, 32);
+  else if (co_b == 32 && ci_b == 16) WG(32, 16);
+  else if (co_b == 16 && ci_b == 64) WG(16, 64);
+  else if (co_b == 16 && ci_b == 32) WG(16, 32);
+  else WG(16, 16);
+#undef WG
+  const long tot = (long)Cout * Cin * taps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ws, (int)chunks, taps, a.CoutPad,
+                     a.CinPad, Cout, Cin, dW, accumulate);
+  return arco_launch_status();
+}
+
+// out[c] (+)= sum over pixels of X[pix][c];  ws holds 256*C floats
+int arco_colsum(const float* X, long ldx, long M, int C, float* ws, float* out, int accumulate, void* stream) {
+  ARCO_CHECK_ARG(X && ws && out && M > 0 && C > 0);
+  int nblk = (int)((M + 1023) / 1024); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), X, ldx, M, C, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), ws, nblk, C, out, accumulate);
+  return arco_launch_status();
+}
+
+int arco_transpose2d(const float* x, long ldx, int rows, int cols, float* y, long ldy, void* stream) {
+  ARCO_CHECK_ARG(rows > 0 && cols > 0);
+  hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, as_stream(stream),
+                     x, ldx, rows, cols, y, ldy);
+  return arco_launch_status();
+}
+
+}  // extern "C"

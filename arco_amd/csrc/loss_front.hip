@@ -1,0 +1,513 @@
+// Loss front-end: per-pixel class masks, stable
+// compaction lists, masked prototype means, key gather, FIFO bank append.
+// All HBM-bound byte/integer work: one pixel per lane, coalesced plane reads,
+// wave-ballot histograms, no atomics on the ordering path (stable compaction).
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// (1) mask codes + per-block counts.   Reference: loss_helper_3d.py:341-342,
+// 352-358 (rank of each class in a descending stable sort), :364-401 (masks).
+// Inputs are NC[spatial] planes exactly as the reference receives them.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_codes_kernel(
+    const int64_t* __restrict__ lab_l, const int64_t* __restrict__ lab_u,
+    const float* __restrict__ prob_l, const float* __restrict__ prob_u,
+    const float* __restrict__ low_mask, const float* __restrict__ high_mask,
+    int n_l_img, int C, long P, long n_pix, float delta_p, float delta_n, int low_rank, int high_rank,
+    uint64_t* __restrict__ codes, uint32_t* __restrict__ block_counts, int nblocks) {
+  const long gp = (long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint64_t code = 0;
+  if (gp < n_pix) {
+    const long img = gp / P, s = gp - img * P;
+    const bool labeled = img < n_l_img;
+    const int64_t* lab = labeled ? lab_l + (img * C) * P + s : lab_u + ((img - n_l_img) * C) * P + s;
+    const float* prob = labeled ? prob_l + (img * C) * P + s : prob_u + ((img - n_l_img) * C) * P + s;
+    const float lowm = low_mask[gp], highm = high_mask[gp];
+    float p[ARCO_MAXC];
+    int64_t lb[ARCO_MAXC];
+#pragma unroll
+    for (int c = 0; c < ARCO_MAXC; ++c) {
+      p[c] = c < C ? prob[(long)c * P] : 0.f;
+      lb[c] = c < C ? lab[(long)c * P] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < ARCO_MAXC; ++c) {
+      if (c < C) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < ARCO_MAXC; ++j)
+          if (j < C) rank += (p[j] > p[c]) || (p[j] == p[c] && j < c);
+        const float labf = (float)lb[c];
+        const bool lv = (labf * lowm) != 0.f;
+        const bool hv = (labf * highm) != 0.f;
+        const bool anchor = (p[c] > delta_p) && lv;
+        const bool hard = (p[c] < delta_n) && hv;
+        const bool cls = labeled ? (rank < low_rank && lb[c] == 0) : (rank >= low_rank && rank < high_rank);
+        const bool neg = hard && cls;
+        code |= (uint64_t)lv << ARCO_BIT_LV(c);
+        code |= (uint64_t)anchor << ARCO_BIT_ANCHOR(c);
+        code |= (uint64_t)neg << ARCO_BIT_NEG(c);
+      }
+    }
+    codes[gp] = code;
+  }
+  __shared__ uint32_t cnt[3 * ARCO_MAXC];
+  if (threadIdx.x < 3 * ARCO_MAXC) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int c = 0; c < C; ++c) {
+    const uint64_t b0 = __ballot((code >> ARCO_BIT_LV(c)) & 1);
+    const uint64_t b1 = __ballot((code >> ARCO_BIT_ANCHOR(c)) & 1);
+    const uint64_t b2 = __ballot((code >> ARCO_BIT_NEG(c)) & 1);
+    if (lane == 0) {
+      atomicAdd(&cnt[c], (uint32_t)__popcll(b0));
+      atomicAdd(&cnt[ARCO_MAXC + c], (uint32_t)__popcll(b1));
+      atomicAdd(&cnt[2 * ARCO_MAXC + c], (uint32_t)__popcll(b2));
+    }
+  }
+  __syncthreads();
+  (void)wid;
+  if (threadIdx.x < 3 * C) {
+    const int kind = threadIdx.x / C, c = threadIdx.x % C;
+    block_counts[(long)(kind * C + c) * nblocks + blockIdx.x] = cnt[kind * ARCO_MAXC + c];
+  }
+}
+
+// (2) exclusive scan of each counter column; one block per (kind, class).
+__global__ __launch_bounds__(256) void scan_counts_kernel(const uint32_t* __restrict__ counts, int nblocks,
+                                                         uint32_t* __restrict__ offsets, int64_t* __restrict__ totals) {
+  const uint32_t* col = counts + (long)blockIdx.x * nblocks;
+  uint32_t* out = offsets + (long)blockIdx.x * nblocks;
+  const int per = (nblocks + 255) / 256;
+  const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
+  uint32_t s = 0;
+  for (int i = b0; i < b1; ++i) s += col[i];
+  __shared__ uint32_t part[256];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 256; ++i) { uint32_t t = part[i]; part[i] = run; run += t; }
+    totals[blockIdx.x] = run;
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (int i = b0; i < b1; ++i) { out[i] = run; run += col[i]; }
+}
+
+// (3) stable compaction: row ids of anchor / negative pixels per class, in
+// (b, spatial) row-major order == torch boolean-mask order (loss_helper_3d.py:377,403).
+__global__ __launch_bounds__(256) void compact_rows_kernel(const uint64_t* __restrict__ codes, long n_pix, int C,
+                                                          const uint32_t* __restrict__ offsets, int nblocks,
+                                                          int32_t* __restrict__ lists /*[2C][n_pix]*/) {
+  const long gp = (long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint64_t code = gp < n_pix ? codes[gp] : 0;
+  __shared__ uint32_t wcnt[4][2 * ARCO_MAXC];
+  for (int c = 0; c < C; ++c) {
+    const uint64_t b1 = __ballot((code >> ARCO_BIT_ANCHOR(c)) & 1);
+    const uint64_t b2 = __ballot((code >> ARCO_BIT_NEG(c)) & 1);
+    if (lane == 0) { wcnt[wid][c] = __popcll(b1); wcnt[wid][ARCO_MAXC + c] = __popcll(b2); }
+  }
+  __syncthreads();
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int c = 0; c < C; ++c) {
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      const int bit = kind == 0 ? ARCO_BIT_ANCHOR(c) : ARCO_BIT_NEG(c);
+      const bool on = (code >> bit) & 1;
+      const uint64_t b = __ballot(on);
+      if (on) {
+        uint32_t base = offsets[(long)((kind + 1) * C + c) * nblocks + blockIdx.x];
+        for (int w = 0; w < wid; ++w) base += wcnt[w][kind * ARCO_MAXC + c];
+        lists[(long)(kind * C + c) * n_pix + base + __popcll(b & lt)] = (int32_t)gp;
+      }
+    }
+  }
+}
+
+// (4) prototype partial sums: sum over low-valid pixels of teacher rows
+// (loss_helper_3d.py:380-384).  Rows are channels-last [n_pix][ldt]; LPR lanes
+// cover one row with float4 loads, 64/LPR rows per wave step.  Deterministic:
+// per-block slabs, fixed-order finalize.
+template <int NDI>
+__global__ __launch_bounds__(256) void masked_row_sum_kernel(const float* __restrict__ T, long ldt,
+                                                            const uint64_t* __restrict__ codes, long n_pix, int D,
+                                                            int c0, int nc, int lpr, long rows_per_block,
+                                                            float* __restrict__ partial /*[grid][nc][D]*/) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][8][D]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rpw = 64 / lpr, sub = lane / lpr, dl = lane % lpr;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(n_pix, r0 + rows_per_block);
+  f32x4 acc[8][NDI];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < NDI; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+  const uint32_t cmask = (1u << nc) - 1u;
+  for (long base = r0 + (long)wid * rpw; base < r1; base += 4 * rpw) {
+    const long row = base + sub;
+    uint32_t bits = 0;
+    if (row < r1) bits = (uint32_t)(codes[row] >> c0) & cmask;
+    if (bits) {
+      const float* src = T + row * ldt;
+#pragma unroll
+      for (int di = 0; di < NDI; ++di) {
+        const int d = (di * lpr + dl) * 4;
+        if (d < D) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + d);
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc)
+            if ((bits >> cc) & 1) acc[cc][di] += v;
+        }
+      }
+    }
+  }
+  // reduce the 64/lpr row-subgroups of the wave
+  for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+      for (int di = 0; di < NDI; ++di)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[cc][di][e] += __shfl_xor(acc[cc][di][e], o, 64);
+  }
+  if (sub == 0) {
+    for (int cc = 0; cc < nc; ++cc)
+#pragma unroll
+      for (int di = 0; di < NDI; ++di) {
+        const int d = (di * lpr + dl) * 4;
+        if (d < D) *reinterpret_cast<f32x4*>(&red[((long)wid * 8 + cc) * D + d]) = acc[cc][di];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc * D; i += 256) {
+    const int cc = i / D, d = i % D;
+    const float s = ((red[(0 * 8 + cc) * (long)D + d] + red[(1 * 8 + cc) * (long)D + d]) +
+                     (red[(2 * 8 + cc) * (long)D + d] + red[(3 * 8 + cc) * (long)D + d]));
+    partial[((long)blockIdx.x * nc + cc) * D + d] = s;
+  }
+}
+
+__global__ void proto_finalize_kernel(const float* __restrict__ partial, int nblk, int nc, int D, int c0,
+                                      const int64_t* __restrict__ totals /*[3C], lv counts first*/,
+                                      float* __restrict__ proto /*[C][D]*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc * D) return;
+  const int cc = i / D, d = i % D;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[((long)b * nc + cc) * D + d];
+  const double n = (double)totals[c0 + cc];
+  proto[(long)(c0 + cc) * D + d] = (float)(s / n);  // 0/0 -> NaN like torch.mean of an empty set
+}
+
+// (5) row gather: out[j] = src[list ? list[idx[j]] : idx[j]]   (rows of D floats)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, long lds_, int D,
+                                                         const int32_t* __restrict__ list,
+                                                         const int64_t* __restrict__ idx64,
+                                                         const int32_t* __restrict__ idx32, long first, long n,
+                                                         float* __restrict__ out, long ldo) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  long r = idx64 ? idx64[first + j] : (idx32 ? (long)idx32[first + j] : first + j);
+  if (list) r = list[r];
+  const float* s = src + r * lds_;
+  float* o = out + j * ldo;
+  if ((D & 3) == 0) {
+    for (int d = lane * 4; d < D; d += 256) *reinterpret_cast<f32x4*>(o + d) = *reinterpret_cast<const f32x4*>(s + d);
+  } else {
+    for (int d = lane; d < D; d += 64) o[d] = s[d];
+  }
+}
+
+// (6) FIFO-by-truncation bank append (loss_helper_3d.py:23-28):
+// out = cat(old, keys)[-min(len_old+n, Q):]
+__global__ void bank_append_kernel(const float* __restrict__ old, long len_old, const float* __restrict__ keys,
+                                   long n, long drop, long out_len, int D, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tot = out_len * D;
+  if (i >= tot) return;
+  const long j = i / D, d = i - j * D;
+  const long srcj = j + drop;
+  out[i] = srcj < len_old ? old[srcj * D + d] : keys[(srcj - len_old) * D + d];
+}
+
+// ---------------------------------------------------------------------------
+// InfoNCE pieces (L6, loss_helper_3d.py:503-509)
+// ---------------------------------------------------------------------------
+// normalized copy: y = x / max(||x||, eps); optional transposed copy yt[D][n]; inv norm out
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, long ldx, long n, int D,
+                                                            float eps, float* __restrict__ y, long ldy,
+                                                            float* __restrict__ yt, long ldyt,
+                                                            float* __restrict__ inv) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const float* s = x + j * ldx;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = s[d]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  const float iv = 1.0f / fmaxf(nrm, eps);
+  if (lane == 0 && inv) inv[j] = iv;
+  for (int d = lane; d < D; d += 64) {
+    const float v = s[d] * iv;
+    if (y) y[j * ldy + d] = v;
+    if (yt) yt[(long)d * ldyt + j] = v;
+  }
+}
+
+// multiplicity matrix M[q][k] += 1 for every sampled negative (exact integer atomics)
+__global__ void neg_multiplicity_kernel(const int64_t* __restrict__ idx, int Q, int Nn, long L, long ld,
+                                        uint32_t* __restrict__ M) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Q * Nn) return;
+  const long q = i / Nn;
+  long k = idx[i];
+  if (k < 0) k += L;
+  atomicAdd(&M[q * ld + k], 1u);
+}
+
+// forward + weight matrix: one block per query.
+//   lse_q = log( exp(pos/T) + sum_k M[q,k] exp(S[q,k]/T) ),  loss_q = lse_q - pos/T
+//   W[q,k] = M[q,k] * exp(S[q,k]/T - lse_q) / T            (d loss_q / d S[q,k])
+//   gpos[q] = (exp(pos/T - lse_q) - 1) / T                   (d loss_q / d pos)
+__global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restrict__ S, long lds_,
+                                                         const uint32_t* __restrict__ M, long L,
+                                                         const float* __restrict__ An, const float* __restrict__ Pn_,
+                                                         long ldp, int D, float inv_temp, float* __restrict__ W,
+                                                         float* __restrict__ gpos, float* __restrict__ loss_q) {
+  const int q = blockIdx.x;
+  const float* s = S + (long)q * lds_;
+  const uint32_t* m = M + (long)q * lds_;
+  const float* Pn = Pn_ + (long)q * ldp;
+  __shared__ float sh[8];
+  // positive logit = <An[q], Pn>
+  float dp = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) dp += An[(long)q * D + d] * Pn[d];
+  dp = wave_sum(dp);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dp;
+  __syncthreads();
+  const float pos = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  float mx = pos * inv_temp;
+  for (long k = threadIdx.x; k < L; k += 256)
+    if (m[k]) mx = fmaxf(mx, s[k] * inv_temp);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  double se = 0.0;
+  for (long k = threadIdx.x; k < L; k += 256) {
+    const uint32_t mk = m[k];
+    if (mk) se += (double)mk * (double)expf(s[k] * inv_temp - mx);
+  }
+  se = wave_sum_d(se);
+  __shared__ double shd[4];
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = se;
+  __syncthreads();
+  const double tot = ((shd[0] + shd[1]) + (shd[2] + shd[3])) + (double)expf(pos * inv_temp - mx);
+  const float lse = mx + (float)log(tot);
+  if (threadIdx.x == 0) {
+    loss_q[q] = lse - pos * inv_temp;
+    gpos[q] = (expf(pos * inv_temp - lse) - 1.0f) * inv_temp;
+  }
+  for (long k = threadIdx.x; k < L; k += 256) {
+    const uint32_t mk = m[k];
+    W[(long)q * lds_ + k] = mk ? (float)mk * expf(s[k] * inv_temp - lse) * inv_temp : 0.f;
+  }
+}
+
+// anchor gradient through the normalisation:  dAhat = G + gpos*Pn ;
+// dA = inv*(dAhat - Ahat*(Ahat.dAhat)) if ||A||>eps else dAhat/eps ; scaled by `scale`
+__global__ __launch_bounds__(256) void infonce_anchor_grad_kernel(const float* __restrict__ G, const float* __restrict__ An,
+                                                                 const float* __restrict__ Pn_, long ldp,
+                                                                 const float* __restrict__ gpos,
+                                                                 const float* __restrict__ inv, int Q, int D, float eps,
+                                                                 float scale, float* __restrict__ dA) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  const float* Pn = Pn_ + (long)q * ldp;
+  const float gp = gpos[q], iv = inv[q];
+  float dot = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float g = G[(long)q * D + d] + gp * Pn[d];
+    dot += g * An[(long)q * D + d];
+  }
+  dot = wave_sum(dot);
+  const bool clamped = iv >= 1.0f / eps;   // ||A|| <= eps : y = A/eps, no norm term
+  for (int d = lane; d < D; d += 64) {
+    const float g = G[(long)q * D + d] + gp * Pn[d];
+    const float v = clamped ? g * iv : iv * (g - An[(long)q * D + d] * dot);
+    dA[(long)q * D + d] = v * scale;
+  }
+}
+
+// dst[rows[j]] += alpha * src[j]   (anchor gradient scatter; duplicates add)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, long lds_, int D,
+                                                              const int32_t* __restrict__ list,
+                                                              const int64_t* __restrict__ idx, long n,
+                                                              const float* __restrict__ alpha_dev, float alpha,
+                                                              float* __restrict__ dst, long ldd) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  long r = idx[j];
+  if (list) r = list[r];
+  const float a = alpha_dev ? alpha * alpha_dev[0] : alpha;
+  for (int d = lane; d < D; d += 64) atomicAdd(&dst[r * ldd + d], a * src[j * lds_ + d]);
+}
+
+__global__ void sum_scale_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out, int accumulate) {
+  // single block deterministic sum
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)x[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) * (double)scale);
+    out[0] = accumulate ? out[0] + v : v;
+  }
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int arco_mask_codes(const int64_t* lab_l, const int64_t* lab_u, const float* prob_l, const float* prob_u,
+                    const float* low_mask, const float* high_mask, int n_l_img, int n_u_img, int C, long P,
+                    float delta_p, float delta_n, int low_rank, int high_rank, uint64_t* codes,
+                    uint32_t* block_counts, uint32_t* block_offsets, int64_t* totals, void* stream) {
+  ARCO_CHECK_ARG(C >= 1 && C <= ARCO_MAXC && P > 0 && n_l_img >= 0 && n_u_img >= 0);
+  const long n_pix = (long)(n_l_img + n_u_img) * P;
+  ARCO_CHECK_ARG(n_pix > 0 && n_pix < (1l << 31));
+  const int nblocks = (int)((n_pix + 255) / 256);
+  hipLaunchKernelGGL(mask_codes_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), lab_l, lab_u, prob_l, prob_u,
+                     low_mask, high_mask, n_l_img, C, P, n_pix, delta_p, delta_n, low_rank, high_rank, codes,
+                     block_counts, nblocks);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(3 * C), dim3(256), 0, as_stream(stream), block_counts, nblocks,
+                     block_offsets, totals);
+  return arco_launch_status();
+}
+
+int arco_compact_rows(const uint64_t* codes, long n_pix, int C, const uint32_t* block_offsets, int32_t* lists,
+                      void* stream) {
+  ARCO_CHECK_ARG(C >= 1 && C <= ARCO_MAXC && n_pix > 0);
+  const int nblocks = (int)((n_pix + 255) / 256);
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), codes, n_pix, C,
+                     block_offsets, nblocks, lists);
+  return arco_launch_status();
+}
+
+// workspace: partial must hold arco_proto_ws_floats(...) floats
+long arco_proto_ws_floats(long n_pix, int C, int D) {
+  long grid = (n_pix + 2047) / 2048;
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  const int nc = C < 8 ? C : 8;
+  return grid * nc * D;
+}
+
+int arco_masked_proto(const float* T, long ldt, const uint64_t* codes, long n_pix, int C, int D,
+                      const int64_t* totals, float* partial, float* proto, void* stream) {
+  ARCO_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 512 && (ldt & 3) == 0 && C <= ARCO_MAXC);
+  long grid = (n_pix + 2047) / 2048;
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  long rpb = (n_pix + grid - 1) / grid;
+  int lpr = 1;
+  while (lpr * 4 < D && lpr < 64) lpr <<= 1;
+  const int ndi = (D + lpr * 4 - 1) / (lpr * 4);
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    const int nc = (C - c0) < 8 ? (C - c0) : 8;
+    const size_t sh = (size_t)4 * 8 * D * sizeof(float);
+    if (ndi == 1)
+      hipLaunchKernelGGL(masked_row_sum_kernel<1>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, codes, n_pix,
+                         D, c0, nc, lpr, rpb, partial);
+    else if (ndi == 2)
+      hipLaunchKernelGGL(masked_row_sum_kernel<2>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, codes, n_pix,
+                         D, c0, nc, lpr, rpb, partial);
+    else
+      hipLaunchKernelGGL(masked_row_sum_kernel<4>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, codes, n_pix,
+                         D, c0, nc, lpr, rpb, partial);
+    hipLaunchKernelGGL(proto_finalize_kernel, dim3((nc * D + 255) / 256), dim3(256), 0, as_stream(stream), partial,
+                       (int)grid, nc, D, c0, totals, proto);
+  }
+  return arco_launch_status();
+}
+
+int arco_gather_rows(const float* src, long ld_src, int D, const int32_t* list, const int64_t* idx64,
+                     const int32_t* idx32, long first, long n, float* out, long ld_out, void* stream) {
+  ARCO_CHECK_ARG(D > 0 && n >= 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), src, ld_src, D, list,
+                     idx64, idx32, first, n, out, ld_out);
+  return arco_launch_status();
+}
+
+int arco_bank_append(const float* old, long len_old, const float* keys, long n, long queue_size, int D, float* out,
+                     void* stream) {
+  ARCO_CHECK_ARG(len_old >= 0 && n >= 0 && queue_size > 0 && D > 0);
+  const long tot = len_old + n;
+  const long out_len = tot >= queue_size ? queue_size : tot;
+  const long drop = tot - out_len;
+  if (out_len == 0) return ARCO_OK;
+  const long work = out_len * D;
+  hipLaunchKernelGGL(bank_append_kernel, dim3((work + 255) / 256), dim3(256), 0, as_stream(stream), old, len_old, keys,
+                     n, drop, out_len, D, out);
+  return arco_launch_status();
+}
+
+int arco_normalize_rows(const float* x, long ldx, long n, int D, float eps, float* y, long ldy, float* yt, long ldyt,
+                        float* inv, void* stream) {
+  ARCO_CHECK_ARG(n >= 0 && D > 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), x, ldx, n, D, eps, y,
+                     ldy, yt, ldyt, inv);
+  return arco_launch_status();
+}
+
+int arco_neg_multiplicity(const int64_t* idx, int Q, int Nn, long L, long ld, uint32_t* M, void* stream) {
+  ARCO_CHECK_ARG(Q > 0 && Nn > 0 && L > 0 && ld >= L);
+  (void)hipMemsetAsync(M, 0, (size_t)Q * ld * sizeof(uint32_t), as_stream(stream));
+  const long n = (long)Q * Nn;
+  hipLaunchKernelGGL(neg_multiplicity_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), idx, Q, Nn, L, ld, M);
+  return arco_launch_status();
+}
+
+// S, M, W share the row stride `ld` (>= L); An/Pn rows have D (padded) floats; ldp = 0 for a shared positive
+int arco_infonce_fwd(const float* S, long ld, const uint32_t* M, long L, const float* An, const float* Pn, long ldp,
+                     int Q, int D, float temp, float* W, float* gpos, float* loss_q, void* stream) {
+  ARCO_CHECK_ARG(Q > 0 && L > 0 && temp > 0.f && ld >= L);
+  hipLaunchKernelGGL(infonce_fwd_kernel, dim3(Q), dim3(256), 0, as_stream(stream), S, ld, M, L, An, Pn, ldp, D,
+                     1.0f / temp, W, gpos, loss_q);
+  return arco_launch_status();
+}
+
+int arco_infonce_anchor_grad(const float* G, const float* An, const float* Pn, long ldp, const float* gpos,
+                             const float* inv, int Q, int D, float eps, float scale, float* dA, void* stream) {
+  hipLaunchKernelGGL(infonce_anchor_grad_kernel, dim3((Q + 3) / 4), dim3(256), 0, as_stream(stream), G, An, Pn, ldp, gpos,
+                     inv, Q, D, eps, scale, dA);
+  return arco_launch_status();
+}
+
+int arco_scatter_add_rows(const float* src, long ld_src, int D, const int32_t* list, const int64_t* idx, long n,
+                          const float* alpha_dev, float alpha, float* dst, long ld_dst, void* stream) {
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), src, ld_src, D, list, idx, n,
+                     alpha_dev, alpha, dst, ld_dst);
+  return arco_launch_status();
+}
+
+int arco_sum_scale(const float* x, int n, float scale, float* out, int accumulate, void* stream) {
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, n, scale, out, accumulate);
+  return arco_launch_status();
+}
+
+}  // extern "C"

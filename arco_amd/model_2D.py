@@ -1,0 +1,119 @@
+"""Drop-in for the reference's code/model_2D.py on MI355X: FeatureExtractor (:20-55),
+create_model (:57-64), ISD (:115-198).  Same names, constructor arguments, attribute names
+(.model, .ema_model, ._momentum_update_key_encoder(), .data_parallel()) and state_dict keys.
+
+FeatureExtractor is five bias-free 1x1 convolutions = fp32 MFMA GEMMs over channels-last
+pixels with the residual add fused in the GEMM epilogue, chained by align_corners bilinear
+resizes.  The MoCo-style heads ISD owns (latent/outputs heads, predictors, queues) are only
+used by stage-1 pre-training; they are kept as parameter containers because
+_momentum_update_key_encoder (model_2D.py:176-182) EMA-updates them every step.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops, optim
+from .networks.net_factory_args import net_factory
+
+
+class FeatureExtractor(nn.Module):
+    def __init__(self, fea_dim=[256, 128, 64, 32, 16], output_dim=256) -> None:
+        super().__init__()
+        assert len(fea_dim) == 5, 'input_dim is not correct'
+        cnt = fea_dim[0]
+        self.fea0 = nn.Conv2d(in_channels=cnt, out_channels=cnt, kernel_size=1, bias=False)
+        cnt += fea_dim[1]
+        self.fea1 = nn.Conv2d(in_channels=cnt, out_channels=cnt, kernel_size=1, bias=False)
+        cnt += fea_dim[2]
+        self.fea2 = nn.Conv2d(in_channels=cnt, out_channels=cnt, kernel_size=1, bias=False)
+        cnt += fea_dim[3]
+        self.fea3 = nn.Conv2d(in_channels=cnt, out_channels=cnt, kernel_size=1, bias=False)
+        cnt += fea_dim[4]
+        self.fea4 = nn.Conv2d(in_channels=cnt, out_channels=output_dim, kernel_size=1, bias=False)
+
+    def forward(self, fea_list):
+        f = [ops.to_channels_last(t) for t in fea_list]
+        x = ops.conv(f[0], self.fea0.weight, None, residual=True)          # fea0(f0) + f0
+        for i, fea in enumerate((self.fea1, self.fea2, self.fea3, self.fea4), start=1):
+            x = ops.bilinear(x, f[i].shape[-2:])
+            x = torch.cat((x, f[i]), dim=1)
+            x = ops.conv(x, fea.weight, None, residual=(i < 4))            # fea_i(x) + x ; fea4(x)
+        return x
+
+
+def create_model(ema=False, num_classes=4, train_encoder=True, train_decoder=True):
+    model = net_factory(net_type='unet', in_chns=1, class_num=num_classes, train_encoder=train_encoder,
+                        train_decoder=train_decoder)
+    if ema:
+        for param in model.parameters():
+            param.detach_()
+    return model
+
+
+class ProjectionHead(nn.Module):
+    def __init__(self, dim_in=4, proj_dim=4, output_pooling_size=16, proj='convmlp'):
+        super(ProjectionHead, self).__init__()
+        if proj == 'linear':
+            self.proj = nn.Conv2d(dim_in, proj_dim, kernel_size=1)
+        elif proj == 'convmlp':
+            self.proj = nn.Sequential(nn.AdaptiveAvgPool2d(output_pooling_size),
+                                      nn.Conv2d(dim_in, dim_in * 2, kernel_size=1),
+                                      nn.Conv2d(dim_in * 2, proj_dim, kernel_size=1))
+
+
+class MLP(nn.Module):
+    def __init__(self, input_channels=256, num_class=128, pooling_size=1):
+        super().__init__()
+        self.gap = nn.AdaptiveAvgPool2d(pooling_size)
+        self.f1 = nn.Linear(input_channels * pooling_size ** 2, input_channels)
+        self.f2 = nn.Linear(input_channels, num_class)
+
+
+class ISD(nn.Module):
+    def __init__(self, K=48, m=0.99, Ts=0.1, Tt=0.01, num_classes=4, train_encoder=True, train_decoder=True,
+                 latent_pooling_size=1, latent_feature_size=256, output_pooling_size=16, patch_size=64):
+        super(ISD, self).__init__()
+        self.K, self.m, self.Ts, self.Tt = K, m, Ts, Tt
+        self.num_classes = num_classes
+        self.patch_size = patch_size
+        self.latent_feature_size = latent_feature_size
+        self.model = create_model(num_classes=num_classes, train_encoder=train_encoder, train_decoder=train_decoder)
+        self.ema_model = create_model(ema=True, num_classes=num_classes, train_encoder=False, train_decoder=False)
+        self.k_latent_head = MLP(256, self.latent_feature_size, latent_pooling_size)
+        self.q_latent_head = MLP(256, self.latent_feature_size, latent_pooling_size)
+        self.latent_predictor = nn.Sequential(nn.Linear(self.latent_feature_size, self.latent_feature_size),
+                                              nn.Linear(self.latent_feature_size, self.latent_feature_size))
+        self.k_outputs_head = ProjectionHead(num_classes, num_classes, output_pooling_size)
+        self.q_outputs_head = ProjectionHead(num_classes, num_classes, output_pooling_size)
+        self.outputs_predictor = nn.Sequential(nn.Conv2d(num_classes, num_classes, kernel_size=1),
+                                               nn.Conv2d(num_classes, num_classes, kernel_size=1))
+        for param_q, param_k in zip(self.model.parameters(), self.ema_model.parameters()):
+            param_k.data.copy_(param_q.data)
+            param_k.requires_grad = False
+        self.register_buffer('queue', nn.functional.normalize(torch.randn(self.K, self.latent_feature_size), dim=0))
+        self.register_buffer('queue_mask', nn.functional.normalize(
+            torch.randn(self.K, 49, num_classes * output_pooling_size ** 2), dim=0))
+        self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.long))
+        self.register_buffer('mask_queue_ptr', torch.zeros(1, dtype=torch.long))
+        self._ema_pairs = None
+
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        """k = m*k + (1-m)*q over parameters() only (BN buffers untouched), model_2D.py:176-182.
+        One fused kernel per (student, teacher) module pair on flat parameter buffers."""
+        if self._ema_pairs is None:
+            self._ema_pairs = [optim.EmaPair(q, k) for q, k in (
+                (self._unwrap(self.model), self._unwrap(self.ema_model)),
+                (self._unwrap(self.q_outputs_head), self._unwrap(self.k_outputs_head)),
+                (self._unwrap(self.q_latent_head), self._unwrap(self.k_latent_head)))]
+        for pair in self._ema_pairs:
+            pair.update(self.m)
+
+    @staticmethod
+    def _unwrap(m):
+        return m.module if hasattr(m, "module") else m
+
+    @torch.no_grad()
+    def data_parallel(self):
+        """The reference wraps sub-modules in nn.DataParallel (model_2D.py:188-198).  On MI355X
+        scaling is one process per GPU over RCCL (arco_amd.dist); inside one process this is a no-op."""
+        return self

@@ -1,0 +1,174 @@
+"""2-D U-Net of the ARCO hot path on MI355X - drop-in for the reference's
+code/networks/unetWithArgs.py (ConvBlock :31-47, DownBlock :50-61, UpBlock :64-85,
+Encoder :88-116, Decoder :119-158, UNet :309-348).
+
+Same class names, constructor arguments, return values and state_dict keys/shapes
+(the nn.Conv2d / nn.BatchNorm2d children are kept as parameter containers so that
+initialisation and checkpoints are identical); the forward pass never calls them -
+it runs the hand-written HIP kernels of arco_amd.ops on channels-last activations:
+conv3x3 (fp32 MFMA implicit GEMM, BN partial statistics fused in the epilogue) ->
+BN finalize -> one fused BN-apply + LeakyReLU + dropout pass.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def _bn_eval_stats(bn):
+    return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+
+
+def _stage(x, conv, bn, act, drop_p, training, drop_mode=1):
+    slope = getattr(act, "negative_slope", 0.0)
+    if training:
+        y = ops.conv_bn_act(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            slope=slope, p=drop_p, drop_mode=drop_mode, momentum=bn.momentum, eps=bn.eps)
+        bn.num_batches_tracked += 1
+        return y
+    return ops.conv_bn_act_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                slope=slope, eps=bn.eps)
+
+
+class ConvBlock(nn.Module):
+    """two convolution layers with batch norm and leaky relu (unetWithArgs.py:31-47)"""
+
+    def __init__(self, in_channels, out_channels, dropout_p):
+        super(ConvBlock, self).__init__()
+        self.conv_conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1),
+            nn.BatchNorm2d(out_channels),
+            nn.LeakyReLU(),
+            nn.Dropout(dropout_p),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1),
+            nn.BatchNorm2d(out_channels),
+            nn.LeakyReLU(),
+        )
+
+    def forward(self, x):
+        s = self.conv_conv
+        x = _stage(x, s[0], s[1], s[2], s[3].p, self.training)
+        return _stage(x, s[4], s[5], s[6], 0.0, self.training)
+
+
+class DownBlock(nn.Module):
+    """Downsampling followed by ConvBlock (unetWithArgs.py:50-61)"""
+
+    def __init__(self, in_channels, out_channels, dropout_p):
+        super(DownBlock, self).__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), ConvBlock(in_channels, out_channels, dropout_p))
+
+    def forward(self, x):
+        return self.maxpool_conv[1](ops.maxpool2(x))
+
+
+class UpBlock(nn.Module):
+    """Upsampling followed by ConvBlock (unetWithArgs.py:64-85).  The reference Decoder never
+    passes `bilinear`, so the default bilinear=True path (1x1 conv + x2 align_corners bilinear) is the
+    one on the hot path; the ConvTranspose2d branch is unreachable from UNet and not provided."""
+
+    def __init__(self, in_channels1, in_channels2, out_channels, dropout_p, bilinear=True):
+        super(UpBlock, self).__init__()
+        self.bilinear = bilinear
+        if not bilinear:
+            raise NotImplementedError("UpBlock(bilinear=False) is not on the ARCO hot path")
+        self.conv1x1 = nn.Conv2d(in_channels1, in_channels2, kernel_size=1)
+        self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        self.conv = ConvBlock(in_channels2 * 2, out_channels, dropout_p)
+
+    def forward(self, x1, x2):
+        x1 = ops.conv(x1, self.conv1x1.weight, self.conv1x1.bias)
+        x1 = ops.bilinear(x1, (x1.shape[2] * 2, x1.shape[3] * 2))
+        x = torch.cat([x2, x1], dim=1)
+        return self.conv(x)
+
+
+class Encoder(nn.Module):
+    def __init__(self, params):
+        super(Encoder, self).__init__()
+        self.params = params
+        self.in_chns = self.params['in_chns']
+        self.ft_chns = self.params['feature_chns']
+        self.n_class = self.params['class_num']
+        self.bilinear = self.params['bilinear']
+        self.dropout = self.params['dropout']
+        assert (len(self.ft_chns) == 5)
+        self.in_conv = ConvBlock(self.in_chns, self.ft_chns[0], self.dropout[0])
+        self.down1 = DownBlock(self.ft_chns[0], self.ft_chns[1], self.dropout[1])
+        self.down2 = DownBlock(self.ft_chns[1], self.ft_chns[2], self.dropout[2])
+        self.down3 = DownBlock(self.ft_chns[2], self.ft_chns[3], self.dropout[3])
+        self.down4 = DownBlock(self.ft_chns[3], self.ft_chns[4], self.dropout[4])
+
+    def forward(self, x):
+        x = ops.to_channels_last(x.to(torch.float32))
+        x0 = self.in_conv(x)
+        x1 = self.down1(x0)
+        x2 = self.down2(x1)
+        x3 = self.down3(x2)
+        x4 = self.down4(x3)
+        return [x0, x1, x2, x3, x4]
+
+
+class Decoder(nn.Module):
+    def __init__(self, params):
+        super(Decoder, self).__init__()
+        self.params = params
+        self.in_chns = self.params['in_chns']
+        self.ft_chns = self.params['feature_chns']
+        self.n_class = self.params['class_num']
+        self.bilinear = self.params['bilinear']
+        assert (len(self.ft_chns) == 5)
+        self.up1 = UpBlock(self.ft_chns[4], self.ft_chns[3], self.ft_chns[3], dropout_p=0.0)
+        self.up2 = UpBlock(self.ft_chns[3], self.ft_chns[2], self.ft_chns[2], dropout_p=0.0)
+        self.up3 = UpBlock(self.ft_chns[2], self.ft_chns[1], self.ft_chns[1], dropout_p=0.0)
+        self.up4 = UpBlock(self.ft_chns[1], self.ft_chns[0], self.ft_chns[0], dropout_p=0.0)
+        self.out_conv = nn.Conv2d(self.ft_chns[0], self.n_class, kernel_size=3, padding=1)
+
+    def forward(self, feature):
+        x0, x1, x2, x3, x4 = feature
+        feature_map = [x4]
+        x = self.up1(x4, x3)
+        feature_map.append(x)
+        x = self.up2(x, x2)
+        feature_map.append(x)
+        x = self.up3(x, x1)
+        feature_map.append(x)
+        x = self.up4(x, x0)
+        feature_map.append(x)
+        output = ops.conv(x, self.out_conv.weight, self.out_conv.bias)
+        return output, feature_map
+
+
+class UNet(nn.Module):
+    def __init__(self, in_chns, class_num, train_encoder=True, train_decoder=True, unfreeze_seg=True):
+        super(UNet, self).__init__()
+        params = {'in_chns': in_chns,
+                  'feature_chns': [16, 32, 64, 128, 256],
+                  'dropout': [0.05, 0.1, 0.2, 0.3, 0.5],
+                  'class_num': class_num,
+                  'bilinear': False,
+                  'acti_func': 'relu'}
+        self.params = params
+        self.encoder = Encoder(params)
+        self.decoder = Decoder(params)
+        self.train_encoder = train_encoder
+        self.train_decoder = train_decoder
+        if not train_encoder:
+            for p in self.encoder.parameters():
+                p.requires_grad = False
+                p.detach_()
+        if not train_decoder:
+            for p in self.decoder.parameters():
+                p.requires_grad = False
+                p.detach_()
+        if not unfreeze_seg:
+            keep = {id(p) for p in self.decoder.out_conv.parameters()}
+            for p in list(self.encoder.parameters()) + list(self.decoder.parameters()):
+                if id(p) not in keep:
+                    p.requires_grad = False
+                    p.detach_()
+
+    def forward(self, x):
+        feature = self.encoder(x)
+        output, feature_map = self.decoder(feature)
+        return output, feature[-1], feature_map

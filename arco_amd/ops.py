@@ -1,0 +1,253 @@
+"""Autograd operators over the C-ABI HIP kernels (channels-last fp32 activations).
+
+Activations are torch tensors with logical shape [N, C, H, W] and channels-last
+memory (rows of C floats per pixel); a channel slice of such a tensor is consumed
+in place through its row stride.  PyTorch only allocates memory and chains the
+autograd graph - every arithmetic op below is a hand-written gfx950 kernel.
+"""
+import torch
+
+from . import _lib as L
+from ._contrast import rows_view
+
+_drop_gen = None
+
+
+def _next_seed():
+    """Dropout seeds come from a private generator so the torch CPU default generator
+    (which defines the bit-exact sampler sequence) is never touched."""
+    global _drop_gen
+    if _drop_gen is None:
+        _drop_gen = torch.Generator()
+        _drop_gen.manual_seed(torch.initial_seed() ^ 0x5DEECE66D)
+    return int(torch.randint(0, 2 ** 62, (1,), generator=_drop_gen))
+
+
+def reseed_dropout(seed):
+    global _drop_gen
+    _drop_gen = torch.Generator()
+    _drop_gen.manual_seed(seed)
+
+
+def _ceil16(x):
+    return (x + 15) // 16 * 16
+
+
+def new_act(nb, c, h, w, dev):
+    """Fresh channels-last activation, logical [nb, c, h, w]."""
+    return torch.empty((nb, h, w, c), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
+
+
+def _geom(x):
+    nb, c, h, w = x.shape
+    r, ld = rows_view(x)
+    return r, ld, int(nb), int(c), int(h), int(w)
+
+
+def pack_weight(weight, taps, mode):
+    """torch [Cout, Cin, kh, kw] -> Wp[taps][Npad][Kpad]; mode 0 forward, 1 dgrad (flipped+transposed)."""
+    co, ci = int(weight.shape[0]), int(weight.shape[1])
+    w = weight.detach().contiguous()
+    if mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0:
+        return w.view(co, ci)                      # already [N][K]
+    n, k = (co, ci) if mode == 0 else (ci, co)
+    wp = torch.empty((taps, _ceil16(n), _ceil16(k)), dtype=torch.float32, device=w.device)
+    L.call("arco_pack_conv_weight", L.ptr(w), co, ci, taps, mode, L.ptr(wp))
+    return wp
+
+
+def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False):
+    """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out [nb,n,h,w] channels-last, stat slabs or None)."""
+    out = new_act(nb, n, h, w, xr.device)
+    ssum = ssq = None
+    nmb = 0
+    if stats:
+        nmb = L.query("arco_conv_mblocks", taps, nb, h, w, n)
+        ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
+        ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
+    L.call("arco_conv_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
+           L.ptr(ssum), L.ptr(ssq), taps, nb, h, w)
+    return out, (ssum, ssq, nmb)
+
+
+def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like):
+    ws = torch.empty(L.query("arco_wgrad_ws_floats", co, ci, taps, nb * h * w), dtype=torch.float32, device=dzr.device)
+    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    L.call("arco_conv_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, h, w, L.ptr(ws), L.ptr(dw), 0)
+    return dw
+
+
+def colsum(xr, ld, m, c):
+    ws = torch.empty(256 * c, dtype=torch.float32, device=xr.device)
+    out = torch.empty(c, dtype=torch.float32, device=xr.device)
+    L.call("arco_colsum", L.ptr(xr), ld, m, c, L.ptr(ws), L.ptr(out), 0)
+    return out
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv_{1x1|3x3}(x) (+ bias) (+ x when residual).  Reference: nn.Conv2d in
+    unetWithArgs.py:72,139 / model_2D.py:25-33 / train_arco_2d.py:231-234."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        L.require_gpu(x, weight)
+        taps = int(weight.shape[2] * weight.shape[3])
+        xr, ld, nb, ci, h, w = _geom(x)
+        co = int(weight.shape[0])
+        wp = pack_weight(weight, taps, 0)
+        y, _ = conv_raw(xr, ld, ci, wp, co, nb, h, w, taps, bias=bias, residual=xr if residual else None,
+                        ld_res=ld if residual else 0)
+        ctx.save_for_backward(x, weight)
+        ctx.residual, ctx.has_bias, ctx.taps = residual, bias is not None, taps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        taps = ctx.taps
+        dyr, ldy, nb, co, h, w = _geom(dy)
+        xr, ldx, _, ci, _, _ = _geom(x)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wd = pack_weight(weight, taps, 1)
+            dx, _ = conv_raw(dyr, ldy, co, wd, ci, nb, h, w, taps, residual=dyr if ctx.residual else None,
+                             ld_res=ldy if ctx.residual else 0)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nb, h, w, weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dyr, ldy, nb * h * w, co)
+        return dx, dw, db, None
+
+
+class ConvBnActFn(torch.autograd.Function):
+    """a = dropout(lrelu(BN_train(conv3x3(x) + bias))) as conv(+fused BN partial stats) ->
+    finalize -> one apply pass.  Reference: ConvBlock stages, unetWithArgs.py:36-44."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps):
+        L.require_gpu(x, weight)
+        taps = int(weight.shape[2] * weight.shape[3])
+        xr, ld, nb, ci, h, w = _geom(x)
+        co = int(weight.shape[0])
+        m = nb * h * w
+        wp = pack_weight(weight, taps, 0)
+        z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nb, h, w, taps, bias=bias, stats=True)
+        mean = torch.empty(co, dtype=torch.float32, device=x.device)
+        istd = torch.empty(co, dtype=torch.float32, device=x.device)
+        L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
+               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var))
+        seed = _next_seed() if p > 0 else 0
+        a = new_act(nb, co, h, w, x.device)
+        zr, ldz = rows_view(z)
+        L.call("arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
+               float(slope), int(drop_mode), float(p), seed, h * w, L.ptr(a), co)
+        ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta)
+        ctx.cfg = (taps, float(slope), float(p), int(drop_mode), seed, bias is not None)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, weight, z, mean, istd, gamma, beta = ctx.saved_tensors
+        taps, slope, p, drop_mode, seed, has_bias = ctx.cfg
+        dar, ldd, nb, co, h, w = _geom(da)
+        xr, ldx, _, ci, _, _ = _geom(x)
+        zr, ldz = rows_view(z)
+        m = nb * h * w
+        nblk = L.query("arco_chan_stats_blocks", m)
+        ws = torch.empty(2 * co * nblk + 2 * co, dtype=torch.float32, device=da.device)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        dz = new_act(nb, co, h, w, da.device)
+        L.call("arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma),
+               L.ptr(beta), slope, drop_mode, p, seed, h * w, L.ptr(ws), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dz), co)
+        dzr, ldzz = rows_view(dz)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wd = pack_weight(weight, taps, 1)
+            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nb, h, w, taps)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nb, h, w, weight)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dzr, ldzz, m, co)
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2) (unetWithArgs.py:55-58)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xr, ld, nb, c, h, w = _geom(x)
+        y = new_act(nb, c, h // 2, w // 2, x.device)
+        L.call("arco_maxpool2_fwd", L.ptr(xr), ld, nb, h, w, c, L.ptr(y), c)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        xr, ld, nb, c, h, w = _geom(x)
+        dyr, ldy = rows_view(dy)
+        dx = new_act(nb, c, h, w, x.device)
+        L.call("arco_maxpool2_bwd", L.ptr(xr), ld, nb, h, w, c, L.ptr(dyr), ldy, L.ptr(dx), c)
+        return dx
+
+
+class BilinearFn(torch.autograd.Function):
+    """nn.Upsample(size, mode='bilinear', align_corners=True) (model_2D.py:43-52, unetWithArgs.py:74-75)."""
+
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        xr, ld, nb, c, h, w = _geom(x)
+        y = new_act(nb, c, ho, wo, x.device)
+        L.call("arco_bilinear_fwd", L.ptr(xr), ld, nb, h, w, c, ho, wo, L.ptr(y), c)
+        ctx.dims = (nb, c, h, w, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        nb, c, h, w, ho, wo = ctx.dims
+        dyr, ldy = rows_view(dy)
+        dx = new_act(nb, c, h, w, dy.device)
+        L.call("arco_bilinear_bwd", L.ptr(dyr), ldy, nb, h, w, c, ho, wo, L.ptr(dx), c, 0)
+        return dx, None, None
+
+
+def conv(x, weight, bias=None, residual=False):
+    return ConvFn.apply(x, weight, bias, residual)
+
+
+def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, slope=0.01, p=0.0, drop_mode=1,
+                momentum=0.1, eps=1e-5):
+    return ConvBnActFn.apply(x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode,
+                             momentum, eps)
+
+
+def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, slope=0.01, eps=1e-5):
+    """Inference-mode stage (BN uses running statistics); no autograd."""
+    with torch.no_grad():
+        taps = int(weight.shape[2] * weight.shape[3])
+        xr, ld, nb, ci, h, w = _geom(x)
+        co = int(weight.shape[0])
+        z, _ = conv_raw(xr, ld, ci, pack_weight(weight, taps, 0), co, nb, h, w, taps, bias=bias)
+        istd = torch.rsqrt(running_var + eps)
+        a = new_act(nb, co, h, w, x.device)
+        zr, ldz = rows_view(z)
+        L.call("arco_bn_act_fwd", L.ptr(zr), ldz, nb * h * w, co, L.ptr(running_mean), L.ptr(istd), L.ptr(gamma),
+               L.ptr(beta), float(slope), 0, 0.0, 0, h * w, L.ptr(a), co)
+        return a
+
+
+def maxpool2(x):
+    return MaxPool2Fn.apply(x)
+
+
+def bilinear(x, size):
+    return BilinearFn.apply(x, int(size[0]), int(size[1]))
+
+
+def to_channels_last(x):
+    """API-boundary layout conversion (memory plumbing): NCHW-contiguous -> channels-last."""
+    if x.dim() == 4:
+        return x.contiguous(memory_format=torch.channels_last)
+    return x.contiguous(memory_format=torch.channels_last_3d)

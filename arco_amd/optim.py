@@ -1,0 +1,123 @@
+"""Flat-buffer optimiser state for the ARCO step.
+
+Parameters of a module group are re-homed into ONE contiguous fp32 buffer (each
+nn.Parameter becomes a view), gradients likewise, so SGD-Nesterov, EMA and the
+data-parallel gradient all-reduce are each one kernel / one collective.
+"""
+import torch
+
+from . import _lib as L
+
+
+def flatten_params(params):
+    """Move `params` into one flat fp32 buffer; returns the buffer.  p.data become views."""
+    params = list(params)
+    n = sum(p.numel() for p in params)
+    flat = torch.empty(n, dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        k = p.numel()
+        flat[off:off + k].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + k].view(p.shape)
+        off += k
+    return flat
+
+
+class EmaPair:
+    """teacher <- m*teacher + (1-m)*student over parameters() (model_2D.py:176-182,
+    train_arco_2d.py:306-308)."""
+
+    def __init__(self, student, teacher):
+        sp = list(student.parameters()) if hasattr(student, "parameters") else list(student)
+        tp = list(teacher.parameters()) if hasattr(teacher, "parameters") else list(teacher)
+        assert len(sp) == len(tp)
+        self.sp, self.tp = sp, tp
+        self.flat_t = flatten_params(tp)
+        self.flat_s = None
+
+    def _student_flat(self):
+        # the student may already live in an optimiser's flat buffer (contiguous views in order)
+        first = self.sp[0]
+        n = sum(p.numel() for p in self.sp)
+        base = first.data.untyped_storage()
+        contiguous = True
+        off = first.data.storage_offset()
+        for p in self.sp:
+            if p.data.untyped_storage().data_ptr() != base.data_ptr() or p.data.storage_offset() != off \
+                    or not p.data.is_contiguous():
+                contiguous = False
+                break
+            off += p.numel()
+        if contiguous:
+            return first.data.as_strided((n,), (1,), first.data.storage_offset())
+        return None
+
+    @torch.no_grad()
+    def update(self, m):
+        s = self._student_flat()
+        if s is None:
+            s = torch.cat([p.data.reshape(-1) for p in self.sp])
+        L.call("arco_ema", L.ptr(self.flat_t), L.ptr(s), self.flat_t.numel(), float(m))
+
+
+class SGDNesterov:
+    """torch.optim.SGD(params, lr, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    (train_arco_2d.py:248) over flat buffers: parameters, gradients (p.grad are views that
+    autograd accumulates into) and momentum live in three contiguous fp32 arrays, and a step
+    is one kernel per run of consecutive parameters that received a gradient (one launch in
+    steady state).  Parameters without a gradient are skipped, like torch.  `param_groups[0]['lr']`
+    is honoured like the reference's poly-LR loop (train_arco_2d.py:433-435)."""
+
+    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0001, nesterov=True):
+        assert nesterov and momentum > 0
+        self.params = [p for p in params]
+        self.flat_p = flatten_params(self.params)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_buf = torch.zeros_like(self.flat_p)
+        self.offsets = []
+        off = 0
+        for i, p in enumerate(self.params):
+            k = p.numel()
+            self.offsets.append((off, k))
+            p.grad = self.flat_g[off:off + k].view(p.shape)
+            p.register_post_accumulate_grad_hook(self._mark(i))
+            off += k
+        self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay, params=self.params)]
+        self._touched = set()
+        self._started = [False] * len(self.params)
+
+    def _mark(self, i):
+        def hook(_p):
+            self._touched.add(i)
+        return hook
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+        self._touched.clear()
+        for (off, k), p in zip(self.offsets, self.params):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + k].view(p.shape)
+
+    @torch.no_grad()
+    def step(self):
+        g = self.param_groups[0]
+        # fold back gradients autograd may have re-homed
+        for i, ((off, k), p) in enumerate(zip(self.offsets, self.params)):
+            if p.grad is not None and p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                self.flat_g[off:off + k].copy_(p.grad.reshape(-1))
+                self._touched.add(i)
+        runs, cur = [], None
+        for i in sorted(self._touched):
+            first = not self._started[i]
+            if cur is not None and cur[1] == i and cur[2] == first:
+                cur[1] = i + 1
+            else:
+                cur = [i, i + 1, first]
+                runs.append(cur)
+        for a, b, first in runs:
+            off = self.offsets[a][0]
+            n = self.offsets[b - 1][0] + self.offsets[b - 1][1] - off
+            L.call("arco_sgd_nesterov", L.ptr(self.flat_p[off:]), L.ptr(self.flat_g[off:]), L.ptr(self.flat_buf[off:]),
+                   n, float(g['lr']), float(g['momentum']), float(g['weight_decay']), 1 if first else 0)
+            for i in range(a, b):
+                self._started[i] = True

@@ -1,0 +1,91 @@
+"""Host side of the stratified samplers.
+
+Bit-exact sample indices are DEFINED by the torch CPU default generator call sequence
+of the reference (loss_helper_3d.py:35-268), so index generation is host logic by
+construction: these functions issue exactly the same generator calls (randperm per
+block, randint per block, one randperm shuffle, one draw per padded element - a
+vector randint of n draws equals n single draws) but with closed-form block geometry
+instead of materialised index images.  The device consumes the returned indices.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+
+__all__ = ["grid_monte_carlo_sample", "grid_as_monte_carlo_sample", "monte_carlo_sample",
+           "as_monte_carlo_sample"]
+
+
+def _one_dim(high, shape, patch, mirror):
+    # loss_helper_3d.py:35-80 (mirror=True) / :83-117
+    if high // patch > shape or high < patch:
+        return torch.randint(high, size=(shape,))
+    blocks = high // patch
+    per = shape // blocks
+    vals = []
+    for b in range(blocks):
+        lo = b * patch
+        if mirror:
+            half = [random.randint(lo, lo + patch - 1) for _ in range(per // 2)]
+            vals += half
+            vals += [2 * lo + patch - 1 - v for v in half]
+        else:
+            vals += [random.randint(lo, lo + patch - 1) for _ in range(per)]
+    vals += [random.randint(0, high - 1) for _ in range(shape - len(vals))]
+    out = torch.tensor(vals, dtype=torch.float32).long()          # float32 round trip (:74/:111)
+    return out[torch.randperm(shape)]
+
+
+def monte_carlo_sample(high=5233, shape=256, patch=16):
+    return _one_dim(high, shape, patch, False)
+
+
+def as_monte_carlo_sample(high=5233, shape=256, patch=16):
+    return _one_dim(high, shape, patch, True)
+
+
+def _grid(high, shape, cut, mirror):
+    # loss_helper_3d.py:120-184 / :187-268
+    edge = round(math.sqrt(high))
+    side = edge // cut
+    if side <= 1:
+        # first block empty or single element: the reference raises before drawing anything
+        # (randint(0,..) / scalar .shape) and falls back to the 1-D sampler
+        return None
+    per_block = shape * edge * edge // high // (cut * cut)
+    take = per_block // 2 if mirror else per_block
+    last = edge - (cut - 1) * side
+    chunks = []
+    for bi in range(cut):
+        h = last if bi == cut - 1 else side
+        for bj in range(cut):
+            w = last if bj == cut - 1 else side
+            n = h * w
+            perm = torch.randperm(n)
+            local = perm[torch.randint(n, (take,))]
+            val = (bi * side + local // w) * edge + bj * side + local % w
+            chunks.append(val)
+            if mirror:
+                # int64(2*mean(block)) == first + last element of the rectangular block (exact)
+                first = (bi * side) * edge + bj * side
+                final = (bi * side + h - 1) * edge + bj * side + w - 1
+                chunks.append(first + final - val)
+    vals = torch.cat(chunks).to(torch.float32).long()              # :163 / :245-246
+    vals = vals[vals < high]
+    vals = vals[torch.randperm(vals.shape[0])]
+    if vals.shape[0] < shape:
+        vals = torch.cat([vals, torch.randint(high, (shape - vals.shape[0],))])
+    return vals[:shape]
+
+
+@torch.no_grad()
+def grid_monte_carlo_sample(high=5233, shape=256, cut_count=4):
+    out = _grid(high, shape, cut_count, False)
+    return monte_carlo_sample(high, shape) if out is None else out
+
+
+@torch.no_grad()
+def grid_as_monte_carlo_sample(high=5233, shape=256, cut_count=4):
+    out = _grid(high, shape, cut_count, True)
+    return as_monte_carlo_sample(high, shape) if out is None else out

@@ -1,0 +1,80 @@
+"""U-Net / FeatureExtractor on the HIP path vs golden vectors captured from the reference (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import fixture_inputs as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def probe_like(t, seed):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.standard_normal(tuple(t.shape)).astype(np.float32)).cuda()
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b, rtol=rtol, atol=atol)
+
+
+def test_unet_vs_reference_golden(golden):
+    from arco_amd.networks.unetWithArgs import UNet
+    g = golden["g3_nets"]
+    net = UNet(1, 4).cuda()
+    assert len(net.state_dict()) == int(g["unet_n_state_keys"])
+    net.load_state_dict(fx.unet_state(21), strict=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net.train()
+    x = fx.image_batch(5, 2, 1, (32, 32)).cuda().requires_grad_(True)
+    logits, latent, fmap = net(x)
+    close(logits, g["unet_logits"], 1e-3, 1e-4)
+    close(latent, g["unet_latent"], 1e-3, 1e-4)
+    for i, f in enumerate(fmap):
+        close(f, g[f"unet_fmap{i}"], 1e-3, 1e-4)
+    loss = (logits * probe_like(logits, 1)).sum()
+    for i, f in enumerate(fmap):
+        loss = loss + (f * probe_like(f, 10 + i)).sum()
+    loss.backward()
+    close(x.grad, g["unet_dx"], 5e-3, 1e-3)
+    params = dict(net.named_parameters())
+    for n in g.files:
+        if n.startswith("unet_grad::"):
+            ref = g[n]
+            close(params[n.split("::")[1]].grad, ref, 5e-3, 2e-3 * max(1e-3, float(np.abs(ref).max())))
+    names = [str(s) for s in g["unet_grad_names"]]
+    for n, ref_abs in zip(names, g["unet_grad_abs"]):
+        got = params[n].grad.double().abs().sum().item()
+        assert abs(got - ref_abs) <= 5e-3 * max(ref_abs, 1e-2), n
+    st = net.state_dict()
+    for n in g.files:
+        if n.startswith("unet_buf::"):
+            close(st[n.split("::")[1]].float(), g[n].astype(np.float32), 1e-3, 1e-5)
+
+
+@pytest.mark.parametrize("tag,dims,od", [("fe_small", (32, 16, 8, 8, 8), 24), ("fe_full", (256, 128, 64, 32, 16), 496)])
+def test_feature_extractor_vs_golden(golden, tag, dims, od):
+    from arco_amd.model_2D import FeatureExtractor
+    g = golden["g3_nets"]
+    sp = 32
+    fe = FeatureExtractor(fea_dim=list(dims), output_dim=od).cuda()
+    fe.load_state_dict(fx.fe_state(31, dims, od, nd=2), strict=True)
+    fl = [fx.image_batch(40 + i, 2, c, (sp >> (4 - i), sp >> (4 - i))).cuda().requires_grad_(True) for i, c in enumerate(dims)]
+    y = fe(fl)
+    (y * probe_like(y, 3)).sum().backward()
+    if tag == "fe_small":
+        close(y, g[tag + "_y"], 1e-3, 1e-4)
+        for i, f in enumerate(fl):
+            close(f.grad, g[tag + f"_dx{i}"], 1e-3, 1e-3)
+        for n, p in fe.named_parameters():
+            close(p.grad, g[tag + "_g::" + n], 2e-3, 2e-3)
+    else:
+        close(y[:, ::31, ::5, ::7], g[tag + "_y_sub"], 1e-3, 1e-4)
+        s = np.array([y.double().sum().item(), y.double().abs().sum().item()])
+        np.testing.assert_allclose(s[1], g[tag + "_y_sum"][1], rtol=1e-4)
+        for n, p in fe.named_parameters():
+            close(p.grad[::13, ::17], g[tag + "_g_sub::" + n], 2e-3, 2e-3 * float(np.abs(g[tag + "_g_sub::" + n]).max()))
+            np.testing.assert_allclose(p.grad.double().abs().sum().item(), g[tag + "_g_sum::" + n][1], rtol=2e-3)
+        for i, f in enumerate(fl):
+            np.testing.assert_allclose(f.grad.double().abs().sum().item(), g[tag + f"_dx{i}_sum"][1], rtol=2e-3)

@@ -1,0 +1,49 @@
+"""Host samplers of the product (arco_amd/samplers.py) vs golden vectors: bit-exact."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_inputs as fx
+from arco_amd import samplers as S
+
+FN = {"smc": S.grid_monte_carlo_sample, "asmc": S.grid_as_monte_carlo_sample,
+      "mc1d": S.monte_carlo_sample, "asmc1d": S.as_monte_carlo_sample}
+
+
+def seed_all(s):
+    random.seed(s); np.random.seed(s); torch.manual_seed(s)
+
+
+@pytest.mark.parametrize("name", list(FN))
+def test_bit_exact(golden, name):
+    g = golden["g1_samplers"]
+    for high in fx.SAMPLER_HIGHS:
+        for shape in fx.SAMPLER_SHAPES:
+            for seed in fx.SAMPLER_SEEDS:
+                key = f"{name}_h{high}_s{shape}_r{seed}"
+                seed_all(seed)
+                idx = FN[name](high, shape)
+                assert idx.dtype == torch.int64 and tuple(idx.shape) == (shape,)
+                np.testing.assert_array_equal(idx.numpy(), g[key].astype(np.int64), err_msg=key)
+                assert [int(torch.randint(1 << 30, (1,))), random.randint(0, 1 << 30)] == g[key + "_probe"].tolist(), key
+
+
+@pytest.mark.parametrize("name", ["smc", "asmc"])
+def test_production_size(golden, name):
+    g = golden["g1_samplers"]
+    for high in (1, 4096, 29999, 50000):
+        key = f"{name}_h{high}_s131072_r3"
+        seed_all(3)
+        idx = FN[name](high, 131072)
+        assert hashlib.sha256(np.ascontiguousarray(idx.numpy()).tobytes()).digest() == g[key + "_sha"].tobytes(), key
+        assert [int(torch.randint(1 << 30, (1,))), random.randint(0, 1 << 30)] == g[key + "_probe"].tolist()
+
+
+def test_range_and_determinism():
+    for high in (1, 5, 57, 1000, 65536, 300001):
+        seed_all(11); a = S.grid_monte_carlo_sample(high, 4096)
+        seed_all(11); b = S.grid_monte_carlo_sample(high, 4096)
+        assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < high
