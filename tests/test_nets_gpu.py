@@ -46,6 +46,11 @@ def test_unet_vs_reference_golden(golden):
     names = [str(s) for s in g["unet_grad_names"]]
     for n, ref_abs in zip(names, g["unet_grad_abs"]):
         got = params[n].grad.double().abs().sum().item()
+        if n.endswith("conv_conv.0.bias") or n.endswith("conv_conv.4.bias"):
+            # a conv bias feeding train-mode BN has an analytically ZERO gradient; both sides hold
+            # only fp32 rounding noise, so compare against the noise scale, not relatively
+            assert got < 1.0 and ref_abs < 1.0, n
+            continue
         assert abs(got - ref_abs) <= 5e-3 * max(ref_abs, 1e-2), n
     st = net.state_dict()
     for n in g.files:
