@@ -43,6 +43,9 @@ _SIGS = {
     "arco_copy_rows": [_P, _L, _L, _I, _P, _L, _I, _P],
     "arco_nchw_to_nhwc": [_P, _I, _I, _L, _P, _L, _P],
     "arco_nhwc_to_nchw": [_P, _L, _I, _I, _L, _P, _P],
+    "arco_softmax_rows": [_P, _L, _L, _I, _L, _P, _P, _P, _P, _P],
+    "arco_label_onehot": [_P, _L, _I, _L, _P, _P],
+    "arco_entropy_masks": [_P, _P, _P, _L, _L, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P],
     "arco_sgd_nesterov": [_P, _P, _P, _L, _F, _F, _F, _I, _P],
     "arco_ema": [_P, _P, _L, _F, _P],
 }
@@ -51,6 +54,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_conv_mblocks": ([_I, _I, _I, _I, _I], _I),
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
     "arco_chan_stats_blocks": ([_L], _I),
+    "arco_sel_state_bytes": ([], _L),
 }
 EXPORTS = sorted(list(_SIGS) + list(_QUERIES))
 

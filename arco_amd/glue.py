@@ -1,0 +1,67 @@
+"""Step glue of the trainers on the GPU: softmax / pseudo-labels /
+one-hot / entropy-percentile masks, mirroring train_arco_2d.py:284-286,342-393,492-498
+(3-D: train_arco_3d.py:463-469).  Thin wrappers over csrc/glue.hip."""
+import torch
+
+from . import _lib as L
+from ._contrast import rows_view
+
+
+def _geom(pred):
+    b, C = int(pred.shape[0]), int(pred.shape[1])
+    P = 1
+    for s in pred.shape[2:]:
+        P *= int(s)
+    r, ld = rows_view(pred.detach())
+    return r, ld, b, C, P
+
+
+@torch.no_grad()
+def softmax(pred):
+    """torch.softmax(pred, dim=1) as NC[spatial]-contiguous planes (what the loss consumes)."""
+    r, ld, b, C, P = _geom(pred)
+    out = torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
+    L.call("arco_softmax_rows", L.ptr(r), ld, b * P, C, P, L.ptr(out), None, None, None)
+    return out
+
+
+@torch.no_grad()
+def softmax_max(pred):
+    """torch.max(torch.softmax(pred, dim=1), dim=1) -> (pseudo_logits, pseudo_labels)  (train_arco_2d.py:286)."""
+    r, ld, b, C, P = _geom(pred)
+    sp = tuple(pred.shape[2:])
+    mp = torch.empty((b, *sp), dtype=torch.float32, device=pred.device)
+    am = torch.empty((b, *sp), dtype=torch.int64, device=pred.device)
+    L.call("arco_softmax_rows", L.ptr(r), ld, b * P, C, P, None, L.ptr(mp), L.ptr(am), None)
+    return mp, am
+
+
+@torch.no_grad()
+def label_onehot(inputs, num_segments):
+    """train_arco_2d.py:492-498; returns int64 like the `.long()` the trainer applies (:394)."""
+    lab = inputs.to(torch.int64).contiguous()
+    b = int(lab.shape[0])
+    P = lab.numel() // b
+    out = torch.empty((b, num_segments, *lab.shape[1:]), dtype=torch.int64, device=lab.device)
+    L.call("arco_label_onehot", L.ptr(lab), b * P, num_segments, P, L.ptr(out))
+    return out
+
+
+@torch.no_grad()
+def entropy_masks(pred_u, label_l_raw, label_u_raw, alpha_t):
+    """low_mask_all / high_mask_all of train_arco_2d.py:352-393: entropy of softmax(pred_u), exact
+    np.percentile(alpha_t) / (100-alpha_t) over valid pixels (device radix select, no host sync)."""
+    r, ld, b, C, P = _geom(pred_u)
+    dev = pred_u.device
+    ent = torch.empty(b * P, dtype=torch.float32, device=dev)
+    L.call("arco_softmax_rows", L.ptr(r), ld, b * P, C, P, None, None, None, L.ptr(ent))
+    ll = label_l_raw.to(torch.int64).contiguous()
+    lu = label_u_raw.to(torch.int64).contiguous()
+    n_l, n_u = ll.numel(), lu.numel()
+    state = torch.empty(L.query("arco_sel_state_bytes"), dtype=torch.uint8, device=dev)
+    sp = tuple(pred_u.shape[2:])
+    low = torch.empty((int(ll.shape[0]) + b, 1, *sp), dtype=torch.float32, device=dev)
+    high = torch.empty_like(low)
+    L.call("arco_entropy_masks", L.ptr(ent), L.ptr(ll), L.ptr(lu), n_l, n_u, float(alpha_t), float(100 - alpha_t),
+           L.ptr(state), L.ptr(low), L.ptr(high))
+    return low, high

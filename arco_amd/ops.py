@@ -11,6 +11,7 @@ from . import _lib as L
 from ._contrast import rows_view
 
 _drop_gen = None
+PROFILE = None      # bench.py sets a dict: (taps, M, N, K) -> [(start_event, end_event)] per conv launch
 
 
 def _next_seed():
@@ -65,8 +66,14 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         nmb = L.query("arco_conv_mblocks", taps, nb, h, w, n)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     L.call("arco_conv_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
            L.ptr(ssum), L.ptr(ssq), taps, nb, h, w)
+    if PROFILE is not None:
+        ev[1].record()
+        PROFILE.setdefault((taps, nb * h * w, n, k), []).append(ev)
     return out, (ssum, ssq, nmb)
 
 

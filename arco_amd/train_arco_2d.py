@@ -1,0 +1,262 @@
+"""Stage-2 ARCO trainer, 2-D, on MI355X - drop-in for the reference's code/train_arco_2d.py.
+
+Plugin surface kept identical: every command-line flag of train_arco_2d.py:26-87 (names,
+types, defaults; the dead ones are accepted and ignored exactly like the reference),
+`--exp` substring dataset dispatch (:91-106), snapshot directory
+../model/{exp}_{labeled_num}_labeledfinal/{model} and `iter_N.pth` = state_dict of the
+student U-Net with the reference's key names (:462-470, :509-511).
+
+The step itself (train_arco_2d.py:284-435) is `ArcoStep2D.step`: hot path (SURVEY §8a rows
+N1-N5, T1, L1-L6, O1) on hand-written HIP kernels.  One process per GPU; with WORLD_SIZE>1
+gradients are all-reduced and new negative keys all-gathered over RCCL (arco_amd/dist.py).
+Not built here (SURVEY §8 "next"/out of scope): dataset readers, CPU augmentation
+(identity on the synthetic path), the TPS equivariance / revisiting / supervised
+CE+Dice / unsupervised-CE loss terms.
+"""
+import argparse
+import logging
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dist as adist
+from . import glue, ops, optim
+from .loss_helper_3d import compute_contra_memobank_loss
+from .model_2D import ISD, FeatureExtractor
+
+FEA_DIM = [256, 128, 64, 32, 16]
+REP_DIM = sum(FEA_DIM)          # 496 (train_arco_2d.py:151,232)
+
+
+def build_parser():
+    """Every add_argument of train_arco_2d.py:26-87, same names/types/defaults."""
+    p = argparse.ArgumentParser()
+    p.add_argument('--root_path', type=str, default='../data/ACDC', help='Name of Experiment')
+    p.add_argument('--exp', type=str, default='ACDC/example_training', help='experiment_name')
+    p.add_argument('--model', type=str, default='unet', help='model_name')
+    p.add_argument('--max_iterations', type=int, default=30000, help='maximum epoch number to train')
+    p.add_argument('--batch_size', type=int, default=4, help='batch_size per gpu')
+    p.add_argument('--deterministic', type=int, default=1, help='whether use deterministic training')
+    p.add_argument('--base_lr', type=float, default=0.01, help='segmentation network learning rate')
+    p.add_argument('--patch_size', type=list, default=[256, 256], help='patch size of network input')
+    p.add_argument('--seed', type=int, default=1337, help='random seed')
+    p.add_argument('--num_classes', type=int, default=4, help='output channel of network')
+    p.add_argument('--consistency', type=float, default=0.1, help='consistency')
+    p.add_argument('--consistency_rampup', type=float, default=200.0, help='consistency_rampup')
+    p.add_argument('--labeled_bs', type=int, default=2, help='labeled_batch_size per gpu')
+    p.add_argument('--labeled_num', type=int, default=7, help='labeled data')
+    p.add_argument('--strong_threshold', default=0.97, type=float)
+    p.add_argument('--strong_threshold_u2pl', default=0.97, type=float)
+    p.add_argument('--weak_threshold', default=0.7, type=float)
+    p.add_argument('--temp', default=0.5, type=float)
+    p.add_argument('--num_negatives', default=512, type=int, help='number of negative keys')
+    p.add_argument('--num_queries', default=256, type=int, help='number of queries per segment per image')
+    p.add_argument('--mona_feature_size', type=int, default=512, help='the feature size of latent vectors')
+    p.add_argument('--apply_aug', default='cutmix', type=str, help='apply semi-supervised method: cutout cutmix classmix')
+    p.add_argument('--resume', type=str, default='ACDC/training_pool_latentF512_K36', help='if we should resume from checkpoint')
+    p.add_argument('--K', type=int, default=36, help='the size of cache')
+    p.add_argument('--k1', type=float, default=0.01, help='the weights for contrastive loss')
+    p.add_argument('--k2', type=float, default=1.0, help='the weights for eqv loss')
+    p.add_argument('--k3', type=float, default=1.0, help='the weights for unsup loss')
+    p.add_argument('--k4', type=float, default=1.0, help='the weights for nn loss')
+    p.add_argument('--k5', type=float, default=1.0, help='the weights for nn loss')
+    p.add_argument('--topk', type=int, default=5, help='the size of cache')
+    p.add_argument('--latent_pooling_size', type=int, default=1, help='the pooling size of latent vector')
+    p.add_argument('--latent_feature_size', type=int, default=512, help='the feature size of latent vectors')
+    p.add_argument('--output_pooling_size', type=int, default=8, help='the pooling size of output head')
+    p.add_argument('--combinations', type=int, default=0, help='0: all, 1: no reco, 2: no unsup')
+    p.add_argument('--mask', type=int, default=0, help='0: no mask, 1: use pre_u')
+    p.add_argument('--func', type=str, default='smc', help='asmc or smc')
+    p.add_argument('--ref_net', type=str, default='vgg19', help='ref_net')
+    p.add_argument('--ref_norm', type=bool, default=False, help='ref_norm')
+    p.add_argument('--ref_layer1', type=str, default='relu3_2', help='ref_layer1')
+    p.add_argument('--ref_layer2', type=str, default='relu5_4', help='ref_layer2')
+    p.add_argument('--ref_weight1', type=float, default=0.33, help='ref_weight1')
+    p.add_argument('--ref_weight2', type=float, default=1.0, help='ref_weight2')
+    p.add_argument('--temperature', type=float, default=.19, help='temperature')
+    p.add_argument('--layer_len', type=int, default=-1, help='layer_len')
+    p.add_argument('--tps_sigma', type=float, default=0.01, help='tps_sigma')
+    # additions of this implementation (not in the reference)
+    p.add_argument('--queue_size', type=int, default=0, help='override per-class bank size (0 = reference 50000/30000)')
+    p.add_argument('--synthetic', type=int, default=0, help='1: train on synthetic ACDC-shaped tensors')
+    p.add_argument('--in_chns', type=int, default=1, help='input channels (reference: 1)')
+    return p
+
+
+def patients_to_slices(dataset, patiens_num):
+    """train_arco_2d.py:91-106."""
+    ref_dict = None
+    if "ACDC" in dataset:
+        ref_dict = {"1": 23, "3": 68, "7": 136, "14": 256, "21": 396, "28": 512, "35": 664, "140": 1312}
+    elif "MM" in dataset:
+        ref_dict = {"1": 38, "2": 76, "5": 191, "10": 382}
+    elif "Syn" in dataset or "syn" in dataset:
+        ref_dict = {"1": 44, "3": 66, "5": 111, "10": 221}
+    elif "Lits" in dataset or "LiTS" in dataset:
+        ref_dict = {"1": 167, "5": 835, "10": 1668, "20": 3336, "50": 8340}
+    elif "jhu" in dataset or "JHU" in dataset:
+        ref_dict = {"1": 57, "5": 275, "10": 568, "100": 5675}
+    else:
+        print("Error")
+    return ref_dict[str(patiens_num)]
+
+
+class ArcoStep2D:
+    """State + one training step of the 2-D hot path (train_arco_2d.py:147-154,220-253,284-435)."""
+
+    def __init__(self, args, device="cuda"):
+        self.args = args
+        self.dev = torch.device(device)
+        C = args.num_classes
+        # memory banks (train_arco_2d.py:147-154); device resident from the first enqueue on
+        self.memobank, self.queue_ptrlis, self.queue_size = [], [], []
+        for i in range(C):
+            self.memobank.append([torch.zeros(1, REP_DIM)])
+            self.queue_size.append(args.queue_size if args.queue_size > 0 else 30000)
+            self.queue_ptrlis.append(torch.zeros(1, dtype=torch.long))
+        if args.queue_size <= 0:
+            self.queue_size[0] = 50000
+        self.isd = ISD(K=args.K, m=0.99, Ts=0.01, Tt=0.1, num_classes=C,
+                       latent_pooling_size=args.latent_pooling_size, latent_feature_size=args.latent_feature_size,
+                       output_pooling_size=args.output_pooling_size, train_encoder=True, train_decoder=True)
+        if args.in_chns != 1:
+            raise NotImplementedError("create_model builds in_chns=1 like the reference (model_2D.py:59)")
+        self.isd = self.isd.to(self.dev)
+        self.model, self.ema_model = self.isd.model, self.isd.ema_model
+        self.q_representation = nn.Sequential(nn.Conv2d(REP_DIM, REP_DIM, kernel_size=1, bias=False),
+                                              nn.Conv2d(REP_DIM, REP_DIM, kernel_size=1, bias=False)).to(self.dev)
+        self.k_feature_extractor = FeatureExtractor(fea_dim=FEA_DIM, output_dim=REP_DIM).to(self.dev)
+        self.q_feature_extractor = FeatureExtractor(fea_dim=FEA_DIM, output_dim=REP_DIM).to(self.dev)
+        adist.broadcast_module_states([self.isd, self.q_representation, self.q_feature_extractor,
+                                       self.k_feature_extractor])
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        params_rep = [p for p in self.q_representation.parameters() if p.requires_grad]
+        params_fea = [p for p in self.q_feature_extractor.parameters() if p.requires_grad]
+        self.optimizer = optim.SGDNesterov(params + params_rep + params_fea, lr=args.base_lr, weight_decay=0.0001,
+                                           momentum=0.9, nesterov=True)
+        with torch.no_grad():                                            # :250-253
+            for t, s in zip(self.k_feature_extractor.parameters(), self.q_feature_extractor.parameters()):
+                t.data.copy_(s.data)
+                t.requires_grad = False
+        self.k_fe_ema = optim.EmaPair(self.q_feature_extractor, self.k_feature_extractor)
+        for m in (self.model, self.ema_model, self.q_representation, self.k_feature_extractor,
+                  self.q_feature_extractor):
+            m.train()                                                   # :263-267
+        self.iter_num = 0
+        self.loss_events = []
+
+    def q_rep(self, x):
+        x = ops.conv(x, self.q_representation[0].weight)
+        return ops.conv(x, self.q_representation[1].weight)
+
+    def step(self, l_data, l_label, u_data, epoch_num=0, max_epoch=1):
+        """One iteration.  Augmentations (augment.py; CPU/PIL, out of scope) are the identity here:
+        train_u_aug_* = (u_data, pseudo_labels, pseudo_logits), images_cj2_l = l_data."""
+        a = self.args
+        C = a.num_classes
+        with torch.no_grad():                                            # :284-286
+            pred_u0, _, _ = self.ema_model(u_data)
+            pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
+        u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits
+        self.k_fe_ema.update(0.99)                                      # :306-308
+        pred_l, _, l_fm = self.model(l_data)                             # :310
+        with torch.no_grad():
+            self.model(l_data)       # images_cj2_l forward (:311): BN running stats only; its FE/q_rep
+                                     # outputs (l_feature_map_2, :319,326) are never read -> not computed
+        pred_u, _, u_fm = self.model(u_aug)                              # :312
+        with torch.no_grad():                                            # teacher params carry no grad (:158-160)
+            pred_l_t, _, l_fm_t = self.ema_model(l_data)                 # :314
+            pred_u_t, _, u_fm_t = self.ema_model(u_aug)                  # :315
+            # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
+            rep_all_teacher = self.k_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)])
+        feat_all = self.q_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm, u_fm)])   # :317-318
+        rep_all = self.q_rep(feat_all)                                   # :324-325,330
+        with torch.no_grad():                                            # :342-393
+            alpha_t = 20 * (1 - epoch_num / max_epoch)
+            label_l = glue.label_onehot(l_label, C)
+            label_u = glue.label_onehot(u_aug_label, C)
+            prob_l_t = glue.softmax(pred_l_t)
+            prob_u_t = glue.softmax(pred_u_t)
+            low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        reco_loss = compute_contra_memobank_loss(                        # :394-398
+            rep_all, label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all, self.memobank,
+            self.queue_ptrlis, self.queue_size, rep_all_teacher, delta_n=a.strong_threshold_u2pl, func=a.func,
+            num_queries=a.num_queries, num_negatives=a.num_negatives)[-1]
+        ev[1].record()
+        self.loss_events.append(ev)
+        loss = a.k1 * reco_loss                                          # :426 (hot-path term)
+        self.optimizer.zero_grad()                                       # :429-431
+        loss.backward()
+        adist.allreduce_grads(self.optimizer)
+        self.optimizer.step()
+        self.isd._momentum_update_key_encoder()                          # :432
+        lr_ = a.base_lr * (1.0 - self.iter_num / a.max_iterations) ** 0.9   # :433-435
+        for g in self.optimizer.param_groups:
+            g['lr'] = lr_
+        self.iter_num += 1
+        return loss, reco_loss
+
+
+def synthetic_batch(b, patch, n_cls, seed, device):
+    """ACDC-shaped synthetic batch: images U[0,1), blob labels with ACDC-like imbalance."""
+    rs = np.random.RandomState(seed)
+    img = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+    lab = np.zeros((b, *patch), dtype=np.int64)
+    yy, xx = np.mgrid[0:patch[0], 0:patch[1]]
+    for i in range(b):
+        for c in range(1, n_cls):
+            cy, cx = rs.randint(patch[0] // 4, 3 * patch[0] // 4), rs.randint(patch[1] // 4, 3 * patch[1] // 4)
+            r = rs.randint(patch[0] // 16, patch[0] // 6)
+            lab[i][(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = c
+    return img.to(device), torch.from_numpy(lab).to(device)
+
+
+def train(args, snapshot_path):
+    if not args.synthetic:
+        raise NotImplementedError(
+            "dataset readers (build_dataset.py / dataloaders/, h5py) are outside the hot path (SURVEY §8f row 4); "
+            "run with --synthetic 1")
+    rank, world = adist.init()
+    dev = torch.device("cuda", adist.local_rank())
+    torch.cuda.set_device(dev)
+    stepper = ArcoStep2D(args, dev)
+    b = args.batch_size
+    iters_per_epoch = 100
+    max_epoch = args.max_iterations // iters_per_epoch + 1
+    while stepper.iter_num < args.max_iterations:
+        it = stepper.iter_num
+        l_img, l_lab = synthetic_batch(b, args.patch_size, args.num_classes, 2 * it * world + rank, dev)
+        u_img, _ = synthetic_batch(b, args.patch_size, args.num_classes, (2 * it + 1) * world + rank, dev)
+        loss, reco = stepper.step(l_img, l_lab, u_img, it // iters_per_epoch, max_epoch)
+        if rank == 0:
+            logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))
+            if stepper.iter_num % 1000 == 0:                           # :462-470
+                path = os.path.join(snapshot_path, 'iter_' + str(stepper.iter_num) + '.pth')
+                torch.save(stepper.isd.model.state_dict(), path)
+                logging.info("save model to {}".format(path))
+    return "Training Finished!"
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    random.seed(args.seed)                                               # :505-508
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed(args.seed)
+    snapshot_path = "../model/{}_{}_labeled{}/{}".format(args.exp, args.labeled_num, 'final', args.model)
+    os.makedirs(snapshot_path, exist_ok=True)
+    logging.basicConfig(filename=snapshot_path + "/log.txt", level=logging.INFO,
+                        format='[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S')
+    logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
+    logging.info(str(args))
+    return train(args, snapshot_path)
+
+
+if __name__ == "__main__":
+    main()

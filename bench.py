@@ -1,0 +1,126 @@
+"""Benchmark of the ARCO 2-D hot-path training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+(N>1: launched by torchrun, one rank per GPU over RCCL.)  Prints ONE JSON line (rank 0).
+
+Workload = BASELINE.json configs[1]: ACDC-shaped 2-D 256x256, --batch_size 8 per stream
+(16 images/step/GPU), C=4, D=496, stratified sampler (smc) + 4096-key/class queue, nq=256,
+nn=512, temp 0.5; synthetic data and random-init weights resident in HBM before timing.
+A step = SURVEY §8a rows N1-N5, T1, L1-L6, O1 (U-Net x6 forwards incl. teacher, FeatureExtractor,
+q_representation, masks, sampler, bank, InfoNCE, backward, SGD-Nesterov, EMA).  Weak scaling:
+per-GPU work is fixed; value = N*K 16-image steps / wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
+
+
+def cpu_baseline():
+    """CPU oracle (port) timed on this box's host cores: one full step at --batch_size 2 (4 images)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_step
+    secs, threads = cpu_step.timed_sample(b=2)
+    # a 16-image step is 4x the 4-image sample (per-image work is constant)
+    return {"value": round(1.0 / (4.0 * secs), 5), "unit": "steps/s (16-image steps)", "cores": threads, "kind": "port",
+            "sample": f"1 full oracle step at --batch_size 2 (4 images, 256x256, C=4, D=496) = {secs:.1f} s on "
+                      f"{threads} threads; scaled x4 to the 16-image step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch_size", type=int, default=8)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    from arco_amd import dist as adist
+    from arco_amd import ops
+    from arco_amd import train_arco_2d as T
+    rank, world = adist.init()
+    dev = torch.device("cuda", adist.local_rank())
+    torch.cuda.set_device(dev)
+    import random
+    import numpy as np
+    random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
+
+    args = T.build_parser().parse_args(["--batch_size", str(a.batch_size), "--queue_size", "4096", "--func", "smc",
+                                        "--synthetic", "1"])
+    stepper = T.ArcoStep2D(args, dev)
+    b = a.batch_size
+    batches = []
+    for i in range(4):        # a few resident synthetic batches, cycled
+        l_img, l_lab = T.synthetic_batch(b, args.patch_size, args.num_classes, 100 + 2 * i * world + rank, dev)
+        u_img, _ = T.synthetic_batch(b, args.patch_size, args.num_classes, 101 + 2 * i * world + rank, dev)
+        batches.append((l_img, l_lab, u_img))
+
+    def run(n, base):
+        for i in range(n):
+            l_img, l_lab, u_img = batches[(base + i) % len(batches)]
+            stepper.step(l_img, l_lab, u_img, 0, 100)
+
+    run(a.warmup, 0)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    stepper.loss_events = []
+    ops.PROFILE = {}           # HIP-event timing of the dominant kernel, on the launch stream
+    t0 = time.perf_counter()
+    run(a.steps, a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # dominant kernel: the 496x496 1x1-conv GEMM at full resolution (igemm_kernel<1,128,128,...>)
+        key = max(prof, key=lambda k: sum(s.elapsed_time(e) for s, e in prof[k])) if prof else None
+        roof = None
+        if key is not None:
+            taps, m, n, k = key
+            ms = [s.elapsed_time(e) for s, e in prof[key]]
+            avg_ms = sum(ms) / len(ms)
+            flop = 2.0 * m * n * k * taps
+            ach = flop / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": f"igemm_kernel 1x1 conv M={m} N={n} K={k} (fp32 MFMA 16x16x4)",
+                    "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
+                    "share_of_step": round(sum(ms) / (dt * 1e3), 4)}
+        out = {
+            "metric": "train steps/sec, ACDC 2D 256x256 bs=16 (hot-path step)", "value": round(world * a.steps / dt, 4),
+            "unit": "steps/s (16-image steps, all GPUs)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ACDC 2D 256x256 bs=16 on 1xMI355X, stratified sampler + 4096-key/class queue "
+                                   "(BASELINE.json configs[1])", "batch_size_per_stream": b, "images_per_step_per_gpu": 2 * b,
+                       "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc",
+                       "parallelism": f"dp{world}"},
+            "contrastive_loss_fwd_ms_per_step": round(sum(s.elapsed_time(e) for s, e in stepper.loss_events)
+                                                      / max(1, len(stepper.loss_events)), 3),
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

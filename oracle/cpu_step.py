@@ -1,0 +1,76 @@
+"""CPU oracle of one hot-path training step (same op sequence as arco_amd.train_arco_2d.ArcoStep2D.step),
+built from the restated pieces in arco_oracle.py.  TEST INFRASTRUCTURE: used by bench.py's
+cpu_baseline leg (timed on the GPU box's host cores) and by tests as the checker."""
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import arco_oracle as orc
+
+
+def make_state(unet_sd, fe_sd, qrep_w):
+    st = dict(
+        student={k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in unet_sd.items()},
+        teacher={k: v.clone() for k, v in unet_sd.items()},
+        q_fe={k: v.clone().requires_grad_(True) for k, v in fe_sd.items()},
+        k_fe={k: v.clone() for k, v in fe_sd.items()},
+        q_rep=[w.clone().requires_grad_(True) for w in qrep_w],
+        mom={}, it=0)
+    return st
+
+
+def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20.0, k1=0.01, lr=0.01,
+         delta_n=0.97, func='smc', nq=256, nn_=512):
+    with torch.no_grad():
+        pred_u0, _, _ = orc.unet_forward(u_data, st["teacher"])
+        pseudo_logits, pseudo_labels = torch.max(torch.softmax(pred_u0, 1), 1)
+        for k in st["k_fe"]:
+            st["k_fe"][k] = st["k_fe"][k] * 0.99 + st["q_fe"][k].detach() * 0.01
+    pred_l, _, l_fm = orc.unet_forward(l_data, st["student"])
+    with torch.no_grad():
+        orc.unet_forward(l_data, st["student"])
+    pred_u, _, u_fm = orc.unet_forward(u_data, st["student"])
+    with torch.no_grad():
+        pred_l_t, _, l_fm_t = orc.unet_forward(l_data, st["teacher"])
+        pred_u_t, _, u_fm_t = orc.unet_forward(u_data, st["teacher"])
+        rep_t = orc.feature_extractor_forward([torch.cat((a, b)) for a, b in zip(l_fm_t, u_fm_t)], st["k_fe"])
+    feat = orc.feature_extractor_forward([torch.cat((a, b)) for a, b in zip(l_fm, u_fm)], st["q_fe"])
+    rep = F.conv2d(F.conv2d(feat, st["q_rep"][0]), st["q_rep"][1])
+    with torch.no_grad():
+        label_l = orc.label_onehot(l_label, n_cls).long()
+        label_u = orc.label_onehot(pseudo_labels, n_cls).long()
+        low, high, _ = orc.entropy_masks(pred_u, l_label, pseudo_labels, alpha_t)
+        pl, pu = torch.softmax(pred_l_t, 1), torch.softmax(pred_u_t, 1)
+    _, reco = orc.compute_contra_memobank_loss(rep, label_l, label_u, pl, pu, low, high, memobank, ptrs, qsize, rep_t,
+                                               delta_n=delta_n, func=func, num_queries=nq, num_negatives=nn_)
+    loss = k1 * reco
+    leaves = [v for v in st["student"].values() if v.requires_grad] + list(st["q_rep"]) + list(st["q_fe"].values())
+    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    with torch.no_grad():
+        for i, (p, g) in enumerate(zip(leaves, grads)):
+            if g is None:
+                continue
+            newp, st["mom"][i] = orc.sgd_nesterov_step(p, g, st["mom"].get(i), lr)
+            p.copy_(newp)
+        for k, v in st["student"].items():
+            if v.requires_grad:
+                st["teacher"][k] = st["teacher"][k] * 0.99 + v.detach() * 0.01
+    st["it"] += 1
+    return float(loss), float(reco)
+
+
+def timed_sample(b=2, patch=(256, 256), n_cls=4, seed=1337, qsize=4096):
+    """One full CPU step at --batch_size b; returns (seconds, threads)."""
+    import fixture_inputs as fx
+    torch.manual_seed(seed)
+    st = make_state(fx.unet_state(21, 1, n_cls), fx.fe_state(31), [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]])
+    rs = np.random.RandomState(seed)
+    l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+    u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+    lab = torch.from_numpy(fx.blob_labels(rs, b, patch, n_cls))
+    bank, ptr, qs = fx.fresh_bank(n_cls, 496, qsize, 'zeros')
+    t0 = time.time()
+    step(st, l, lab, u, bank, ptr, qs, n_cls)
+    return time.time() - t0, torch.get_num_threads()

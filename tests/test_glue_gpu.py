@@ -1,0 +1,76 @@
+"""T1 step glue on the GPU vs golden vectors from the reference's trainer text and vs numpy (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import fixture_inputs as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs():
+    rs = np.random.RandomState(77)
+    b, C, H, W = 2, 4, 24, 20
+    pred_l = torch.from_numpy(rs.standard_normal((b, C, H, W)).astype(np.float32) * 2)
+    pred_u = torch.from_numpy(rs.standard_normal((b, C, H, W)).astype(np.float32) * 2)
+    lab_l = torch.from_numpy(fx.blob_labels(rs, b, (H, W), C))
+    lab_u = torch.from_numpy(fx.blob_labels(rs, b, (H, W), C))
+    lab_u[0, :3, :4] = -1
+    return pred_l, pred_u, lab_l, lab_u, C
+
+
+def test_masks_onehot_vs_reference(golden):
+    from arco_amd import glue
+    g = golden["g4_glue"]
+    pred_l, pred_u, lab_l, lab_u, C = _inputs()
+    oh = glue.label_onehot(lab_u.cuda(), C)
+    np.testing.assert_array_equal(oh.cpu().numpy(), g["onehot_u"].astype(np.int64))
+    for epoch, max_epoch in ((0, 10), (3, 10)):
+        alpha = 20 * (1 - epoch / max_epoch)
+        for pu in (pred_u.cuda(), pred_u.cuda().contiguous(memory_format=torch.channels_last)):
+            low, high = glue.entropy_masks(pu, lab_l.cuda(), lab_u.cuda(), alpha)
+            # entropy differs from the CPU value by ~1 ulp, so a pixel exactly at the threshold may flip
+            dl = (low.cpu().numpy() != g[f"mask_e{epoch}_low"]).sum()
+            dh = (high.cpu().numpy() != g[f"mask_e{epoch}_high"]).sum()
+            assert dl <= 2 and dh <= 2, (dl, dh)
+
+
+def test_percentile_exact_vs_numpy():
+    """Radix-select percentiles are bit-exact w.r.t. np.percentile on the SAME entropy values."""
+    from arco_amd import glue, _lib as L
+    rs = np.random.RandomState(5)
+    for n, q in ((1000, 20.0), (65536, 13.7), (300001, 0.0), (4097, 2.5)):
+        b, C = 1, 4
+        pred = torch.from_numpy(rs.standard_normal((b, C, n, 1)).astype(np.float32) * 3).cuda()
+        lab_u = torch.from_numpy((rs.uniform(size=(b, n, 1)) > 0.1).astype(np.int64) - 1 + 1).cuda()
+        lab_u[0, :7] = -1
+        lab_l = torch.zeros((b, n, 1), dtype=torch.int64).cuda()
+        low, high = glue.entropy_masks(pred, lab_l, lab_u, q)
+        prob = torch.softmax(pred, 1)
+        ent_gpu = torch.empty(b * n, dtype=torch.float32, device="cuda")
+        r = pred.permute(0, 2, 3, 1).contiguous().view(-1, C)
+        L.call("arco_softmax_rows", L.ptr(r), C, b * n, C, n, None, None, None, L.ptr(ent_gpu))
+        ent = ent_gpu.cpu().numpy().reshape(b, n, 1)
+        valid = (lab_u.cpu().numpy() >= 0)
+        lo_t = np.percentile(ent[valid].flatten(), q)
+        hi_t = np.percentile(ent[valid].flatten(), 100 - q)
+        exp_low = ((torch.from_numpy(ent).le(lo_t)).float() * torch.from_numpy(valid)).numpy()
+        exp_high = ((torch.from_numpy(ent).ge(hi_t)).float() * torch.from_numpy(valid)).numpy()
+        np.testing.assert_array_equal(low.cpu().numpy()[b:, 0], exp_low)
+        np.testing.assert_array_equal(high.cpu().numpy()[b:, 0], exp_high)
+        assert (low.cpu().numpy()[:b] == 1).all()
+        np.testing.assert_allclose(ent, (-(prob * torch.log(prob + 1e-10)).sum(1)).cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_softmax_and_pseudo_labels():
+    from arco_amd import glue
+    rs = np.random.RandomState(9)
+    pred = torch.from_numpy(rs.standard_normal((3, 4, 16, 12)).astype(np.float32) * 4)
+    for p in (pred.cuda(), pred.cuda().contiguous(memory_format=torch.channels_last)):
+        sm = glue.softmax(p)
+        assert sm.is_contiguous()
+        np.testing.assert_allclose(sm.cpu().numpy(), torch.softmax(pred, 1).numpy(), rtol=1e-5, atol=1e-7)
+        mp, am = glue.softmax_max(p)
+        rm, ra = torch.max(torch.softmax(pred, 1), 1)
+        np.testing.assert_allclose(mp.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_array_equal(am.cpu().numpy(), ra.numpy())
