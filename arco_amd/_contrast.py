@@ -6,14 +6,19 @@ Mirrors compute_contra_memobank_loss / dequeue_and_enqueue of the reference
 implementation is rank-generic).  Same signature, same in-place mutation of
 `memobank` / `queue_prtlis`, same return values, same degenerate-batch behaviour.
 
-Device pipeline (all on the caller's current HIP stream):
-  mask_codes -> scan -> compact_rows   per-pixel class masks, counts, stable row lists
-  masked_proto                         prototypes = masked mean of teacher rows
-  gather_rows + bank_append            FIFO-by-truncation banks, resident in HBM
-  [host]  samplers.*                   torch-CPU-generator index replay (bit-exact)
-  gather_rows / normalize_rows / conv_fwd(1x1 MFMA GEMM) / neg_multiplicity /
-  infonce_fwd / conv_fwd / infonce_anchor_grad      InfoNCE value + anchor gradient
-One device->host copy per call (the 3*C counters), none per class.
+The work is cut into four stages so a trainer can overlap the host sampler with GPU work
+(compute_contra_memobank_loss simply runs them back to back):
+
+  contrast_masks     GPU   per-pixel class masks + counts (mask_codes, scan); async D2H of 3*C counters
+  contrast_sample    host  wait for the counters, replay the torch-CPU-generator samplers (bit-exact
+                           indices; needs only counts and the post-enqueue bank lengths)
+  contrast_enqueue   GPU   stable row lists, prototypes (masked mean of teacher rows), key gather,
+                           FIFO-by-truncation bank append (banks stay resident in HBM)
+  contrast_infonce   GPU   anchors [n,D] -> normalise -> scores vs the whole bank on the fp32 matrix
+                           cores -> multiplicity-weighted softmax-CE -> anchor gradient (second GEMM)
+Only the anchor ROWS of `rep` enter the loss, so `rep` is touched through a row gather whose
+backward is a row scatter; a trainer may instead feed anchor rows computed lazily
+(arco_amd.head) - same values, no dense 496-channel tensor.
 """
 import torch
 
@@ -24,9 +29,11 @@ EPS = 1e-8          # torch.cosine_similarity eps
 DELTA_P = 0.3       # current_class_threshold      (loss_helper_3d.py:316)
 LOW_RANK, HIGH_RANK = 3, 20                        # (loss_helper_3d.py:318)
 
-# hook for data-parallel training: callable(keys[n,D], class_id) -> keys gathered from all ranks
+# hook for data-parallel training: callable(keys[n,D]) -> keys gathered from all ranks
 # (rank order); installed by arco_amd.dist.  None = single process.
 key_gather_hook = None
+# companion hook: callable(list[int] per-class local counts) -> list[int] global counts
+count_gather_hook = None
 
 
 def _ceil(x, m):
@@ -50,190 +57,250 @@ def rows_view(x):
 
 
 @torch.no_grad()
-def dequeue_and_enqueue(keys, queue, queue_ptr, queue_size):
-    """Device-resident version of loss_helper_3d.py:12-32: queue[0] <- cat(queue[0], keys)[-queue_size:].
-    `queue[0]` is replaced by a GPU tensor; `queue_ptr[0]` gets the reference's pointer value."""
-    L.require_gpu(keys)
-    keys = keys.detach().to(torch.float32).contiguous()
-    n, D = int(keys.shape[0]), int(keys.shape[1])
+def _append(keys, n_all, queue, queue_ptr, queue_size):
+    """queue[0] <- cat(queue[0], all n_all new keys)[-queue_size:], given (at least) the last
+    min(n_all, queue_size) of them in `keys`; pointer arithmetic of loss_helper_3d.py:24-30."""
+    D = int(keys.shape[1])
+    take = min(int(keys.shape[0]), queue_size)
+    if take < keys.shape[0]:
+        keys = keys[keys.shape[0] - take:]
     old = queue[0].to(device=keys.device, dtype=torch.float32).contiguous()
-    if key_gather_hook is not None:
-        keys = key_gather_hook(keys)
-        n_all = int(keys.shape[0])
-    else:
-        n_all = n
-    take = min(n_all, queue_size)
-    if take < n_all:
-        keys = keys[n_all - take:]
     len_old = int(old.shape[0])
     out_len = min(len_old + take, queue_size)
     out = torch.empty((out_len, D), device=keys.device, dtype=torch.float32)
-    L.call("arco_bank_append", L.ptr(old), len_old, L.ptr(keys), take, queue_size, D, L.ptr(out))
+    L.call("arco_bank_append", L.ptr(old), len_old, L.ptr(keys.contiguous()), take, queue_size, D, L.ptr(out))
     queue[0] = out
     if len_old + n_all >= queue_size:
         queue_ptr[0] = queue_size
     else:
         queue_ptr[0] = (int(queue_ptr) + n_all) % queue_size
+
+
+@torch.no_grad()
+def dequeue_and_enqueue(keys, queue, queue_ptr, queue_size):
+    """Device-resident version of loss_helper_3d.py:12-32.  `queue[0]` is replaced by a GPU tensor;
+    `queue_ptr[0]` gets the reference's pointer value.  With the data-parallel hook installed the
+    keys of all ranks are concatenated in rank order first (the reference's commented-out
+    gather_together, loss_helper_3d.py:16-17)."""
+    L.require_gpu(keys)
+    keys = keys.detach().to(torch.float32).contiguous()
+    n = int(keys.shape[0])
+    if key_gather_hook is not None:
+        keys = key_gather_hook(keys)
+    _append(keys, int(keys.shape[0]), queue, queue_ptr, queue_size)
     return n
 
 
-class _AnchorGrad(torch.autograd.Function):
-    """Attaches the precomputed anchor-row gradient of the loss to `rep`."""
+class GatherRowsFn(torch.autograd.Function):
+    """A[j] = rows(rep)[pix[j]]; backward scatters (duplicates add) into a zero tensor shaped like rep."""
 
     @staticmethod
-    def forward(ctx, rep, loss_val, lists, pieces):
-        ctx.lists, ctx.pieces = lists, pieces
-        ctx.rep_shape = rep.shape
+    def forward(ctx, rep, pix):
+        R, ld = rows_view(rep)
+        D = int(rep.shape[1])
+        n = int(pix.shape[0])
+        A = torch.empty((n, D), dtype=torch.float32, device=rep.device)
+        L.call("arco_gather_rows", L.ptr(R), ld, D, None, L.ptr(pix), None, 0, n, L.ptr(A), D)
+        ctx.save_for_backward(pix)
+        ctx.rep_shape = tuple(rep.shape)
+        return A
+
+    @staticmethod
+    def backward(ctx, dA):
+        (pix,) = ctx.saved_tensors
+        B, D = ctx.rep_shape[0], ctx.rep_shape[1]
+        sp = ctx.rep_shape[2:]
+        n_pix = B
+        for s in sp:
+            n_pix *= s
+        grad = torch.zeros((n_pix, D), device=dA.device, dtype=torch.float32)
+        dA = dA.contiguous()
+        L.call("arco_scatter_add_rows", L.ptr(dA), D, D, None, L.ptr(pix), int(pix.shape[0]), None, 1.0,
+               L.ptr(grad), D)
+        return grad.view(B, *sp, D).movedim(-1, 1), None
+
+
+class _CompactGrad(torch.autograd.Function):
+    """loss value with the precomputed d loss / d A attached to the compact anchor matrix A."""
+
+    @staticmethod
+    def forward(ctx, A, loss_val, dA):
+        ctx.save_for_backward(dA)
         return loss_val.clone()
 
     @staticmethod
     def backward(ctx, g):
-        B, D = ctx.rep_shape[0], ctx.rep_shape[1]
-        sp = tuple(ctx.rep_shape[2:])
-        n_pix = B
-        for s in sp:
-            n_pix *= s
-        grad = torch.zeros((n_pix, D), device=g.device, dtype=torch.float32)
-        gs = g.to(torch.float32).contiguous()
-        for (cls, idx, dA, ld) in ctx.pieces:
-            lst = ctx.lists[cls]
-            L.call("arco_scatter_add_rows", L.ptr(dA), ld, D, L.ptr(lst), L.ptr(idx), int(idx.shape[0]),
-                   L.ptr(gs), 1.0, L.ptr(grad), D)
-        return grad.view(B, *sp, D).movedim(-1, 1), None, None, None
+        (dA,) = ctx.saved_tensors
+        return dA * g, None, None
 
 
-def compute_contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask, memobank,
-                                 queue_prtlis, queue_size, rep_teacher, momentum_prototype=None, i_iter=0,
-                                 delta_n=1.0, func='asmc', num_queries=256, num_negatives=512, temp=0.5,
-                                 _trace=None):
+class ContrastPlan:
+    pass
+
+
+# ----------------------------------------------------------------------------------------------
+# stage 1 (GPU): masks + counts                                    loss_helper_3d.py:341-401
+# ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def contrast_masks(label_l, label_u, prob_l, prob_u, low_mask, high_mask, delta_n=1.0):
     L.load()
-    L.require_gpu(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask, rep_teacher)
-    dev = rep.device
-    D = int(rep.shape[1])
+    L.require_gpu(label_l, label_u, prob_l, prob_u, low_mask, high_mask)
+    pl = ContrastPlan()
+    dev = label_l.device
     C = int(label_l.shape[1])
     n_l, n_u = int(label_l.shape[0]), int(label_u.shape[0])
     P = 1
     for s in label_l.shape[2:]:
         P *= int(s)
     n_pix = (n_l + n_u) * P
-    if D % 4 != 0:
-        raise RuntimeError("arco_amd: feature dim must be a multiple of 4")
-
-    if func == 'asmc':                                                  # loss_helper_3d.py:327-338
-        draw, q_arg, n_arg = samplers.grid_as_monte_carlo_sample, num_queries, num_queries * num_negatives
-    elif func == 'smc':
-        draw, q_arg, n_arg = samplers.grid_monte_carlo_sample, num_queries, num_queries * num_negatives
-    else:
-        draw, q_arg, n_arg = torch.randint, (num_queries,), (num_queries * num_negatives,)
-
-    R, ldr = rows_view(rep)
-    T, ldt = rows_view(rep_teacher.detach())
     lab_l = label_l.to(torch.int64).contiguous()
     lab_u = label_u.to(torch.int64).contiguous()
-    pl = prob_l.detach().to(torch.float32).contiguous()
-    pu = prob_u.detach().to(torch.float32).contiguous()
+    p_l = prob_l.detach().to(torch.float32).contiguous()
+    p_u = prob_u.detach().to(torch.float32).contiguous()
     lowm = low_mask.to(torch.float32).contiguous()
     highm = high_mask.to(torch.float32).contiguous()
     assert lowm.numel() == n_pix and highm.numel() == n_pix
-
-    # ---- L1/L2: masks, counts, stable row lists, prototypes
     nblocks = (n_pix + 255) // 256
-    codes = torch.empty(n_pix, dtype=torch.int64, device=dev)
+    pl.codes = torch.empty(n_pix, dtype=torch.int64, device=dev)
     counts = torch.empty(3 * C * nblocks, dtype=torch.int32, device=dev)
-    offsets = torch.empty(3 * C * nblocks, dtype=torch.int32, device=dev)
-    totals = torch.empty(3 * C, dtype=torch.int64, device=dev)
-    L.call("arco_mask_codes", L.ptr(lab_l), L.ptr(lab_u), L.ptr(pl), L.ptr(pu), L.ptr(lowm), L.ptr(highm),
-           n_l, n_u, C, P, DELTA_P, float(delta_n), LOW_RANK, HIGH_RANK, L.ptr(codes), L.ptr(counts),
-           L.ptr(offsets), L.ptr(totals))
-    lists = torch.empty((2 * C, n_pix), dtype=torch.int32, device=dev)
-    L.call("arco_compact_rows", L.ptr(codes), n_pix, C, L.ptr(offsets), L.ptr(lists))
-    proto = torch.empty((C, D), dtype=torch.float32, device=dev)
+    pl.offsets = torch.empty(3 * C * nblocks, dtype=torch.int32, device=dev)
+    pl.totals = torch.empty(3 * C, dtype=torch.int64, device=dev)
+    L.call("arco_mask_codes", L.ptr(lab_l), L.ptr(lab_u), L.ptr(p_l), L.ptr(p_u), L.ptr(lowm), L.ptr(highm),
+           n_l, n_u, C, P, DELTA_P, float(delta_n), LOW_RANK, HIGH_RANK, L.ptr(pl.codes), L.ptr(counts),
+           L.ptr(pl.offsets), L.ptr(pl.totals))
+    pl.totals_host = torch.empty(3 * C, dtype=torch.int64).pin_memory()
+    pl.totals_host.copy_(pl.totals, non_blocking=True)
+    pl.ready = torch.cuda.Event()
+    pl.ready.record()
+    pl.C, pl.P, pl.n_pix, pl.dev = C, P, n_pix, dev
+    pl.spatial = tuple(int(s) for s in label_l.shape[2:])
+    pl.n_img = n_l + n_u
+    return pl
+
+
+# ----------------------------------------------------------------------------------------------
+# stage 2 (host): counters -> bank bookkeeping -> sampler replay      loss_helper_3d.py:413-476
+# ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def contrast_sample(pl, memobank, queue_size, func='asmc', num_queries=256, num_negatives=512, _trace=None):
+    pl.ready.synchronize()                                  # the one device->host dependency of the loss
+    C = pl.C
+    tot = pl.totals_host.tolist()
+    pl.n_lv, pl.n_anchor, pl.n_neg = tot[:C], tot[C:2 * C], tot[2 * C:]
+    n_neg_all = pl.n_neg if count_gather_hook is None else count_gather_hook(pl.n_neg)
+    pl.n_neg_all = n_neg_all
+    # bank lengths after this step's enqueue (loss_helper_3d.py:23-26)
+    pl.bank_len = [min(int(memobank[c][0].shape[0]) + int(n_neg_all[c]), int(queue_size[c])) for c in range(C)]
+    pl.valid_classes = [c for c in range(C) if pl.n_lv[c] > 0]        # :413-415
+    pl.valid_seg = len(pl.valid_classes)
+    pl.Q, pl.Nn = int(num_queries), int(num_negatives)
+    if func == 'asmc':                                                  # :327-338
+        draw, q_arg, n_arg = samplers.grid_as_monte_carlo_sample, pl.Q, pl.Q * pl.Nn
+    elif func == 'smc':
+        draw, q_arg, n_arg = samplers.grid_monte_carlo_sample, pl.Q, pl.Q * pl.Nn
+    else:
+        draw, q_arg, n_arg = torch.randint, (pl.Q,), (pl.Q * pl.Nn,)
+    pl.entries = []
+    if pl.valid_seg > 1:
+        for k in range(pl.valid_seg):                                   # :435-476, k = LOOP COUNTER
+            vc = pl.valid_classes[k]
+            if pl.n_anchor[k] == 0 or pl.bank_len[vc] == 0:
+                continue
+            a_idx = draw(int(pl.n_anchor[k]), q_arg)
+            n_idx = draw(int(pl.bank_len[vc]), n_arg)
+            pl.entries.append((k, vc, a_idx.pin_memory().to(pl.dev, non_blocking=True),
+                               n_idx.pin_memory().to(pl.dev, non_blocking=True)))
+            if _trace is not None:
+                _trace.setdefault("anchor_idx", []).append(a_idx)
+                _trace.setdefault("neg_idx", []).append(n_idx)
+    return pl
+
+
+# ----------------------------------------------------------------------------------------------
+# stage 3 (GPU): row lists, prototypes, key enqueue                 loss_helper_3d.py:376-411
+# ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace=None):
+    L.require_gpu(rep_teacher)
+    C, n_pix, dev = pl.C, pl.n_pix, pl.dev
+    T, ldt = rows_view(rep_teacher.detach())
+    D = int(rep_teacher.shape[1])
+    if D % 4 != 0:
+        raise RuntimeError("arco_amd: feature dim must be a multiple of 4")
+    pl.D = D
+    pl.lists = torch.empty((2 * C, n_pix), dtype=torch.int32, device=dev)
+    L.call("arco_compact_rows", L.ptr(pl.codes), n_pix, C, L.ptr(pl.offsets), L.ptr(pl.lists))
+    pl.proto = torch.empty((C, D), dtype=torch.float32, device=dev)
     ws = torch.empty(L.query("arco_proto_ws_floats", n_pix, C, D), dtype=torch.float32, device=dev)
-    L.call("arco_masked_proto", L.ptr(T), ldt, L.ptr(codes), n_pix, C, D, L.ptr(totals), L.ptr(ws), L.ptr(proto))
-    tot = totals.cpu().tolist()                                         # the one D2H sync of the call
-    n_lv, n_anchor, n_neg = tot[:C], tot[C:2 * C], tot[2 * C:]
-
-    # ---- L3: enqueue the new negative keys of every class (loss_helper_3d.py:403-411)
-    new_keys, seg_num, valid_classes = [], [], []
+    L.call("arco_masked_proto", L.ptr(T), ldt, L.ptr(pl.codes), n_pix, C, D, L.ptr(pl.totals), L.ptr(ws),
+           L.ptr(pl.proto))
+    pl.new_keys = []
     for c in range(C):
-        n = n_neg[c]
-        take = min(n, queue_size[c]) if key_gather_hook is None else n
+        n = int(pl.n_neg[c])
+        # only the last queue_size rows can survive cat(...)[-queue_size:] (per rank: an upper bound)
+        take = min(n, int(queue_size[c]))
         keys = torch.empty((take, D), dtype=torch.float32, device=dev)
-        L.call("arco_gather_rows", L.ptr(T), ldt, D, None, None, L.ptr(lists[C + c]), n - take, take,
+        L.call("arco_gather_rows", L.ptr(T), ldt, D, None, None, L.ptr(pl.lists[C + c]), n - take, take,
                L.ptr(keys), D)
-        if take < n:        # only the last queue_size rows can survive the truncation
-            pad_n = n
-            new_keys.append(_enqueue_counted(keys, pad_n, memobank[c], queue_prtlis[c], queue_size[c]))
-        else:
-            new_keys.append(dequeue_and_enqueue(keys, memobank[c], queue_prtlis[c], queue_size[c]))
-        if n_lv[c] > 0:                                                 # :413-415
-            seg_num.append(int(n_lv[c]))
-            valid_classes.append(c)
+        if key_gather_hook is not None:
+            keys = key_gather_hook(keys)
+        _append(keys, int(pl.n_neg_all[c]), memobank[c], queue_prtlis[c], int(queue_size[c]))
+        assert int(memobank[c][0].shape[0]) == pl.bank_len[c]
+        pl.new_keys.append(n)
     if _trace is not None:
-        _trace["lists"], _trace["totals"], _trace["proto"] = lists, tot, proto
+        _trace["lists"], _trace["totals"], _trace["proto"] = pl.lists, pl.totals_host.tolist(), pl.proto
+    # global pixel id of every sampled anchor, entries concatenated
+    if pl.entries:
+        pl.anchor_pix = torch.cat([pl.lists[k][a_dev].to(torch.int64) for (k, vc, a_dev, n_dev) in pl.entries])
+    else:
+        pl.anchor_pix = torch.empty(0, dtype=torch.int64, device=dev)
+    return pl
 
-    if len(seg_num) <= 1:                                               # :417-424
-        zero = rep.sum() * 0.0
-        return (new_keys, zero) if momentum_prototype is None else (momentum_prototype, new_keys, zero)
 
-    valid_seg = len(seg_num)
-    Q, Nn = int(num_queries), int(num_negatives)
+# ----------------------------------------------------------------------------------------------
+# stage 4 (GPU): InfoNCE over the compact anchor matrix             loss_helper_3d.py:478-513
+# ----------------------------------------------------------------------------------------------
+def contrast_infonce(pl, A_all, memobank, temp=0.5, momentum_prototype=None, i_iter=0):
+    """A_all [len(entries)*Q, D]: the sampled anchor rows (student), entries in plan order.
+    Returns (loss, prototype-or-None).  The gradient w.r.t. A_all is computed here (it only needs
+    forward quantities) and attached through _CompactGrad."""
+    dev, D, Q, Nn, C = pl.dev, pl.D, pl.Q, pl.Nn, pl.C
     Dp = _ceil(D, 16)
-    prototype = None
-    if momentum_prototype is not None:
-        prototype = torch.zeros((C, Q, 1, D), device=dev)
+    valid_seg = pl.valid_seg
+    need_grad = A_all.requires_grad and torch.is_grad_enabled()
+    prototype = torch.zeros((C, Q, 1, D), device=dev) if momentum_prototype is not None else None
     loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
-    pieces = []
-    need_grad = rep.requires_grad and torch.is_grad_enabled()
+    dA_all = torch.zeros((A_all.shape[0], D), dtype=torch.float32, device=dev) if need_grad else None
+    A_det = A_all.detach().contiguous()
     norm_cache = {}
-
-    # ---- L4: host index generation in the reference's call order (anchor, then negatives, per class)
-    plan = []
-    for k in range(valid_seg):                                          # :435-509, k = LOOP COUNTER
-        bank = memobank[valid_classes[k]][0]
-        if n_anchor[k] == 0 or bank.shape[0] == 0:
-            continue
-        a_idx = draw(int(n_anchor[k]), q_arg)
-        n_idx = draw(int(bank.shape[0]), n_arg)
-        plan.append((k, a_idx, n_idx))
-        if _trace is not None:
-            _trace.setdefault("anchor_idx", []).append(a_idx)
-            _trace.setdefault("neg_idx", []).append(n_idx)
-
-    for (k, a_idx, n_idx) in plan:
-        vc = valid_classes[k]
+    for e, (k, vc, a_dev, n_dev) in enumerate(pl.entries):
         bank = memobank[vc][0]
         Lb = int(bank.shape[0])
         Lp = _ceil(Lb, 16)
-        a_dev = a_idx.to(dev, non_blocking=True)
-        n_dev = n_idx.to(dev, non_blocking=True)
-        # anchors (student rows; gradient flows)                          :455-457
-        A = torch.empty((Q, D), dtype=torch.float32, device=dev)
-        L.call("arco_gather_rows", L.ptr(R), ldr, D, L.ptr(lists[k]), L.ptr(a_dev), None, 0, Q, L.ptr(A), D)
+        A = A_det[e * Q:(e + 1) * Q]
         An = torch.zeros((Q, Dp), dtype=torch.float32, device=dev)
         invA = torch.empty(Q, dtype=torch.float32, device=dev)
         L.call("arco_normalize_rows", L.ptr(A), D, Q, D, EPS, L.ptr(An), Dp, None, 0, L.ptr(invA))
-        # bank, normalised once per class                                  :466
-        if vc not in norm_cache:
+        if vc not in norm_cache:                                         # bank normalised once per class
             Bn = torch.zeros((Lp, Dp), dtype=torch.float32, device=dev)
             Bt = torch.zeros((Dp, Lp), dtype=torch.float32, device=dev) if need_grad else None
             L.call("arco_normalize_rows", L.ptr(bank), D, Lb, D, EPS, L.ptr(Bn), Dp, L.ptr(Bt), Lp, None)
             norm_cache[vc] = (Bn, Bt)
         Bn, Bt = norm_cache[vc]
-        # positive = prototype of LOOP-COUNTER class k                     :480-486
-        pos = proto[k].view(1, D)
+        pos = pl.proto[k].view(1, D)              # prototype of LOOP-COUNTER class k    (:480-486)
         if momentum_prototype is not None:                               # :488-497
             pos = pos.view(1, 1, D).repeat(Q, 1, 1)
             if not bool((momentum_prototype == 0).all()):
                 decay = min(1 - 1 / i_iter, 0.999)
                 pos = (1 - decay) * pos + decay * momentum_prototype[vc].to(dev)
             prototype[vc] = pos.clone()
-            pos = pos.view(Q, D).contiguous()
+            pos = pos.view(Q, D)
+        pos = pos.contiguous()
         nP = int(pos.shape[0])
         Pn = torch.zeros((nP, Dp), dtype=torch.float32, device=dev)
-        L.call("arco_normalize_rows", L.ptr(pos.contiguous()), D, nP, D, EPS, L.ptr(Pn), Dp, None, 0, None)
+        L.call("arco_normalize_rows", L.ptr(pos), D, nP, D, EPS, L.ptr(Pn), Dp, None, 0, None)
         ldp = Dp if nP > 1 else 0
-        # scores vs the whole bank on the matrix cores, then multiplicity-weighted softmax-CE   :503-509
+        # scores vs the whole bank on the matrix cores, multiplicity-weighted softmax-CE     (:503-509)
         S = torch.empty((Q, Lp), dtype=torch.float32, device=dev)
         L.call("arco_conv_fwd", L.ptr(An), Dp, Dp, L.ptr(Bn), Lb, L.ptr(S), Lp, None, None, 0, None, None,
                1, 1, 1, Q)
@@ -252,25 +319,32 @@ def compute_contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask
             dA = torch.empty((Q, Dp), dtype=torch.float32, device=dev)
             L.call("arco_infonce_anchor_grad", L.ptr(G), L.ptr(An), L.ptr(Pn), ldp, L.ptr(gpos), L.ptr(invA),
                    Q, Dp, EPS, 1.0 / (Q * valid_seg), L.ptr(dA))
-            pieces.append((k, a_dev, dA, Dp))
-
+            dA_all[e * Q:(e + 1) * Q] = dA[:, :D]
     loss = loss_acc[0]
     if need_grad:
-        loss = _AnchorGrad.apply(rep, loss, lists, pieces)
+        loss = _CompactGrad.apply(A_all, loss, dA_all)
+    return loss, prototype
+
+
+def compute_contra_memobank_loss(rep, label_l, label_u, prob_l, prob_u, low_mask, high_mask, memobank,
+                                 queue_prtlis, queue_size, rep_teacher, momentum_prototype=None, i_iter=0,
+                                 delta_n=1.0, func='asmc', num_queries=256, num_negatives=512, temp=0.5,
+                                 _trace=None):
+    L.load()
+    L.require_gpu(rep, rep_teacher)
+    pl = contrast_masks(label_l, label_u, prob_l, prob_u, low_mask, high_mask, delta_n)
+    contrast_sample(pl, memobank, queue_size, func, num_queries, num_negatives, _trace)
+    contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace)
+    if pl.valid_seg <= 1:                                               # :417-424
+        zero = rep.sum() * 0.0
+        return (pl.new_keys, zero) if momentum_prototype is None else (momentum_prototype, pl.new_keys, zero)
+    if pl.entries:
+        A_all = GatherRowsFn.apply(rep, pl.anchor_pix)                  # :455-457 (grad flows to rep rows)
+        loss, prototype = contrast_infonce(pl, A_all, memobank, temp, momentum_prototype, i_iter)
+    else:
+        loss = rep.sum() * 0.0
+        prototype = torch.zeros((pl.C, int(num_queries), 1, int(rep.shape[1])), device=rep.device) \
+            if momentum_prototype is not None else None
     if momentum_prototype is None:
-        return new_keys, loss
-    return prototype, new_keys, loss
-
-
-@torch.no_grad()
-def _enqueue_counted(keys_tail, n_total, queue, queue_ptr, queue_size):
-    """Enqueue when only the last `queue_size` of `n_total` new keys were gathered
-    (the rest cannot survive cat(...)[-queue_size:]); returns n_total like the reference."""
-    D = int(keys_tail.shape[1])
-    old = queue[0].to(device=keys_tail.device, dtype=torch.float32).contiguous()
-    out = torch.empty((queue_size, D), device=keys_tail.device, dtype=torch.float32)
-    L.call("arco_bank_append", L.ptr(old), int(old.shape[0]), L.ptr(keys_tail), int(keys_tail.shape[0]),
-           queue_size, D, L.ptr(out))
-    queue[0] = out
-    queue_ptr[0] = queue_size
-    return n_total
+        return pl.new_keys, loss
+    return prototype, pl.new_keys, loss

@@ -17,15 +17,17 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
   return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
-// ---- BN statistics finalize: block partial (sum, sumsq) -> mean, istd, running stats
-__global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
+// ---- BN statistics finalize: block partial (sum, sumsq) -> mean, istd, running stats.
+//      One 64-lane wave per channel; fp64 tree over the partial slabs.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
                                    double count, float eps, float momentum, float* __restrict__ mean,
                                    float* __restrict__ istd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += (double)ssum[(long)c * nblk + b]; q += (double)ssq[(long)c * nblk + b]; }
+  for (int b = threadIdx.x; b < nblk; b += 64) { s += (double)ssum[(long)c * nblk + b]; q += (double)ssq[(long)c * nblk + b]; }
+  s = wave_sum_d(s); q = wave_sum_d(q);
+  if (threadIdx.x != 0) return;
   const double m = s / count;
   double var = q / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -134,12 +136,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int nblk, int C,
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int nblk, int C,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double a = 0.0, b = 0.0;
-  for (int i = 0; i < nblk; ++i) { a += (double)s_dy[(long)c * nblk + i]; b += (double)s_dyx[(long)c * nblk + i]; }
+  for (int i = threadIdx.x; i < nblk; i += 64) { a += (double)s_dy[(long)c * nblk + i]; b += (double)s_dyx[(long)c * nblk + i]; }
+  a = wave_sum_d(a); b = wave_sum_d(b);
+  if (threadIdx.x != 0) return;
   dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
   dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
 }
@@ -291,6 +294,64 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
   }
 }
 
+// ---- anchor-row gather of cat(bilinear_up(lo), hi) and its adjoint (row-sparse student head).
+// For anchor j with high-res pixel id pix[j] = (n, y, x):  X[j][0..Clo) = align_corners bilinear
+// sample of `lo` at (y, x) (same fp32 index math / lerp order as bilinear_fwd_kernel, so rows are
+// bit-identical to the dense upsample+cat), X[j][Clo..Clo+Chi) = hi[pix[j]].
+__global__ __launch_bounds__(256) void gather_upcat_rows_kernel(const float* __restrict__ lo, long ldlo, int Clo, int Hi, int Wi,
+                                                               const float* __restrict__ hi, long ldhi, int Chi, int Ho, int Wo,
+                                                               const int64_t* __restrict__ pix, long n, float* __restrict__ X, long ldx) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const long p = pix[j];
+  const long img = p / ((long)Ho * Wo); const int rem = (int)(p - img * (long)Ho * Wo);
+  const int yo = rem / Wo, xo = rem - yo * Wo;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  int y0, y1, x0, x1; float ly, lx;
+  ac_src(yo, sh, Hi, y0, y1, ly); ac_src(xo, sw, Wi, x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* b = lo + (img * Hi) * (long)Wi * ldlo;
+  const float* r00 = b + ((long)y0 * Wi + x0) * ldlo; const float* r01 = b + ((long)y0 * Wi + x1) * ldlo;
+  const float* r10 = b + ((long)y1 * Wi + x0) * ldlo; const float* r11 = b + ((long)y1 * Wi + x1) * ldlo;
+  float* o = X + j * ldx;
+  for (int c = lane * 4; c < Clo; c += 256) {
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(r00 + c), v01 = *reinterpret_cast<const f32x4*>(r01 + c);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(r10 + c), v11 = *reinterpret_cast<const f32x4*>(r11 + c);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(o + c) = r;
+  }
+  const float* h = hi + p * ldhi;
+  for (int c = lane * 4; c < Chi; c += 256) *reinterpret_cast<f32x4*>(o + Clo + c) = *reinterpret_cast<const f32x4*>(h + c);
+}
+__global__ __launch_bounds__(256) void scatter_upcat_rows_kernel(const float* __restrict__ dX, long ldx, const int64_t* __restrict__ pix, long n,
+                                                                float* __restrict__ dlo, long ldlo, int Clo, int Hi, int Wi,
+                                                                float* __restrict__ dhi, long ldhi, int Chi, int Ho, int Wo) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const long p = pix[j];
+  const long img = p / ((long)Ho * Wo); const int rem = (int)(p - img * (long)Ho * Wo);
+  const int yo = rem / Wo, xo = rem - yo * Wo;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  int y0, y1, x0, x1; float ly, lx;
+  ac_src(yo, sh, Hi, y0, y1, ly); ac_src(xo, sw, Wi, x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  float* b = dlo + (img * Hi) * (long)Wi * ldlo;
+  float* r00 = b + ((long)y0 * Wi + x0) * ldlo; float* r01 = b + ((long)y0 * Wi + x1) * ldlo;
+  float* r10 = b + ((long)y1 * Wi + x0) * ldlo; float* r11 = b + ((long)y1 * Wi + x1) * ldlo;
+  const float* g = dX + j * ldx;
+  for (int c = lane; c < Clo; c += 64) {
+    const float v = g[c];
+    atomicAdd(r00 + c, hy * hx * v); atomicAdd(r01 + c, hy * lx * v);
+    atomicAdd(r10 + c, ly * hx * v); atomicAdd(r11 + c, ly * lx * v);
+  }
+  float* h = dhi + p * ldhi;
+  for (int c = lane; c < Chi; c += 64) atomicAdd(h + c, g[Clo + c]);
+}
+
 // ---- strided channel-slice copy / add:  Y[r][0..C) (+)= X[r][0..C)
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ X, long ldx, long M, int C,
                                                        float* __restrict__ Y, long ldy, int accumulate) {
@@ -367,12 +428,12 @@ extern "C" {
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
                      float* mean, float* istd, float* running_mean, float* running_var, void* stream) {
   ARCO_CHECK_ARG(C > 0 && nblk > 0 && count > 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), ssum, ssq, nblk, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), ssum, ssq, nblk, C,
                      (double)count, eps, momentum, mean, istd, running_mean, running_var);
   return arco_launch_status();
 }
 
-int arco_chan_stats_blocks(long M) { long b = (M + 2047) / 2048; if (b > 512) b = 512; if (b < 1) b = 1; return (int)b; }
+int arco_chan_stats_blocks(long M) { long b = (M + 511) / 512; if (b > 2048) b = 2048; if (b < 1) b = 1; return (int)b; }
 
 int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream) {
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldx & 3) == 0);
@@ -404,12 +465,12 @@ int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
     float* s_dy = ws; float* s_dyx = ws + (long)C * nblk; float* sums = ws + 2l * C * nblk;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, M,
                        C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums + C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums + C,
                        sums, 0);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
                        mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)M, dZ, ldo);
     // grads: dbeta = sum dy, dgamma = sum dy*xhat
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, s_dy, s_dyx, nblk, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, dgamma,
                        dbeta, accumulate);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
@@ -444,6 +505,22 @@ int arco_bilinear_bwd(const float* dY, long ldy, int NB, int Hi, int Wi, int C, 
   ARCO_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0);
   hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_grid((long)NB * Hi * Wi * (C / 4))), dim3(256), 0, as_stream(stream),
                      dY, ldy, NB, Hi, Wi, C, Ho, Wo, dX, ldx, accumulate);
+  return arco_launch_status();
+}
+
+int arco_gather_upcat_rows(const float* lo, long ldlo, int Clo, int Hi, int Wi, const float* hi, long ldhi, int Chi,
+                           int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream) {
+  ARCO_CHECK_ARG((Clo & 3) == 0 && (Chi & 3) == 0 && (ldlo & 3) == 0 && (ldhi & 3) == 0 && (ldx & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(gather_upcat_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), lo, ldlo, Clo, Hi, Wi,
+                     hi, ldhi, Chi, Ho, Wo, pix, n, X, ldx);
+  return arco_launch_status();
+}
+int arco_scatter_upcat_rows(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo, int Hi,
+                            int Wi, float* dhi, long ldhi, int Chi, int Ho, int Wo, void* stream) {
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(scatter_upcat_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), dX, ldx, pix, n, dlo,
+                     ldlo, Clo, Hi, Wi, dhi, ldhi, Chi, Ho, Wo);
   return arco_launch_status();
 }
 

@@ -375,24 +375,40 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int chunk
   dW[i] = accumulate ? dW[i] + s : s;
 }
 
-// column sums (bias gradient): out[c] = sum_pix X[pix][c]
+// column sums (bias gradient): out[c] = sum_pix X[pix][c].  float4 lanes along channels,
+// rows strided over the block, per-block slabs + fp64 fixed-order finalize.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, long M, int C,
                                                             float* __restrict__ partial) {
-  // block handles a pixel range; thread t handles channel t % C for rows t / C + k*(256/C)
-  const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
-  const long r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += X[r * ldx + c];
-    partial[(long)blockIdx.x * C + c] = s;
+  const long rpb = (M + gridDim.x - 1) / gridDim.x;
+  const long r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [256][4]
+  if ((C & 3) == 0 && (ldx & 3) == 0 && C <= 1024) {
+    const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
+    f32x4 s = {0, 0, 0, 0};
+    if (tr < rstep)
+      for (long r = r0 + tr; r < r1; r += rstep) s += *reinterpret_cast<const f32x4*>(X + r * ldx + 4 * tq);
+    *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int qq = c / 4, e = c % 4;
+      float a = 0.f;
+      for (int r = 0; r < rstep; ++r) a += red[(r * q4 + qq) * 4 + e];
+      partial[(long)blockIdx.x * C + c] = a;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f;
+      for (long r = r0; r < r1; ++r) s += X[r * ldx + c];
+      partial[(long)blockIdx.x * C + c] = s;
+    }
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * C + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)partial[(long)b * C + c];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 __global__ void transpose2d_kernel(const float* __restrict__ x, long ldx, int rows, int cols, float* __restrict__ y, long ldy) {
@@ -492,12 +508,12 @@ int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long
   return arco_launch_status();
 }
 
-// out[c] (+)= sum over pixels of X[pix][c];  ws holds 256*C floats
+// out[c] (+)= sum over pixels of X[pix][c];  ws holds 1024*C floats
 int arco_colsum(const float* X, long ldx, long M, int C, float* ws, float* out, int accumulate, void* stream) {
   ARCO_CHECK_ARG(X && ws && out && M > 0 && C > 0);
-  int nblk = (int)((M + 1023) / 1024); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), X, ldx, M, C, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), ws, nblk, C, out, accumulate);
+  int nblk = (int)((M + 511) / 512); if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 1024 * sizeof(float), as_stream(stream), X, ldx, M, C, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, as_stream(stream), ws, nblk, C, out, accumulate);
   return arco_launch_status();
 }
 

@@ -39,6 +39,7 @@ def init(backend=None):
         td.init_process_group(backend=backend)
     if is_dist():
         _contrast.key_gather_hook = gather_keys
+        _contrast.count_gather_hook = gather_counts
         return td.get_rank(), td.get_world_size()
     return 0, 1
 
@@ -79,3 +80,12 @@ def gather_keys(keys):
     out = [torch.empty_like(pad) for _ in range(world)]
     td.all_gather(out, pad)
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+
+
+def gather_counts(counts):
+    """Per-class key counts summed over ranks (host ints in, host ints out): bank lengths and queue
+    pointers are then identical on every rank."""
+    dev = torch.device("cuda", local_rank()) if td.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]

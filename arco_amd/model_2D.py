@@ -30,14 +30,22 @@ class FeatureExtractor(nn.Module):
         cnt += fea_dim[4]
         self.fea4 = nn.Conv2d(in_channels=cnt, out_channels=output_dim, kernel_size=1, bias=False)
 
-    def forward(self, fea_list):
+    def forward_lowres(self, fea_list):
+        """Everything up to (not including) the last upsample: returns (fea3(x)+x at the
+        second-finest level, finest feature map).  Used by the row-sparse head (arco_amd.head)."""
         f = [ops.to_channels_last(t) for t in fea_list]
         x = ops.conv(f[0], self.fea0.weight, None, residual=True)          # fea0(f0) + f0
-        for i, fea in enumerate((self.fea1, self.fea2, self.fea3, self.fea4), start=1):
+        for i, fea in enumerate((self.fea1, self.fea2, self.fea3), start=1):
             x = ops.bilinear(x, f[i].shape[-2:])
             x = torch.cat((x, f[i]), dim=1)
-            x = ops.conv(x, fea.weight, None, residual=(i < 4))            # fea_i(x) + x ; fea4(x)
-        return x
+            x = ops.conv(x, fea.weight, None, residual=True)               # fea_i(x) + x
+        return x, f[4]
+
+    def forward(self, fea_list):
+        x, f4 = self.forward_lowres(fea_list)
+        x = ops.bilinear(x, f4.shape[-2:])
+        x = torch.cat((x, f4), dim=1)
+        return ops.conv(x, self.fea4.weight, None, residual=False)         # fea4(x)
 
 
 def create_model(ema=False, num_classes=4, train_encoder=True, train_decoder=True):

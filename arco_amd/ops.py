@@ -85,7 +85,7 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like):
 
 
 def colsum(xr, ld, m, c):
-    ws = torch.empty(256 * c, dtype=torch.float32, device=xr.device)
+    ws = torch.empty(1024 * c, dtype=torch.float32, device=xr.device)
     out = torch.empty(c, dtype=torch.float32, device=xr.device)
     L.call("arco_colsum", L.ptr(xr), ld, m, c, L.ptr(ws), L.ptr(out), 0)
     return out

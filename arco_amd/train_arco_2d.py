@@ -24,8 +24,8 @@ import torch
 import torch.nn as nn
 
 from . import dist as adist
-from . import glue, ops, optim
-from .loss_helper_3d import compute_contra_memobank_loss
+from . import _contrast as C_
+from . import glue, head, ops, optim
 from .model_2D import ISD, FeatureExtractor
 
 FEA_DIM = [256, 128, 64, 32, 16]
@@ -84,6 +84,7 @@ def build_parser():
     p.add_argument('--queue_size', type=int, default=0, help='override per-class bank size (0 = reference 50000/30000)')
     p.add_argument('--synthetic', type=int, default=0, help='1: train on synthetic ACDC-shaped tensors')
     p.add_argument('--in_chns', type=int, default=1, help='input channels (reference: 1)')
+    p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
     return p
 
 
@@ -155,28 +156,25 @@ class ArcoStep2D:
 
     def step(self, l_data, l_label, u_data, epoch_num=0, max_epoch=1):
         """One iteration.  Augmentations (augment.py; CPU/PIL, out of scope) are the identity here:
-        train_u_aug_* = (u_data, pseudo_labels, pseudo_logits), images_cj2_l = l_data."""
+        train_u_aug_* = (u_data, pseudo_labels, pseudo_logits), images_cj2_l = l_data.
+
+        Same operations and results as train_arco_2d.py:284-435 restricted to the hot-path loss term;
+        the ORDER is arranged for the GPU: everything the host sampler needs (3*C counters) is
+        produced first and copied asynchronously, the large teacher/student GEMMs are queued behind
+        it, and the torch-CPU-generator index replay runs on the host while they execute."""
         a = self.args
         C = a.num_classes
+        dense = getattr(a, "dense_head", 0)
         with torch.no_grad():                                            # :284-286
             pred_u0, _, _ = self.ema_model(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits
         self.k_fe_ema.update(0.99)                                      # :306-308
-        pred_l, _, l_fm = self.model(l_data)                             # :310
-        with torch.no_grad():
-            self.model(l_data)       # images_cj2_l forward (:311): BN running stats only; its FE/q_rep
-                                     # outputs (l_feature_map_2, :319,326) are never read -> not computed
-        pred_u, _, u_fm = self.model(u_aug)                              # :312
+        pred_u, _, u_fm = self.model(u_aug)                              # :312 (needed first: entropy masks)
         with torch.no_grad():                                            # teacher params carry no grad (:158-160)
             pred_l_t, _, l_fm_t = self.ema_model(l_data)                 # :314
             pred_u_t, _, u_fm_t = self.ema_model(u_aug)                  # :315
-            # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
-            rep_all_teacher = self.k_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)])
-        feat_all = self.q_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm, u_fm)])   # :317-318
-        rep_all = self.q_rep(feat_all)                                   # :324-325,330
-        with torch.no_grad():                                            # :342-393
-            alpha_t = 20 * (1 - epoch_num / max_epoch)
+            alpha_t = 20 * (1 - epoch_num / max_epoch)                   # :342-393
             label_l = glue.label_onehot(l_label, C)
             label_u = glue.label_onehot(u_aug_label, C)
             prob_l_t = glue.softmax(pred_l_t)
@@ -184,12 +182,38 @@ class ArcoStep2D:
             low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-        reco_loss = compute_contra_memobank_loss(                        # :394-398
-            rep_all, label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all, self.memobank,
-            self.queue_ptrlis, self.queue_size, rep_all_teacher, delta_n=a.strong_threshold_u2pl, func=a.func,
-            num_queries=a.num_queries, num_negatives=a.num_negatives)[-1]
+        plan = C_.contrast_masks(label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all,
+                                 delta_n=a.strong_threshold_u2pl)       # :341-401 (counts -> async D2H)
         ev[1].record()
-        self.loss_events.append(ev)
+        # ---- large GPU work queued while the host waits for the counters and samples
+        pred_l, _, l_fm = self.model(l_data)                             # :310
+        with torch.no_grad():
+            self.model(l_data)       # images_cj2_l forward (:311): BN running stats only; its FE/q_rep
+                                     # outputs (l_feature_map_2, :319,326) are never read -> not computed
+            # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
+            rep_all_teacher = self.k_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)])
+        fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]         # :317-318
+        if dense:
+            rep_all = self.q_rep(self.q_feature_extractor(fm_all))       # :324-325,330
+        else:
+            x3p, f4 = self.q_feature_extractor.forward_lowres(fm_all)
+        # ---- host: sampler replay (bit-exact torch-CPU-generator sequence), overlapped with the above
+        C_.contrast_sample(plan, self.memobank, self.queue_size, a.func, a.num_queries, a.num_negatives)
+        ev2 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev2[0].record()
+        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size)
+        if plan.valid_seg <= 1 or not plan.entries:
+            reco_loss = self.q_representation[1].weight.sum() * 0.0      # :417-424 zero attached to the graph
+        else:
+            if dense:
+                A_all = C_.GatherRowsFn.apply(rep_all, plan.anchor_pix)
+            else:
+                A_all = head.lazy_head(x3p, f4, self.q_feature_extractor.fea4.weight,
+                                       self.q_representation[0].weight, self.q_representation[1].weight,
+                                       plan.anchor_pix)
+            reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)   # :394-398 (temp default)
+        ev2[1].record()
+        self.loss_events.append((ev, ev2))
         loss = a.k1 * reco_loss                                          # :426 (hot-path term)
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()

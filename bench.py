@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch_size", type=int, default=8)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--dense_head", type=int, default=0)
     a = ap.parse_args()
 
     from arco_amd import dist as adist
@@ -56,7 +57,7 @@ def main():
     random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 
     args = T.build_parser().parse_args(["--batch_size", str(a.batch_size), "--queue_size", "4096", "--func", "smc",
-                                        "--synthetic", "1"])
+                                        "--synthetic", "1", "--dense_head", str(a.dense_head)])
     stepper = T.ArcoStep2D(args, dev)
     b = a.batch_size
     batches = []
@@ -113,7 +114,8 @@ def main():
                                    "(BASELINE.json configs[1])", "batch_size_per_stream": b, "images_per_step_per_gpu": 2 * b,
                        "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc",
                        "parallelism": f"dp{world}"},
-            "contrastive_loss_fwd_ms_per_step": round(sum(s.elapsed_time(e) for s, e in stepper.loss_events)
+            "contrastive_loss_fwd_ms_per_step": round(sum(a[0].elapsed_time(a[1]) + b[0].elapsed_time(b[1])
+                                                          for a, b in stepper.loss_events)
                                                       / max(1, len(stepper.loss_events)), 3),
             "roofline": roof,
         }
