@@ -46,7 +46,8 @@ def as_monte_carlo_sample(high=5233, shape=256, patch=16):
 
 
 def _grid(high, shape, cut, mirror):
-    # loss_helper_3d.py:120-184 / :187-268
+    # loss_helper_3d.py:120-184 / :187-268.  Only the generator calls go through torch (they
+    # define the sequence); the index arithmetic is numpy (no intra-op thread fan-out on tiny arrays).
     edge = round(math.sqrt(high))
     side = edge // cut
     if side <= 1:
@@ -56,27 +57,33 @@ def _grid(high, shape, cut, mirror):
     per_block = shape * edge * edge // high // (cut * cut)
     take = per_block // 2 if mirror else per_block
     last = edge - (cut - 1) * side
-    chunks = []
+    nblk = cut * cut
+    local = np.empty((nblk, take), dtype=np.int64)
+    wid = np.empty((nblk, 1), dtype=np.int64)
+    org = np.empty((nblk, 1), dtype=np.int64)
+    fin = np.empty((nblk, 1), dtype=np.int64)
+    i = 0
     for bi in range(cut):
         h = last if bi == cut - 1 else side
         for bj in range(cut):
             w = last if bj == cut - 1 else side
             n = h * w
-            perm = torch.randperm(n)
-            local = perm[torch.randint(n, (take,))]
-            val = (bi * side + local // w) * edge + bj * side + local % w
-            chunks.append(val)
-            if mirror:
-                # int64(2*mean(block)) == first + last element of the rectangular block (exact)
-                first = (bi * side) * edge + bj * side
-                final = (bi * side + h - 1) * edge + bj * side + w - 1
-                chunks.append(first + final - val)
-    vals = torch.cat(chunks).to(torch.float32).long()              # :163 / :245-246
+            perm = torch.randperm(n).numpy()
+            local[i] = perm[torch.randint(n, (take,)).numpy()]
+            wid[i, 0] = w
+            org[i, 0] = (bi * side) * edge + bj * side
+            # int64(2*mean(block)) == first + last element of the rectangular block (exact)
+            fin[i, 0] = org[i, 0] + (bi * side + h - 1) * edge + bj * side + w - 1
+            i += 1
+    val = org + (local // wid) * edge + local % wid
+    if mirror:
+        val = np.stack((val, fin - val), axis=1)          # block0 picks, block0 mirrors, block1 picks, ...
+    vals = val.reshape(-1).astype(np.float32).astype(np.int64)     # float32 round trip (:163 / :245-246)
     vals = vals[vals < high]
-    vals = vals[torch.randperm(vals.shape[0])]
+    vals = vals[torch.randperm(vals.shape[0]).numpy()]
     if vals.shape[0] < shape:
-        vals = torch.cat([vals, torch.randint(high, (shape - vals.shape[0],))])
-    return vals[:shape]
+        vals = np.concatenate([vals, torch.randint(high, (shape - vals.shape[0],)).numpy()])
+    return torch.from_numpy(np.ascontiguousarray(vals[:shape]))
 
 
 @torch.no_grad()
