@@ -57,6 +57,9 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
     "arco_chan_stats_blocks": ([_L], _I),
     "arco_sel_state_bytes": ([], _L),
+    # host-side native sampler replay (no GPU work)
+    "arco_grid_sample": ([_P, _L, _L, _L, _I, _I, _P], _L),
+    "arco_randint": ([_P, _L, _L, _L, _P], _L),
 }
 EXPORTS = sorted(list(_SIGS) + list(_QUERIES))
 

@@ -86,13 +86,39 @@ def _grid(high, shape, cut, mirror):
     return torch.from_numpy(np.ascontiguousarray(vals[:shape]))
 
 
+def _grid_native(high, shape, cut, mirror):
+    """Same draws through the native mt19937 replay (csrc/sampler_host.hip) on the serialized
+    generator state; returns NotImplemented when the library / state layout is unavailable."""
+    try:
+        from . import _lib
+        lib = _lib.load()
+    except (RuntimeError, OSError):
+        return NotImplemented
+    if high >= 2 ** 31:
+        return NotImplemented
+    st = torch.get_rng_state()
+    out = torch.empty(shape, dtype=torch.int64)
+    rc = lib.arco_grid_sample(st.data_ptr(), st.numel(), int(high), int(shape), int(cut), int(mirror), out.data_ptr())
+    if rc == 0:
+        return None                      # reference falls back to the 1-D sampler, nothing drawn
+    if rc != shape:
+        return NotImplemented
+    torch.set_rng_state(st)
+    return out
+
+
+def _grid_any(high, shape, cut, mirror):
+    out = _grid_native(high, shape, cut, mirror)
+    return _grid(high, shape, cut, mirror) if out is NotImplemented else out
+
+
 @torch.no_grad()
 def grid_monte_carlo_sample(high=5233, shape=256, cut_count=4):
-    out = _grid(high, shape, cut_count, False)
+    out = _grid_any(high, shape, cut_count, False)
     return monte_carlo_sample(high, shape) if out is None else out
 
 
 @torch.no_grad()
 def grid_as_monte_carlo_sample(high=5233, shape=256, cut_count=4):
-    out = _grid(high, shape, cut_count, True)
+    out = _grid_any(high, shape, cut_count, True)
     return as_monte_carlo_sample(high, shape) if out is None else out

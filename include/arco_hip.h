@@ -1,0 +1,135 @@
+/* arco_hip.h - C ABI of libarco_hip.so: the MI355X (gfx950) kernels behind the ARCO
+ * stratified pixel-contrastive training hot path.
+ *
+ * The reference (charlesyou999648/ARCO) is pure Python/PyTorch: it has no FFI layer, so the
+ * "interface each entry point replaces" is the PyTorch call sequence at the cited reference
+ * file:line (paths relative to the reference's code/ directory).  The Python host
+ * (arco_amd/*.py) binds these with ctypes (arco_amd/_lib.py); INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *    (PyTorch allocates), except the two host-side sampler entry points at the end;
+ *  - no allocation, no ownership transfer, no global state: kernels are stateless, re-entrant,
+ *    and are enqueued on the caller's HIP stream (`stream` = hipStream_t);
+ *  - activations are channels-last fp32 "rows": pixel p of an [N, C, *spatial] tensor is the C
+ *    consecutive floats at base + p*ld (ld >= C lets a channel slice be used in place);
+ *  - return 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 unsupported);
+ *    the *_ws_* / *_blocks / *_bytes helpers return sizes.
+ */
+#ifndef ARCO_HIP_H
+#define ARCO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- L1/L2  per-pixel class masks, counts, stable compaction (loss_helper_3d.py:341-342,352-358,
+ *      364-401; loss_helper.py:512-572).  codes: bit c = low-valid, 21+c = anchor candidate,
+ *      42+c = negative key (C <= 21).  totals = [n_low_valid[C] | n_anchor[C] | n_neg[C]].           */
+int arco_mask_codes(const int64_t* lab_l, const int64_t* lab_u, const float* prob_l, const float* prob_u,
+                    const float* low_mask, const float* high_mask, int n_l_img, int n_u_img, int C, long P,
+                    float delta_p, float delta_n, int low_rank, int high_rank, uint64_t* codes,
+                    uint32_t* block_counts, uint32_t* block_offsets, int64_t* totals, void* stream);
+/* lists[(kind*C + c)*n_pix + j] = row id of the j-th anchor (kind 0) / negative (kind 1) pixel of class c,
+ * in (b, spatial) row-major order == torch boolean-mask order (loss_helper_3d.py:377,403).                */
+int arco_compact_rows(const uint64_t* codes, long n_pix, int C, const uint32_t* block_offsets, int32_t* lists,
+                      void* stream);
+/* prototype[c] = mean of teacher rows over low-valid pixels (loss_helper_3d.py:380-384); NaN when empty. */
+long arco_proto_ws_floats(long n_pix, int C, int D);
+int arco_masked_proto(const float* T, long ldt, const uint64_t* codes, long n_pix, int C, int D,
+                      const int64_t* totals, float* partial, float* proto, void* stream);
+/* out[j] = src[list ? list[idx[j]] : idx[j]], idx = idx64 | idx32 | identity, j in [first, first+n)
+ * (rep[mask][idx] / rep_teacher[negative_mask], loss_helper_3d.py:403,455-457).                           */
+int arco_gather_rows(const float* src, long ld_src, int D, const int32_t* list, const int64_t* idx64,
+                     const int32_t* idx32, long first, long n, float* out, long ld_out, void* stream);
+/* ---- L3  out = cat(old, keys)[-min(len_old+n, queue_size):]  (dequeue_and_enqueue, loss_helper_3d.py:12-32) */
+int arco_bank_append(const float* old, long len_old, const float* keys, long n, long queue_size, int D, float* out,
+                     void* stream);
+/* ---- L6  InfoNCE (loss_helper_3d.py:503-509): y = x/max(||x||,eps) (+transposed copy, +1/norm) ...      */
+int arco_normalize_rows(const float* x, long ldx, long n, int D, float eps, float* y, long ldy, float* yt, long ldyt,
+                        float* inv, void* stream);
+/* ... M[q][k] = multiplicity of bank row k among query q's sampled negatives ...                          */
+int arco_neg_multiplicity(const int64_t* idx, int Q, int Nn, long L, long ld, uint32_t* M, void* stream);
+/* ... loss_q = logsumexp([pos, S[q, idx]]/T) - pos/T ; W = d loss_q/dS ; gpos = d loss_q/dpos             */
+int arco_infonce_fwd(const float* S, long ld, const uint32_t* M, long L, const float* An, const float* Pn, long ldp,
+                     int Q, int D, float temp, float* W, float* gpos, float* loss_q, void* stream);
+/* ... dA = scale * d(loss)/dA through the cosine normalisation (G = W @ Bn)                                */
+int arco_infonce_anchor_grad(const float* G, const float* An, const float* Pn, long ldp, const float* gpos,
+                             const float* inv, int Q, int D, float eps, float scale, float* dA, void* stream);
+/* dst[list?list[idx[j]]:idx[j]] += alpha * (alpha_dev?*alpha_dev:1) * src[j]  (backward of the anchor gather) */
+int arco_scatter_add_rows(const float* src, long ld_src, int D, const int32_t* list, const int64_t* idx, long n,
+                          const float* alpha_dev, float alpha, float* dst, long ld_dst, void* stream);
+int arco_sum_scale(const float* x, int n, float scale, float* out, int accumulate, void* stream);
+
+/* ---- N1-N4  convolutions on the fp32 matrix cores (nn.Conv2d 3x3 / 1x1: unetWithArgs.py:36-44,72,139;
+ *      model_2D.py:25-33; train_arco_2d.py:231-234).  Wp = packed weights [taps][ceil16(N)][ceil16(K)].    */
+int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream);
+int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout);
+/* out = conv(in) (+bias)(+residual); optional per-channel (sum, sumsq) block partials for train-mode BN. */
+int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                  const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                  int NB, int H, int W, void* stream);
+long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M);
+/* dW[co][ci][tap] (+)= sum_pix dZ[pix][co] * in[pix+tap][ci]   (torch weight layout)                      */
+int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NB,
+                    int H, int W, float* ws, float* dW, int accumulate, void* stream);
+int arco_colsum(const float* X, long ldx, long M, int C, float* ws, float* out, int accumulate, void* stream);
+int arco_transpose2d(const float* x, long ldx, int rows, int cols, float* y, long ldy, void* stream);
+
+/* ---- N1  train-mode BatchNorm + (Leaky)ReLU + dropout (nn.BatchNorm2d/LeakyReLU/Dropout,
+ *      unetWithArgs.py:36-44; vnetWithArgs.py:16-25)                                                      */
+int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
+                     float* mean, float* istd, float* running_mean, float* running_var, void* stream);
+int arco_chan_stats_blocks(long M);
+int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream);
+int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                    const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
+                    void* stream);
+int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
+                    const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
+                    uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
+                    void* stream);
+/* ---- N2/N3  nn.MaxPool2d(2) (unetWithArgs.py:55-58); nn.Upsample(bilinear, align_corners=True)
+ *      (unetWithArgs.py:74-75, model_2D.py:43-52)                                                          */
+int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, float* Y, long ldy, void* stream);
+int arco_maxpool2_bwd(const float* X, long ldx, int NB, int H, int W, int C, const float* dY, long ldy, float* dX,
+                      long ldo, void* stream);
+int arco_bilinear_fwd(const float* X, long ldx, int NB, int Hi, int Wi, int C, int Ho, int Wo, float* Y, long ldy,
+                      void* stream);
+int arco_bilinear_bwd(const float* dY, long ldy, int NB, int Hi, int Wi, int C, int Ho, int Wo, float* dX, long ldx,
+                      int accumulate, void* stream);
+/* rows of cat(upsample(lo), hi) at selected high-res pixels, and the adjoint scatter (row-sparse head of
+ * FeatureExtractor.fea4 / q_representation: model_2D.py:51-53, train_arco_2d.py:324-325)                   */
+int arco_gather_upcat_rows(const float* lo, long ldlo, int Clo, int Hi, int Wi, const float* hi, long ldhi, int Chi,
+                           int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
+int arco_scatter_upcat_rows(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo,
+                            int Hi, int Wi, float* dhi, long ldhi, int Chi, int Ho, int Wo, void* stream);
+int arco_copy_rows(const float* X, long ldx, long M, int C, float* Y, long ldy, int accumulate, void* stream);
+int arco_nchw_to_nhwc(const float* X, int NB, int C, long P, float* Y, long ldy, void* stream);
+int arco_nhwc_to_nchw(const float* X, long ldx, int NB, int C, long P, float* Y, void* stream);
+
+/* ---- O1/N5  torch.optim.SGD(nesterov) step and EMA over flat buffers (train_arco_2d.py:248,306-308,431-432;
+ *      model_2D.py:176-182)                                                                                */
+int arco_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                      int first, void* stream);
+int arco_ema(float* k, const float* q, long n, float m, void* stream);
+
+/* ---- T1  trainer glue (train_arco_2d.py:284-286,342-393,492-498)                                        */
+int arco_softmax_rows(const float* X, long ld, long M, int C, long P, float* prob_planes, float* maxp, int64_t* amax,
+                      float* entropy, void* stream);
+int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, void* stream);
+long arco_sel_state_bytes();
+/* exact np.percentile(entropy[valid], q) (linear) by device radix select -> low/high masks              */
+int arco_entropy_masks(const float* ent, const int64_t* lab_l, const int64_t* lab_u, long n_l, long n_u, double q_lo,
+                       double q_hi, void* state, float* low, float* high, void* stream);
+
+/* ---- L4  HOST entry points (CPU memory, no stream): native replay of the stratified samplers
+ *      grid_monte_carlo_sample / grid_as_monte_carlo_sample (loss_helper_3d.py:120-268) on the
+ *      serialized torch CPU generator state (torch.get_rng_state()), bit-exact incl. final state.        */
+long arco_grid_sample(uint8_t* state, long state_bytes, long high, long shape, int cut, int mirror, int64_t* out);
+long arco_randint(uint8_t* state, long state_bytes, long high, long n, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARCO_HIP_H */

@@ -47,3 +47,22 @@ def test_range_and_determinism():
         seed_all(11); a = S.grid_monte_carlo_sample(high, 4096)
         seed_all(11); b = S.grid_monte_carlo_sample(high, 4096)
         assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < high
+
+
+def test_native_and_python_paths_agree(monkeypatch):
+    """The native mt19937 replay and the torch-call implementation give the same indices and leave
+    the generator in the same state."""
+    from arco_amd import _lib
+    try:
+        _lib.load()
+    except RuntimeError:
+        pytest.skip("library not built")
+    for high in (57, 100, 4096, 5233, 30000, 262144, 1000003):
+        for shape in (256, 131072):
+            for mirror in (False, True):
+                seed_all(high + shape)
+                a = S._grid(high, shape, 4, mirror); pa = int(torch.randint(1 << 30, (1,)))
+                seed_all(high + shape)
+                b = S._grid_native(high, shape, 4, mirror); pb = int(torch.randint(1 << 30, (1,)))
+                assert b is not NotImplemented
+                assert torch.equal(a, b) and pa == pb, (high, shape, mirror)
