@@ -1,0 +1,75 @@
+"""world_size-2 gloo tests of the data-parallel exchange steps on CPU:
+flat gradient all-reduce, key-count all-reduce, key all-gather-v in rank order."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as td
+    from arco_amd import dist as adist
+    from arco_amd import _contrast
+    r, w = adist.init(backend="gloo")
+    assert (r, w) == (rank, world) and adist.is_dist()
+    assert _contrast.key_gather_hook is adist.gather_keys and _contrast.count_gather_hook is adist.gather_counts
+    # 1. key all-gather-v: ragged counts incl. an empty rank, rank order, exact values
+    for n_by_rank in ([3, 5], [0, 4], [0, 0], [7, 1]):
+        n = n_by_rank[rank]
+        keys = torch.arange(n * 4, dtype=torch.float32).view(n, 4) + 1000 * rank
+        out = adist.gather_keys(keys)
+        exp = torch.cat([torch.arange(m * 4, dtype=torch.float32).view(m, 4) + 1000 * rr for rr, m in enumerate(n_by_rank)])
+        assert torch.equal(out, exp), (rank, n_by_rank)
+    # 2. key counters summed identically on every rank
+    assert adist.gather_counts([rank + 1, 10 * rank, 0, 7]) == [3, 10, 0, 14]
+    # 3. flat gradient all-reduce = mean over ranks, every parameter marked as touched
+    class Opt:
+        pass
+    opt = Opt()
+    opt.flat_g = torch.full((17,), float(rank + 1))
+    opt.params = [0, 1, 2]
+    opt._touched = set()
+    adist.allreduce_grads(opt)
+    assert torch.allclose(opt.flat_g, torch.full((17,), 1.5)) and opt._touched == {0, 1, 2}
+    # 4. broadcast of module state from rank 0
+    m = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        m.weight.fill_(float(rank + 5))
+    adist.broadcast_module_states([m])
+    assert float(m.weight[0, 0]) == 5.0
+    # 5. banks built from gathered keys are identical on all ranks (CPU emulation of the FIFO truncation)
+    old = torch.zeros(1, 4)
+    keys = torch.randn(6 + rank, 4, generator=torch.Generator().manual_seed(rank))
+    allk = adist.gather_keys(keys)
+    bank = torch.cat((old, allk))[-8:]
+    gathered = [torch.empty_like(bank) for _ in range(world)]
+    td.all_gather(gathered, bank)
+    assert all(torch.equal(g, bank) for g in gathered)
+    td.barrier()
+    q.put((rank, "ok"))
+
+
+def test_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, "ok"), (1, "ok")]
