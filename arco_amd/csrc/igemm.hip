@@ -25,17 +25,19 @@ struct IgemmArgs {
   long M;                            // total pixels
 };
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int TH = BM / 16;
   constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
+  constexpr int BROWS = TAPS * BN;
   constexpr int LDK = KC + 4;
   constexpr int A_T = BM / 16 / WAVES_M;
   constexpr int C_T = BN / 16 / WAVES_N;
   constexpr int Q4 = KC / 4;
+  constexpr int NA_IT = (AROWS * Q4 + 255) / 256;
+  constexpr int NB_IT = (BROWS * Q4 + 255) / 256;
+  constexpr int BUF = (AROWS + BROWS) * LDK;          // floats per LDS buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;
-  float* Bs = smem + AROWS * LDK;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -62,11 +64,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 
   const bool vecA = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
 
-  for (int kc0 = 0; kc0 < a.Kpad; kc0 += KC) {
-    // ---- stage A (input patch)
-    for (int idx = tid; idx < AROWS * Q4; idx += 256) {
+  // chunk-invariant staging geometry: source row pointers (null = zero fill) and LDS offsets
+  const float* srcA[NA_IT]; int ldsA[NA_IT], kA[NA_IT];
+#pragma unroll
+  for (int it = 0; it < NA_IT; ++it) {
+    const int idx = tid + it * 256;
+    srcA[it] = nullptr; ldsA[it] = -1; kA[it] = 0;
+    if (idx < AROWS * Q4) {
       const int row = idx / Q4, q = idx - row * Q4;
-      const int k = kc0 + 4 * q;
       long pix = -1;
       if (TAPS == 9) {
         const int hy = row / 18, hx = row - hy * 18;
@@ -76,30 +81,53 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         const long m = m0 + row;
         if (m < a.M) pix = m;
       }
-      f32x4 v = f32x4{0, 0, 0, 0};
-      if (pix >= 0) {
-        const float* src = a.A + pix * a.lda + k;
-        if (vecA) {
-          if (k < a.K) v = *reinterpret_cast<const f32x4*>(src);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k + e < a.K) v[e] = src[e];
-        }
-      }
-      *reinterpret_cast<f32x4*>(&As[row * LDK + 4 * q]) = v;
+      ldsA[it] = row * LDK + 4 * q; kA[it] = 4 * q;
+      if (pix >= 0) srcA[it] = a.A + pix * a.lda + 4 * q;
     }
-    // ---- stage B (weights of every tap for this K-chunk)
-    for (int idx = tid; idx < TAPS * BN * Q4; idx += 256) {
+  }
+  const float* srcB[NB_IT]; int ldsB[NB_IT], kB[NB_IT];
+#pragma unroll
+  for (int it = 0; it < NB_IT; ++it) {
+    const int idx = tid + it * 256;
+    srcB[it] = nullptr; ldsB[it] = -1; kB[it] = 0;
+    if (idx < BROWS * Q4) {
       const int row = idx / Q4, q = idx - row * Q4;
       const int tap = row / BN, n = row - tap * BN;
-      f32x4 v = f32x4{0, 0, 0, 0};
-      if (n0 + n < a.Npad)
-        v = *reinterpret_cast<const f32x4*>(a.Wp + ((long)tap * a.Npad + n0 + n) * a.Kpad + kc0 + 4 * q);
-      *reinterpret_cast<f32x4*>(&Bs[row * LDK + 4 * q]) = v;
+      ldsB[it] = AROWS * LDK + row * LDK + 4 * q; kB[it] = 4 * q;
+      if (n0 + n < a.Npad) srcB[it] = a.Wp + ((long)tap * a.Npad + n0 + n) * a.Kpad + 4 * q;
     }
-    __syncthreads();
-    // ---- MFMA
+  }
+
+  f32x4 ra[NA_IT], rb[NB_IT];
+  auto load_chunk = [&](int kc0) {
+#pragma unroll
+    for (int it = 0; it < NA_IT; ++it) {
+      f32x4 v = f32x4{0, 0, 0, 0};
+      const int k = kc0 + kA[it];
+      if (srcA[it]) {
+        if (vecA) { if (k < a.K) v = *reinterpret_cast<const f32x4*>(srcA[it] + kc0); }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < a.K) v[e] = srcA[it][kc0 + e];
+        }
+      }
+      ra[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NB_IT; ++it) {
+      f32x4 v = f32x4{0, 0, 0, 0};
+      if (srcB[it] && kc0 + kB[it] < a.Kpad) v = *reinterpret_cast<const f32x4*>(srcB[it] + kc0);
+      rb[it] = v;
+    }
+  };
+  auto store_chunk = [&](float* buf) {
+#pragma unroll
+    for (int it = 0; it < NA_IT; ++it) if (ldsA[it] >= 0) *reinterpret_cast<f32x4*>(&buf[ldsA[it]]) = ra[it];
+#pragma unroll
+    for (int it = 0; it < NB_IT; ++it) if (ldsB[it] >= 0) *reinterpret_cast<f32x4*>(&buf[ldsB[it]]) = rb[it];
+  };
+  auto compute = [&](const float* buf) {
+    const float* As = buf; const float* Bs = buf + AROWS * LDK;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
@@ -125,6 +153,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
             for (int ct = 0; ct < C_T; ++ct)
               acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[at][j], bf[ct][j], acc[at][ct], 0, 0, 0);
       }
+    }
+  };
+
+  // main loop: the global loads of chunk k+1 are in flight while chunk k is on the matrix cores
+  const int nchunks = (a.Kpad + KC - 1) / KC;
+  load_chunk(0);
+  store_chunk(smem);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    float* cur = DB ? smem + (c & 1) * BUF : smem;
+    float* nxt = DB ? smem + ((c + 1) & 1) * BUF : smem;
+    const bool more = c + 1 < nchunks;
+    if (more) load_chunk((c + 1) * KC);
+    compute(cur);
+    if (more) {
+      if (!DB) __syncthreads();          // single buffer: everyone done reading before it is overwritten
+      store_chunk(nxt);
     }
     __syncthreads();
   }
@@ -189,7 +234,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 }
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   constexpr int TH = BM / 16;
   constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
@@ -197,11 +242,11 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) 
   if (TAPS == 9) mblocks = a.NB * ((a.H + TH - 1) / TH) * ((a.W + 15) / 16);
   else mblocks = (int)((a.M + BM - 1) / BM);
   if (n_mblocks_out) { *n_mblocks_out = mblocks; return ARCO_OK; }
-  size_t sh = (size_t)(AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
+  size_t sh = (size_t)(DB ? 2 : 1) * (AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
-  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC>;
-  if (sh > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB>;
+  if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   IgemmArgs b = a;
   b.n_mblocks = mblocks;
   dim3 grid(mblocks, (a.Npad + BN - 1) / BN);
@@ -212,16 +257,16 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) 
 // config choice shared by the launch and the "how many M-blocks" query
 static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb) {
   if (taps == 1) {
-    if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16>(a, st, nmb);
-    if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 16>(a, st, nmb);
-    if (a.M * (long)a.Npad <= 4096l * 1024) return launch_igemm<1, 64, 64, 2, 2, 16>(a, st, nmb);
-    return launch_igemm<1, 128, 128, 2, 2, 16>(a, st, nmb);
+    if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16, true>(a, st, nmb);
+    if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 16, true>(a, st, nmb);
+    if (a.M * (long)a.Npad <= 4096l * 1024) return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
+    return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
   }
   if (taps == 9) {
-    if (a.Npad <= 16) return launch_igemm<9, 256, 16, 4, 1, 16>(a, st, nmb);
-    if (a.Npad <= 32) return launch_igemm<9, 128, 32, 4, 1, 16>(a, st, nmb);
-    if ((long)a.NB * a.H * a.W <= 16384) return launch_igemm<9, 64, 64, 2, 2, 16>(a, st, nmb);
-    return launch_igemm<9, 128, 64, 4, 1, 16>(a, st, nmb);
+    if (a.Npad <= 16) return launch_igemm<9, 256, 16, 4, 1, 16, false>(a, st, nmb);
+    if (a.Npad <= 32) return launch_igemm<9, 128, 32, 4, 1, 16, false>(a, st, nmb);
+    if ((long)a.NB * a.H * a.W <= 16384) return launch_igemm<9, 64, 64, 2, 2, 16, false>(a, st, nmb);
+    return launch_igemm<9, 128, 64, 4, 1, 16, false>(a, st, nmb);
   }
   return ARCO_ERR_UNSUPPORTED;
 }
