@@ -20,12 +20,12 @@ struct IgemmArgs {
   const float* bias;
   const float* R; long ldr;
   float* stat_sum; float* stat_sq;   // [N][n_mblocks] block partials (nullable)
-  int n_mblocks;
+  int n_mblocks; int n_nblocks;
   int NB, H, W;                      // images, rows, cols (TAPS==9); TAPS==1 uses M only
   long M;                            // total pixels
 };
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int TH = BM / 16;
   constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
@@ -42,18 +42,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int li = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so the
+  // N-tiles of one M-tile (which share the input rows) are given consecutive slots of ONE XCD.
+  int mblk, nblk;
+  {
+    const int T = a.n_mblocks * a.n_nblocks, L = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = L & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    mblk = v / a.n_nblocks; nblk = v - mblk * a.n_nblocks;
+  }
+  const int n0 = nblk * BN;
 
   // tile origin
   long m0 = 0; int img = 0, y0 = 0, x0 = 0;
   if (TAPS == 9) {
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + TH - 1) / TH;
-    int t = blockIdx.x;
+    int t = mblk;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y; img = t / tiles_y;
     y0 = ty * TH; x0 = tx * 16;
   } else {
-    m0 = (long)blockIdx.x * BM;
+    m0 = (long)mblk * BM;
   }
 
   f32x4 acc[A_T][C_T];
@@ -61,8 +70,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   for (int i = 0; i < A_T; ++i)
 #pragma unroll
     for (int j = 0; j < C_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-
-  const bool vecA = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
 
   // chunk-invariant staging geometry: source row pointers (null = zero fill) and LDS offsets
   const float* srcA[NA_IT]; int ldsA[NA_IT], kA[NA_IT];
@@ -104,9 +111,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     for (int it = 0; it < NA_IT; ++it) {
       f32x4 v = f32x4{0, 0, 0, 0};
       const int k = kc0 + kA[it];
-      if (srcA[it]) {
-        if (vecA) { if (k < a.K) v = *reinterpret_cast<const f32x4*>(srcA[it] + kc0); }
-        else {
+      if constexpr (VEC) {
+        // (the scalar variant lives in its own instantiation: sharing registers between the two load
+        //  forms makes hipcc wait vmcnt(0) before every vector load and serialises the prefetch)
+        if (srcA[it] && k < a.K) v = *reinterpret_cast<const f32x4*>(srcA[it] + kc0);
+      } else {
+        if (srcA[it]) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (k + e < a.K) v[e] = srcA[it][kc0 + e];
         }
@@ -227,15 +237,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         float v1 = 0.f, v2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES_M; ++w) { v1 += red[(0 * WAVES_M + w) * BN + nl]; v2 += red[(1 * WAVES_M + w) * BN + nl]; }
-        a.stat_sum[(long)n * a.n_mblocks + blockIdx.x] = v1;
-        a.stat_sq[(long)n * a.n_mblocks + blockIdx.x] = v2;
+        a.stat_sum[(long)n * a.n_mblocks + mblk] = v1;
+        a.stat_sq[(long)n * a.n_mblocks + mblk] = v2;
       }
     }
   }
 }
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB>
-static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC>
+static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   constexpr int TH = BM / 16;
   constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
   int mblocks;
@@ -245,13 +255,21 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) 
   size_t sh = (size_t)(DB ? 2 : 1) * (AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
-  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB>;
+  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC>;
   if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   IgemmArgs b = a;
   b.n_mblocks = mblocks;
-  dim3 grid(mblocks, (a.Npad + BN - 1) / BN);
+  b.n_nblocks = (a.Npad + BN - 1) / BN;
+  dim3 grid((unsigned)(mblocks * b.n_nblocks));
   hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, b);
   return arco_launch_status();
+}
+
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB>
+static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
+  const bool vec = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
+  if (vec) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true>(a, st, n_mblocks_out);
+  return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, false>(a, st, n_mblocks_out);
 }
 
 // config choice shared by the launch and the "how many M-blocks" query
