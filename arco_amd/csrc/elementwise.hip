@@ -70,11 +70,14 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Z, long ldz, long M, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ istd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float slope, int drop_mode, float p, uint64_t seed, long P,
-                                                        float* __restrict__ Aout, long lda) {
+                                                        float slope, int drop_mode, float p, uint64_t seed_, long P,
+                                                        float* __restrict__ Aout, long lda,
+                                                        const uint64_t* __restrict__ seed_dev) {
   const int q4 = C / 4;
   const long tot = M * q4;
   const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
+  // graph-captured forwards read a per-replay salt from device memory (fresh masks on every replay)
+  const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
     const long r = i / q4; const int c = (int)(i - r * q4) * 4;
     const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
@@ -445,10 +448,10 @@ int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float*
 
 int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                     const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
-                    void* stream) {
+                    const uint64_t* seed_dev, void* stream) {
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && p < 1.0f);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, as_stream(stream), Z, ldz, M, C, mean,
-                     istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda);
+                     istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda, seed_dev);
   return arco_launch_status();
 }
 

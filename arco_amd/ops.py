@@ -11,6 +11,7 @@ from . import _lib as L
 from ._contrast import rows_view
 
 _drop_gen = None
+SEED_DEV = None     # device uint64 salt for dropout masks of graph-captured forwards (graphs.py)
 PROFILE = None      # bench.py sets a dict: (taps, M, N, K) -> [(start_event, end_event)] per conv launch
 
 
@@ -45,15 +46,34 @@ def _geom(x):
     return r, ld, int(nb), int(c), int(h), int(w)
 
 
+# packed weights are reused until the weights change: optimizers / EMA bump WEIGHT_EPOCH
+WEIGHT_EPOCH = 0
+_pack_cache = {}
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+    _pack_cache.clear()
+
+
 def pack_weight(weight, taps, mode):
-    """torch [Cout, Cin, kh, kw] -> Wp[taps][Npad][Kpad]; mode 0 forward, 1 dgrad (flipped+transposed)."""
+    """torch [Cout, Cin, kh, kw] -> Wp[taps][Npad][Kpad]; mode 0 forward, 1 dgrad (flipped+transposed).
+    Cached per weight-epoch (a step uses each model's weights in several forwards)."""
     co, ci = int(weight.shape[0]), int(weight.shape[1])
-    w = weight.detach().contiguous()
-    if mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0:
+    w = weight.detach()
+    if mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0 and w.is_contiguous():
         return w.view(co, ci)                      # already [N][K]
+    key = (w.data_ptr(), co, ci, taps, mode)
+    hit = _pack_cache.get(key)
+    if hit is not None and not torch.cuda.is_current_stream_capturing():
+        return hit
+    w = w.contiguous()
     n, k = (co, ci) if mode == 0 else (ci, co)
     wp = torch.empty((taps, _ceil16(n), _ceil16(k)), dtype=torch.float32, device=w.device)
     L.call("arco_pack_conv_weight", L.ptr(w), co, ci, taps, mode, L.ptr(wp))
+    if not torch.cuda.is_current_stream_capturing():
+        _pack_cache[key] = wp
     return wp
 
 
@@ -146,8 +166,10 @@ class ConvBnActFn(torch.autograd.Function):
         seed = _next_seed() if p > 0 else 0
         a = new_act(nb, co, h, w, x.device)
         zr, ldz = rows_view(z)
+        # inside a graph capture (no-grad forwards only) the mask salt comes from device memory
+        seed_dev = SEED_DEV if (p > 0 and torch.cuda.is_current_stream_capturing()) else None
         L.call("arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
-               float(slope), int(drop_mode), float(p), seed, h * w, L.ptr(a), co)
+               float(slope), int(drop_mode), float(p), seed, h * w, L.ptr(a), co, L.ptr(seed_dev))
         ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta)
         ctx.cfg = (taps, float(slope), float(p), int(drop_mode), seed, bias is not None)
         return a
@@ -241,7 +263,7 @@ def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, sl
         a = new_act(nb, co, h, w, x.device)
         zr, ldz = rows_view(z)
         L.call("arco_bn_act_fwd", L.ptr(zr), ldz, nb * h * w, co, L.ptr(running_mean), L.ptr(istd), L.ptr(gamma),
-               L.ptr(beta), float(slope), 0, 0.0, 0, h * w, L.ptr(a), co)
+               L.ptr(beta), float(slope), 0, 0.0, 0, h * w, L.ptr(a), co, None)
         return a
 
 

@@ -7,6 +7,7 @@ data-parallel gradient all-reduce are each one kernel / one collective.
 import torch
 
 from . import _lib as L
+from . import ops
 
 
 def flatten_params(params):
@@ -58,6 +59,7 @@ class EmaPair:
         if s is None:
             s = torch.cat([p.data.reshape(-1) for p in self.sp])
         L.call("arco_ema", L.ptr(self.flat_t), L.ptr(s), self.flat_t.numel(), float(m))
+        ops.bump_weight_epoch()
 
 
 class SGDNesterov:
@@ -121,3 +123,4 @@ class SGDNesterov:
                    n, float(g['lr']), float(g['momentum']), float(g['weight_decay']), 1 if first else 0)
             for i in range(a, b):
                 self._started[i] = True
+        ops.bump_weight_epoch()

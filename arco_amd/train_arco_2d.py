@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import dist as adist
 from . import _contrast as C_
-from . import glue, head, ops, optim
+from . import glue, graphs, head, ops, optim
 from .model_2D import ISD, FeatureExtractor
 
 FEA_DIM = [256, 128, 64, 32, 16]
@@ -84,6 +84,7 @@ def build_parser():
     p.add_argument('--queue_size', type=int, default=0, help='override per-class bank size (0 = reference 50000/30000)')
     p.add_argument('--synthetic', type=int, default=0, help='1: train on synthetic ACDC-shaped tensors')
     p.add_argument('--in_chns', type=int, default=1, help='input channels (reference: 1)')
+    p.add_argument('--graphs', type=int, default=1, help='1: replay the no-grad U-Net forwards as HIP graphs')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
     return p
 
@@ -149,6 +150,12 @@ class ArcoStep2D:
             m.train()                                                   # :263-267
         self.iter_num = 0
         self.loss_events = []
+        # no-grad forwards replayed as HIP graphs (one graph per call site: outputs are static buffers)
+        use_graphs = bool(getattr(args, "graphs", 1))
+        self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
+        self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
+        self.t_fwd_u = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
+        self.s_fwd_stats = graphs.GraphedForward(self.model, enabled=use_graphs)
 
     def q_rep(self, x):
         x = ops.conv(x, self.q_representation[0].weight)
@@ -166,14 +173,14 @@ class ArcoStep2D:
         C = a.num_classes
         dense = getattr(a, "dense_head", 0)
         with torch.no_grad():                                            # :284-286
-            pred_u0, _, _ = self.ema_model(u_data)
+            pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits
         self.k_fe_ema.update(0.99)                                      # :306-308
         pred_u, _, u_fm = self.model(u_aug)                              # :312 (needed first: entropy masks)
         with torch.no_grad():                                            # teacher params carry no grad (:158-160)
-            pred_l_t, _, l_fm_t = self.ema_model(l_data)                 # :314
-            pred_u_t, _, u_fm_t = self.ema_model(u_aug)                  # :315
+            pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)                   # :314
+            pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                    # :315
             alpha_t = 20 * (1 - epoch_num / max_epoch)                   # :342-393
             label_l = glue.label_onehot(l_label, C)
             label_u = glue.label_onehot(u_aug_label, C)
@@ -188,7 +195,7 @@ class ArcoStep2D:
         # ---- large GPU work queued while the host waits for the counters and samples
         pred_l, _, l_fm = self.model(l_data)                             # :310
         with torch.no_grad():
-            self.model(l_data)       # images_cj2_l forward (:311): BN running stats only; its FE/q_rep
+            self.s_fwd_stats(l_data)  # images_cj2_l forward (:311): BN running stats only; its FE/q_rep
                                      # outputs (l_feature_map_2, :319,326) are never read -> not computed
             # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
             rep_all_teacher = self.k_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)])

@@ -84,7 +84,7 @@ int arco_chan_stats_blocks(long M);
 int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream);
 int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                     const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
-                    void* stream);
+                    const uint64_t* seed_dev, void* stream);
 int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
                     const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
                     uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
