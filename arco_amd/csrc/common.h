@@ -13,8 +13,10 @@
     if (!(cond)) return ARCO_ERR_ARG; \
   } while (0)
 
+#include <stdio.h>
 static inline int arco_launch_status() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) fprintf(stderr, "arco_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
   return e == hipSuccess ? ARCO_OK : ARCO_ERR_LAUNCH;
 }
 

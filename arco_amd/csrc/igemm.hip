@@ -256,7 +256,8 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
   auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC>;
-  if (sh > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  static bool attr_set = false;      // once per instantiation (never inside a stream capture after warm-up)
+  if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
   IgemmArgs b = a;
   b.n_mblocks = mblocks;
   b.n_nblocks = (a.Npad + BN - 1) / BN;

@@ -46,15 +46,14 @@ def _geom(x):
     return r, ld, int(nb), int(c), int(h), int(w)
 
 
-# packed weights are reused until the weights change: optimizers / EMA bump WEIGHT_EPOCH
+# packed weights are reused until the weights change: optimizers / EMA bump WEIGHT_EPOCH.
+# The cache lives ON the weight tensor object (no stale hits when memory is recycled).
 WEIGHT_EPOCH = 0
-_pack_cache = {}
 
 
 def bump_weight_epoch():
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
-    _pack_cache.clear()
 
 
 def pack_weight(weight, taps, mode):
@@ -64,16 +63,26 @@ def pack_weight(weight, taps, mode):
     w = weight.detach()
     if mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0 and w.is_contiguous():
         return w.view(co, ci)                      # already [N][K]
-    key = (w.data_ptr(), co, ci, taps, mode)
-    hit = _pack_cache.get(key)
-    if hit is not None and not torch.cuda.is_current_stream_capturing():
-        return hit
+    capturing = torch.cuda.is_current_stream_capturing()
+    cache = getattr(weight, "_arco_pack", None)
+    key = (mode, weight._version)
+    if cache is not None and not capturing:
+        hit = cache.get(key)
+        if hit is not None and hit[0] == WEIGHT_EPOCH:
+            return hit[1]
     w = w.contiguous()
     n, k = (co, ci) if mode == 0 else (ci, co)
     wp = torch.empty((taps, _ceil16(n), _ceil16(k)), dtype=torch.float32, device=w.device)
     L.call("arco_pack_conv_weight", L.ptr(w), co, ci, taps, mode, L.ptr(wp))
-    if not torch.cuda.is_current_stream_capturing():
-        _pack_cache[key] = wp
+    if not capturing:
+        if cache is None:
+            cache = {}
+            try:
+                weight._arco_pack = cache
+            except AttributeError:
+                return wp
+        cache.clear() if len(cache) > 4 else None
+        cache[key] = (WEIGHT_EPOCH, wp)
     return wp
 
 

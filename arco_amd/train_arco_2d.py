@@ -276,6 +276,7 @@ def train(args, snapshot_path):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    torch.set_num_threads(min(4, torch.get_num_threads()))   # host logic only; avoids OpenMP oversubscription stalls
     random.seed(args.seed)                                               # :505-508
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)

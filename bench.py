@@ -13,8 +13,16 @@ per-GPU work is fixed; value = N*K 16-image steps / wall time.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+
+# Host logic needs no CPU parallelism; torch's default (one OpenMP thread per hardware thread, spinning
+# after every small CPU op) oversubscribes shared hosts and stalls the launch thread by 20-80 ms at
+# random (measured: 40 ms/step steady with 4 threads vs 40-200 ms with 128).  Must precede `import torch`.
+if os.environ.get("ARCO_CPU_BASELINE_CHILD") != "1":
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    os.environ.setdefault("MKL_NUM_THREADS", "4")
 
 import torch
 
@@ -24,12 +32,25 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 
 
-def cpu_baseline():
-    """CPU oracle (port) timed on this box's host cores: one full step at --batch_size 2 (4 images)."""
+def cpu_baseline_child():
+    """Runs in a child process (all host cores, no GPU): one full oracle step at --batch_size 2."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_step
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    cpu_step.timed_sample(b=1, patch=(64, 64))          # warm the thread pool / allocator
     secs, threads = cpu_step.timed_sample(b=2)
+    print(json.dumps({"secs": secs, "threads": threads}))
+
+
+def cpu_baseline():
+    """CPU oracle (port) timed on this box's host cores: one full step at --batch_size 2 (4 images)."""
+    env = dict(os.environ, ARCO_CPU_BASELINE_CHILD="1")
+    env.pop("OMP_NUM_THREADS", None); env.pop("MKL_NUM_THREADS", None)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu_baseline_child"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    secs, threads = r["secs"], r["threads"]
     # a 16-image step is 4x the 4-image sample (per-image work is constant)
     return {"value": round(1.0 / (4.0 * secs), 5), "unit": "steps/s (16-image steps)", "cores": threads, "kind": "port",
             "sample": f"1 full oracle step at --batch_size 2 (4 images, 256x256, C=4, D=496) = {secs:.1f} s on "
@@ -44,7 +65,11 @@ def main():
     ap.add_argument("--batch_size", type=int, default=8)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--dense_head", type=int, default=0)
+    ap.add_argument("--graphs", type=int, default=1)
+    ap.add_argument("--cpu_baseline_child", action="store_true")
     a = ap.parse_args()
+    if a.cpu_baseline_child:
+        return cpu_baseline_child()
 
     from arco_amd import dist as adist
     from arco_amd import ops
@@ -57,7 +82,7 @@ def main():
     random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 
     args = T.build_parser().parse_args(["--batch_size", str(a.batch_size), "--queue_size", "4096", "--func", "smc",
-                                        "--synthetic", "1", "--dense_head", str(a.dense_head)])
+                                        "--synthetic", "1", "--dense_head", str(a.dense_head), "--graphs", str(a.graphs)])
     stepper = T.ArcoStep2D(args, dev)
     b = a.batch_size
     batches = []
