@@ -355,6 +355,68 @@ __global__ __launch_bounds__(256) void scatter_upcat_rows_kernel(const float* __
   for (int c = lane; c < Chi; c += 64) atomicAdd(h + c, g[Clo + c]);
 }
 
+// ---- second level of the row-sparse head: the 4 low-res neighbours of each anchor as explicit rows.
+// nb4[4j+t] = low-res pixel id of neighbour t (00,01,10,11) of high-res pixel pix[j]; lylx[j] = (ly, lx)
+__global__ void up_neighbors_kernel(const int64_t* __restrict__ pix, long n, int Hi, int Wi, int Ho, int Wo,
+                                    int64_t* __restrict__ nb4, float* __restrict__ lylx) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long p = pix[j];
+  const long img = p / ((long)Ho * Wo); const int rem = (int)(p - img * (long)Ho * Wo);
+  const int yo = rem / Wo, xo = rem - yo * Wo;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  int y0, y1, x0, x1; float ly, lx;
+  ac_src(yo, sh, Hi, y0, y1, ly); ac_src(xo, sw, Wi, x0, x1, lx);
+  const long b = img * (long)Hi * Wi;
+  nb4[4 * j + 0] = b + (long)y0 * Wi + x0; nb4[4 * j + 1] = b + (long)y0 * Wi + x1;
+  nb4[4 * j + 2] = b + (long)y1 * Wi + x0; nb4[4 * j + 3] = b + (long)y1 * Wi + x1;
+  lylx[2 * j] = ly; lylx[2 * j + 1] = lx;
+}
+// X[j][0..Clo) = hy*(hx*V[4j]+lx*V[4j+1]) + ly*(hx*V[4j+2]+lx*V[4j+3])  (same order as bilinear_fwd_kernel);
+// X[j][Clo..Clo+Chi) = hi[pix[j]]
+__global__ __launch_bounds__(256) void lerp4_cat_rows_kernel(const float* __restrict__ V, long ldv, int Clo,
+                                                            const float* __restrict__ lylx, const float* __restrict__ hi,
+                                                            long ldhi, int Chi, const int64_t* __restrict__ pix, long n,
+                                                            float* __restrict__ X, long ldx) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const float ly = lylx[2 * j], lx = lylx[2 * j + 1], hy = 1.f - ly, hx = 1.f - lx;
+  const float* v0 = V + (4 * j) * ldv;
+  float* o = X + j * ldx;
+  for (int c = lane * 4; c < Clo; c += 256) {
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(v0 + c), v01 = *reinterpret_cast<const f32x4*>(v0 + ldv + c);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(v0 + 2 * ldv + c), v11 = *reinterpret_cast<const f32x4*>(v0 + 3 * ldv + c);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(o + c) = r;
+  }
+  const float* h = hi + pix[j] * ldhi;
+  for (int c = lane * 4; c < Chi; c += 256) *reinterpret_cast<f32x4*>(o + Clo + c) = *reinterpret_cast<const f32x4*>(h + c);
+}
+// adjoint: dV[4j+t] = w_t * dX[j][0..Clo) ; dhi[pix[j]] += dX[j][Clo..)
+__global__ __launch_bounds__(256) void lerp4_cat_rows_bwd_kernel(const float* __restrict__ dX, long ldx, int Clo,
+                                                                const float* __restrict__ lylx, const int64_t* __restrict__ pix,
+                                                                long n, float* __restrict__ dV, long ldv,
+                                                                float* __restrict__ dhi, long ldhi, int Chi) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const float ly = lylx[2 * j], lx = lylx[2 * j + 1], hy = 1.f - ly, hx = 1.f - lx;
+  const float* g = dX + j * ldx;
+  float* v0 = dV + (4 * j) * ldv;
+  for (int c = lane * 4; c < Clo; c += 256) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(g + c);
+    *reinterpret_cast<f32x4*>(v0 + c) = d * (hy * hx);
+    *reinterpret_cast<f32x4*>(v0 + ldv + c) = d * (hy * lx);
+    *reinterpret_cast<f32x4*>(v0 + 2 * ldv + c) = d * (ly * hx);
+    *reinterpret_cast<f32x4*>(v0 + 3 * ldv + c) = d * (ly * lx);
+  }
+  float* h = dhi + pix[j] * ldhi;
+  for (int c = lane; c < Chi; c += 64) atomicAdd(h + c, g[Clo + c]);
+}
+
 // ---- strided channel-slice copy / add:  Y[r][0..C) (+)= X[r][0..C)
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ X, long ldx, long M, int C,
                                                        float* __restrict__ Y, long ldy, int accumulate) {
@@ -524,6 +586,28 @@ int arco_scatter_upcat_rows(const float* dX, long ldx, const int64_t* pix, long 
   if (n == 0) return ARCO_OK;
   hipLaunchKernelGGL(scatter_upcat_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), dX, ldx, pix, n, dlo,
                      ldlo, Clo, Hi, Wi, dhi, ldhi, Chi, Ho, Wo);
+  return arco_launch_status();
+}
+
+int arco_up_neighbors(const int64_t* pix, long n, int Hi, int Wi, int Ho, int Wo, int64_t* nb4, float* lylx, void* stream) {
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(up_neighbors_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), pix, n, Hi, Wi, Ho, Wo, nb4, lylx);
+  return arco_launch_status();
+}
+int arco_lerp4_cat_rows(const float* V, long ldv, int Clo, const float* lylx, const float* hi, long ldhi, int Chi,
+                        const int64_t* pix, long n, float* X, long ldx, void* stream) {
+  ARCO_CHECK_ARG((Clo & 3) == 0 && (Chi & 3) == 0 && (ldv & 3) == 0 && (ldhi & 3) == 0 && (ldx & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(lerp4_cat_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), V, ldv, Clo, lylx, hi, ldhi,
+                     Chi, pix, n, X, ldx);
+  return arco_launch_status();
+}
+int arco_lerp4_cat_rows_bwd(const float* dX, long ldx, int Clo, const float* lylx, const int64_t* pix, long n, float* dV,
+                            long ldv, float* dhi, long ldhi, int Chi, void* stream) {
+  ARCO_CHECK_ARG((Clo & 3) == 0 && (ldv & 3) == 0 && (ldx & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(lerp4_cat_rows_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), dX, ldx, Clo, lylx, pix,
+                     n, dV, ldv, dhi, ldhi, Chi);
   return arco_launch_status();
 }
 

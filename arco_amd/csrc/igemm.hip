@@ -430,13 +430,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int taps, int CoutPad, int CinPad,
                                     int Cout, int Cin, float* __restrict__ dW, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long tot = (long)Cout * Cin * taps;
-  if (i >= tot) return;
-  const int tap = i % taps; const long r = i / taps; const int ci = r % Cin; const int co = r / Cin;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += partial[(((long)c * taps + tap) * CoutPad + co) * CinPad + ci];
-  dW[i] = accumulate ? dW[i] + s : s;
+  // threads walk the slab layout [tap][co][ci] (ci fastest -> coalesced slab reads); dW is torch layout
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tot = (long)taps * Cout * Cin;
+  if (j >= tot) return;
+  const int ci = j % Cin; const long r = j / Cin; const int co = r % Cout; const int tap = r / Cout;
+  const long off = ((long)tap * CoutPad + co) * CinPad + ci, stride = (long)taps * CoutPad * CinPad;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 3 < chunks; c += 4) {
+    s0 += partial[off + (long)c * stride]; s1 += partial[off + (long)(c + 1) * stride];
+    s2 += partial[off + (long)(c + 2) * stride]; s3 += partial[off + (long)(c + 3) * stride];
+  }
+  for (; c < chunks; ++c) s0 += partial[off + (long)c * stride];
+  const float s = (s0 + s1) + (s2 + s3);
+  const long o = ((long)co * Cin + ci) * taps + tap;
+  dW[o] = accumulate ? dW[o] + s : s;
 }
 
 // column sums (bias gradient): out[c] = sum_pix X[pix][c].  float4 lanes along channels,

@@ -78,3 +78,71 @@ class LazyHeadFn(torch.autograd.Function):
 def lazy_head(x3p, f4, fea4_weight, q1_weight, q2_weight, pix):
     """Anchor rows of q_representation(FeatureExtractor(...)) at high-res pixel ids `pix`."""
     return LazyHeadFn.apply(x3p, f4, fea4_weight, q1_weight, q2_weight, pix)
+
+
+class LazyHead2Fn(torch.autograd.Function):
+    """Two-level row-sparse head: also fea3 (the 128x128 level) is evaluated only on the <= 4 low-res
+    neighbours of each anchor.  Inputs: x2p = fea2(x)+x [B,448,64,64] (dense), f3 [B,32,128,128],
+    f4 [B,16,256,256].  Rows are bit-identical to the dense modules (same lerp order, same K-order MFMA
+    accumulation); d loss/d x2p becomes dense again from the 64x64 level down."""
+
+    @staticmethod
+    def forward(ctx, x2p, f3, f4, w3, w4, w1, w2, pix):
+        dev = x2p.device
+        n = int(pix.shape[0])
+        nb, c2, h2, w2_ = (int(v) for v in x2p.shape)
+        c3, h3, w3_ = int(f3.shape[1]), int(f3.shape[2]), int(f3.shape[3])
+        c4, h4, w4_ = int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3])
+        lo2, ld2 = rows_view(x2p)
+        r3, ld3 = rows_view(f3)
+        r4, ld4 = rows_view(f4)
+        nb4 = torch.empty(4 * n, dtype=torch.int64, device=dev)
+        lylx = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        L.call("arco_up_neighbors", L.ptr(pix), n, h3, w3_, h4, w4_, L.ptr(nb4), L.ptr(lylx))
+        k3 = c2 + c3
+        X3 = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
+        L.call("arco_gather_upcat_rows", L.ptr(lo2), ld2, c2, h2, w2_, L.ptr(r3), ld3, c3, h3, w3_, L.ptr(nb4), 4 * n,
+               L.ptr(X3), k3)
+        y3, _ = ops.conv_raw(X3, k3, k3, ops.pack_weight(w3, 1, 0), k3, 1, 1, 4 * n, 1, residual=X3, ld_res=k3)
+        X3p = y3.permute(0, 2, 3, 1).reshape(4 * n, k3)                     # fea3(x)+x rows
+        k4 = k3 + c4
+        X4 = torch.empty((n, k4), dtype=torch.float32, device=dev)
+        L.call("arco_lerp4_cat_rows", L.ptr(X3p), k3, k3, L.ptr(lylx), L.ptr(r4), ld4, c4, L.ptr(pix), n, L.ptr(X4), k4)
+        h0 = _gemm(X4, w4)
+        h1 = _gemm(h0, w1)
+        a = _gemm(h1, w2)
+        ctx.save_for_backward(X3, X4, h0, h1, w3, w4, w1, w2, pix, nb4, lylx)
+        ctx.geom = (nb, c2, h2, w2_, c3, h3, w3_, c4, h4, w4_)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        X3, X4, h0, h1, w3, w4, w1, w2, pix, nb4, lylx = ctx.saved_tensors
+        nb, c2, h2, w2_, c3, h3, w3_, c4, h4, w4_ = ctx.geom
+        dev = da.device
+        n = int(pix.shape[0])
+        k3 = c2 + c3
+        da = da.contiguous()
+        dw2 = _wgrad(da, h1, w2)
+        dh1 = _gemm_t(da, w2)
+        dw1 = _wgrad(dh1, h0, w1)
+        dh0 = _gemm_t(dh1, w1)
+        dw4 = _wgrad(dh0, X4, w4)
+        dX4 = _gemm_t(dh0, w4)
+        dX3p = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
+        df4 = torch.zeros((nb, h4, w4_, c4), dtype=torch.float32, device=dev)
+        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX4), k3 + c4, k3, L.ptr(lylx), L.ptr(pix), n, L.ptr(dX3p), k3,
+               L.ptr(df4), c4, c4)
+        dw3 = _wgrad(dX3p, X3, w3)
+        # d(fea3(x)+x)/dx: W3^T dy + dy  (residual fused in the dgrad GEMM epilogue)
+        y, _ = ops.conv_raw(dX3p, k3, k3, ops.pack_weight(w3, 1, 1), k3, 1, 1, 4 * n, 1, residual=dX3p, ld_res=k3)
+        dX3 = y.permute(0, 2, 3, 1).reshape(4 * n, k3)
+        dx2p = torch.zeros((nb, h2, w2_, c2), dtype=torch.float32, device=dev)
+        df3 = torch.zeros((nb, h3, w3_, c3), dtype=torch.float32, device=dev)
+        L.call("arco_scatter_upcat_rows", L.ptr(dX3), k3, L.ptr(nb4), 4 * n, L.ptr(dx2p), c2, c2, h2, w2_, L.ptr(df3), c3,
+               c3, h3, w3_)
+        return (dx2p.permute(0, 3, 1, 2), df3.permute(0, 3, 1, 2), df4.permute(0, 3, 1, 2), dw3, dw4, dw1, dw2, None)
+
+
+def lazy_head2(x2p, f3, f4, fea3_weight, fea4_weight, q1_weight, q2_weight, pix):
+    return LazyHead2Fn.apply(x2p, f3, f4, fea3_weight, fea4_weight, q1_weight, q2_weight, pix)

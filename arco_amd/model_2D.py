@@ -41,6 +41,16 @@ class FeatureExtractor(nn.Module):
             x = ops.conv(x, fea.weight, None, residual=True)               # fea_i(x) + x
         return x, f[4]
 
+    def forward_lowres2(self, fea_list):
+        """Up to fea2 (third level): returns (fea2(x)+x, f3, f4) for the two-level row-sparse head."""
+        f = [ops.to_channels_last(t) for t in fea_list]
+        x = ops.conv(f[0], self.fea0.weight, None, residual=True)
+        for i, fea in enumerate((self.fea1, self.fea2), start=1):
+            x = ops.bilinear(x, f[i].shape[-2:])
+            x = torch.cat((x, f[i]), dim=1)
+            x = ops.conv(x, fea.weight, None, residual=True)
+        return x, f[3], f[4]
+
     def forward(self, fea_list):
         x, f4 = self.forward_lowres(fea_list)
         x = ops.bilinear(x, f4.shape[-2:])

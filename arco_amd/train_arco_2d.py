@@ -85,6 +85,7 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=0, help='1: train on synthetic ACDC-shaped tensors')
     p.add_argument('--in_chns', type=int, default=1, help='input channels (reference: 1)')
     p.add_argument('--graphs', type=int, default=1, help='1: replay the no-grad U-Net forwards as HIP graphs')
+    p.add_argument('--head_levels', type=int, default=2, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
     return p
 
@@ -202,8 +203,10 @@ class ArcoStep2D:
         fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]         # :317-318
         if dense:
             rep_all = self.q_rep(self.q_feature_extractor(fm_all))       # :324-325,330
-        else:
+        elif getattr(a, "head_levels", 2) == 1:
             x3p, f4 = self.q_feature_extractor.forward_lowres(fm_all)
+        else:
+            x2p, f3, f4 = self.q_feature_extractor.forward_lowres2(fm_all)
         # ---- host: sampler replay (bit-exact torch-CPU-generator sequence), overlapped with the above
         C_.contrast_sample(plan, self.memobank, self.queue_size, a.func, a.num_queries, a.num_negatives)
         ev2 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -214,10 +217,14 @@ class ArcoStep2D:
         else:
             if dense:
                 A_all = C_.GatherRowsFn.apply(rep_all, plan.anchor_pix)
-            else:
+            elif getattr(a, "head_levels", 2) == 1:
                 A_all = head.lazy_head(x3p, f4, self.q_feature_extractor.fea4.weight,
                                        self.q_representation[0].weight, self.q_representation[1].weight,
                                        plan.anchor_pix)
+            else:
+                A_all = head.lazy_head2(x2p, f3, f4, self.q_feature_extractor.fea3.weight,
+                                        self.q_feature_extractor.fea4.weight, self.q_representation[0].weight,
+                                        self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)   # :394-398 (temp default)
         ev2[1].record()
         self.loss_events.append((ev, ev2))

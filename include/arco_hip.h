@@ -104,6 +104,13 @@ int arco_gather_upcat_rows(const float* lo, long ldlo, int Clo, int Hi, int Wi, 
                            int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
 int arco_scatter_upcat_rows(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo,
                             int Hi, int Wi, float* dhi, long ldhi, int Chi, int Ho, int Wo, void* stream);
+/* second level of the row-sparse head: explicit low-res neighbour rows of each anchor (ids + (ly,lx)),
+ * their 4-way lerp + cat with the high-res map, and the adjoint                                            */
+int arco_up_neighbors(const int64_t* pix, long n, int Hi, int Wi, int Ho, int Wo, int64_t* nb4, float* lylx, void* stream);
+int arco_lerp4_cat_rows(const float* V, long ldv, int Clo, const float* lylx, const float* hi, long ldhi, int Chi,
+                        const int64_t* pix, long n, float* X, long ldx, void* stream);
+int arco_lerp4_cat_rows_bwd(const float* dX, long ldx, int Clo, const float* lylx, const int64_t* pix, long n, float* dV,
+                            long ldv, float* dhi, long ldhi, int Chi, void* stream);
 int arco_copy_rows(const float* X, long ldx, long M, int C, float* Y, long ldy, int accumulate, void* stream);
 int arco_nchw_to_nhwc(const float* X, int NB, int C, long P, float* Y, long ldy, void* stream);
 int arco_nhwc_to_nchw(const float* X, long ldx, int NB, int C, long P, float* Y, void* stream);

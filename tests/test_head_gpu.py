@@ -8,14 +8,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(dense, steps=2):
+def _run(dense, steps=2, levels=2):
     from arco_amd import ops
     from arco_amd import train_arco_2d as T
     random.seed(3); np.random.seed(3); torch.manual_seed(3)
     ops.reseed_dropout(99)
     args = T.build_parser().parse_args(["--batch_size", "2", "--queue_size", "300", "--synthetic", "1",
                                         "--num_queries", "64", "--num_negatives", "32", "--dense_head", str(dense),
-                                        "--k1", "1.0", "--base_lr", "0.05"])
+                                        "--k1", "1.0", "--base_lr", "0.05", "--head_levels", str(levels)])
     args.patch_size = [64, 64]
     st = T.ArcoStep2D(args, "cuda:0")
     losses = []
@@ -30,9 +30,10 @@ def _run(dense, steps=2):
     return losses, params, teacher, banks
 
 
-def test_lazy_head_matches_dense_step():
+@pytest.mark.parametrize("levels", [1, 2])
+def test_lazy_head_matches_dense_step(levels):
     l_d, p_d, t_d, b_d = _run(1)
-    l_s, p_s, t_s, b_s = _run(0)
+    l_s, p_s, t_s, b_s = _run(0, levels=levels)
     assert all(abs(l) > 1e-3 for l in l_d)
     np.testing.assert_allclose(l_s, l_d, rtol=1e-5, atol=1e-6)
     for x, y in zip(b_s, b_d):
