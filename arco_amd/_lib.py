@@ -19,6 +19,8 @@ _SIGS = {
     "arco_mask_codes": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _F, _F, _I, _I, _P, _P, _P, _P, _P],
     "arco_compact_rows": [_P, _L, _I, _P, _P, _P],
     "arco_masked_proto": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P],
+    "arco_lv_weights": [_P, _L, _I, _I, _P, _P],
+    "arco_weighted_row_sum": [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _L, _P],
     "arco_gather_rows": [_P, _L, _I, _P, _P, _P, _L, _L, _P, _L, _P],
     "arco_bank_append": [_P, _L, _P, _L, _L, _I, _P, _P],
     "arco_normalize_rows": [_P, _L, _L, _I, _F, _P, _L, _P, _L, _P, _P],

@@ -189,6 +189,83 @@ __global__ __launch_bounds__(256) void masked_row_sum_kernel(const float* __rest
   }
 }
 
+// low-valid bits -> float weight rows [n_pix][Cp] (1.0 / 0.0), input of the bilinear adjoint
+__global__ void lv_weights_kernel(const uint64_t* __restrict__ codes, long n_pix, int C, int Cp, float* __restrict__ W) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pix * Cp) return;
+  const long p = i / Cp; const int c = (int)(i - p * Cp);
+  W[i] = (c < C && ((codes[p] >> ARCO_BIT_LV(c)) & 1)) ? 1.f : 0.f;
+}
+
+// weighted row sums: out[c][:] = sum_rows Wt[row][c0+c] * T[row][:]   (same tiling as masked_row_sum)
+template <int NDI>
+__global__ __launch_bounds__(256) void weighted_row_sum_kernel(const float* __restrict__ T, long ldt,
+                                                              const float* __restrict__ Wt, long ldw, long n_rows, int D,
+                                                              int c0, int nc, int lpr, long rows_per_block,
+                                                              float* __restrict__ partial /*[grid][nc][D]*/) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][8][D]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rpw = 64 / lpr, sub = lane / lpr, dl = lane % lpr;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
+  f32x4 acc[8][NDI];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < NDI; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+  for (long base = r0 + (long)wid * rpw; base < r1; base += 4 * rpw) {
+    const long row = base + sub;
+    float w[8]; bool any = false;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) { w[cc] = (row < r1 && cc < nc) ? Wt[row * ldw + c0 + cc] : 0.f; any |= (w[cc] != 0.f); }
+    if (any) {
+      const float* src = T + row * ldt;
+#pragma unroll
+      for (int di = 0; di < NDI; ++di) {
+        const int d = (di * lpr + dl) * 4;
+        if (d < D) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + d);
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) if (w[cc] != 0.f) acc[cc][di] += v * w[cc];
+        }
+      }
+    }
+  }
+  for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+      for (int di = 0; di < NDI; ++di)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[cc][di][e] += __shfl_xor(acc[cc][di][e], o, 64);
+  }
+  if (sub == 0) {
+    for (int cc = 0; cc < nc; ++cc)
+#pragma unroll
+      for (int di = 0; di < NDI; ++di) {
+        const int d = (di * lpr + dl) * 4;
+        if (d < D) *reinterpret_cast<f32x4*>(&red[((long)wid * 8 + cc) * D + d]) = acc[cc][di];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc * D; i += 256) {
+    const int cc = i / D, d = i % D;
+    const float s = ((red[(0 * 8 + cc) * (long)D + d] + red[(1 * 8 + cc) * (long)D + d]) +
+                     (red[(2 * 8 + cc) * (long)D + d] + red[(3 * 8 + cc) * (long)D + d]));
+    partial[((long)blockIdx.x * nc + cc) * D + d] = s;
+  }
+}
+// out[(c0+cc)*ldo + d] = (sum over slabs) * (totals ? 1/totals[c0+cc] : 1)
+__global__ void row_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nc, int D, int c0,
+                                        const int64_t* __restrict__ totals, float* __restrict__ out, long ldo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc * D) return;
+  const int cc = i / D, d = i % D;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[((long)b * nc + cc) * D + d];
+  if (totals) s /= (double)totals[c0 + cc];
+  out[(long)(c0 + cc) * ldo + d] = (float)s;
+}
+
 __global__ void proto_finalize_kernel(const float* __restrict__ partial, int nblk, int nc, int D, int c0,
                                       const int64_t* __restrict__ totals /*[3C], lv counts first*/,
                                       float* __restrict__ proto /*[C][D]*/) {
@@ -438,6 +515,40 @@ int arco_masked_proto(const float* T, long ldt, const uint64_t* codes, long n_pi
                          D, c0, nc, lpr, rpb, partial);
     hipLaunchKernelGGL(proto_finalize_kernel, dim3((nc * D + 255) / 256), dim3(256), 0, as_stream(stream), partial,
                        (int)grid, nc, D, c0, totals, proto);
+  }
+  return arco_launch_status();
+}
+
+int arco_lv_weights(const uint64_t* codes, long n_pix, int C, int Cp, float* W, void* stream) {
+  ARCO_CHECK_ARG(C <= ARCO_MAXC && Cp >= C);
+  const long tot = n_pix * Cp;
+  hipLaunchKernelGGL(lv_weights_kernel, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), codes, n_pix, C, Cp, W);
+  return arco_launch_status();
+}
+
+// out[c][0..D) = sum_rows Wt[row][c] * T[row][0..D)  (divided by totals[c] when totals != NULL);
+// partial: arco_proto_ws_floats(n_rows, C, D) floats
+int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
+                          const int64_t* totals, float* partial, float* out, long ldo, void* stream) {
+  ARCO_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 512 && (ldt & 3) == 0 && C <= ARCO_MAXC);
+  long grid = (n_rows + 2047) / 2048;
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  long rpb = (n_rows + grid - 1) / grid;
+  int lpr = 1;
+  while (lpr * 4 < D && lpr < 64) lpr <<= 1;
+  const int ndi = (D + lpr * 4 - 1) / (lpr * 4);
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    const int nc = (C - c0) < 8 ? (C - c0) : 8;
+    const size_t sh = (size_t)4 * 8 * D * sizeof(float);
+    if (ndi == 1)
+      hipLaunchKernelGGL(weighted_row_sum_kernel<1>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
+    else if (ndi == 2)
+      hipLaunchKernelGGL(weighted_row_sum_kernel<2>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
+    else
+      hipLaunchKernelGGL(weighted_row_sum_kernel<4>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
+    hipLaunchKernelGGL(row_sum_finalize_kernel, dim3((nc * D + 255) / 256), dim3(256), 0, as_stream(stream), partial,
+                       (int)grid, nc, D, c0, totals, out, ldo);
   }
   return arco_launch_status();
 }

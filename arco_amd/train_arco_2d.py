@@ -85,6 +85,7 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=0, help='1: train on synthetic ACDC-shaped tensors')
     p.add_argument('--in_chns', type=int, default=1, help='input channels (reference: 1)')
     p.add_argument('--graphs', type=int, default=1, help='1: replay the no-grad U-Net forwards as HIP graphs')
+    p.add_argument('--dense_teacher', type=int, default=0, help='1: materialise the dense teacher representation')
     p.add_argument('--head_levels', type=int, default=2, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
     return p
@@ -199,7 +200,12 @@ class ArcoStep2D:
             self.s_fwd_stats(l_data)  # images_cj2_l forward (:311): BN running stats only; its FE/q_rep
                                      # outputs (l_feature_map_2, :319,326) are never read -> not computed
             # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
-            rep_all_teacher = self.k_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)])
+            fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
+            if getattr(a, "dense_teacher", 0) or dense:
+                rep_all_teacher, lazy_t = self.k_feature_extractor(fm_t), None
+            else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys/class
+                x3p_t, f4_t = self.k_feature_extractor.forward_lowres(fm_t)
+                rep_all_teacher, lazy_t = None, (x3p_t, f4_t, self.k_feature_extractor.fea4.weight)
         fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]         # :317-318
         if dense:
             rep_all = self.q_rep(self.q_feature_extractor(fm_all))       # :324-325,330
@@ -211,7 +217,8 @@ class ArcoStep2D:
         C_.contrast_sample(plan, self.memobank, self.queue_size, a.func, a.num_queries, a.num_negatives)
         ev2 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev2[0].record()
-        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size)
+        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size,
+                            lazy_teacher=lazy_t)
         if plan.valid_seg <= 1 or not plan.entries:
             reco_loss = self.q_representation[1].weight.sum() * 0.0      # :417-424 zero attached to the graph
         else:

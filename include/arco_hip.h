@@ -38,6 +38,11 @@ int arco_compact_rows(const uint64_t* codes, long n_pix, int C, const uint32_t* 
 long arco_proto_ws_floats(long n_pix, int C, int D);
 int arco_masked_proto(const float* T, long ldt, const uint64_t* codes, long n_pix, int C, int D,
                       const int64_t* totals, float* partial, float* proto, void* stream);
+/* linear-prototype path: low-valid bits as float rows; weighted row sums sum_rows Wt[row][c]*T[row][:]
+ * (prototype = W_fea4 . masked mean of the fea4 INPUT, mask pushed through the bilinear adjoint)           */
+int arco_lv_weights(const uint64_t* codes, long n_pix, int C, int Cp, float* W, void* stream);
+int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
+                          const int64_t* totals, float* partial, float* out, long ldo, void* stream);
 /* out[j] = src[list ? list[idx[j]] : idx[j]], idx = idx64 | idx32 | identity, j in [first, first+n)
  * (rep[mask][idx] / rep_teacher[negative_mask], loss_helper_3d.py:403,455-457).                           */
 int arco_gather_rows(const float* src, long ld_src, int D, const int32_t* list, const int64_t* idx64,

@@ -8,14 +8,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(dense, steps=2, levels=2):
+def _run(dense, steps=2, levels=2, dense_teacher=1):
     from arco_amd import ops
     from arco_amd import train_arco_2d as T
     random.seed(3); np.random.seed(3); torch.manual_seed(3)
     ops.reseed_dropout(99)
     args = T.build_parser().parse_args(["--batch_size", "2", "--queue_size", "300", "--synthetic", "1",
                                         "--num_queries", "64", "--num_negatives", "32", "--dense_head", str(dense),
-                                        "--k1", "1.0", "--base_lr", "0.05", "--head_levels", str(levels)])
+                                        "--k1", "1.0", "--base_lr", "0.05", "--head_levels", str(levels), "--dense_teacher", str(dense_teacher)])
     args.patch_size = [64, 64]
     st = T.ArcoStep2D(args, "cuda:0")
     losses = []
@@ -42,3 +42,14 @@ def test_lazy_head_matches_dense_step(levels):
     np.testing.assert_allclose(p_s.numpy(), p_d.numpy(), rtol=1e-3, atol=2e-5)
     np.testing.assert_allclose(t_s.numpy(), t_d.numpy(), rtol=1e-4, atol=1e-6)
     assert float((p_s - p_d).abs().max()) < 1e-3
+
+
+def test_lazy_teacher_matches_dense_teacher():
+    """Linear-prototype + lazy-key teacher path vs the dense teacher representation (same sparse student head)."""
+    l_d, p_d, t_d, b_d = _run(0, dense_teacher=1)
+    l_s, p_s, t_s, b_s = _run(0, dense_teacher=0)
+    np.testing.assert_allclose(l_s, l_d, rtol=5e-5, atol=1e-6)
+    for x, y in zip(b_s, b_d):
+        assert x.shape == y.shape
+        np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(p_s.numpy(), p_d.numpy(), rtol=1e-3, atol=2e-5)
