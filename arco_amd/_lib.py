@@ -47,6 +47,11 @@ _SIGS = {
     "arco_up_neighbors": [_P, _L, _I, _I, _I, _I, _P, _P, _P],
     "arco_lerp4_cat_rows": [_P, _L, _I, _P, _P, _L, _I, _P, _L, _P, _L, _P],
     "arco_lerp4_cat_rows_bwd": [_P, _L, _I, _P, _P, _L, _P, _L, _P, _L, _I, _P],
+    "arco_s2d3": [_P, _L, _I, _I, _I, _I, _I, _P, _L, _I, _P],
+    "arco_trilinear_fwd": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "arco_trilinear_bwd": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "arco_conv3d_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
+    "arco_conv3d_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "arco_copy_rows": [_P, _L, _L, _I, _P, _L, _I, _P],
     "arco_nchw_to_nhwc": [_P, _I, _I, _L, _P, _L, _P],
     "arco_nhwc_to_nchw": [_P, _L, _I, _I, _L, _P, _P],

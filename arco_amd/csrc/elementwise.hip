@@ -417,6 +417,92 @@ __global__ __launch_bounds__(256) void lerp4_cat_rows_bwd_kernel(const float* __
   for (int c = lane; c < Chi; c += 64) atomicAdd(h + c, g[Clo + c]);
 }
 
+// ---- 3-D: space-to-depth / depth-to-space (factor 2) for the k2s2 (transposed) convs of the V-Net
+// (vnetWithArgs.py:67-118): a k=2,s=2 Conv3d is a GEMM over the 8*C channels of the packed tensor.
+// dir 0: P[q][tap*C + c] = V[(n, 2x+dx, 2y+dy, 2z+dz)][c] ; dir 1: the inverse scatter.  tap = dx*4+dy*2+dz
+__global__ __launch_bounds__(256) void s2d3_kernel(float* __restrict__ V, long ldv, int NV, int X2, int Y2, int Z2, int C,
+                                                  float* __restrict__ P, long ldp, int dir) {
+  const int q4 = C / 4;
+  const long tot = (long)NV * X2 * Y2 * Z2 * 8 * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q4) * 4; long r = i / q4;
+    const int tap = r % 8; r /= 8;
+    const int z = r % Z2; r /= Z2; const int y = r % Y2; r /= Y2; const int x = r % X2; const long n = r / X2;
+    const long q = ((n * X2 + x) * Y2 + y) * (long)Z2 + z;
+    const long v = (((n * (2 * X2) + 2 * x + (tap >> 2)) * (2 * Y2) + 2 * y + ((tap >> 1) & 1)) * (long)(2 * Z2) + 2 * z + (tap & 1));
+    float* pv = V + v * ldv + c; float* pp = P + q * ldp + tap * C + c;
+    if (dir == 0) *reinterpret_cast<f32x4*>(pp) = *reinterpret_cast<const f32x4*>(pv);
+    else *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(pp);
+  }
+}
+
+// ---- trilinear resize, align_corners=True (nn.Upsample(mode='trilinear'), model_3D.py:46-58)
+__global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ X, long ldx, int NV, int Di, int Hi, int Wi,
+                                                           int C, int Do, int Ho, int Wo, float* __restrict__ Y, long ldy) {
+  const int q4 = C / 4;
+  const float sd = Do > 1 ? (float)(Di - 1) / (float)(Do - 1) : 0.f, sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f,
+              sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  const long tot = (long)NV * Do * Ho * Wo * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q4) * 4; long r = i / q4;
+    const int xo = r % Wo; r /= Wo; const int yo = r % Ho; r /= Ho; const int zo = r % Do; const long n = r / Do;
+    int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+    ac_src(zo, sd, Di, z0, z1, lz); ac_src(yo, sh, Hi, y0, y1, ly); ac_src(xo, sw, Wi, x0, x1, lx);
+    const float hz = 1.f - lz, hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = X + (n * Di) * (long)Hi * Wi * ldx + c;
+#define TL(zz, yy, xx) (*reinterpret_cast<const f32x4*>(b + (((long)(zz) * Hi + (yy)) * Wi + (xx)) * ldx))
+    const f32x4 v000 = TL(z0, y0, x0), v001 = TL(z0, y0, x1), v010 = TL(z0, y1, x0), v011 = TL(z0, y1, x1);
+    const f32x4 v100 = TL(z1, y0, x0), v101 = TL(z1, y0, x1), v110 = TL(z1, y1, x0), v111 = TL(z1, y1, x1);
+#undef TL
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = hz * (hy * (hx * v000[e] + lx * v001[e]) + ly * (hx * v010[e] + lx * v011[e])) +
+             lz * (hy * (hx * v100[e] + lx * v101[e]) + ly * (hx * v110[e] + lx * v111[e]));
+    *reinterpret_cast<f32x4*>(Y + (((n * Do + zo) * Ho + yo) * (long)Wo + xo) * ldy + c) = o;
+  }
+}
+__device__ __forceinline__ void ac_range(int i, float s, int out_size, int& a, int& b) {
+  if (s > 0.f) { const float is = 1.f / s; a = (int)floorf((float)(i - 1) * is) - 1; b = (int)ceilf((float)(i + 1) * is) + 1; }
+  else { a = 0; b = out_size - 1; }
+  a = max(a, 0); b = min(b, out_size - 1);
+}
+__device__ __forceinline__ float ac_weight(int o, float s, int in_size, int i) {
+  int i0, i1; float l; ac_src(o, s, in_size, i0, i1, l);
+  float w = 0.f;
+  if (i0 == i) w += 1.f - l;
+  if (i1 == i) w += l;
+  return (i0 == i || i1 == i) ? w : -1.f;      // -1: output o does not reference input i
+}
+__global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restrict__ dY, long ldy, int NV, int Di, int Hi, int Wi,
+                                                           int C, int Do, int Ho, int Wo, float* __restrict__ dX, long ldx) {
+  const int q4 = C / 4;
+  const float sd = Do > 1 ? (float)(Di - 1) / (float)(Do - 1) : 0.f, sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f,
+              sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  const long tot = (long)NV * Di * Hi * Wi * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q4) * 4; long r = i / q4;
+    const int xi = r % Wi; r /= Wi; const int yi = r % Hi; r /= Hi; const int zi = r % Di; const long n = r / Di;
+    int za, zb, ya, yb, xa, xb;
+    ac_range(zi, sd, Do, za, zb); ac_range(yi, sh, Ho, ya, yb); ac_range(xi, sw, Wo, xa, xb);
+    f32x4 acc = {0, 0, 0, 0};
+    for (int zo = za; zo <= zb; ++zo) {
+      const float wz = ac_weight(zo, sd, Di, zi); if (wz < 0.f) continue;
+      for (int yo = ya; yo <= yb; ++yo) {
+        const float wy = ac_weight(yo, sh, Hi, yi); if (wy < 0.f) continue;
+        for (int xo = xa; xo <= xb; ++xo) {
+          const float wx = ac_weight(xo, sw, Wi, xi); if (wx < 0.f) continue;
+          const f32x4 g = *reinterpret_cast<const f32x4*>(dY + (((n * Do + zo) * Ho + yo) * (long)Wo + xo) * ldy + c);
+          const float w = wz * wy * wx;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += w * g[e];
+        }
+      }
+    }
+    *reinterpret_cast<f32x4*>(dX + (((n * Di + zi) * Hi + yi) * (long)Wi + xi) * ldx + c) = acc;
+  }
+}
+
 // ---- strided channel-slice copy / add:  Y[r][0..C) (+)= X[r][0..C)
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ X, long ldx, long M, int C,
                                                        float* __restrict__ Y, long ldy, int accumulate) {
@@ -608,6 +694,27 @@ int arco_lerp4_cat_rows_bwd(const float* dX, long ldx, int Clo, const float* lyl
   if (n == 0) return ARCO_OK;
   hipLaunchKernelGGL(lerp4_cat_rows_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), dX, ldx, Clo, lylx, pix,
                      n, dV, ldv, dhi, ldhi, Chi);
+  return arco_launch_status();
+}
+
+int arco_s2d3(float* V, long ldv, int NV, int X2, int Y2, int Z2, int C, float* P, long ldp, int dir, void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (ldv & 3) == 0 && (ldp & 3) == 0);
+  hipLaunchKernelGGL(s2d3_kernel, dim3(ew_grid((long)NV * X2 * Y2 * Z2 * 8 * (C / 4))), dim3(256), 0, as_stream(stream), V, ldv,
+                     NV, X2, Y2, Z2, C, P, ldp, dir);
+  return arco_launch_status();
+}
+int arco_trilinear_fwd(const float* X, long ldx, int NV, int Di, int Hi, int Wi, int C, int Do, int Ho, int Wo, float* Y,
+                       long ldy, void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0);
+  hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(ew_grid((long)NV * Do * Ho * Wo * (C / 4))), dim3(256), 0, as_stream(stream),
+                     X, ldx, NV, Di, Hi, Wi, C, Do, Ho, Wo, Y, ldy);
+  return arco_launch_status();
+}
+int arco_trilinear_bwd(const float* dY, long ldy, int NV, int Di, int Hi, int Wi, int C, int Do, int Ho, int Wo, float* dX,
+                       long ldx, void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0);
+  hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(ew_grid((long)NV * Di * Hi * Wi * (C / 4))), dim3(256), 0, as_stream(stream),
+                     dY, ldy, NV, Di, Hi, Wi, C, Do, Ho, Wo, dX, ldx);
   return arco_launch_status();
 }
 

@@ -21,11 +21,12 @@ struct IgemmArgs {
   const float* R; long ldr;
   float* stat_sum; float* stat_sq;   // [N][n_mblocks] block partials (nullable)
   int n_mblocks; int n_nblocks;
-  int NB, H, W;                      // images, rows, cols (TAPS==9); TAPS==1 uses M only
+  int NB, H, W;                      // images (planes for 3-D), rows, cols (TAPS==9); TAPS==1 uses M only
+  int D3;                            // 3-D: planes per volume (depth taps active when DEPTH==3); 2-D: 1
   long M;                            // total pixels
 };
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int TH = BM / 16;
   constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
@@ -105,8 +106,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     }
   }
 
+  // 3-D (DEPTH==3): a 3x3x3 conv is the sum over the depth tap dd of a 3x3 conv of input plane x+dd-1
+  // with weight slice Wp[dd*9 .. dd*9+8]; the K loop simply runs DEPTH times over shifted planes.
+  const int nchunks = (a.Kpad + KC - 1) / KC;
+  const int plane = DEPTH == 3 ? img % a.D3 : 0;
+  const long plane_elems = (long)a.H * a.W * a.lda;
+  const long wslice = (long)9 * a.Npad * a.Kpad;
   f32x4 ra[NA_IT], rb[NB_IT];
-  auto load_chunk = [&](int kc0) {
+  auto load_chunk = [&](int itc) {
+    const int dd = DEPTH == 3 ? itc / nchunks : 0;
+    const int kc0 = (DEPTH == 3 ? itc - dd * nchunks : itc) * KC;
+    const bool plane_ok = DEPTH == 3 ? (plane + dd - 1 >= 0 && plane + dd - 1 < a.D3) : true;
+    const long aoff = DEPTH == 3 ? (long)(dd - 1) * plane_elems + kc0 : kc0;
+    const long boff = DEPTH == 3 ? (long)dd * wslice + kc0 : kc0;
 #pragma unroll
     for (int it = 0; it < NA_IT; ++it) {
       f32x4 v = f32x4{0, 0, 0, 0};
@@ -114,11 +126,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
       if constexpr (VEC) {
         // (the scalar variant lives in its own instantiation: sharing registers between the two load
         //  forms makes hipcc wait vmcnt(0) before every vector load and serialises the prefetch)
-        if (srcA[it] && k < a.K) v = *reinterpret_cast<const f32x4*>(srcA[it] + kc0);
+        if (srcA[it] && plane_ok && k < a.K) v = *reinterpret_cast<const f32x4*>(srcA[it] + aoff);
       } else {
-        if (srcA[it]) {
+        if (srcA[it] && plane_ok) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (k + e < a.K) v[e] = srcA[it][kc0 + e];
+          for (int e = 0; e < 4; ++e) if (k + e < a.K) v[e] = srcA[it][aoff + e];
         }
       }
       ra[it] = v;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
     for (int it = 0; it < NB_IT; ++it) {
       f32x4 v = f32x4{0, 0, 0, 0};
-      if (srcB[it] && kc0 + kB[it] < a.Kpad) v = *reinterpret_cast<const f32x4*>(srcB[it] + kc0);
+      if (srcB[it] && kc0 + kB[it] < a.Kpad) v = *reinterpret_cast<const f32x4*>(srcB[it] + boff);
       rb[it] = v;
     }
   };
@@ -167,15 +179,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   };
 
   // main loop: the global loads of chunk k+1 are in flight while chunk k is on the matrix cores
-  const int nchunks = (a.Kpad + KC - 1) / KC;
+  const int niter = DEPTH * nchunks;
   load_chunk(0);
   store_chunk(smem);
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c = 0; c < niter; ++c) {
     float* cur = DB ? smem + (c & 1) * BUF : smem;
     float* nxt = DB ? smem + ((c + 1) & 1) * BUF : smem;
-    const bool more = c + 1 < nchunks;
-    if (more) load_chunk((c + 1) * KC);
+    const bool more = c + 1 < niter;
+    if (more) load_chunk(c + 1);
     compute(cur);
     if (more) {
       if (!DB) __syncthreads();          // single buffer: everyone done reading before it is overwritten
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 }
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH>
 static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   constexpr int TH = BM / 16;
   constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
@@ -255,7 +267,7 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   size_t sh = (size_t)(DB ? 2 : 1) * (AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
-  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC>;
+  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC, DEPTH>;
   static bool attr_set = false;      // once per instantiation (never inside a stream capture after warm-up)
   if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
   IgemmArgs b = a;
@@ -266,11 +278,11 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   return arco_launch_status();
 }
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, int DEPTH = 1>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   const bool vec = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
-  if (vec) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true>(a, st, n_mblocks_out);
-  return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, false>(a, st, n_mblocks_out);
+  if (vec) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH>(a, st, n_mblocks_out);
+  return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, false, DEPTH>(a, st, n_mblocks_out);
 }
 
 // config choice shared by the launch and the "how many M-blocks" query
@@ -280,6 +292,12 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
     if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 16, true>(a, st, nmb);
     if (a.M * (long)a.Npad <= 4096l * 1024) return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
     return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
+  }
+  if (taps == 27) {   // 3x3x3: planes of H x W, depth taps looped inside the kernel
+    if (a.Npad <= 16) return launch_igemm<9, 128, 16, 4, 1, 16, false, 3>(a, st, nmb);
+    if (a.Npad <= 32) return launch_igemm<9, 128, 32, 4, 1, 16, false, 3>(a, st, nmb);
+    if ((long)a.NB * a.H * a.W <= 32768) return launch_igemm<9, 64, 64, 2, 2, 16, false, 3>(a, st, nmb);
+    return launch_igemm<9, 128, 64, 4, 1, 16, false, 3>(a, st, nmb);
   }
   if (taps == 9) {
     if (a.Npad <= 16) return launch_igemm<9, 256, 16, 4, 1, 16, false>(a, st, nmb);
@@ -318,7 +336,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int Ci
 struct WgradArgs {
   const float* dZ; long ldz; int Cout;
   const float* Ain; long lda; int Cin;
-  int taps, NB, H, W; long M;
+  int taps, NB, H, W, D3; long M;
   float* partial;      // [chunks][taps][CoutPad][CinPad]
   int CoutPad, CinPad, n_tiles;
 };
@@ -335,7 +353,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const int ci_tiles = a.CinPad / CI_B;
   const int tap = blockIdx.z / ci_tiles, cit = blockIdx.z % ci_tiles;
   const int co0 = blockIdx.y * CO_B, ci0 = cit * CI_B;
-  const int dy = a.taps == 9 ? tap / 3 - 1 : 0, dx = a.taps == 9 ? tap % 3 - 1 : 0;
+  const bool sp = a.taps >= 9;                     // spatial taps (3x3 per plane, x3 planes when taps == 27)
+  const int t9 = tap % 9, dpl = a.taps == 27 ? tap / 9 - 1 : 0;
+  const int dy = sp ? t9 / 3 - 1 : 0, dx = sp ? t9 % 3 - 1 : 0;
   const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
 
   f32x4 acc[CO_T][CI_T];
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
   for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
     int img = 0, y0 = 0, x0 = 0; long m0 = 0;
-    if (a.taps == 9) {
+    if (sp) {
       int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; img = tt / tiles_y;
       y0 = ty * 8; x0 = tx * 16;
     } else {
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     for (int idx = tid; idx < 128 * (CO_B / 4); idx += 256) {
       const int p = idx / (CO_B / 4), q = idx % (CO_B / 4);
       long pix = -1;
-      if (a.taps == 9) { const int y = y0 + p / 16, x = x0 + p % 16; if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x; }
+      if (sp) { const int y = y0 + p / 16, x = x0 + p % 16; if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x; }
       else { const long m = m0 + p; if (m < a.M) pix = m; }
       f32x4 v = f32x4{0, 0, 0, 0};
       if (pix >= 0) {
@@ -374,10 +394,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     for (int idx = tid; idx < 128 * (CI_B / 4); idx += 256) {
       const int p = idx / (CI_B / 4), q = idx % (CI_B / 4);
       long pix = -1;
-      if (a.taps == 9) {
+      if (sp) {
         const int yo = y0 + p / 16, xo = x0 + p % 16;
         const int y = yo + dy, x = xo + dx;
-        if (yo < a.H && xo < a.W && y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
+        const int pl = a.taps == 27 ? img % a.D3 + dpl : 0;
+        if (yo < a.H && xo < a.W && y >= 0 && y < a.H && x >= 0 && x < a.W && pl >= 0 && pl < a.D3)
+          pix = ((long)(img + dpl) * a.H + y) * a.W + x;
       } else { const long m = m0 + p; if (m < a.M) pix = m; }
       f32x4 v = f32x4{0, 0, 0, 0};
       if (pix >= 0) {
@@ -503,7 +525,7 @@ extern "C" {
 // Query: number of M-blocks (= BN-stat partial slabs per channel) the conv launch will use.
 int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout) {
   IgemmArgs a{};
-  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W;
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
   a.N = Cout; a.Npad = (Cout + 15) / 16 * 16;
   int nmb = 0;
   if (dispatch_igemm(a, taps, nullptr, &nmb) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
@@ -520,24 +542,38 @@ int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode,
   return arco_launch_status();
 }
 
+int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                    const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                    int NV, int D3, int H, int W, void* stream);
 // out[pix][0..N) = conv(in)[pix] (+bias) (+residual); channels-last; taps in {1, 9}
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                   int NB, int H, int W, void* stream) {
-  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0);
+  return arco_conv3d_fwd(in, ld_in, K, Wp, N, out, ld_out, bias, residual, ld_res, stat_sum, stat_sq, taps, NB, 1, H, W,
+                         stream);
+}
+
+// 3-D generalisation: NV volumes of D3 planes of H x W; taps in {1, 9 (per plane), 27 (3x3x3, pad 1)}
+int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                    const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                    int NV, int D3, int H, int W, void* stream) {
+  const int NB = NV * D3;
+  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0);
   IgemmArgs a{};
   a.A = in; a.lda = ld_in; a.Wp = Wp; a.N = N; a.K = K;
   a.Npad = (N + 15) / 16 * 16; a.Kpad = (K + 15) / 16 * 16;
   a.C = out; a.ldc = ld_out; a.bias = bias; a.R = residual; a.ldr = ld_res;
   a.stat_sum = stat_sum; a.stat_sq = stat_sq;
-  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W;
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = D3;
   return dispatch_igemm(a, taps, as_stream(stream), nullptr);
 }
 
+int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
+                      int D3, int H, int W, float* ws, float* dW, int accumulate, void* stream);
 long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M) {
   const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
   const int CoutPad = (Cout + co_b - 1) / co_b * co_b, CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
-  const long n_tiles = (M + 127) / 128 + 64;   // upper bound incl. ragged 2-D tiles
+  const long n_tiles = (M + 127) / 128 * 4 + 64;   // upper bound incl. ragged spatial tiles
   const long yz = (long)(CoutPad / co_b) * (CinPad / ci_b) * taps;
   long chunks = 2048 / yz; if (chunks < 1) chunks = 1; if (chunks > n_tiles) chunks = n_tiles;
   return chunks * taps * CoutPad * CinPad;
@@ -545,13 +581,20 @@ long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M) {
 
 int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NB,
                     int H, int W, float* ws, float* dW, int accumulate, void* stream) {
-  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9));
+  return arco_conv3d_wgrad(dZ, ld_dz, Cout, in, ld_in, Cin, taps, NB, 1, H, W, ws, dW, accumulate, stream);
+}
+
+int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
+                      int D3, int H, int W, float* ws, float* dW, int accumulate, void* stream) {
+  const int NB = NV * D3;
+  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9 || taps == 27));
   WgradArgs a{};
+  a.D3 = D3;
   a.dZ = dZ; a.ldz = ld_dz; a.Cout = Cout; a.Ain = in; a.lda = ld_in; a.Cin = Cin; a.taps = taps;
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.partial = ws;
   const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
   a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
-  a.n_tiles = taps == 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
+  a.n_tiles = taps >= 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
   const long yz = (long)(a.CoutPad / co_b) * (a.CinPad / ci_b) * taps;
   long chunks = 2048 / yz; if (chunks < 1) chunks = 1; if (chunks > a.n_tiles) chunks = a.n_tiles;
   dim3 grid((unsigned)chunks, a.CoutPad / co_b, (a.CinPad / ci_b) * taps);

@@ -1,0 +1,163 @@
+"""3-D V-Net of the ARCO hot path on MI355X - drop-in for the reference's
+code/networks/vnetWithArgs.py (ConvBlock :5-31, DownsamplingConvBlock :67-91,
+UpsamplingDeconvBlock :94-118, VNet :145-252), batch-norm variant (the one
+net_factory_3d builds, net_factory_3dArgs.py:16-18).
+
+Same class names, constructor arguments, return values and state_dict keys (the nn.Conv3d /
+nn.BatchNorm3d children are parameter containers).  Forward on channels-last-3d activations:
+  3x3x3 conv  = fp32 MFMA implicit GEMM, the depth tap is an outer loop over shifted planes,
+                BN partial statistics fused in the epilogue, then one BN+ReLU apply pass;
+  k2 s2 conv  = space-to-depth (8*C channels) + 1x1x1 GEMM (+fused BN statistics);
+  k2 s2 convT = 1x1x1 GEMM to 8*C channels + depth-to-space, then BN+ReLU.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def _need_bn(normalization):
+    if normalization != 'batchnorm':
+        raise NotImplementedError("only normalization='batchnorm' is on the ARCO hot path "
+                                  "(net_factory_3dArgs.py:17-18)")
+
+
+def _bn_stage(x, conv, bn, training):
+    if training:
+        y = ops.conv_bn_act(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            slope=0.0, p=0.0, momentum=bn.momentum, eps=bn.eps)
+        bn.num_batches_tracked += 1
+        return y
+    return ops.conv_bn_act_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                slope=0.0, eps=bn.eps)
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, n_stages, n_filters_in, n_filters_out, normalization='none'):
+        super(ConvBlock, self).__init__()
+        _need_bn(normalization)
+        ops_ = []
+        for i in range(n_stages):
+            ops_.append(nn.Conv3d(n_filters_in if i == 0 else n_filters_out, n_filters_out, 3, padding=1))
+            ops_.append(nn.BatchNorm3d(n_filters_out))
+            ops_.append(nn.ReLU(inplace=True))
+        self.conv = nn.Sequential(*ops_)
+        self.n_stages = n_stages
+
+    def forward(self, x):
+        for i in range(self.n_stages):
+            x = _bn_stage(x, self.conv[3 * i], self.conv[3 * i + 1], self.training)
+        return x
+
+
+class DownsamplingConvBlock(nn.Module):
+    def __init__(self, n_filters_in, n_filters_out, stride=2, normalization='none'):
+        super(DownsamplingConvBlock, self).__init__()
+        _need_bn(normalization)
+        assert stride == 2
+        self.conv = nn.Sequential(nn.Conv3d(n_filters_in, n_filters_out, stride, padding=0, stride=stride),
+                                  nn.BatchNorm3d(n_filters_out), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        conv, bn = self.conv[0], self.conv[1]
+        co, ci = conv.weight.shape[0], conv.weight.shape[1]
+        w2 = conv.weight.permute(0, 2, 3, 4, 1).reshape(co, 8 * ci, 1, 1, 1)      # [co][(dx,dy,dz), ci]
+        xs = ops.space_to_depth3(x)
+        if self.training:
+            y = ops.conv_bn_act(xs, w2, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
+                                p=0.0, momentum=bn.momentum, eps=bn.eps)
+            bn.num_batches_tracked += 1
+            return y
+        return ops.conv_bn_act_eval(xs, w2, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
+                                    eps=bn.eps)
+
+
+class UpsamplingDeconvBlock(nn.Module):
+    def __init__(self, n_filters_in, n_filters_out, stride=2, normalization='none'):
+        super(UpsamplingDeconvBlock, self).__init__()
+        _need_bn(normalization)
+        assert stride == 2
+        self.conv = nn.Sequential(nn.ConvTranspose3d(n_filters_in, n_filters_out, stride, padding=0, stride=stride),
+                                  nn.BatchNorm3d(n_filters_out), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        conv, bn = self.conv[0], self.conv[1]
+        ci, co = conv.weight.shape[0], conv.weight.shape[1]
+        w2 = conv.weight.permute(2, 3, 4, 1, 0).reshape(8 * co, ci, 1, 1, 1)      # [(dx,dy,dz), co][ci]
+        y = ops.conv(x, w2, conv.bias.repeat(8))
+        z = ops.depth_to_space3(y)
+        if self.training:
+            a = ops.bn_act(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, momentum=bn.momentum,
+                           eps=bn.eps)
+            bn.num_batches_tracked += 1
+            return a
+        with torch.no_grad():
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+            return torch.relu(z * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
+
+
+class VNet(nn.Module):
+    def __init__(self, n_channels=3, n_classes=2, n_filters=16, normalization='none', has_dropout=False):
+        super(VNet, self).__init__()
+        self.has_dropout = has_dropout
+        nf = n_filters
+        self.block_one = ConvBlock(1, n_channels, nf, normalization=normalization)
+        self.block_one_dw = DownsamplingConvBlock(nf, 2 * nf, normalization=normalization)
+        self.block_two = ConvBlock(2, nf * 2, nf * 2, normalization=normalization)
+        self.block_two_dw = DownsamplingConvBlock(nf * 2, nf * 4, normalization=normalization)
+        self.block_three = ConvBlock(3, nf * 4, nf * 4, normalization=normalization)
+        self.block_three_dw = DownsamplingConvBlock(nf * 4, nf * 8, normalization=normalization)
+        self.block_four = ConvBlock(3, nf * 8, nf * 8, normalization=normalization)
+        self.block_four_dw = DownsamplingConvBlock(nf * 8, nf * 16, normalization=normalization)
+        self.block_five = ConvBlock(3, nf * 16, nf * 16, normalization=normalization)
+        self.block_five_up = UpsamplingDeconvBlock(nf * 16, nf * 8, normalization=normalization)
+        self.block_six = ConvBlock(3, nf * 8, nf * 8, normalization=normalization)
+        self.block_six_up = UpsamplingDeconvBlock(nf * 8, nf * 4, normalization=normalization)
+        self.block_seven = ConvBlock(3, nf * 4, nf * 4, normalization=normalization)
+        self.block_seven_up = UpsamplingDeconvBlock(nf * 4, nf * 2, normalization=normalization)
+        self.block_eight = ConvBlock(2, nf * 2, nf * 2, normalization=normalization)
+        self.block_eight_up = UpsamplingDeconvBlock(nf * 2, nf, normalization=normalization)
+        self.block_nine = ConvBlock(1, nf, nf, normalization=normalization)
+        self.out_conv = nn.Conv3d(nf, n_classes, 1, padding=0)
+        self.dropout = nn.Dropout3d(p=0.5, inplace=False)
+
+    def _drop(self, x):
+        if self.has_dropout and self.training:
+            return ops.dropout3d(x, self.dropout.p)
+        return x
+
+    def encoder(self, input):
+        x = ops.to_channels_last(input.to(torch.float32))
+        x1 = self.block_one(x)
+        x2 = self.block_two(self.block_one_dw(x1))
+        x3 = self.block_three(self.block_two_dw(x2))
+        x4 = self.block_four(self.block_three_dw(x3))
+        x5 = self._drop(self.block_five(self.block_four_dw(x4)))
+        return [x1, x2, x3, x4, x5]
+
+    def decoder(self, features):
+        x1, x2, x3, x4, x5 = features
+        x5_up = self.block_five_up(x5) + x4
+        feature_map = [x5_up]
+        x6_up = self.block_six_up(self.block_six(x5_up)) + x3
+        feature_map.append(x6_up)
+        x7_up = self.block_seven_up(self.block_seven(x6_up)) + x2
+        feature_map.append(x7_up)
+        x8_up = self.block_eight_up(self.block_eight(x7_up)) + x1
+        feature_map.append(x8_up)
+        x9 = self.block_nine(x8_up)
+        feature_map.append(x9)
+        x9 = self._drop(x9)
+        out = ops.conv(x9, self.out_conv.weight, self.out_conv.bias)
+        return out, feature_map
+
+    def forward(self, input, turnoff_drop=False):
+        if turnoff_drop:
+            has_dropout = self.has_dropout
+            self.has_dropout = False
+        features = self.encoder(input)
+        out, feature_map = self.decoder(features)
+        if turnoff_drop:
+            self.has_dropout = has_dropout
+        return out, feature_map[0], feature_map

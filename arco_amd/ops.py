@@ -40,10 +40,32 @@ def new_act(nb, c, h, w, dev):
     return torch.empty((nb, h, w, c), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
 
 
+def new_act_nd(n, c, spatial, dev):
+    """Fresh channels-last activation, logical [n, c, *spatial] (2-D or 3-D)."""
+    t = torch.empty((n, *spatial, c), dtype=torch.float32, device=dev)
+    return t.movedim(-1, 1)
+
+
 def _geom(x):
     nb, c, h, w = x.shape
     r, ld = rows_view(x)
     return r, ld, int(nb), int(c), int(h), int(w)
+
+
+def _geom_nd(x):
+    """rows, ld, n_volumes, planes-per-volume (1 for 2-D), H, W, C, spatial tuple."""
+    r, ld = rows_view(x)
+    sp = tuple(int(v) for v in x.shape[2:])
+    if len(sp) == 2:
+        return r, ld, int(x.shape[0]), 1, sp[0], sp[1], int(x.shape[1]), sp
+    return r, ld, int(x.shape[0]), sp[0], sp[1], sp[2], int(x.shape[1]), sp
+
+
+def _taps(weight):
+    t = 1
+    for k in weight.shape[2:]:
+        t *= int(k)
+    return t
 
 
 # packed weights are reused until the weights change: optimizers / EMA bump WEIGHT_EPOCH.
@@ -86,30 +108,35 @@ def pack_weight(weight, taps, mode):
     return wp
 
 
-def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False):
-    """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out [nb,n,h,w] channels-last, stat slabs or None)."""
-    out = new_act(nb, n, h, w, xr.device)
+def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1):
+    """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out channels-last, stat slabs or None).
+    2-D: nb images of h x w -> out [nb,n,h,w].  3-D (d3 > 1): nb volumes of d3 planes -> out [nb,n,d3,h,w]."""
+    if d3 > 1:
+        out = new_act_nd(nb, n, (d3, h, w), xr.device)
+    else:
+        out = new_act(nb, n, h, w, xr.device)
     ssum = ssq = None
     nmb = 0
     if stats:
-        nmb = L.query("arco_conv_mblocks", taps, nb, h, w, n)
+        nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, n)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
     if PROFILE is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    L.call("arco_conv_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
-           L.ptr(ssum), L.ptr(ssq), taps, nb, h, w)
+    L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
+           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w)
     if PROFILE is not None:
         ev[1].record()
-        PROFILE.setdefault((taps, nb * h * w, n, k), []).append(ev)
+        PROFILE.setdefault((taps, nb * d3 * h * w, n, k), []).append(ev)
     return out, (ssum, ssq, nmb)
 
 
-def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like):
-    ws = torch.empty(L.query("arco_wgrad_ws_floats", co, ci, taps, nb * h * w), dtype=torch.float32, device=dzr.device)
+def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
+    ws = torch.empty(L.query("arco_wgrad_ws_floats", co, ci, taps, nb * d3 * h * w), dtype=torch.float32,
+                     device=dzr.device)
     dw = torch.empty_like(like, memory_format=torch.contiguous_format)
-    L.call("arco_conv_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, h, w, L.ptr(ws), L.ptr(dw), 0)
+    L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(dw), 0)
     return dw
 
 
@@ -121,18 +148,19 @@ def colsum(xr, ld, m, c):
 
 
 class ConvFn(torch.autograd.Function):
-    """y = conv_{1x1|3x3}(x) (+ bias) (+ x when residual).  Reference: nn.Conv2d in
-    unetWithArgs.py:72,139 / model_2D.py:25-33 / train_arco_2d.py:231-234."""
+    """y = conv(x) (+ bias) (+ x when residual) for 1x1 / 3x3 (2-D) and 1x1x1 / 3x3x3 (3-D) kernels.
+    Reference: nn.Conv2d in unetWithArgs.py:72,139 / model_2D.py:25-33 / train_arco_2d.py:231-234;
+    nn.Conv3d in vnetWithArgs.py:182, model_3D.py:25-35, train_arco_3d.py:206-209."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
         L.require_gpu(x, weight)
-        taps = int(weight.shape[2] * weight.shape[3])
-        xr, ld, nb, ci, h, w = _geom(x)
+        taps = _taps(weight)
+        xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
         wp = pack_weight(weight, taps, 0)
-        y, _ = conv_raw(xr, ld, ci, wp, co, nb, h, w, taps, bias=bias, residual=xr if residual else None,
-                        ld_res=ld if residual else 0)
+        y, _ = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, residual=xr if residual else None,
+                        ld_res=ld if residual else 0, d3=d3)
         ctx.save_for_backward(x, weight)
         ctx.residual, ctx.has_bias, ctx.taps = residual, bias is not None, taps
         return y
@@ -141,44 +169,65 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         taps = ctx.taps
-        dyr, ldy, nb, co, h, w = _geom(dy)
-        xr, ldx, _, ci, _, _ = _geom(x)
+        dyr, ldy, nv, d3, h, w, co, sp = _geom_nd(dy)
+        xr, ldx = rows_view(x)
+        ci = int(x.shape[1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wd = pack_weight(weight, taps, 1)
-            dx, _ = conv_raw(dyr, ldy, co, wd, ci, nb, h, w, taps, residual=dyr if ctx.residual else None,
-                             ld_res=ldy if ctx.residual else 0)
+            dx, _ = conv_raw(dyr, ldy, co, wd, ci, nv, h, w, taps, residual=dyr if ctx.residual else None,
+                             ld_res=ldy if ctx.residual else 0, d3=d3)
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nb, h, w, weight)
+            dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dyr, ldy, nb * h * w, co)
+            db = colsum(dyr, ldy, nv * d3 * h * w, co)
         return dx, dw, db, None
 
 
+def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out):
+    seed_dev = SEED_DEV if (p > 0 and torch.cuda.is_current_stream_capturing()) else None
+    L.call("arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
+           float(slope), int(drop_mode), float(p), seed, P, L.ptr(out), co, L.ptr(seed_dev))
+
+
+def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P):
+    """Returns (dz, dgamma, dbeta) for a = drop(lrelu(BN(z)))."""
+    dar, ldd = rows_view(da)
+    zr, ldz = rows_view(z)
+    co = int(z.shape[1])
+    m = zr.shape[0]
+    nblk = L.query("arco_chan_stats_blocks", m)
+    ws = torch.empty(2 * co * nblk + 2 * co, dtype=torch.float32, device=da.device)
+    dgamma = torch.empty_like(gamma) if gamma is not None else None
+    dbeta = torch.empty_like(beta) if beta is not None else None
+    dz = new_act_nd(int(z.shape[0]), co, tuple(int(v) for v in z.shape[2:]), da.device)
+    L.call("arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma),
+           L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dz), co)
+    return dz, dgamma, dbeta
+
+
 class ConvBnActFn(torch.autograd.Function):
-    """a = dropout(lrelu(BN_train(conv3x3(x) + bias))) as conv(+fused BN partial stats) ->
-    finalize -> one apply pass.  Reference: ConvBlock stages, unetWithArgs.py:36-44."""
+    """a = dropout(lrelu(BN_train(conv(x) + bias))) as conv (+fused BN partial stats in the epilogue) ->
+    finalize -> one apply pass.  2-D 3x3 (ConvBlock stages, unetWithArgs.py:36-44), 3-D 3x3x3 and the
+    GEMM-form k2s2 down conv (vnetWithArgs.py:16-25,67-91)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps):
         L.require_gpu(x, weight)
-        taps = int(weight.shape[2] * weight.shape[3])
-        xr, ld, nb, ci, h, w = _geom(x)
+        taps = _taps(weight)
+        xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
-        m = nb * h * w
+        m = nv * d3 * h * w
         wp = pack_weight(weight, taps, 0)
-        z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nb, h, w, taps, bias=bias, stats=True)
+        z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, stats=True, d3=d3)
         mean = torch.empty(co, dtype=torch.float32, device=x.device)
         istd = torch.empty(co, dtype=torch.float32, device=x.device)
         L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
                L.ptr(istd), L.ptr(running_mean), L.ptr(running_var))
         seed = _next_seed() if p > 0 else 0
-        a = new_act(nb, co, h, w, x.device)
+        a = new_act_nd(nv, co, sp, x.device)
         zr, ldz = rows_view(z)
-        # inside a graph capture (no-grad forwards only) the mask salt comes from device memory
-        seed_dev = SEED_DEV if (p > 0 and torch.cuda.is_current_stream_capturing()) else None
-        L.call("arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
-               float(slope), int(drop_mode), float(p), seed, h * w, L.ptr(a), co, L.ptr(seed_dev))
+        _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w, a)
         ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta)
         ctx.cfg = (taps, float(slope), float(p), int(drop_mode), seed, bias is not None)
         return a
@@ -187,27 +236,107 @@ class ConvBnActFn(torch.autograd.Function):
     def backward(ctx, da):
         x, weight, z, mean, istd, gamma, beta = ctx.saved_tensors
         taps, slope, p, drop_mode, seed, has_bias = ctx.cfg
-        dar, ldd, nb, co, h, w = _geom(da)
-        xr, ldx, _, ci, _, _ = _geom(x)
-        zr, ldz = rows_view(z)
-        m = nb * h * w
-        nblk = L.query("arco_chan_stats_blocks", m)
-        ws = torch.empty(2 * co * nblk + 2 * co, dtype=torch.float32, device=da.device)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(beta)
-        dz = new_act(nb, co, h, w, da.device)
-        L.call("arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma),
-               L.ptr(beta), slope, drop_mode, p, seed, h * w, L.ptr(ws), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dz), co)
+        xr, ldx, nv, d3, h, w, ci, sp = _geom_nd(x)
+        co = int(weight.shape[0])
+        dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w)
         dzr, ldzz = rows_view(dz)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wd = pack_weight(weight, taps, 1)
-            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nb, h, w, taps)
+            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3)
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nb, h, w, weight)
+            dw = conv_wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dzr, ldzz, m, co)
+            db = colsum(dzr, ldzz, nv * d3 * h * w, co)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class BnActFn(torch.autograd.Function):
+    """a = lrelu(BN_train(z)) for a tensor that did not come out of the conv kernel (the depth-to-space'd
+    transposed conv of UpsamplingDeconvBlock, vnetWithArgs.py:94-118).  gamma=None: plain dropout/activation."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps):
+        zr, ldz = rows_view(z)
+        co = int(z.shape[1])
+        m = zr.shape[0]
+        sp = tuple(int(v) for v in z.shape[2:])
+        P = 1
+        for v in sp:
+            P *= v
+        mean = istd = None
+        if gamma is not None:
+            nblk = L.query("arco_chan_stats_blocks", m)
+            ssum = torch.empty((co, nblk), dtype=torch.float32, device=z.device)
+            ssq = torch.empty((co, nblk), dtype=torch.float32, device=z.device)
+            L.call("arco_chan_stats", L.ptr(zr), ldz, m, co, L.ptr(ssum), L.ptr(ssq))
+            mean = torch.empty(co, dtype=torch.float32, device=z.device)
+            istd = torch.empty(co, dtype=torch.float32, device=z.device)
+            L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nblk, co, m, float(eps), float(momentum), L.ptr(mean),
+                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var))
+        seed = _next_seed() if p > 0 else 0
+        a = new_act_nd(int(z.shape[0]), co, sp, z.device)
+        _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a)
+        ctx.save_for_backward(z, mean, istd, gamma, beta)
+        ctx.cfg = (float(slope), float(p), int(drop_mode), seed, P)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        z, mean, istd, gamma, beta = ctx.saved_tensors
+        slope, p, drop_mode, seed, P = ctx.cfg
+        dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P)
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class S2D3Fn(torch.autograd.Function):
+    """[N,C,2X,2Y,2Z] -> [N,8C,X,Y,Z] (tap-major channels) and back (inverse=True): pure data movement that
+    turns the k=2,s=2 (transposed) Conv3d of the V-Net into a 1x1x1 GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, inverse):
+        ctx.inverse = inverse
+        return _s2d3(x, inverse)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _s2d3(dy, not ctx.inverse), None
+
+
+def _s2d3(x, inverse):
+    n, c = int(x.shape[0]), int(x.shape[1])
+    sp = [int(v) for v in x.shape[2:]]
+    xr, ld = rows_view(x)
+    if not inverse:
+        x2, y2, z2 = sp[0] // 2, sp[1] // 2, sp[2] // 2
+        out = new_act_nd(n, 8 * c, (x2, y2, z2), x.device)
+        L.call("arco_s2d3", L.ptr(xr), ld, n, x2, y2, z2, c, L.ptr(out), 8 * c, 0)
+    else:
+        cv = c // 8
+        out = new_act_nd(n, cv, (2 * sp[0], 2 * sp[1], 2 * sp[2]), x.device)
+        L.call("arco_s2d3", L.ptr(out), cv, n, sp[0], sp[1], sp[2], cv, L.ptr(xr), ld, 1)
+    return out
+
+
+class TrilinearFn(torch.autograd.Function):
+    """nn.Upsample(size, mode='trilinear', align_corners=True) (model_3D.py:46-58)."""
+
+    @staticmethod
+    def forward(ctx, x, do, ho, wo):
+        xr, ld = rows_view(x)
+        n, c, di, hi, wi = (int(v) for v in x.shape)
+        y = new_act_nd(n, c, (do, ho, wo), x.device)
+        L.call("arco_trilinear_fwd", L.ptr(xr), ld, n, di, hi, wi, c, do, ho, wo, L.ptr(y), c)
+        ctx.dims = (n, c, di, hi, wi, do, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, di, hi, wi, do, ho, wo = ctx.dims
+        dyr, ldy = rows_view(dy)
+        dx = new_act_nd(n, c, (di, hi, wi), dy.device)
+        L.call("arco_trilinear_bwd", L.ptr(dyr), ldy, n, di, hi, wi, c, do, ho, wo, L.ptr(dx), c)
+        return dx, None, None, None
 
 
 class MaxPool2Fn(torch.autograd.Function):
@@ -264,16 +393,39 @@ def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, slope=0
 def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, slope=0.01, eps=1e-5):
     """Inference-mode stage (BN uses running statistics); no autograd."""
     with torch.no_grad():
-        taps = int(weight.shape[2] * weight.shape[3])
-        xr, ld, nb, ci, h, w = _geom(x)
+        taps = _taps(weight)
+        xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
-        z, _ = conv_raw(xr, ld, ci, pack_weight(weight, taps, 0), co, nb, h, w, taps, bias=bias)
+        z, _ = conv_raw(xr, ld, ci, pack_weight(weight, taps, 0), co, nv, h, w, taps, bias=bias, d3=d3)
         istd = torch.rsqrt(running_var + eps)
-        a = new_act(nb, co, h, w, x.device)
+        a = new_act_nd(nv, co, sp, x.device)
         zr, ldz = rows_view(z)
-        L.call("arco_bn_act_fwd", L.ptr(zr), ldz, nb * h * w, co, L.ptr(running_mean), L.ptr(istd), L.ptr(gamma),
-               L.ptr(beta), float(slope), 0, 0.0, 0, h * w, L.ptr(a), co, None)
+        L.call("arco_bn_act_fwd", L.ptr(zr), ldz, nv * d3 * h * w, co, L.ptr(running_mean), L.ptr(istd), L.ptr(gamma),
+               L.ptr(beta), float(slope), 0, 0.0, 0, d3 * h * w, L.ptr(a), co, None)
         return a
+
+
+def bn_act(z, gamma, beta, running_mean, running_var, slope=0.0, p=0.0, drop_mode=0, momentum=0.1, eps=1e-5):
+    return BnActFn.apply(z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps)
+
+
+def dropout3d(x, p):
+    """nn.Dropout3d(p) in training mode: whole (sample, channel) volumes are dropped (vnetWithArgs.py:195,238)."""
+    return BnActFn.apply(x, None, None, None, None, 1.0, p, 2, 0.1, 1e-5)
+
+
+def space_to_depth3(x):
+    return S2D3Fn.apply(x, False)
+
+
+def depth_to_space3(x):
+    return S2D3Fn.apply(x, True)
+
+
+def trilinear(x, size):
+    if tuple(int(v) for v in x.shape[2:]) == tuple(int(v) for v in size):
+        return x                                   # align_corners resize to the same size is the identity
+    return TrilinearFn.apply(x, int(size[0]), int(size[1]), int(size[2]))
 
 
 def maxpool2(x):

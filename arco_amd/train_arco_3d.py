@@ -1,0 +1,181 @@
+"""Stage-2 ARCO trainer, 3-D (LA heart V-Net 112x112x80), on MI355X - drop-in for the reference's
+code/train_arco_3d.py.  Every flag of train_arco_3d.py:26-87 is accepted with the same name / type /
+default (they equal the 2-D trainer's except --patch_size [112,112,80], --func asmc, --k5 0.1).
+
+`ArcoStep3D.step` follows train_arco_3d.py:257-415 restricted to the hot-path loss term: V-Net student /
+teacher forwards, FeatureExtractor_3d, the two 1x1x1 q_representation convs (D=16), the 5-D contrastive
+loss (arco_amd.loss_helper), SGD-Nesterov, EMA.  batch_transform is the identity in the reference's 3-D
+pipeline (augment_3d.py:133-159), cutmix/TPS/other loss terms are outside the hot path.
+"""
+import logging
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _contrast as C_
+from . import dist as adist
+from . import glue, graphs, ops, optim
+from .model_3D import ISD_3d, FeatureExtractor_3d
+from .train_arco_2d import build_parser as _build_parser_2d
+
+FEA_DIM_3D = [128, 64, 32, 16, 16]
+REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
+
+
+def build_parser():
+    p = _build_parser_2d()
+    p.set_defaults(patch_size=[112, 112, 80], func='asmc', k5=0.1, root_path='../data/ACDC')
+    return p
+
+
+class ArcoStep3D:
+    """State + one training step of the 3-D hot path (train_arco_3d.py:144-151,195-232,257-415)."""
+
+    def __init__(self, args, device="cuda"):
+        self.args = args
+        self.dev = torch.device(device)
+        C = args.num_classes
+        self.memobank, self.queue_ptrlis, self.queue_size = [], [], []
+        for i in range(C):                                                # :144-151
+            self.memobank.append([torch.randn(1, REP_DIM_3D)])
+            self.queue_size.append(args.queue_size if args.queue_size > 0 else 30000)
+            self.queue_ptrlis.append(torch.zeros(1, dtype=torch.long))
+        if args.queue_size <= 0:
+            self.queue_size[0] = 50000
+        self.isd = ISD_3d(K=args.K, m=0.99, Ts=0.01, Tt=0.1, num_classes=C,
+                          latent_pooling_size=args.latent_pooling_size, latent_feature_size=args.latent_feature_size,
+                          output_pooling_size=args.output_pooling_size, train_encoder=True, train_decoder=True).to(self.dev)
+        self.model, self.ema_model = self.isd.model, self.isd.ema_model
+        self.q_representation = nn.Sequential(nn.Conv3d(REP_DIM_3D, REP_DIM_3D, kernel_size=1, bias=False),
+                                              nn.Conv3d(REP_DIM_3D, REP_DIM_3D, kernel_size=1, bias=False)).to(self.dev)
+        self.k_feature_extractor = FeatureExtractor_3d(fea_dim=FEA_DIM_3D, output_dim=REP_DIM_3D).to(self.dev)
+        self.q_feature_extractor = FeatureExtractor_3d(fea_dim=FEA_DIM_3D, output_dim=REP_DIM_3D).to(self.dev)
+        adist.broadcast_module_states([self.isd, self.q_representation, self.q_feature_extractor,
+                                       self.k_feature_extractor])
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        params_rep = [p for p in self.q_representation.parameters() if p.requires_grad]
+        params_fea = [p for p in self.q_feature_extractor.parameters() if p.requires_grad]
+        self.optimizer = optim.SGDNesterov(params + params_rep + params_fea, lr=args.base_lr, weight_decay=0.0001,
+                                           momentum=0.9, nesterov=True)
+        with torch.no_grad():
+            for t, s in zip(self.k_feature_extractor.parameters(), self.q_feature_extractor.parameters()):
+                t.data.copy_(s.data)
+                t.requires_grad = False
+        self.k_fe_ema = optim.EmaPair(self.q_feature_extractor, self.k_feature_extractor)
+        for m in (self.model, self.ema_model, self.q_representation, self.k_feature_extractor,
+                  self.q_feature_extractor):
+            m.train()
+        self.iter_num = 0
+        use_graphs = bool(getattr(args, "graphs", 1))
+        self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
+        self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
+        self.t_fwd_u = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
+
+    def q_rep(self, x):
+        x = ops.conv(x, self.q_representation[0].weight)
+        return ops.conv(x, self.q_representation[1].weight)
+
+    def step(self, l_data, l_label, u_data, epoch_num=0, max_epoch=1):
+        a = self.args
+        C = a.num_classes
+        with torch.no_grad():                                            # :260-262
+            pred_u0, _, _ = self.t_fwd_u0(u_data)
+            pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
+        u_aug, u_aug_label = u_data, pseudo_labels                       # :268-278 (identity transforms)
+        self.k_fe_ema.update(0.99)                                      # :279-281
+        pred_u, _, u_fm = self.model(u_aug)                              # :284
+        with torch.no_grad():
+            pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)                   # :286
+            pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                    # :287
+            alpha_t = 20 * (1 - epoch_num / max_epoch)
+            label_l = glue.label_onehot(l_label, C)
+            label_u = glue.label_onehot(u_aug_label, C)
+            prob_l_t = glue.softmax(pred_l_t)
+            prob_u_t = glue.softmax(pred_u_t)
+            low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
+        plan = C_.contrast_masks(label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all,
+                                 delta_n=a.strong_threshold_u2pl)
+        pred_l, _, l_fm = self.model(l_data)                             # :283
+        with torch.no_grad():
+            rep_all_teacher = self.k_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)])   # :292-293
+        rep_all = self.q_rep(self.q_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]))       # :289-296,301
+        C_.contrast_sample(plan, self.memobank, self.queue_size, a.func, a.num_queries, a.num_negatives)
+        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size)
+        if plan.valid_seg <= 1 or not plan.entries:
+            reco_loss = self.q_representation[1].weight.sum() * 0.0
+        else:
+            A_all = C_.GatherRowsFn.apply(rep_all, plan.anchor_pix)
+            reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
+        loss = a.k1 * reco_loss
+        self.optimizer.zero_grad()
+        loss.backward()
+        adist.allreduce_grads(self.optimizer)
+        self.optimizer.step()
+        self.isd._momentum_update_key_encoder()
+        lr_ = a.base_lr * (1.0 - self.iter_num / a.max_iterations) ** 0.9
+        for g in self.optimizer.param_groups:
+            g['lr'] = lr_
+        self.iter_num += 1
+        return loss, reco_loss
+
+
+def synthetic_volume_batch(b, patch, n_cls, seed, device):
+    """LA-shaped synthetic batch: volumes U[0,1), ellipsoid labels."""
+    rs = np.random.RandomState(seed)
+    img = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+    lab = np.zeros((b, *patch), dtype=np.int64)
+    g = np.mgrid[0:patch[0], 0:patch[1], 0:patch[2]]
+    for i in range(b):
+        for c in range(1, n_cls):
+            ctr = [rs.randint(p // 4, 3 * p // 4) for p in patch]
+            r = [max(2, rs.randint(p // 8, p // 3)) for p in patch]
+            lab[i][sum(((g[d] - ctr[d]) / r[d]) ** 2 for d in range(3)) < 1.0] = c
+    return img.to(device), torch.from_numpy(lab).to(device)
+
+
+def train(args, snapshot_path):
+    if not args.synthetic:
+        raise NotImplementedError("dataset readers (dataloaders/la_heart.py, h5py) are outside the hot path "
+                                  "(SURVEY §8f row 4); run with --synthetic 1")
+    rank, world = adist.init()
+    dev = torch.device("cuda", adist.local_rank())
+    torch.cuda.set_device(dev)
+    stepper = ArcoStep3D(args, dev)
+    b = args.batch_size
+    iters_per_epoch = 100
+    max_epoch = args.max_iterations // iters_per_epoch + 1
+    while stepper.iter_num < args.max_iterations:
+        it = stepper.iter_num
+        l_img, l_lab = synthetic_volume_batch(b, args.patch_size, args.num_classes, 2 * it * world + rank, dev)
+        u_img, _ = synthetic_volume_batch(b, args.patch_size, args.num_classes, (2 * it + 1) * world + rank, dev)
+        loss, reco = stepper.step(l_img, l_lab, u_img, it // iters_per_epoch, max_epoch)
+        if rank == 0:
+            logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))
+            if stepper.iter_num % 1000 == 0:                           # :441-449
+                path = os.path.join(snapshot_path, 'iter_' + str(stepper.iter_num) + '.pth')
+                torch.save(stepper.isd.model.state_dict(), path)
+    return "Training Finished!"
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    torch.set_num_threads(min(4, torch.get_num_threads()))
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed(args.seed)
+    snapshot_path = "../model/{}_{}_labeled{}/{}".format(args.exp, args.labeled_num, 'final', args.model)
+    os.makedirs(snapshot_path, exist_ok=True)
+    logging.basicConfig(filename=snapshot_path + "/log.txt", level=logging.INFO,
+                        format='[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S')
+    logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
+    logging.info(str(args))
+    return train(args, snapshot_path)
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,12 @@ int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout);
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                   int NB, int H, int W, void* stream);
+/* 3-D: NV volumes of D3 planes of H x W; taps = 27 is nn.Conv3d(3, padding=1) (vnetWithArgs.py:16)      */
+int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                    const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                    int NV, int D3, int H, int W, void* stream);
+int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
+                      int D3, int H, int W, float* ws, float* dW, int accumulate, void* stream);
 long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M);
 /* dW[co][ci][tap] (+)= sum_pix dZ[pix][co] * in[pix+tap][ci]   (torch weight layout)                      */
 int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NB,
@@ -116,6 +122,13 @@ int arco_lerp4_cat_rows(const float* V, long ldv, int Clo, const float* lylx, co
                         const int64_t* pix, long n, float* X, long ldx, void* stream);
 int arco_lerp4_cat_rows_bwd(const float* dX, long ldx, int Clo, const float* lylx, const int64_t* pix, long n, float* dV,
                             long ldv, float* dhi, long ldhi, int Chi, void* stream);
+/* V-Net k2s2 (transposed) convs as GEMMs over packed 2x2x2 blocks (vnetWithArgs.py:67-118); trilinear
+ * align_corners resize of FeatureExtractor_3d (model_3D.py:46-58)                                          */
+int arco_s2d3(float* V, long ldv, int NV, int X2, int Y2, int Z2, int C, float* P, long ldp, int dir, void* stream);
+int arco_trilinear_fwd(const float* X, long ldx, int NV, int Di, int Hi, int Wi, int C, int Do, int Ho, int Wo, float* Y,
+                       long ldy, void* stream);
+int arco_trilinear_bwd(const float* dY, long ldy, int NV, int Di, int Hi, int Wi, int C, int Do, int Ho, int Wo, float* dX,
+                       long ldx, void* stream);
 int arco_copy_rows(const float* X, long ldx, long M, int C, float* Y, long ldy, int accumulate, void* stream);
 int arco_nchw_to_nhwc(const float* X, int NB, int C, long P, float* Y, long ldy, void* stream);
 int arco_nhwc_to_nchw(const float* X, long ldx, int NB, int C, long P, float* Y, void* stream);
