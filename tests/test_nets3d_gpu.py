@@ -1,0 +1,173 @@
+"""3-D path on the HIP kernels: conv3d family vs PyTorch-CPU fp32, V-Net / FeatureExtractor_3d vs golden
+vectors captured from the reference, and one 3-D training step (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import fixture_inputs as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(rs, *shape, scale=1.0):
+    return torch.from_numpy((scale * rs.standard_normal(shape)).astype(np.float32))
+
+
+def cl3(x):
+    return x.cuda().contiguous(memory_format=torch.channels_last_3d)
+
+
+def close(a, b, rtol=3e-4, atol=3e-5):
+    bb = b.detach().cpu().numpy() if torch.is_tensor(b) else b
+    np.testing.assert_allclose(a.detach().cpu().numpy(), bb, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("nb,ci,co,d,h,w,k", [(2, 16, 16, 6, 8, 16, 3), (1, 1, 16, 8, 8, 16, 3), (2, 32, 64, 4, 7, 10, 3),
+                                                (1, 128, 128, 3, 7, 5, 3), (2, 16, 2, 4, 8, 16, 1), (1, 240, 240, 4, 8, 16, 1)])
+def test_conv3d_fwd_bwd(nb, ci, co, d, h, w, k):
+    from arco_amd import ops
+    rs = np.random.RandomState(ci + co + d)
+    x = rnd(rs, nb, ci, d, h, w)
+    wt = rnd(rs, co, ci, k, k, k, scale=1 / np.sqrt(ci * k ** 3))
+    b = rnd(rs, co, scale=0.1)
+    gy = rnd(rs, nb, co, d, h, w)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br, padding=k // 2)
+    yr.backward(gy)
+    xg, wg, bg = cl3(x).requires_grad_(True), wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yg = ops.conv(xg, wg, bg)
+    yg.backward(cl3(gy))
+    close(yg, yr)
+    close(xg.grad, xr.grad)
+    close(wg.grad, wr.grad, rtol=5e-4, atol=5e-4 * float(wr.grad.abs().max()))
+    close(bg.grad, br.grad, rtol=5e-4, atol=5e-4 * float(br.grad.abs().max()))
+
+
+def test_down_up_blocks_vs_torch():
+    from arco_amd.networks.vnetWithArgs import DownsamplingConvBlock, UpsamplingDeconvBlock
+    rs = np.random.RandomState(4)
+    for cls, cin, cout, shape, ref in ((DownsamplingConvBlock, 16, 32, (8, 8, 16), "down"),
+                                       (UpsamplingDeconvBlock, 32, 16, (4, 4, 8), "up")):
+        blk = cls(cin, cout, normalization='batchnorm')
+        x = rnd(rs, 2, cin, *shape)
+        blk_ref = torch.nn.Sequential(
+            (torch.nn.Conv3d if ref == "down" else torch.nn.ConvTranspose3d)(cin, cout, 2, padding=0, stride=2),
+            torch.nn.BatchNorm3d(cout), torch.nn.ReLU())
+        blk_ref.load_state_dict({k.replace("conv.", ""): v for k, v in blk.state_dict().items()})
+        blk_ref.train()
+        blk = blk.cuda().train()
+        xr = x.clone().requires_grad_(True)
+        yr = blk_ref(xr)
+        gy = rnd(rs, *yr.shape)
+        yr.backward(gy)
+        xg = cl3(x).requires_grad_(True)
+        yg = blk(xg)
+        yg.backward(cl3(gy))
+        close(yg, yr, 5e-4, 5e-5)
+        close(xg.grad, xr.grad, 2e-3, 2e-4)
+        pr = dict(blk_ref.named_parameters())
+        for n, p in blk.named_parameters():
+            r = pr[n.replace("conv.", "")].grad
+            if n.endswith("0.bias"):
+                continue        # zero-gradient bias under train-mode BN (rounding noise)
+            close(p.grad, r, 3e-3, 3e-4 * max(1e-3, float(r.abs().max())))
+        close(blk.conv[1].running_var, blk_ref[1].running_var, 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("c,si,so", [(16, (3, 4, 5), (6, 8, 10)), (32, (7, 7, 5), (14, 14, 10)), (16, (4, 4, 4), (7, 9, 5))])
+def test_trilinear(c, si, so):
+    from arco_amd import ops
+    rs = np.random.RandomState(2)
+    x = rnd(rs, 2, c, *si)
+    gy = rnd(rs, 2, c, *so)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=so, mode='trilinear', align_corners=True)
+    yr.backward(gy)
+    xg = cl3(x).requires_grad_(True)
+    yg = ops.trilinear(xg, so)
+    yg.backward(cl3(gy))
+    close(yg, yr, 1e-4, 5e-6)
+    close(xg.grad, xr.grad, 1e-4, 3e-5)
+
+
+def test_dropout3d_drops_whole_channels():
+    from arco_amd import ops
+    x = cl3(torch.ones(4, 32, 4, 4, 8)).requires_grad_(True)
+    y = ops.dropout3d(x, 0.5)
+    per = y.detach().flatten(2)
+    assert bool(((per == 0).all(2) | (per == 2.0).all(2)).all())
+    frac = float((per[:, :, 0] == 0).float().mean())
+    assert 0.25 < frac < 0.75
+    y.sum().backward()
+    assert torch.equal((x.grad != 0), (y.detach() != 0))
+
+
+def probe_like(t, seed):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.standard_normal(tuple(t.shape)).astype(np.float32)).cuda()
+
+
+def test_vnet_and_fe3d_vs_reference_golden(golden):
+    from arco_amd.networks.vnetWithArgs import VNet
+    from arco_amd.model_3D import FeatureExtractor_3d
+    g = golden["g3_nets"]
+    net = VNet(n_channels=1, n_classes=2, normalization='batchnorm', has_dropout=True).cuda()
+    net.load_state_dict(fx.vnet_state(51), strict=True)
+    net.train()
+    x = fx.image_batch(8, 2, 1, (16, 16, 16)).cuda().requires_grad_(True)
+    out, f0, fmap = net(x, turnoff_drop=True)
+    close(out, g["vnet_out"], 2e-3, 2e-4)
+    for i, f in enumerate(fmap):
+        close(f, g[f"vnet_fmap{i}"], 2e-3, 2e-4)
+    loss = (out * probe_like(out, 4)).sum()
+    for i, f in enumerate(fmap):
+        loss = loss + (f * probe_like(f, 20 + i)).sum()
+    loss.backward()
+    close(x.grad, g["vnet_dx"], 1e-2, 2e-3)
+    params = dict(net.named_parameters())
+    names = [str(s) for s in g["vnet_grad_names"]]
+    for n, ref_abs in zip(names, g["vnet_grad_abs"]):
+        got = params[n].grad.double().abs().sum().item()
+        if n.endswith(".bias") and ".conv." in n and int(n.split(".")[-2]) % 3 == 0:
+            assert got < 1.0 and ref_abs < 1.0, n           # conv bias under train-mode BN: rounding noise only
+            continue
+        assert abs(got - ref_abs) <= 1e-2 * max(ref_abs, 1e-2), (n, got, ref_abs)
+    st = net.state_dict()
+    for n in g.files:
+        if n.startswith("vnet_buf::"):
+            close(st[n.split("::")[1]].float(), g[n].astype(np.float32), 1e-3, 1e-5)
+    fe = FeatureExtractor_3d(fea_dim=[128, 64, 32, 16, 16], output_dim=16).cuda()
+    fe.load_state_dict(fx.fe_state(61, (128, 64, 32, 16, 16), 16, nd=3), strict=True)
+    fl = [f.detach().clone().requires_grad_(True) for f in fmap]
+    y = fe(fl)
+    close(y, g["fe3d_y"], 2e-3, 2e-4)
+    (y * probe_like(y, 5)).sum().backward()
+    for i, f in enumerate(fl):
+        np.testing.assert_allclose(f.grad.double().abs().sum().item(), g[f"fe3d_dx{i}_sum"][1], rtol=5e-3)
+    for n, p in fe.named_parameters():
+        np.testing.assert_allclose(p.grad.double().abs().sum().item(), g["fe3d_g_sum::" + n][1], rtol=5e-3)
+
+
+def test_train_step_3d_runs_and_updates():
+    import random
+    from arco_amd import train_arco_3d as T3
+    random.seed(5)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    args = T3.build_parser().parse_args(["--batch_size", "1", "--queue_size", "256", "--synthetic", "1",
+                                         "--num_classes", "2", "--num_queries", "64", "--num_negatives", "32",
+                                         "--k1", "1.0"])
+    args.patch_size = [32, 32, 32]
+    st = T3.ArcoStep3D(args, "cuda:0")
+    before = torch.cat([p.detach().reshape(-1) for p in st.optimizer.params]).clone()
+    losses = []
+    for i in range(4):
+        l_img, l_lab = T3.synthetic_volume_batch(1, args.patch_size, 2, 10 + i, "cuda:0")
+        u_img, _ = T3.synthetic_volume_batch(1, args.patch_size, 2, 20 + i, "cuda:0")
+        loss, reco = st.step(l_img, l_lab, u_img)
+        losses.append(float(reco.detach()))
+    assert all(np.isfinite(losses))
+    after = torch.cat([p.detach().reshape(-1) for p in st.optimizer.params])
+    assert float((after - before).abs().max()) > 0
+    assert all(b[0].is_cuda and b[0].shape[1] == 16 for b in st.memobank)
