@@ -108,10 +108,12 @@ def pack_weight(weight, taps, mode):
     return wp
 
 
-def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1):
+def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1, sp=None):
     """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out channels-last, stat slabs or None).
     2-D: nb images of h x w -> out [nb,n,h,w].  3-D (d3 > 1): nb volumes of d3 planes -> out [nb,n,d3,h,w]."""
-    if d3 > 1:
+    if sp is not None:
+        out = new_act_nd(nb, n, sp, xr.device)         # keeps the caller's rank (a 3-D volume may have depth 1)
+    elif d3 > 1:
         out = new_act_nd(nb, n, (d3, h, w), xr.device)
     else:
         out = new_act(nb, n, h, w, xr.device)
@@ -160,7 +162,7 @@ class ConvFn(torch.autograd.Function):
         co = int(weight.shape[0])
         wp = pack_weight(weight, taps, 0)
         y, _ = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, residual=xr if residual else None,
-                        ld_res=ld if residual else 0, d3=d3)
+                        ld_res=ld if residual else 0, d3=d3, sp=sp)
         ctx.save_for_backward(x, weight)
         ctx.residual, ctx.has_bias, ctx.taps = residual, bias is not None, taps
         return y
@@ -176,7 +178,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wd = pack_weight(weight, taps, 1)
             dx, _ = conv_raw(dyr, ldy, co, wd, ci, nv, h, w, taps, residual=dyr if ctx.residual else None,
-                             ld_res=ldy if ctx.residual else 0, d3=d3)
+                             ld_res=ldy if ctx.residual else 0, d3=d3, sp=sp)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -219,7 +221,7 @@ class ConvBnActFn(torch.autograd.Function):
         co = int(weight.shape[0])
         m = nv * d3 * h * w
         wp = pack_weight(weight, taps, 0)
-        z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, stats=True, d3=d3)
+        z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, stats=True, d3=d3, sp=sp)
         mean = torch.empty(co, dtype=torch.float32, device=x.device)
         istd = torch.empty(co, dtype=torch.float32, device=x.device)
         L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
@@ -243,7 +245,7 @@ class ConvBnActFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wd = pack_weight(weight, taps, 1)
-            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3)
+            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3, sp=sp)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if has_bias and ctx.needs_input_grad[2]:
@@ -396,7 +398,7 @@ def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, sl
         taps = _taps(weight)
         xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
-        z, _ = conv_raw(xr, ld, ci, pack_weight(weight, taps, 0), co, nv, h, w, taps, bias=bias, d3=d3)
+        z, _ = conv_raw(xr, ld, ci, pack_weight(weight, taps, 0), co, nv, h, w, taps, bias=bias, d3=d3, sp=sp)
         istd = torch.rsqrt(running_var + eps)
         a = new_act_nd(nv, co, sp, x.device)
         zr, ldz = rows_view(z)
