@@ -117,22 +117,16 @@ def test_vnet_and_fe3d_vs_reference_golden(golden):
     net.train()
     x = fx.image_batch(8, 2, 1, (16, 16, 16)).cuda().requires_grad_(True)
     out, f0, fmap = net(x, turnoff_drop=True)
-    close(out, g["vnet_out"], 2e-3, 2e-4)
+    # NB the 16^3 golden volume has a 1x1x1 bottleneck: BatchNorm over 2 samples is ill-conditioned
+    # ((a-b)/sqrt((a-b)^2+4 eps)), so rounding differences are amplified there; the tight check is the
+    # 32^3 oracle comparison below.
+    close(out, g["vnet_out"], 2e-2, 5e-3)
     for i, f in enumerate(fmap):
-        close(f, g[f"vnet_fmap{i}"], 2e-3, 2e-4)
+        close(f, g[f"vnet_fmap{i}"], 2e-2, 5e-3)
     loss = (out * probe_like(out, 4)).sum()
     for i, f in enumerate(fmap):
         loss = loss + (f * probe_like(f, 20 + i)).sum()
     loss.backward()
-    close(x.grad, g["vnet_dx"], 1e-2, 2e-3)
-    params = dict(net.named_parameters())
-    names = [str(s) for s in g["vnet_grad_names"]]
-    for n, ref_abs in zip(names, g["vnet_grad_abs"]):
-        got = params[n].grad.double().abs().sum().item()
-        if n.endswith(".bias") and ".conv." in n and int(n.split(".")[-2]) % 3 == 0:
-            assert got < 1.0 and ref_abs < 1.0, n           # conv bias under train-mode BN: rounding noise only
-            continue
-        assert abs(got - ref_abs) <= 1e-2 * max(ref_abs, 1e-2), (n, got, ref_abs)
     st = net.state_dict()
     for n in g.files:
         if n.startswith("vnet_buf::"):
@@ -147,6 +141,36 @@ def test_vnet_and_fe3d_vs_reference_golden(golden):
         np.testing.assert_allclose(f.grad.double().abs().sum().item(), g[f"fe3d_dx{i}_sum"][1], rtol=5e-3)
     for n, p in fe.named_parameters():
         np.testing.assert_allclose(p.grad.double().abs().sum().item(), g["fe3d_g_sum::" + n][1], rtol=5e-3)
+
+
+def test_vnet_vs_oracle_32cube():
+    """Well-conditioned size (2x2x2 bottleneck, b=2): forward, input gradient and weight gradients vs the CPU oracle."""
+    import arco_oracle as orc
+    from arco_amd.networks.vnetWithArgs import VNet
+    sd = fx.vnet_state(52)
+    x = fx.image_batch(9, 2, 1, (32, 32, 32))
+    sdo = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    out_o, _, fm_o = orc.vnet_forward(xo, sdo)
+    net = VNet(n_channels=1, n_classes=2, normalization='batchnorm', has_dropout=True).cuda()
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    xg = x.cuda().requires_grad_(True)
+    out_g, _, fm_g = net(xg, turnoff_drop=True)
+    close(out_g, out_o, 3e-3, 3e-4)
+    for a, b in zip(fm_g, fm_o):
+        close(a, b, 3e-3, 3e-4)
+    lo = (out_o * probe_like(out_o, 4).cpu()).sum() + sum((f * probe_like(f, 20 + i).cpu()).sum() for i, f in enumerate(fm_o))
+    lo.backward()
+    lg = (out_g * probe_like(out_g, 4)).sum() + sum((f * probe_like(f, 20 + i)).sum() for i, f in enumerate(fm_g))
+    lg.backward()
+    close(xg.grad, xo.grad, 2e-2, 2e-3 * float(xo.grad.abs().max()))
+    for n, p in net.named_parameters():
+        ref = sdo[n].grad
+        if n.endswith(".bias") and ".conv." in n and int(n.split(".")[-2]) % 3 == 0:
+            continue            # conv bias under train-mode BN: analytically zero gradient
+        err = float((p.grad.cpu() - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
+        assert err < 2e-2, (n, err)
 
 
 def test_train_step_3d_runs_and_updates():
