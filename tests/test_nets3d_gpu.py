@@ -133,7 +133,8 @@ def test_vnet_and_fe3d_vs_reference_golden(golden):
             close(st[n.split("::")[1]].float(), g[n].astype(np.float32), 1e-3, 1e-5)
     fe = FeatureExtractor_3d(fea_dim=[128, 64, 32, 16, 16], output_dim=16).cuda()
     fe.load_state_dict(fx.fe_state(61, (128, 64, 32, 16, 16), 16, nd=3), strict=True)
-    fl = [f.detach().clone().requires_grad_(True) for f in fmap]
+    # feed the reference's own feature maps so FeatureExtractor_3d parity is isolated from the V-Net's conditioning
+    fl = [torch.from_numpy(g[f"vnet_fmap{i}"]).cuda().requires_grad_(True) for i in range(5)]
     y = fe(fl)
     close(y, g["fe3d_y"], 2e-3, 2e-4)
     (y * probe_like(y, 5)).sum().backward()
