@@ -25,6 +25,10 @@ def is_dist():
 
 
 def local_rank():
+    """Device index of this rank.  ARCO_FORCE_DEVICE pins every rank to one device (single-GPU
+    rehearsal of the multi-rank path, together with ARCO_DIST_BACKEND=gloo)."""
+    if "ARCO_FORCE_DEVICE" in os.environ:
+        return int(os.environ["ARCO_FORCE_DEVICE"])
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
@@ -33,7 +37,7 @@ def init(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not td.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ARCO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank())
         td.init_process_group(backend=backend)
@@ -85,7 +89,7 @@ def gather_keys(keys):
 def gather_counts(counts):
     """Per-class key counts summed over ranks (host ints in, host ints out): bank lengths and queue
     pointers are then identical on every rank."""
-    dev = torch.device("cuda", local_rank()) if td.get_backend() == "nccl" else torch.device("cpu")
+    dev = torch.device("cuda", local_rank()) if td.get_backend() == "nccl" else torch.device("cpu")   # tiny, host-side
     t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=dev)
     td.all_reduce(t, op=td.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]
