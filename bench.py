@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
+# HBM bytes per launch from the PMC passes in profiles/r01_pmc_gemm_traffic.md (FETCH_SIZE x2 + WRITE_SIZE), by (M, N, K)
+PMC_TRAFFIC_BYTES = {(1048576, 496, 496): 5.595e9, (262144, 480, 480): 1.240e9}
 
 
 def cpu_baseline_child():
@@ -127,7 +129,9 @@ def main():
             flop = 2.0 * m * n * k * taps
             ach = flop / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get((m, n, k)),
+                    "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_gemm_traffic.md)",
+                    "algorithmic_bytes": 4.0 * (m * k + n * k + m * n),
                     "kernel": f"igemm_kernel 1x1 conv M={m} N={n} K={k} (fp32 MFMA 16x16x4)",
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
                     "share_of_step": round(sum(ms) / (dt * 1e3), 4)}
