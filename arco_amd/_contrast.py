@@ -222,10 +222,10 @@ def contrast_sample(pl, memobank, queue_size, func='asmc', num_queries=256, num_
 @torch.no_grad()
 def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace=None, lazy_teacher=None):
     """Row lists, prototypes and key enqueue.  Teacher rows come either from the dense `rep_teacher`
-    [B,D,*spatial] (public API) or - 2-D trainers - lazily from `lazy_teacher = (x3p, f4, w_fea4)`:
-    the FeatureExtractor is linear, so prototype_c = W_fea4 . mean_c(cat(up(x3p), f4)) with the class
-    mask pushed through the bilinear adjoint to the low-res level, and only the <= queue_size key rows per
-    class are evaluated.  Same values up to fp32 re-association of the mean."""
+    [B,D,*spatial] (public API) or lazily from a `lazy_teacher` object (arco_amd.head): the FeatureExtractor
+    is linear, so prototype_c = W_fea4 . mean_c(fea4 input) with the class mask pushed through the
+    bi/trilinear adjoint to the low-res level, and only the <= queue_size key rows per class are evaluated.
+    Same values up to fp32 re-association of the mean."""
     C, n_pix, dev = pl.C, pl.n_pix, pl.dev
     pl.lists = torch.empty((2 * C, n_pix), dtype=torch.int32, device=dev)
     L.call("arco_compact_rows", L.ptr(pl.codes), n_pix, C, L.ptr(pl.offsets), L.ptr(pl.lists))
@@ -248,40 +248,12 @@ def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace
                    L.ptr(keys), D)
             key_rows.append(keys)
     else:
-        x3p, f4, w4 = lazy_teacher
-        lo, ldlo = rows_view(x3p)
-        hi, ldhi = rows_view(f4)
-        nb, clo, hi_h, hi_w = (int(v) for v in x3p.shape)
-        chi, ho, wo = int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3])
-        D, K = int(w4.shape[0]), clo + chi
-        Cp = _ceil(C, 4)
-        wm = torch.empty((n_pix, Cp), dtype=torch.float32, device=dev)
-        L.call("arco_lv_weights", L.ptr(pl.codes), n_pix, C, Cp, L.ptr(wm))
-        n_lo = nb * hi_h * hi_w
-        wlo = torch.empty((n_lo, Cp), dtype=torch.float32, device=dev)
-        L.call("arco_bilinear_bwd", L.ptr(wm), Cp, nb, hi_h, hi_w, Cp, ho, wo, L.ptr(wlo), Cp, 0)
-        S = torch.zeros((_ceil(C, 16), K), dtype=torch.float32, device=dev)
-        ws = torch.empty(max(L.query("arco_proto_ws_floats", n_lo, C, clo), L.query("arco_proto_ws_floats", n_pix, C, chi)),
-                         dtype=torch.float32, device=dev)
-        L.call("arco_weighted_row_sum", L.ptr(lo), ldlo, L.ptr(wlo), Cp, n_lo, C, clo, L.ptr(pl.totals), L.ptr(ws),
-               L.ptr(S), K)
-        L.call("arco_weighted_row_sum", L.ptr(hi), ldhi, L.ptr(wm), Cp, n_pix, C, chi, L.ptr(pl.totals), L.ptr(ws),
-               L.ptr(S[:, clo:]), K)
-        from . import ops
-        wp = ops.pack_weight(w4, 1, 0)
-        y, _ = ops.conv_raw(S, K, K, wp, D, 1, 1, int(S.shape[0]), 1)
-        pl.proto = y.permute(0, 2, 3, 1).reshape(int(S.shape[0]), D)[:C].contiguous()
-        # key rows of every class in one gather + one GEMM
+        # lazy teacher (arco_amd.head.LazyTeacher2D / LazyTeacher3D): class means through the linear head,
+        # and only the key rows that can survive the truncation
+        pl.proto = lazy_teacher.prototypes(pl)
+        D = int(pl.proto.shape[1])
         pix = torch.cat([pl.lists[C + c][int(pl.n_neg[c]) - takes[c]:int(pl.n_neg[c])] for c in range(C)]).to(torch.int64)
-        nk = int(pix.shape[0])
-        if nk > 0:
-            X = torch.empty((nk, K), dtype=torch.float32, device=dev)
-            L.call("arco_gather_upcat_rows", L.ptr(lo), ldlo, clo, hi_h, hi_w, L.ptr(hi), ldhi, chi, ho, wo, L.ptr(pix), nk,
-                   L.ptr(X), K)
-            y, _ = ops.conv_raw(X, K, K, wp, D, 1, 1, nk, 1)
-            allk = y.permute(0, 2, 3, 1).reshape(nk, D)
-        else:
-            allk = torch.empty((0, D), dtype=torch.float32, device=dev)
+        allk = lazy_teacher.rows(pix) if int(pix.shape[0]) > 0 else torch.empty((0, D), dtype=torch.float32, device=dev)
         key_rows, off = [], 0
         for c in range(C):
             key_rows.append(allk[off:off + takes[c]])

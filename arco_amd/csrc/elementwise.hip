@@ -503,6 +503,77 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restr
   }
 }
 
+// ---- 3-D anchor-row gather of cat(trilinear_up(lo), hi) and its adjoint (row-sparse head of FeatureExtractor_3d,
+// model_3D.py:52-55).  Same fp32 index math / lerp order as trilinear_fwd_kernel -> rows bit-identical to the dense path.
+__global__ __launch_bounds__(256) void gather_upcat_rows3d_kernel(const float* __restrict__ lo, long ldlo, int Clo, int Di, int Hi, int Wi,
+                                                                 const float* __restrict__ hi, long ldhi, int Chi, int Do, int Ho, int Wo,
+                                                                 const int64_t* __restrict__ pix, long n, float* __restrict__ X, long ldx) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const long p = pix[j];
+  const long vol = (long)Do * Ho * Wo;
+  const long img = p / vol; long rem = p - img * vol;
+  const int zo = (int)(rem / ((long)Ho * Wo)); rem -= (long)zo * Ho * Wo;
+  const int yo = (int)(rem / Wo), xo = (int)(rem - (long)yo * Wo);
+  const float sd = Do > 1 ? (float)(Di - 1) / (float)(Do - 1) : 0.f, sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f,
+              sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+  ac_src(zo, sd, Di, z0, z1, lz); ac_src(yo, sh, Hi, y0, y1, ly); ac_src(xo, sw, Wi, x0, x1, lx);
+  const float hz = 1.f - lz, hy = 1.f - ly, hx = 1.f - lx;
+  const float* b = lo + (img * Di) * (long)Hi * Wi * ldlo;
+#define GP(zz, yy, xx) (b + (((long)(zz) * Hi + (yy)) * Wi + (xx)) * ldlo)
+  const float *p000 = GP(z0, y0, x0), *p001 = GP(z0, y0, x1), *p010 = GP(z0, y1, x0), *p011 = GP(z0, y1, x1);
+  const float *p100 = GP(z1, y0, x0), *p101 = GP(z1, y0, x1), *p110 = GP(z1, y1, x0), *p111 = GP(z1, y1, x1);
+#undef GP
+  float* o = X + j * ldx;
+  for (int c = lane * 4; c < Clo; c += 256) {
+    const f32x4 v000 = *reinterpret_cast<const f32x4*>(p000 + c), v001 = *reinterpret_cast<const f32x4*>(p001 + c);
+    const f32x4 v010 = *reinterpret_cast<const f32x4*>(p010 + c), v011 = *reinterpret_cast<const f32x4*>(p011 + c);
+    const f32x4 v100 = *reinterpret_cast<const f32x4*>(p100 + c), v101 = *reinterpret_cast<const f32x4*>(p101 + c);
+    const f32x4 v110 = *reinterpret_cast<const f32x4*>(p110 + c), v111 = *reinterpret_cast<const f32x4*>(p111 + c);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      r[e] = hz * (hy * (hx * v000[e] + lx * v001[e]) + ly * (hx * v010[e] + lx * v011[e])) +
+             lz * (hy * (hx * v100[e] + lx * v101[e]) + ly * (hx * v110[e] + lx * v111[e]));
+    *reinterpret_cast<f32x4*>(o + c) = r;
+  }
+  const float* h = hi + p * ldhi;
+  for (int c = lane * 4; c < Chi; c += 256) *reinterpret_cast<f32x4*>(o + Clo + c) = *reinterpret_cast<const f32x4*>(h + c);
+}
+__global__ __launch_bounds__(256) void scatter_upcat_rows3d_kernel(const float* __restrict__ dX, long ldx, const int64_t* __restrict__ pix, long n,
+                                                                  float* __restrict__ dlo, long ldlo, int Clo, int Di, int Hi, int Wi,
+                                                                  float* __restrict__ dhi, long ldhi, int Chi, int Do, int Ho, int Wo) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const long p = pix[j];
+  const long vol = (long)Do * Ho * Wo;
+  const long img = p / vol; long rem = p - img * vol;
+  const int zo = (int)(rem / ((long)Ho * Wo)); rem -= (long)zo * Ho * Wo;
+  const int yo = (int)(rem / Wo), xo = (int)(rem - (long)yo * Wo);
+  const float sd = Do > 1 ? (float)(Di - 1) / (float)(Do - 1) : 0.f, sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f,
+              sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  int zz[2], yy[2], xx[2]; float lz, ly, lx;
+  ac_src(zo, sd, Di, zz[0], zz[1], lz); ac_src(yo, sh, Hi, yy[0], yy[1], ly); ac_src(xo, sw, Wi, xx[0], xx[1], lx);
+  const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+  float* b = dlo + (img * Di) * (long)Hi * Wi * ldlo;
+  const float* g = dX + j * ldx;
+  for (int c = lane; c < Clo; c += 64) {
+    const float v = g[c];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          atomicAdd(b + (((long)zz[a] * Hi + yy[bb]) * Wi + xx[d]) * ldlo + c, wz[a] * wy[bb] * wx[d] * v);
+  }
+  float* h = dhi + p * ldhi;
+  for (int c = lane; c < Chi; c += 64) atomicAdd(h + c, g[Clo + c]);
+}
+
 // ---- strided channel-slice copy / add:  Y[r][0..C) (+)= X[r][0..C)
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ X, long ldx, long M, int C,
                                                        float* __restrict__ Y, long ldy, int accumulate) {
@@ -715,6 +786,22 @@ int arco_trilinear_bwd(const float* dY, long ldy, int NV, int Di, int Hi, int Wi
   ARCO_CHECK_ARG((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0);
   hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(ew_grid((long)NV * Di * Hi * Wi * (C / 4))), dim3(256), 0, as_stream(stream),
                      dY, ldy, NV, Di, Hi, Wi, C, Do, Ho, Wo, dX, ldx);
+  return arco_launch_status();
+}
+
+int arco_gather_upcat_rows3d(const float* lo, long ldlo, int Clo, int Di, int Hi, int Wi, const float* hi, long ldhi, int Chi,
+                             int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream) {
+  ARCO_CHECK_ARG((Clo & 3) == 0 && (Chi & 3) == 0 && (ldlo & 3) == 0 && (ldhi & 3) == 0 && (ldx & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(gather_upcat_rows3d_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), lo, ldlo, Clo, Di, Hi, Wi,
+                     hi, ldhi, Chi, Do, Ho, Wo, pix, n, X, ldx);
+  return arco_launch_status();
+}
+int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo, int Di,
+                              int Hi, int Wi, float* dhi, long ldhi, int Chi, int Do, int Ho, int Wo, void* stream) {
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(scatter_upcat_rows3d_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), dX, ldx, pix, n, dlo,
+                     ldlo, Clo, Di, Hi, Wi, dhi, ldhi, Chi, Do, Ho, Wo);
   return arco_launch_status();
 }
 

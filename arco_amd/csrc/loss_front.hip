@@ -260,8 +260,14 @@ __global__ void row_sum_finalize_kernel(const float* __restrict__ partial, int n
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nc * D) return;
   const int cc = i / D, d = i % D;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[((long)b * nc + cc) * D + d];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    s0 += (double)partial[((long)b * nc + cc) * D + d]; s1 += (double)partial[((long)(b + 1) * nc + cc) * D + d];
+    s2 += (double)partial[((long)(b + 2) * nc + cc) * D + d]; s3 += (double)partial[((long)(b + 3) * nc + cc) * D + d];
+  }
+  for (; b < nblk; ++b) s0 += (double)partial[((long)b * nc + cc) * D + d];
+  double s = (s0 + s1) + (s2 + s3);
   if (totals) s /= (double)totals[c0 + cc];
   out[(long)(c0 + cc) * ldo + d] = (float)s;
 }
@@ -484,8 +490,8 @@ int arco_compact_rows(const uint64_t* codes, long n_pix, int C, const uint32_t* 
 
 // workspace: partial must hold arco_proto_ws_floats(...) floats
 long arco_proto_ws_floats(long n_pix, int C, int D) {
-  long grid = (n_pix + 2047) / 2048;
-  if (grid > 1024) grid = 1024;
+  long grid = (n_pix + 255) / 256;
+  if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   const int nc = C < 8 ? C : 8;
   return grid * nc * D;
@@ -494,8 +500,8 @@ long arco_proto_ws_floats(long n_pix, int C, int D) {
 int arco_masked_proto(const float* T, long ldt, const uint64_t* codes, long n_pix, int C, int D,
                       const int64_t* totals, float* partial, float* proto, void* stream) {
   ARCO_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 512 && (ldt & 3) == 0 && C <= ARCO_MAXC);
-  long grid = (n_pix + 2047) / 2048;
-  if (grid > 1024) grid = 1024;
+  long grid = (n_pix + 255) / 256;
+  if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   long rpb = (n_pix + grid - 1) / grid;
   int lpr = 1;
@@ -531,8 +537,8 @@ int arco_lv_weights(const uint64_t* codes, long n_pix, int C, int Cp, float* W, 
 int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
                           const int64_t* totals, float* partial, float* out, long ldo, void* stream) {
   ARCO_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 512 && (ldt & 3) == 0 && C <= ARCO_MAXC);
-  long grid = (n_rows + 2047) / 2048;
-  if (grid > 1024) grid = 1024;
+  long grid = (n_rows + 255) / 256;
+  if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   long rpb = (n_rows + grid - 1) / grid;
   int lpr = 1;

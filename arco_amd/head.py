@@ -17,7 +17,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from ._contrast import rows_view
+from ._contrast import _ceil, rows_view
 
 
 def _gemm(x, w):
@@ -146,3 +146,153 @@ class LazyHead2Fn(torch.autograd.Function):
 
 def lazy_head2(x2p, f3, f4, fea3_weight, fea4_weight, q1_weight, q2_weight, pix):
     return LazyHead2Fn.apply(x2p, f3, f4, fea3_weight, fea4_weight, q1_weight, q2_weight, pix)
+
+
+def _class_weights(pl):
+    """low-valid bits of every pixel as float rows [n_pix, Cp] (Cp = C padded to 4)."""
+    Cp = _ceil(pl.C, 4)
+    wm = torch.empty((pl.n_pix, Cp), dtype=torch.float32, device=pl.dev)
+    L.call("arco_lv_weights", L.ptr(pl.codes), pl.n_pix, pl.C, Cp, L.ptr(wm))
+    return wm, Cp
+
+
+def _wsum(rows, ld, wt, ldw, n_rows, C, D, totals, out, ldo):
+    ws = torch.empty(L.query("arco_proto_ws_floats", n_rows, C, D), dtype=torch.float32, device=rows.device)
+    L.call("arco_weighted_row_sum", L.ptr(rows), ld, L.ptr(wt), ldw, n_rows, C, D, L.ptr(totals), L.ptr(ws), L.ptr(out), ldo)
+
+
+class LazyTeacher2D:
+    """Teacher side of the 2-D step without the dense 496-channel tensor: x3p = fea3(x)+x [B,480,128,128],
+    f4 [B,16,256,256], w4 = fea4 weight (model_2D.py:51-53)."""
+
+    def __init__(self, x3p, f4, w4):
+        self.x3p, self.f4, self.w4 = x3p, f4, w4
+
+    @torch.no_grad()
+    def prototypes(self, pl):
+        lo, ldlo = rows_view(self.x3p)
+        hi, ldhi = rows_view(self.f4)
+        nb, clo, hi_h, hi_w = (int(v) for v in self.x3p.shape)
+        chi, ho, wo = int(self.f4.shape[1]), int(self.f4.shape[2]), int(self.f4.shape[3])
+        C, K, D = pl.C, clo + chi, int(self.w4.shape[0])
+        wm, Cp = _class_weights(pl)
+        n_lo = nb * hi_h * hi_w
+        wlo = torch.empty((n_lo, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_bilinear_bwd", L.ptr(wm), Cp, nb, hi_h, hi_w, Cp, ho, wo, L.ptr(wlo), Cp, 0)
+        S = torch.zeros((_ceil(C, 16), K), dtype=torch.float32, device=pl.dev)
+        _wsum(lo, ldlo, wlo, Cp, n_lo, C, clo, pl.totals, S, K)
+        _wsum(hi, ldhi, wm, Cp, pl.n_pix, C, chi, pl.totals, S[:, clo:], K)
+        return _gemm(S, self.w4)[:C].contiguous()
+
+    @torch.no_grad()
+    def rows(self, pix):
+        lo, ldlo = rows_view(self.x3p)
+        hi, ldhi = rows_view(self.f4)
+        nb, clo, hi_h, hi_w = (int(v) for v in self.x3p.shape)
+        chi, ho, wo = int(self.f4.shape[1]), int(self.f4.shape[2]), int(self.f4.shape[3])
+        n = int(pix.shape[0])
+        X = torch.empty((n, clo + chi), dtype=torch.float32, device=pix.device)
+        L.call("arco_gather_upcat_rows", L.ptr(lo), ldlo, clo, hi_h, hi_w, L.ptr(hi), ldhi, chi, ho, wo, L.ptr(pix), n,
+               L.ptr(X), clo + chi)
+        return _gemm(X, self.w4)
+
+
+def _rows3d_forward(x2p, f3, f4, w3, w4, pix):
+    """X3 = cat(trilinear(x2p)[pix], f3[pix]); X3p = fea3(X3)+X3; X4 = cat(X3p, f4[pix]); returns (X3, X4, fea4(X4))."""
+    lo, ldlo = rows_view(x2p)
+    r3, ld3 = rows_view(f3)
+    r4, ld4 = rows_view(f4)
+    nb, c2, d2, h2, w2_ = (int(v) for v in x2p.shape)
+    c3, d3, h3, w3_ = (int(v) for v in f3.shape[1:])
+    c4 = int(f4.shape[1])
+    n = int(pix.shape[0])
+    k3 = c2 + c3
+    X3 = torch.empty((n, k3), dtype=torch.float32, device=pix.device)
+    L.call("arco_gather_upcat_rows3d", L.ptr(lo), ldlo, c2, d2, h2, w2_, L.ptr(r3), ld3, c3, d3, h3, w3_, L.ptr(pix), n,
+           L.ptr(X3), k3)
+    y3, _ = ops.conv_raw(X3, k3, k3, ops.pack_weight(w3, 1, 0), k3, 1, 1, n, 1, residual=X3, ld_res=k3)
+    X4 = torch.empty((n, k3 + c4), dtype=torch.float32, device=pix.device)
+    X4[:, :k3] = y3.permute(0, 2, 3, 1).reshape(n, k3)
+    L.call("arco_gather_rows", L.ptr(r4), ld4, c4, None, L.ptr(pix), None, 0, n, L.ptr(X4[:, k3:]), k3 + c4)
+    return X3, X4, _gemm(X4, w4)
+
+
+class LazyHead3dFn(torch.autograd.Function):
+    """Row-sparse student head of the 3-D step: q_representation(FeatureExtractor_3d(...)) rows at the sampled
+    voxels only.  Everything above the 56x56x40 level is per-voxel (fea3, the identity resize, fea4, q_rep),
+    so one trilinear gather from x2p = fea2(x)+x suffices (model_3D.py:46-58, train_arco_3d.py:289-296)."""
+
+    @staticmethod
+    def forward(ctx, x2p, f3, f4, w3, w4, w1, w2, pix):
+        X3, X4, h0 = _rows3d_forward(x2p, f3, f4, w3, w4, pix)
+        h1 = _gemm(h0, w1)
+        a = _gemm(h1, w2)
+        ctx.save_for_backward(X3, X4, h0, h1, w3, w4, w1, w2, pix)
+        ctx.shapes = (tuple(x2p.shape), tuple(f3.shape), tuple(f4.shape))
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        X3, X4, h0, h1, w3, w4, w1, w2, pix = ctx.saved_tensors
+        s2, s3, s4 = ctx.shapes
+        dev = da.device
+        n = int(pix.shape[0])
+        k3, c4 = int(X3.shape[1]), int(s4[1])
+        da = da.contiguous()
+        dw2 = _wgrad(da, h1, w2)
+        dh1 = _gemm_t(da, w2)
+        dw1 = _wgrad(dh1, h0, w1)
+        dh0 = _gemm_t(dh1, w1)
+        dw4 = _wgrad(dh0, X4, w4)
+        dX4 = _gemm_t(dh0, w4)
+        dX3p = dX4[:, :k3].contiguous()
+        df4 = torch.zeros((s4[0], *s4[2:], c4), dtype=torch.float32, device=dev)
+        L.call("arco_scatter_add_rows", L.ptr(dX4[:, k3:]), k3 + c4, c4, None, L.ptr(pix), n, None, 1.0, L.ptr(df4), c4)
+        dw3 = _wgrad(dX3p, X3, w3)
+        y, _ = ops.conv_raw(dX3p, k3, k3, ops.pack_weight(w3, 1, 1), k3, 1, 1, n, 1, residual=dX3p, ld_res=k3)
+        dX3 = y.permute(0, 2, 3, 1).reshape(n, k3)
+        c2, c3 = int(s2[1]), int(s3[1])
+        dx2p = torch.zeros((s2[0], *s2[2:], c2), dtype=torch.float32, device=dev)
+        df3 = torch.zeros((s3[0], *s3[2:], c3), dtype=torch.float32, device=dev)
+        L.call("arco_scatter_upcat_rows3d", L.ptr(dX3), k3, L.ptr(pix), n, L.ptr(dx2p), c2, c2, s2[2], s2[3], s2[4],
+               L.ptr(df3), c3, c3, s3[2], s3[3], s3[4])
+        return (dx2p.movedim(-1, 1), df3.movedim(-1, 1), df4.movedim(-1, 1), dw3, dw4, dw1, dw2, None)
+
+
+def lazy_head3d(x2p, f3, f4, fea3_weight, fea4_weight, q1_weight, q2_weight, pix):
+    return LazyHead3dFn.apply(x2p, f3, f4, fea3_weight, fea4_weight, q1_weight, q2_weight, pix)
+
+
+class LazyTeacher3D:
+    """Teacher side of the 3-D step: prototype_c = W4 . cat((W3+I) . mean_c(cat(up(x2p), f3)), mean_c(f4)) with the
+    class mask pushed through the trilinear adjoint; key rows evaluated at the key voxels only."""
+
+    def __init__(self, x2p, f3, f4, w3, w4):
+        self.x2p, self.f3, self.f4, self.w3, self.w4 = x2p, f3, f4, w3, w4
+
+    @torch.no_grad()
+    def prototypes(self, pl):
+        lo, ldlo = rows_view(self.x2p)
+        r3, ld3 = rows_view(self.f3)
+        r4, ld4 = rows_view(self.f4)
+        nb, c2, d2, h2, w2_ = (int(v) for v in self.x2p.shape)
+        c3, d3, h3, w3_ = (int(v) for v in self.f3.shape[1:])
+        c4 = int(self.f4.shape[1])
+        C, k3 = pl.C, c2 + c3
+        wm, Cp = _class_weights(pl)
+        n_lo = nb * d2 * h2 * w2_
+        wlo = torch.empty((n_lo, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_trilinear_bwd", L.ptr(wm), Cp, nb, d2, h2, w2_, Cp, d3, h3, w3_, L.ptr(wlo), Cp)
+        R = _ceil(C, 16)
+        S3 = torch.zeros((R, k3), dtype=torch.float32, device=pl.dev)
+        _wsum(lo, ldlo, wlo, Cp, n_lo, C, c2, pl.totals, S3, k3)
+        _wsum(r3, ld3, wm, Cp, pl.n_pix, C, c3, pl.totals, S3[:, c2:], k3)
+        y3, _ = ops.conv_raw(S3, k3, k3, ops.pack_weight(self.w3, 1, 0), k3, 1, 1, R, 1, residual=S3, ld_res=k3)
+        S4 = torch.zeros((R, k3 + c4), dtype=torch.float32, device=pl.dev)
+        S4[:, :k3] = y3.permute(0, 2, 3, 1).reshape(R, k3)
+        _wsum(r4, ld4, wm, Cp, pl.n_pix, C, c4, pl.totals, S4[:, k3:], k3 + c4)
+        return _gemm(S4, self.w4)[:C].contiguous()
+
+    @torch.no_grad()
+    def rows(self, pix):
+        return _rows3d_forward(self.x2p, self.f3, self.f4, self.w3, self.w4, pix)[2]

@@ -24,6 +24,16 @@ class FeatureExtractor_3d(nn.Module):
         cnt += fea_dim[4]
         self.fea4 = nn.Conv3d(in_channels=cnt, out_channels=output_dim, kernel_size=1, bias=False)
 
+    def forward_lowres2(self, fea_list):
+        """Up to fea2 (56x56x40 level): (fea2(x)+x, f3, f4) for the row-sparse head (arco_amd.head)."""
+        f = [ops.to_channels_last(t) for t in fea_list]
+        x = ops.conv(f[0], self.fea0.weight, None, residual=True)
+        for i, fea in enumerate((self.fea1, self.fea2), start=1):
+            x = ops.trilinear(x, f[i].shape[-3:])
+            x = torch.cat((x, f[i]), dim=1)
+            x = ops.conv(x, fea.weight, None, residual=True)
+        return x, f[3], f[4]
+
     def forward(self, fea_list):
         f = [ops.to_channels_last(t) for t in fea_list]
         x = ops.conv(f[0], self.fea0.weight, None, residual=True)            # fea0(f0) + f0

@@ -205,7 +205,7 @@ class ArcoStep2D:
                 rep_all_teacher, lazy_t = self.k_feature_extractor(fm_t), None
             else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys/class
                 x3p_t, f4_t = self.k_feature_extractor.forward_lowres(fm_t)
-                rep_all_teacher, lazy_t = None, (x3p_t, f4_t, self.k_feature_extractor.fea4.weight)
+                rep_all_teacher, lazy_t = None, head.LazyTeacher2D(x3p_t, f4_t, self.k_feature_extractor.fea4.weight)
         fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]         # :317-318
         if dense:
             rep_all = self.q_rep(self.q_feature_extractor(fm_all))       # :324-325,330

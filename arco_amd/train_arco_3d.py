@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _contrast as C_
 from . import dist as adist
-from . import glue, graphs, ops, optim
+from . import glue, graphs, head, ops, optim
 from .model_3D import ISD_3d, FeatureExtractor_3d
 from .train_arco_2d import build_parser as _build_parser_2d
 
@@ -100,15 +100,29 @@ class ArcoStep3D:
         plan = C_.contrast_masks(label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all,
                                  delta_n=a.strong_threshold_u2pl)
         pred_l, _, l_fm = self.model(l_data)                             # :283
-        with torch.no_grad():
-            rep_all_teacher = self.k_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)])   # :292-293
-        rep_all = self.q_rep(self.q_feature_extractor([torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]))       # :289-296,301
+        dense = getattr(a, "dense_head", 0)
+        fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
+        fm_s = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]
+        kfe, qfe = self.k_feature_extractor, self.q_feature_extractor
+        with torch.no_grad():                                            # :292-293
+            if dense:
+                rep_all_teacher, lazy_t = kfe(fm_t), None
+            else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys per class
+                rep_all_teacher, lazy_t = None, head.LazyTeacher3D(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
+        if dense:
+            rep_all = self.q_rep(qfe(fm_s))                              # :289-296,301
+        else:
+            x2p, f3, f4 = qfe.forward_lowres2(fm_s)
         C_.contrast_sample(plan, self.memobank, self.queue_size, a.func, a.num_queries, a.num_negatives)
-        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size)
+        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size, lazy_teacher=lazy_t)
         if plan.valid_seg <= 1 or not plan.entries:
             reco_loss = self.q_representation[1].weight.sum() * 0.0
-        else:
+        elif dense:
             A_all = C_.GatherRowsFn.apply(rep_all, plan.anchor_pix)
+            reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
+        else:
+            A_all = head.lazy_head3d(x2p, f3, f4, qfe.fea3.weight, qfe.fea4.weight, self.q_representation[0].weight,
+                                     self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
         loss = a.k1 * reco_loss
         self.optimizer.zero_grad()

@@ -129,6 +129,11 @@ int arco_trilinear_fwd(const float* X, long ldx, int NV, int Di, int Hi, int Wi,
                        long ldy, void* stream);
 int arco_trilinear_bwd(const float* dY, long ldy, int NV, int Di, int Hi, int Wi, int C, int Do, int Ho, int Wo, float* dX,
                        long ldx, void* stream);
+/* 3-D row-sparse head: rows of cat(trilinear_up(lo), hi) at selected voxels + adjoint (model_3D.py:52-55) */
+int arco_gather_upcat_rows3d(const float* lo, long ldlo, int Clo, int Di, int Hi, int Wi, const float* hi, long ldhi, int Chi,
+                             int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
+int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo, int Di,
+                              int Hi, int Wi, float* dhi, long ldhi, int Chi, int Do, int Ho, int Wo, void* stream);
 int arco_copy_rows(const float* X, long ldx, long M, int C, float* Y, long ldy, int accumulate, void* stream);
 int arco_nchw_to_nhwc(const float* X, int NB, int C, long P, float* Y, long ldy, void* stream);
 int arco_nhwc_to_nchw(const float* X, long ldx, int NB, int C, long P, float* Y, void* stream);

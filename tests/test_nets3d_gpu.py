@@ -200,3 +200,41 @@ def test_train_step_3d_runs_and_updates():
     after = torch.cat([p.detach().reshape(-1) for p in st.optimizer.params])
     assert float((after - before).abs().max()) > 0
     assert all(b[0].is_cuda and b[0].shape[1] == 16 for b in st.memobank)
+
+
+def _run3d(dense, steps=2):
+    import random
+    from arco_amd import ops, train_arco_3d as T3
+    random.seed(3); np.random.seed(3); torch.manual_seed(3)
+    ops.reseed_dropout(77)
+    args = T3.build_parser().parse_args(["--batch_size", "1", "--queue_size", "300", "--synthetic", "1", "--num_classes", "2",
+                                         "--num_queries", "64", "--num_negatives", "32", "--k1", "1.0", "--dense_head", str(dense),
+                                         "--graphs", "0"])
+    args.patch_size = [32, 32, 32]
+    st = T3.ArcoStep3D(args, "cuda:0")
+    for m in st.model.modules():            # dropout off in both nets: the two runs consume dropout seeds differently
+        if isinstance(m, torch.nn.Dropout3d):
+            m.p = 0.0
+    for m in st.ema_model.modules():
+        if isinstance(m, torch.nn.Dropout3d):
+            m.p = 0.0
+    st.model.has_dropout = st.ema_model.has_dropout = False
+    losses = []
+    for i in range(steps):
+        l_img, l_lab = T3.synthetic_volume_batch(1, args.patch_size, 2, 10 + i, "cuda:0")
+        u_img, _ = T3.synthetic_volume_batch(1, args.patch_size, 2, 20 + i, "cuda:0")
+        loss, reco = st.step(l_img, l_lab, u_img)
+        losses.append(float(reco.detach()))
+    fe = torch.cat([p.detach().reshape(-1) for p in list(st.q_feature_extractor.parameters()) + list(st.q_representation.parameters())]).cpu()
+    return losses, fe, [b[0].cpu() for b in st.memobank]
+
+
+def test_lazy_3d_head_and_teacher_match_dense():
+    l_d, p_d, b_d = _run3d(1)
+    l_s, p_s, b_s = _run3d(0)
+    assert all(abs(v) > 1e-3 for v in l_d)
+    np.testing.assert_allclose(l_s, l_d, rtol=2e-4, atol=1e-5)
+    for x, y in zip(b_s, b_d):
+        assert x.shape == y.shape
+    # step-1 banks come from identical teachers: rows equal up to the re-associated key GEMM
+    np.testing.assert_allclose(p_s.numpy(), p_d.numpy(), rtol=2e-2, atol=2e-4)
