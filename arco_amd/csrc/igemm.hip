@@ -450,6 +450,116 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// all-taps weight gradient for the shallow layers (Cout, Cin <= 32): one block owns a tile of 8x16 output
+// pixels of one plane, stages the dZ tile and the input HALO patch once in LDS and accumulates all 9 taps of
+// the plane (3-D: the depth tap dd = blockIdx.z, input plane x+dd-1) -> both operands are read from HBM/L2
+// once instead of once per tap.  acc[tap][co_t][ci_t]; A fragment (dZ^T) is shared by the 9 taps.
+// partial layout identical to wgrad_kernel: [chunk][tap][CoutPad][CinPad].
+// ---------------------------------------------------------------------------
+template <int CO_B, int CI_B>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs a) {
+  constexpr int LDZ = (CO_B % 32 == 0) ? CO_B + 16 : CO_B;
+  constexpr int LDA = (CI_B % 32 == 0) ? CI_B + 16 : CI_B;
+  constexpr int CO_T = CO_B / 16, CI_T = CI_B / 16;
+  constexpr int HROWS = 10 * 18;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zs = smem;                 // [128][LDZ]
+  float* Xs = smem + 128 * LDZ;     // [180][LDA]   halo patch
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int dd = blockIdx.z;                                   // depth tap (3-D) ; 0 for 2-D
+  const int dpl = a.taps == 27 ? dd - 1 : 0;
+  const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
+
+  f32x4 acc[9][CO_T][CI_T];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < CO_T; ++i)
+#pragma unroll
+      for (int j = 0; j < CI_T; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
+
+  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; const int img = tt / tiles_y;
+    const int y0 = ty * 8, x0 = tx * 16;
+    const int pl = a.taps == 27 ? img % a.D3 + dpl : 0;
+    const bool plane_ok = pl >= 0 && pl < a.D3;
+    __syncthreads();
+    for (int idx = tid; idx < 128 * (CO_B / 4); idx += 256) {
+      const int p = idx / (CO_B / 4), q = idx % (CO_B / 4);
+      const int y = y0 + p / 16, x = x0 + p % 16;
+      f32x4 v = f32x4{0, 0, 0, 0};
+      if (y < a.H && x < a.W && plane_ok) {
+        const int c = 4 * q;
+        const float* src = a.dZ + (((long)img * a.H + y) * a.W + x) * a.ldz + c;
+        if (((a.Cout & 3) == 0) && ((a.ldz & 3) == 0)) { if (c < a.Cout) v = *reinterpret_cast<const f32x4*>(src); }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c + e < a.Cout) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Zs[p * LDZ + 4 * q]) = v;
+    }
+    for (int idx = tid; idx < HROWS * (CI_B / 4); idx += 256) {
+      const int r = idx / (CI_B / 4), q = idx % (CI_B / 4);
+      const int y = y0 + r / 18 - 1, x = x0 + r % 18 - 1;
+      f32x4 v = f32x4{0, 0, 0, 0};
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok) {
+        const int c = 4 * q;
+        const float* src = a.Ain + (((long)(img + dpl) * a.H + y) * a.W + x) * a.lda + c;
+        if (((a.Cin & 3) == 0) && ((a.lda & 3) == 0)) { if (c < a.Cin) v = *reinterpret_cast<const f32x4*>(src); }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c + e < a.Cin) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Xs[r * LDA + 4 * q]) = v;
+    }
+    __syncthreads();
+    // wave `wid` reduces tile rows 2*wid, 2*wid+1 (32 pixels = 8 k-steps of 4 pixels)
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ++ks) {
+      const int p = wid * 32 + ks * 4 + g;          // pixel of this lane's k index
+      const int py = p / 16, px = p % 16;
+      float zf[CO_T];
+#pragma unroll
+      for (int i = 0; i < CO_T; ++i) zf[i] = Zs[p * LDZ + i * 16 + li];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int hr = (py + tap / 3) * 18 + px + tap % 3;
+#pragma unroll
+        for (int j = 0; j < CI_T; ++j) {
+          const float xf = Xs[hr * LDA + j * 16 + li];
+#pragma unroll
+          for (int i = 0; i < CO_T; ++i)
+            acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[i], xf, acc[tap][i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // cross-wave reduction through LDS (tap by tap), then slab store
+  float* red = smem;   // [4][CO_B][CI_B]
+  for (int tap = 0; tap < 9; ++tap) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CO_T; ++i)
+#pragma unroll
+      for (int j = 0; j < CI_T; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[((wid * CO_B) + i * 16 + 4 * g + r) * CI_B + j * 16 + li] = acc[tap][i][j][r];
+    __syncthreads();
+    const int gtap = dd * 9 + tap;
+    float* out = a.partial + (((long)blockIdx.x * a.taps + gtap) * a.CoutPad) * a.CinPad;
+    for (int idx = tid; idx < CO_B * CI_B; idx += 256) {
+      const int co = idx / CI_B, ci = idx % CI_B;
+      const float v = (red[(0 * CO_B + co) * CI_B + ci] + red[(1 * CO_B + co) * CI_B + ci]) +
+                      (red[(2 * CO_B + co) * CI_B + ci] + red[(3 * CO_B + co) * CI_B + ci]);
+      out[(long)co * a.CinPad + ci] = v;
+    }
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int taps, int CoutPad, int CinPad,
                                     int Cout, int Cin, float* __restrict__ dW, int accumulate) {
   // threads walk the slab layout [tap][co][ci] (ci fastest -> coalesced slab reads); dW is torch layout
@@ -576,6 +686,7 @@ long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M) {
   const long n_tiles = (M + 127) / 128 * 4 + 64;   // upper bound incl. ragged spatial tiles
   const long yz = (long)(CoutPad / co_b) * (CinPad / ci_b) * taps;
   long chunks = 2048 / yz; if (chunks < 1) chunks = 1; if (chunks > n_tiles) chunks = n_tiles;
+  if (taps >= 9 && Cout <= 32 && Cin <= 32) { chunks = 1024 / (taps / 9); if (chunks > n_tiles) chunks = n_tiles; }
   return chunks * taps * CoutPad * CinPad;
 }
 
@@ -595,10 +706,31 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
   a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
   a.n_tiles = taps >= 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
+  hipStream_t st = as_stream(stream);
+  if (taps >= 9 && Cout <= 32 && Cin <= 32) {       // shallow layers: all taps of a plane per block (halo in LDS)
+    const int zdim = taps / 9;
+    long chunks = 1024 / zdim; if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
+    dim3 hgrid((unsigned)chunks, 1, zdim);
+#define WH(COB, CIB)                                                                              \
+    do {                                                                                          \
+      constexpr int LZ = (COB % 32 == 0) ? COB + 16 : COB, LA = (CIB % 32 == 0) ? CIB + 16 : CIB; \
+      size_t sh = (size_t)(128 * LZ + 180 * LA) * 4; const size_t rd = (size_t)4 * COB * CIB * 4; \
+      if (sh < rd) sh = rd;                                                                       \
+      hipLaunchKernelGGL((wgrad_halo_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);             \
+    } while (0)
+    if (co_b == 32 && ci_b == 32) WH(32, 32);
+    else if (co_b == 32 && ci_b == 16) WH(32, 16);
+    else if (co_b == 16 && ci_b == 32) WH(16, 32);
+    else WH(16, 16);
+#undef WH
+    const long tot = (long)Cout * Cin * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ws, (int)chunks, taps, a.CoutPad,
+                       a.CinPad, Cout, Cin, dW, accumulate);
+    return arco_launch_status();
+  }
   const long yz = (long)(a.CoutPad / co_b) * (a.CinPad / ci_b) * taps;
   long chunks = 2048 / yz; if (chunks < 1) chunks = 1; if (chunks > a.n_tiles) chunks = a.n_tiles;
   dim3 grid((unsigned)chunks, a.CoutPad / co_b, (a.CinPad / ci_b) * taps);
-  hipStream_t st = as_stream(stream);
 #define WG(COB, CIB)                                                                              \
   do {                                                                                            \
     constexpr int LZ = (COB % 32 == 0) ? COB + 16 : COB, LA = (CIB % 32 == 0) ? CIB + 16 : CIB;   \
