@@ -560,24 +560,29 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs a) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int taps, int CoutPad, int CinPad,
+__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int taps, int CoutPad, int CinPad,
                                     int Cout, int Cin, float* __restrict__ dW, int accumulate) {
-  // threads walk the slab layout [tap][co][ci] (ci fastest -> coalesced slab reads); dW is torch layout
-  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // block = 64 consecutive slab elements (coalesced) x 8 slab groups; slab layout [tap][co][ci], dW torch layout.
+  __shared__ float red[8][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long j = (long)blockIdx.x * 64 + tx;
   const long tot = (long)taps * Cout * Cin;
-  if (j >= tot) return;
-  const int ci = j % Cin; const long r = j / Cin; const int co = r % Cout; const int tap = r / Cout;
-  const long off = ((long)tap * CoutPad + co) * CinPad + ci, stride = (long)taps * CoutPad * CinPad;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int c = 0;
-  for (; c + 3 < chunks; c += 4) {
-    s0 += partial[off + (long)c * stride]; s1 += partial[off + (long)(c + 1) * stride];
-    s2 += partial[off + (long)(c + 2) * stride]; s3 += partial[off + (long)(c + 3) * stride];
+  float s0 = 0.f, s1 = 0.f;
+  int ci = 0, co = 0, tap = 0;
+  if (j < tot) {
+    ci = j % Cin; const long r = j / Cin; co = r % Cout; tap = r / Cout;
+    const long off = ((long)tap * CoutPad + co) * CinPad + ci, stride = (long)taps * CoutPad * CinPad;
+    int c = ty;
+    for (; c + 8 < chunks; c += 16) { s0 += partial[off + (long)c * stride]; s1 += partial[off + (long)(c + 8) * stride]; }
+    for (; c < chunks; c += 8) s0 += partial[off + (long)c * stride];
   }
-  for (; c < chunks; ++c) s0 += partial[off + (long)c * stride];
-  const float s = (s0 + s1) + (s2 + s3);
-  const long o = ((long)co * Cin + ci) * taps + tap;
-  dW[o] = accumulate ? dW[o] + s : s;
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty == 0 && j < tot) {
+    const float s = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    const long o = ((long)co * Cin + ci) * taps + tap;
+    dW[o] = accumulate ? dW[o] + s : s;
+  }
 }
 
 // column sums (bias gradient): out[c] = sum_pix X[pix][c].  float4 lanes along channels,
@@ -709,7 +714,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   hipStream_t st = as_stream(stream);
   if (taps >= 9 && Cout <= 32 && Cin <= 32) {       // shallow layers: all taps of a plane per block (halo in LDS)
     const int zdim = taps / 9;
-    long chunks = 1024 / zdim; if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
+    long chunks = 768 / zdim; if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
     dim3 hgrid((unsigned)chunks, 1, zdim);
 #define WH(COB, CIB)                                                                              \
     do {                                                                                          \
@@ -724,7 +729,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     else WH(16, 16);
 #undef WH
     const long tot = (long)Cout * Cin * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ws, (int)chunks, taps, a.CoutPad,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(512), 0, st, ws, (int)chunks, taps, a.CoutPad,
                        a.CinPad, Cout, Cin, dW, accumulate);
     return arco_launch_status();
   }
@@ -751,7 +756,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   else WG(16, 16);
 #undef WG
   const long tot = (long)Cout * Cin * taps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ws, (int)chunks, taps, a.CoutPad,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(512), 0, st, ws, (int)chunks, taps, a.CoutPad,
                      a.CinPad, Cout, Cin, dW, accumulate);
   return arco_launch_status();
 }
