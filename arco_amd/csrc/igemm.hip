@@ -470,6 +470,8 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs a) {
   const int dd = blockIdx.z;                                   // depth tap (3-D) ; 0 for 2-D
   const int dpl = a.taps == 27 ? dd - 1 : 0;
   const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
+  const int ci_tiles = a.CinPad / CI_B;
+  const int co0 = (blockIdx.y / ci_tiles) * CO_B, ci0 = (blockIdx.y % ci_tiles) * CI_B;
 
   f32x4 acc[9][CO_T][CI_T];
 #pragma unroll
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs a) {
       const int y = y0 + p / 16, x = x0 + p % 16;
       f32x4 v = f32x4{0, 0, 0, 0};
       if (y < a.H && x < a.W && plane_ok) {
-        const int c = 4 * q;
+        const int c = co0 + 4 * q;
         const float* src = a.dZ + (((long)img * a.H + y) * a.W + x) * a.ldz + c;
         if (((a.Cout & 3) == 0) && ((a.ldz & 3) == 0)) { if (c < a.Cout) v = *reinterpret_cast<const f32x4*>(src); }
         else {
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs a) {
       const int y = y0 + r / 18 - 1, x = x0 + r % 18 - 1;
       f32x4 v = f32x4{0, 0, 0, 0};
       if (y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok) {
-        const int c = 4 * q;
+        const int c = ci0 + 4 * q;
         const float* src = a.Ain + (((long)(img + dpl) * a.H + y) * a.W + x) * a.lda + c;
         if (((a.Cin & 3) == 0) && ((a.lda & 3) == 0)) { if (c < a.Cin) v = *reinterpret_cast<const f32x4*>(src); }
         else {
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs a) {
       const int co = idx / CI_B, ci = idx % CI_B;
       const float v = (red[(0 * CO_B + co) * CI_B + ci] + red[(1 * CO_B + co) * CI_B + ci]) +
                       (red[(2 * CO_B + co) * CI_B + ci] + red[(3 * CO_B + co) * CI_B + ci]);
-      out[(long)co * a.CinPad + ci] = v;
+      out[(long)(co0 + co) * a.CinPad + ci0 + ci] = v;
     }
   }
 }
@@ -691,7 +693,12 @@ long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M) {
   const long n_tiles = (M + 127) / 128 * 4 + 64;   // upper bound incl. ragged spatial tiles
   const long yz = (long)(CoutPad / co_b) * (CinPad / ci_b) * taps;
   long chunks = 2048 / yz; if (chunks < 1) chunks = 1; if (chunks > n_tiles) chunks = n_tiles;
-  if (taps >= 9 && Cout <= 32 && Cin <= 32) { chunks = 1024 / (taps / 9); if (chunks > n_tiles) chunks = n_tiles; }
+  if (taps >= 9) {
+    const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
+    const long cop = (Cout + hco - 1) / hco * hco, cip = (Cin + hci - 1) / hci * hci;
+    chunks = 1536 / ((taps / 9) * (cop / hco) * (cip / hci)); if (chunks > n_tiles) chunks = n_tiles; if (chunks < 1) chunks = 1;
+    return chunks * taps * cop * cip;
+  }
   return chunks * taps * CoutPad * CinPad;
 }
 
@@ -712,10 +719,12 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
   a.n_tiles = taps >= 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
   hipStream_t st = as_stream(stream);
-  if (taps >= 9 && Cout <= 32 && Cin <= 32) {       // shallow layers: all taps of a plane per block (halo in LDS)
-    const int zdim = taps / 9;
-    long chunks = 768 / zdim; if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
-    dim3 hgrid((unsigned)chunks, 1, zdim);
+  if (taps >= 9) {       // spatial kernels: all taps of a plane per block, operands staged once (halo in LDS)
+    const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
+    a.CoutPad = (Cout + hco - 1) / hco * hco; a.CinPad = (Cin + hci - 1) / hci * hci;
+    const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
+    long chunks = 1536 / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
+    dim3 hgrid((unsigned)chunks, ydim, zdim);
 #define WH(COB, CIB)                                                                              \
     do {                                                                                          \
       constexpr int LZ = (COB % 32 == 0) ? COB + 16 : COB, LA = (CIB % 32 == 0) ? CIB + 16 : CIB; \
@@ -723,9 +732,9 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
       if (sh < rd) sh = rd;                                                                       \
       hipLaunchKernelGGL((wgrad_halo_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);             \
     } while (0)
-    if (co_b == 32 && ci_b == 32) WH(32, 32);
-    else if (co_b == 32 && ci_b == 16) WH(32, 16);
-    else if (co_b == 16 && ci_b == 32) WH(16, 32);
+    if (hco == 32 && hci == 32) WH(32, 32);
+    else if (hco == 32 && hci == 16) WH(32, 16);
+    else if (hco == 16 && hci == 32) WH(16, 32);
     else WH(16, 16);
 #undef WH
     const long tot = (long)Cout * Cin * taps;
