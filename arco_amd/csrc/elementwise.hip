@@ -22,8 +22,9 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
                                    double count, float eps, float momentum, float* __restrict__ mean,
                                    float* __restrict__ istd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var) {
+                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x;
+  if (c == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
   double s = 0.0, q = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 64) { s += (double)ssum[(long)c * nblk + b]; q += (double)ssq[(long)c * nblk + b]; }
   s = wave_sum_d(s); q = wave_sum_d(q);
@@ -648,10 +649,11 @@ static inline int ew_grid(long work) {
 extern "C" {
 
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
-                     float* mean, float* istd, float* running_mean, float* running_var, void* stream) {
+                     float* mean, float* istd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     void* stream) {
   ARCO_CHECK_ARG(C > 0 && nblk > 0 && count > 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), ssum, ssq, nblk, C,
-                     (double)count, eps, momentum, mean, istd, running_mean, running_var);
+                     (double)count, eps, momentum, mean, istd, running_mean, running_var, num_batches_tracked);
   return arco_launch_status();
 }
 

@@ -23,8 +23,8 @@ def _stage(x, conv, bn, act, drop_p, training, drop_mode=1):
     slope = getattr(act, "negative_slope", 0.0)
     if training:
         y = ops.conv_bn_act(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            slope=slope, p=drop_p, drop_mode=drop_mode, momentum=bn.momentum, eps=bn.eps)
-        bn.num_batches_tracked += 1
+                            slope=slope, p=drop_p, drop_mode=drop_mode, momentum=bn.momentum, eps=bn.eps,
+                            num_batches_tracked=bn.num_batches_tracked)
         return y
     return ops.conv_bn_act_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 slope=slope, eps=bn.eps)

@@ -25,8 +25,8 @@ def _need_bn(normalization):
 def _bn_stage(x, conv, bn, training):
     if training:
         y = ops.conv_bn_act(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            slope=0.0, p=0.0, momentum=bn.momentum, eps=bn.eps)
-        bn.num_batches_tracked += 1
+                            slope=0.0, p=0.0, momentum=bn.momentum, eps=bn.eps,
+                            num_batches_tracked=bn.num_batches_tracked)
         return y
     return ops.conv_bn_act_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 slope=0.0, eps=bn.eps)
@@ -64,10 +64,8 @@ class DownsamplingConvBlock(nn.Module):
         w2 = conv.weight.permute(0, 2, 3, 4, 1).reshape(co, 8 * ci, 1, 1, 1)      # [co][(dx,dy,dz), ci]
         xs = ops.space_to_depth3(x)
         if self.training:
-            y = ops.conv_bn_act(xs, w2, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
-                                p=0.0, momentum=bn.momentum, eps=bn.eps)
-            bn.num_batches_tracked += 1
-            return y
+            return ops.conv_bn_act(xs, w2, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
+                                   p=0.0, momentum=bn.momentum, eps=bn.eps, num_batches_tracked=bn.num_batches_tracked)
         return ops.conv_bn_act_eval(xs, w2, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
                                     eps=bn.eps)
 
@@ -87,10 +85,8 @@ class UpsamplingDeconvBlock(nn.Module):
         y = ops.conv(x, w2, conv.bias.repeat(8))
         z = ops.depth_to_space3(y)
         if self.training:
-            a = ops.bn_act(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, momentum=bn.momentum,
-                           eps=bn.eps)
-            bn.num_batches_tracked += 1
-            return a
+            return ops.bn_act(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, momentum=bn.momentum,
+                              eps=bn.eps, num_batches_tracked=bn.num_batches_tracked)
         with torch.no_grad():
             scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
             shift = bn.bias - bn.running_mean * scale

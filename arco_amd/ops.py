@@ -137,9 +137,39 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
 def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
     ws = torch.empty(L.query("arco_wgrad_ws_floats", co, ci, taps, nb * d3 * h * w), dtype=torch.float32,
                      device=dzr.device)
-    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
-    L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(dw), 0)
-    return dw
+
+    def compute(out, accumulate):
+        L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
+               accumulate)
+    return _grad_into(like, compute)
+
+
+_zero_cache = {}
+
+
+def _zeros_like_cached(t):
+    """Shared read-only zero tensor (never written): the gradient of a conv bias under train-mode BN."""
+    key = (tuple(t.shape), t.device)
+    z = _zero_cache.get(key)
+    if z is None:
+        z = torch.zeros_like(t)
+        _zero_cache[key] = z
+    return z
+
+
+def _grad_into(param, compute):
+    """Weight gradients go straight into the optimiser's flat gradient view when the parameter has one
+    (param._arco_grad_view, installed by optim.SGDNesterov): `compute(out, accumulate)` writes there with
+    accumulate=1 and autograd gets None - no per-parameter AccumulateGrad add kernel.  Otherwise the gradient
+    is returned normally."""
+    view = getattr(param, "_arco_grad_view", None)
+    if view is not None and param.grad is not None and param.grad.data_ptr() == view.data_ptr():
+        compute(view, 1)
+        param._arco_mark()
+        return None
+    out = torch.empty_like(param, memory_format=torch.contiguous_format)
+    compute(out, 0)
+    return out
 
 
 def colsum(xr, ld, m, c):
@@ -214,7 +244,8 @@ class ConvBnActFn(torch.autograd.Function):
     GEMM-form k2s2 down conv (vnetWithArgs.py:16-25,67-91)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps,
+                nbt=None):
         L.require_gpu(x, weight)
         taps = _taps(weight)
         xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
@@ -225,7 +256,7 @@ class ConvBnActFn(torch.autograd.Function):
         mean = torch.empty(co, dtype=torch.float32, device=x.device)
         istd = torch.empty(co, dtype=torch.float32, device=x.device)
         L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
-               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var))
+               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt))
         seed = _next_seed() if p > 0 else 0
         a = new_act_nd(nv, co, sp, x.device)
         zr, ldz = rows_view(z)
@@ -249,8 +280,11 @@ class ConvBnActFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dzr, ldzz, nv * d3 * h * w, co)
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+            # a conv bias under train-mode BN has an analytically ZERO gradient (BN removes the channel mean):
+            # sum(dz) = -gamma*istd*mean(dy*xhat)*sum(xhat) and sum(xhat) == 0.  The reference's autograd
+            # produces fp32 rounding noise (~1e-7) here; we return exact zeros instead of a column-sum pass.
+            db = _zeros_like_cached(bias)
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class BnActFn(torch.autograd.Function):
@@ -258,7 +292,7 @@ class BnActFn(torch.autograd.Function):
     transposed conv of UpsamplingDeconvBlock, vnetWithArgs.py:94-118).  gamma=None: plain dropout/activation."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps, nbt=None):
         zr, ldz = rows_view(z)
         co = int(z.shape[1])
         m = zr.shape[0]
@@ -275,7 +309,7 @@ class BnActFn(torch.autograd.Function):
             mean = torch.empty(co, dtype=torch.float32, device=z.device)
             istd = torch.empty(co, dtype=torch.float32, device=z.device)
             L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nblk, co, m, float(eps), float(momentum), L.ptr(mean),
-                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var))
+                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt))
         seed = _next_seed() if p > 0 else 0
         a = new_act_nd(int(z.shape[0]), co, sp, z.device)
         _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a)
@@ -288,7 +322,7 @@ class BnActFn(torch.autograd.Function):
         z, mean, istd, gamma, beta = ctx.saved_tensors
         slope, p, drop_mode, seed, P = ctx.cfg
         dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P)
-        return dz, dgamma, dbeta, None, None, None, None, None, None, None
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class S2D3Fn(torch.autograd.Function):
@@ -387,9 +421,10 @@ def conv(x, weight, bias=None, residual=False):
 
 
 def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, slope=0.01, p=0.0, drop_mode=1,
-                momentum=0.1, eps=1e-5):
+                momentum=0.1, eps=1e-5, num_batches_tracked=None):
+    """`num_batches_tracked` (int64 buffer) is incremented inside the BN finalize kernel."""
     return ConvBnActFn.apply(x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode,
-                             momentum, eps)
+                             momentum, eps, num_batches_tracked)
 
 
 def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, slope=0.01, eps=1e-5):
@@ -407,8 +442,10 @@ def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, sl
         return a
 
 
-def bn_act(z, gamma, beta, running_mean, running_var, slope=0.0, p=0.0, drop_mode=0, momentum=0.1, eps=1e-5):
-    return BnActFn.apply(z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps)
+def bn_act(z, gamma, beta, running_mean, running_var, slope=0.0, p=0.0, drop_mode=0, momentum=0.1, eps=1e-5,
+           num_batches_tracked=None):
+    return BnActFn.apply(z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps,
+                         num_batches_tracked)
 
 
 def dropout3d(x, p):

@@ -83,6 +83,10 @@ class SGDNesterov:
             self.offsets.append((off, k))
             p.grad = self.flat_g[off:off + k].view(p.shape)
             p.register_post_accumulate_grad_hook(self._mark(i))
+            # direct-write path of arco_amd.ops (contiguous torch-layout weights only)
+            if p.dim() >= 2:
+                p._arco_grad_view = p.grad
+                p._arco_mark = self._marker(i)
             off += k
         self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay, params=self.params)]
         self._touched = set()
@@ -92,6 +96,11 @@ class SGDNesterov:
         def hook(_p):
             self._touched.add(i)
         return hook
+
+    def _marker(self, i):
+        def mark():
+            self._touched.add(i)
+        return mark
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()

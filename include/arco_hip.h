@@ -90,7 +90,8 @@ int arco_transpose2d(const float* x, long ldx, int rows, int cols, float* y, lon
 /* ---- N1  train-mode BatchNorm + (Leaky)ReLU + dropout (nn.BatchNorm2d/LeakyReLU/Dropout,
  *      unetWithArgs.py:36-44; vnetWithArgs.py:16-25)                                                      */
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
-                     float* mean, float* istd, float* running_mean, float* running_var, void* stream);
+                     float* mean, float* istd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     void* stream);
 int arco_chan_stats_blocks(long M);
 int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream);
 int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
