@@ -147,12 +147,12 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
 _zero_cache = {}
 
 
-def _zeros_like_cached(t):
+def _zeros_cached(shape, device):
     """Shared read-only zero tensor (never written): the gradient of a conv bias under train-mode BN."""
-    key = (tuple(t.shape), t.device)
+    key = (tuple(shape), device)
     z = _zero_cache.get(key)
     if z is None:
-        z = torch.zeros_like(t)
+        z = torch.zeros(shape, dtype=torch.float32, device=device)
         _zero_cache[key] = z
     return z
 
@@ -283,7 +283,7 @@ class ConvBnActFn(torch.autograd.Function):
             # a conv bias under train-mode BN has an analytically ZERO gradient (BN removes the channel mean):
             # sum(dz) = -gamma*istd*mean(dy*xhat)*sum(xhat) and sum(xhat) == 0.  The reference's autograd
             # produces fp32 rounding noise (~1e-7) here; we return exact zeros instead of a column-sum pass.
-            db = _zeros_like_cached(bias)
+            db = _zeros_cached((co,), da.device)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
