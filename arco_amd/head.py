@@ -80,6 +80,32 @@ def lazy_head(x3p, f4, fea4_weight, q1_weight, q2_weight, pix):
     return LazyHeadFn.apply(x3p, f4, fea4_weight, q1_weight, q2_weight, pix)
 
 
+def _rows2d_forward(x2p, f3, f4, w3, w4, pix):
+    """Two-level row path: X3 = cat(bilinear(x2p), f3) on the 4 low-res neighbours of each anchor, X3p = fea3(X3)+X3,
+    X4 = cat(4-way lerp of X3p, f4[pix]); returns (X3, X4, nb4, lylx, fea4(X4))."""
+    dev = x2p.device
+    n = int(pix.shape[0])
+    nb, c2, h2, w2_ = (int(v) for v in x2p.shape)
+    c3, h3, w3_ = int(f3.shape[1]), int(f3.shape[2]), int(f3.shape[3])
+    c4, h4, w4_ = int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3])
+    lo2, ld2 = rows_view(x2p)
+    r3, ld3 = rows_view(f3)
+    r4, ld4 = rows_view(f4)
+    nb4 = torch.empty(4 * n, dtype=torch.int64, device=dev)
+    lylx = torch.empty(2 * n, dtype=torch.float32, device=dev)
+    L.call("arco_up_neighbors", L.ptr(pix), n, h3, w3_, h4, w4_, L.ptr(nb4), L.ptr(lylx))
+    k3 = c2 + c3
+    X3 = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
+    L.call("arco_gather_upcat_rows", L.ptr(lo2), ld2, c2, h2, w2_, L.ptr(r3), ld3, c3, h3, w3_, L.ptr(nb4), 4 * n,
+           L.ptr(X3), k3)
+    y3, _ = ops.conv_raw(X3, k3, k3, ops.pack_weight(w3, 1, 0), k3, 1, 1, 4 * n, 1, residual=X3, ld_res=k3)
+    X3p = y3.permute(0, 2, 3, 1).reshape(4 * n, k3)                     # fea3(x)+x rows
+    k4 = k3 + c4
+    X4 = torch.empty((n, k4), dtype=torch.float32, device=dev)
+    L.call("arco_lerp4_cat_rows", L.ptr(X3p), k3, k3, L.ptr(lylx), L.ptr(r4), ld4, c4, L.ptr(pix), n, L.ptr(X4), k4)
+    return X3, X4, nb4, lylx, _gemm(X4, w4)
+
+
 class LazyHead2Fn(torch.autograd.Function):
     """Two-level row-sparse head: also fea3 (the 128x128 level) is evaluated only on the <= 4 low-res
     neighbours of each anchor.  Inputs: x2p = fea2(x)+x [B,448,64,64] (dense), f3 [B,32,128,128],
@@ -88,27 +114,10 @@ class LazyHead2Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2p, f3, f4, w3, w4, w1, w2, pix):
-        dev = x2p.device
-        n = int(pix.shape[0])
         nb, c2, h2, w2_ = (int(v) for v in x2p.shape)
         c3, h3, w3_ = int(f3.shape[1]), int(f3.shape[2]), int(f3.shape[3])
         c4, h4, w4_ = int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3])
-        lo2, ld2 = rows_view(x2p)
-        r3, ld3 = rows_view(f3)
-        r4, ld4 = rows_view(f4)
-        nb4 = torch.empty(4 * n, dtype=torch.int64, device=dev)
-        lylx = torch.empty(2 * n, dtype=torch.float32, device=dev)
-        L.call("arco_up_neighbors", L.ptr(pix), n, h3, w3_, h4, w4_, L.ptr(nb4), L.ptr(lylx))
-        k3 = c2 + c3
-        X3 = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
-        L.call("arco_gather_upcat_rows", L.ptr(lo2), ld2, c2, h2, w2_, L.ptr(r3), ld3, c3, h3, w3_, L.ptr(nb4), 4 * n,
-               L.ptr(X3), k3)
-        y3, _ = ops.conv_raw(X3, k3, k3, ops.pack_weight(w3, 1, 0), k3, 1, 1, 4 * n, 1, residual=X3, ld_res=k3)
-        X3p = y3.permute(0, 2, 3, 1).reshape(4 * n, k3)                     # fea3(x)+x rows
-        k4 = k3 + c4
-        X4 = torch.empty((n, k4), dtype=torch.float32, device=dev)
-        L.call("arco_lerp4_cat_rows", L.ptr(X3p), k3, k3, L.ptr(lylx), L.ptr(r4), ld4, c4, L.ptr(pix), n, L.ptr(X4), k4)
-        h0 = _gemm(X4, w4)
+        X3, X4, nb4, lylx, h0 = _rows2d_forward(x2p, f3, f4, w3, w4, pix)
         h1 = _gemm(h0, w1)
         a = _gemm(h1, w2)
         ctx.save_for_backward(X3, X4, h0, h1, w3, w4, w1, w2, pix, nb4, lylx)
@@ -296,3 +305,40 @@ class LazyTeacher3D:
     @torch.no_grad()
     def rows(self, pix):
         return _rows3d_forward(self.x2p, self.f3, self.f4, self.w3, self.w4, pix)[2]
+
+
+class LazyTeacher2DL2:
+    """Two-level lazy teacher (default of the 2-D step): also fea3 is never evaluated densely.
+    prototype_c = W4 . cat((W3+I) . mean_c(cat(up(x2p), f3)), mean_c(f4)), the class mask being pushed through
+    TWO bilinear adjoints (256^2 -> 128^2 -> 64^2); key rows through the two-level row path."""
+
+    def __init__(self, x2p, f3, f4, w3, w4):
+        self.x2p, self.f3, self.f4, self.w3, self.w4 = x2p, f3, f4, w3, w4
+
+    @torch.no_grad()
+    def prototypes(self, pl):
+        lo, ldlo = rows_view(self.x2p)
+        r3, ld3 = rows_view(self.f3)
+        r4, ld4 = rows_view(self.f4)
+        nb, c2, h2, w2_ = (int(v) for v in self.x2p.shape)
+        c3, h3, w3_ = (int(v) for v in self.f3.shape[1:])
+        c4, h4, w4_ = (int(v) for v in self.f4.shape[1:])
+        C, k3 = pl.C, c2 + c3
+        wm, Cp = _class_weights(pl)
+        w3l = torch.empty((nb * h3 * w3_, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_bilinear_bwd", L.ptr(wm), Cp, nb, h3, w3_, Cp, h4, w4_, L.ptr(w3l), Cp, 0)
+        w2l = torch.empty((nb * h2 * w2_, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_bilinear_bwd", L.ptr(w3l), Cp, nb, h2, w2_, Cp, h3, w3_, L.ptr(w2l), Cp, 0)
+        R = _ceil(C, 16)
+        S3 = torch.zeros((R, k3), dtype=torch.float32, device=pl.dev)
+        _wsum(lo, ldlo, w2l, Cp, nb * h2 * w2_, C, c2, pl.totals, S3, k3)
+        _wsum(r3, ld3, w3l, Cp, nb * h3 * w3_, C, c3, pl.totals, S3[:, c2:], k3)
+        y3, _ = ops.conv_raw(S3, k3, k3, ops.pack_weight(self.w3, 1, 0), k3, 1, 1, R, 1, residual=S3, ld_res=k3)
+        S4 = torch.zeros((R, k3 + c4), dtype=torch.float32, device=pl.dev)
+        S4[:, :k3] = y3.permute(0, 2, 3, 1).reshape(R, k3)
+        _wsum(r4, ld4, wm, Cp, pl.n_pix, C, c4, pl.totals, S4[:, k3:], k3 + c4)
+        return _gemm(S4, self.w4)[:C].contiguous()
+
+    @torch.no_grad()
+    def rows(self, pix):
+        return _rows2d_forward(self.x2p, self.f3, self.f4, self.w3, self.w4, pix)[4]

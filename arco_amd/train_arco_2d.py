@@ -203,9 +203,13 @@ class ArcoStep2D:
             fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
             if getattr(a, "dense_teacher", 0) or dense:
                 rep_all_teacher, lazy_t = self.k_feature_extractor(fm_t), None
-            else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys/class
+            elif getattr(a, "head_levels", 2) == 1:
                 x3p_t, f4_t = self.k_feature_extractor.forward_lowres(fm_t)
                 rep_all_teacher, lazy_t = None, head.LazyTeacher2D(x3p_t, f4_t, self.k_feature_extractor.fea4.weight)
+            else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys/class
+                kfe = self.k_feature_extractor
+                rep_all_teacher = None
+                lazy_t = head.LazyTeacher2DL2(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
         fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]         # :317-318
         if dense:
             rep_all = self.q_rep(self.q_feature_extractor(fm_all))       # :324-325,330
