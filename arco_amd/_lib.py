@@ -60,6 +60,10 @@ _SIGS = {
     "arco_softmax_rows": [_P, _L, _L, _I, _L, _P, _P, _P, _P, _P],
     "arco_label_onehot": [_P, _L, _I, _L, _P, _P],
     "arco_entropy_masks": [_P, _P, _P, _L, _L, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P],
+    "arco_sup_loss_fwd": [_P, _L, _L, _I, _P, _P, _P, _P],
+    "arco_sup_loss_bwd": [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _P],
+    "arco_unsup_loss_fwd": [_P, _L, _I, _L, _I, _P, _P, _F, _P, _P, _P],
+    "arco_unsup_loss_bwd": [_P, _L, _I, _L, _I, _P, _P, _P, _P, _L, _P],
     "arco_sgd_nesterov": [_P, _P, _P, _L, _F, _F, _F, _I, _P],
     "arco_ema": [_P, _P, _L, _F, _P],
 }
@@ -69,6 +73,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
     "arco_chan_stats_blocks": ([_L], _I),
     "arco_sel_state_bytes": ([], _L),
+    "arco_seg_ws_doubles": ([_L, _I, _I], _L),
     # host-side native sampler replay (no GPU work)
     "arco_grid_sample": ([_P, _L, _L, _L, _I, _I, _P], _L),
     "arco_randint": ([_P, _L, _L, _L, _P], _L),

@@ -139,6 +139,149 @@ __global__ __launch_bounds__(256) void entropy_masks_kernel(const float* __restr
   }
 }
 
+// ---- segmentation loss terms on the logits: supervised CE + Dice
+// (train_arco_2d.py:336-339, utils/losses.py:173-209) and the confidence-weighted unsupervised CE
+// (train_arco_2d.py:482-489).  Forward = per-block partial sums (deterministic finalize in fp64);
+// backward = one elementwise pass producing d loss / d logits (channels-last rows).
+//   partial layout per block: [ce_sum, n_px, I_c (C), Z_c (C), Y_c (C)]            (supervised)
+//                             per image: [n_conf, n_valid, sum(CE>0), n(CE>0)]     (unsupervised)
+#define SEG_MAXP (2 + 3 * GL_MAXC)
+__global__ __launch_bounds__(256) void sup_loss_partial_kernel(const float* __restrict__ X, long ld, long M, int C,
+                                                              const int64_t* __restrict__ lab, double* __restrict__ part) {
+  double acc[SEG_MAXP];
+#pragma unroll
+  for (int i = 0; i < SEG_MAXP; ++i) acc[i] = 0.0;
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+    const float* x = X + r * ld;
+    float v[GL_MAXC]; float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < GL_MAXC; ++c) if (c < C) { v[c] = x[c]; mx = fmaxf(mx, v[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < GL_MAXC; ++c) if (c < C) s += expf(v[c] - mx);
+    const float lse = mx + logf(s);
+    const int64_t l = lab[r];
+#pragma unroll
+    for (int c = 0; c < GL_MAXC; ++c) if (c < C) {
+      const float p = expf(v[c] - lse);
+      const float t = (l == c) ? 1.f : 0.f;
+      if (l == c) acc[0] += (double)(lse - v[c]);
+      acc[2 + c] += (double)(p * t); acc[2 + C + c] += (double)(p * p); acc[2 + 2 * C + c] += (double)t;
+    }
+    acc[1] += 1.0;
+  }
+  __shared__ double sh[4][SEG_MAXP];
+  const int np = 2 + 3 * C;
+  for (int i = 0; i < np; ++i) {
+    const double w = wave_sum_d(acc[i]);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][i] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < np) part[(long)blockIdx.x * np + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+// sums[0..np) = sum over blocks; out[0] = CE mean, out[1] = dice
+__global__ void sup_loss_final_kernel(const double* __restrict__ part, int nblk, int C, double* __restrict__ sums, float* __restrict__ out) {
+  const int np = 2 + 3 * C;
+  __shared__ double s[SEG_MAXP];
+  if (threadIdx.x < np) { double a = 0.0; for (int b = 0; b < nblk; ++b) a += part[(long)b * np + threadIdx.x]; s[threadIdx.x] = a; sums[threadIdx.x] = a; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = (float)(s[0] / s[1]);
+    double d = 0.0;
+    for (int c = 0; c < C; ++c) d += 1.0 - (2.0 * s[2 + c] + 1e-5) / (s[2 + C + c] + s[2 + 2 * C + c] + 1e-5);
+    out[1] = (float)(d / C);
+  }
+}
+// dX = g_ce * (p - t)/M + g_dice * softmax-Jacobian^T * dDice/dp
+__global__ __launch_bounds__(256) void sup_loss_bwd_kernel(const float* __restrict__ X, long ld, long M, int C,
+                                                          const int64_t* __restrict__ lab, const double* __restrict__ sums,
+                                                          const float* __restrict__ g_ce, const float* __restrict__ g_dice,
+                                                          float* __restrict__ dX, long ldo) {
+  const float gce = g_ce[0] / (float)M, gd = g_dice[0] / (float)C;
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+    const float* x = X + r * ld;
+    float v[GL_MAXC]; float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < GL_MAXC; ++c) if (c < C) { v[c] = x[c]; mx = fmaxf(mx, v[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < GL_MAXC; ++c) if (c < C) { v[c] = expf(v[c] - mx); s += v[c]; }
+    const int64_t l = lab[r];
+    float dp[GL_MAXC]; float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < GL_MAXC; ++c) if (c < C) {
+      v[c] /= s;
+      const float t = (l == c) ? 1.f : 0.f;
+      const double den = sums[2 + C + c] + sums[2 + 2 * C + c] + 1e-5, num = 2.0 * sums[2 + c] + 1e-5;
+      dp[c] = -gd * (float)((2.0 * t * den - num * 2.0 * v[c]) / (den * den));   // d dice / d p_c
+      dot += dp[c] * v[c];
+    }
+#pragma unroll
+    for (int c = 0; c < GL_MAXC; ++c) if (c < C)
+      dX[r * ldo + c] = gce * (v[c] - ((l == c) ? 1.f : 0.f)) + v[c] * (dp[c] - dot);
+  }
+}
+
+// unsupervised: per-image partials [n_conf, n_valid, sum CE (where CE>0), n (CE>0)]; one block column per image
+__global__ __launch_bounds__(256) void unsup_loss_partial_kernel(const float* __restrict__ X, long ld, long P, int C,
+                                                                const int64_t* __restrict__ lab, const float* __restrict__ conf,
+                                                                float thr, double* __restrict__ part /*[B][gridDim.x][4]*/) {
+  const long img = blockIdx.y;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (long sp = (long)blockIdx.x * 256 + threadIdx.x; sp < P; sp += (long)gridDim.x * 256) {
+    const long r = img * P + sp;
+    const int64_t l = lab[r];
+    a0 += conf[r] >= thr; a1 += l >= 0;
+    if (l >= 0) {
+      const float* x = X + r * ld;
+      float mx = -INFINITY;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[c]);
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) s += expf(x[c] - mx);
+      const float ce = mx + logf(s) - x[l];
+      if (ce > 0.f) { a2 += (double)ce; a3 += 1.0; }
+    }
+  }
+  __shared__ double sh[4][4];
+  double w;
+  w = wave_sum_d(a0); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][0] = w;
+  w = wave_sum_d(a1); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][1] = w;
+  w = wave_sum_d(a2); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][2] = w;
+  w = wave_sum_d(a3); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][3] = w;
+  __syncthreads();
+  if (threadIdx.x < 4) part[(img * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+// per-image weights w_b = n_conf/n_valid; loss = sum_b w_b * S_b / sum_b n_b ; stats[b] = {w_b}, stats[B] = N_sel
+__global__ void unsup_loss_final_kernel(const double* __restrict__ part, int B, int nblk, double* __restrict__ stats, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  double num = 0.0, cnt = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s[4] = {0, 0, 0, 0};
+    for (int k = 0; k < nblk; ++k) for (int i = 0; i < 4; ++i) s[i] += part[((long)b * nblk + k) * 4 + i];
+    const double w = s[0] / s[1];
+    stats[b] = w; num += w * s[2]; cnt += s[3];
+  }
+  stats[B] = cnt;
+  out[0] = (float)(num / cnt);
+}
+__global__ __launch_bounds__(256) void unsup_loss_bwd_kernel(const float* __restrict__ X, long ld, long P, long M, int C,
+                                                            const int64_t* __restrict__ lab, const double* __restrict__ stats, int B,
+                                                            const float* __restrict__ g, float* __restrict__ dX, long ldo) {
+  const float gs = g[0] / (float)stats[B];
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+    const int64_t l = lab[r];
+    const float* x = X + r * ld;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[c] - mx);
+    const float lse = mx + logf(s);
+    const bool sel = l >= 0 && (lse - x[l >= 0 ? l : 0]) > 0.f;
+    const float w = sel ? gs * (float)stats[r / P] : 0.f;
+    for (int c = 0; c < C; ++c) dX[r * ldo + c] = sel ? w * (expf(x[c] - lse) - (l == c ? 1.f : 0.f)) : 0.f;
+  }
+}
+
 static inline int gl_grid(long work) { long g = (work + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
 
 extern "C" {
@@ -153,6 +296,38 @@ int arco_softmax_rows(const float* X, long ld, long M, int C, long P, float* pro
 
 int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, void* stream) {
   hipLaunchKernelGGL(onehot_kernel, dim3(gl_grid(M)), dim3(256), 0, as_stream(stream), lab, M, C, P, out);
+  return arco_launch_status();
+}
+
+// supervised CE + Dice: ws = arco_seg_ws_doubles(...) doubles; out[0] = CE, out[1] = Dice
+long arco_seg_ws_doubles(long M, int C, int B) { return 1024l * (2 + 3 * C) + (2 + 3 * C) + 1024l * 4 * (B > 0 ? B : 1) + B + 1; }
+int arco_sup_loss_fwd(const float* X, long ld, long M, int C, const int64_t* lab, double* ws, float* out, void* stream) {
+  ARCO_CHECK_ARG(C >= 1 && C <= GL_MAXC && M > 0);
+  int nblk = gl_grid(M); if (nblk > 1024) nblk = 1024;
+  double* sums = ws + 1024l * (2 + 3 * C);
+  hipLaunchKernelGGL(sup_loss_partial_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), X, ld, M, C, lab, ws);
+  hipLaunchKernelGGL(sup_loss_final_kernel, dim3(1), dim3(128), 0, as_stream(stream), ws, nblk, C, sums, out);
+  return arco_launch_status();
+}
+int arco_sup_loss_bwd(const float* X, long ld, long M, int C, const int64_t* lab, const double* ws, const float* g_ce,
+                      const float* g_dice, float* dX, long ldo, void* stream) {
+  const double* sums = ws + 1024l * (2 + 3 * C);
+  hipLaunchKernelGGL(sup_loss_bwd_kernel, dim3(gl_grid(M)), dim3(256), 0, as_stream(stream), X, ld, M, C, lab, sums, g_ce, g_dice, dX, ldo);
+  return arco_launch_status();
+}
+// unsupervised weighted CE: B images of P pixels; ws >= 64*4*B + B + 1 doubles; out[0] = loss
+int arco_unsup_loss_fwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const float* conf, float thr,
+                        double* ws, float* out, void* stream) {
+  ARCO_CHECK_ARG(C >= 1 && C <= GL_MAXC && B > 0 && P > 0);
+  const int nblk = 64;
+  hipLaunchKernelGGL(unsup_loss_partial_kernel, dim3(nblk, B), dim3(256), 0, as_stream(stream), X, ld, P, C, lab, conf, thr, ws);
+  hipLaunchKernelGGL(unsup_loss_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), ws, B, nblk, ws + (long)nblk * 4 * B, out);
+  return arco_launch_status();
+}
+int arco_unsup_loss_bwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const double* ws, const float* g,
+                        float* dX, long ldo, void* stream) {
+  hipLaunchKernelGGL(unsup_loss_bwd_kernel, dim3(gl_grid((long)B * P)), dim3(256), 0, as_stream(stream), X, ld, P, (long)B * P, C,
+                     lab, ws + 64l * 4 * B, B, g, dX, ldo);
   return arco_launch_status();
 }
 

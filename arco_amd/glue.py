@@ -65,3 +65,55 @@ def entropy_masks(pred_u, label_l_raw, label_u_raw, alpha_t):
     L.call("arco_entropy_masks", L.ptr(ent), L.ptr(ll), L.ptr(lu), n_l, n_u, float(alpha_t), float(100 - alpha_t),
            L.ptr(state), L.ptr(low), L.ptr(high))
     return low, high
+
+
+class _SupLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, label):
+        r, ld, b, C, P = _geom(pred)
+        lab = label.to(torch.int64).contiguous()
+        ws = torch.empty(L.query("arco_seg_ws_doubles", b * P, C, b), dtype=torch.float64, device=pred.device)
+        out = torch.empty(2, dtype=torch.float32, device=pred.device)
+        L.call("arco_sup_loss_fwd", L.ptr(r), ld, b * P, C, L.ptr(lab), L.ptr(ws), L.ptr(out))
+        ctx.save_for_backward(pred, lab, ws)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_ce, g_dice):
+        pred, lab, ws = ctx.saved_tensors
+        r, ld, b, C, P = _geom(pred)
+        dx = torch.empty((b, *pred.shape[2:], C), dtype=torch.float32, device=pred.device)
+        L.call("arco_sup_loss_bwd", L.ptr(r), ld, b * P, C, L.ptr(lab), L.ptr(ws), L.ptr(g_ce.contiguous().float()),
+               L.ptr(g_dice.contiguous().float()), L.ptr(dx), C)
+        return dx.movedim(-1, 1), None
+
+
+def supervised_loss(pred_l, label):
+    """(CrossEntropyLoss()(pred_l, label), DiceLoss(C)(softmax(pred_l), label)) of train_arco_2d.py:336-339."""
+    return _SupLossFn.apply(pred_l, label)
+
+
+class _UnsupLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, conf, thr):
+        r, ld, b, C, P = _geom(pred)
+        lab = target.to(torch.int64).contiguous()
+        cf = conf.to(torch.float32).contiguous()
+        ws = torch.empty(64 * 4 * b + b + 1, dtype=torch.float64, device=pred.device)
+        out = torch.empty(1, dtype=torch.float32, device=pred.device)
+        L.call("arco_unsup_loss_fwd", L.ptr(r), ld, b, P, C, L.ptr(lab), L.ptr(cf), float(thr), L.ptr(ws), L.ptr(out))
+        ctx.save_for_backward(pred, lab, ws)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, lab, ws = ctx.saved_tensors
+        r, ld, b, C, P = _geom(pred)
+        dx = torch.empty((b, *pred.shape[2:], C), dtype=torch.float32, device=pred.device)
+        L.call("arco_unsup_loss_bwd", L.ptr(r), ld, b, P, C, L.ptr(lab), L.ptr(ws), L.ptr(g.contiguous().float()), L.ptr(dx), C)
+        return dx.movedim(-1, 1), None, None, None
+
+
+def compute_unsupervised_loss(predict, target, logits, strong_threshold):
+    """train_arco_2d.py:482-489 (same name and arguments)."""
+    return _UnsupLossFn.apply(predict, target, logits, strong_threshold)

@@ -10,8 +10,8 @@ The step itself (train_arco_2d.py:284-435) is `ArcoStep2D.step`: hot path (SURVE
 N1-N5, T1, L1-L6, O1) on hand-written HIP kernels.  One process per GPU; with WORLD_SIZE>1
 gradients are all-reduced and new negative keys all-gathered over RCCL (arco_amd/dist.py).
 Not built here (SURVEY §8 "next"/out of scope): dataset readers, CPU augmentation
-(identity on the synthetic path), the TPS equivariance / revisiting / supervised
-CE+Dice / unsupervised-CE loss terms.
+(identity on the synthetic path), the TPS equivariance and revisiting loss terms (the supervised CE+Dice
+and the unsupervised CE terms ARE part of the step).
 """
 import argparse
 import logging
@@ -239,7 +239,11 @@ class ArcoStep2D:
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)   # :394-398 (temp default)
         ev2[1].record()
         self.loss_events.append((ev, ev2))
-        loss = a.k1 * reco_loss                                          # :426 (hot-path term)
+        # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340).  Not built:
+        # k2*loss_eqv (RandTPS) and k4*loss_q (revisiting loss; it has no gradient path to any parameter).
+        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)
+        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
+        loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()
         adist.allreduce_grads(self.optimizer)
@@ -249,6 +253,7 @@ class ArcoStep2D:
         for g in self.optimizer.param_groups:
             g['lr'] = lr_
         self.iter_num += 1
+        self.last_terms = dict(ce=loss_ce, dice=loss_dice, unsup=unsup_loss, reco=reco_loss)
         return loss, reco_loss
 
 

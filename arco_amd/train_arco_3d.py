@@ -85,7 +85,7 @@ class ArcoStep3D:
         with torch.no_grad():                                            # :260-262
             pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
-        u_aug, u_aug_label = u_data, pseudo_labels                       # :268-278 (identity transforms)
+        u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits   # :268-278 (identity transforms)
         self.k_fe_ema.update(0.99)                                      # :279-281
         pred_u, _, u_fm = self.model(u_aug)                              # :284
         with torch.no_grad():
@@ -124,7 +124,9 @@ class ArcoStep3D:
             A_all = head.lazy_head3d(x2p, f3, f4, qfe.fea3.weight, qfe.fea4.weight, self.q_representation[0].weight,
                                      self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
-        loss = a.k1 * reco_loss
+        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
+        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
+        loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q: no gradient path, not built)
         self.optimizer.zero_grad()
         loss.backward()
         adist.allreduce_grads(self.optimizer)

@@ -149,6 +149,16 @@ int arco_ema(float* k, const float* q, long n, float m, void* stream);
 int arco_softmax_rows(const float* X, long ld, long M, int C, long P, float* prob_planes, float* maxp, int64_t* amax,
                       float* entropy, void* stream);
 int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, void* stream);
+/* ---- §8f row 1: supervised CrossEntropy + Dice (train_arco_2d.py:336-339, utils/losses.py:173-209) and the
+ *      confidence-weighted unsupervised CE (train_arco_2d.py:482-489) on channels-last logits             */
+long arco_seg_ws_doubles(long M, int C, int B);
+int arco_sup_loss_fwd(const float* X, long ld, long M, int C, const int64_t* lab, double* ws, float* out, void* stream);
+int arco_sup_loss_bwd(const float* X, long ld, long M, int C, const int64_t* lab, const double* ws, const float* g_ce,
+                      const float* g_dice, float* dX, long ldo, void* stream);
+int arco_unsup_loss_fwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const float* conf, float thr,
+                        double* ws, float* out, void* stream);
+int arco_unsup_loss_bwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const double* ws, const float* g,
+                        float* dX, long ldo, void* stream);
 long arco_sel_state_bytes();
 /* exact np.percentile(entropy[valid], q) (linear) by device radix select -> low/high masks              */
 int arco_entropy_masks(const float* ent, const int64_t* lab_l, const int64_t* lab_u, long n_l, long n_u, double q_lo,

@@ -371,6 +371,19 @@ def compute_unsupervised_loss(predict, target, logits, strong_threshold):
     return torch.mean(torch.masked_select(w, ce > 0))
 
 
+def supervised_loss(pred_l, label, n_cls):
+    """CrossEntropyLoss + DiceLoss(softmax(pred)) of train_arco_2d.py:336-339 (utils/losses.py:173-209):
+    dice = 1/C sum_c (1 - (2 sum(p_c t_c) + s) / (sum p_c^2 + sum t_c^2 + s)), s = 1e-5."""
+    ce = F.cross_entropy(pred_l, label.long())
+    p = torch.softmax(pred_l, dim=1)
+    dice = 0.0
+    for c in range(n_cls):
+        t = (label == c).float()
+        inter, z, y = (p[:, c] * t).sum(), (p[:, c] * p[:, c]).sum(), (t * t).sum()
+        dice = dice + (1 - (2 * inter + 1e-5) / (z + y + 1e-5))
+    return ce, dice / n_cls
+
+
 def entropy_masks(pred_u, label_l_raw, label_u_raw, alpha_t):
     """Entropy-percentile masks, train_arco_2d.py:352-393 (F.interpolate to the same
     size is the identity and is omitted).  Returns (low_mask_all, high_mask_all, entropy)."""

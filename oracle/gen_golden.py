@@ -286,6 +286,22 @@ def gen_glue():
         out[t + "thr"] = np.array([env["low_thresh"], env["high_thresh"]], dtype=np.float64)
         out[t + "label_l"] = env["label_l"].numpy(); out[t + "label_u"] = env["label_u"].numpy()
         out[t + "alpha"] = np.array(env["alpha_t"])
+    # supervised CE + Dice (train_arco_2d.py:336-339; utils/losses.py:173-209) with gradients w.r.t. the logits
+    import importlib
+    losses_mod = importlib.import_module("utils.losses")
+    dice_loss = losses_mod.DiceLoss(C)
+    pl_ = pred_l.clone().requires_grad_(True)
+    lab_pos = lab_l.clone()
+    ce = torch.nn.CrossEntropyLoss()(pl_, lab_pos.long())
+    dice = dice_loss(torch.softmax(pl_, dim=1), lab_pos.unsqueeze(1))
+    (ce + dice).backward()
+    out["sup_ce"] = np.array(ce.item()); out["sup_dice"] = np.array(dice.item()); out["sup_grad"] = pl_.grad.numpy().copy()
+    pu_ = pred_u.clone().requires_grad_(True)
+    ul = ns["compute_unsupervised_loss"](pu_, lab_u, logits_u, 0.97)
+    ul.backward()
+    out["unsup_grad"] = pu_.grad.numpy().copy()
+    ul2 = ns["compute_unsupervised_loss"](pred_u, lab_u, logits_u, 0.5)
+    out["unsup_loss_t05"] = np.array(ul2.item())
     # revisiting loss + pool enqueue (train_arco_2d.py:108-136)
     K, feat = 6, 3 * 8 * 8
     pool = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((K, feat)).astype(np.float32)), dim=1)

@@ -74,3 +74,28 @@ def test_softmax_and_pseudo_labels():
         rm, ra = torch.max(torch.softmax(pred, 1), 1)
         np.testing.assert_allclose(mp.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-7)
         np.testing.assert_array_equal(am.cpu().numpy(), ra.numpy())
+
+
+def test_supervised_and_unsup_losses_vs_reference(golden):
+    from arco_amd import glue
+    g = golden["g4_glue"]
+    pred_l, pred_u, lab_l, lab_u, C = _inputs()
+    rs = np.random.RandomState(77)
+    for _ in range(2):
+        rs.standard_normal((2, 4, 24, 20))
+    fx.blob_labels(rs, 2, (24, 20), 4); fx.blob_labels(rs, 2, (24, 20), 4)
+    logits_u = torch.from_numpy(rs.uniform(0.3, 1.0, size=(2, 24, 20)).astype(np.float32))
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        pl_ = pred_l.cuda().contiguous(memory_format=fmt).requires_grad_(True)
+        ce, dice = glue.supervised_loss(pl_, lab_l.cuda())
+        (ce + dice).backward()
+        np.testing.assert_allclose(ce.item(), float(g["sup_ce"]), rtol=1e-5)
+        np.testing.assert_allclose(dice.item(), float(g["sup_dice"]), rtol=1e-5)
+        np.testing.assert_allclose(pl_.grad.cpu().numpy(), g["sup_grad"], rtol=1e-4, atol=1e-8)
+        pu_ = pred_u.cuda().contiguous(memory_format=fmt).requires_grad_(True)
+        ul = glue.compute_unsupervised_loss(pu_, lab_u.cuda(), logits_u.cuda(), 0.97)
+        ul.backward()
+        np.testing.assert_allclose(ul.item(), float(g["unsup_loss"]), rtol=1e-5)
+        np.testing.assert_allclose(pu_.grad.cpu().numpy(), g["unsup_grad"], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(glue.compute_unsupervised_loss(pu_, lab_u.cuda(), logits_u.cuda(), 0.5).item(),
+                                   float(g["unsup_loss_t05"]), rtol=1e-5)

@@ -162,6 +162,16 @@ def test_trainer_glue(golden):
     np.testing.assert_array_equal(orc.label_onehot(lab_u, C).numpy(), g["onehot_u"])
     np.testing.assert_allclose(orc.compute_unsupervised_loss(pred_u, lab_u, logits_u, 0.97).item(),
                                float(g["unsup_loss"]), rtol=1e-6)
+    pl_ = pred_l.clone().requires_grad_(True)
+    ce, dice = orc.supervised_loss(pl_, lab_l, C)
+    (ce + dice).backward()
+    np.testing.assert_allclose(ce.item(), float(g["sup_ce"]), rtol=1e-6)
+    np.testing.assert_allclose(dice.item(), float(g["sup_dice"]), rtol=1e-6)
+    np.testing.assert_allclose(pl_.grad.numpy(), g["sup_grad"], rtol=1e-5, atol=1e-9)
+    pu_ = pred_u.clone().requires_grad_(True)
+    orc.compute_unsupervised_loss(pu_, lab_u, logits_u, 0.97).backward()
+    np.testing.assert_allclose(pu_.grad.numpy(), g["unsup_grad"], rtol=1e-5, atol=1e-10)
+    np.testing.assert_allclose(orc.compute_unsupervised_loss(pred_u, lab_u, logits_u, 0.5).item(), float(g["unsup_loss_t05"]), rtol=1e-6)
     for epoch, max_epoch in ((0, 10), (3, 10)):
         alpha = 20 * (1 - epoch / max_epoch)
         assert alpha == float(g[f"mask_e{epoch}_alpha"])
