@@ -7,7 +7,8 @@ Workload = BASELINE.json configs[1]: ACDC-shaped 2-D 256x256, --batch_size 8 per
 (16 images/step/GPU), C=4, D=496, stratified sampler (smc) + 4096-key/class queue, nq=256,
 nn=512, temp 0.5; synthetic data and random-init weights resident in HBM before timing.
 A step = SURVEY §8a rows N1-N5, T1, L1-L6, O1 (U-Net x6 forwards incl. teacher, FeatureExtractor,
-q_representation, masks, sampler, bank, InfoNCE, backward, SGD-Nesterov, EMA).  Weak scaling:
+q_representation, masks, sampler, bank, InfoNCE, backward, SGD-Nesterov, EMA) plus the supervised CE+Dice and
+unsupervised CE terms of §8f row 1.  Weak scaling:
 per-GPU work is fixed; value = N*K 16-image steps / wall time.
 """
 import argparse

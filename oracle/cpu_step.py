@@ -45,7 +45,9 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
         pl, pu = torch.softmax(pred_l_t, 1), torch.softmax(pred_u_t, 1)
     _, reco = orc.compute_contra_memobank_loss(rep, label_l, label_u, pl, pu, low, high, memobank, ptrs, qsize, rep_t,
                                                delta_n=delta_n, func=func, num_queries=nq, num_negatives=nn_)
-    loss = k1 * reco
+    ce, dice = orc.supervised_loss(pred_l, l_label, n_cls)
+    unsup = orc.compute_unsupervised_loss(pred_u, pseudo_labels, pseudo_logits, 0.97)
+    loss = k1 * reco + unsup + (ce + dice)
     leaves = [v for v in st["student"].values() if v.requires_grad] + list(st["q_rep"]) + list(st["q_fe"].values())
     grads = torch.autograd.grad(loss, leaves, allow_unused=True)
     with torch.no_grad():
