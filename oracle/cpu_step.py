@@ -60,6 +60,7 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
             if v.requires_grad:
                 st["teacher"][k] = st["teacher"][k] * 0.99 + v.detach() * 0.01
     st["it"] += 1
+    st["last_terms"] = dict(ce=float(ce), dice=float(dice), unsup=float(unsup), reco=float(reco))
     return float(loss), float(reco)
 
 

@@ -1,0 +1,82 @@
+"""Whole training step on the HIP path vs the CPU oracle step (oracle/cpu_step.py): same weights, same CPU-generator
+seed, dropout off, two chained steps.  Checks every loss term, the banks and the updated student/teacher weights (-m gpu)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_step
+import fixture_inputs as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def _drop_off(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+
+
+@pytest.mark.parametrize("variant", [dict(dense_head=1), dict(dense_head=0, head_levels=2, dense_teacher=0)])
+def test_two_steps_vs_cpu_oracle(variant):
+    from arco_amd import train_arco_2d as T
+    b, patch, C, Q, Nn, qs = 2, (64, 64), 4, 64, 32, 300
+    unet_sd, fe_sd = fx.unet_state(21, 1, C), fx.fe_state(31)
+    qrep_w = [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]]
+    argv = ["--batch_size", str(b), "--queue_size", str(qs), "--synthetic", "1", "--num_queries", str(Q),
+            "--num_negatives", str(Nn), "--k1", "1.0", "--base_lr", "0.01", "--graphs", "0"]
+    for k, v in variant.items():
+        argv += [f"--{k}", str(v)]
+    args = T.build_parser().parse_args(argv)
+    args.patch_size = list(patch)
+    st_g = T.ArcoStep2D(args, "cuda:0")
+    st_g.model.load_state_dict(unet_sd, strict=True)
+    st_g.ema_model.load_state_dict(unet_sd, strict=True)
+    st_g.q_feature_extractor.load_state_dict(fe_sd, strict=True)
+    st_g.k_feature_extractor.load_state_dict(fe_sd, strict=True)
+    with torch.no_grad():
+        st_g.q_representation[0].weight.copy_(qrep_w[0])
+        st_g.q_representation[1].weight.copy_(qrep_w[1])
+    for m in (st_g.model, st_g.ema_model):
+        _drop_off(m)
+    st_o = cpu_step.make_state(unet_sd, fe_sd, qrep_w)
+    bank_o, ptr_o, qsz = fx.fresh_bank(C, 496, qs, 'zeros')
+    rs = np.random.RandomState(3)
+    for it in range(2):
+        l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
+        random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
+        cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn)
+        random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
+        st_g.step(l.cuda(), lab.cuda(), u.cuda())
+        to, tg = st_o["last_terms"], st_g.last_terms
+        for k in ("ce", "dice", "unsup", "reco"):
+            np.testing.assert_allclose(float(tg[k]), to[k], rtol=2e-3, atol=1e-5, err_msg=f"step {it} {k}")
+        for bo, bg in zip(bank_o, st_g.memobank):
+            assert bo[0].shape == bg[0].shape
+            np.testing.assert_allclose(bg[0].cpu().numpy(), bo[0].numpy(), rtol=2e-3, atol=2e-4)
+        assert [int(p) for p in ptr_o] == [int(p) for p in st_g.queue_ptrlis]
+    # updated weights: student U-Net (by name), heads, teacher
+    sd_g = st_g.model.state_dict()
+    worst = 0.0
+    for k, v in st_o["student"].items():
+        if not v.requires_grad:
+            continue
+        ref = v.detach()
+        err = float((sd_g[k].cpu() - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
+        worst = max(worst, err)
+    assert worst < 2e-3, worst
+    for k, v in st_o["q_fe"].items():
+        ref = v.detach()
+        got = st_g.q_feature_extractor.state_dict()[k].cpu()
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 2e-3, k
+    for i in range(2):
+        ref = st_o["q_rep"][i].detach()
+        got = st_g.q_representation[i].weight.detach().cpu()
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 2e-3
+    sd_t = st_g.ema_model.state_dict()
+    for k, v in st_o["teacher"].items():
+        if v.is_floating_point() and "running" not in k:
+            assert float((sd_t[k].cpu() - v).abs().max()) / max(1e-6, float(v.abs().max())) < 2e-3, k
