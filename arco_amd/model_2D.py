@@ -58,8 +58,9 @@ class FeatureExtractor(nn.Module):
         return ops.conv(x, self.fea4.weight, None, residual=False)         # fea4(x)
 
 
-def create_model(ema=False, num_classes=4, train_encoder=True, train_decoder=True):
-    model = net_factory(net_type='unet', in_chns=1, class_num=num_classes, train_encoder=train_encoder,
+def create_model(ema=False, num_classes=4, train_encoder=True, train_decoder=True, in_chns=1):
+    """model_2D.py:57-64 (the reference hard-codes in_chns=1; `in_chns` is an extension for RGB inputs)."""
+    model = net_factory(net_type='unet', in_chns=in_chns, class_num=num_classes, train_encoder=train_encoder,
                         train_decoder=train_decoder)
     if ema:
         for param in model.parameters():
@@ -88,14 +89,16 @@ class MLP(nn.Module):
 
 class ISD(nn.Module):
     def __init__(self, K=48, m=0.99, Ts=0.1, Tt=0.01, num_classes=4, train_encoder=True, train_decoder=True,
-                 latent_pooling_size=1, latent_feature_size=256, output_pooling_size=16, patch_size=64):
+                 latent_pooling_size=1, latent_feature_size=256, output_pooling_size=16, patch_size=64, in_chns=1):
         super(ISD, self).__init__()
         self.K, self.m, self.Ts, self.Tt = K, m, Ts, Tt
         self.num_classes = num_classes
         self.patch_size = patch_size
         self.latent_feature_size = latent_feature_size
-        self.model = create_model(num_classes=num_classes, train_encoder=train_encoder, train_decoder=train_decoder)
-        self.ema_model = create_model(ema=True, num_classes=num_classes, train_encoder=False, train_decoder=False)
+        self.model = create_model(num_classes=num_classes, train_encoder=train_encoder, train_decoder=train_decoder,
+                                  in_chns=in_chns)
+        self.ema_model = create_model(ema=True, num_classes=num_classes, train_encoder=False, train_decoder=False,
+                                      in_chns=in_chns)
         self.k_latent_head = MLP(256, self.latent_feature_size, latent_pooling_size)
         self.q_latent_head = MLP(256, self.latent_feature_size, latent_pooling_size)
         self.latent_predictor = nn.Sequential(nn.Linear(self.latent_feature_size, self.latent_feature_size),

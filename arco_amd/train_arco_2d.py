@@ -126,9 +126,8 @@ class ArcoStep2D:
             self.queue_size[0] = 50000
         self.isd = ISD(K=args.K, m=0.99, Ts=0.01, Tt=0.1, num_classes=C,
                        latent_pooling_size=args.latent_pooling_size, latent_feature_size=args.latent_feature_size,
-                       output_pooling_size=args.output_pooling_size, train_encoder=True, train_decoder=True)
-        if args.in_chns != 1:
-            raise NotImplementedError("create_model builds in_chns=1 like the reference (model_2D.py:59)")
+                       output_pooling_size=args.output_pooling_size, train_encoder=True, train_decoder=True,
+                       in_chns=args.in_chns)
         self.isd = self.isd.to(self.dev)
         self.model, self.ema_model = self.isd.model, self.isd.ema_model
         self.q_representation = nn.Sequential(nn.Conv2d(REP_DIM, REP_DIM, kernel_size=1, bias=False),
@@ -257,10 +256,10 @@ class ArcoStep2D:
         return loss, reco_loss
 
 
-def synthetic_batch(b, patch, n_cls, seed, device):
+def synthetic_batch(b, patch, n_cls, seed, device, in_chns=1):
     """ACDC-shaped synthetic batch: images U[0,1), blob labels with ACDC-like imbalance."""
     rs = np.random.RandomState(seed)
-    img = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+    img = torch.from_numpy(rs.uniform(size=(b, in_chns, *patch)).astype(np.float32))
     lab = np.zeros((b, *patch), dtype=np.int64)
     yy, xx = np.mgrid[0:patch[0], 0:patch[1]]
     for i in range(b):

@@ -80,3 +80,19 @@ def test_two_steps_vs_cpu_oracle(variant):
     for k, v in st_o["teacher"].items():
         if v.is_floating_point() and "running" not in k:
             assert float((sd_t[k].cpu() - v).abs().max()) / max(1e-6, float(v.abs().max())) < 2e-3, k
+
+
+def test_cityscapes_shaped_step_runs():
+    """BASELINE config 4 shape at reduced size: RGB input, 19 classes, non-square image; 3 steps, finite, banks fill."""
+    from arco_amd import train_arco_2d as T
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    args = T.build_parser().parse_args(["--batch_size", "2", "--queue_size", "128", "--synthetic", "1", "--num_classes", "19",
+                                        "--in_chns", "3", "--num_queries", "32", "--num_negatives", "16", "--k1", "1.0"])
+    args.patch_size = [32, 64]
+    st = T.ArcoStep2D(args, "cuda:0")
+    for i in range(3):
+        l_img, l_lab = T.synthetic_batch(2, args.patch_size, 19, 5 + i, "cuda:0", in_chns=3)
+        u_img, _ = T.synthetic_batch(2, args.patch_size, 19, 50 + i, "cuda:0", in_chns=3)
+        loss, reco = st.step(l_img, l_lab, u_img)
+        assert torch.isfinite(loss).item()
+    assert len(st.memobank) == 19 and all(b[0].shape[1] == 496 for b in st.memobank)
