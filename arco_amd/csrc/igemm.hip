@@ -285,7 +285,30 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) 
   return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, false, DEPTH>(a, st, n_mblocks_out);
 }
 
-// config choice shared by the launch and the "how many M-blocks" query
+// config choice shared by the launch and the "how many M-blocks" query.
+// Spatial convs: prefer the largest tile that still gives >= 2 workgroups per CU (512 blocks); the mid/deep
+// U-Net / V-Net levels have few pixels, and one 4-wave block per CU leaves the matrix pipe half idle.
+static long conv_blocks(const IgemmArgs& a, int bm, int bn) {
+  const int th = bm / 16;
+  return (long)a.NB * ((a.H + th - 1) / th) * ((a.W + 15) / 16) * ((a.Npad + bn - 1) / bn);
+}
+template <int DEPTH>
+static int dispatch_spatial(const IgemmArgs& a, hipStream_t st, int* nmb) {
+  const long want = 512;
+  if (a.Npad <= 16) {
+    if (DEPTH == 1 && conv_blocks(a, 256, 16) >= want) return launch_igemm<9, 256, 16, 4, 1, 16, false, DEPTH>(a, st, nmb);
+    if (conv_blocks(a, 128, 16) >= want || DEPTH == 3) return launch_igemm<9, 128, 16, 4, 1, 16, false, DEPTH>(a, st, nmb);
+    return launch_igemm<9, 64, 16, 4, 1, 16, false, DEPTH>(a, st, nmb);
+  }
+  if (a.Npad <= 32) {
+    if (conv_blocks(a, 128, 32) >= want) return launch_igemm<9, 128, 32, 4, 1, 16, false, DEPTH>(a, st, nmb);
+    return launch_igemm<9, 64, 32, 2, 2, 16, false, DEPTH>(a, st, nmb);
+  }
+  if (conv_blocks(a, 128, 64) >= want) return launch_igemm<9, 128, 64, 4, 1, 16, false, DEPTH>(a, st, nmb);
+  if (conv_blocks(a, 64, 64) >= want) return launch_igemm<9, 64, 64, 2, 2, 16, false, DEPTH>(a, st, nmb);
+  if (conv_blocks(a, 64, 32) >= want) return launch_igemm<9, 64, 32, 2, 2, 16, false, DEPTH>(a, st, nmb);
+  return launch_igemm<9, 32, 32, 2, 2, 16, false, DEPTH>(a, st, nmb);
+}
 static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb) {
   if (taps == 1) {
     if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16, true>(a, st, nmb);
@@ -293,18 +316,8 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
     if (a.M * (long)a.Npad <= 4096l * 1024) return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
     return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
   }
-  if (taps == 27) {   // 3x3x3: planes of H x W, depth taps looped inside the kernel
-    if (a.Npad <= 16) return launch_igemm<9, 128, 16, 4, 1, 16, false, 3>(a, st, nmb);
-    if (a.Npad <= 32) return launch_igemm<9, 128, 32, 4, 1, 16, false, 3>(a, st, nmb);
-    if ((long)a.NB * a.H * a.W <= 32768) return launch_igemm<9, 64, 64, 2, 2, 16, false, 3>(a, st, nmb);
-    return launch_igemm<9, 128, 64, 4, 1, 16, false, 3>(a, st, nmb);
-  }
-  if (taps == 9) {
-    if (a.Npad <= 16) return launch_igemm<9, 256, 16, 4, 1, 16, false>(a, st, nmb);
-    if (a.Npad <= 32) return launch_igemm<9, 128, 32, 4, 1, 16, false>(a, st, nmb);
-    if ((long)a.NB * a.H * a.W <= 16384) return launch_igemm<9, 64, 64, 2, 2, 16, false>(a, st, nmb);
-    return launch_igemm<9, 128, 64, 4, 1, 16, false>(a, st, nmb);
-  }
+  if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
+  if (taps == 9) return dispatch_spatial<1>(a, st, nmb);
   return ARCO_ERR_UNSUPPORTED;
 }
 
