@@ -263,7 +263,12 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   int mblocks;
   if (TAPS == 9) mblocks = a.NB * ((a.H + TH - 1) / TH) * ((a.W + 15) / 16);
   else mblocks = (int)((a.M + BM - 1) / BM);
-  if (n_mblocks_out) { *n_mblocks_out = mblocks; return ARCO_OK; }
+  if (n_mblocks_out) {
+    n_mblocks_out[0] = mblocks;
+    n_mblocks_out[1] = TAPS * 1000000 + BM * 1000 + BN;        // instantiation id (query only)
+    n_mblocks_out[2] = KC * 100 + DEPTH * 10 + (DB ? 1 : 0);
+    return ARCO_OK;
+  }
   size_t sh = (size_t)(DB ? 2 : 1) * (AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
@@ -657,9 +662,21 @@ int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout) {
   IgemmArgs a{};
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
   a.N = Cout; a.Npad = (Cout + 15) / 16 * 16;
-  int nmb = 0;
-  if (dispatch_igemm(a, taps, nullptr, &nmb) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
-  return nmb;
+  int q[3] = {0, 0, 0};
+  if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
+  return q[0];
+}
+
+// which igemm_kernel<TAPS,BM,BN,..> instantiation a launch uses: returns TAPS*1e6 + BM*1e3 + BN (kernel-tap form:
+// 9 for both 3x3 and 3x3x3); *kc_depth_db = KC*100 + DEPTH*10 + DB
+int arco_conv_config(int taps, int NB, int H, int W, int Cout, int* kc_depth_db) {
+  IgemmArgs a{};
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16;
+  int q[3] = {0, 0, 0};
+  if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
+  if (kc_depth_db) *kc_depth_db = q[2];
+  return q[1];
 }
 
 int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream) {

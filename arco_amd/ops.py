@@ -130,7 +130,8 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
            L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w)
     if PROFILE is not None:
         ev[1].record()
-        PROFILE.setdefault((taps, nb * d3 * h * w, n, k), []).append(ev)
+        cfg = L.query("arco_conv_config", taps, nb * d3, h, w, n, None)        # igemm_kernel<TAPS,BM,BN,..> instantiation
+        PROFILE.setdefault(cfg, []).append((ev[0], ev[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
     return out, (ssum, ssq, nmb)
 
 

@@ -120,22 +120,33 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        # dominant kernel: the 496x496 1x1-conv GEMM at full resolution (igemm_kernel<1,128,128,...>)
-        key = max(prof, key=lambda k: sum(s.elapsed_time(e) for s, e in prof[k])) if prof else None
+        # dominant kernel = the igemm_kernel<TAPS,BM,BN,...> instantiation with the largest total time in the
+        # timed region (one row of rocprofv3's kernel stats); achieved = its algorithmic FLOP per launch / its
+        # average launch duration, both averaged over its launches (HIP events on the launch stream).
         roof = None
-        if key is not None:
-            taps, m, n, k = key
-            ms = [s.elapsed_time(e) for s, e in prof[key]]
-            avg_ms = sum(ms) / len(ms)
-            flop = 2.0 * m * n * k * taps
-            ach = flop / (avg_ms * 1e-3) / 1e12
+        if prof:
+            tot = {c: sum(s_.elapsed_time(e_) for s_, e_, _, _ in v) for c, v in prof.items()}
+            cfg = max(tot, key=tot.get)
+            launches = prof[cfg]
+            avg_ms = tot[cfg] / len(launches)
+            avg_flop = sum(f for _, _, f, _ in launches) / len(launches)
+            ach = avg_flop / (avg_ms * 1e-3) / 1e12
+            shapes = {}
+            for s_, e_, f, shp in launches:
+                d_ = shapes.setdefault(shp, [0, 0.0, f]); d_[0] += 1; d_[1] += s_.elapsed_time(e_)
+            top = max(shapes.items(), key=lambda kv: kv[1][1])
+            (taps, m, n, k), (cnt, ms_sum, f) = top
+            fam_ms = sum(tot.values()); fam_flop = sum(f_ for v in prof.values() for _, _, f_, _ in v)
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get((m, n, k)),
-                    "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_gemm_traffic.md)",
-                    "algorithmic_bytes": 4.0 * (m * k + n * k + m * n),
-                    "kernel": f"igemm_kernel 1x1 conv M={m} N={n} K={k} (fp32 MFMA 16x16x4)",
-                    "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
-                    "share_of_step": round(sum(ms) / (dt * 1e3), 4)}
+                    "kernel": f"igemm_kernel<{cfg // 1000000},{cfg // 1000 % 1000},{cfg % 1000},...> (fp32 MFMA 16x16x4 implicit GEMM)",
+                    "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(launches),
+                    "avg_flop_per_launch": avg_flop, "share_of_step": round(tot[cfg] / (dt * 1e3), 4),
+                    "largest_shape": {"taps": taps, "M": m, "N": n, "K": k, "launches": cnt,
+                                      "tflops": round(f / (ms_sum / cnt * 1e-3) / 1e12, 2)},
+                    "igemm_family": {"tflops": round(fam_flop / (fam_ms * 1e-3) / 1e12, 2),
+                                     "share_of_step": round(fam_ms / (dt * 1e3), 4),
+                                     "flop_per_step": fam_flop / a.steps}}
         out = {
             "metric": "train steps/sec, ACDC 2D 256x256 bs=16 (hot-path step)", "value": round(world * a.steps / dt, 4),
             "unit": "steps/s (16-image steps, all GPUs)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -70,6 +70,7 @@ int arco_sum_scale(const float* x, int n, float scale, float* out, int accumulat
  *      model_2D.py:25-33; train_arco_2d.py:231-234).  Wp = packed weights [taps][ceil16(N)][ceil16(K)].    */
 int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream);
 int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout);
+int arco_conv_config(int taps, int NB, int H, int W, int Cout, int* kc_depth_db);   /* which igemm instantiation */
 /* out = conv(in) (+bias)(+residual); optional per-channel (sum, sumsq) block partials for train-mode BN. */
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
