@@ -30,6 +30,7 @@ _SIGS = {
     "arco_scatter_add_rows": [_P, _L, _I, _P, _P, _L, _P, _F, _P, _L, _P],
     "arco_sum_scale": [_P, _I, _F, _P, _I, _P],
     "arco_pack_conv_weight": [_P, _I, _I, _I, _I, _P, _P],
+    "arco_pack_many": [_P, _I, _L, _P],
     "arco_conv_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     "arco_conv_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "arco_colsum": [_P, _L, _L, _I, _P, _P, _I, _P],
@@ -74,6 +75,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
     "arco_chan_stats_blocks": ([_L], _I),
     "arco_sel_state_bytes": ([], _L),
+    "arco_pack_desc_bytes": ([], _L),
     "arco_seg_ws_doubles": ([_L, _I, _I], _L),
     # host-side native sampler replay (no GPU work)
     "arco_grid_sample": ([_P, _L, _L, _L, _I, _I, _P], _L),

@@ -141,14 +141,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 }
 
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int nblk, int C,
+                                       float* __restrict__ sum_dy, float* __restrict__ sum_dyx,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   const int c = blockIdx.x;
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nblk; i += 64) { a += (double)s_dy[(long)c * nblk + i]; b += (double)s_dyx[(long)c * nblk + i]; }
   a = wave_sum_d(a); b = wave_sum_d(b);
   if (threadIdx.x != 0) return;
-  dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-  dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+  sum_dy[c] = (float)a; sum_dyx[c] = (float)b;                    // this call's sums (read by the apply pass)
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
 }
 
 // ---- BN backward pass 2: dz = gamma*istd*(dy - sum_dy/n - xhat*sum_dyx/n)
@@ -689,13 +691,10 @@ int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
     float* s_dy = ws; float* s_dyx = ws + (long)C * nblk; float* sums = ws + 2l * C * nblk;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, M,
                        C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums + C,
-                       sums, 0);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums, sums + C, dgamma,
+                       dbeta, accumulate);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
                        mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)M, dZ, ldo);
-    // grads: dbeta = sum dy, dgamma = sum dy*xhat
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, dgamma,
-                       dbeta, accumulate);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
                        nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo);

@@ -343,6 +343,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int Ci
   Wp[i] = v;
 }
 
+// one launch packs every conv weight of a model: desc[i] = {src, dst, Cout, Cin, taps, mode, Npad, Kpad, first}
+struct PackDesc { const float* src; float* dst; int Cout, Cin, taps, mode, Npad, Kpad; long first; };
+__global__ void pack_many_kernel(const PackDesc* __restrict__ desc, int n_desc, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].first <= i) lo = mid; else hi = mid - 1; }
+    const PackDesc d = desc[lo];
+    const long j = i - d.first;
+    const int k = j % d.Kpad; const long r = j / d.Kpad; const int n = r % d.Npad; const int tap = r / d.Npad;
+    float v = 0.f;
+    if (d.mode == 0) { if (n < d.Cout && k < d.Cin) v = d.src[((long)n * d.Cin + k) * d.taps + tap]; }
+    else { if (n < d.Cin && k < d.Cout) v = d.src[((long)k * d.Cin + n) * d.taps + (d.taps - 1 - tap)]; }
+    d.dst[j] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // weight gradient:  dW[co][ci][tap] = sum_pix dZ[pix][co] * Ain[pix + tap][ci]
 // M = co, N = ci, K = pixels.  grid.x = pixel chunk, grid.y = co tile,
@@ -692,6 +708,15 @@ int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode,
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                     int NV, int D3, int H, int W, void* stream);
+// desc: device array of n_desc PackDesc records (arco_pack_desc_bytes() each, see igemm.hip); total = sum of packed sizes
+long arco_pack_desc_bytes() { return (long)sizeof(PackDesc); }
+int arco_pack_many(const void* desc, int n_desc, long total, void* stream) {
+  if (n_desc <= 0 || total <= 0) return ARCO_OK;
+  long g = (total + 255) / 256; if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), (const PackDesc*)desc, n_desc, total);
+  return arco_launch_status();
+}
+
 // out[pix][0..N) = conv(in)[pix] (+bias) (+residual); channels-last; taps in {1, 9}
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,

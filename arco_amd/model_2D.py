@@ -121,13 +121,17 @@ class ISD(nn.Module):
     def _momentum_update_key_encoder(self):
         """k = m*k + (1-m)*q over parameters() only (BN buffers untouched), model_2D.py:176-182.
         One fused kernel per (student, teacher) module pair on flat parameter buffers."""
+        self._ensure_ema_pairs()
+        for pair in self._ema_pairs:
+            pair.update(self.m)
+
+    def _ensure_ema_pairs(self):
         if self._ema_pairs is None:
             self._ema_pairs = [optim.EmaPair(q, k) for q, k in (
                 (self._unwrap(self.model), self._unwrap(self.ema_model)),
                 (self._unwrap(self.q_outputs_head), self._unwrap(self.k_outputs_head)),
                 (self._unwrap(self.q_latent_head), self._unwrap(self.k_latent_head)))]
-        for pair in self._ema_pairs:
-            pair.update(self.m)
+        return self._ema_pairs
 
     @staticmethod
     def _unwrap(m):

@@ -102,12 +102,16 @@ class ISD_3d(nn.Module):
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
         """model_3D.py:267-274: k = m*k + (1-m)*q over parameters() of the net and the two head pairs."""
+        self._ensure_ema_pairs()
+        for pair in self._ema_pairs:
+            pair.update(self.m)
+
+    def _ensure_ema_pairs(self):
         if self._ema_pairs is None:
             self._ema_pairs = [optim.EmaPair(q, k) for q, k in (
                 (self.model, self.ema_model), (self.q_outputs_head, self.k_outputs_head),
                 (self.q_latent_head, self.k_latent_head))]
-        for pair in self._ema_pairs:
-            pair.update(self.m)
+        return self._ema_pairs
 
     @torch.no_grad()
     def data_parallel(self):

@@ -73,18 +73,83 @@ def _taps(weight):
 WEIGHT_EPOCH = 0
 
 
+_plans = []
+
+
 def bump_weight_epoch():
+    """Weights changed in place: cached packs are stale; plans must be refreshed by their owners."""
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
+    for p in _plans:
+        p.valid = False
+
+
+class PackPlan:
+    """Packed copies of every conv weight of a module, refreshed by ONE kernel launch (`refresh()`), instead of
+    one pack launch per layer per forward.  The owner calls refresh() whenever the weights changed (optimiser
+    step / EMA update); pack_weight() then serves the plan's buffers."""
+
+    def __init__(self, modules, with_dgrad):
+        import struct
+        recs, self.entries = [], []
+        dev = None
+        total = 0
+        mods = [m for top in (modules if isinstance(modules, (list, tuple)) else [modules]) for m in top.modules()]
+        for m in mods:
+            w = getattr(m, "weight", None)
+            if not isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d)) or w is None:
+                continue
+            dev = w.device
+            co, ci = int(w.shape[0]), int(w.shape[1])
+            taps = _taps(w)
+            if taps not in (1, 9, 27):
+                continue
+            for mode in ((0, 1) if with_dgrad and w.requires_grad else (0,)):
+                if mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0:
+                    continue                       # served zero-copy by pack_weight
+                n, k = (co, ci) if mode == 0 else (ci, co)
+                npad, kpad = _ceil16(n), _ceil16(k)
+                buf = torch.empty((taps, npad, kpad), dtype=torch.float32, device=dev)
+                recs.append((w, buf, co, ci, taps, mode, npad, kpad, total))
+                total += buf.numel()
+                self.entries.append((w, mode, buf))
+        self.total, self.n = total, len(recs)
+        self.valid = False
+        _plans.append(self)
+        if self.n:
+            raw = b"".join(struct.pack("<QQiiiiiiq", w.data_ptr(), b.data_ptr(), co, ci, taps, mode, npad, kpad, first)
+                           for (w, b, co, ci, taps, mode, npad, kpad, first) in recs)
+            assert len(raw) == self.n * L.query("arco_pack_desc_bytes")
+            self.desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+            self.ptrs = [(w.data_ptr(), w) for (w, *_r) in recs]
+            for w, mode, buf in self.entries:
+                d = getattr(w, "_arco_plan", None)
+                if d is None:
+                    d = {}
+                    w._arco_plan = d
+                d[mode] = (self, buf)
+
+    def refresh(self):
+        """Re-pack every weight of the plan (one launch).  Called by whoever changed the weights."""
+        if self.n:
+            for ptr, w in self.ptrs:
+                if w.data_ptr() != ptr:
+                    raise RuntimeError("PackPlan: a parameter moved after the plan was built (build plans after "
+                                       "the optimiser has flattened the parameters)")
+            L.call("arco_pack_many", L.ptr(self.desc), self.n, self.total)
+        self.valid = True
 
 
 def pack_weight(weight, taps, mode):
     """torch [Cout, Cin, kh, kw] -> Wp[taps][Npad][Kpad]; mode 0 forward, 1 dgrad (flipped+transposed).
-    Cached per weight-epoch (a step uses each model's weights in several forwards)."""
+    Served from the module's PackPlan when one is valid, else cached per weight-epoch."""
     co, ci = int(weight.shape[0]), int(weight.shape[1])
     w = weight.detach()
     if mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0 and w.is_contiguous():
         return w.view(co, ci)                      # already [N][K]
+    plan = getattr(weight, "_arco_plan", None)
+    if plan is not None and mode in plan and plan[mode][0].valid:
+        return plan[mode][1]
     capturing = torch.cuda.is_current_stream_capturing()
     cache = getattr(weight, "_arco_pack", None)
     key = (mode, weight._version)
@@ -231,11 +296,22 @@ def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P):
     m = zr.shape[0]
     nblk = L.query("arco_chan_stats_blocks", m)
     ws = torch.empty(2 * co * nblk + 2 * co, dtype=torch.float32, device=da.device)
-    dgamma = torch.empty_like(gamma) if gamma is not None else None
-    dbeta = torch.empty_like(beta) if beta is not None else None
     dz = new_act_nd(int(z.shape[0]), co, tuple(int(v) for v in z.shape[2:]), da.device)
+    dgamma = dbeta = None
+    acc = 0
+    if gamma is not None:
+        gv, bv = getattr(gamma, "_arco_grad_view", None), getattr(beta, "_arco_grad_view", None)
+        if (gv is not None and bv is not None and gamma.grad is not None and beta.grad is not None
+                and gamma.grad.data_ptr() == gv.data_ptr() and beta.grad.data_ptr() == bv.data_ptr()):
+            dg_t, db_t, acc = gv, bv, 1               # straight into the optimiser's flat gradient buffer
+            gamma._arco_mark(); beta._arco_mark()
+        else:
+            dg_t = dgamma = torch.empty_like(gamma)
+            db_t = dbeta = torch.empty_like(beta)
+    else:
+        dg_t = db_t = None
     L.call("arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma),
-           L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dz), co)
+           L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dz), co)
     return dz, dgamma, dbeta
 
 

@@ -24,7 +24,19 @@ def flatten_params(params):
     return flat
 
 
+def _weights_changed(self):
+    """Owner-side invalidation: with PackPlans attached (`self.plans`) only they are refreshed (one launch each);
+    otherwise every cached packed weight is declared stale."""
+    plans = getattr(self, "plans", None)
+    if plans:
+        for pl in plans:
+            pl.refresh()
+    else:
+        ops.bump_weight_epoch()
+
+
 class EmaPair:
+    _weights_changed = _weights_changed
     """teacher <- m*teacher + (1-m)*student over parameters() (model_2D.py:176-182,
     train_arco_2d.py:306-308)."""
 
@@ -59,10 +71,11 @@ class EmaPair:
         if s is None:
             s = torch.cat([p.data.reshape(-1) for p in self.sp])
         L.call("arco_ema", L.ptr(self.flat_t), L.ptr(s), self.flat_t.numel(), float(m))
-        ops.bump_weight_epoch()
+        self._weights_changed()
 
 
 class SGDNesterov:
+    _weights_changed = _weights_changed
     """torch.optim.SGD(params, lr, momentum=0.9, weight_decay=1e-4, nesterov=True)
     (train_arco_2d.py:248) over flat buffers: parameters, gradients (p.grad are views that
     autograd accumulates into) and momentum live in three contiguous fp32 arrays, and a step
@@ -84,9 +97,8 @@ class SGDNesterov:
             p.grad = self.flat_g[off:off + k].view(p.shape)
             p.register_post_accumulate_grad_hook(self._mark(i))
             # direct-write path of arco_amd.ops (contiguous torch-layout weights only)
-            if p.dim() >= 2:
-                p._arco_grad_view = p.grad
-                p._arco_mark = self._marker(i)
+            p._arco_grad_view = p.grad
+            p._arco_mark = self._marker(i)
             off += k
         self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay, params=self.params)]
         self._touched = set()
@@ -132,4 +144,4 @@ class SGDNesterov:
                    n, float(g['lr']), float(g['momentum']), float(g['weight_decay']), 1 if first else 0)
             for i in range(a, b):
                 self._started[i] = True
-        ops.bump_weight_epoch()
+        self._weights_changed()

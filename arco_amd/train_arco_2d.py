@@ -149,6 +149,15 @@ class ArcoStep2D:
         for m in (self.model, self.ema_model, self.q_representation, self.k_feature_extractor,
                   self.q_feature_extractor):
             m.train()                                                   # :263-267
+        # packed conv weights: one launch per weight owner per step (ops.PackPlan), refreshed by the owner
+        plan_s = ops.PackPlan([self.model, self.q_representation, self.q_feature_extractor], True)
+        self.optimizer.plans = [plan_s]
+        pairs = self.isd._ensure_ema_pairs()
+        pairs[0].plans = [ops.PackPlan([self.ema_model], False)]
+        for pr in pairs[1:]:
+            pr.plans = [ops.PackPlan([], False)]
+        self.k_fe_ema.plans = [ops.PackPlan([self.k_feature_extractor], False)]
+        self.plans = [plan_s] + [pl for pr in pairs for pl in pr.plans] + self.k_fe_ema.plans
         self.iter_num = 0
         self.loss_events = []
         # no-grad forwards replayed as HIP graphs (one graph per call site: outputs are static buffers)
@@ -172,6 +181,9 @@ class ArcoStep2D:
         it, and the torch-CPU-generator index replay runs on the host while they execute."""
         a = self.args
         C = a.num_classes
+        for pl in self.plans:                                            # stale only if someone else touched weights
+            if not pl.valid:
+                pl.refresh()
         dense = getattr(a, "dense_head", 0)
         with torch.no_grad():                                            # :284-286
             pred_u0, _, _ = self.t_fwd_u0(u_data)

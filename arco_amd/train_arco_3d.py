@@ -69,6 +69,15 @@ class ArcoStep3D:
         for m in (self.model, self.ema_model, self.q_representation, self.k_feature_extractor,
                   self.q_feature_extractor):
             m.train()
+        # packed conv weights: one launch per weight owner per step (ops.PackPlan), refreshed by the owner
+        plan_s = ops.PackPlan([self.model, self.q_representation, self.q_feature_extractor], True)
+        self.optimizer.plans = [plan_s]
+        pairs = self.isd._ensure_ema_pairs()
+        pairs[0].plans = [ops.PackPlan([self.ema_model], False)]
+        for pr in pairs[1:]:
+            pr.plans = [ops.PackPlan([], False)]
+        self.k_fe_ema.plans = [ops.PackPlan([self.k_feature_extractor], False)]
+        self.plans = [plan_s] + [pl for pr in pairs for pl in pr.plans] + self.k_fe_ema.plans
         self.iter_num = 0
         use_graphs = bool(getattr(args, "graphs", 1))
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -82,6 +91,9 @@ class ArcoStep3D:
     def step(self, l_data, l_label, u_data, epoch_num=0, max_epoch=1):
         a = self.args
         C = a.num_classes
+        for pl in self.plans:                                            # stale only if someone else touched weights
+            if not pl.valid:
+                pl.refresh()
         with torch.no_grad():                                            # :260-262
             pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)

@@ -69,6 +69,10 @@ int arco_sum_scale(const float* x, int n, float scale, float* out, int accumulat
 /* ---- N1-N4  convolutions on the fp32 matrix cores (nn.Conv2d 3x3 / 1x1: unetWithArgs.py:36-44,72,139;
  *      model_2D.py:25-33; train_arco_2d.py:231-234).  Wp = packed weights [taps][ceil16(N)][ceil16(K)].    */
 int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream);
+/* all conv weights of a model in ONE launch: `desc` = device array of records {const float* src; float* dst;
+ * int Cout, Cin, taps, mode, Npad, Kpad; long first;} (arco_pack_desc_bytes() bytes each)                */
+long arco_pack_desc_bytes();
+int arco_pack_many(const void* desc, int n_desc, long total, void* stream);
 int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout);
 int arco_conv_config(int taps, int NB, int H, int W, int Cout, int* kc_depth_db);   /* which igemm instantiation */
 /* out = conv(in) (+bias)(+residual); optional per-channel (sum, sumsq) block partials for train-mode BN. */
