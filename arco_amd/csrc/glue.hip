@@ -61,10 +61,13 @@ __device__ __forceinline__ float fkey_inv(unsigned int k) {
   return __uint_as_float(u);
 }
 __global__ __launch_bounds__(256) void sel_count_kernel(const int64_t* __restrict__ lab, long n, SelState* st) {
-  unsigned long long c = 0;
+  unsigned int c = 0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) c += lab[i] >= 0;
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&st->n_valid, c);
+  __shared__ unsigned int sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { const unsigned long long t = (unsigned long long)sh[0] + sh[1] + sh[2] + sh[3]; if (t) atomicAdd(&st->n_valid, t); }
 }
 // np.percentile(method='linear'): virtual index (n-1)*q/100 in float64, neighbours floor / floor+1
 __global__ void sel_init_kernel(SelState* st, double q_lo, double q_hi) {
@@ -183,7 +186,13 @@ __global__ __launch_bounds__(256) void sup_loss_partial_kernel(const float* __re
 __global__ void sup_loss_final_kernel(const double* __restrict__ part, int nblk, int C, double* __restrict__ sums, float* __restrict__ out) {
   const int np = 2 + 3 * C;
   __shared__ double s[SEG_MAXP];
-  if (threadIdx.x < np) { double a = 0.0; for (int b = 0; b < nblk; ++b) a += part[(long)b * np + threadIdx.x]; s[threadIdx.x] = a; sums[threadIdx.x] = a; }
+  // one wave per quantity (blockDim = 256 = 4 waves), fixed summation order
+  for (int i = threadIdx.x >> 6; i < np; i += 4) {
+    double a = 0.0;
+    for (int b = threadIdx.x & 63; b < nblk; b += 64) a += part[(long)b * np + i];
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) { s[i] = a; sums[i] = a; }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     out[0] = (float)(s[0] / s[1]);
@@ -253,14 +262,16 @@ __global__ __launch_bounds__(256) void unsup_loss_partial_kernel(const float* __
 }
 // per-image weights w_b = n_conf/n_valid; loss = sum_b w_b * S_b / sum_b n_b ; stats[b] = {w_b}, stats[B] = N_sel
 __global__ void unsup_loss_final_kernel(const double* __restrict__ part, int B, int nblk, double* __restrict__ stats, float* __restrict__ out) {
-  if (threadIdx.x != 0) return;
-  double num = 0.0, cnt = 0.0;
+  double num = 0.0, cnt = 0.0;                       // one wave; lanes stride over the per-image partials
   for (int b = 0; b < B; ++b) {
     double s[4] = {0, 0, 0, 0};
-    for (int k = 0; k < nblk; ++k) for (int i = 0; i < 4; ++i) s[i] += part[((long)b * nblk + k) * 4 + i];
+    for (int k = threadIdx.x; k < nblk; k += 64) for (int i = 0; i < 4; ++i) s[i] += part[((long)b * nblk + k) * 4 + i];
+    for (int i = 0; i < 4; ++i) s[i] = wave_sum_d(s[i]);
     const double w = s[0] / s[1];
-    stats[b] = w; num += w * s[2]; cnt += s[3];
+    if (threadIdx.x == 0) stats[b] = w;
+    num += w * s[2]; cnt += s[3];
   }
+  if (threadIdx.x != 0) return;
   stats[B] = cnt;
   out[0] = (float)(num / cnt);
 }
@@ -306,7 +317,7 @@ int arco_sup_loss_fwd(const float* X, long ld, long M, int C, const int64_t* lab
   int nblk = gl_grid(M); if (nblk > 1024) nblk = 1024;
   double* sums = ws + 1024l * (2 + 3 * C);
   hipLaunchKernelGGL(sup_loss_partial_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), X, ld, M, C, lab, ws);
-  hipLaunchKernelGGL(sup_loss_final_kernel, dim3(1), dim3(128), 0, as_stream(stream), ws, nblk, C, sums, out);
+  hipLaunchKernelGGL(sup_loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), ws, nblk, C, sums, out);
   return arco_launch_status();
 }
 int arco_sup_loss_bwd(const float* X, long ld, long M, int C, const int64_t* lab, const double* ws, const float* g_ce,
@@ -340,7 +351,7 @@ int arco_entropy_masks(const float* ent, const int64_t* lab_l, const int64_t* la
   hipStream_t st = as_stream(stream);
   SelState* s = reinterpret_cast<SelState*>(state);
   (void)hipMemsetAsync(s, 0, sizeof(SelState), st);
-  hipLaunchKernelGGL(sel_count_kernel, dim3(gl_grid(n_u)), dim3(256), 0, st, lab_u, n_u, s);
+  hipLaunchKernelGGL(sel_count_kernel, dim3(gl_grid(n_u) > 256 ? 256 : gl_grid(n_u)), dim3(256), 0, st, lab_u, n_u, s);
   hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(1), 0, st, s, q_lo, q_hi);
   for (int pass = 0; pass < 4; ++pass) {
     hipLaunchKernelGGL(sel_hist_kernel, dim3(gl_grid(n_u) > 256 ? 256 : gl_grid(n_u)), dim3(256), 0, st, ent, lab_u, n_u, pass, s);

@@ -12,6 +12,7 @@
 // ds_read_b128 fragment reads (4 consecutive k per lane) are bank-conflict free.
 // A b128 fragment feeds 4 MFMAs: lane (i, g) holds k = 4g+j for j = 0..3.
 #include "common.h"
+#include <stdlib.h>
 
 struct IgemmArgs {
   const float* A; long lda;
@@ -778,7 +779,8 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
     a.CoutPad = (Cout + hco - 1) / hco * hco; a.CinPad = (Cin + hci - 1) / hci * hci;
     const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
-    long chunks = 1536 / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
+    static const long target_blocks = getenv("ARCO_WGRAD_BLOCKS") ? atol(getenv("ARCO_WGRAD_BLOCKS")) : 1536;
+    long chunks = target_blocks / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
     dim3 hgrid((unsigned)chunks, ydim, zdim);
 #define WH(COB, CIB)                                                                              \
     do {                                                                                          \

@@ -257,17 +257,23 @@ __global__ __launch_bounds__(256) void weighted_row_sum_kernel(const float* __re
 // out[(c0+cc)*ldo + d] = (sum over slabs) * (totals ? 1/totals[c0+cc] : 1)
 __global__ void row_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nc, int D, int c0,
                                         const int64_t* __restrict__ totals, float* __restrict__ out, long ldo) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nc * D) return;
-  const int cc = i / D, d = i % D;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) {
-    s0 += (double)partial[((long)b * nc + cc) * D + d]; s1 += (double)partial[((long)(b + 1) * nc + cc) * D + d];
-    s2 += (double)partial[((long)(b + 2) * nc + cc) * D + d]; s3 += (double)partial[((long)(b + 3) * nc + cc) * D + d];
+  // block = 64 outputs x 4 slab segments (threadIdx.y), combined through LDS in a fixed order
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const bool ok = i < nc * D;
+  const int cc = ok ? i / D : 0, d = ok ? i % D : 0;
+  double s0 = 0.0, s1 = 0.0;
+  if (ok) {
+    int b = threadIdx.y;
+    for (; b + 4 < nblk; b += 8) {
+      s0 += (double)partial[((long)b * nc + cc) * D + d]; s1 += (double)partial[((long)(b + 4) * nc + cc) * D + d];
+    }
+    for (; b < nblk; b += 4) s0 += (double)partial[((long)b * nc + cc) * D + d];
   }
-  for (; b < nblk; ++b) s0 += (double)partial[((long)b * nc + cc) * D + d];
-  double s = (s0 + s1) + (s2 + s3);
+  __shared__ double sh[4][64];
+  sh[threadIdx.y][threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.y != 0 || !ok) return;
+  double s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
   if (totals) s /= (double)totals[c0 + cc];
   out[(long)(c0 + cc) * ldo + d] = (float)s;
 }
@@ -490,8 +496,11 @@ int arco_compact_rows(const uint64_t* codes, long n_pix, int C, const uint32_t* 
 
 // workspace: partial must hold arco_proto_ws_floats(...) floats
 long arco_proto_ws_floats(long n_pix, int C, int D) {
-  long grid = (n_pix + 255) / 256;
+  long grid = (n_pix + 255) / 256;                      // masked_row_sum slabs
   if (grid > 2048) grid = 2048;
+  long g2 = (n_pix + 63) / 64;                          // weighted_row_sum slabs
+  if (g2 > 1024) g2 = 1024;
+  if (g2 > grid) grid = g2;
   if (grid < 1) grid = 1;
   const int nc = C < 8 ? C : 8;
   return grid * nc * D;
@@ -537,8 +546,8 @@ int arco_lv_weights(const uint64_t* codes, long n_pix, int C, int Cp, float* W, 
 int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
                           const int64_t* totals, float* partial, float* out, long ldo, void* stream) {
   ARCO_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 512 && (ldt & 3) == 0 && C <= ARCO_MAXC);
-  long grid = (n_rows + 255) / 256;
-  if (grid > 2048) grid = 2048;
+  long grid = (n_rows + 63) / 64;                      // HBM-bound row sweep: >= 4 blocks per CU in flight
+  if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
   long rpb = (n_rows + grid - 1) / grid;
   int lpr = 1;
@@ -553,7 +562,7 @@ int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, l
       hipLaunchKernelGGL(weighted_row_sum_kernel<2>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
     else
       hipLaunchKernelGGL(weighted_row_sum_kernel<4>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
-    hipLaunchKernelGGL(row_sum_finalize_kernel, dim3((nc * D + 255) / 256), dim3(256), 0, as_stream(stream), partial,
+    hipLaunchKernelGGL(row_sum_finalize_kernel, dim3((nc * D + 63) / 64), dim3(64, 4), 0, as_stream(stream), partial,
                        (int)grid, nc, D, c0, totals, out, ldo);
   }
   return arco_launch_status();
