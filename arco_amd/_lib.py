@@ -70,8 +70,8 @@ _SIGS = {
 }
 _QUERIES = {   # plain host helpers returning sizes
     "arco_proto_ws_floats": ([_L, _I, _I], _L),
-    "arco_conv_mblocks": ([_I, _I, _I, _I, _I], _I),
-    "arco_conv_config": ([_I, _I, _I, _I, _I, _P], _I),
+    "arco_conv_mblocks": ([_I, _I, _I, _I, _I, _I, _L], _I),
+    "arco_conv_config": ([_I, _I, _I, _I, _I, _I, _L, _P], _I),
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
     "arco_chan_stats_blocks": ([_L], _I),
     "arco_sel_state_bytes": ([], _L),

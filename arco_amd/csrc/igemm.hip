@@ -315,6 +315,177 @@ static int dispatch_spatial(const IgemmArgs& a, hipStream_t st, int* nmb) {
   if (conv_blocks(a, 64, 32) >= want) return launch_igemm<9, 64, 32, 2, 2, 16, false, DEPTH>(a, st, nmb);
   return launch_igemm<9, 32, 32, 2, 2, 16, false, DEPTH>(a, st, nmb);
 }
+
+// ---------------------------------------------------------------------------
+// 3x3 convolution for the shallow levels (Cin in {16, 32}, Cout <= 32): persistent workgroups,
+// weights resident in LDS for the whole launch, one input HALO tile staged per output tile
+// (every input pixel is fetched once per tile instead of once per tap), all 9 taps fed to the
+// MFMAs from LDS with no barrier in between, next tile's halo prefetched into registers while
+// the current one is computed.  D = W (16 cout x 4 k) * X^T (4 k x 16 px): a lane ends up with
+// 4 consecutive output channels of one pixel -> 16-byte coalesced stores.
+//   tile = 8 rows x TW cols; wave w owns rows 2w, 2w+1.
+// ---------------------------------------------------------------------------
+template <int CIN, int COUT, int TW>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(IgemmArgs a) {
+  constexpr int TH = 8, HW_ = TW + 2, NP = (TH + 2) * HW_;
+  constexpr int LDC = CIN + 4, Q4 = CIN / 4, KJ = CIN / 16, NT = COUT / 16, MT = 2 * (TW / 16);
+  constexpr int UNITS = NP * Q4, NLD = (UNITS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                        // [9][COUT][LDC]
+  float* As = smem + 9 * COUT * LDC;       // [NP][LDC]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const long n_tiles = (long)a.NB * tiles_y * tiles_x;
+
+  for (int u = tid; u < 9 * COUT * Q4; u += 256) {          // weights: Wp[tap][Npad][Kpad], Kpad == CIN
+    const int q = u % Q4, r = u / Q4, n = r % COUT, tap = r / COUT;
+    f32x4 v = {0, 0, 0, 0};
+    if (n < a.Npad) v = *reinterpret_cast<const f32x4*>(a.Wp + ((long)tap * a.Npad + n) * a.Kpad + 4 * q);
+    *reinterpret_cast<f32x4*>(&Ws[(tap * COUT + n) * LDC + 4 * q]) = v;
+  }
+
+  f32x4 pre[NLD];
+  auto fetch = [&](long tile) {
+    const int tx = tile % tiles_x; const long r = tile / tiles_x; const int ty = r % tiles_y; const int nb = r / tiles_y;
+    const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int u = tid + i * 256;
+      const int hp = u / Q4, q = u % Q4, hy = hp / HW_, hx = hp % HW_;
+      const int gy = y0 + hy, gx = x0 + hx;
+      f32x4 v = {0, 0, 0, 0};
+      if (u < UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+        v = *reinterpret_cast<const f32x4*>(a.A + (((long)nb * a.H + gy) * a.W + gx) * a.lda + 4 * q);
+      pre[i] = v;
+    }
+  };
+
+  f32x4 s1[NT], s2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { s1[nt] = f32x4{0, 0, 0, 0}; s2[nt] = f32x4{0, 0, 0, 0}; }
+  f32x4 bias4[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int n = nt * 16 + 4 * g + e; bias4[nt][e] = (a.bias && n < a.N) ? a.bias[n] : 0.f; }
+
+  long tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile);
+  while (tile < n_tiles) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int u = tid + i * 256;
+      if (u < UNITS) *reinterpret_cast<f32x4*>(&As[(u / Q4) * LDC + 4 * (u % Q4)]) = pre[i];
+    }
+    __syncthreads();
+    const long next = tile + gridDim.x;
+    if (next < n_tiles) fetch(next);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        f32x4 bw[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bw[nt] = *reinterpret_cast<const f32x4*>(&Ws[(tap * COUT + nt * 16 + li) * LDC + 16 * j + 4 * g]);
+        f32x4 ax[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int prow = 2 * w + mt / (TW / 16) + dy, pcol = (mt % (TW / 16)) * 16 + li + dx;
+          ax[mt] = *reinterpret_cast<const f32x4*>(&As[(prow * HW_ + pcol) * LDC + 16 * j + 4 * g]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)                       // independent accumulators back to back
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[nt][e], ax[mt][e], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    {
+      const int tx = tile % tiles_x; const long r = tile / tiles_x; const int ty = r % tiles_y; const int nb = r / tiles_y;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int gy = ty * TH + 2 * w + mt / (TW / 16), gx = tx * TW + (mt % (TW / 16)) * 16 + li;
+        if (gy < a.H && gx < a.W) {
+          const long pix = ((long)nb * a.H + gy) * a.W + gx;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + 4 * g;
+            if (n < a.N) {
+              f32x4 v = acc[mt][nt] + bias4[nt];
+              if (a.R) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += a.R[pix * a.ldr + n + e];
+              }
+              if ((a.ldc & 3) == 0) *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + n) = v;
+              else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a.C[pix * a.ldc + n + e] = v[e];
+              }
+              s1[nt] += v; s2[nt] += v * v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    tile = next;
+  }
+
+  if (a.stat_sum) {
+    float* red = As;                       // [2][4 waves][COUT]; As is idle (barrier above / no tile at all)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v1 = s1[nt][e], v2 = s2[nt][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+        if (li == 0) { red[(0 * 4 + w) * COUT + nt * 16 + 4 * g + e] = v1; red[(1 * 4 + w) * COUT + nt * 16 + 4 * g + e] = v2; }
+      }
+    __syncthreads();
+    if (tid < COUT && tid < a.N) {
+      float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) { v1 += red[(0 * 4 + ww) * COUT + tid]; v2 += red[(1 * 4 + ww) * COUT + tid]; }
+      a.stat_sum[(long)tid * a.n_mblocks + blockIdx.x] = v1;
+      a.stat_sq[(long)tid * a.n_mblocks + blockIdx.x] = v2;
+    }
+  }
+}
+
+// eligibility + launch; the block count (= BN-stat slabs per channel) is a pure function of the geometry
+static bool halo_eligible(const IgemmArgs& a) {
+  static const bool off = getenv("ARCO_CONV_HALO") && atoi(getenv("ARCO_CONV_HALO")) == 0;   // A/B switch
+  if (off) return false;
+  return (a.K == 16 || a.K == 32) && a.Kpad == a.K && a.Npad <= 32 && (a.N & 3) == 0 && (a.lda & 3) == 0;
+}
+template <int CIN, int COUT, int TW>
+static int launch_halo(const IgemmArgs& a, hipStream_t st, int* q) {
+  const long n_tiles = (long)a.NB * ((a.H + 7) / 8) * ((a.W + TW - 1) / TW);
+  constexpr size_t sh = (size_t)(9 * COUT * (CIN + 4) + 10 * (TW + 2) * (CIN + 4)) * sizeof(float);
+  constexpr int per_cu = sh * 4 <= 160 * 1024 ? 4 : (sh * 3 <= 160 * 1024 ? 3 : (sh * 2 <= 160 * 1024 ? 2 : 1));
+  long blocks = 256l * (per_cu > 3 ? 3 : per_cu); if (blocks > n_tiles) blocks = n_tiles;   // <= 3 waves/SIMD by VGPRs
+  if (q) { q[0] = (int)blocks; q[1] = 9 * 1000000 + 900000 + CIN * 1000 + COUT; q[2] = CIN * 100 + 10; return ARCO_OK; }
+  auto kern = conv3x3_halo_kernel<CIN, COUT, TW>;
+  static bool attr_set = false;
+  if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
+  IgemmArgs b = a; b.n_mblocks = (int)blocks; b.n_nblocks = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), sh, st, b);
+  return arco_launch_status();
+}
+static int dispatch_halo(const IgemmArgs& a, hipStream_t st, int* q) {
+  if (a.K == 16) return a.Npad <= 16 ? launch_halo<16, 16, 32>(a, st, q) : launch_halo<16, 32, 32>(a, st, q);
+  return a.Npad <= 16 ? launch_halo<32, 16, 16>(a, st, q) : launch_halo<32, 32, 16>(a, st, q);
+}
 static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb) {
   if (taps == 1) {
     if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16, true>(a, st, nmb);
@@ -323,7 +494,7 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
     return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
   }
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
-  if (taps == 9) return dispatch_spatial<1>(a, st, nmb);
+  if (taps == 9) return halo_eligible(a) ? dispatch_halo(a, st, nmb) : dispatch_spatial<1>(a, st, nmb);
   return ARCO_ERR_UNSUPPORTED;
 }
 
@@ -675,10 +846,10 @@ __global__ void transpose2d_kernel(const float* __restrict__ x, long ldx, int ro
 extern "C" {
 
 // Query: number of M-blocks (= BN-stat partial slabs per channel) the conv launch will use.
-int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout) {
+int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in) {
   IgemmArgs a{};
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
-  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in;
   int q[3] = {0, 0, 0};
   if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
   return q[0];
@@ -686,10 +857,10 @@ int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout) {
 
 // which igemm_kernel<TAPS,BM,BN,..> instantiation a launch uses: returns TAPS*1e6 + BM*1e3 + BN (kernel-tap form:
 // 9 for both 3x3 and 3x3x3); *kc_depth_db = KC*100 + DEPTH*10 + DB
-int arco_conv_config(int taps, int NB, int H, int W, int Cout, int* kc_depth_db) {
+int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int* kc_depth_db) {
   IgemmArgs a{};
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
-  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in;
   int q[3] = {0, 0, 0};
   if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
   if (kc_depth_db) *kc_depth_db = q[2];
@@ -779,8 +950,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
     a.CoutPad = (Cout + hco - 1) / hco * hco; a.CinPad = (Cin + hci - 1) / hci * hci;
     const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
-    static const long target_blocks = getenv("ARCO_WGRAD_BLOCKS") ? atol(getenv("ARCO_WGRAD_BLOCKS")) : 1536;
-    long chunks = target_blocks / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
+    long chunks = 1536 / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
     dim3 hgrid((unsigned)chunks, ydim, zdim);
 #define WH(COB, CIB)                                                                              \
     do {                                                                                          \

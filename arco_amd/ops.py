@@ -185,7 +185,7 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
     ssum = ssq = None
     nmb = 0
     if stats:
-        nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, n)
+        nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, k, n, ld)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
     if PROFILE is not None:
@@ -195,7 +195,7 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
            L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w)
     if PROFILE is not None:
         ev[1].record()
-        cfg = L.query("arco_conv_config", taps, nb * d3, h, w, n, None)        # igemm_kernel<TAPS,BM,BN,..> instantiation
+        cfg = L.query("arco_conv_config", taps, nb * d3, h, w, k, n, ld, None)  # kernel instantiation id
         PROFILE.setdefault(cfg, []).append((ev[0], ev[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
     return out, (ssum, ssq, nmb)
 

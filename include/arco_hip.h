@@ -73,8 +73,10 @@ int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode,
  * int Cout, Cin, taps, mode, Npad, Kpad; long first;} (arco_pack_desc_bytes() bytes each)                */
 long arco_pack_desc_bytes();
 int arco_pack_many(const void* desc, int n_desc, long total, void* stream);
-int arco_conv_mblocks(int taps, int NB, int H, int W, int Cout);
-int arco_conv_config(int taps, int NB, int H, int W, int Cout, int* kc_depth_db);   /* which igemm instantiation */
+int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in);
+/* which kernel instantiation a launch uses: igemm_kernel<TAPS,BM,BN,..> -> TAPS*1e6 + BM*1e3 + BN;
+ * conv3x3_halo_kernel<CIN,COUT,..> -> 9.9e6 + CIN*1e3 + COUT */
+int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int* kc_depth_db);
 /* out = conv(in) (+bias)(+residual); optional per-channel (sum, sumsq) block partials for train-mode BN. */
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,

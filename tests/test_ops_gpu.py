@@ -25,6 +25,10 @@ def close(a, b, rtol=2e-4, atol=2e-5):
     (1, 16, 4, 32, 32, 3, True, False), (1, 16, 19, 16, 32, 3, True, False), (2, 128, 64, 8, 8, 1, True, False),
     (1, 496, 496, 24, 24, 1, False, False), (2, 48, 48, 16, 16, 1, False, True), (1, 384, 384, 32, 32, 1, False, True),
     (1, 32, 16, 64, 64, 1, True, False), (3, 20, 36, 10, 14, 3, False, False),
+    # persistent halo-tile kernel (Cin in {16,32}, Cout <= 32): all instantiations, ragged edges, residual
+    (2, 16, 32, 13, 37, 3, True, False), (2, 32, 16, 9, 70, 3, False, False), (3, 32, 32, 21, 19, 3, True, False),
+    (1, 16, 16, 7, 5, 3, True, False), (2, 32, 32, 24, 40, 3, False, True), (2, 16, 16, 40, 64, 3, True, True),
+    (1, 32, 4, 17, 33, 3, True, False), (5, 16, 16, 256, 256, 3, True, False), (3, 32, 32, 200, 136, 3, True, False),
 ])
 def test_conv_fwd_bwd(nb, ci, co, h, w, k, bias, res):
     from arco_amd import ops

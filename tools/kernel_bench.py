@@ -36,7 +36,7 @@ if which in ("all", "gemm"):
     fwd(1, 496, 496, 32, 32, 1); fwd(8, 256, 128, 16, 16, 1); fwd(8, 32, 16, 128, 128, 1)
 if which in ("all", "conv"):
     for nb in (8,):
-        fwd(nb, 1, 16, 256, 256, 3); fwd(nb, 16, 16, 256, 256, 3); fwd(nb, 32, 16, 256, 256, 3)
+        fwd(nb, 1, 16, 256, 256, 3); fwd(nb, 16, 16, 256, 256, 3); fwd(nb, 32, 16, 256, 256, 3); fwd(nb, 16, 32, 256, 256, 3)
         fwd(nb, 16, 32, 128, 128, 3); fwd(nb, 32, 32, 128, 128, 3); fwd(nb, 64, 32, 128, 128, 3)
         fwd(nb, 64, 64, 64, 64, 3); fwd(nb, 128, 64, 64, 64, 3); fwd(nb, 128, 128, 32, 32, 3)
         fwd(nb, 256, 128, 32, 32, 3); fwd(nb, 256, 256, 16, 16, 3); fwd(nb, 16, 4, 256, 256, 3)
