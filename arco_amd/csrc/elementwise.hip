@@ -107,8 +107,9 @@ __device__ __forceinline__ float bn_dy(float dA, float y, float slope, int drop_
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dA, long ldd, const float* __restrict__ Z, long ldz, long M, int C,
     const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed, long P,
-    float* __restrict__ s_dy, float* __restrict__ s_dyx, int nblk) {
+    const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed_, long P,
+    float* __restrict__ s_dy, float* __restrict__ s_dyx, int nblk, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
   const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
   const long rpb = (M + nblk - 1) / nblk;
   const long r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
@@ -176,9 +177,10 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dA, long ldd, const float* __restrict__ Z, long ldz, long M, int C,
     const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed, long P,
+    const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed_, long P,
     const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, float inv_count,
-    float* __restrict__ dZ, long ldo) {
+    float* __restrict__ dZ, long ldo, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
   const int q4 = C / 4;
   const long tot = M * q4;
   const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
@@ -700,7 +702,7 @@ int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, 
 int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
                     const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
                     uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
-                    void* stream) {
+                    const uint64_t* seed_dev, void* stream) {
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldz & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0);
   const int dm = p > 0.f ? drop_mode : 0;
   hipStream_t st = as_stream(stream);
@@ -708,14 +710,14 @@ int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
     const int nblk = arco_chan_stats_blocks(M);
     float* s_dy = ws; float* s_dyx = ws + (long)C * nblk; float* sums = ws + 2l * C * nblk;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, M,
-                       C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk);
+                       C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk, seed_dev);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums, sums + C, dgamma,
                        dbeta, accumulate);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
-                       mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)M, dZ, ldo);
+                       mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)M, dZ, ldo, seed_dev);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
-                       nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo);
+                       nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo, seed_dev);
   }
   return arco_launch_status();
 }

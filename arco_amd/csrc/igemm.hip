@@ -978,7 +978,8 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     size_t sh = (size_t)128 * (LZ + LA) * 4; const size_t rd = (size_t)4 * COB * CIB * 4;         \
     if (sh < rd) sh = rd;                                                                         \
     auto kern = wgrad_kernel<COB, CIB>;                                                           \
-    if (sh > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    static bool attr_set = false;   /* once per instantiation: not legal inside a stream capture */ \
+    if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; } \
     hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, a);                                         \
   } while (0)
   if (co_b == 64 && ci_b == 64) WG(64, 64);

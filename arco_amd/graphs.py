@@ -45,3 +45,110 @@ class GraphedForward:
         static_in.copy_(x)
         g.replay()
         return out
+
+
+
+class _GraphedTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gt, x, *params):
+        gt.static_in.copy_(x)
+        gt.salt.add_(1)
+        gt.fwd_g.replay()
+        ctx.gt = gt
+        return tuple(o.detach() for o in gt.flat_outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gt = ctx.gt
+        for i, j in enumerate(gt.diff_idx):
+            g, sg = grads[j], gt.static_grads[i]
+            if g is None:
+                if gt.grad_live[i]:
+                    sg.zero_()
+                    gt.grad_live[i] = False
+            else:
+                if g.data_ptr() != sg.data_ptr():
+                    sg.copy_(g)
+                gt.grad_live[i] = True
+        gt.bwd_g.replay()
+        for mark in gt.markers:
+            mark()
+        return (None, gt.static_dx) + tuple(gt.static_pgrads)
+
+
+class GraphedTrain:
+    """Forward AND backward of `module(x)` as two HIP graphs behind one autograd node (the scheme of
+    torch.cuda.make_graphed_callables, specialised to this package's ops): per step the ~100 forward and ~200
+    backward launches of a U-Net / V-Net pass cost two host calls.  Requirements met by the trainers:
+    fixed input shape per instance, parameters and their gradient buffers at fixed addresses (flat buffers;
+    weight / BN gradients are accumulated straight into them by the captured kernels), packed weights served
+    by an ops.PackPlan, BN statistics and dropout salts updated on the device.  One instance per call site:
+    the activations saved for backward live in the instance's private pool until its backward has replayed.
+    The capture is taken w.r.t. leaf aliases of the parameters (see _capture), so live autograd graphs over
+    the real parameters (optimizer hooks, the other pass of the same step) do not leak into it."""
+
+    def __init__(self, module, warmup=2, enabled=True):
+        self.module, self.warmup, self.enabled = module, warmup, enabled
+        self.calls = 0
+        self.captured = False
+
+    def _capture(self, x):
+        from torch.utils import _pytree as pytree
+        dev = x.device
+        named = [(n, p) for n, p in self.module.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
+        self.markers = [p._arco_mark for p in self.params if hasattr(p, "_arco_mark")]
+        self.salt = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.static_in = x.detach().clone().requires_grad_(x.requires_grad)
+        prev_salt = ops.SEED_DEV
+        ops.SEED_DEV = self.salt
+        try:
+            torch.cuda.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            self.fwd_g = torch.cuda.CUDAGraph()
+            with torch.enable_grad(), torch.cuda.graph(self.fwd_g, pool=pool):
+                # The capture differentiates w.r.t. fresh leaf ALIASES of the parameters (same storage, same
+                # flat-gradient views / packed-weight plans): their gradient accumulators are born on the
+                # capture stream.  The real parameters' accumulators may be alive on the legacy stream (optimizer
+                # hooks, another pass of the same step); autograd would wait on that stream inside the capture.
+                alias = {}
+                for n, p in named:
+                    a = p.detach().requires_grad_(True)
+                    for k, v in p.__dict__.items():
+                        if k.startswith("_arco"):
+                            setattr(a, k, v)
+                    if p.grad is not None:
+                        a.grad = p.grad
+                    alias[n] = a
+                self.alias = alias
+                outs = torch.func.functional_call(self.module, alias, (self.static_in,))
+            self.flat_outs, self.spec = pytree.tree_flatten(outs)
+            self.diff_idx = [i for i, o in enumerate(self.flat_outs) if o.requires_grad]
+            self.static_grads = [torch.zeros_like(self.flat_outs[i]) for i in self.diff_idx]
+            self.grad_live = [False] * len(self.diff_idx)
+            inputs = ([self.static_in] if self.static_in.requires_grad else []) + [alias[n] for n, _ in named]
+            torch.cuda.synchronize()
+            self.bwd_g = torch.cuda.CUDAGraph()
+            # single-threaded autograd: every captured launch is issued by the capturing thread
+            with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(self.bwd_g, pool=pool):
+                grads = torch.autograd.grad([self.flat_outs[i] for i in self.diff_idx], inputs, self.static_grads,
+                                            allow_unused=True)
+            grads = list(grads)
+            self.static_dx = grads.pop(0) if self.static_in.requires_grad else None
+            self.static_pgrads = grads         # None where the kernels wrote into the flat gradient buffer
+        finally:
+            ops.SEED_DEV = prev_salt
+        self.captured = True
+        self.shape = tuple(x.shape)
+
+    def __call__(self, x):
+        self.calls += 1
+        if not self.enabled or self.calls <= self.warmup or not torch.is_grad_enabled():
+            return self.module(x)
+        if not self.captured:
+            self._capture(x)
+        if tuple(x.shape) != self.shape:
+            return self.module(x)
+        from torch.utils import _pytree as pytree
+        outs = _GraphedTrainFn.apply(self, x, *self.params)
+        return pytree.tree_unflatten(list(outs), self.spec)

@@ -188,12 +188,13 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, k, n, ld)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
-    if PROFILE is not None:
+    prof = PROFILE is not None and not torch.cuda.is_current_stream_capturing()
+    if prof:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
            L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w)
-    if PROFILE is not None:
+    if prof:
         ev[1].record()
         cfg = L.query("arco_conv_config", taps, nb * d3, h, w, k, n, ld, None)  # kernel instantiation id
         PROFILE.setdefault(cfg, []).append((ev[0], ev[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
@@ -286,9 +287,10 @@ def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed
     seed_dev = SEED_DEV if (p > 0 and torch.cuda.is_current_stream_capturing()) else None
     L.call("arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
            float(slope), int(drop_mode), float(p), seed, P, L.ptr(out), co, L.ptr(seed_dev))
+    return seed_dev
 
 
-def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P):
+def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, seed_dev=None):
     """Returns (dz, dgamma, dbeta) for a = drop(lrelu(BN(z)))."""
     dar, ldd = rows_view(da)
     zr, ldz = rows_view(z)
@@ -311,7 +313,7 @@ def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P):
     else:
         dg_t = db_t = None
     L.call("arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma),
-           L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dz), co)
+           L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dz), co, L.ptr(seed_dev))
     return dz, dgamma, dbeta
 
 
@@ -337,9 +339,10 @@ class ConvBnActFn(torch.autograd.Function):
         seed = _next_seed() if p > 0 else 0
         a = new_act_nd(nv, co, sp, x.device)
         zr, ldz = rows_view(z)
-        _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w, a)
+        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w, a)
         ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta)
         ctx.cfg = (taps, float(slope), float(p), int(drop_mode), seed, bias is not None)
+        ctx.bias_param = bias
         return a
 
     @staticmethod
@@ -348,7 +351,8 @@ class ConvBnActFn(torch.autograd.Function):
         taps, slope, p, drop_mode, seed, has_bias = ctx.cfg
         xr, ldx, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
-        dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w)
+        dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w,
+                                         ctx.seed_dev)
         dzr, ldzz = rows_view(dz)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -360,7 +364,12 @@ class ConvBnActFn(torch.autograd.Function):
             # a conv bias under train-mode BN has an analytically ZERO gradient (BN removes the channel mean):
             # sum(dz) = -gamma*istd*mean(dy*xhat)*sum(xhat) and sum(xhat) == 0.  The reference's autograd
             # produces fp32 rounding noise (~1e-7) here; we return exact zeros instead of a column-sum pass.
-            db = _zeros_cached((co,), da.device)
+            b = ctx.bias_param
+            view = getattr(b, "_arco_grad_view", None)
+            if view is not None and b.grad is not None and b.grad.data_ptr() == view.data_ptr():
+                b._arco_mark()          # += 0 into the flat gradient: nothing to launch, the optimiser still steps it
+            else:
+                db = _zeros_cached((co,), da.device)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
@@ -389,7 +398,7 @@ class BnActFn(torch.autograd.Function):
                    L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt))
         seed = _next_seed() if p > 0 else 0
         a = new_act_nd(int(z.shape[0]), co, sp, z.device)
-        _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a)
+        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a)
         ctx.save_for_backward(z, mean, istd, gamma, beta)
         ctx.cfg = (float(slope), float(p), int(drop_mode), seed, P)
         return a
@@ -398,7 +407,7 @@ class BnActFn(torch.autograd.Function):
     def backward(ctx, da):
         z, mean, istd, gamma, beta = ctx.saved_tensors
         slope, p, drop_mode, seed, P = ctx.cfg
-        dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P)
+        dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, ctx.seed_dev)
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

@@ -85,6 +85,9 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=0, help='1: train on synthetic ACDC-shaped tensors')
     p.add_argument('--in_chns', type=int, default=1, help='input channels (reference: 1)')
     p.add_argument('--graphs', type=int, default=1, help='1: replay the no-grad U-Net forwards as HIP graphs')
+    p.add_argument('--graph_train', type=int, default=0,
+                   help='1 (with --graphs 1): the student forward+backward passes are HIP graphs too (halves the '
+                        'host work per step; on an unloaded host the eager passes measured 2%% faster, DESIGN.md)')
     p.add_argument('--dense_teacher', type=int, default=0, help='1: materialise the dense teacher representation')
     p.add_argument('--head_levels', type=int, default=2, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
@@ -162,6 +165,10 @@ class ArcoStep2D:
         self.loss_events = []
         # no-grad forwards replayed as HIP graphs (one graph per call site: outputs are static buffers)
         use_graphs = bool(getattr(args, "graphs", 1))
+        g_train = use_graphs and bool(getattr(args, "graph_train", 0))
+        sub = os.environ.get("ARCO_GT_SUBSET", "ul")
+        self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train and "u" in sub)    # student passes: fwd + bwd graphs
+        self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train and "l" in sub)
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -190,7 +197,7 @@ class ArcoStep2D:
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits
         self.k_fe_ema.update(0.99)                                      # :306-308
-        pred_u, _, u_fm = self.model(u_aug)                              # :312 (needed first: entropy masks)
+        pred_u, _, u_fm = self.s_train_u(u_aug)                              # :312 (needed first: entropy masks)
         with torch.no_grad():                                            # teacher params carry no grad (:158-160)
             pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)                   # :314
             pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                    # :315
@@ -206,7 +213,7 @@ class ArcoStep2D:
                                  delta_n=a.strong_threshold_u2pl)       # :341-401 (counts -> async D2H)
         ev[1].record()
         # ---- large GPU work queued while the host waits for the counters and samples
-        pred_l, _, l_fm = self.model(l_data)                             # :310
+        pred_l, _, l_fm = self.s_train_l(l_data)                             # :310
         with torch.no_grad():
             self.s_fwd_stats(l_data)  # images_cj2_l forward (:311): BN running stats only; its FE/q_rep
                                      # outputs (l_feature_map_2, :319,326) are never read -> not computed
@@ -264,8 +271,11 @@ class ArcoStep2D:
         for g in self.optimizer.param_groups:
             g['lr'] = lr_
         self.iter_num += 1
-        self.last_terms = dict(ce=loss_ce, dice=loss_dice, unsup=unsup_loss, reco=reco_loss)
-        return loss, reco_loss
+        # values only: nothing returned or kept may hold this step's autograd graph alive into the next step
+        # (graphs.GraphedTrain needs the parameters' gradient accumulators recreated on its capture stream)
+        self.last_terms = dict(ce=loss_ce.detach(), dice=loss_dice.detach(), unsup=unsup_loss.detach(),
+                               reco=reco_loss.detach())
+        return loss.detach(), reco_loss.detach()
 
 
 def synthetic_batch(b, patch, n_cls, seed, device, in_chns=1):

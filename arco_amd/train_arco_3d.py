@@ -80,6 +80,9 @@ class ArcoStep3D:
         self.plans = [plan_s] + [pl for pr in pairs for pl in pr.plans] + self.k_fe_ema.plans
         self.iter_num = 0
         use_graphs = bool(getattr(args, "graphs", 1))
+        g_train = use_graphs and bool(getattr(args, "graph_train", 0))
+        self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train)    # student passes: fwd + bwd graphs
+        self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train)
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -99,7 +102,7 @@ class ArcoStep3D:
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits   # :268-278 (identity transforms)
         self.k_fe_ema.update(0.99)                                      # :279-281
-        pred_u, _, u_fm = self.model(u_aug)                              # :284
+        pred_u, _, u_fm = self.s_train_u(u_aug)                              # :284
         with torch.no_grad():
             pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)                   # :286
             pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                    # :287
@@ -111,7 +114,7 @@ class ArcoStep3D:
             low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
         plan = C_.contrast_masks(label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all,
                                  delta_n=a.strong_threshold_u2pl)
-        pred_l, _, l_fm = self.model(l_data)                             # :283
+        pred_l, _, l_fm = self.s_train_l(l_data)                             # :283
         dense = getattr(a, "dense_head", 0)
         fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
         fm_s = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]
@@ -148,7 +151,9 @@ class ArcoStep3D:
         for g in self.optimizer.param_groups:
             g['lr'] = lr_
         self.iter_num += 1
-        return loss, reco_loss
+        self.last_terms = dict(ce=loss_ce.detach(), dice=loss_dice.detach(), unsup=unsup_loss.detach(),
+                               reco=reco_loss.detach())
+        return loss.detach(), reco_loss.detach()
 
 
 def synthetic_volume_batch(b, patch, n_cls, seed, device):

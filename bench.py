@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--dense_head", type=int, default=0)
     ap.add_argument("--graphs", type=int, default=1)
+    ap.add_argument("--graph_train", type=int, default=0)
     ap.add_argument("--dense_teacher", type=int, default=0)
     ap.add_argument("--cpu_baseline_child", action="store_true")
     a = ap.parse_args()
@@ -86,7 +87,7 @@ def main():
     random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 
     args = T.build_parser().parse_args(["--batch_size", str(a.batch_size), "--queue_size", "4096", "--func", "smc",
-                                        "--synthetic", "1", "--dense_head", str(a.dense_head), "--graphs", str(a.graphs), "--dense_teacher", str(a.dense_teacher)])
+                                        "--synthetic", "1", "--dense_head", str(a.dense_head), "--graphs", str(a.graphs), "--graph_train", str(a.graph_train), "--dense_teacher", str(a.dense_teacher)])
     stepper = T.ArcoStep2D(args, dev)
     b = a.batch_size
     batches = []

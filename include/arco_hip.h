@@ -107,7 +107,7 @@ int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, 
 int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
                     const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
                     uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
-                    void* stream);
+                    const uint64_t* seed_dev /* same device salt as the forward (graph replays), or NULL */, void* stream);
 /* ---- N2/N3  nn.MaxPool2d(2) (unetWithArgs.py:55-58); nn.Upsample(bilinear, align_corners=True)
  *      (unetWithArgs.py:74-75, model_2D.py:43-52)                                                          */
 int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, float* Y, long ldy, void* stream);

@@ -96,3 +96,142 @@ def test_cityscapes_shaped_step_runs():
         loss, reco = st.step(l_img, l_lab, u_img)
         assert torch.isfinite(loss).item()
     assert len(st.memobank) == 19 and all(b[0].shape[1] == 496 for b in st.memobank)
+
+
+def _trainer(graphs, seed_state):
+    from arco_amd import train_arco_2d as T
+    b, patch, C = 2, (64, 64), 4
+    unet_sd, fe_sd, qrep_w = seed_state
+    argv = ["--batch_size", str(b), "--queue_size", "300", "--synthetic", "1", "--num_queries", "64",
+            "--num_negatives", "32", "--k1", "1.0", "--base_lr", "0.01", "--graphs", str(graphs), "--graph_train", str(graphs)]
+    args = T.build_parser().parse_args(argv)
+    args.patch_size = list(patch)
+    st = T.ArcoStep2D(args, "cuda:0")
+    st.model.load_state_dict(unet_sd, strict=True)
+    st.ema_model.load_state_dict(unet_sd, strict=True)
+    st.q_feature_extractor.load_state_dict(fe_sd, strict=True)
+    st.k_feature_extractor.load_state_dict(fe_sd, strict=True)
+    with torch.no_grad():
+        st.q_representation[0].weight.copy_(qrep_w[0])
+        st.q_representation[1].weight.copy_(qrep_w[1])
+    for m in (st.model, st.ema_model):
+        _drop_off(m)
+    from arco_amd import ops
+    ops.bump_weight_epoch()
+    return st
+
+
+def _sync_state(dst, src):
+    """dst <- src: weights, momentum, BN buffers, teacher, banks (so that ONE step is compared from equal state;
+    whole trajectories diverge chaotically from 1-ulp differences of the atomics-based scatters)."""
+    from arco_amd import ops
+    with torch.no_grad():
+        dst.optimizer.flat_p.copy_(src.optimizer.flat_p)
+        dst.optimizer.flat_buf.copy_(src.optimizer.flat_buf)
+        dst.optimizer._started = list(src.optimizer._started)
+        for g_d, g_s in zip(dst.optimizer.param_groups, src.optimizer.param_groups):
+            g_d['lr'] = g_s['lr']
+        for md, ms in ((dst.model, src.model), (dst.ema_model, src.ema_model),
+                       (dst.k_feature_extractor, src.k_feature_extractor)):
+            for (kd, vd), (ks, vs) in zip(md.state_dict().items(), ms.state_dict().items()):
+                assert kd == ks
+                vd.copy_(vs)
+        for c in range(len(src.memobank)):
+            dst.memobank[c] = [t.clone() for t in src.memobank[c]]
+            dst.queue_ptrlis[c] = src.queue_ptrlis[c].clone() if torch.is_tensor(src.queue_ptrlis[c]) else src.queue_ptrlis[c]
+    dst.iter_num = src.iter_num
+    ops.bump_weight_epoch()
+
+
+def test_graphed_student_passes_match_eager():
+    """From equal state, a step whose student passes replay as HIP graphs (graphs.GraphedTrain; steps 3..) gives
+    the losses, weights and banks of the eager step."""
+    b, patch, C = 2, (64, 64), 4
+    seed_state = (fx.unet_state(21, 1, C), fx.fe_state(31), [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]])
+    st_e, st_g = _trainer(0, seed_state), _trainer(1, seed_state)
+    rs = np.random.RandomState(5)
+    for it in range(6):
+        l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32)).cuda()
+        u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32)).cuda()
+        lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C)).cuda()
+        _sync_state(st_g, st_e)
+        terms = []
+        for st in (st_e, st_g):
+            random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
+            st.step(l, lab, u)
+            terms.append({k: float(v) for k, v in st.last_terms.items()})
+        for k in terms[0]:
+            np.testing.assert_allclose(terms[1][k], terms[0][k], rtol=2e-5, atol=1e-6, err_msg=f"step {it} {k}")
+        pe, pg = st_e.optimizer.flat_p, st_g.optimizer.flat_p
+        assert float((pe - pg).abs().max()) <= 1e-5 * float(pe.abs().max()), it
+        for (k, ve), (_, vg) in zip(st_e.model.state_dict().items(), st_g.model.state_dict().items()):
+            if ve.is_floating_point():
+                np.testing.assert_allclose(vg.cpu().numpy(), ve.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=f"{it} {k}")
+            else:
+                assert int(ve) == int(vg), k                      # num_batches_tracked
+        for be, bg in zip(st_e.memobank, st_g.memobank):
+            np.testing.assert_allclose(bg[0].cpu().numpy(), be[0].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert st_g.s_train_u.captured and st_g.s_train_l.captured
+
+
+def test_graphed_unet_pass_is_bit_exact_even_with_a_live_eager_graph():
+    """GraphedTrain(U-Net): outputs and every parameter gradient equal the eager pass bit for bit; the capture
+    happens while an eager autograd graph over the same parameters is alive (as in the step: u pass, then l pass)."""
+    from arco_amd import graphs
+    from arco_amd.networks import unetWithArgs as U
+    torch.manual_seed(0)
+    m = U.UNet(1, 4).cuda().train()
+    _drop_off(m)
+    gt = graphs.GraphedTrain(m, warmup=0)
+    for it in range(3):
+        x = torch.rand(2, 1, 64, 64, device="cuda")
+        bufs = {k: v.clone() for k, v in m.state_dict().items()}
+        pe, _, fe = m(x)
+        ge = torch.autograd.grad([pe.sum() + sum(f.sum() for f in fe)], list(m.parameters()), allow_unused=True,
+                                 retain_graph=True)
+        m.load_state_dict(bufs)                                   # undo the running-stat update
+        pg, _, fg = gt(x)                                         # eager graph (pe, fe) still alive here
+        for p_ in m.parameters():
+            p_.grad = None
+        (pg.sum() + sum(f.sum() for f in fg)).backward()
+        assert torch.equal(pg.detach(), pe.detach())
+        for a, b_ in zip(fg, fe):
+            assert torch.equal(a.detach(), b_.detach())
+        for p_, g in zip(m.parameters(), ge):
+            if g is not None:
+                assert torch.equal(p_.grad, g)
+        del pg, fg, pe, fe, ge
+    assert gt.captured
+
+
+def test_graphed_dropout_mask_is_fresh_and_shared_with_backward():
+    """Dropout inside a captured forward/backward pair: every replay draws a new mask (device salt) and the
+    backward replay uses the mask of ITS forward."""
+    from arco_amd import graphs, ops
+
+    class Drop(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1, device="cuda"))
+
+        def forward(self, x):
+            z = x * self.w                                  # something with a parameter: autograd reaches backward
+            return ops.bn_act(z, None, None, None, None, slope=1.0, p=0.5, drop_mode=1)
+
+    m = Drop()
+    gt = graphs.GraphedTrain(m, warmup=1)
+    masks = []
+    for it in range(5):
+        x = (torch.rand(2, 16, 8, 8, device="cuda") + 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        a = gt(x)
+        a.backward(torch.ones_like(a))
+        a = a.detach()                                      # no autograd graph may survive into the next call
+        keep_f = (a != 0)
+        keep_b = (x.grad != 0)
+        assert torch.equal(keep_f, keep_b), it
+        frac = float(keep_f.float().mean())
+        assert 0.35 < frac < 0.65
+        np.testing.assert_allclose(a[keep_f].cpu().numpy(), (2.0 * x.detach())[keep_f].cpu().numpy(), rtol=1e-6)
+        masks.append(keep_f.cpu())
+    assert gt.captured
+    assert not torch.equal(masks[-1], masks[-2]) and not torch.equal(masks[-2], masks[-3])

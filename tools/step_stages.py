@@ -1,4 +1,5 @@
 import sys, os, time, gc
+os.environ.setdefault('OMP_NUM_THREADS', '4'); os.environ.setdefault('MKL_NUM_THREADS', '4')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from arco_amd import train_arco_2d as T, _contrast as C_
