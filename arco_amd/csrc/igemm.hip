@@ -660,110 +660,122 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // all-taps weight gradient for the shallow layers (Cout, Cin <= 32): one block owns a tile of 8x16 output
 // pixels of one plane, stages the dZ tile and the input HALO patch once in LDS and accumulates all 9 taps of
 // the plane (3-D: the depth tap dd = blockIdx.z, input plane x+dd-1) -> both operands are read from HBM/L2
-// once instead of once per tap.  acc[tap][co_t][ci_t]; A fragment (dZ^T) is shared by the 9 taps.
+// once instead of once per tap.  The A fragment (dZ^T) is shared by the 9 taps.
 // partial layout identical to wgrad_kernel: [chunk][tap][CoutPad][CinPad].
 // ---------------------------------------------------------------------------
+// Persistent over pixel tiles with the NEXT tile's operands prefetched into
+// registers during the MFMAs.  The block's CO_B x CI_B outputs are split into 16x16 sub-tiles; each sub-tile is
+// owned by 4 / n_sub waves for all 9 taps (32x32: one wave per sub-tile walking all 128 pixels -> no cross-wave
+// reduction, 36 accumulator registers instead of 144; 16x32 / 32x16: two waves per sub-tile, 64 pixels each;
+// 16x16: four waves, 32 pixels each), partners are summed once per LAUNCH through LDS.
 template <int CO_B, int CI_B>
-__global__ __launch_bounds__(256) void wgrad_halo_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
   constexpr int LDZ = (CO_B % 32 == 0) ? CO_B + 16 : CO_B;
   constexpr int LDA = (CI_B % 32 == 0) ? CI_B + 16 : CI_B;
-  constexpr int CO_T = CO_B / 16, CI_T = CI_B / 16;
-  constexpr int HROWS = 10 * 18;
+  constexpr int QZ = CO_B / 4, QA = CI_B / 4, HROWS = 10 * 18;
+  constexpr int NZ = (128 * QZ + 255) / 256, NX = (HROWS * QA + 255) / 256;
+  constexpr int CI_T = CI_B / 16, NSUB = (CO_B / 16) * CI_T, WPS = 4 / NSUB, KSTEPS = 32 / WPS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Zs = smem;                 // [128][LDZ]
   float* Xs = smem + 128 * LDZ;     // [180][LDA]   halo patch
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int sub = wid / WPS, part = wid % WPS, wi = sub / CI_T, wj = sub % CI_T;
   const int dd = blockIdx.z;                                   // depth tap (3-D) ; 0 for 2-D
   const int dpl = a.taps == 27 ? dd - 1 : 0;
   const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
   const int ci_tiles = a.CinPad / CI_B;
   const int co0 = (blockIdx.y / ci_tiles) * CO_B, ci0 = (blockIdx.y % ci_tiles) * CI_B;
+  const bool vz = ((a.Cout & 3) == 0) && ((a.ldz & 3) == 0), vx = ((a.Cin & 3) == 0) && ((a.lda & 3) == 0);
 
-  f32x4 acc[9][CO_T][CI_T];
+  f32x4 acc[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int i = 0; i < CO_T; ++i)
-#pragma unroll
-      for (int j = 0; j < CI_T; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
-
-  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
+  f32x4 pz[NZ], px_[NX];
+  auto fetch = [&](int t) {
     int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; const int img = tt / tiles_y;
     const int y0 = ty * 8, x0 = tx * 16;
     const int pl = a.taps == 27 ? img % a.D3 + dpl : 0;
     const bool plane_ok = pl >= 0 && pl < a.D3;
-    __syncthreads();
-    for (int idx = tid; idx < 128 * (CO_B / 4); idx += 256) {
-      const int p = idx / (CO_B / 4), q = idx % (CO_B / 4);
-      const int y = y0 + p / 16, x = x0 + p % 16;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      const int idx = tid + i * 256, p = idx / QZ, q = idx % QZ;
+      const int y = y0 + p / 16, x = x0 + p % 16, c = co0 + 4 * q;
       f32x4 v = f32x4{0, 0, 0, 0};
-      if (y < a.H && x < a.W && plane_ok) {
-        const int c = co0 + 4 * q;
+      if (idx < 128 * QZ && y < a.H && x < a.W && plane_ok) {
         const float* src = a.dZ + (((long)img * a.H + y) * a.W + x) * a.ldz + c;
-        if (((a.Cout & 3) == 0) && ((a.ldz & 3) == 0)) { if (c < a.Cout) v = *reinterpret_cast<const f32x4*>(src); }
+        if (vz) { if (c < a.Cout) v = *reinterpret_cast<const f32x4*>(src); }
         else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (c + e < a.Cout) v[e] = src[e];
         }
       }
-      *reinterpret_cast<f32x4*>(&Zs[p * LDZ + 4 * q]) = v;
+      pz[i] = v;
     }
-    for (int idx = tid; idx < HROWS * (CI_B / 4); idx += 256) {
-      const int r = idx / (CI_B / 4), q = idx % (CI_B / 4);
-      const int y = y0 + r / 18 - 1, x = x0 + r % 18 - 1;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = tid + i * 256, r = idx / QA, q = idx % QA;
+      const int y = y0 + r / 18 - 1, x = x0 + r % 18 - 1, c = ci0 + 4 * q;
       f32x4 v = f32x4{0, 0, 0, 0};
-      if (y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok) {
-        const int c = ci0 + 4 * q;
+      if (idx < HROWS * QA && y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok) {
         const float* src = a.Ain + (((long)(img + dpl) * a.H + y) * a.W + x) * a.lda + c;
-        if (((a.Cin & 3) == 0) && ((a.lda & 3) == 0)) { if (c < a.Cin) v = *reinterpret_cast<const f32x4*>(src); }
+        if (vx) { if (c < a.Cin) v = *reinterpret_cast<const f32x4*>(src); }
         else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (c + e < a.Cin) v[e] = src[e];
         }
       }
-      *reinterpret_cast<f32x4*>(&Xs[r * LDA + 4 * q]) = v;
+      px_[i] = v;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < a.n_tiles) fetch(t);
+  while (t < a.n_tiles) {
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) { const int idx = tid + i * 256; if (idx < 128 * QZ) *reinterpret_cast<f32x4*>(&Zs[(idx / QZ) * LDZ + 4 * (idx % QZ)]) = pz[i]; }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { const int idx = tid + i * 256; if (idx < HROWS * QA) *reinterpret_cast<f32x4*>(&Xs[(idx / QA) * LDA + 4 * (idx % QA)]) = px_[i]; }
+    __syncthreads();
+    const int next = t + gridDim.x;
+    if (next < a.n_tiles) fetch(next);
+#pragma unroll 4
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int p = (part * KSTEPS + ks) * 4 + g, py = p >> 4, pxx = p & 15;
+      const float zf = Zs[p * LDZ + wi * 16 + li];
+      const float* xrow = Xs + (py * 18 + pxx) * LDA + wj * 16 + li;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf, xrow[((tap / 3) * 18 + tap % 3) * LDA], acc[tap], 0, 0, 0);
     }
     __syncthreads();
-    // wave `wid` reduces tile rows 2*wid, 2*wid+1 (32 pixels = 8 k-steps of 4 pixels)
-#pragma unroll 2
-    for (int ks = 0; ks < 8; ++ks) {
-      const int p = wid * 32 + ks * 4 + g;          // pixel of this lane's k index
-      const int py = p / 16, px = p % 16;
-      float zf[CO_T];
+    t = next;
+  }
+  if (WPS > 1) {                      // sum the pixel-split partner waves (once per launch)
+    float* red = smem;                // [4 waves][9][256]
 #pragma unroll
-      for (int i = 0; i < CO_T; ++i) zf[i] = Zs[p * LDZ + i * 16 + li];
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int hr = (py + tap / 3) * 18 + px + tap % 3;
+      for (int r = 0; r < 4; ++r) red[(wid * 9 + tap) * 256 + r * 64 + lane] = acc[tap][r];
+    __syncthreads();
+    if (part == 0) {
 #pragma unroll
-        for (int j = 0; j < CI_T; ++j) {
-          const float xf = Xs[hr * LDA + j * 16 + li];
+      for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-          for (int i = 0; i < CO_T; ++i)
-            acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[i], xf, acc[tap][i][j], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[tap][r];
+#pragma unroll
+          for (int w2 = 1; w2 < WPS; ++w2) v += red[((wid + w2) * 9 + tap) * 256 + r * 64 + lane];
+          acc[tap][r] = v;
         }
-      }
     }
   }
-  // cross-wave reduction through LDS (tap by tap), then slab store
-  float* red = smem;   // [4][CO_B][CI_B]
-  for (int tap = 0; tap < 9; ++tap) {
-    __syncthreads();
+  if (part == 0) {
 #pragma unroll
-    for (int i = 0; i < CO_T; ++i)
+    for (int tap = 0; tap < 9; ++tap) {
+      float* out = a.partial + (((long)blockIdx.x * a.taps + dd * 9 + tap) * a.CoutPad) * a.CinPad;
 #pragma unroll
-      for (int j = 0; j < CI_T; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          red[((wid * CO_B) + i * 16 + 4 * g + r) * CI_B + j * 16 + li] = acc[tap][i][j][r];
-    __syncthreads();
-    const int gtap = dd * 9 + tap;
-    float* out = a.partial + (((long)blockIdx.x * a.taps + gtap) * a.CoutPad) * a.CinPad;
-    for (int idx = tid; idx < CO_B * CI_B; idx += 256) {
-      const int co = idx / CI_B, ci = idx % CI_B;
-      const float v = (red[(0 * CO_B + co) * CI_B + ci] + red[(1 * CO_B + co) * CI_B + ci]) +
-                      (red[(2 * CO_B + co) * CI_B + ci] + red[(3 * CO_B + co) * CI_B + ci]);
-      out[(long)(co0 + co) * a.CinPad + ci0 + ci] = v;
+      for (int r = 0; r < 4; ++r)
+        out[(long)(co0 + wi * 16 + 4 * g + r) * a.CinPad + ci0 + wj * 16 + li] = acc[tap][r];
     }
   }
 }
@@ -950,14 +962,16 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
     a.CoutPad = (Cout + hco - 1) / hco * hco; a.CinPad = (Cin + hci - 1) / hci * hci;
     const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
-    long chunks = 1536 / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
+    // 32x32 blocks run persistent (2 workgroups per CU, several tiles each); the others one slab per ~tile
+    const long target = (hco == 32 && hci == 32) ? 512 : 768;
+    long chunks = target / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
     dim3 hgrid((unsigned)chunks, ydim, zdim);
 #define WH(COB, CIB)                                                                              \
     do {                                                                                          \
       constexpr int LZ = (COB % 32 == 0) ? COB + 16 : COB, LA = (CIB % 32 == 0) ? CIB + 16 : CIB; \
-      size_t sh = (size_t)(128 * LZ + 180 * LA) * 4; const size_t rd = (size_t)4 * COB * CIB * 4; \
-      if (sh < rd) sh = rd;                                                                       \
-      hipLaunchKernelGGL((wgrad_halo_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);             \
+      size_t sh = (size_t)(128 * LZ + 180 * LA) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4;  \
+      if (sh < rd && (COB / 16) * (CIB / 16) < 4) sh = rd;                                        \
+      hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);            \
     } while (0)
     if (hco == 32 && hci == 32) WH(32, 32);
     else if (hco == 32 && hci == 16) WH(32, 16);
