@@ -491,6 +491,9 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
     if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16, true>(a, st, nmb);
     if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 16, true>(a, st, nmb);
     if (a.M * (long)a.Npad <= 4096l * 1024) return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
+    // N-tile 224 (14 sub-tiles, 7 per wave column) when it pads N less than 128 does: 448 = 2 x 224 exactly
+    // (64 x 224: 56 accumulator registers, 3 workgroups per CU; 128 x 224 needs 276 registers -> 1 wave per SIMD)
+    if ((a.Npad + 223) / 224 * 224 < (a.Npad + 127) / 128 * 128) return launch_igemm<1, 64, 224, 2, 2, 16, true>(a, st, nmb);
     return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
   }
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
