@@ -43,6 +43,41 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
 
 // ---- generic per-channel (sum, sumsq) partials of a channels-last tensor (for
 //      tensors not produced by the conv kernel, e.g. the V-Net k2s2 convs)
+// Block-level per-channel totals of (s, q): thread (tq = tid % q4, tr = tid / q4) holds partial sums of the
+// channel quad tq.  Power-of-two q4 <= 64: the lanes of a wave that share a quad differ only in lane bits >= q4 ->
+// xor-shuffle tree, then a 4-wave sum through LDS (the serial rstep-long loop it replaces dominated the kernel
+// for C = 16: 64 dependent LDS reads by 16 threads).  Other q4: the serial loop.
+__device__ __forceinline__ void block_channel_totals(f32x4 s, f32x4 q, int C, float* red /*>= 2048 floats*/,
+                                                     float* __restrict__ out_s, float* __restrict__ out_q, int nblk) {
+  const int q4 = C / 4, rstep = 256 / q4;
+  if ((q4 & (q4 - 1)) == 0 && q4 <= 64) {
+    for (int o = q4; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += __shfl_xor(s[e], o, 64); q[e] += __shfl_xor(q[e], o, 64); }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < q4) {
+      *reinterpret_cast<f32x4*>(&red[w * C + 4 * lane]) = s;
+      *reinterpret_cast<f32x4*>(&red[1024 + w * C + 4 * lane]) = q;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      out_s[(long)c * nblk + blockIdx.x] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
+      out_q[(long)c * nblk + blockIdx.x] = (red[1024 + c] + red[1024 + C + c]) + (red[1024 + 2 * C + c] + red[1024 + 3 * C + c]);
+    }
+    return;
+  }
+  *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s;
+  *reinterpret_cast<f32x4*>(&red[1024 + threadIdx.x * 4]) = q;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int qq = c / 4, e = c % 4;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rstep; ++r) { a += red[(r * q4 + qq) * 4 + e]; b += red[1024 + (r * q4 + qq) * 4 + e]; }
+    out_s[(long)c * nblk + blockIdx.x] = a; out_q[(long)c * nblk + blockIdx.x] = b;
+  }
+}
+
 __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ X, long ldx, long M, int C,
                                                         float* __restrict__ ssum, float* __restrict__ ssq, int nblk) {
   const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
@@ -55,15 +90,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
       s += v; q += v * v;
     }
   extern __shared__ __attribute__((aligned(16))) float red[];   // [2][256][4]
-  *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s;
-  *reinterpret_cast<f32x4*>(&red[1024 + threadIdx.x * 4]) = q;
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int qq = c / 4, e = c % 4;
-    float a = 0.f, b = 0.f;
-    for (int r = 0; r < rstep; ++r) { a += red[(r * q4 + qq) * 4 + e]; b += red[1024 + (r * q4 + qq) * 4 + e]; }
-    ssum[(long)c * nblk + blockIdx.x] = a; ssq[(long)c * nblk + blockIdx.x] = b;
-  }
+  block_channel_totals(s, q, C, red, ssum, ssq, nblk);
 }
 
 // ---- BN apply + LeakyReLU(slope) + dropout:  a = drop(lrelu((z-mean)*istd*gamma+beta))
@@ -148,15 +175,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     }
   }
   extern __shared__ __attribute__((aligned(16))) float red[];
-  *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s;
-  *reinterpret_cast<f32x4*>(&red[1024 + threadIdx.x * 4]) = q;
-  __syncthreads();
-  for (int cc = threadIdx.x; cc < C; cc += 256) {
-    const int qq = cc / 4, e = cc % 4;
-    float a = 0.f, b = 0.f;
-    for (int r = 0; r < rstep; ++r) { a += red[(r * q4 + qq) * 4 + e]; b += red[1024 + (r * q4 + qq) * 4 + e]; }
-    s_dy[(long)cc * nblk + blockIdx.x] = a; s_dyx[(long)cc * nblk + blockIdx.x] = b;
-  }
+  block_channel_totals(s, q, C, red, s_dy, s_dyx, nblk);
 }
 
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int nblk, int C,
@@ -679,7 +698,16 @@ int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long 
   return arco_launch_status();
 }
 
-int arco_chan_stats_blocks(long M) { long b = (M + 511) / 512; if (b > 2048) b = 2048; if (b < 1) b = 1; return (int)b; }
+// slabs for the per-channel reductions: 512 rows per block on big tensors, but never fewer than ~512 blocks while
+// a block still has >= 16 rows (the deep levels have 2048-8192 rows x 128-256 channels: 4-16 blocks left the GPU idle)
+int arco_chan_stats_blocks(long M) {
+  long b = (M + 511) / 512;
+  long fill = (M + 15) / 16; if (fill > 512) fill = 512;
+  if (b < fill) b = fill;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
 
 int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream) {
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldx & 3) == 0);
