@@ -181,6 +181,22 @@ def contrast_masks(label_l, label_u, prob_l, prob_u, low_mask, high_mask, delta_
 # ----------------------------------------------------------------------------------------------
 # stage 2 (host): counters -> bank bookkeeping -> sampler replay      loss_helper_3d.py:413-476
 # ----------------------------------------------------------------------------------------------
+_pin_ring = {"bufs": [], "i": 0}
+
+
+def _pinned_i64(n, depth=3):
+    """Rotating pinned staging buffers for the sampled indices (a buffer is reused `depth` steps later, long after
+    its asynchronous upload has completed)."""
+    r = _pin_ring
+    if len(r["bufs"]) < depth:
+        r["bufs"].append(torch.empty(max(n, 1 << 20), dtype=torch.int64).pin_memory())
+        return r["bufs"][-1]
+    r["i"] = (r["i"] + 1) % depth
+    if r["bufs"][r["i"]].numel() < n:
+        r["bufs"][r["i"]] = torch.empty(n, dtype=torch.int64).pin_memory()
+    return r["bufs"][r["i"]]
+
+
 @torch.no_grad()
 def contrast_sample(pl, memobank, queue_size, func='asmc', num_queries=256, num_negatives=512, _trace=None):
     pl.ready.synchronize()                                  # the one device->host dependency of the loss
@@ -202,17 +218,39 @@ def contrast_sample(pl, memobank, queue_size, func='asmc', num_queries=256, num_
         draw, q_arg, n_arg = torch.randint, (pl.Q,), (pl.Q * pl.Nn,)
     pl.entries = []
     if pl.valid_seg > 1:
-        for k in range(pl.valid_seg):                                   # :435-476, k = LOOP COUNTER
-            vc = pl.valid_classes[k]
-            if pl.n_anchor[k] == 0 or pl.bank_len[vc] == 0:
-                continue
-            a_idx = draw(int(pl.n_anchor[k]), q_arg)
-            n_idx = draw(int(pl.bank_len[vc]), n_arg)
-            pl.entries.append((k, vc, a_idx.pin_memory().to(pl.dev, non_blocking=True),
-                               n_idx.pin_memory().to(pl.dev, non_blocking=True)))
-            if _trace is not None:
-                _trace.setdefault("anchor_idx", []).append(a_idx)
-                _trace.setdefault("neg_idx", []).append(n_idx)
+        ks = [k for k in range(pl.valid_seg)                               # :435-476, k = LOOP COUNTER
+              if not (pl.n_anchor[k] == 0 or pl.bank_len[pl.valid_classes[k]] == 0)]
+        if func in ('asmc', 'smc') and ks:
+            # all 2*len(ks) sampler calls of the step in ONE native call (generator order: anchors k, negatives k,
+            # ...; the big negative draws run in worker threads), written back to back into one pinned buffer
+            # and uploaded with one copy
+            jobs = []
+            for k in ks:
+                jobs += [(int(pl.n_anchor[k]), pl.Q), (int(pl.bank_len[pl.valid_classes[k]]), pl.Q * pl.Nn)]
+            total = sum(sh for _, sh in jobs)
+            host = _pinned_i64(total)
+            views = samplers.grid_sample_many(jobs, func == 'asmc', out=host)
+            dev_all = torch.empty(total, dtype=torch.int64, device=pl.dev)
+            dev_all.copy_(host[:total], non_blocking=True)
+            pl._host_idx = host                                           # keep the staging buffer alive until used
+            off = 0
+            for i, k in enumerate(ks):
+                a_dev = dev_all[off:off + pl.Q]; off += pl.Q
+                n_dev = dev_all[off:off + pl.Q * pl.Nn]; off += pl.Q * pl.Nn
+                pl.entries.append((k, pl.valid_classes[k], a_dev, n_dev))
+                if _trace is not None:
+                    _trace.setdefault("anchor_idx", []).append(views[2 * i].clone())
+                    _trace.setdefault("neg_idx", []).append(views[2 * i + 1].clone())
+        else:
+            for k in ks:
+                vc = pl.valid_classes[k]
+                a_idx = draw(int(pl.n_anchor[k]), q_arg)
+                n_idx = draw(int(pl.bank_len[vc]), n_arg)
+                pl.entries.append((k, vc, a_idx.pin_memory().to(pl.dev, non_blocking=True),
+                                   n_idx.pin_memory().to(pl.dev, non_blocking=True)))
+                if _trace is not None:
+                    _trace.setdefault("anchor_idx", []).append(a_idx)
+                    _trace.setdefault("neg_idx", []).append(n_idx)
     return pl
 
 

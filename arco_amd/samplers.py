@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 __all__ = ["grid_monte_carlo_sample", "grid_as_monte_carlo_sample", "monte_carlo_sample",
-           "as_monte_carlo_sample"]
+           "as_monte_carlo_sample", "grid_sample_many"]
 
 
 def _one_dim(high, shape, patch, mirror):
@@ -122,3 +122,46 @@ def grid_monte_carlo_sample(high=5233, shape=256, cut_count=4):
 def grid_as_monte_carlo_sample(high=5233, shape=256, cut_count=4):
     out = _grid_any(high, shape, cut_count, True)
     return as_monte_carlo_sample(high, shape) if out is None else out
+
+
+@torch.no_grad()
+def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=8):
+    """[(high, shape), ...] -> list of index tensors, the SAME draws as calling grid_(as_)monte_carlo_sample
+    for each job in order, through ONE native call: jobs whose generator consumption does not depend on the drawn
+    values (the negative draws: high = bank length = a perfect square) run in worker threads on copies of the
+    generator state while the generator is skipped ahead (csrc/sampler_host.hip).  `out`: optional int64 CPU
+    tensor of sum(shape) elements (e.g. pinned) that receives the jobs back to back."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    single = grid_as_monte_carlo_sample if mirror else grid_monte_carlo_sample
+    n = len(jobs)
+    total = sum(int(sh) for _, sh in jobs)
+    buf = out if out is not None else torch.empty(total, dtype=torch.int64)
+    assert buf.dtype == torch.int64 and buf.numel() >= total and buf.is_contiguous()
+    views, off = [], 0
+    for _, sh in jobs:
+        views.append(buf[off:off + int(sh)])
+        off += int(sh)
+    if any(int(h) >= 2 ** 31 for h, _ in jobs):
+        for v, (h, sh) in zip(views, jobs):
+            v.copy_(single(int(h), int(sh), cut_count))
+        return views
+    first = 0
+    while first < n:
+        m = n - first
+        highs = (ctypes.c_long * m)(*[int(h) for h, _ in jobs[first:]])
+        shapes = (ctypes.c_long * m)(*[int(sh) for _, sh in jobs[first:]])
+        outs = (ctypes.c_void_p * m)(*[v.data_ptr() for v in views[first:]])
+        st = torch.get_rng_state()
+        rc = lib.arco_grid_sample_many(st.data_ptr(), st.numel(), m, highs, shapes, int(cut_count), int(bool(mirror)),
+                                       outs, int(max_threads))
+        if rc < 0:
+            raise RuntimeError(f"arco_grid_sample_many failed ({rc})")
+        torch.set_rng_state(st)
+        first += int(rc)
+        if first < n:                     # this job takes the reference's 1-D fallback (python `random` + torch)
+            h, sh = jobs[first]
+            views[first].copy_(single(int(h), int(sh), cut_count))
+            first += 1
+    return views

@@ -175,6 +175,11 @@ int arco_entropy_masks(const float* ent, const int64_t* lab_l, const int64_t* la
  *      grid_monte_carlo_sample / grid_as_monte_carlo_sample (loss_helper_3d.py:120-268) on the
  *      serialized torch CPU generator state (torch.get_rng_state()), bit-exact incl. final state.        */
 long arco_grid_sample(uint8_t* state, long state_bytes, long high, long shape, int cut, int mirror, int64_t* out);
+/* a sequence of sampler calls in generator order; value-independent calls run on state copies in worker threads
+ * while the generator is skipped ahead.  Returns the index of the first call that needs the 1-D fallback
+ * (n_jobs when all ran; `state` = generator state right before that call), <0 on error.                       */
+long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const long* highs, const long* shapes, int cut,
+                           int mirror, int64_t* const* outs, int max_threads);
 long arco_randint(uint8_t* state, long state_bytes, long high, long n, int64_t* out);
 
 #ifdef __cplusplus

@@ -66,3 +66,23 @@ def test_native_and_python_paths_agree(monkeypatch):
                 b = S._grid_native(high, shape, 4, mirror); pb = int(torch.randint(1 << 30, (1,)))
                 assert b is not NotImplemented
                 assert torch.equal(a, b) and pa == pb, (high, shape, mirror)
+
+
+@pytest.mark.parametrize("mirror", [False, True])
+def test_grid_sample_many_equals_sequential_calls(mirror):
+    """One threaded multi-call == the same calls one by one (indices AND final generator state), including
+    value-dependent jobs (non-square highs), skipped-ahead jobs (square highs, large shapes) and 1-D fallbacks."""
+    import random
+    from arco_amd import samplers
+    single = samplers.grid_as_monte_carlo_sample if mirror else samplers.grid_monte_carlo_sample
+    jobs = [(5233, 256), (4096, 256 * 512), (90000, 256), (4096, 256 * 512), (13, 256), (1024, 16384), (300, 64),
+            (4096, 256 * 512), (40, 256), (123457, 256), (65536, 40000)]
+    torch.manual_seed(77); random.seed(5)
+    ref = [single(h, sh) for h, sh in jobs]
+    st_ref = torch.get_rng_state().clone()
+    for threads in (0, 1, 8):
+        torch.manual_seed(77); random.seed(5)
+        got = samplers.grid_sample_many(jobs, mirror, max_threads=threads)
+        assert torch.equal(torch.get_rng_state(), st_ref), threads
+        for r, g_ in zip(ref, got):
+            assert torch.equal(r, g_), threads

@@ -17,6 +17,10 @@ for n in ("contrast_masks", "contrast_sample", "contrast_enqueue", "contrast_inf
     wrap(C_, n)
 import arco_amd.head as H
 wrap(H, "lazy_head")
+_es = torch.cuda.Event.synchronize
+def es(self):
+    t0 = time.perf_counter(); r = _es(self); marks.setdefault("event_sync", []).append((time.perf_counter() - t0) * 1e3); return r
+torch.cuda.Event.synchronize = es
 orig_bw = torch.Tensor.backward
 def bw(self, *a, **k):
     t0 = time.perf_counter(); r = orig_bw(self, *a, **k); marks.setdefault("backward", []).append((time.perf_counter() - t0) * 1e3); return r
@@ -34,5 +38,5 @@ for i in range(30):
     tot.append(((t1 - t0) * 1e3, (t2 - t0) * 1e3))
 print("host/wall:", " ".join(f"{a:.0f}/{b:.0f}" for a, b in tot))
 for k, v in marks.items():
-    print(f"{k:18s}", " ".join(f"{x:.0f}" for x in v))
+    print(f"{k:18s}", " ".join(f"{x:.1f}" for x in v[-12:]))
 print("gc:", [(round(a, 1), g) for a, g in gc_t if a > 2][:40])
