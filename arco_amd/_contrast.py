@@ -372,8 +372,9 @@ def contrast_infonce(pl, A_all, memobank, temp=0.5, momentum_prototype=None, i_i
         L.call("arco_sum_scale", L.ptr(loss_q), Q, 1.0 / (Q * valid_seg), L.ptr(loss_acc), 1)
         if need_grad:
             G = torch.empty((Q, Dp), dtype=torch.float32, device=dev)
-            L.call("arco_conv_fwd", L.ptr(W), Lp, Lp, L.ptr(Bt), Dp, L.ptr(G), Dp, None, None, 0, None, None,
-                   1, 1, 1, Q)
+            splits = max(1, min(16, Lp // 256))               # 256 x 496 outputs, K = bank length: split-K fills the GPU
+            ws = torch.empty((splits, Q, Dp), dtype=torch.float32, device=dev)
+            L.call("arco_gemm_splitk", L.ptr(W), Lp, Lp, L.ptr(Bt), Dp, L.ptr(G), Dp, Q, splits, L.ptr(ws))
             dA = torch.empty((Q, Dp), dtype=torch.float32, device=dev)
             L.call("arco_infonce_anchor_grad", L.ptr(G), L.ptr(An), L.ptr(Pn), ldp, L.ptr(gpos), L.ptr(invA),
                    Q, Dp, EPS, 1.0 / (Q * valid_seg), L.ptr(dA))

@@ -25,6 +25,7 @@ struct IgemmArgs {
   int NB, H, W;                      // images (planes for 3-D), rows, cols (TAPS==9); TAPS==1 uses M only
   int D3;                            // 3-D: planes per volume (depth taps active when DEPTH==3); 2-D: 1
   long M;                            // total pixels
+  int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
 };
 
 template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH>
@@ -180,11 +181,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   };
 
   // main loop: the global loads of chunk k+1 are in flight while chunk k is on the matrix cores
-  const int niter = DEPTH * nchunks;
-  load_chunk(0);
-  store_chunk(smem);
+  // (split-K launches: this block covers the chunk range of slab blockIdx.y and writes its own output slab)
+  int c_first = 0, niter = DEPTH * nchunks;
+  if (TAPS == 1 && a.ksplit > 1) {
+    const int per = (nchunks + a.ksplit - 1) / a.ksplit;
+    c_first = blockIdx.y * per;
+    niter = min(nchunks, c_first + per);
+    a.C += (long)blockIdx.y * a.slab_stride;
+  }
+  if (c_first < niter) {
+    load_chunk(c_first);
+    store_chunk(DB ? smem + (c_first & 1) * BUF : smem);
+  }
   __syncthreads();
-  for (int c = 0; c < niter; ++c) {
+  for (int c = c_first; c < niter; ++c) {
     float* cur = DB ? smem + (c & 1) * BUF : smem;
     float* nxt = DB ? smem + ((c + 1) & 1) * BUF : smem;
     const bool more = c + 1 < niter;
@@ -279,7 +289,7 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   IgemmArgs b = a;
   b.n_mblocks = mblocks;
   b.n_nblocks = (a.Npad + BN - 1) / BN;
-  dim3 grid((unsigned)(mblocks * b.n_nblocks));
+  dim3 grid((unsigned)(mblocks * b.n_nblocks), (unsigned)(TAPS == 1 && a.ksplit > 1 ? a.ksplit : 1));
   hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, b);
   return arco_launch_status();
 }
@@ -516,6 +526,15 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int Ci
   if (mode == 0) { if (n < Cout && k < Cin) v = W[((long)n * Cin + k) * taps + tap]; }
   else { if (n < Cin && k < Cout) v = W[((long)k * Cin + n) * taps + (taps - 1 - tap)]; }
   Wp[i] = v;
+}
+
+// out = sum over slabs (fixed order), float4 lanes
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ ws, int splits, long n4, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
+  for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(ws)[(long)k * n4 + i];
+  reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
 // one launch packs every conv weight of a model: desc[i] = {src, dst, Cout, Cin, taps, mode, Npad, Kpad, first}
@@ -901,6 +920,24 @@ int arco_pack_many(const void* desc, int n_desc, long total, void* stream) {
   if (n_desc <= 0 || total <= 0) return ARCO_OK;
   long g = (total + 255) / 256; if (g > 2048) g = 2048;
   hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), (const PackDesc*)desc, n_desc, total);
+  return arco_launch_status();
+}
+
+// out[M][N] = in[M][K] . W[N][K]^T for a SMALL M x N and a LONG K (the InfoNCE anchor gradient: 256 x 496 x ~4600):
+// K is cut into `splits` slabs (grid.y) so the launch has splits x as many workgroups; slabs land in ws
+// (splits * M * ld_out floats) and are summed in fixed order.
+int arco_gemm_splitk(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out, long M,
+                     int splits, float* ws, void* stream) {
+  ARCO_CHECK_ARG(in && Wp && out && ws && K > 0 && N > 0 && M > 0 && splits >= 1 && (ld_out & 3) == 0);
+  IgemmArgs a{};
+  a.A = in; a.lda = ld_in; a.Wp = Wp; a.N = N; a.K = K;
+  a.Npad = (N + 15) / 16 * 16; a.Kpad = (K + 15) / 16 * 16;
+  a.C = ws; a.ldc = ld_out; a.NB = 1; a.H = 1; a.W = (int)M; a.M = M; a.D3 = 1;
+  a.ksplit = splits; a.slab_stride = M * ld_out;
+  const int rc = dispatch_igemm(a, 1, as_stream(stream), nullptr);
+  if (rc != ARCO_OK) return rc;
+  const long n4 = M * ld_out / 4;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), ws, splits, n4, out);
   return arco_launch_status();
 }
 

@@ -73,6 +73,10 @@ int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode,
  * int Cout, Cin, taps, mode, Npad, Kpad; long first;} (arco_pack_desc_bytes() bytes each)                */
 long arco_pack_desc_bytes();
 int arco_pack_many(const void* desc, int n_desc, long total, void* stream);
+/* small-M x N, long-K GEMM (InfoNCE anchor gradient, loss_helper_3d.py:503-509 backward): K split into `splits`
+ * slabs over grid.y, slab outputs in ws (splits*M*ld_out floats), fixed-order sum into out                  */
+int arco_gemm_splitk(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out, long M,
+                     int splits, float* ws, void* stream);
 int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in);
 /* which kernel instantiation a launch uses: igemm_kernel<TAPS,BM,BN,..> -> TAPS*1e6 + BM*1e3 + BN;
  * conv3x3_halo_kernel<CIN,COUT,..> -> 9.9e6 + CIN*1e3 + COUT */
