@@ -42,13 +42,24 @@ class FeatureExtractor(nn.Module):
         return x, f[4]
 
     def forward_lowres2(self, fea_list):
-        """Up to fea2 (third level): returns (fea2(x)+x, f3, f4) for the two-level row-sparse head."""
+        """Up to fea2 (third level): returns (fea2(x)+x, f3, f4) for the two-level row-sparse head.
+
+        Same function as the reference order  x <- fea_i(cat(up(x), f_i)) + cat(up(x), f_i)  (model_2D.py:43-50),
+        evaluated with the 1x1 conv pushed BELOW the upsample: a bias-free 1x1 conv acts per pixel and bilinear
+        interpolation per channel, so they commute, and with W' = W_i + I (residual folded into the weights)
+            x <- up(W'[:, :c] . x) + W'[:, c:] . f_i              (c = channels of the low-resolution x).
+        The wide block of W' (c of the c + c_i input channels) then runs on 4x fewer pixels: 26.3 -> 9.4 GFLOP for
+        fea2 at config 2 (and the same factor in its dgrad / wgrad).  Values differ from the reference order by
+        fp32 rounding only (tests/test_head_gpu.py)."""
         f = [ops.to_channels_last(t) for t in fea_list]
         x = ops.conv(f[0], self.fea0.weight, None, residual=True)
         for i, fea in enumerate((self.fea1, self.fea2), start=1):
-            x = ops.bilinear(x, f[i].shape[-2:])
-            x = torch.cat((x, f[i]), dim=1)
-            x = ops.conv(x, fea.weight, None, residual=True)
+            c = int(x.shape[1])
+            n = c + int(f[i].shape[1])
+            w = fea.weight.view(n, n) + torch.eye(n, dtype=torch.float32, device=x.device)
+            lo = ops.conv(x, w[:, :c].contiguous().view(n, c, 1, 1))                 # at the low resolution
+            x = ops.conv(f[i], w[:, c:].contiguous().view(n, n - c, 1, 1), None,
+                         residual=ops.bilinear(lo, f[i].shape[-2:]))
         return x, f[3], f[4]
 
     def forward(self, fea_list):

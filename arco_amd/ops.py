@@ -258,10 +258,16 @@ class ConvFn(torch.autograd.Function):
         xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
         wp = pack_weight(weight, taps, 0)
-        y, _ = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, residual=xr if residual else None,
-                        ld_res=ld if residual else 0, d3=d3, sp=sp)
+        if isinstance(residual, torch.Tensor):              # y = conv(x) + R  (R: any tensor of y's shape)
+            rr, ldr = rows_view(residual)
+            res_self = False
+        else:                                               # True: y = conv(x) + x
+            rr, ldr = (xr, ld) if residual else (None, 0)
+            res_self = bool(residual)
+        y, _ = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, residual=rr, ld_res=ldr, d3=d3, sp=sp)
         ctx.save_for_backward(x, weight)
-        ctx.residual, ctx.has_bias, ctx.taps = residual, bias is not None, taps
+        ctx.residual, ctx.has_bias, ctx.taps = res_self, bias is not None, taps
+        ctx.res_tensor = isinstance(residual, torch.Tensor)
         return y
 
     @staticmethod
@@ -280,7 +286,7 @@ class ConvFn(torch.autograd.Function):
             dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dyr, ldy, nv * d3 * h * w, co)
-        return dx, dw, db, None
+        return dx, dw, db, (dy if ctx.res_tensor and ctx.needs_input_grad[3] else None)
 
 
 def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out):
