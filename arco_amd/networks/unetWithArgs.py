@@ -19,12 +19,12 @@ def _bn_eval_stats(bn):
     return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
 
 
-def _stage(x, conv, bn, act, drop_p, training, drop_mode=1):
+def _stage(x, conv, bn, act, drop_p, training, drop_mode=1, cat_room=0):
     slope = getattr(act, "negative_slope", 0.0)
     if training:
         y = ops.conv_bn_act(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                             slope=slope, p=drop_p, drop_mode=drop_mode, momentum=bn.momentum, eps=bn.eps,
-                            num_batches_tracked=bn.num_batches_tracked)
+                            num_batches_tracked=bn.num_batches_tracked, cat_room=cat_room)
         return y
     return ops.conv_bn_act_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 slope=slope, eps=bn.eps)
@@ -45,10 +45,12 @@ class ConvBlock(nn.Module):
             nn.LeakyReLU(),
         )
 
+    cat_room = 0      # Encoder sets it on the blocks whose output is a skip connection (see ops.upcat)
+
     def forward(self, x):
         s = self.conv_conv
         x = _stage(x, s[0], s[1], s[2], s[3].p, self.training)
-        return _stage(x, s[4], s[5], s[6], 0.0, self.training)
+        return _stage(x, s[4], s[5], s[6], 0.0, self.training, cat_room=self.cat_room)
 
 
 class DownBlock(nn.Module):
@@ -78,8 +80,11 @@ class UpBlock(nn.Module):
 
     def forward(self, x1, x2):
         x1 = ops.conv(x1, self.conv1x1.weight, self.conv1x1.bias)
-        x1 = ops.bilinear(x1, (x1.shape[2] * 2, x1.shape[3] * 2))
-        x = torch.cat([x2, x1], dim=1)
+        if (x1.shape[2] * 2, x1.shape[3] * 2) == tuple(x2.shape[2:]):
+            x = ops.upcat(x1, x2)                       # cat([x2, up(x1)]) written in place behind the skip
+        else:
+            x1 = ops.bilinear(x1, (x1.shape[2] * 2, x1.shape[3] * 2))
+            x = torch.cat([x2, x1], dim=1)
         return self.conv(x)
 
 
@@ -98,6 +103,10 @@ class Encoder(nn.Module):
         self.down2 = DownBlock(self.ft_chns[1], self.ft_chns[2], self.dropout[2])
         self.down3 = DownBlock(self.ft_chns[2], self.ft_chns[3], self.dropout[3])
         self.down4 = DownBlock(self.ft_chns[3], self.ft_chns[4], self.dropout[4])
+        # x0..x3 are concatenated with an equally wide upsampled tensor in the decoder: write them with room for it
+        self.in_conv.cat_room = self.ft_chns[0]
+        for blk, c in ((self.down1, self.ft_chns[1]), (self.down2, self.ft_chns[2]), (self.down3, self.ft_chns[3])):
+            blk.maxpool_conv[1].cat_room = c
 
     def forward(self, x):
         x = ops.to_channels_last(x.to(torch.float32))

@@ -289,10 +289,11 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, (dy if ctx.res_tensor and ctx.needs_input_grad[3] else None)
 
 
-def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out):
+def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out, ld_out=None):
     seed_dev = SEED_DEV if (p > 0 and torch.cuda.is_current_stream_capturing()) else None
     L.call("arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
-           float(slope), int(drop_mode), float(p), seed, P, L.ptr(out), co, L.ptr(seed_dev))
+           float(slope), int(drop_mode), float(p), seed, P, L.ptr(out), co if ld_out is None else ld_out,
+           L.ptr(seed_dev))
     return seed_dev
 
 
@@ -330,7 +331,8 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps,
-                nbt=None):
+                nbt=None, cat_room=0):
+        global _LAST_CAT_BUF
         L.require_gpu(x, weight)
         taps = _taps(weight)
         xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
@@ -343,9 +345,15 @@ class ConvBnActFn(torch.autograd.Function):
         L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
                L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt))
         seed = _next_seed() if p > 0 else 0
-        a = new_act_nd(nv, co, sp, x.device)
+        if cat_room:        # leave room behind the channels for a later in-place channel concat (ops.upcat)
+            buf = new_act_nd(nv, co + int(cat_room), sp, x.device)
+            a, ld_a = buf[:, :co], co + int(cat_room)
+            _LAST_CAT_BUF = buf
+        else:
+            a, ld_a = new_act_nd(nv, co, sp, x.device), co
         zr, ldz = rows_view(z)
-        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w, a)
+        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w, a,
+                                 ld_a)
         ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta)
         ctx.cfg = (taps, float(slope), float(p), int(drop_mode), seed, bias is not None)
         ctx.bias_param = bias
@@ -376,7 +384,7 @@ class ConvBnActFn(torch.autograd.Function):
                 b._arco_mark()          # += 0 into the flat gradient: nothing to launch, the optimiser still steps it
             else:
                 db = _zeros_cached((co,), da.device)
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 class BnActFn(torch.autograd.Function):
@@ -512,11 +520,51 @@ def conv(x, weight, bias=None, residual=False):
     return ConvFn.apply(x, weight, bias, residual)
 
 
+_LAST_CAT_BUF = None
+
+
 def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, slope=0.01, p=0.0, drop_mode=1,
-                momentum=0.1, eps=1e-5, num_batches_tracked=None):
-    """`num_batches_tracked` (int64 buffer) is incremented inside the BN finalize kernel."""
-    return ConvBnActFn.apply(x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode,
-                             momentum, eps, num_batches_tracked)
+                momentum=0.1, eps=1e-5, num_batches_tracked=None, cat_room=0):
+    """`num_batches_tracked` (int64 buffer) is incremented inside the BN finalize kernel.
+    cat_room > 0: the result is written as the leading channels of a buffer with `cat_room` more channels
+    (`result._arco_cat_buf`), so that `upcat` can append an upsampled tensor behind it without a copy."""
+    global _LAST_CAT_BUF
+    y = ConvBnActFn.apply(x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode,
+                          momentum, eps, num_batches_tracked, cat_room)
+    if cat_room:
+        y._arco_cat_buf, _LAST_CAT_BUF = _LAST_CAT_BUF, None
+    return y
+
+
+class UpCatFn(torch.autograd.Function):
+    """cat([skip, bilinear_x2(x)], dim=1) (unetWithArgs.py:80-83) without the concat copy: `skip` already is the
+    leading channel block of `buf` (conv_bn_act(cat_room=...)); the upsample writes the trailing block in place."""
+
+    @staticmethod
+    def forward(ctx, x, skip, buf):
+        xr, ld, nb, c, h, w = _geom(x)
+        c2, ho, wo = int(skip.shape[1]), int(skip.shape[2]), int(skip.shape[3])
+        ctot = int(buf.shape[1])
+        L.call("arco_bilinear_fwd", L.ptr(xr), ld, nb, h, w, c, ho, wo, L.ptr(buf[:, c2:]), ctot)
+        ctx.dims = (nb, c, h, w, ho, wo, c2)
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        nb, c, h, w, ho, wo, c2 = ctx.dims
+        dr, ldd = rows_view(dbuf)
+        dx = new_act(nb, c, h, w, dbuf.device)
+        L.call("arco_bilinear_bwd", L.ptr(dr[:, c2:]), ldd, nb, h, w, c, ho, wo, L.ptr(dx), c, 0)
+        return dx, dbuf[:, :c2], None
+
+
+def upcat(x, skip):
+    """cat([skip, bilinear(x, skip.shape[-2:])], 1); in place when `skip` came with concat room."""
+    buf = getattr(skip, "_arco_cat_buf", None)
+    if (buf is None or buf.shape[1] != skip.shape[1] + x.shape[1] or buf.data_ptr() != skip.data_ptr()
+            or buf.shape[0] != x.shape[0]):
+        return torch.cat([skip, bilinear(x, skip.shape[-2:])], dim=1)
+    return UpCatFn.apply(x, skip, buf)
 
 
 def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, slope=0.01, eps=1e-5):
