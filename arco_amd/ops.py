@@ -12,7 +12,9 @@ from ._contrast import rows_view
 
 _drop_gen = None
 SEED_DEV = None     # device uint64 salt for dropout masks of graph-captured forwards (graphs.py)
-PROFILE = None      # bench.py sets a dict: (taps, M, N, K) -> [(start_event, end_event)] per conv launch
+PROFILE = None       # bench.py sets a dict: kernel instantiation id -> {n, flop, timed: [(ev0, ev1, flop, (taps, M, N, K))]}
+_cfg_cache = {}
+PROFILE_EVERY = 1    # time every n-th conv launch of an instantiation (bench.py: 7, prime vs the per-step launch counts)
 
 
 def _next_seed():
@@ -188,16 +190,25 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, k, n, ld)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
-    prof = PROFILE is not None and not torch.cuda.is_current_stream_capturing()
-    if prof:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
+    prof = cfg = None
+    if PROFILE is not None and not torch.cuda.is_current_stream_capturing():
+        # every launch is counted; every PROFILE_EVERY-th one is bracketed by HIP events on the launch stream
+        # (an event pair per launch costs ~1.5 ms/step of stream bubbles at ~350 conv launches per step)
+        key = (taps, nb * d3, h, w, k, n, ld)
+        cfg = _cfg_cache.get(key)
+        if cfg is None:
+            cfg = _cfg_cache[key] = L.query("arco_conv_config", *key, None)       # kernel instantiation id
+        rec = PROFILE.setdefault(cfg, {"n": 0, "flop": 0.0, "timed": []})
+        rec["n"] += 1
+        rec["flop"] += 2.0 * taps * nb * d3 * h * w * n * k
+        if rec["n"] % PROFILE_EVERY == 1 % PROFILE_EVERY:
+            prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            prof[0].record()
     L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
            L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w)
-    if prof:
-        ev[1].record()
-        cfg = L.query("arco_conv_config", taps, nb * d3, h, w, k, n, ld, None)  # kernel instantiation id
-        PROFILE.setdefault(cfg, []).append((ev[0], ev[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
+    if prof is not None:
+        prof[1].record()
+        PROFILE[cfg]["timed"].append((prof[0], prof[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
     return out, (ssum, ssq, nmb)
 
 

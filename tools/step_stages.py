@@ -3,7 +3,7 @@ os.environ.setdefault('OMP_NUM_THREADS', '4'); os.environ.setdefault('MKL_NUM_TH
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from arco_amd import train_arco_2d as T, _contrast as C_
-args = T.build_parser().parse_args(["--batch_size", "8", "--queue_size", "4096", "--synthetic", "1", "--graphs", "1"])
+args = T.build_parser().parse_args(["--batch_size", "8", "--queue_size", "4096", "--synthetic", "1", "--graphs", "1", "--graph_train", os.environ.get("GT", "0")])
 st = T.ArcoStep2D(args, "cuda:0")
 l, ll = T.synthetic_batch(8, args.patch_size, 4, 1, "cuda:0")
 u, _ = T.synthetic_batch(8, args.patch_size, 4, 2, "cuda:0")
