@@ -106,6 +106,36 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
   // graph-captured forwards read a per-replay salt from device memory (fresh masks on every replay)
   const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
+  if (mean && 256 % q4 == 0) {
+    // a thread keeps ONE channel quad for the whole sweep (the grid stride is a multiple of q4): the four
+    // per-channel parameters are loaded once, and four rows are in flight per trip
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x, rstride = (long)gridDim.x * 256 / q4;
+    const int c = (int)(gt % q4) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(istd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    for (long rb = gt / q4; rb < M; rb += 4 * rstride) {
+      f32x4 z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const long r = rb + u * rstride; if (r < M) z[u] = *reinterpret_cast<const f32x4*>(Z + r * ldz + c); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long r = rb + u * rstride;
+        if (r < M) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float y = (z[u][e] - mu[e]) * is[e] * ga[e] + be[e];
+            y = y >= 0.f ? y : y * slope;
+            if (drop_mode == 1) y = drop_keep(seed, (uint64_t)(r * C + c + e), p) ? y * keep_scale : 0.f;
+            else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)((r / P) * C + c + e), p) ? y * keep_scale : 0.f;
+            o[e] = y;
+          }
+          *reinterpret_cast<f32x4*>(Aout + r * lda + c) = o;
+        }
+      }
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
     const long r = i / q4; const int c = (int)(i - r * q4) * 4;
     const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
@@ -203,6 +233,38 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   const int q4 = C / 4;
   const long tot = M * q4;
   const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
+  if (mean && 256 % q4 == 0) {          // one channel quad per thread, parameters hoisted, two rows in flight
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x, rstride = (long)gridDim.x * 256 / q4;
+    const int c = (int)(gt % q4) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(istd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 sd = *reinterpret_cast<const f32x4*>(sum_dy + c), sx = *reinterpret_cast<const f32x4*>(sum_dyx + c);
+    for (long rb = gt / q4; rb < M; rb += 2 * rstride) {
+      f32x4 z[2], d[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long r = rb + u * rstride;
+        if (r < M) { z[u] = *reinterpret_cast<const f32x4*>(Z + r * ldz + c); d[u] = *reinterpret_cast<const f32x4*>(dA + r * ldd + c); }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long r = rb + u * rstride;
+        if (r < M) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint64_t ei = drop_mode == 2 ? (uint64_t)((r / P) * C + c + e) : (uint64_t)(r * C + c + e);
+            const float xh = (z[u][e] - mu[e]) * is[e];
+            const float y = xh * ga[e] + be[e];
+            const float dy = bn_dy(d[u][e], y, slope, drop_mode, p, keep_scale, seed, ei);
+            o[e] = ga[e] * is[e] * (dy - sd[e] * inv_count - xh * sx[e] * inv_count);
+          }
+          *reinterpret_cast<f32x4*>(dZ + r * ldo + c) = o;
+        }
+      }
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
     const long r = i / q4; const int c = (int)(i - r * q4) * 4;
     const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
