@@ -110,7 +110,16 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """The current torch HIP stream of the current device as a hipStream_t.  torch.cuda.current_stream() costs
+    ~9 us of Python per call (device-index plumbing); the raw accessors cost ~0.3 us - at ~500 launches per step
+    that is 4 ms of host time."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
