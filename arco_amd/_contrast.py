@@ -34,6 +34,8 @@ LOW_RANK, HIGH_RANK = 3, 20                        # (loss_helper_3d.py:318)
 key_gather_hook = None
 # companion hook: callable(list[int] per-class local counts) -> list[int] global counts
 count_gather_hook = None
+# callable(keys[n,D], cls, queue_size) -> only the rows that survive the FIFO truncation (rank order)
+tail_gather_hook = None
 
 
 def _ceil(x, m):
@@ -300,7 +302,9 @@ def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace
     pl.new_keys = []
     for c in range(C):
         keys = key_rows[c]
-        if key_gather_hook is not None:
+        if tail_gather_hook is not None:
+            keys = tail_gather_hook(keys.contiguous(), c, int(queue_size[c]))
+        elif key_gather_hook is not None:
             keys = key_gather_hook(keys.contiguous())
         _append(keys, int(pl.n_neg_all[c]), memobank[c], queue_prtlis[c], int(queue_size[c]))
         assert int(memobank[c][0].shape[0]) == pl.bank_len[c]

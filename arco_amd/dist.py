@@ -4,10 +4,13 @@ xGMI on ROCm).  SURVEY §8e.  The path shards by batch; three exchange steps exi
  1. gradient all-reduce (mean) - ONE collective on the optimiser's flat fp32 gradient buffer
     (12.8 MB for the 2-D model).  xGMI is point-to-point (7 links/GPU): a single large message
     lets RCCL drive all links instead of paying per-bucket latency.
- 2. all-gather-v of the new negative keys of each class (counts first, then rows padded to the
-    max count), concatenated in rank order before the FIFO truncation, so every rank holds a
-    bit-identical bank - the `gather_together(keys)` the reference left commented out
-    (loss_helper_3d.py:16-17).
+ 2. exchange of the new negative keys of each class so that every rank holds a bit-identical bank - the
+    `gather_together(keys)` the reference left commented out (loss_helper_3d.py:16-17): the bank keeps the
+    LAST queue_size rows of cat(rank 0 keys, rank 1 keys, ...).  The per-rank counts of all classes travel in
+    ONE all-gather per step (gather_counts); every rank then knows which (rank, row range) survive the
+    truncation and only those rows are broadcast (gather_tail_keys) - typically the last rank's queue_size
+    rows: 8 MB per class instead of world x 8 MB, no host synchronisation.  gather_keys is the generic
+    all-gather-v (counts, then rows padded to the max count) behind the public dequeue_and_enqueue.
  3. (optional) all-reduce of prototype partial sums - not enabled: prototypes are per-rank means,
     like the per-replica statistics under the reference's nn.DataParallel.
 Works unchanged with backend "gloo" on CPU tensors for the world_size-2 tests.
@@ -44,6 +47,7 @@ def init(backend=None):
     if is_dist():
         _contrast.key_gather_hook = gather_keys
         _contrast.count_gather_hook = gather_counts
+        _contrast.tail_gather_hook = gather_tail_keys
         return td.get_rank(), td.get_world_size()
     return 0, 1
 
@@ -86,10 +90,45 @@ def gather_keys(keys):
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
+_rank_counts = None      # [world][C] local key counts of the current step (set by gather_counts)
+
+
 def gather_counts(counts):
     """Per-class key counts summed over ranks (host ints in, host ints out): bank lengths and queue
-    pointers are then identical on every rank."""
+    pointers are then identical on every rank.  One all-gather of the C-vector; the per-rank table is kept
+    for gather_tail_keys."""
+    global _rank_counts
     dev = torch.device("cuda", local_rank()) if td.get_backend() == "nccl" else torch.device("cpu")   # tiny, host-side
     t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=dev)
-    td.all_reduce(t, op=td.ReduceOp.SUM)
-    return [int(v) for v in t.tolist()]
+    allc = [torch.empty_like(t) for _ in range(td.get_world_size())]
+    td.all_gather(allc, t)
+    _rank_counts = [[int(v) for v in a.tolist()] for a in allc]
+    return [sum(r[c] for r in _rank_counts) for c in range(len(counts))]
+
+
+@torch.no_grad()
+def gather_tail_keys(keys, cls, queue_size):
+    """The rows of cat_r(keys_r) that survive `[-queue_size:]`, for class `cls`: keys_r = the last
+    min(n_r, queue_size) new keys of rank r (n_r from this step's gather_counts).  Walks the ranks from the last
+    one down until queue_size rows are covered; each contributing rank broadcasts exactly its surviving rows.
+    Returns them concatenated in rank order (>= the last min(sum n_r, queue_size) keys, what _append needs)."""
+    world, rank = td.get_world_size(), td.get_rank()
+    rows = [min(int(_rank_counts[r][cls]), int(queue_size)) for r in range(world)]
+    assert rows[rank] == int(keys.shape[0]), (rows, rank, keys.shape)
+    need, take = int(queue_size), [0] * world
+    for r in range(world - 1, -1, -1):
+        take[r] = min(rows[r], need)
+        need -= take[r]
+    pieces = []
+    for r in range(world):
+        if take[r] == 0:
+            continue
+        if r == rank:
+            buf = keys[rows[r] - take[r]:].contiguous()
+        else:
+            buf = torch.empty((take[r], keys.shape[1]), dtype=keys.dtype, device=keys.device)
+        td.broadcast(buf, src=r)
+        pieces.append(buf)
+    if not pieces:
+        return keys[:0]
+    return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=0)

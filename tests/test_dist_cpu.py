@@ -56,6 +56,21 @@ def _worker(rank, world, port, q):
     gathered = [torch.empty_like(bank) for _ in range(world)]
     td.all_gather(gathered, bank)
     assert all(torch.equal(g, bank) for g in gathered)
+    # 6. tail gather: only the rows that survive the truncation travel; the bank equals the all-gather-v one
+    D = 4
+    for qs, n_by_rank in ((8, [20, 3]), (8, [5, 20]), (8, [2, 3]), (8, [0, 5]), (8, [6, 0]), (8, [0, 0]), (5, [5, 5])):
+        n = n_by_rank[rank]
+        full = torch.arange(n * D, dtype=torch.float32).view(n, D) + 1000 * rank + 7 * qs
+        adist.gather_counts([0, n, 1])                       # class 1 carries this case's counts
+        mine = full[max(0, n - qs):]                           # the last min(n, qs) local rows
+        tail = adist.gather_tail_keys(mine, 1, qs)
+        ref = adist.gather_keys(mine)
+        n_all = sum(n_by_rank)
+        old_bank = torch.full((3, D), -1.0)
+        banks = [torch.cat((old_bank, got))[-qs:] for got in (tail, ref)]     # CPU emulation of _append's FIFO
+        assert torch.equal(banks[0], banks[1]), (rank, qs, n_by_rank)
+        assert n_all >= 0
+        assert tail.shape[0] == min(qs, sum(min(m, qs) for m in n_by_rank))
     td.barrier()
     q.put((rank, "ok"))
 
