@@ -32,7 +32,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 # HBM bytes per launch from the PMC passes in profiles/r01_pmc_gemm_traffic.md (FETCH_SIZE x2 + WRITE_SIZE), by (M, N, K)
-PMC_TRAFFIC_BYTES = {(1048576, 496, 496): 5.595e9, (262144, 480, 480): 1.240e9}
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes):
+# profiles/r01_pmc_conv_traffic.md (3x3 backbone kernel) and profiles/r01_pmc_gemm_traffic.md; key (taps, M, N, K)
+PMC_TRAFFIC_BYTES = {(9, 32768, 64, 64): 1.840e7, (9, 32768, 64, 128): 2.797e7,
+                     (1, 1048576, 496, 496): 5.595e9, (1, 262144, 480, 480): 1.240e9}
 
 
 def cpu_baseline_child():
@@ -149,7 +152,7 @@ def main():
             kid = (f"conv3x3_halo_kernel<{(cfg - 9900000) // 1000},{cfg % 1000},..>" if cfg >= 9900000
                    else f"igemm_kernel<{cfg // 1000000},{cfg // 1000 % 1000},{cfg % 1000},...>")
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get((m, n, k)),
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get((taps, m, n, k)),
                     "kernel": kid + " (fp32 MFMA 16x16x4 implicit GEMM)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": rec["n"], "launches_timed": len(launches),
                     "avg_flop_per_launch": avg_flop, "share_of_step": round(tot[cfg] / (dt * 1e3), 4),
