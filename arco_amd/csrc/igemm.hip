@@ -496,6 +496,87 @@ static int dispatch_halo(const IgemmArgs& a, hipStream_t st, int* q) {
   if (a.K == 16) return a.Npad <= 16 ? launch_halo<16, 16, 32>(a, st, q) : launch_halo<16, 32, 32>(a, st, q);
   return a.Npad <= 16 ? launch_halo<32, 16, 16>(a, st, q) : launch_halo<32, 32, 16>(a, st, q);
 }
+// ---------------------------------------------------------------------------
+// 3x3 convolution of an IMAGE (Cin <= 4: the network's first layer, 1 or 3 input channels) to 16 channels.
+// 9*Cin <= 36 multiply-adds per output value: far too little K for the matrix pipe (the MFMA path pads K to 16
+// and spends 16x the work) - this is a streaming kernel: 2 MB in, 33.5 MB out at 8x256x256.  A lane owns 4
+// output channels of one pixel (16-byte coalesced stores), the 6x18 input halo and the weights sit in LDS,
+// workgroups are persistent so the BN partials stay <= 1024 slabs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_image_kernel(IgemmArgs a) {
+  constexpr int TH = 16, TW = 16, HW_ = TW + 2, NP = (TH + 2) * HW_;
+  __shared__ float Xs[4][NP];            // [k][halo pixel]
+  __shared__ __attribute__((aligned(16))) float Ws[9 * 4 * 16];   // [tap][k][n]
+  __shared__ float red[2][4][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int pl = tid >> 2, qd = tid & 3;                         // pixel of the tile (0..63), channel quad
+  const int K = a.K;
+  for (int u = tid; u < 9 * 4 * 16; u += 256) {
+    const int n = u & 15, k = (u >> 4) & 3, tap = u >> 6;
+    Ws[u] = (k < K && n < a.Npad) ? a.Wp[((long)tap * a.Npad + n) * a.Kpad + k] : 0.f;
+  }
+  f32x4 bias4 = {0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) if (a.bias && 4 * qd + e < a.N) bias4[e] = a.bias[4 * qd + e];
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const long n_tiles = (long)a.NB * tiles_y * tiles_x;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tx = t % tiles_x; const long r = t / tiles_x; const int ty = r % tiles_y; const int nb = r / tiles_y;
+    __syncthreads();
+    for (int u = tid; u < NP * K; u += 256) {
+      const int k = u % K, hp = u / K, hy = hp / HW_, hx = hp % HW_;
+      const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
+      Xs[k][hp] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? a.A[(((long)nb * a.H + gy) * a.W + gx) * a.lda + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TH * TW / 64; ++i) {                     // 4 pixels per lane: rows py, py + 4, ...
+      const int p = pl + 64 * i, py = p / TW, px = p % TW;
+      f32x4 acc = bias4;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int hp = (py + tap / 3) * HW_ + px + tap % 3;
+        for (int k = 0; k < K; ++k) {
+          const float x = Xs[k][hp];
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(&Ws[(tap * 4 + k) * 16 + 4 * qd]);
+          acc += wv * x;
+        }
+      }
+      const int gy = ty * TH + py, gx = tx * TW + px;
+      if (gy < a.H && gx < a.W && 4 * qd < a.N) {
+        const long pix = ((long)nb * a.H + gy) * a.W + gx;
+        *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + 4 * qd) = acc;
+        s1 += acc; s2 += acc * acc;
+      }
+    }
+  }
+  if (a.stat_sum) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v1 = s1[e], v2 = s2[e];
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+      if (lane < 4) { red[0][w][4 * lane + e] = v1; red[1][w][4 * lane + e] = v2; }
+    }
+    __syncthreads();
+    if (tid < 16 && tid < a.N) {
+      a.stat_sum[(long)tid * a.n_mblocks + blockIdx.x] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+      a.stat_sq[(long)tid * a.n_mblocks + blockIdx.x] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+    }
+  }
+}
+static bool image_conv_eligible(const IgemmArgs& a) {
+  return a.K <= 4 && a.Npad == 16 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && a.R == nullptr;
+}
+static int launch_image_conv(const IgemmArgs& a, hipStream_t st, int* q) {
+  const long n_tiles = (long)a.NB * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+  long blocks = n_tiles < 1024 ? n_tiles : 1024;
+  if (q) { q[0] = (int)blocks; q[1] = 9 * 1000000 + 800000 + a.K * 1000 + 16; q[2] = 10; return ARCO_OK; }
+  IgemmArgs b = a; b.n_mblocks = (int)blocks; b.n_nblocks = 1;
+  hipLaunchKernelGGL(conv3x3_image_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+  return arco_launch_status();
+}
 static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb) {
   if (taps == 1) {
     if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16, true>(a, st, nmb);
@@ -507,6 +588,7 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
     return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
   }
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
+  if (taps == 9 && image_conv_eligible(a)) return launch_image_conv(a, st, nmb);
   if (taps == 9) return halo_eligible(a) ? dispatch_halo(a, st, nmb) : dispatch_spatial<1>(a, st, nmb);
   return ARCO_ERR_UNSUPPORTED;
 }
