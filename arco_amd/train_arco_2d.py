@@ -166,7 +166,6 @@ class ArcoStep2D:
         # no-grad forwards replayed as HIP graphs (one graph per call site: outputs are static buffers)
         use_graphs = bool(getattr(args, "graphs", 1))
         g_train = use_graphs and bool(getattr(args, "graph_train", 0))
-        self.stats_pass_early = bool(g_train)
         sub = os.environ.get("ARCO_GT_SUBSET", "ul")
         self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train and "u" in sub)    # student passes: fwd + bwd graphs
         self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train and "l" in sub)
@@ -217,13 +216,9 @@ class ArcoStep2D:
         pred_l, _, l_fm = self.s_train_l(l_data)                             # :310
         with torch.no_grad():
             # images_cj2_l forward (:311): BN running statistics only - its FE/q_rep outputs (l_feature_map_2,
-            # :319,326) are never read.  One graph launch (~1 ms of GPU work) whose place in the queue is free:
-            # with eager student passes the host is the slower side and the launch goes right AFTER the host sync
-            # (work for the GPU while the launch-bound head / loss section is issued); with graphed student
-            # passes the host runs ahead and it goes BEFORE the sync (work for the GPU while the host samples).
-            # Measured: 15.4 vs 16.3 ms/step (eager), 16.1 vs 16.4 (graphed).
-            if self.stats_pass_early:
-                self.s_fwd_stats(l_data)
+            # :319,326) are never read.  One graph launch (~1 ms of GPU work) queued BEFORE the host sync: work for
+            # the GPU while the host replays the samplers (14.8 vs 15.1 ms/step when queued after the sync).
+            self.s_fwd_stats(l_data)
             # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
             fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
             if getattr(a, "dense_teacher", 0) or dense:
@@ -244,9 +239,6 @@ class ArcoStep2D:
             x2p, f3, f4 = self.q_feature_extractor.forward_lowres2(fm_all)
         # ---- host: sampler replay (bit-exact torch-CPU-generator sequence), overlapped with the above
         C_.contrast_sample(plan, self.memobank, self.queue_size, a.func, a.num_queries, a.num_negatives)
-        if not self.stats_pass_early:
-            with torch.no_grad():
-                self.s_fwd_stats(l_data)
         ev2 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev2[0].record()
         C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size,
