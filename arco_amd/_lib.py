@@ -36,10 +36,10 @@ _SIGS = {
     "arco_conv_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "arco_colsum": [_P, _L, _L, _I, _P, _P, _I, _P],
     "arco_transpose2d": [_P, _L, _I, _I, _P, _L, _P],
-    "arco_bn_finalize": [_P, _P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P],
+    "arco_bn_finalize": [_P, _P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "arco_chan_stats": [_P, _L, _L, _I, _P, _P, _P],
-    "arco_bn_act_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _L, _P, _P],
-    "arco_bn_act_bwd": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _P, _P, _I, _P, _L, _P, _P],
+    "arco_bn_act_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _L, _P, _I, _P],
+    "arco_bn_act_bwd": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _P, _P, _I, _P, _L, _P, _I, _P],
     "arco_maxpool2_fwd": [_P, _L, _I, _I, _I, _I, _P, _L, _P],
     "arco_maxpool2_bwd": [_P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "arco_bilinear_fwd": [_P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],
@@ -52,7 +52,7 @@ _SIGS = {
     "arco_s2d3": [_P, _L, _I, _I, _I, _I, _I, _P, _L, _I, _P],
     "arco_trilinear_fwd": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "arco_trilinear_bwd": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
-    "arco_conv3d_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
+    "arco_conv3d_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "arco_conv3d_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "arco_gather_upcat_rows3d": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "arco_scatter_upcat_rows3d": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P],
@@ -71,7 +71,7 @@ _SIGS = {
 }
 _QUERIES = {   # plain host helpers returning sizes
     "arco_proto_ws_floats": ([_L, _I, _I], _L),
-    "arco_conv_mblocks": ([_I, _I, _I, _I, _I, _I, _L], _I),
+    "arco_conv_mblocks": ([_I, _I, _I, _I, _I, _I, _L, _I], _I),
     "arco_conv_config": ([_I, _I, _I, _I, _I, _I, _L, _P], _I),
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
     "arco_chan_stats_blocks": ([_L], _I),

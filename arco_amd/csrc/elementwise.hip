@@ -22,22 +22,28 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
                                    double count, float eps, float momentum, float* __restrict__ mean,
                                    float* __restrict__ istd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
-  const int c = blockIdx.x;
-  if (c == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
-  double s = 0.0, q = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 64) { s += (double)ssum[(long)c * nblk + b]; q += (double)ssq[(long)c * nblk + b]; }
-  s = wave_sum_d(s); q = wave_sum_d(q);
-  if (threadIdx.x != 0) return;
-  const double m = s / count;
-  double var = q / count - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)m;
-  istd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
-    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked, int groups) {
+  // groups > 1: the batch is `groups` independent BN batches (e.g. the labelled and the unlabelled half of one
+  // launch); group g owns the slabs [g*nblk/groups, ...), has `count` elements per channel, gets mean/istd row g,
+  // and the running statistics receive the groups' updates one after the other (as separate forwards would)
+  const int c = blockIdx.x, npg = nblk / groups;
+  if (c == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += groups;
+  for (int g = 0; g < groups; ++g) {
+    double s = 0.0, q = 0.0;
+    for (int b = threadIdx.x; b < npg; b += 64) { s += (double)ssum[(long)c * nblk + g * npg + b]; q += (double)ssq[(long)c * nblk + g * npg + b]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if (threadIdx.x == 0) {
+      const double m = s / count;
+      double var = q / count - m * m;
+      if (var < 0.0) var = 0.0;
+      mean[(long)g * C + c] = (float)m;
+      istd[(long)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+      }
+    }
   }
 }
 
@@ -102,6 +108,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                         float* __restrict__ Aout, long lda,
                                                         const uint64_t* __restrict__ seed_dev) {
   const int q4 = C / 4;
+  // blockIdx.y = BN group: rows [g*M, (g+1)*M) of the tensor with parameter row g (M = rows per group)
+  const long row0 = (long)blockIdx.y * M;
+  Z += row0 * ldz; Aout += row0 * lda;
+  if (mean) { mean += (long)blockIdx.y * C; istd += (long)blockIdx.y * C; }
   const long tot = M * q4;
   const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
   // graph-captured forwards read a per-replay salt from device memory (fresh masks on every replay)
@@ -126,8 +136,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
           for (int e = 0; e < 4; ++e) {
             float y = (z[u][e] - mu[e]) * is[e] * ga[e] + be[e];
             y = y >= 0.f ? y : y * slope;
-            if (drop_mode == 1) y = drop_keep(seed, (uint64_t)(r * C + c + e), p) ? y * keep_scale : 0.f;
-            else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)((r / P) * C + c + e), p) ? y * keep_scale : 0.f;
+            if (drop_mode == 1) y = drop_keep(seed, (uint64_t)((r + row0) * C + c + e), p) ? y * keep_scale : 0.f;
+            else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)(((r + row0) / P) * C + c + e), p) ? y * keep_scale : 0.f;
             o[e] = y;
           }
           *reinterpret_cast<f32x4*>(Aout + r * lda + c) = o;
@@ -144,8 +154,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     for (int e = 0; e < 4; ++e) {
       float y = mean ? (z[e] - mean[c + e]) * istd[c + e] * gamma[c + e] + beta[c + e] : z[e];
       y = y >= 0.f ? y : y * slope;
-      if (drop_mode == 1) y = drop_keep(seed, (uint64_t)(r * C + c + e), p) ? y * keep_scale : 0.f;
-      else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)((r / P) * C + c + e), p) ? y * keep_scale : 0.f;
+      if (drop_mode == 1) y = drop_keep(seed, (uint64_t)((r + row0) * C + c + e), p) ? y * keep_scale : 0.f;
+      else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)(((r + row0) / P) * C + c + e), p) ? y * keep_scale : 0.f;
       o[e] = y;
     }
     *reinterpret_cast<f32x4*>(Aout + r * lda + c) = o;
@@ -167,6 +177,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed_, long P,
     float* __restrict__ s_dy, float* __restrict__ s_dyx, int nblk, const uint64_t* __restrict__ seed_dev) {
   const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
+  // blockIdx.y = BN group (rows [g*M, (g+1)*M), parameter row g, slab block [g][C][nblk])
+  const long row0 = (long)blockIdx.y * M;
+  dA += row0 * ldd; Z += row0 * ldz;
+  mean += (long)blockIdx.y * C; istd += (long)blockIdx.y * C;
+  s_dy += (long)blockIdx.y * C * nblk; s_dyx += (long)blockIdx.y * C * nblk;
   const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
   const long rpb = (M + nblk - 1) / nblk;
   const long r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
           for (int e = 0; e < 4; ++e) {
             const float xh = (z[u][e] - mu[e]) * is[e];
             const float y = xh * ga[e] + be[e];
-            const uint64_t ei = drop_mode == 2 ? (uint64_t)((r / P) * C + c + e) : (uint64_t)(r * C + c + e);
+            const uint64_t ei = drop_mode == 2 ? (uint64_t)(((r + row0) / P) * C + c + e) : (uint64_t)((r + row0) * C + c + e);
             const float dy = bn_dy(d[u][e], y, slope, drop_mode, p, keep_scale, seed, ei);
             s[e] += dy; q[e] += dy * xh;
           }
@@ -209,16 +224,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 }
 
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int nblk, int C,
-                                       float* __restrict__ sum_dy, float* __restrict__ sum_dyx,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+                                       float* __restrict__ sums /*[G][2][C]*/,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int groups) {
   const int c = blockIdx.x;
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += 64) { a += (double)s_dy[(long)c * nblk + i]; b += (double)s_dyx[(long)c * nblk + i]; }
-  a = wave_sum_d(a); b = wave_sum_d(b);
+  double ga = 0.0, gb = 0.0;
+  for (int g = 0; g < groups; ++g) {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) { a += (double)s_dy[((long)g * C + c) * nblk + i]; b += (double)s_dyx[((long)g * C + c) * nblk + i]; }
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    if (threadIdx.x == 0) { sums[(2l * g) * C + c] = (float)a; sums[(2l * g + 1) * C + c] = (float)b; }   // this group's sums (apply pass)
+    if (groups == 1) { ga = a; gb = b; } else { ga += (double)(float)a; gb += (double)(float)b; }   // = two separate backward passes
+  }
   if (threadIdx.x != 0) return;
-  sum_dy[c] = (float)a; sum_dyx[c] = (float)b;                    // this call's sums (read by the apply pass)
-  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)ga : (float)ga;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)gb : (float)gb;
 }
 
 // ---- BN backward pass 2: dz = gamma*istd*(dy - sum_dy/n - xhat*sum_dyx/n)
@@ -230,6 +249,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, float inv_count,
     float* __restrict__ dZ, long ldo, const uint64_t* __restrict__ seed_dev) {
   const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
+  const long row0 = (long)blockIdx.y * M;                 // blockIdx.y = BN group
+  dA += row0 * ldd; Z += row0 * ldz; dZ += row0 * ldo;
+  if (mean) { mean += (long)blockIdx.y * C; istd += (long)blockIdx.y * C; sum_dy += 2l * blockIdx.y * C; sum_dyx += 2l * blockIdx.y * C; }
   const int q4 = C / 4;
   const long tot = M * q4;
   const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const uint64_t ei = drop_mode == 2 ? (uint64_t)((r / P) * C + c + e) : (uint64_t)(r * C + c + e);
+            const uint64_t ei = drop_mode == 2 ? (uint64_t)(((r + row0) / P) * C + c + e) : (uint64_t)((r + row0) * C + c + e);
             const float xh = (z[u][e] - mu[e]) * is[e];
             const float y = xh * ga[e] + be[e];
             const float dy = bn_dy(d[u][e], y, slope, drop_mode, p, keep_scale, seed, ei);
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const uint64_t ei = drop_mode == 2 ? (uint64_t)((r / P) * C + c + e) : (uint64_t)(r * C + c + e);
+      const uint64_t ei = drop_mode == 2 ? (uint64_t)(((r + row0) / P) * C + c + e) : (uint64_t)((r + row0) * C + c + e);
       if (mean) {
         const float xh = (z[e] - mean[c + e]) * istd[c + e];
         const float y = xh * gamma[c + e] + beta[c + e];
@@ -753,10 +775,12 @@ extern "C" {
 
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
                      float* mean, float* istd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                     void* stream) {
-  ARCO_CHECK_ARG(C > 0 && nblk > 0 && count > 0);
+                     int groups, void* stream) {
+  if (groups < 1) groups = 1;
+  ARCO_CHECK_ARG(C > 0 && nblk > 0 && count > 0 && nblk % groups == 0 && count % groups == 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), ssum, ssq, nblk, C,
-                     (double)count, eps, momentum, mean, istd, running_mean, running_var, num_batches_tracked);
+                     (double)(count / groups), eps, momentum, mean, istd, running_mean, running_var, num_batches_tracked,
+                     groups);
   return arco_launch_status();
 }
 
@@ -781,30 +805,34 @@ int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float*
 
 int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                     const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
-                    const uint64_t* seed_dev, void* stream) {
-  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && p < 1.0f);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, as_stream(stream), Z, ldz, M, C, mean,
+                    const uint64_t* seed_dev, int groups, void* stream) {
+  if (groups < 1) groups = 1;
+  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && p < 1.0f && M % groups == 0);
+  const long Mg = M / groups;                 // mean / istd: [groups][C]; rows [g*Mg, (g+1)*Mg) use row g
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, as_stream(stream), Z, ldz, Mg, C, mean,
                      istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda, seed_dev);
   return arco_launch_status();
 }
 
-// ws: 2*C*nblk floats + 2*C floats (this call's sums);  nblk = arco_chan_stats_blocks(M)
+// ws: groups * (2*C*nblk + 2*C) floats;  nblk = arco_chan_stats_blocks(M / groups)
 int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
                     const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
                     uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
-                    const uint64_t* seed_dev, void* stream) {
-  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldz & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0);
+                    const uint64_t* seed_dev, int groups, void* stream) {
+  if (groups < 1) groups = 1;
+  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldz & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0 && M % groups == 0);
   const int dm = p > 0.f ? drop_mode : 0;
   hipStream_t st = as_stream(stream);
+  const long Mg = M / groups;
   if (mean) {
-    const int nblk = arco_chan_stats_blocks(M);
-    float* s_dy = ws; float* s_dyx = ws + (long)C * nblk; float* sums = ws + 2l * C * nblk;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, M,
+    const int nblk = arco_chan_stats_blocks(Mg);
+    float* s_dy = ws; float* s_dyx = ws + (long)groups * C * nblk; float* sums = ws + 2l * groups * C * nblk;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk, groups), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, Mg,
                        C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk, seed_dev);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums, sums + C, dgamma,
-                       dbeta, accumulate);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
-                       mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)M, dZ, ldo, seed_dev);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums, dgamma,
+                       dbeta, accumulate, groups);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, st, dA, ldd, Z, ldz, Mg, C,
+                       mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)Mg, dZ, ldo, seed_dev);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
                        nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo, seed_dev);

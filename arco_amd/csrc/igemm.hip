@@ -26,6 +26,7 @@ struct IgemmArgs {
   int D3;                            // 3-D: planes per volume (depth taps active when DEPTH==3); 2-D: 1
   long M;                            // total pixels
   int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
+  int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
 };
 
 template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH>
@@ -379,17 +380,21 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(IgemmArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const int n = nt * 16 + 4 * g + e; bias4[nt][e] = (a.bias && n < a.N) ? a.bias[n] : 0.f; }
 
-  long tile = blockIdx.x;
-  if (tile < n_tiles) fetch(tile);
-  while (tile < n_tiles) {
+  // a workgroup stays inside ONE BN group of images (its stat slab belongs to that group): group g owns the
+  // blocks [g*bpg, (g+1)*bpg) and the tiles [g*tpg, (g+1)*tpg)
+  const int n_grp = a.stat_groups > 1 ? a.stat_groups : 1, bpg = gridDim.x / n_grp;
+  const long tpg = n_tiles / n_grp, t_end = (blockIdx.x / bpg + 1) * tpg;
+  long tile = (blockIdx.x / bpg) * tpg + blockIdx.x % bpg;
+  if (tile < t_end) fetch(tile);
+  while (tile < t_end) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int u = tid + i * 256;
       if (u < UNITS) *reinterpret_cast<f32x4*>(&As[(u / Q4) * LDC + 4 * (u % Q4)]) = pre[i];
     }
     __syncthreads();
-    const long next = tile + gridDim.x;
-    if (next < n_tiles) fetch(next);
+    const long next = tile + bpg;
+    if (next < t_end) fetch(next);
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -483,7 +488,11 @@ static int launch_halo(const IgemmArgs& a, hipStream_t st, int* q) {
   const long n_tiles = (long)a.NB * ((a.H + 7) / 8) * ((a.W + TW - 1) / TW);
   constexpr size_t sh = (size_t)(9 * COUT * (CIN + 4) + 10 * (TW + 2) * (CIN + 4)) * sizeof(float);
   constexpr int per_cu = sh * 4 <= 160 * 1024 ? 4 : (sh * 3 <= 160 * 1024 ? 3 : (sh * 2 <= 160 * 1024 ? 2 : 1));
-  long blocks = 256l * (per_cu > 3 ? 3 : per_cu); if (blocks > n_tiles) blocks = n_tiles;   // <= 3 waves/SIMD by VGPRs
+  const int n_grp = a.stat_groups > 1 ? a.stat_groups : 1;
+  if (a.NB % n_grp != 0) return ARCO_ERR_ARG;
+  long bpg = 256l * (per_cu > 3 ? 3 : per_cu) / n_grp; if (bpg > n_tiles / n_grp) bpg = n_tiles / n_grp;   // <= 3 waves/SIMD by VGPRs
+  if (bpg < 1) bpg = 1;
+  const long blocks = bpg * n_grp;
   if (q) { q[0] = (int)blocks; q[1] = 9 * 1000000 + 900000 + CIN * 1000 + COUT; q[2] = CIN * 100 + 10; return ARCO_OK; }
   auto kern = conv3x3_halo_kernel<CIN, COUT, TW>;
   static bool attr_set = false;
@@ -521,7 +530,9 @@ __global__ __launch_bounds__(256) void conv3x3_image_kernel(IgemmArgs a) {
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const long n_tiles = (long)a.NB * tiles_y * tiles_x;
   f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  const int n_grp = a.stat_groups > 1 ? a.stat_groups : 1, bpg = gridDim.x / n_grp;      // one BN group per workgroup
+  const long tpg = n_tiles / n_grp, t_end = (blockIdx.x / bpg + 1) * tpg;
+  for (long t = (blockIdx.x / bpg) * tpg + blockIdx.x % bpg; t < t_end; t += bpg) {
     const int tx = t % tiles_x; const long r = t / tiles_x; const int ty = r % tiles_y; const int nb = r / tiles_y;
     __syncthreads();
     for (int u = tid; u < NP * K; u += 256) {
@@ -571,7 +582,10 @@ static bool image_conv_eligible(const IgemmArgs& a) {
 }
 static int launch_image_conv(const IgemmArgs& a, hipStream_t st, int* q) {
   const long n_tiles = (long)a.NB * ((a.H + 15) / 16) * ((a.W + 15) / 16);
-  long blocks = n_tiles < 1024 ? n_tiles : 1024;
+  const int n_grp = a.stat_groups > 1 ? a.stat_groups : 1;
+  if (a.NB % n_grp != 0) return ARCO_ERR_ARG;
+  long bpg = 1024 / n_grp; if (bpg > n_tiles / n_grp) bpg = n_tiles / n_grp; if (bpg < 1) bpg = 1;
+  const long blocks = bpg * n_grp;
   if (q) { q[0] = (int)blocks; q[1] = 9 * 1000000 + 800000 + a.K * 1000 + 16; q[2] = 10; return ARCO_OK; }
   IgemmArgs b = a; b.n_mblocks = (int)blocks; b.n_nblocks = 1;
   hipLaunchKernelGGL(conv3x3_image_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
@@ -962,8 +976,9 @@ __global__ void transpose2d_kernel(const float* __restrict__ x, long ldx, int ro
 extern "C" {
 
 // Query: number of M-blocks (= BN-stat partial slabs per channel) the conv launch will use.
-int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in) {
+int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups) {
   IgemmArgs a{};
+  a.stat_groups = stat_groups > 1 ? stat_groups : 1;
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
   a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in;
   int q[3] = {0, 0, 0};
@@ -995,7 +1010,7 @@ int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode,
 
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
-                    int NV, int D3, int H, int W, void* stream);
+                    int NV, int D3, int H, int W, int stat_groups, void* stream);
 // desc: device array of n_desc PackDesc records (arco_pack_desc_bytes() each, see igemm.hip); total = sum of packed sizes
 long arco_pack_desc_bytes() { return (long)sizeof(PackDesc); }
 int arco_pack_many(const void* desc, int n_desc, long total, void* stream) {
@@ -1028,13 +1043,13 @@ int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, fl
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                   int NB, int H, int W, void* stream) {
   return arco_conv3d_fwd(in, ld_in, K, Wp, N, out, ld_out, bias, residual, ld_res, stat_sum, stat_sq, taps, NB, 1, H, W,
-                         stream);
+                         1, stream);
 }
 
 // 3-D generalisation: NV volumes of D3 planes of H x W; taps in {1, 9 (per plane), 27 (3x3x3, pad 1)}
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
-                    int NV, int D3, int H, int W, void* stream) {
+                    int NV, int D3, int H, int W, int stat_groups, void* stream) {
   const int NB = NV * D3;
   ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0);
   IgemmArgs a{};
@@ -1043,6 +1058,8 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
   a.C = out; a.ldc = ld_out; a.bias = bias; a.R = residual; a.ldr = ld_res;
   a.stat_sum = stat_sum; a.stat_sq = stat_sq;
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = D3;
+  a.stat_groups = stat_groups > 1 ? stat_groups : 1;
+  ARCO_CHECK_ARG(NV % a.stat_groups == 0);
   return dispatch_igemm(a, taps, as_stream(stream), nullptr);
 }
 

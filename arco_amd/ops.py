@@ -14,7 +14,26 @@ _drop_gen = None
 SEED_DEV = None     # device uint64 salt for dropout masks of graph-captured forwards (graphs.py)
 PROFILE = None       # bench.py sets a dict: kernel instantiation id -> {n, flop, timed: [(ev0, ev1, flop, (taps, M, N, K))]}
 _cfg_cache = {}
+BN_GROUPS = 1         # see bn_groups()
 PROFILE_EVERY = 1    # time every n-th conv launch of an instantiation (bench.py: 7, prime vs the per-step launch counts)
+
+
+class bn_groups:
+    """`with ops.bn_groups(g):` - inside, a batch is treated by every train-mode BatchNorm as g independent batches
+    of equal size (images [i*B/g, (i+1)*B/g) form batch i): per-group statistics, running statistics updated group
+    after group.  One launch sequence then does the work of g separate forwards (and backwards) of B/g images -
+    the trainers run the labelled and the unlabelled half of a step this way."""
+
+    def __init__(self, g):
+        self.g = int(g)
+
+    def __enter__(self):
+        global BN_GROUPS
+        self.prev, BN_GROUPS = BN_GROUPS, self.g
+
+    def __exit__(self, *exc):
+        global BN_GROUPS
+        BN_GROUPS = self.prev
 
 
 def _next_seed():
@@ -175,7 +194,8 @@ def pack_weight(weight, taps, mode):
     return wp
 
 
-def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1, sp=None):
+def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1, sp=None,
+             stat_groups=1):
     """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out channels-last, stat slabs or None).
     2-D: nb images of h x w -> out [nb,n,h,w].  3-D (d3 > 1): nb volumes of d3 planes -> out [nb,n,d3,h,w]."""
     if sp is not None:
@@ -187,7 +207,9 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
     ssum = ssq = None
     nmb = 0
     if stats:
-        nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, k, n, ld)
+        if stat_groups > 1 and taps == 1:
+            raise RuntimeError("arco_amd: grouped BN statistics are only produced by the spatial conv kernels")
+        nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, k, n, ld, stat_groups)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
     prof = cfg = None
@@ -205,7 +227,7 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
             prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             prof[0].record()
     L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
-           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w)
+           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1)
     if prof is not None:
         prof[1].record()
         PROFILE[cfg]["timed"].append((prof[0], prof[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
@@ -300,22 +322,22 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, (dy if ctx.res_tensor and ctx.needs_input_grad[3] else None)
 
 
-def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out, ld_out=None):
+def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out, ld_out=None, groups=1):
     seed_dev = SEED_DEV if (p > 0 and torch.cuda.is_current_stream_capturing()) else None
     L.call("arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
            float(slope), int(drop_mode), float(p), seed, P, L.ptr(out), co if ld_out is None else ld_out,
-           L.ptr(seed_dev))
+           L.ptr(seed_dev), groups)
     return seed_dev
 
 
-def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, seed_dev=None):
+def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, seed_dev=None, groups=1):
     """Returns (dz, dgamma, dbeta) for a = drop(lrelu(BN(z)))."""
     dar, ldd = rows_view(da)
     zr, ldz = rows_view(z)
     co = int(z.shape[1])
     m = zr.shape[0]
-    nblk = L.query("arco_chan_stats_blocks", m)
-    ws = torch.empty(2 * co * nblk + 2 * co, dtype=torch.float32, device=da.device)
+    nblk = L.query("arco_chan_stats_blocks", m // groups)
+    ws = torch.empty(groups * (2 * co * nblk + 2 * co), dtype=torch.float32, device=da.device)
     dz = new_act_nd(int(z.shape[0]), co, tuple(int(v) for v in z.shape[2:]), da.device)
     dgamma = dbeta = None
     acc = 0
@@ -331,7 +353,8 @@ def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, s
     else:
         dg_t = db_t = None
     L.call("arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma),
-           L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dz), co, L.ptr(seed_dev))
+           L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dz), co, L.ptr(seed_dev),
+           groups)
     return dz, dgamma, dbeta
 
 
@@ -350,11 +373,15 @@ class ConvBnActFn(torch.autograd.Function):
         co = int(weight.shape[0])
         m = nv * d3 * h * w
         wp = pack_weight(weight, taps, 0)
-        z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, stats=True, d3=d3, sp=sp)
-        mean = torch.empty(co, dtype=torch.float32, device=x.device)
-        istd = torch.empty(co, dtype=torch.float32, device=x.device)
+        G = BN_GROUPS
+        if G > 1 and nv % G != 0:
+            raise RuntimeError(f"arco_amd: bn_groups({G}) needs a batch that is a multiple of {G}, got {nv}")
+        z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, stats=True, d3=d3, sp=sp,
+                                       stat_groups=G)
+        mean = torch.empty(G * co, dtype=torch.float32, device=x.device)      # [G][co]
+        istd = torch.empty(G * co, dtype=torch.float32, device=x.device)
         L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
-               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt))
+               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G)
         seed = _next_seed() if p > 0 else 0
         if cat_room:        # leave room behind the channels for a later in-place channel concat (ops.upcat)
             buf = new_act_nd(nv, co + int(cat_room), sp, x.device)
@@ -364,7 +391,8 @@ class ConvBnActFn(torch.autograd.Function):
             a, ld_a = new_act_nd(nv, co, sp, x.device), co
         zr, ldz = rows_view(z)
         ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w, a,
-                                 ld_a)
+                                 ld_a, G)
+        ctx.groups = G
         ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta)
         ctx.cfg = (taps, float(slope), float(p), int(drop_mode), seed, bias is not None)
         ctx.bias_param = bias
@@ -377,7 +405,7 @@ class ConvBnActFn(torch.autograd.Function):
         xr, ldx, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
         dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w,
-                                         ctx.seed_dev)
+                                         ctx.seed_dev, ctx.groups)
         dzr, ldzz = rows_view(dz)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -420,7 +448,7 @@ class BnActFn(torch.autograd.Function):
             mean = torch.empty(co, dtype=torch.float32, device=z.device)
             istd = torch.empty(co, dtype=torch.float32, device=z.device)
             L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nblk, co, m, float(eps), float(momentum), L.ptr(mean),
-                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt))
+                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), 1)
         seed = _next_seed() if p > 0 else 0
         a = new_act_nd(int(z.shape[0]), co, sp, z.device)
         ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a)
@@ -589,7 +617,7 @@ def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, sl
         a = new_act_nd(nv, co, sp, x.device)
         zr, ldz = rows_view(z)
         L.call("arco_bn_act_fwd", L.ptr(zr), ldz, nv * d3 * h * w, co, L.ptr(running_mean), L.ptr(istd), L.ptr(gamma),
-               L.ptr(beta), float(slope), 0, 0.0, 0, d3 * h * w, L.ptr(a), co, None)
+               L.ptr(beta), float(slope), 0, 0.0, 0, d3 * h * w, L.ptr(a), co, None, 1)
         return a
 
 

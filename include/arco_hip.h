@@ -77,7 +77,7 @@ int arco_pack_many(const void* desc, int n_desc, long total, void* stream);
  * slabs over grid.y, slab outputs in ws (splits*M*ld_out floats), fixed-order sum into out                  */
 int arco_gemm_splitk(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out, long M,
                      int splits, float* ws, void* stream);
-int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in);
+int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups);
 /* which kernel instantiation a launch uses: igemm_kernel<TAPS,BM,BN,..> -> TAPS*1e6 + BM*1e3 + BN;
  * conv3x3_halo_kernel<CIN,COUT,..> -> 9.9e6 + CIN*1e3 + COUT */
 int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int* kc_depth_db);
@@ -88,7 +88,8 @@ int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, fl
 /* 3-D: NV volumes of D3 planes of H x W; taps = 27 is nn.Conv3d(3, padding=1) (vnetWithArgs.py:16)      */
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
-                    int NV, int D3, int H, int W, void* stream);
+                    int NV, int D3, int H, int W,
+                    int stat_groups /* BN groups: volumes [g*NV/G,..) feed stat slabs [g*nmb/G,..); 1 = one batch */, void* stream);
 int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
                       int D3, int H, int W, float* ws, float* dW, int accumulate, void* stream);
 long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M);
@@ -102,16 +103,16 @@ int arco_transpose2d(const float* x, long ldx, int rows, int cols, float* y, lon
  *      unetWithArgs.py:36-44; vnetWithArgs.py:16-25)                                                      */
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
                      float* mean, float* istd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                     void* stream);
+                     int groups /* mean/istd rows: [groups][C] */, void* stream);
 int arco_chan_stats_blocks(long M);
 int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream);
 int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                     const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
-                    const uint64_t* seed_dev, void* stream);
+                    const uint64_t* seed_dev, int groups, void* stream);
 int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
                     const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
                     uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
-                    const uint64_t* seed_dev /* same device salt as the forward (graph replays), or NULL */, void* stream);
+                    const uint64_t* seed_dev /* same device salt as the forward (graph replays), or NULL */, int groups, void* stream);
 /* ---- N2/N3  nn.MaxPool2d(2) (unetWithArgs.py:55-58); nn.Upsample(bilinear, align_corners=True)
  *      (unetWithArgs.py:74-75, model_2D.py:43-52)                                                          */
 int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, float* Y, long ldy, void* stream);

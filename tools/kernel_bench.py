@@ -35,12 +35,14 @@ if which in ("all", "gemm"):
     fwd(16, 496, 496, 256, 256, 1); fwd(16, 480, 480, 128, 128, 1); fwd(16, 448, 448, 64, 64, 1)
     fwd(1, 496, 496, 32, 32, 1); fwd(8, 256, 128, 16, 16, 1); fwd(8, 32, 16, 128, 128, 1)
 if which in ("all", "conv"):
-    for nb in (8,):
+    for nb in ((8, 16) if os.environ.get("NB16") else (8,)):
         fwd(nb, 1, 16, 256, 256, 3); fwd(nb, 16, 16, 256, 256, 3); fwd(nb, 32, 16, 256, 256, 3); fwd(nb, 16, 32, 256, 256, 3)
         fwd(nb, 16, 32, 128, 128, 3); fwd(nb, 32, 32, 128, 128, 3); fwd(nb, 64, 32, 128, 128, 3)
         fwd(nb, 64, 64, 64, 64, 3); fwd(nb, 128, 64, 64, 64, 3); fwd(nb, 128, 128, 32, 32, 3)
         fwd(nb, 256, 128, 32, 32, 3); fwd(nb, 256, 256, 16, 16, 3); fwd(nb, 16, 4, 256, 256, 3)
 if which in ("all", "wgrad"):
     wg(16, 480, 480, 128, 128, 1); wg(1, 496, 496, 32, 32, 1)
+    if os.environ.get("NB16"):
+        wg(16, 16, 16, 256, 256, 3); wg(16, 32, 32, 128, 128, 3); wg(16, 64, 64, 64, 64, 3); wg(16, 128, 128, 32, 32, 3); wg(16, 256, 256, 16, 16, 3)
     wg(8, 16, 16, 256, 256, 3); wg(8, 32, 32, 128, 128, 3); wg(8, 64, 64, 64, 64, 3); wg(8, 128, 128, 32, 32, 3)
     wg(8, 256, 256, 16, 16, 3); wg(8, 32, 16, 256, 256, 3)
