@@ -85,6 +85,8 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=0, help='1: train on synthetic ACDC-shaped tensors')
     p.add_argument('--in_chns', type=int, default=1, help='input channels (reference: 1)')
     p.add_argument('--graphs', type=int, default=1, help='1: replay the no-grad U-Net forwards as HIP graphs')
+    p.add_argument('--batched_passes', type=int, default=1,
+                   help='1: labelled + unlabelled student (and teacher) forwards as one pass with two BatchNorm groups')
     p.add_argument('--graph_train', type=int, default=0,
                    help='1 (with --graphs 1): the student forward+backward passes are HIP graphs too (halves the '
                         'host work per step; on an unloaded host the eager passes measured 2%% faster, DESIGN.md)')
@@ -169,6 +171,9 @@ class ArcoStep2D:
         sub = os.environ.get("ARCO_GT_SUBSET", "ul")
         self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train and "u" in sub)    # student passes: fwd + bwd graphs
         self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train and "l" in sub)
+        self.batched_passes = bool(getattr(args, "batched_passes", 1))
+        self.s_train_lu = graphs.GraphedTrain(self.model, enabled=g_train)
+        self.t_fwd_lu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -197,10 +202,27 @@ class ArcoStep2D:
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits
         self.k_fe_ema.update(0.99)                                      # :306-308
-        pred_u, _, u_fm = self.s_train_u(u_aug)                              # :312 (needed first: entropy masks)
+        batched = self.batched_passes and l_data.shape == u_aug.shape
+        if batched:
+            # the labelled and the unlabelled student forward (:310,312) as ONE batch-2b pass with two BatchNorm
+            # groups (ops.bn_groups: per-half batch statistics, running statistics updated half after half) - same
+            # results as two passes, every conv / BN / pooling launch works on twice the pixels (the mid and deep
+            # U-Net levels are too small to fill the GPU at b images: 20-35 % less kernel time), one backward.
+            lu = torch.cat((l_data, u_aug))
+            with ops.bn_groups(2):
+                pred_all, _, fm_all = self.s_train_lu(lu)
+            nb_l = int(l_data.shape[0])
+            pred_l, pred_u = pred_all[:nb_l], pred_all[nb_l:]
+        else:
+            pred_u, _, u_fm = self.s_train_u(u_aug)                      # :312 (needed first: entropy masks)
         with torch.no_grad():                                            # teacher params carry no grad (:158-160)
-            pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)                   # :314
-            pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                    # :315
+            if batched:
+                with ops.bn_groups(2):
+                    pred_t, _, fm_t = self.t_fwd_lu(lu)                  # :314-315 as one grouped pass
+                pred_l_t, pred_u_t = pred_t[:nb_l], pred_t[nb_l:]
+            else:
+                pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)               # :314
+                pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                # :315
             alpha_t = 20 * (1 - epoch_num / max_epoch)                   # :342-393
             label_l = glue.label_onehot(l_label, C)
             label_u = glue.label_onehot(u_aug_label, C)
@@ -213,14 +235,16 @@ class ArcoStep2D:
                                  delta_n=a.strong_threshold_u2pl)       # :341-401 (counts -> async D2H)
         ev[1].record()
         # ---- large GPU work queued while the host waits for the counters and samples
-        pred_l, _, l_fm = self.s_train_l(l_data)                             # :310
+        if not batched:
+            pred_l, _, l_fm = self.s_train_l(l_data)                     # :310
         with torch.no_grad():
             # images_cj2_l forward (:311): BN running statistics only - its FE/q_rep outputs (l_feature_map_2,
             # :319,326) are never read.  One graph launch (~1 ms of GPU work) queued BEFORE the host sync: work for
             # the GPU while the host replays the samplers (14.8 vs 15.1 ms/step when queued after the sync).
             self.s_fwd_stats(l_data)
             # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
-            fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
+            if not batched:
+                fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
             if getattr(a, "dense_teacher", 0) or dense:
                 rep_all_teacher, lazy_t = self.k_feature_extractor(fm_t), None
             elif getattr(a, "head_levels", 2) == 1:
@@ -230,7 +254,8 @@ class ArcoStep2D:
                 kfe = self.k_feature_extractor
                 rep_all_teacher = None
                 lazy_t = head.LazyTeacher2DL2(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
-        fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]         # :317-318
+        if not batched:
+            fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]     # :317-318
         if dense:
             rep_all = self.q_rep(self.q_feature_extractor(fm_all))       # :324-325,330
         elif getattr(a, "head_levels", 2) == 1:

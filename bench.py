@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--dense_head", type=int, default=0)
     ap.add_argument("--graphs", type=int, default=1)
     ap.add_argument("--graph_train", type=int, default=0)
+    ap.add_argument("--batched_passes", type=int, default=1)
     ap.add_argument("--dense_teacher", type=int, default=0)
     ap.add_argument("--cpu_baseline_child", action="store_true")
     a = ap.parse_args()
@@ -90,7 +91,7 @@ def main():
     random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 
     args = T.build_parser().parse_args(["--batch_size", str(a.batch_size), "--queue_size", "4096", "--func", "smc",
-                                        "--synthetic", "1", "--dense_head", str(a.dense_head), "--graphs", str(a.graphs), "--graph_train", str(a.graph_train), "--dense_teacher", str(a.dense_teacher)])
+                                        "--synthetic", "1", "--dense_head", str(a.dense_head), "--graphs", str(a.graphs), "--graph_train", str(a.graph_train), "--batched_passes", str(a.batched_passes), "--dense_teacher", str(a.dense_teacher)])
     stepper = T.ArcoStep2D(args, dev)
     b = a.batch_size
     batches = []

@@ -171,7 +171,7 @@ def test_graphed_student_passes_match_eager():
                 assert int(ve) == int(vg), k                      # num_batches_tracked
         for be, bg in zip(st_e.memobank, st_g.memobank):
             np.testing.assert_allclose(bg[0].cpu().numpy(), be[0].cpu().numpy(), rtol=1e-4, atol=1e-6)
-    assert st_g.s_train_u.captured and st_g.s_train_l.captured
+    assert st_g.s_train_lu.captured        # the labelled + unlabelled halves run as one grouped pass
 
 
 def test_graphed_unet_pass_is_bit_exact_even_with_a_live_eager_graph():
