@@ -201,6 +201,14 @@ def _pinned_i64(n, depth=3):
 
 @torch.no_grad()
 def contrast_sample(pl, memobank, queue_size, func='asmc', num_queries=256, num_negatives=512, _trace=None):
+    """stage 2 = contrast_counts (host sync + bookkeeping) then contrast_draw (sampler replay + upload).  The
+    trainers call the two halves separately and queue sample-independent GPU work in between."""
+    contrast_counts(pl, memobank, queue_size, num_queries, num_negatives)
+    return contrast_draw(pl, func, _trace)
+
+
+@torch.no_grad()
+def contrast_counts(pl, memobank, queue_size, num_queries=256, num_negatives=512):
     pl.ready.synchronize()                                  # the one device->host dependency of the loss
     C = pl.C
     tot = pl.totals_host.tolist()
@@ -212,6 +220,11 @@ def contrast_sample(pl, memobank, queue_size, func='asmc', num_queries=256, num_
     pl.valid_classes = [c for c in range(C) if pl.n_lv[c] > 0]        # :413-415
     pl.valid_seg = len(pl.valid_classes)
     pl.Q, pl.Nn = int(num_queries), int(num_negatives)
+    return pl
+
+
+@torch.no_grad()
+def contrast_draw(pl, func='asmc', _trace=None):
     if func == 'asmc':                                                  # :327-338
         draw, q_arg, n_arg = samplers.grid_as_monte_carlo_sample, pl.Q, pl.Q * pl.Nn
     elif func == 'smc':
@@ -260,7 +273,8 @@ def contrast_sample(pl, memobank, queue_size, func='asmc', num_queries=256, num_
 # stage 3 (GPU): row lists, prototypes, key enqueue                 loss_helper_3d.py:376-411
 # ----------------------------------------------------------------------------------------------
 @torch.no_grad()
-def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace=None, lazy_teacher=None):
+def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace=None, lazy_teacher=None,
+                     defer_anchor_pix=False):
     """Row lists, prototypes and key enqueue.  Teacher rows come either from the dense `rep_teacher`
     [B,D,*spatial] (public API) or lazily from a `lazy_teacher` object (arco_amd.head): the FeatureExtractor
     is linear, so prototype_c = W_fea4 . mean_c(fea4 input) with the class mask pushed through the
@@ -311,11 +325,18 @@ def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace
         pl.new_keys.append(int(pl.n_neg[c]))
     if _trace is not None:
         _trace["lists"], _trace["totals"], _trace["proto"] = pl.lists, pl.totals_host.tolist(), pl.proto
-    # global pixel id of every sampled anchor, entries concatenated
+    if not defer_anchor_pix:                 # needs the sampled indices (contrast_draw); everything above does not
+        contrast_anchor_pix(pl)
+    return pl
+
+
+@torch.no_grad()
+def contrast_anchor_pix(pl):
+    """global pixel id of every sampled anchor, entries concatenated"""
     if pl.entries:
         pl.anchor_pix = torch.cat([pl.lists[k][a_dev].to(torch.int64) for (k, vc, a_dev, n_dev) in pl.entries])
     else:
-        pl.anchor_pix = torch.empty(0, dtype=torch.int64, device=dev)
+        pl.anchor_pix = torch.empty(0, dtype=torch.int64, device=pl.dev)
     return pl
 
 

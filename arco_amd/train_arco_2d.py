@@ -262,12 +262,23 @@ class ArcoStep2D:
             x3p, f4 = self.q_feature_extractor.forward_lowres(fm_all)
         else:
             x2p, f3, f4 = self.q_feature_extractor.forward_lowres2(fm_all)
-        # ---- host: sampler replay (bit-exact torch-CPU-generator sequence), overlapped with the above
-        C_.contrast_sample(plan, self.memobank, self.queue_size, a.func, a.num_queries, a.num_negatives)
+        # ---- host: wait for the counters; everything that needs the COUNTS but not the sampled INDICES is queued
+        #      first (row lists, prototypes, key rows, bank append, the supervised / unsupervised loss forwards), so the
+        #      GPU has work while the host replays the samplers (bit-exact torch-CPU-generator sequence, ~2 ms)
+        C_.contrast_counts(plan, self.memobank, self.queue_size, a.num_queries, a.num_negatives)
         ev2 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev2[0].record()
         C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size,
-                            lazy_teacher=lazy_t)
+                            lazy_teacher=lazy_t, defer_anchor_pix=True)
+        ev2[1].record()
+        # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340; SURVEY §8f row 1).  Not built:
+        # k2*loss_eqv (RandTPS) and k4*loss_q (revisiting loss; it has no gradient path to any parameter).
+        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)
+        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
+        C_.contrast_draw(plan, a.func)
+        ev3 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev3[0].record()
+        C_.contrast_anchor_pix(plan)
         if plan.valid_seg <= 1 or not plan.entries:
             reco_loss = self.q_representation[1].weight.sum() * 0.0      # :417-424 zero attached to the graph
         else:
@@ -282,12 +293,8 @@ class ArcoStep2D:
                                         self.q_feature_extractor.fea4.weight, self.q_representation[0].weight,
                                         self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)   # :394-398 (temp default)
-        ev2[1].record()
-        self.loss_events.append((ev, ev2))
-        # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340; SURVEY §8f row 1).  Not built:
-        # k2*loss_eqv (RandTPS) and k4*loss_q (revisiting loss; it has no gradient path to any parameter).
-        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)
-        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
+        ev3[1].record()
+        self.loss_events.append((ev, ev2, ev3))      # masks | lists, prototypes, keys, banks | anchors, head, InfoNCE
         loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()
