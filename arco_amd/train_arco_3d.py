@@ -128,8 +128,14 @@ class ArcoStep3D:
             rep_all = self.q_rep(qfe(fm_s))                              # :289-296,301
         else:
             x2p, f3, f4 = qfe.forward_lowres2(fm_s)
-        C_.contrast_sample(plan, self.memobank, self.queue_size, a.func, a.num_queries, a.num_negatives)
-        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size, lazy_teacher=lazy_t)
+        # counters -> [sample-independent GPU work] -> sampler replay on the host -> anchors (see train_arco_2d.py)
+        C_.contrast_counts(plan, self.memobank, self.queue_size, a.num_queries, a.num_negatives)
+        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size, lazy_teacher=lazy_t,
+                            defer_anchor_pix=True)
+        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
+        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
+        C_.contrast_draw(plan, a.func)
+        C_.contrast_anchor_pix(plan)
         if plan.valid_seg <= 1 or not plan.entries:
             reco_loss = self.q_representation[1].weight.sum() * 0.0
         elif dense:
@@ -139,8 +145,6 @@ class ArcoStep3D:
             A_all = head.lazy_head3d(x2p, f3, f4, qfe.fea3.weight, qfe.fea4.weight, self.q_representation[0].weight,
                                      self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
-        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
-        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
         loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q: no gradient path, not built)
         self.optimizer.zero_grad()
         loss.backward()
