@@ -37,7 +37,7 @@ _SIGS = {
     "arco_colsum": [_P, _L, _L, _I, _P, _P, _I, _P],
     "arco_transpose2d": [_P, _L, _I, _I, _P, _L, _P],
     "arco_bn_finalize": [_P, _P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _I, _P],
-    "arco_chan_stats": [_P, _L, _L, _I, _P, _P, _P],
+    "arco_chan_stats": [_P, _L, _L, _I, _P, _P, _I, _P],
     "arco_bn_act_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _L, _P, _I, _P],
     "arco_bn_act_bwd": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _P, _P, _I, _P, _L, _P, _I, _P],
     "arco_maxpool2_fwd": [_P, _L, _I, _I, _I, _I, _P, _L, _P],

@@ -87,6 +87,8 @@ __device__ __forceinline__ void block_channel_totals(f32x4 s, f32x4 q, int C, fl
 __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ X, long ldx, long M, int C,
                                                         float* __restrict__ ssum, float* __restrict__ ssq, int nblk) {
   const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
+  // blockIdx.y = BN group: rows [g*M, (g+1)*M), slabs [g*nblk, (g+1)*nblk) of the gridDim.y*nblk slabs per channel
+  X += (long)blockIdx.y * M * ldx;
   const long rpb = (M + nblk - 1) / nblk;
   const long r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
   f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
       s += v; q += v * v;
     }
   extern __shared__ __attribute__((aligned(16))) float red[];   // [2][256][4]
-  block_channel_totals(s, q, C, red, ssum, ssq, nblk);
+  block_channel_totals(s, q, C, red, ssum + (long)blockIdx.y * nblk, ssq + (long)blockIdx.y * nblk, nblk * gridDim.y);
 }
 
 // ---- BN apply + LeakyReLU(slope) + dropout:  a = drop(lrelu((z-mean)*istd*gamma+beta))
@@ -795,11 +797,12 @@ int arco_chan_stats_blocks(long M) {
   return (int)b;
 }
 
-int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream) {
-  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldx & 3) == 0);
-  const int nblk = arco_chan_stats_blocks(M);
-  hipLaunchKernelGGL(chan_stats_kernel, dim3(nblk), dim3(256), 2048 * sizeof(float), as_stream(stream), X, ldx, M, C,
-                     ssum, ssq, nblk);
+int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, int groups, void* stream) {
+  if (groups < 1) groups = 1;
+  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldx & 3) == 0 && M % groups == 0);
+  const int nblk = arco_chan_stats_blocks(M / groups);            // slabs per group; ssum/ssq: [C][groups*nblk]
+  hipLaunchKernelGGL(chan_stats_kernel, dim3(nblk, groups), dim3(256), 2048 * sizeof(float), as_stream(stream), X, ldx,
+                     M / groups, C, ssum, ssq, nblk);
   return arco_launch_status();
 }
 

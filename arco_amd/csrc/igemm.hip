@@ -68,6 +68,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   } else {
     m0 = (long)mblk * BM;
   }
+  // rows of this block end at m_lim: the tensor's end, or (GEMM form with grouped BN statistics) the end of the
+  // block's BN group - M-blocks are laid out per group so that no stat slab mixes two groups
+  long m_lim = a.M;
+  if (TAPS == 1 && a.stat_groups > 1) {
+    const int mpg = a.n_mblocks / a.stat_groups, g_ = mblk / mpg;
+    const long Mg = a.M / a.stat_groups;
+    m0 = g_ * Mg + (long)(mblk - g_ * mpg) * BM;
+    m_lim = (g_ + 1) * Mg;
+  }
 
   f32x4 acc[A_T][C_T];
 #pragma unroll
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         if (y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
       } else {
         const long m = m0 + row;
-        if (m < a.M) pix = m;
+        if (m < m_lim) pix = m;
       }
       ldsA[it] = row * LDK + 4 * q; kA[it] = 4 * q;
       if (pix >= 0) srcA[it] = a.A + pix * a.lda + 4 * q;
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
           if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
         } else {
           const long m = m0 + s * 16 + i;
-          if (m < a.M) pix = m;
+          if (m < m_lim) pix = m;
         }
         if (pix >= 0 && nok) {
           float v = acc[at][ct][r] + bv;
@@ -274,6 +283,7 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
   int mblocks;
   if (TAPS == 9) mblocks = a.NB * ((a.H + TH - 1) / TH) * ((a.W + 15) / 16);
+  else if (a.stat_groups > 1) mblocks = a.stat_groups * (int)((a.M / a.stat_groups + BM - 1) / BM);   // per-group M-blocks
   else mblocks = (int)((a.M + BM - 1) / BM);
   if (n_mblocks_out) {
     n_mblocks_out[0] = mblocks;

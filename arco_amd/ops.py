@@ -207,8 +207,6 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
     ssum = ssq = None
     nmb = 0
     if stats:
-        if stat_groups > 1 and taps == 1:
-            raise RuntimeError("arco_amd: grouped BN statistics are only produced by the spatial conv kernels")
         nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, k, n, ld, stat_groups)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
@@ -440,18 +438,23 @@ class BnActFn(torch.autograd.Function):
         for v in sp:
             P *= v
         mean = istd = None
+        G = 1
         if gamma is not None:
-            nblk = L.query("arco_chan_stats_blocks", m)
-            ssum = torch.empty((co, nblk), dtype=torch.float32, device=z.device)
-            ssq = torch.empty((co, nblk), dtype=torch.float32, device=z.device)
-            L.call("arco_chan_stats", L.ptr(zr), ldz, m, co, L.ptr(ssum), L.ptr(ssq))
-            mean = torch.empty(co, dtype=torch.float32, device=z.device)
-            istd = torch.empty(co, dtype=torch.float32, device=z.device)
-            L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nblk, co, m, float(eps), float(momentum), L.ptr(mean),
-                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), 1)
+            G = BN_GROUPS
+            if G > 1 and int(z.shape[0]) % G != 0:
+                raise RuntimeError(f"arco_amd: bn_groups({G}) needs a batch that is a multiple of {G}")
+            nblk = L.query("arco_chan_stats_blocks", m // G)
+            ssum = torch.empty((co, G * nblk), dtype=torch.float32, device=z.device)
+            ssq = torch.empty((co, G * nblk), dtype=torch.float32, device=z.device)
+            L.call("arco_chan_stats", L.ptr(zr), ldz, m, co, L.ptr(ssum), L.ptr(ssq), G)
+            mean = torch.empty(G * co, dtype=torch.float32, device=z.device)
+            istd = torch.empty(G * co, dtype=torch.float32, device=z.device)
+            L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), G * nblk, co, m, float(eps), float(momentum), L.ptr(mean),
+                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G)
         seed = _next_seed() if p > 0 else 0
         a = new_act_nd(int(z.shape[0]), co, sp, z.device)
-        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a)
+        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a, None, G)
+        ctx.groups = G
         ctx.save_for_backward(z, mean, istd, gamma, beta)
         ctx.cfg = (float(slope), float(p), int(drop_mode), seed, P)
         return a
@@ -460,7 +463,8 @@ class BnActFn(torch.autograd.Function):
     def backward(ctx, da):
         z, mean, istd, gamma, beta = ctx.saved_tensors
         slope, p, drop_mode, seed, P = ctx.cfg
-        dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, ctx.seed_dev)
+        dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, ctx.seed_dev,
+                                         ctx.groups)
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

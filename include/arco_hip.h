@@ -105,7 +105,7 @@ int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long 
                      float* mean, float* istd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                      int groups /* mean/istd rows: [groups][C] */, void* stream);
 int arco_chan_stats_blocks(long M);
-int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, void* stream);
+int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, int groups, void* stream);
 int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                     const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
                     const uint64_t* seed_dev, int groups, void* stream);
