@@ -83,6 +83,9 @@ class ArcoStep3D:
         g_train = use_graphs and bool(getattr(args, "graph_train", 0))
         self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train)    # student passes: fwd + bwd graphs
         self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train)
+        self.batched_passes = bool(getattr(args, "batched_passes", 1))
+        self.s_train_lu = graphs.GraphedTrain(self.model, enabled=g_train)
+        self.t_fwd_lu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -102,10 +105,23 @@ class ArcoStep3D:
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits   # :268-278 (identity transforms)
         self.k_fe_ema.update(0.99)                                      # :279-281
-        pred_u, _, u_fm = self.s_train_u(u_aug)                              # :284
+        batched = self.batched_passes and l_data.shape == u_aug.shape
+        if batched:     # labelled + unlabelled volumes as one pass with two BatchNorm groups (see train_arco_2d.py)
+            lu = torch.cat((l_data, u_aug))
+            nb_l = int(l_data.shape[0])
+            with ops.bn_groups(2):
+                pred_all, _, fm_s = self.s_train_lu(lu)                  # :283-284
+            pred_l, pred_u = pred_all[:nb_l], pred_all[nb_l:]
+        else:
+            pred_u, _, u_fm = self.s_train_u(u_aug)                      # :284
         with torch.no_grad():
-            pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)                   # :286
-            pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                    # :287
+            if batched:
+                with ops.bn_groups(2):
+                    pred_t, _, fm_t = self.t_fwd_lu(lu)                  # :286-287
+                pred_l_t, pred_u_t = pred_t[:nb_l], pred_t[nb_l:]
+            else:
+                pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)               # :286
+                pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                # :287
             alpha_t = 20 * (1 - epoch_num / max_epoch)
             label_l = glue.label_onehot(l_label, C)
             label_u = glue.label_onehot(u_aug_label, C)
@@ -114,10 +130,11 @@ class ArcoStep3D:
             low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
         plan = C_.contrast_masks(label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all,
                                  delta_n=a.strong_threshold_u2pl)
-        pred_l, _, l_fm = self.s_train_l(l_data)                             # :283
         dense = getattr(a, "dense_head", 0)
-        fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
-        fm_s = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]
+        if not batched:
+            pred_l, _, l_fm = self.s_train_l(l_data)                     # :283
+            fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
+            fm_s = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]
         kfe, qfe = self.k_feature_extractor, self.q_feature_extractor
         with torch.no_grad():                                            # :292-293
             if dense:
