@@ -19,20 +19,26 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
 
 // ---- BN statistics finalize: block partial (sum, sumsq) -> mean, istd, running stats.
 //      One 64-lane wave per channel; fp64 tree over the partial slabs.
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
                                    double count, float eps, float momentum, float* __restrict__ mean,
                                    float* __restrict__ istd, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked, int groups) {
   // groups > 1: the batch is `groups` independent BN batches (e.g. the labelled and the unlabelled half of one
   // launch); group g owns the slabs [g*nblk/groups, ...), has `count` elements per channel, gets mean/istd row g,
-  // and the running statistics receive the groups' updates one after the other (as separate forwards would)
-  const int c = blockIdx.x, npg = nblk / groups;
+  // and the running statistics receive the groups' updates one after the other (as separate forwards would).
+  // One 4-wave block per channel (the 3-D levels have up to 31 360 slabs per channel), fixed summation order.
+  __shared__ double sh[2][4];
+  const int c = blockIdx.x, npg = nblk / groups, w = threadIdx.x >> 6;
   if (c == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += groups;
   for (int g = 0; g < groups; ++g) {
     double s = 0.0, q = 0.0;
-    for (int b = threadIdx.x; b < npg; b += 64) { s += (double)ssum[(long)c * nblk + g * npg + b]; q += (double)ssq[(long)c * nblk + g * npg + b]; }
+    for (int b = threadIdx.x; b < npg; b += 256) { s += (double)ssum[(long)c * nblk + g * npg + b]; q += (double)ssq[(long)c * nblk + g * npg + b]; }
     s = wave_sum_d(s); q = wave_sum_d(q);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = q; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+      s = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]); q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
       const double m = s / count;
       double var = q / count - m * m;
       if (var < 0.0) var = 0.0;
@@ -780,7 +786,7 @@ int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long 
                      int groups, void* stream) {
   if (groups < 1) groups = 1;
   ARCO_CHECK_ARG(C > 0 && nblk > 0 && count > 0 && nblk % groups == 0 && count % groups == 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), ssum, ssq, nblk, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), ssum, ssq, nblk, C,
                      (double)(count / groups), eps, momentum, mean, istd, running_mean, running_var, num_batches_tracked,
                      groups);
   return arco_launch_status();
