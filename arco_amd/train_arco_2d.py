@@ -168,9 +168,8 @@ class ArcoStep2D:
         # no-grad forwards replayed as HIP graphs (one graph per call site: outputs are static buffers)
         use_graphs = bool(getattr(args, "graphs", 1))
         g_train = use_graphs and bool(getattr(args, "graph_train", 0))
-        sub = os.environ.get("ARCO_GT_SUBSET", "ul")
-        self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train and "u" in sub)    # student passes: fwd + bwd graphs
-        self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train and "l" in sub)
+        self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train)    # student passes: fwd + bwd graphs
+        self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train)
         self.batched_passes = bool(getattr(args, "batched_passes", 1))
         self.s_train_lu = graphs.GraphedTrain(self.model, enabled=g_train)
         self.t_fwd_lu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
