@@ -359,7 +359,11 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed(args.seed)
     snapshot_path = "../model/{}_{}_labeled{}/{}".format(args.exp, args.labeled_num, 'final', args.model)
-    os.makedirs(snapshot_path, exist_ok=True)
+    try:                                                             # the reference writes next to the repo (../model)
+        os.makedirs(snapshot_path, exist_ok=True)
+    except OSError:                                                  # read-only parent: keep the run inside the cwd
+        snapshot_path = snapshot_path[1:]
+        os.makedirs(snapshot_path, exist_ok=True)
     logging.basicConfig(filename=snapshot_path + "/log.txt", level=logging.INFO,
                         format='[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S')
     logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
