@@ -293,6 +293,24 @@ __global__ __launch_bounds__(256) void unsup_loss_bwd_kernel(const float* __rest
   }
 }
 
+
+// ---- evaluation: per-class overlap counts of two label maps (test_2D.py:52-66, medpy dc / jc):
+//      out[c] = {|pred == c|, |gt == c|, |pred == c and gt == c|}; integer atomics -> deterministic
+__global__ __launch_bounds__(256) void overlap_counts_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ gt,
+                                                            long n, int C, unsigned long long* __restrict__ out) {
+  __shared__ unsigned int h[3 * GL_MAXC];
+  for (int i = threadIdx.x; i < 3 * C; i += 256) h[i] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int64_t p = pred[i], g = gt[i];
+    if (p >= 0 && p < C) atomicAdd(&h[3 * p], 1u);
+    if (g >= 0 && g < C) atomicAdd(&h[3 * g + 1], 1u);
+    if (p == g && p >= 0 && p < C) atomicAdd(&h[3 * p + 2], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) if (h[i]) atomicAdd(&out[i], (unsigned long long)h[i]);
+}
+
 static inline int gl_grid(long work) { long g = (work + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
 
 extern "C" {
@@ -307,6 +325,16 @@ int arco_softmax_rows(const float* X, long ld, long M, int C, long P, float* pro
 
 int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, void* stream) {
   hipLaunchKernelGGL(onehot_kernel, dim3(gl_grid(M)), dim3(256), 0, as_stream(stream), lab, M, C, P, out);
+  return arco_launch_status();
+}
+
+// out: C*3 int64 counters {pred, gt, both} per class (zeroed here)
+int arco_overlap_counts(const int64_t* pred, const int64_t* gt, long n, int C, int64_t* out, void* stream) {
+  ARCO_CHECK_ARG(pred && gt && out && n > 0 && C >= 1 && C <= GL_MAXC);
+  (void)hipMemsetAsync(out, 0, sizeof(int64_t) * 3 * C, as_stream(stream));
+  int g = gl_grid(n); if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(overlap_counts_kernel, dim3(g), dim3(256), 0, as_stream(stream), pred, gt, n, C,
+                     reinterpret_cast<unsigned long long*>(out));
   return arco_launch_status();
 }
 

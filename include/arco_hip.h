@@ -163,6 +163,8 @@ int arco_softmax_rows(const float* X, long ld, long M, int C, long P, float* pro
 int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, void* stream);
 /* ---- §8f row 1: supervised CrossEntropy + Dice (train_arco_2d.py:336-339, utils/losses.py:173-209) and the
  *      confidence-weighted unsupervised CE (train_arco_2d.py:482-489) on channels-last logits             */
+/* ---- V  evaluation (test_2D.py:52-66): out[c] = {|pred==c|, |gt==c|, |pred==c & gt==c|} as int64[C][3]          */
+int arco_overlap_counts(const int64_t* pred, const int64_t* gt, long n, int C, int64_t* out, void* stream);
 long arco_seg_ws_doubles(long M, int C, int B);
 int arco_sup_loss_fwd(const float* X, long ld, long M, int C, const int64_t* lab, double* ws, float* out, void* stream);
 int arco_sup_loss_bwd(const float* X, long ld, long M, int C, const int64_t* lab, const double* ws, const float* g_ce,

@@ -268,31 +268,36 @@ def bn_train(x, w, b, rm=None, rv=None, momentum=0.1, eps=1e-5):
     return F.batch_norm(x, rm, rv, w, b, True, momentum, eps)
 
 
-def conv_block_2d(x, sd, pre, slope=0.01):
-    """networks/unetWithArgs.py:31-47 with Dropout disabled (p forced to 0)."""
+def conv_block_2d(x, sd, pre, slope=0.01, train=True):
+    """networks/unetWithArgs.py:31-47 with Dropout disabled (p forced to 0).  train=False: net.eval()
+    (BatchNorm on the running statistics, test_2D.py:78)."""
     for k in ("0", "4"):
         x = F.conv2d(x, sd[f"{pre}.conv_conv.{k}.weight"], sd[f"{pre}.conv_conv.{k}.bias"], padding=1)
         bnk = str(int(k) + 1)
-        x = bn_train(x, sd[f"{pre}.conv_conv.{bnk}.weight"], sd[f"{pre}.conv_conv.{bnk}.bias"])
+        if train:
+            x = bn_train(x, sd[f"{pre}.conv_conv.{bnk}.weight"], sd[f"{pre}.conv_conv.{bnk}.bias"])
+        else:
+            x = F.batch_norm(x, sd[f"{pre}.conv_conv.{bnk}.running_mean"], sd[f"{pre}.conv_conv.{bnk}.running_var"],
+                             sd[f"{pre}.conv_conv.{bnk}.weight"], sd[f"{pre}.conv_conv.{bnk}.bias"], False, 0.1, 1e-5)
         x = F.leaky_relu(x, slope)
     return x
 
 
-def unet_forward(x, sd):
+def unet_forward(x, sd, train=True):
     """networks/unetWithArgs.py:109-116 (Encoder), :142-158 (Decoder), :345-348 (UNet);
     dropout off.  NB the Decoder constructs UpBlock WITHOUT passing `bilinear`
     (:130-137), so UpBlock's default bilinear=True applies (:66): the up-path is
     conv1x1 (bias) -> x2 bilinear upsample align_corners=True (:72-75,80-83), not
     ConvTranspose2d, whatever params['bilinear'] (:317) says."""
-    feats = [conv_block_2d(x, sd, "encoder.in_conv")]
+    feats = [conv_block_2d(x, sd, "encoder.in_conv", train=train)]
     for i in range(1, 5):
-        feats.append(conv_block_2d(F.max_pool2d(feats[-1], 2), sd, f"encoder.down{i}.maxpool_conv.1"))
+        feats.append(conv_block_2d(F.max_pool2d(feats[-1], 2), sd, f"encoder.down{i}.maxpool_conv.1", train=train))
     x = feats[4]
     fmap = [x]
     for i, skip in zip(range(1, 5), (feats[3], feats[2], feats[1], feats[0])):
         up = F.conv2d(x, sd[f"decoder.up{i}.conv1x1.weight"], sd[f"decoder.up{i}.conv1x1.bias"])
         up = F.interpolate(up, scale_factor=2, mode='bilinear', align_corners=True)
-        x = conv_block_2d(torch.cat([skip, up], 1), sd, f"decoder.up{i}.conv")
+        x = conv_block_2d(torch.cat([skip, up], 1), sd, f"decoder.up{i}.conv", train=train)
         fmap.append(x)
     out = F.conv2d(x, sd["decoder.out_conv.weight"], sd["decoder.out_conv.bias"], padding=1)
     return out, feats[4], fmap
@@ -415,3 +420,37 @@ def sgd_nesterov_step(p, g, buf, lr, momentum=0.9, wd=1e-4):
     g = g + wd * p
     buf = g.clone() if buf is None else momentum * buf + g
     return p - lr * (g + momentum * buf), buf
+
+
+# --------------------------------------------------------------------------
+# V  evaluation: test_2D.py:52-103
+# --------------------------------------------------------------------------
+
+
+def dice_jaccard(pred, gt):
+    """calculate_metric_percase (test_2D.py:52-66) restricted to the overlap metrics: medpy's binary dc / jc
+    (2|A&B| / (|A|+|B|), |A&B| / |A|B|) with the reference's empty-set conventions; hd95 / asd need medpy."""
+    pred = np.asarray(pred) > 0
+    gt = np.asarray(gt) > 0
+    if pred.sum() > 0 and gt.sum() > 0:
+        inter = float(np.logical_and(pred, gt).sum())
+        return 2.0 * inter / float(pred.sum() + gt.sum()), inter / float(np.logical_or(pred, gt).sum())
+    if pred.sum() > 0 and gt.sum() == 0:
+        return 1.0, 1.0
+    return 0.0, 0.0
+
+
+def test_single_volume(image, label, sd, classes, patch=(256, 256)):
+    """test_2D.py:67-92 on arrays: per slice zoom(order=0) to `patch`, eval-mode net, argmax(softmax), zoom back;
+    then (dice, jaccard) for classes 1..classes-1."""
+    from scipy.ndimage import zoom
+    prediction = np.zeros_like(label)
+    for ind in range(image.shape[0]):
+        sl = image[ind]
+        x, y = sl.shape
+        sl = zoom(sl, (patch[0] / x, patch[1] / y), order=0)
+        inp = torch.from_numpy(sl).unsqueeze(0).unsqueeze(0).float()
+        with torch.no_grad():
+            out = torch.argmax(torch.softmax(unet_forward(inp, sd, train=False)[0], dim=1), dim=1).squeeze(0).numpy()
+        prediction[ind] = zoom(out, (x / patch[0], y / patch[1]), order=0)
+    return [dice_jaccard(prediction == i, label == i) for i in range(1, classes)], prediction

@@ -1,0 +1,59 @@
+"""Evaluation path: eval-mode inference, zoom round trip and Dice / Jaccard on the HIP path vs
+the CPU oracle (oracle/arco_oracle.py: test_single_volume, dice_jaccard) - test_2D.py:52-92 of the reference."""
+import numpy as np
+import pytest
+import torch
+
+import arco_oracle as orc
+import fixture_inputs as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def _volume(rs, S, x, y, C):
+    img = rs.uniform(size=(S, x, y)).astype(np.float32)
+    lab = np.stack([fx.blob_labels(rs, 1, (x, y), C)[0] for _ in range(S)]).astype(np.int64)
+    return img, lab
+
+
+def test_overlap_counts_match_numpy():
+    from arco_amd import test_2D
+    rs = np.random.RandomState(0)
+    for n, C in ((1000, 4), (70001, 19), (5, 2)):
+        p = rs.randint(0, C, size=n); g = rs.randint(0, C, size=n)
+        got = test_2D.overlap_counts(torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda(), C).cpu().numpy()
+        exp = np.array([[(p == c).sum(), (g == c).sum(), ((p == c) & (g == c)).sum()] for c in range(C)])
+        np.testing.assert_array_equal(got, exp)
+
+
+def test_single_volume_matches_oracle():
+    """Non-square slices (zoom both ways), eval-mode BatchNorm with non-trivial running statistics."""
+    from arco_amd import test_2D
+    from arco_amd.networks.unetWithArgs import UNet
+    C = 4
+    sd = fx.unet_state(21, 1, C)
+    rs = np.random.RandomState(4)
+    for k in list(sd):                      # make the running statistics differ from (0, 1)
+        if k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(rs.normal(scale=0.1, size=tuple(sd[k].shape)).astype(np.float32))
+        if k.endswith("running_var"):
+            sd[k] = torch.from_numpy(rs.uniform(0.5, 1.5, size=tuple(sd[k].shape)).astype(np.float32))
+    net = UNet(1, C).cuda()
+    net.load_state_dict(sd, strict=True)
+    img, lab = _volume(rs, 5, 48, 80, C)
+    patch = (64, 64)
+    exp_metrics, exp_pred = orc.test_single_volume(img, lab, sd, C, patch)
+    got_pred = test_2D.predict_volume(img, net, patch)
+    agree = float((got_pred == exp_pred).mean())
+    assert agree > 0.999, agree             # argmax flips only where two logits tie to fp32 rounding
+    got = test_2D.test_single_volume(img, lab, net, C, patch)
+    assert len(got) == C - 1
+    for (d, j, _, _), (de, je) in zip(got, exp_metrics):
+        assert abs(d - de) < 5e-3 and abs(j - je) < 5e-3, ((d, j), (de, je))
+    # the reference's empty-set conventions
+    assert test_2D.calculate_metric_percase(np.zeros((4, 4)), np.zeros((4, 4)))[:2] == (0.0, 0.0)
+    assert test_2D.calculate_metric_percase(np.ones((4, 4)), np.zeros((4, 4)))[:2] == (1.0, 1.0)
+    m = np.zeros((4, 4)); m[:2] = 1; g = np.zeros((4, 4)); g[1:3] = 1
+    d, j, _, _ = test_2D.calculate_metric_percase(m, g)
+    assert abs(d - 0.5) < 1e-12 and abs(j - 1.0 / 3.0) < 1e-12
+    assert net.training                      # predict_volume restores the mode it found

@@ -187,3 +187,13 @@ def test_trainer_glue(golden):
         p, buf = orc.sgd_nesterov_step(p, torch.from_numpy(g["sgd_g"][it]), buf, lr)
         np.testing.assert_allclose(p.numpy(), g[f"sgd_p{it}"], rtol=1e-6, atol=1e-7)
         lr = orc.poly_lr(0.01, it, 30000)
+
+
+def test_dice_jaccard_conventions():
+    """oracle.dice_jaccard = medpy dc / jc with the reference's empty-set cases (test_2D.py:52-66)."""
+    a = np.zeros((6, 6), dtype=bool); a[1:4, 1:4] = True        # 9 px
+    b = np.zeros((6, 6), dtype=bool); b[2:5, 2:5] = True        # 9 px, 4 shared
+    d, j = orc.dice_jaccard(a, b)
+    assert abs(d - 8.0 / 18.0) < 1e-12 and abs(j - 4.0 / 14.0) < 1e-12
+    assert orc.dice_jaccard(a, np.zeros_like(a)) == (1.0, 1.0)
+    assert orc.dice_jaccard(np.zeros_like(a), b) == (0.0, 0.0)
