@@ -454,3 +454,88 @@ def test_single_volume(image, label, sd, classes, patch=(256, 256)):
             out = torch.argmax(torch.softmax(unet_forward(inp, sd, train=False)[0], dim=1), dim=1).squeeze(0).numpy()
         prediction[ind] = zoom(out, (x / patch[0], y / patch[1]), order=0)
     return [dice_jaccard(prediction == i, label == i) for i in range(1, classes)], prediction
+
+
+# --------------------------------------------------------------------------
+# E  equivariance loss: tps/rand_tps.py:48-153, tps_stn_pytorch/tps_grid_gen.py:9-71,
+#    tps/grid_sample.py:11-20, train_arco_2d.py:404-423
+# --------------------------------------------------------------------------
+
+
+def _tps_u(points, controls):
+    """U(r) = 0.5 * r^2 * log(r^2) between two point sets, 0 where r == 0 (tps_grid_gen.py:9-21)."""
+    d = points.view(-1, 1, 2) - controls.view(1, -1, 2)
+    d2 = d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]
+    u = 0.5 * d2 * torch.log(d2)
+    u[u != u] = 0
+    return u
+
+
+def tps_constants(height, width):
+    """(target control points [25,2], inverse kernel [28,28], target coordinate representation [H*W, 28]):
+    rand_tps.py:101-104 and TPSGridGen.__init__ (tps_grid_gen.py:25-57).  Pixel (y, x) -> (X, Y) in [-1, 1]."""
+    ticks = torch.arange(-1.0, 1.00001, 2.0 / 4)
+    tcp = torch.Tensor([(float(a), float(b)) for a in ticks for b in ticks])
+    n = tcp.shape[0]
+    k = torch.zeros(n + 3, n + 3)
+    k[:n, :n] = _tps_u(tcp, tcp)
+    k[:n, -3] = 1
+    k[-3, :n] = 1
+    k[:n, -2:] = tcp
+    k[-2:, :n] = tcp.t()
+    inv = torch.inverse(k)
+    yy, xx = torch.meshgrid(torch.arange(height, dtype=torch.float32), torch.arange(width, dtype=torch.float32), indexing="ij")
+    Y = yy.reshape(-1, 1) * 2 / (height - 1) - 1
+    X = xx.reshape(-1, 1) * 2 / (width - 1) - 1
+    coord = torch.cat([X, Y], dim=1)
+    rep = torch.cat([_tps_u(coord, tcp), torch.ones(height * width, 1), coord], dim=1)
+    return tcp, inv, rep
+
+
+def rand_tps_source_points(tcp, batch, sigma, random_scale=(0.8, 1.2), translate=0.1, rotate=60, mirror=True):
+    """RandTPS.reset_control_points up to the control points (rand_tps.py:110-139), mode 'affine'.  Generator calls,
+    in order: one torch uniform_ of [batch,25,2]; four numpy uniforms of [batch] (angle, scale, shift x, shift y);
+    one python random.randint(0, 1)."""
+    src = tcp.unsqueeze(0).repeat(batch, 1, 1)
+    src = src + torch.Tensor(src.size()).uniform_(-sigma, sigma)
+    inv_scale = (1.0 / random_scale[1], 1.0 / random_scale[0])          # applied target -> source (rand_tps.py:88)
+    ang = np.random.uniform(size=[batch], low=-rotate, high=rotate) / 180.0 * np.pi
+    sc = np.random.uniform(size=[batch], low=inv_scale[0], high=inv_scale[1])
+    sx = np.random.uniform(size=(batch,), low=-translate, high=translate).reshape(-1, 1)
+    sy = np.random.uniform(size=(batch,), low=-translate, high=translate).reshape(-1, 1)
+    half = np.float32(np.float32(2.0) / 2.0)                           # img_sz = 2.0
+    cos_v = (sc * np.cos(ang)).reshape(-1, 1)
+    sin_v = (sc * np.sin(ang)).reshape(-1, 1)
+    theta = np.concatenate([cos_v, -sin_v, sx * half, sin_v, cos_v, sy * half], axis=1)
+    t = torch.from_numpy(theta.reshape(-1, 2, 3).copy()).type(torch.FloatTensor).transpose(1, 2)    # [B,3,2]
+    src = torch.matmul(torch.cat((src, torch.ones(batch, src.shape[1], 1)), dim=2), t)
+    if mirror and random.randint(0, 1):
+        src[:, :, 0] = -src[:, :, 0]
+    return src
+
+
+def tps_grid(src, inv, rep, height, width):
+    """TPSGridGen.forward (tps_grid_gen.py:59-71): grid [B, H, W, 2] of source (x, y) in [-1, 1]."""
+    Y = torch.cat([src, torch.zeros(src.shape[0], 3, 2)], 1)
+    return torch.matmul(rep, torch.matmul(inv, Y)).view(-1, height, width, 2)
+
+
+def grid_sample(x, grid, padding_mode='zeros'):
+    """tps/grid_sample.py:11-12 (canvas=None): bilinear, align_corners=True."""
+    return F.grid_sample(x, grid, mode='bilinear', padding_mode=padding_mode, align_corners=True)
+
+
+def eqv_mask(labels, logits, weak_threshold):
+    """train_arco_2d.py:406-410: 1 where the (pseudo-)label is foreground and its confidence >= weak_threshold."""
+    m = torch.ones(labels.shape, dtype=torch.float32)
+    m[labels == 0] = 0
+    m[logits < weak_threshold] = 0
+    return m.unsqueeze(1)
+
+
+def eqv_loss(pred_tps, pred_tps_org, mask_tps):
+    """train_arco_2d.py:419-423: per-image masked mean of KL(softmax(pred_tps_org) || softmax(pred_tps)) summed over
+    classes, averaged over images."""
+    kl = F.kl_div(F.log_softmax(pred_tps, dim=1), F.softmax(pred_tps_org, dim=1), reduction='none')
+    per = (kl * mask_tps).flatten(1).sum(1) / (mask_tps.flatten(1).sum(1) + 1e-7)
+    return per.mean()

@@ -331,10 +331,63 @@ def gen_glue():
     print("g4_glue", len(out))
 
 
+# ---------------------------------------------------------------- G5 equivariance loss
+def gen_eqv():
+    """RandTPS (tps/rand_tps.py:82-153 + tps_stn_pytorch/tps_grid_gen.py) and the loss_eqv block of
+    train_arco_2d.py:404-423, run from the reference modules on CPU for fixed seeds."""
+    import importlib
+    import torch.nn as nn
+    import torch.nn.functional as F
+    rand_tps = importlib.import_module("tps.rand_tps")
+    out = {}
+    cases = [("a", 4, 24, 32, 0.01, 11), ("b", 3, 16, 16, 0.05, 12), ("c", 2, 32, 24, 0.01, 13)]
+    for tag, B, W, H, sigma, seed in cases:                 # RandTPS(width, height, ...) as the trainer calls it
+        seed_all(seed)
+        tps = rand_tps.RandTPS(W, H, batch_size=B, sigma=sigma, border_padding=False, random_mirror=True,
+                               random_scale=(0.8, 1.2), mode='affine')
+        probe0 = (rng_probe(), float(np.random.uniform()), random.random())
+        out[f"{tag}_cfg"] = np.array([B, W, H, sigma, seed], dtype=np.float64)
+        out[f"{tag}_grid_init"] = tps.grid.data.numpy().copy()
+        out[f"{tag}_probe_init"] = np.array(probe0, dtype=np.float64)
+        seed_all(seed + 100)
+        tps.reset_control_points()
+        probe1 = (rng_probe(), float(np.random.uniform()), random.random())
+        out[f"{tag}_grid"] = tps.grid.data.numpy().copy()
+        out[f"{tag}_probe"] = np.array(probe1, dtype=np.float64)
+        # tensors of the trainer's shapes: images [B,1,h,w], mask [B,1,h,w], predictions [B,C,h,w]; grid is [B, H, W, 2]
+        h, w = tps.grid.shape[1], tps.grid.shape[2]
+        rs = np.random.RandomState(seed + 7)
+        C = 4
+        img = torch.from_numpy(rs.uniform(size=(B, 1, h, w)).astype(np.float32))
+        labels = torch.from_numpy(rs.randint(0, C, size=(B, h, w)))
+        logits = torch.from_numpy(rs.uniform(size=(B, h, w)).astype(np.float32))
+        pred_all = torch.from_numpy(rs.normal(size=(B, C, h, w)).astype(np.float32))
+        pred_tps = torch.from_numpy(rs.normal(size=(B, C, h, w)).astype(np.float32)).requires_grad_(True)
+        mask = torch.ones((B, h, w)); neg = torch.zeros((B, h, w))
+        mask = torch.where(labels == 0, neg, mask)
+        mask = torch.where(logits < 0.7, neg, mask)
+        mask = mask.unsqueeze(1)
+        images_tps = tps(img)
+        mask_tps = tps(mask.float(), padding_mode='zeros')
+        pred_tps_org = tps(pred_all, padding_mode='zeros')
+        kl = nn.KLDivLoss(reduction='none')
+        loss_eqv = kl(F.log_softmax(pred_tps, dim=1), F.softmax(pred_tps_org, dim=1))
+        loss_eqv = (loss_eqv * mask_tps).flatten(1).sum(1) / (mask_tps.flatten(1).sum(1) + 1e-7)
+        loss_eqv = loss_eqv.mean()
+        loss_eqv.backward()
+        for k, v in (("img", img), ("labels", labels), ("logits", logits), ("pred_all", pred_all), ("pred_tps", pred_tps.detach()),
+                     ("images_tps", images_tps), ("mask_tps", mask_tps), ("pred_tps_org", pred_tps_org),
+                     ("loss", loss_eqv.detach()), ("grad", pred_tps.grad)):
+            out[f"{tag}_{k}"] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g5_eqv.npz"), **out)
+    print("g5_eqv", len(out))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
     if "g4" in which: gen_glue()
+    if "g5" in which: gen_eqv()

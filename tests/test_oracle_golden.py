@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/arco_oracle.py) to golden vectors produced by the real
 reference (oracle/gen_golden.py).  CPU-only; no reference import at test time."""
 import hashlib
+import os
 import random
 
 import numpy as np
@@ -197,3 +198,40 @@ def test_dice_jaccard_conventions():
     assert abs(d - 8.0 / 18.0) < 1e-12 and abs(j - 4.0 / 14.0) < 1e-12
     assert orc.dice_jaccard(a, np.zeros_like(a)) == (1.0, 1.0)
     assert orc.dice_jaccard(np.zeros_like(a), b) == (0.0, 0.0)
+
+
+@pytest.fixture(scope="module")
+def g5():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "g5_eqv.npz"))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_eqv_oracle_vs_reference(g5, tag):
+    """RandTPS grids (incl. how much of the three generators a reset consumes), grid_sample and loss_eqv with its
+    gradient: oracle restatement vs vectors produced by the reference's tps modules (oracle/gen_golden.py g5)."""
+    B, W, H, sigma, seed = g5[f"{tag}_cfg"]
+    B, W, H, seed = int(B), int(W), int(H), int(seed)
+    tcp, inv, rep = orc.tps_constants(H, W)
+    seed_all(seed)
+    src = orc.rand_tps_source_points(tcp, B, float(sigma))                   # the constructor's reset
+    np.testing.assert_allclose(orc.tps_grid(src, inv, rep, H, W).numpy(), g5[f"{tag}_grid_init"], rtol=1e-5, atol=2e-6)
+    probe = (int(torch.randint(1 << 30, (1,))), float(np.random.uniform()), random.random())
+    np.testing.assert_allclose(np.array(probe), g5[f"{tag}_probe_init"], rtol=0, atol=0)
+    seed_all(seed + 100)
+    src = orc.rand_tps_source_points(tcp, B, float(sigma))
+    grid = orc.tps_grid(src, inv, rep, H, W)
+    np.testing.assert_allclose(grid.numpy(), g5[f"{tag}_grid"], rtol=1e-5, atol=2e-6)
+    probe = (int(torch.randint(1 << 30, (1,))), float(np.random.uniform()), random.random())
+    np.testing.assert_allclose(np.array(probe), g5[f"{tag}_probe"], rtol=0, atol=0)
+    g = torch.from_numpy(g5[f"{tag}_grid"])
+    np.testing.assert_allclose(orc.grid_sample(torch.from_numpy(g5[f"{tag}_img"]), g).numpy(), g5[f"{tag}_images_tps"], atol=1e-6)
+    mask = orc.eqv_mask(torch.from_numpy(g5[f"{tag}_labels"]), torch.from_numpy(g5[f"{tag}_logits"]), 0.7)
+    mask_tps = orc.grid_sample(mask, g)
+    np.testing.assert_allclose(mask_tps.numpy(), g5[f"{tag}_mask_tps"], atol=1e-6)
+    org = orc.grid_sample(torch.from_numpy(g5[f"{tag}_pred_all"]), g)
+    np.testing.assert_allclose(org.numpy(), g5[f"{tag}_pred_tps_org"], atol=1e-6)
+    p = torch.from_numpy(g5[f"{tag}_pred_tps"]).requires_grad_(True)
+    loss = orc.eqv_loss(p, org, mask_tps)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g5[f"{tag}_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(p.grad.numpy(), g5[f"{tag}_grad"], rtol=1e-5, atol=1e-9)
