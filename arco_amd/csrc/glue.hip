@@ -311,6 +311,100 @@ __global__ __launch_bounds__(256) void overlap_counts_kernel(const int64_t* __re
   for (int i = threadIdx.x; i < 3 * C; i += 256) if (h[i]) atomicAdd(&out[i], (unsigned long long)h[i]);
 }
 
+// ---- equivariance loss (tps/rand_tps.py, tps_stn_pytorch/tps_grid_gen.py, train_arco_2d.py:404-423)
+// grid[b][p][0..1] = rep[p][0..NR) . mapping[b][0..NR)[0..1]   (TPSGridGen.forward, NR = 25 control points + 3)
+__global__ __launch_bounds__(256) void tps_grid_kernel(const float* __restrict__ rep, const float* __restrict__ mapping, int B,
+                                                      long HW, int NR, float* __restrict__ grid) {
+  extern __shared__ float mp[];                      // [B][NR][2]
+  for (int i = threadIdx.x; i < B * NR * 2; i += 256) mp[i] = mapping[i];
+  __syncthreads();
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    float r[32];
+    for (int k = 0; k < NR; ++k) r[k] = rep[p * NR + k];
+    for (int b = 0; b < B; ++b) {
+      float gx = 0.f, gy = 0.f;
+      for (int k = 0; k < NR; ++k) { gx += r[k] * mp[(b * NR + k) * 2]; gy += r[k] * mp[(b * NR + k) * 2 + 1]; }
+      grid[((long)b * HW + p) * 2] = gx; grid[((long)b * HW + p) * 2 + 1] = gy;
+    }
+  }
+}
+// F.grid_sample(mode='bilinear', align_corners=True), channels-last rows; padding 0: zeros, 1: border
+__global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __restrict__ X, long ldx, int NB, int H, int W, int C,
+                                                             const float* __restrict__ grid, int Ho, int Wo, int border,
+                                                             float* __restrict__ Y, long ldy) {
+  const long tot = (long)NB * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C); const long po = i / C; const int n = (int)(po / ((long)Ho * Wo));
+    float ix = (grid[po * 2] + 1.f) * 0.5f * (float)(W - 1), iy = (grid[po * 2 + 1] + 1.f) * 0.5f * (float)(H - 1);
+    if (border) { ix = fminf(fmaxf(ix, 0.f), (float)(W - 1)); iy = fminf(fmaxf(iy, 0.f), (float)(H - 1)); }
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    const float* base = X + (long)n * H * W * ldx + c;
+    float v = 0.f;
+    if (y0 >= 0 && y0 < H && x0 >= 0 && x0 < W) v += base[((long)y0 * W + x0) * ldx] * (wx0 * wy0);
+    if (y0 >= 0 && y0 < H && x1 >= 0 && x1 < W) v += base[((long)y0 * W + x1) * ldx] * (wx1 * wy0);
+    if (y1 >= 0 && y1 < H && x0 >= 0 && x0 < W) v += base[((long)y1 * W + x0) * ldx] * (wx0 * wy1);
+    if (y1 >= 0 && y1 < H && x1 >= 0 && x1 < W) v += base[((long)y1 * W + x1) * ldx] * (wx1 * wy1);
+    Y[po * ldy + c] = v;
+  }
+}
+// masked KL(softmax(q) || softmax(p)) per image: partial [b][blk] = {sum mask*kl, sum mask}
+__global__ __launch_bounds__(256) void eqv_loss_partial_kernel(const float* __restrict__ Pm, long ldp, const float* __restrict__ Qm, long ldq,
+                                                              const float* __restrict__ mask, long P, int C, double* __restrict__ part) {
+  const long img = blockIdx.y;
+  double a0 = 0.0, a1 = 0.0;
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < P; r += (long)gridDim.x * 256) {
+    const long row = img * P + r;
+    const float m = mask[row];
+    const float* p = Pm + row * ldp; const float* q = Qm + row * ldq;
+    float mp = -INFINITY, mq = -INFINITY;
+    for (int c = 0; c < C; ++c) { mp = fmaxf(mp, p[c]); mq = fmaxf(mq, q[c]); }
+    float sp = 0.f, sq = 0.f;
+    for (int c = 0; c < C; ++c) { sp += expf(p[c] - mp); sq += expf(q[c] - mq); }
+    const float lsp = mp + logf(sp), lsq = mq + logf(sq);
+    float kl = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float lt = q[c] - lsq, t = expf(lt);
+      if (t > 0.f) kl += t * (lt - (p[c] - lsp));
+    }
+    a0 += (double)(kl * m); a1 += (double)m;
+  }
+  __shared__ double sh[4][2];
+  double w0 = wave_sum_d(a0), w1 = wave_sum_d(a1);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = w0; sh[threadIdx.x >> 6][1] = w1; }
+  __syncthreads();
+  if (threadIdx.x < 2) part[(img * gridDim.x + blockIdx.x) * 2 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+// den[b] = sum mask + 1e-7; out = mean_b(num_b / den_b)
+__global__ void eqv_loss_final_kernel(const double* __restrict__ part, int B, int nblk, double* __restrict__ den, float* __restrict__ out) {
+  double tot = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) { s0 += part[((long)b * nblk + k) * 2]; s1 += part[((long)b * nblk + k) * 2 + 1]; }
+    s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+    const double d = s1 + 1e-7;
+    if (threadIdx.x == 0) den[b] = d;
+    tot += s0 / d;
+  }
+  if (threadIdx.x == 0) out[0] = (float)(tot / B);
+}
+// d loss / d p = g * mask / (den_b * B) * (softmax(p) - softmax(q))
+__global__ __launch_bounds__(256) void eqv_loss_bwd_kernel(const float* __restrict__ Pm, long ldp, const float* __restrict__ Qm, long ldq,
+                                                          const float* __restrict__ mask, long P, long M, int C, int B,
+                                                          const double* __restrict__ den, const float* __restrict__ g,
+                                                          float* __restrict__ dP, long ldo) {
+  for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < M; row += (long)gridDim.x * 256) {
+    const float w = g[0] * mask[row] / (float)(den[row / P] * (double)B);
+    const float* p = Pm + row * ldp; const float* q = Qm + row * ldq;
+    float mp = -INFINITY, mq = -INFINITY;
+    for (int c = 0; c < C; ++c) { mp = fmaxf(mp, p[c]); mq = fmaxf(mq, q[c]); }
+    float sp = 0.f, sq = 0.f;
+    for (int c = 0; c < C; ++c) { sp += expf(p[c] - mp); sq += expf(q[c] - mq); }
+    for (int c = 0; c < C; ++c) dP[row * ldo + c] = w * (expf(p[c] - mp) / sp - expf(q[c] - mq) / sq);
+  }
+}
+
 static inline int gl_grid(long work) { long g = (work + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
 
 extern "C" {
@@ -325,6 +419,36 @@ int arco_softmax_rows(const float* X, long ld, long M, int C, long P, float* pro
 
 int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, void* stream) {
   hipLaunchKernelGGL(onehot_kernel, dim3(gl_grid(M)), dim3(256), 0, as_stream(stream), lab, M, C, P, out);
+  return arco_launch_status();
+}
+
+// TPS grid: rep [HW][NR], mapping [B][NR][2] -> grid [B][HW][2]   (NR <= 32)
+int arco_tps_grid(const float* rep, const float* mapping, int B, long HW, int NR, float* grid, void* stream) {
+  ARCO_CHECK_ARG(rep && mapping && grid && B > 0 && HW > 0 && NR > 0 && NR <= 32 && (size_t)B * NR * 2 * 4 <= 60 * 1024);
+  hipLaunchKernelGGL(tps_grid_kernel, dim3(gl_grid(HW)), dim3(256), (size_t)B * NR * 2 * sizeof(float), as_stream(stream), rep,
+                     mapping, B, HW, NR, grid);
+  return arco_launch_status();
+}
+int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int C, const float* grid, int Ho, int Wo,
+                         int border, float* Y, long ldy, void* stream) {
+  ARCO_CHECK_ARG(X && grid && Y && NB > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0);
+  hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(gl_grid((long)NB * Ho * Wo * C)), dim3(256), 0, as_stream(stream), X, ldx,
+                     NB, H, W, C, grid, Ho, Wo, border, Y, ldy);
+  return arco_launch_status();
+}
+// ws: 64*2*B + B doubles; out[0] = loss_eqv
+int arco_eqv_loss_fwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C, double* ws,
+                      float* out, void* stream) {
+  ARCO_CHECK_ARG(P_ && Q_ && mask && ws && out && B > 0 && P > 0 && C >= 1);
+  const int nblk = 64;
+  hipLaunchKernelGGL(eqv_loss_partial_kernel, dim3(nblk, B), dim3(256), 0, as_stream(stream), P_, ldp, Q_, ldq, mask, P, C, ws);
+  hipLaunchKernelGGL(eqv_loss_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), ws, B, nblk, ws + 64l * 2 * B, out);
+  return arco_launch_status();
+}
+int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C,
+                      const double* ws, const float* g, float* dP, long ldo, void* stream) {
+  hipLaunchKernelGGL(eqv_loss_bwd_kernel, dim3(gl_grid((long)B * P)), dim3(256), 0, as_stream(stream), P_, ldp, Q_, ldq, mask, P,
+                     (long)B * P, C, B, ws + 64l * 2 * B, g, dP, ldo);
   return arco_launch_status();
 }
 

@@ -4,6 +4,7 @@ one-hot / entropy-percentile masks, mirroring train_arco_2d.py:284-286,342-393,4
 import torch
 
 from . import _lib as L
+from . import ops
 from ._contrast import rows_view
 
 
@@ -117,3 +118,39 @@ class _UnsupLossFn(torch.autograd.Function):
 def compute_unsupervised_loss(predict, target, logits, strong_threshold):
     """train_arco_2d.py:482-489 (same name and arguments)."""
     return _UnsupLossFn.apply(predict, target, logits, strong_threshold)
+
+
+@torch.no_grad()
+def eqv_mask(labels, logits, weak_threshold):
+    """train_arco_2d.py:406-410: [B,1,H,W] float mask, 1 where the (pseudo-)label is foreground and its confidence
+    reaches weak_threshold."""
+    return ((labels != 0) & (logits >= weak_threshold)).to(torch.float32).unsqueeze(1)
+
+
+class _EqvLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_tps, pred_tps_org, mask_tps):
+        L.require_gpu(pred_tps, pred_tps_org, mask_tps)
+        p, ldp, b, C, P = _geom(pred_tps)
+        q, ldq, _, _, _ = _geom(pred_tps_org.detach())
+        m = mask_tps.detach().to(torch.float32).contiguous().view(-1)
+        ws = torch.empty(64 * 2 * b + b, dtype=torch.float64, device=pred_tps.device)
+        out = torch.empty(1, dtype=torch.float32, device=pred_tps.device)
+        L.call("arco_eqv_loss_fwd", L.ptr(p), ldp, L.ptr(q), ldq, L.ptr(m), b, P, C, L.ptr(ws), L.ptr(out))
+        ctx.save_for_backward(pred_tps, pred_tps_org, m, ws)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred_tps, pred_tps_org, m, ws = ctx.saved_tensors
+        p, ldp, b, C, P = _geom(pred_tps)
+        q, ldq, _, _, _ = _geom(pred_tps_org)
+        d = ops.new_act_nd(b, C, tuple(int(v) for v in pred_tps.shape[2:]), pred_tps.device)
+        gg = g.reshape(1).to(torch.float32).contiguous()
+        L.call("arco_eqv_loss_bwd", L.ptr(p), ldp, L.ptr(q), ldq, L.ptr(m), b, P, C, L.ptr(ws), L.ptr(gg), L.ptr(d), C)
+        return d, None, None
+
+
+def eqv_loss(pred_tps, pred_tps_org, mask_tps):
+    """train_arco_2d.py:419-423: mean over images of the masked mean of KL(softmax(pred_tps_org) || softmax(pred_tps))."""
+    return _EqvLossFn.apply(pred_tps, pred_tps_org, mask_tps)

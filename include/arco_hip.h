@@ -163,6 +163,15 @@ int arco_softmax_rows(const float* X, long ld, long M, int C, long P, float* pro
 int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, void* stream);
 /* ---- §8f row 1: supervised CrossEntropy + Dice (train_arco_2d.py:336-339, utils/losses.py:173-209) and the
  *      confidence-weighted unsupervised CE (train_arco_2d.py:482-489) on channels-last logits             */
+/* ---- E  equivariance loss (train_arco_2d.py:404-423; tps/rand_tps.py, tps_stn_pytorch/tps_grid_gen.py:59-71,
+ *      tps/grid_sample.py:11-12 = F.grid_sample(bilinear, align_corners=True))                                  */
+int arco_tps_grid(const float* rep, const float* mapping, int B, long HW, int NR, float* grid, void* stream);
+int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int C, const float* grid, int Ho, int Wo,
+                         int border, float* Y, long ldy, void* stream);
+int arco_eqv_loss_fwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C, double* ws,
+                      float* out, void* stream);
+int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C,
+                      const double* ws, const float* g, float* dP, long ldo, void* stream);
 /* ---- V  evaluation (test_2D.py:52-66): out[c] = {|pred==c|, |gt==c|, |pred==c & gt==c|} as int64[C][3]          */
 int arco_overlap_counts(const int64_t* pred, const int64_t* gt, long n, int C, int64_t* out, void* stream);
 long arco_seg_ws_doubles(long M, int C, int B);
