@@ -26,6 +26,7 @@ import torch.nn as nn
 from . import dist as adist
 from . import _contrast as C_
 from . import glue, graphs, head, ops, optim
+from .tps import RandTPS
 from .model_2D import ISD, FeatureExtractor
 
 FEA_DIM = [256, 128, 64, 32, 16]
@@ -170,6 +171,13 @@ class ArcoStep2D:
         g_train = use_graphs and bool(getattr(args, "graph_train", 0))
         self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train)    # student passes: fwd + bwd graphs
         self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train)
+        # RandTPS of the equivariance term: built here like the reference (:255-261; the constructor draws one warp
+        # from the generators), rebuilt in step() only if the batch size differs
+        self.tps = None
+        if getattr(args, "k2", 0) != 0:
+            self.tps = RandTPS(args.patch_size[0], args.patch_size[1], batch_size=2 * args.batch_size,
+                               sigma=args.tps_sigma, border_padding=False, random_mirror=True, random_scale=(0.8, 1.2),
+                               mode='affine', device=device)
         self.batched_passes = bool(getattr(args, "batched_passes", 1))
         self.s_train_lu = graphs.GraphedTrain(self.model, enabled=g_train)
         self.t_fwd_lu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -270,11 +278,31 @@ class ArcoStep2D:
         C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size,
                             lazy_teacher=lazy_t, defer_anchor_pix=True)
         ev2[1].record()
-        # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340).  Not built:
-        # k2*loss_eqv (RandTPS) and k4*loss_q (revisiting loss; it has no gradient path to any parameter).
+        # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340); the equivariance
+        # term follows the sampler draw below.  Not built: k4*loss_q (revisiting loss; no gradient path to any parameter).
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)
         unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
         C_.contrast_draw(plan, a.func)
+        loss_eqv = None
+        if a.k2 != 0:
+            # equivariance term (:404-423).  The warp is drawn AFTER the samplers, as in the reference: both consume
+            # the torch CPU generator, and the sampled indices must not depend on whether this term is on.
+            nb2 = int(l_data.shape[0]) + int(u_aug.shape[0])
+            if self.tps is None or self.tps.batch_size != nb2:
+                self.tps = RandTPS(a.patch_size[0], a.patch_size[1], batch_size=nb2, sigma=a.tps_sigma,
+                                   border_padding=False, random_mirror=True, random_scale=(0.8, 1.2), mode='affine',
+                                   device=l_data.device)                 # :255-261 (draws one warp, like the reference)
+            with torch.no_grad():
+                labels_all = torch.cat((l_label, u_aug_label))
+                # images_cj1_logits_l (:287-288) is the constant 255 pushed through ToTensor = 1.0 everywhere
+                logits_all = torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits))
+                eq_mask = glue.eqv_mask(labels_all, logits_all, a.weak_threshold)
+                self.tps.reset_control_points()                          # :412
+                images_tps = self.tps(torch.cat((l_data, u_aug)))        # images_cj2 = the un-augmented pair here
+                mask_tps = self.tps(eq_mask, padding_mode='zeros')
+                pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
+            pred_tps = self.model(images_tps)[0]                         # :415 one more student pass (one BN batch)
+            loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)   # :419-423
         ev3 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev3[0].record()
         C_.contrast_anchor_pix(plan)
@@ -294,7 +322,9 @@ class ArcoStep2D:
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)   # :394-398 (temp default)
         ev3[1].record()
         self.loss_events.append((ev, ev2, ev3))      # masks | lists, prototypes, keys, banks | anchors, head, InfoNCE
-        loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
+        loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426 (k4*loss_q: no gradient path)
+        if loss_eqv is not None:
+            loss = loss + a.k2 * loss_eqv
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()
         adist.allreduce_grads(self.optimizer)
@@ -308,6 +338,8 @@ class ArcoStep2D:
         # (graphs.GraphedTrain needs the parameters' gradient accumulators recreated on its capture stream)
         self.last_terms = dict(ce=loss_ce.detach(), dice=loss_dice.detach(), unsup=unsup_loss.detach(),
                                reco=reco_loss.detach())
+        if loss_eqv is not None:
+            self.last_terms["eqv"] = loss_eqv.detach()
         return loss.detach(), reco_loss.detach()
 
 

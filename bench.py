@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--graphs", type=int, default=1)
     ap.add_argument("--graph_train", type=int, default=0)
     ap.add_argument("--batched_passes", type=int, default=1)
+    ap.add_argument("--eqv_steps", type=int, default=10, help="extra steps timed with the equivariance term on (0: skip)")
     ap.add_argument("--dense_teacher", type=int, default=0)
     ap.add_argument("--cpu_baseline_child", action="store_true")
     a = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 
     args = T.build_parser().parse_args(["--batch_size", str(a.batch_size), "--queue_size", "4096", "--func", "smc",
-                                        "--synthetic", "1", "--dense_head", str(a.dense_head), "--graphs", str(a.graphs), "--graph_train", str(a.graph_train), "--batched_passes", str(a.batched_passes), "--dense_teacher", str(a.dense_teacher)])
+                                        "--synthetic", "1", "--dense_head", str(a.dense_head), "--graphs", str(a.graphs), "--graph_train", str(a.graph_train), "--batched_passes", str(a.batched_passes), "--k2", "0", "--dense_teacher", str(a.dense_teacher)])
     stepper = T.ArcoStep2D(args, dev)
     b = a.batch_size
     batches = []
@@ -121,6 +122,19 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    # secondary figure: the same step with the reference's equivariance term on (k2 = 1: RandTPS warp + one more
+    # student pass over the 16 images + masked KL).  The headline workload is the north-star path
+    # (contrastive + supervised + unsupervised terms), timed above with k2 = 0.
+    eqv_ms = None
+    if world == 1 and a.eqv_steps > 0:
+        stepper.args.k2 = 1.0
+        run(3, 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(a.eqv_steps, 3)
+        torch.cuda.synchronize()
+        eqv_ms = (time.perf_counter() - t1) / a.eqv_steps * 1e3
+        stepper.args.k2 = 0.0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -170,11 +184,15 @@ def main():
             "config": {"workload": "ACDC 2D 256x256 bs=16 on 1xMI355X, stratified sampler + 4096-key/class queue "
                                    "(BASELINE.json configs[1])", "batch_size_per_stream": b, "images_per_step_per_gpu": 2 * b,
                        "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc",
+                       "loss_terms": "k1*contrastive + k3*unsupervised + CE + Dice (k2 = 0)",
                        "parallelism": f"dp{world}"},
             "contrastive_loss_fwd_ms_per_step": round(sum(e0.elapsed_time(e1) for evs in stepper.loss_events for e0, e1 in evs)
                                                       / max(1, len(stepper.loss_events)), 3),
             "roofline": roof,
         }
+        if eqv_ms is not None:
+            out["with_equivariance_term"] = {"ms_per_step": round(eqv_ms, 3), "steps_per_s": round(1e3 / eqv_ms, 3),
+                                             "steps": a.eqv_steps, "note": "k2 = 1: + RandTPS warp, one more student pass, masked KL"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -22,7 +22,7 @@ def make_state(unet_sd, fe_sd, qrep_w):
 
 
 def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20.0, k1=0.01, lr=0.01,
-         delta_n=0.97, func='smc', nq=256, nn_=512):
+         delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7):
     with torch.no_grad():
         pred_u0, _, _ = orc.unet_forward(u_data, st["teacher"])
         pseudo_logits, pseudo_labels = torch.max(torch.softmax(pred_u0, 1), 1)
@@ -48,6 +48,24 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
     ce, dice = orc.supervised_loss(pred_l, l_label, n_cls)
     unsup = orc.compute_unsupervised_loss(pred_u, pseudo_labels, pseudo_logits, 0.97)
     loss = k1 * reco + unsup + (ce + dice)
+    eqv = None
+    if k2 != 0:      # train_arco_2d.py:404-423; the warp is drawn after the samplers (same torch-generator order)
+        H, W = int(l_data.shape[2]), int(l_data.shape[3])
+        if "tps" not in st:
+            st["tps"] = orc.tps_constants(H, W)
+        tcp, inv, rep = st["tps"]
+        nb2 = int(l_data.shape[0]) + int(u_data.shape[0])
+        with torch.no_grad():
+            labels_all = torch.cat((l_label, pseudo_labels))
+            logits_all = torch.cat((torch.ones(l_label.shape), pseudo_logits))
+            mask = orc.eqv_mask(labels_all, logits_all, weak_threshold)
+            grid = orc.tps_grid(orc.rand_tps_source_points(tcp, nb2, tps_sigma), inv, rep, H, W)
+            images_tps = orc.grid_sample(torch.cat((l_data, u_data)), grid)
+            mask_tps = orc.grid_sample(mask, grid)
+            org = orc.grid_sample(torch.cat((pred_l.detach(), pred_u.detach())), grid)
+        pred_tps = orc.unet_forward(images_tps, st["student"])[0]
+        eqv = orc.eqv_loss(pred_tps, org, mask_tps)
+        loss = loss + k2 * eqv
     leaves = [v for v in st["student"].values() if v.requires_grad] + list(st["q_rep"]) + list(st["q_fe"].values())
     grads = torch.autograd.grad(loss, leaves, allow_unused=True)
     with torch.no_grad():
@@ -61,6 +79,8 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
                 st["teacher"][k] = st["teacher"][k] * 0.99 + v.detach() * 0.01
     st["it"] += 1
     st["last_terms"] = dict(ce=float(ce), dice=float(dice), unsup=float(unsup), reco=float(reco))
+    if eqv is not None:
+        st["last_terms"]["eqv"] = float(eqv)
     return float(loss), float(reco)
 
 

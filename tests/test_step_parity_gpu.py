@@ -18,7 +18,8 @@ def _drop_off(m):
             mod.p = 0.0
 
 
-@pytest.mark.parametrize("variant", [dict(dense_head=1), dict(dense_head=0, head_levels=2, dense_teacher=0)])
+@pytest.mark.parametrize("variant", [dict(dense_head=1, k2=0.0), dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0),
+                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0)])
 def test_two_steps_vs_cpu_oracle(variant):
     from arco_amd import train_arco_2d as T
     b, patch, C, Q, Nn, qs = 2, (64, 64), 4, 64, 32, 300
@@ -48,11 +49,11 @@ def test_two_steps_vs_cpu_oracle(variant):
         u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
         lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
-        cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn)
+        cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn, k2=variant["k2"])
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
         st_g.step(l.cuda(), lab.cuda(), u.cuda())
         to, tg = st_o["last_terms"], st_g.last_terms
-        for k in ("ce", "dice", "unsup", "reco"):
+        for k in ("ce", "dice", "unsup", "reco") + (("eqv",) if variant["k2"] else ()):
             np.testing.assert_allclose(float(tg[k]), to[k], rtol=2e-3, atol=1e-5, err_msg=f"step {it} {k}")
         for bo, bg in zip(bank_o, st_g.memobank):
             assert bo[0].shape == bg[0].shape
