@@ -34,7 +34,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f3
 # HBM bytes per launch from the PMC passes in profiles/r01_pmc_gemm_traffic.md (FETCH_SIZE x2 + WRITE_SIZE), by (M, N, K)
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes):
 # profiles/r01_pmc_conv_traffic.md (3x3 backbone kernel) and profiles/r01_pmc_gemm_traffic.md; key (taps, M, N, K)
-PMC_TRAFFIC_BYTES = {(9, 32768, 64, 64): 1.840e7, (9, 32768, 64, 128): 2.797e7,
+PMC_TRAFFIC_BYTES = {(9, 65536, 64, 64): 3.526e7, (9, 65536, 64, 128): 5.322e7,
+                     (9, 32768, 64, 64): 1.840e7, (9, 32768, 64, 128): 2.797e7,
                      (1, 1048576, 496, 496): 5.595e9, (1, 262144, 480, 480): 1.240e9}
 
 
