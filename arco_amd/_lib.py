@@ -33,7 +33,7 @@ _SIGS = {
     "arco_pack_many": [_P, _I, _L, _P],
     "arco_overlap_counts": [_P, _P, _L, _I, _P, _P],
     "arco_tps_grid": [_P, _P, _I, _L, _I, _P, _P],
-    "arco_grid_sample_fwd": [_P, _L, _I, _I, _I, _I, _P, _I, _I, _I, _P, _L, _P],
+    "arco_grid_sample_fwd": [_P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _L, _P],
     "arco_eqv_loss_fwd": [_P, _L, _P, _L, _P, _I, _L, _I, _P, _P, _P],
     "arco_eqv_loss_bwd": [_P, _L, _P, _L, _P, _I, _L, _I, _P, _P, _P, _L, _P],
     "arco_gemm_splitk": [_P, _L, _I, _P, _I, _P, _L, _L, _I, _P, _P],

@@ -328,25 +328,28 @@ __global__ __launch_bounds__(256) void tps_grid_kernel(const float* __restrict__
     }
   }
 }
-// F.grid_sample(mode='bilinear', align_corners=True), channels-last rows; padding 0: zeros, 1: border
-__global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __restrict__ X, long ldx, int NB, int H, int W, int C,
+// F.grid_sample(mode='bilinear', align_corners=True), channels-last rows; padding 0: zeros, 1: border.
+// D3 > 1: the same 2-D warp applied to every slice z of a volume [NB, H, W, D3, C] (tps/rand_tps_3d.py:147-166)
+__global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __restrict__ X, long ldx, int NB, int H, int W, int D3, int C,
                                                              const float* __restrict__ grid, int Ho, int Wo, int border,
                                                              float* __restrict__ Y, long ldy) {
-  const long tot = (long)NB * Ho * Wo * C;
+  const long tot = (long)NB * Ho * Wo * D3 * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C); const long po = i / C; const int n = (int)(po / ((long)Ho * Wo));
+    const int c = (int)(i % C); const long pz = i / C; const int z = (int)(pz % D3); const long po = pz / D3;
+    const int n = (int)(po / ((long)Ho * Wo));
     float ix = (grid[po * 2] + 1.f) * 0.5f * (float)(W - 1), iy = (grid[po * 2 + 1] + 1.f) * 0.5f * (float)(H - 1);
     if (border) { ix = fminf(fmaxf(ix, 0.f), (float)(W - 1)); iy = fminf(fmaxf(iy, 0.f), (float)(H - 1)); }
     const float fx = floorf(ix), fy = floorf(iy);
     const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
     const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
-    const float* base = X + (long)n * H * W * ldx + c;
+    const float* base = X + ((long)n * H * W * D3 + z) * ldx + c;
+    const long sx = (long)D3 * ldx, sy = (long)W * D3 * ldx;
     float v = 0.f;
-    if (y0 >= 0 && y0 < H && x0 >= 0 && x0 < W) v += base[((long)y0 * W + x0) * ldx] * (wx0 * wy0);
-    if (y0 >= 0 && y0 < H && x1 >= 0 && x1 < W) v += base[((long)y0 * W + x1) * ldx] * (wx1 * wy0);
-    if (y1 >= 0 && y1 < H && x0 >= 0 && x0 < W) v += base[((long)y1 * W + x0) * ldx] * (wx0 * wy1);
-    if (y1 >= 0 && y1 < H && x1 >= 0 && x1 < W) v += base[((long)y1 * W + x1) * ldx] * (wx1 * wy1);
-    Y[po * ldy + c] = v;
+    if (y0 >= 0 && y0 < H && x0 >= 0 && x0 < W) v += base[y0 * sy + x0 * sx] * (wx0 * wy0);
+    if (y0 >= 0 && y0 < H && x1 >= 0 && x1 < W) v += base[y0 * sy + x1 * sx] * (wx1 * wy0);
+    if (y1 >= 0 && y1 < H && x0 >= 0 && x0 < W) v += base[y1 * sy + x0 * sx] * (wx0 * wy1);
+    if (y1 >= 0 && y1 < H && x1 >= 0 && x1 < W) v += base[y1 * sy + x1 * sx] * (wx1 * wy1);
+    Y[pz * ldy + c] = v;
   }
 }
 // masked KL(softmax(q) || softmax(p)) per image: partial [b][blk] = {sum mask*kl, sum mask}
@@ -429,11 +432,11 @@ int arco_tps_grid(const float* rep, const float* mapping, int B, long HW, int NR
                      mapping, B, HW, NR, grid);
   return arco_launch_status();
 }
-int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int C, const float* grid, int Ho, int Wo,
+int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int D3, int C, const float* grid, int Ho, int Wo,
                          int border, float* Y, long ldy, void* stream) {
-  ARCO_CHECK_ARG(X && grid && Y && NB > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0);
-  hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(gl_grid((long)NB * Ho * Wo * C)), dim3(256), 0, as_stream(stream), X, ldx,
-                     NB, H, W, C, grid, Ho, Wo, border, Y, ldy);
+  ARCO_CHECK_ARG(X && grid && Y && NB > 0 && H > 0 && W > 0 && D3 > 0 && C > 0 && Ho > 0 && Wo > 0);
+  hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(gl_grid((long)NB * Ho * Wo * D3 * C)), dim3(256), 0, as_stream(stream), X, ldx,
+                     NB, H, W, D3, C, grid, Ho, Wo, border, Y, ldy);
   return arco_launch_status();
 }
 // ws: 64*2*B + B doubles; out[0] = loss_eqv

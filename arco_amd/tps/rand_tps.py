@@ -93,11 +93,17 @@ class RandTPS(nn.Module):
         pm = self.padding_mode if padding_mode is None else padding_mode
         L.require_gpu(x)
         xr, ld = rows_view(x.to(torch.float32))
-        nb, c, h, w = (int(v) for v in x.shape)
+        nb, c, h, w = (int(v) for v in x.shape[:4])
+        d3 = int(x.shape[4]) if x.dim() == 5 else 1          # 5-D: the same warp on every slice x[..., z] (rand_tps_3d.py:155-165)
         Ho, Wo = int(self.grid.shape[1]), int(self.grid.shape[2])
         if nb != self.batch_size:
             raise RuntimeError(f"RandTPS was built for batch {self.batch_size}, got {nb}")
-        y = torch.empty((nb, Ho, Wo, c), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
-        L.call("arco_grid_sample_fwd", L.ptr(xr), ld, nb, h, w, c, L.ptr(self.grid), Ho, Wo, 1 if pm == 'border' else 0,
+        if d3 > 1 and (Ho, Wo) != (h, w):
+            raise RuntimeError("the slice-wise warp of a volume needs a grid of the volume's own (X, Y) size")
+        if d3 > 1:
+            y = torch.empty((nb, Ho, Wo, d3, c), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+        else:
+            y = torch.empty((nb, Ho, Wo, c), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+        L.call("arco_grid_sample_fwd", L.ptr(xr), ld, nb, h, w, d3, c, L.ptr(self.grid), Ho, Wo, 1 if pm == 'border' else 0,
                L.ptr(y), c)
         return y

@@ -19,6 +19,7 @@ import torch.nn as nn
 from . import _contrast as C_
 from . import dist as adist
 from . import glue, graphs, head, ops, optim
+from .tps.rand_tps_3d import RandTPS as RandTPS3D
 from .model_3D import ISD_3d, FeatureExtractor_3d
 from .train_arco_2d import build_parser as _build_parser_2d
 
@@ -29,6 +30,10 @@ REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
 def build_parser():
     p = _build_parser_2d()
     p.set_defaults(patch_size=[112, 112, 80], func='asmc', k5=0.1, root_path='../data/ACDC')
+    p.add_argument('--eqv_pass', type=int, default=1,
+                   help='1: run the equivariance block of train_arco_3d.py:368-388 (warp + one more student forward); '
+                        'its loss only enters the objective at iteration 0 there (:390-393), afterwards it is a logged '
+                        'value and a BatchNorm running-statistics update')
     return p
 
 
@@ -83,6 +88,11 @@ class ArcoStep3D:
         g_train = use_graphs and bool(getattr(args, "graph_train", 0))
         self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train)    # student passes: fwd + bwd graphs
         self.s_train_l = graphs.GraphedTrain(self.model, enabled=g_train)
+        self.tps = None
+        if getattr(args, "eqv_pass", 1):                                 # :231-237 (the constructor draws one warp)
+            self.tps = RandTPS3D(args.patch_size[0], args.patch_size[1], args.patch_size[2], batch_size=2 * args.batch_size,
+                                 sigma=args.tps_sigma, border_padding=False, random_mirror=True, random_scale=(0.8, 1.2),
+                                 mode='affine', device=device)
         self.batched_passes = bool(getattr(args, "batched_passes", 1))
         self.s_train_lu = graphs.GraphedTrain(self.model, enabled=g_train)
         self.t_fwd_lu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -152,6 +162,24 @@ class ArcoStep3D:
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
         unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
         C_.contrast_draw(plan, a.func)
+        loss_eqv = None
+        if getattr(a, "eqv_pass", 1):
+            # :368-388.  The warp is drawn after the samplers (same torch-generator order as the reference).
+            nb2 = int(l_data.shape[0]) + int(u_aug.shape[0])
+            if self.tps is None or self.tps.batch_size != nb2:
+                self.tps = RandTPS3D(a.patch_size[0], a.patch_size[1], a.patch_size[2], batch_size=nb2, sigma=a.tps_sigma,
+                                     border_padding=False, random_mirror=True, random_scale=(0.8, 1.2), mode='affine',
+                                     device=l_data.device)
+            with torch.no_grad():
+                eq_mask = glue.eqv_mask(torch.cat((l_label, u_aug_label)),
+                                        torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits)), a.weak_threshold)
+                self.tps.reset_control_points()                          # :377
+                images_tps = self.tps(torch.cat((l_data, u_aug)))
+                mask_tps = self.tps(eq_mask, padding_mode='zeros')
+                pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
+            with torch.set_grad_enabled(self.iter_num == 0):             # only iteration 0 back-propagates it (:390-393)
+                pred_tps = self.model(images_tps)[0]                     # :380
+                loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
         C_.contrast_anchor_pix(plan)
         if plan.valid_seg <= 1 or not plan.entries:
             reco_loss = self.q_representation[1].weight.sum() * 0.0
@@ -162,7 +190,10 @@ class ArcoStep3D:
             A_all = head.lazy_head3d(x2p, f3, f4, qfe.fea3.weight, qfe.fea4.weight, self.q_representation[0].weight,
                                      self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
-        loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q: no gradient path, not built)
+        if self.iter_num == 0 and loss_eqv is not None:
+            loss = unsup_loss + (loss_dice + loss_ce) + loss_eqv         # :393 (iter_num / max_iterations == 0)
+        else:
+            loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q: no gradient path, not built)
         self.optimizer.zero_grad()
         loss.backward()
         adist.allreduce_grads(self.optimizer)
@@ -174,6 +205,8 @@ class ArcoStep3D:
         self.iter_num += 1
         self.last_terms = dict(ce=loss_ce.detach(), dice=loss_dice.detach(), unsup=unsup_loss.detach(),
                                reco=reco_loss.detach())
+        if loss_eqv is not None:
+            self.last_terms["eqv"] = loss_eqv.detach()
         return loss.detach(), reco_loss.detach()
 
 

@@ -166,8 +166,8 @@ int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, v
 /* ---- E  equivariance loss (train_arco_2d.py:404-423; tps/rand_tps.py, tps_stn_pytorch/tps_grid_gen.py:59-71,
  *      tps/grid_sample.py:11-12 = F.grid_sample(bilinear, align_corners=True))                                  */
 int arco_tps_grid(const float* rep, const float* mapping, int B, long HW, int NR, float* grid, void* stream);
-int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int C, const float* grid, int Ho, int Wo,
-                         int border, float* Y, long ldy, void* stream);
+int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int D3 /* slices per volume, 1 in 2-D */, int C,
+                         const float* grid, int Ho, int Wo, int border, float* Y, long ldy, void* stream);
 int arco_eqv_loss_fwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C, double* ws,
                       float* out, void* stream);
 int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C,

@@ -379,6 +379,19 @@ def gen_eqv():
                      ("images_tps", images_tps), ("mask_tps", mask_tps), ("pred_tps_org", pred_tps_org),
                      ("loss", loss_eqv.detach()), ("grad", pred_tps.grad)):
             out[f"{tag}_{k}"] = v.numpy().copy()
+    # volume variant (tps/rand_tps_3d.py): the same 2-D warp on every slice of a [B,C,X,Y,Z] tensor
+    rand_tps_3d = importlib.import_module("tps.rand_tps_3d")
+    seed_all(21)
+    tps3 = rand_tps_3d.RandTPS(12, 12, 6, batch_size=2, sigma=0.02, border_padding=False, random_mirror=True,
+                               random_scale=(0.8, 1.2), mode='affine')
+    seed_all(121)
+    tps3.reset_control_points()
+    rs = np.random.RandomState(5)
+    vol = torch.from_numpy(rs.normal(size=(2, 3, 12, 12, 6)).astype(np.float32))
+    out["v_grid"] = tps3.grid.data.numpy().copy()
+    out["v_vol"] = vol.numpy().copy()
+    out["v_vol_tps"] = tps3(vol, padding_mode='zeros').numpy().copy()
+    out["v_probe"] = np.array((rng_probe(), float(np.random.uniform()), random.random()), dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "g5_eqv.npz"), **out)
     print("g5_eqv", len(out))
 

@@ -75,3 +75,20 @@ def test_grid_sample_border_and_identity():
     for pm in ("zeros", "border"):
         ref = F.grid_sample(x.cpu(), tps.grid.cpu(), mode="bilinear", padding_mode=pm, align_corners=True)
         np.testing.assert_allclose(tps(x, padding_mode=pm).cpu().numpy(), ref.numpy(), atol=2e-5)
+
+
+def test_rand_tps_3d_slicewise_vs_reference(g5):
+    """Volume variant (tps/rand_tps_3d.py): same grid for the seed, the warp applied to every slice x[..., z]."""
+    from arco_amd.tps.rand_tps_3d import RandTPS
+    seed_all(21)
+    tps = RandTPS(12, 12, 6, batch_size=2, sigma=0.02, border_padding=False, random_mirror=True, random_scale=(0.8, 1.2),
+                  mode='affine')
+    seed_all(121)
+    tps.reset_control_points()
+    np.testing.assert_allclose(tps.grid.cpu().numpy(), g5["v_grid"], rtol=1e-4, atol=3e-5)
+    probe = (int(torch.randint(1 << 30, (1,))), float(np.random.uniform()), random.random())
+    np.testing.assert_allclose(np.array(probe), g5["v_probe"], rtol=0, atol=0)
+    tps.grid.copy_(torch.from_numpy(g5["v_grid"]).cuda())
+    got = tps(torch.from_numpy(g5["v_vol"]).cuda(), padding_mode='zeros')
+    assert got.shape == (2, 3, 12, 12, 6)
+    np.testing.assert_allclose(got.cpu().numpy(), g5["v_vol_tps"], atol=2e-5)

@@ -6,7 +6,9 @@ import torch, random, numpy as np
 from arco_amd import train_arco_3d as T3
 random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1", "--num_classes", "2"])
+eqv = int(os.environ.get("EQV_PASS", "0"))     # 1: with the reference's equivariance block (one more student forward per step)
+args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1", "--num_classes", "2",
+                                     "--eqv_pass", str(eqv)])
 st = T3.ArcoStep3D(args, "cuda:0")
 l, ll = T3.synthetic_volume_batch(b, args.patch_size, 2, 1, "cuda:0")
 u, _ = T3.synthetic_volume_batch(b, args.patch_size, 2, 2, "cuda:0")
@@ -15,4 +17,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 8
 for _ in range(n): loss, reco = st.step(l, ll, u)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"3D step b={b}: {dt*1e3:.1f} ms/step  {1/dt:.2f} steps/s  loss {float(reco):.4f}  mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB")
+print(f"3D step b={b} eqv_pass={eqv}: {dt*1e3:.1f} ms/step  {1/dt:.2f} steps/s  loss {float(reco):.4f}  mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB")
