@@ -15,7 +15,6 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from .. import ops
 from .._contrast import rows_view
 
 

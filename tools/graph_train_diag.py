@@ -60,8 +60,6 @@ def run(case):
             for it in range(3):
                 f(x).sum().backward()
             torch.cuda.synchronize(); print(case, "OK"); return
-        if case == "torch_mine_mt":
-            os.environ["ARCO_GT_MT"] = "1"
         gt = graphs.GraphedTrain(m, warmup=1)
         for it in range(4):
             gt(x).sum().backward(); torch.cuda.synchronize()
