@@ -260,3 +260,37 @@ def test_training_reduces_the_supervised_loss():
     assert last < 0.8 * first, (first, last)
     for p in st.model.parameters():
         assert bool(torch.isfinite(p).all())
+
+
+def test_batched_passes_match_separate_passes_and_ragged_batches_run():
+    """One step from equal state: the grouped-BN batched passes (default) give the losses and weights of the separate
+    labelled / unlabelled passes (--batched_passes 0); a step whose labelled and unlabelled batches differ in size
+    takes the separate-pass route and stays finite."""
+    from arco_amd import train_arco_2d as T
+    b, patch, C = 2, (64, 64), 4
+    seed_state = (fx.unet_state(21, 1, C), fx.fe_state(31), [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]])
+    st_a, st_b = _trainer(0, seed_state), _trainer(0, seed_state)
+    st_b.batched_passes = False
+    rs = np.random.RandomState(9)
+    for it in range(3):
+        l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32)).cuda()
+        u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32)).cuda()
+        lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C)).cuda()
+        _sync_state(st_b, st_a)
+        terms = []
+        for st in (st_a, st_b):
+            random.seed(20 + it); np.random.seed(20 + it); torch.manual_seed(20 + it)
+            st.step(l, lab, u)
+            terms.append({k: float(v) for k, v in st.last_terms.items()})
+        for k in terms[0]:
+            np.testing.assert_allclose(terms[1][k], terms[0][k], rtol=5e-4, atol=1e-6, err_msg=f"step {it} {k}")
+        pa, pb = st_a.optimizer.flat_p, st_b.optimizer.flat_p
+        assert float((pa - pb).abs().max()) <= 1e-4 * float(pa.abs().max()), it
+    # ragged: 2 labelled + 3 unlabelled images
+    st_r = _trainer(0, seed_state)
+    st_r.args.k2 = 0.0                                   # (the warp of the equivariance term is built per batch size)
+    l = torch.from_numpy(rs.uniform(size=(2, 1, *patch)).astype(np.float32)).cuda()
+    u = torch.from_numpy(rs.uniform(size=(3, 1, *patch)).astype(np.float32)).cuda()
+    lab = torch.from_numpy(fx.blob_labels(rs, 2, patch, C)).cuda()
+    loss, reco = st_r.step(l, lab, u)
+    assert bool(torch.isfinite(loss)) and bool(torch.isfinite(reco))
