@@ -92,3 +92,31 @@ def test_rand_tps_3d_slicewise_vs_reference(g5):
     got = tps(torch.from_numpy(g5["v_vol"]).cuda(), padding_mode='zeros')
     assert got.shape == (2, 3, 12, 12, 6)
     np.testing.assert_allclose(got.cpu().numpy(), g5["v_vol_tps"], atol=2e-5)
+
+
+def test_eqv_loss_edge_cases():
+    """all-zero mask -> loss 0 and zero gradient (denominator 1e-7, train_arco_2d.py:422); identical predictions ->
+    zero KL; 19 classes; the value against a plain torch evaluation."""
+    import torch.nn.functional as F
+    from arco_amd import glue
+    torch.manual_seed(0)
+    B, C, H, W = 3, 19, 12, 20
+    p = torch.randn(B, C, H, W, device="cuda").requires_grad_(True)
+    q = torch.randn(B, C, H, W, device="cuda")
+    z = torch.zeros(B, 1, H, W, device="cuda")
+    loss = glue.eqv_loss(p, q, z)
+    loss.backward()
+    assert float(loss) == 0.0 and float(p.grad.abs().max()) == 0.0
+    m = (torch.rand(B, 1, H, W, device="cuda") > 0.4).float()
+    m[1] = 0                                                   # one image without any valid pixel
+    p2 = torch.randn(B, C, H, W, device="cuda").requires_grad_(True)
+    got = glue.eqv_loss(p2, q, m)
+    got.backward()
+    pr = p2.detach().cpu().requires_grad_(True)
+    kl = F.kl_div(F.log_softmax(pr, 1), F.softmax(q.cpu(), 1), reduction='none')
+    ref = ((kl * m.cpu()).flatten(1).sum(1) / (m.cpu().flatten(1).sum(1) + 1e-7)).mean()
+    ref.backward()
+    np.testing.assert_allclose(float(got), float(ref), rtol=1e-5)
+    np.testing.assert_allclose(p2.grad.cpu().numpy(), pr.grad.numpy(), rtol=1e-4, atol=1e-9)
+    same = glue.eqv_loss(q.clone().requires_grad_(True), q, m)
+    assert abs(float(same)) < 1e-6
