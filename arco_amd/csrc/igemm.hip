@@ -29,10 +29,15 @@ struct IgemmArgs {
   int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
 };
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH>
+// FLAT (3x3 only): the M-tile is BM consecutive positions of the plane stored with a padded row stride Wp = W + 2
+// (one halo column each side) instead of a TH x 16 pixel rectangle.  A tap is then a uniform shift dy*Wp + dx of the
+// position, rows need no tiling, and the padding waste is 2 / (W + 2) instead of rounding BOTH plane dimensions up
+// to the tile: 7x7 planes waste 23 % instead of 62 %, 28x28 planes 7 % instead of 23 % (the V-Net's deep levels).
+constexpr int IGEMM_FLAT_WPMAX = 64;
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH, bool FLAT = false>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int TH = BM / 16;
-  constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
+  constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * IGEMM_FLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
   constexpr int BROWS = TAPS * BN;
   constexpr int LDK = KC + 4;
   constexpr int A_T = BM / 16 / WAVES_M;
@@ -59,7 +64,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 
   // tile origin
   long m0 = 0; int img = 0, y0 = 0, x0 = 0;
-  if (TAPS == 9) {
+  const int Wp = a.W + 2;                 // FLAT: padded row stride
+  int f0 = 0;                             // FLAT: first padded-plane position of this block
+  if (TAPS == 9 && FLAT) {
+    const int per_plane = (a.H * Wp + BM - 1) / BM;
+    img = mblk / per_plane; f0 = (mblk - img * per_plane) * BM;
+  } else if (TAPS == 9) {
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + TH - 1) / TH;
     int t = mblk;
     const int tx = t % tiles_x; t /= tiles_x;
@@ -93,7 +103,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     if (idx < AROWS * Q4) {
       const int row = idx / Q4, q = idx - row * Q4;
       long pix = -1;
-      if (TAPS == 9) {
+      if (TAPS == 9 && FLAT) {
+        const int pidx = f0 + row - 1;               // position in the plane padded by one halo row / column
+        if (pidx >= 0 && row < BM + 2 * Wp + 2) {
+          const int py = pidx / Wp, px = pidx - py * Wp;
+          const int y = py - 1, x = px - 1;
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
+        }
+      } else if (TAPS == 9) {
         const int hy = row / 18, hx = row - hy * 18;
         const int y = y0 + hy - 1, x = x0 + hx - 1;
         if (y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int at = 0; at < A_T; ++at) {
           const int s = wm * A_T + at;
-          const int row = TAPS == 9 ? (s + dy) * 18 + li + dx : s * 16 + li;
+          const int row = TAPS == 9 ? (FLAT ? s * 16 + li + dy * Wp + dx : (s + dy) * 18 + li + dx) : s * 16 + li;
           af[at] = *reinterpret_cast<const f32x4*>(&As[row * LDK + kk * 16 + 4 * g]);
         }
 #pragma unroll
@@ -233,7 +250,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int i = 4 * g + r;
         long pix = -1;
-        if (TAPS == 9) {
+        if (TAPS == 9 && FLAT) {
+          const int f = f0 + s * 16 + i, y = f / Wp, xq = f - y * Wp;
+          if (y < a.H && xq >= 1 && xq <= a.W) pix = ((long)img * a.H + y) * a.W + xq - 1;
+        } else if (TAPS == 9) {
           const int y = y0 + s, x = x0 + i;
           if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
         } else {
@@ -277,24 +297,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 }
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH, bool FLAT = false>
 static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   constexpr int TH = BM / 16;
-  constexpr int AROWS = TAPS == 9 ? (TH + 2) * 18 : BM;
+  constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * IGEMM_FLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
   int mblocks;
-  if (TAPS == 9) mblocks = a.NB * ((a.H + TH - 1) / TH) * ((a.W + 15) / 16);
+  if (TAPS == 9 && FLAT) mblocks = a.NB * ((a.H * (a.W + 2) + BM - 1) / BM);
+  else if (TAPS == 9) mblocks = a.NB * ((a.H + TH - 1) / TH) * ((a.W + 15) / 16);
   else if (a.stat_groups > 1) mblocks = a.stat_groups * (int)((a.M / a.stat_groups + BM - 1) / BM);   // per-group M-blocks
   else mblocks = (int)((a.M + BM - 1) / BM);
   if (n_mblocks_out) {
     n_mblocks_out[0] = mblocks;
-    n_mblocks_out[1] = TAPS * 1000000 + BM * 1000 + BN;        // instantiation id (query only)
+    n_mblocks_out[1] = TAPS * 1000000 + BM * 1000 + BN + (FLAT ? 500000 : 0);   // instantiation id (query only)
     n_mblocks_out[2] = KC * 100 + DEPTH * 10 + (DB ? 1 : 0);
     return ARCO_OK;
   }
   size_t sh = (size_t)(DB ? 2 : 1) * (AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
-  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC, DEPTH>;
+  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC, DEPTH, FLAT>;
   static bool attr_set = false;      // once per instantiation (never inside a stream capture after warm-up)
   if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
   IgemmArgs b = a;
@@ -305,11 +326,11 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   return arco_launch_status();
 }
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, int DEPTH = 1>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, int DEPTH = 1, bool FLAT = false>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   const bool vec = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
-  if (vec) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH>(a, st, n_mblocks_out);
-  return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, false, DEPTH>(a, st, n_mblocks_out);
+  if (vec) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH, FLAT>(a, st, n_mblocks_out);
+  return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, false, DEPTH, FLAT>(a, st, n_mblocks_out);
 }
 
 // config choice shared by the launch and the "how many M-blocks" query.
@@ -319,9 +340,26 @@ static long conv_blocks(const IgemmArgs& a, int bm, int bn) {
   const int th = bm / 16;
   return (long)a.NB * ((a.H + th - 1) / th) * ((a.W + 15) / 16) * ((a.Npad + bn - 1) / bn);
 }
+// flat-position tiles for narrow planes whose width is not a multiple of 16 (the V-Net's 56 / 28 / 14 / 7)
+static long flat_blocks(const IgemmArgs& a, int bm, int bn) {
+  return (long)a.NB * ((a.H * (a.W + 2) + bm - 1) / bm) * ((a.Npad + bn - 1) / bn);
+}
+static int dispatch_flat3(const IgemmArgs& a, hipStream_t st, int* nmb) {
+  const long want = 512;
+  if (a.Npad <= 16) return launch_igemm<9, 128, 16, 4, 1, 16, false, 3, true>(a, st, nmb);
+  if (a.Npad <= 32) {
+    if (flat_blocks(a, 128, 32) >= want) return launch_igemm<9, 128, 32, 4, 1, 16, false, 3, true>(a, st, nmb);
+    return launch_igemm<9, 64, 32, 2, 2, 16, false, 3, true>(a, st, nmb);
+  }
+  if (flat_blocks(a, 128, 64) >= want) return launch_igemm<9, 128, 64, 4, 1, 16, false, 3, true>(a, st, nmb);
+  if (flat_blocks(a, 64, 64) >= want) return launch_igemm<9, 64, 64, 2, 2, 16, false, 3, true>(a, st, nmb);
+  if (flat_blocks(a, 64, 32) >= want) return launch_igemm<9, 64, 32, 2, 2, 16, false, 3, true>(a, st, nmb);
+  return launch_igemm<9, 32, 32, 2, 2, 16, false, 3, true>(a, st, nmb);
+}
 template <int DEPTH>
 static int dispatch_spatial(const IgemmArgs& a, hipStream_t st, int* nmb) {
   const long want = 512;
+  if (DEPTH == 3 && (a.W & 15) != 0 && a.W + 2 <= IGEMM_FLAT_WPMAX) return dispatch_flat3(a, st, nmb);
   if (a.Npad <= 16) {
     if (DEPTH == 1 && conv_blocks(a, 256, 16) >= want) return launch_igemm<9, 256, 16, 4, 1, 16, false, DEPTH>(a, st, nmb);
     if (conv_blocks(a, 128, 16) >= want || DEPTH == 3) return launch_igemm<9, 128, 16, 4, 1, 16, false, DEPTH>(a, st, nmb);
