@@ -834,11 +834,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // owned by 4 / n_sub waves for all 9 taps (32x32: one wave per sub-tile walking all 128 pixels -> no cross-wave
 // reduction, 36 accumulator registers instead of 144; 16x32 / 32x16: two waves per sub-tile, 64 pixels each;
 // 16x16: four waves, 32 pixels each), partners are summed once per LAUNCH through LDS.
-template <int CO_B, int CI_B>
+// FLAT: tiles are 128 consecutive positions of the plane stored with padded row stride W + 2 (see igemm_kernel FLAT)
+template <int CO_B, int CI_B, bool FLAT = false>
 __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
   constexpr int LDZ = (CO_B % 32 == 0) ? CO_B + 16 : CO_B;
   constexpr int LDA = (CI_B % 32 == 0) ? CI_B + 16 : CI_B;
-  constexpr int QZ = CO_B / 4, QA = CI_B / 4, HROWS = 10 * 18;
+  constexpr int QZ = CO_B / 4, QA = CI_B / 4, HROWS = FLAT ? 128 + 2 * IGEMM_FLAT_WPMAX + 2 : 10 * 18;
   constexpr int NZ = (128 * QZ + 255) / 256, NX = (HROWS * QA + 255) / 256;
   constexpr int CI_T = CI_B / 16, NSUB = (CO_B / 16) * CI_T, WPS = 4 / NSUB, KSTEPS = 32 / WPS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -849,6 +850,7 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
   const int dd = blockIdx.z;                                   // depth tap (3-D) ; 0 for 2-D
   const int dpl = a.taps == 27 ? dd - 1 : 0;
   const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
+  const int Wp = a.W + 2, flat_per_plane = (a.H * Wp + 127) / 128;
   const int ci_tiles = a.CinPad / CI_B;
   const int co0 = (blockIdx.y / ci_tiles) * CO_B, ci0 = (blockIdx.y % ci_tiles) * CI_B;
   const bool vz = ((a.Cout & 3) == 0) && ((a.ldz & 3) == 0), vx = ((a.Cin & 3) == 0) && ((a.lda & 3) == 0);
@@ -858,16 +860,18 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
   f32x4 pz[NZ], px_[NX];
   auto fetch = [&](int t) {
-    int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; const int img = tt / tiles_y;
-    const int y0 = ty * 8, x0 = tx * 16;
+    int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y;
+    const int img = FLAT ? t / flat_per_plane : tt / tiles_y;
+    const int y0 = ty * 8, x0 = tx * 16, f0 = FLAT ? (t - img * flat_per_plane) * 128 : 0;
     const int pl = a.taps == 27 ? img % a.D3 + dpl : 0;
     const bool plane_ok = pl >= 0 && pl < a.D3;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
       const int idx = tid + i * 256, p = idx / QZ, q = idx % QZ;
-      const int y = y0 + p / 16, x = x0 + p % 16, c = co0 + 4 * q;
+      const int fy = (f0 + p) / Wp, fx = (f0 + p) - fy * Wp;                  // FLAT: output position -> (row, padded column)
+      const int y = FLAT ? fy : y0 + p / 16, x = FLAT ? fx - 1 : x0 + p % 16, c = co0 + 4 * q;
       f32x4 v = f32x4{0, 0, 0, 0};
-      if (idx < 128 * QZ && y < a.H && x < a.W && plane_ok) {
+      if (idx < 128 * QZ && y < a.H && x >= 0 && x < a.W && plane_ok) {
         const float* src = a.dZ + (((long)img * a.H + y) * a.W + x) * a.ldz + c;
         if (vz) { if (c < a.Cout) v = *reinterpret_cast<const f32x4*>(src); }
         else {
@@ -880,9 +884,10 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int idx = tid + i * 256, r = idx / QA, q = idx % QA;
-      const int y = y0 + r / 18 - 1, x = x0 + r % 18 - 1, c = ci0 + 4 * q;
+      const int pidx = f0 + r - 1, py = pidx >= 0 ? pidx / Wp : -1, ppx = pidx - py * Wp;      // FLAT: padded-plane position
+      const int y = FLAT ? py - 1 : y0 + r / 18 - 1, x = FLAT ? ppx - 1 : x0 + r % 18 - 1, c = ci0 + 4 * q;
       f32x4 v = f32x4{0, 0, 0, 0};
-      if (idx < HROWS * QA && y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok) {
+      if (idx < HROWS * QA && (!FLAT || (pidx >= 0 && r < 128 + 2 * Wp + 2)) && y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok) {
         const float* src = a.Ain + (((long)(img + dpl) * a.H + y) * a.W + x) * a.lda + c;
         if (vx) { if (c < a.Cin) v = *reinterpret_cast<const f32x4*>(src); }
         else {
@@ -908,10 +913,10 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int p = (part * KSTEPS + ks) * 4 + g, py = p >> 4, pxx = p & 15;
       const float zf = Zs[p * LDZ + wi * 16 + li];
-      const float* xrow = Xs + (py * 18 + pxx) * LDA + wj * 16 + li;
+      const float* xrow = Xs + (FLAT ? p : py * 18 + pxx) * LDA + wj * 16 + li;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap)
-        acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf, xrow[((tap / 3) * 18 + tap % 3) * LDA], acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf, xrow[(FLAT ? (tap / 3) * Wp + tap % 3 : (tap / 3) * 18 + tap % 3) * LDA], acc[tap], 0, 0, 0);
     }
     __syncthreads();
     t = next;
@@ -1148,6 +1153,8 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   if (taps >= 9) {       // spatial kernels: all taps of a plane per block, operands staged once (halo in LDS)
     const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
     a.CoutPad = (Cout + hco - 1) / hco * hco; a.CinPad = (Cin + hci - 1) / hci * hci;
+    const bool flat = (W & 15) != 0 && W + 2 <= IGEMM_FLAT_WPMAX;     // narrow planes: flat-position tiles
+    if (flat) a.n_tiles = NB * ((H * (W + 2) + 127) / 128);
     const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
     // 32x32 blocks run persistent (2 workgroups per CU, several tiles each); the others one slab per ~tile
     const long target = (hco == 32 && hci == 32) ? 512 : 768;
@@ -1156,9 +1163,13 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
 #define WH(COB, CIB)                                                                              \
     do {                                                                                          \
       constexpr int LZ = (COB % 32 == 0) ? COB + 16 : COB, LA = (CIB % 32 == 0) ? CIB + 16 : CIB; \
-      size_t sh = (size_t)(128 * LZ + 180 * LA) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4;  \
+      size_t sh = (size_t)(128 * LZ + (flat ? 128 + 2 * (W + 2) + 2 : 180) * LA) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4;  \
       if (sh < rd && (COB / 16) * (CIB / 16) < 4) sh = rd;                                        \
-      hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);            \
+      if (flat) {                                                                                 \
+        static bool attr_set = false;                                                             \
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo2_kernel<COB, CIB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 * LZ + (128 + 2 * IGEMM_FLAT_WPMAX + 2) * LA) * 4); attr_set = true; } \
+        hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB, true>), hgrid, dim3(256), sh, st, a);    \
+      } else hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);     \
     } while (0)
     if (hco == 32 && hci == 32) WH(32, 32);
     else if (hco == 32 && hci == 16) WH(32, 16);
