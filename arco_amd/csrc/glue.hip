@@ -455,6 +455,47 @@ int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, cons
   return arco_launch_status();
 }
 
+// ---- V  3-D sliding-window evaluation (test_util.py:139-211) ----
+// score[c][x][y][z] += prob[c][i][j][k] over the window at (xs, ys, zs); cnt += 1.  One thread per window voxel; windows are
+// accumulated by successive launches on one stream, i.e. in the reference's (x, y, z) loop order -> same fp32 sums.
+__global__ void window_accumulate_kernel(const float* __restrict__ prob, int C, int px, int py, int pz, float* __restrict__ score,
+                                         float* __restrict__ cnt, long hh, long dd, long vol, int xs, int ys, int zs) {
+  const long pv = (long)px * py * pz;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pv; i += (long)gridDim.x * blockDim.x) {
+    const int k = i % pz; const long r = i / pz; const int j = r % py, ii = r / py;
+    const long o = ((long)(xs + ii) * hh + (ys + j)) * dd + (zs + k);
+    for (int c = 0; c < C; ++c) score[c * vol + o] += prob[c * pv + i];
+    cnt[o] += 1.f;
+  }
+}
+// score /= cnt (in place, fp32 like the numpy division); label = first argmax over classes (np.argmax)
+__global__ void score_finalize_kernel(float* __restrict__ score, const float* __restrict__ cnt, int C, long vol,
+                                      int64_t* __restrict__ label) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < vol; i += (long)gridDim.x * blockDim.x) {
+    const float n = cnt[i];
+    float best = 0.f; int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = score[c * vol + i] / n;
+      score[c * vol + i] = v;
+      if (c == 0 || v > best) { best = v; arg = c; }
+    }
+    label[i] = arg;
+  }
+}
+int arco_window_accumulate(const float* prob, int C, int px, int py, int pz, float* score, float* cnt, int ww, int hh, int dd,
+                           int xs, int ys, int zs, void* stream) {
+  ARCO_CHECK_ARG(prob && score && cnt && C > 0 && px > 0 && py > 0 && pz > 0 && xs >= 0 && ys >= 0 && zs >= 0 &&
+                 xs + px <= ww && ys + py <= hh && zs + pz <= dd);
+  hipLaunchKernelGGL(window_accumulate_kernel, dim3(gl_grid((long)px * py * pz)), dim3(256), 0, as_stream(stream), prob, C, px, py,
+                     pz, score, cnt, (long)hh, (long)dd, (long)ww * hh * dd, xs, ys, zs);
+  return arco_launch_status();
+}
+int arco_score_finalize(float* score, const float* cnt, int C, long vol, int64_t* label, void* stream) {
+  ARCO_CHECK_ARG(score && cnt && label && C > 0 && vol > 0);
+  hipLaunchKernelGGL(score_finalize_kernel, dim3(gl_grid(vol)), dim3(256), 0, as_stream(stream), score, cnt, C, vol, label);
+  return arco_launch_status();
+}
+
 // out: C*3 int64 counters {pred, gt, both} per class (zeroed here)
 int arco_overlap_counts(const int64_t* pred, const int64_t* gt, long n, int C, int64_t* out, void* stream) {
   ARCO_CHECK_ARG(pred && gt && out && n > 0 && C >= 1 && C <= GL_MAXC);

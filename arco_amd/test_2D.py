@@ -4,18 +4,15 @@ handling around it is I/O and stays with the caller).
 
 Inference runs in eval mode (BatchNorm on running statistics) on the HIP kernels, ALL slices of a volume in one
 batch (eval-mode results do not depend on the batch); the zoom(order=0) round trip is scipy on the host exactly as
-in the reference; the overlap counts behind Dice / Jaccard are one integer-atomics kernel.  hd95 / asd are surface
-distances from medpy (not importable here): returned as 0.0 unless medpy is available."""
+in the reference; the overlap counts behind Dice / Jaccard are one integer-atomics kernel.  hd95 / asd are medpy's
+surface distances (host scipy code) restated in utils/metrics.py."""
 import numpy as np
 import torch
 
 from . import _lib as L
 from . import glue
 
-try:                                    # the reference's metric backend; optional
-    from medpy import metric as _medpy_metric
-except Exception:                       # pragma: no cover
-    _medpy_metric = None
+from .utils import metrics as _medpy_metric       # medpy.metric.binary's dc / jc / hd95 / asd on scipy
 
 
 def overlap_counts(pred, gt, classes):
@@ -42,7 +39,7 @@ def calculate_metric_percase(pred, gt):
     gt = np.asarray(gt.cpu() if torch.is_tensor(gt) else gt) > 0
     dice, jc = _dice_jc(int(pred.sum()), int(gt.sum()), int(np.logical_and(pred, gt).sum()))
     hd95 = asd = 0.0
-    if _medpy_metric is not None and pred.sum() > 0 and gt.sum() > 0:
+    if pred.sum() > 0 and gt.sum() > 0:
         asd = _medpy_metric.binary.asd(pred, gt)
         hd95 = _medpy_metric.binary.hd95(pred, gt)
     return dice, jc, hd95, asd
@@ -80,7 +77,7 @@ def test_single_volume(image, label, net, classes, patch_size=(256, 256), device
     for c in range(1, classes):
         dice, jc = _dice_jc(int(cnt[c, 0]), int(cnt[c, 1]), int(cnt[c, 2]))
         hd95 = asd = 0.0
-        if _medpy_metric is not None and cnt[c, 0] > 0 and cnt[c, 1] > 0:
+        if cnt[c, 0] > 0 and cnt[c, 1] > 0:
             asd = _medpy_metric.binary.asd(prediction == c, label == c)
             hd95 = _medpy_metric.binary.hd95(prediction == c, label == c)
         metric_list.append((dice, jc, hd95, asd))

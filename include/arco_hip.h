@@ -174,6 +174,11 @@ int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, cons
                       const double* ws, const float* g, float* dP, long ldo, void* stream);
 /* ---- V  evaluation (test_2D.py:52-66): out[c] = {|pred==c|, |gt==c|, |pred==c & gt==c|} as int64[C][3]          */
 int arco_overlap_counts(const int64_t* pred, const int64_t* gt, long n, int C, int64_t* out, void* stream);
+/* ---- V  3-D sliding-window evaluation (test_util.py:139-211): score[C][ww][hh][dd] += prob[C][px][py][pz] at (xs, ys, zs),
+ *      cnt += 1 (test_util.py:196-199); then score /= cnt, label = argmax over classes (:200-201)                    */
+int arco_window_accumulate(const float* prob, int C, int px, int py, int pz, float* score, float* cnt, int ww, int hh, int dd,
+                           int xs, int ys, int zs, void* stream);
+int arco_score_finalize(float* score, const float* cnt, int C, long vol, int64_t* label, void* stream);
 long arco_seg_ws_doubles(long M, int C, int B);
 int arco_sup_loss_fwd(const float* X, long ld, long M, int C, const int64_t* lab, double* ws, float* out, void* stream);
 int arco_sup_loss_bwd(const float* X, long ld, long M, int C, const int64_t* lab, const double* ws, const float* g_ce,

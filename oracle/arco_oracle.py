@@ -320,35 +320,43 @@ def feature_extractor_forward(fmap, sd, mode='bilinear'):
 # --------------------------------------------------------------------------
 
 
-def _vnet_stage(x, sd, pre, n):
+def _vnet_bn(x, sd, key, train):
+    if train:
+        return bn_train(x, sd[f"{key}.weight"], sd[f"{key}.bias"])
+    return F.batch_norm(x, sd[f"{key}.running_mean"], sd[f"{key}.running_var"], sd[f"{key}.weight"], sd[f"{key}.bias"],
+                        False, 0.1, 1e-5)
+
+
+def _vnet_stage(x, sd, pre, n, train=True):
     for s in range(n):
         x = F.conv3d(x, sd[f"{pre}.conv.{3 * s}.weight"], sd[f"{pre}.conv.{3 * s}.bias"], padding=1)
-        x = bn_train(x, sd[f"{pre}.conv.{3 * s + 1}.weight"], sd[f"{pre}.conv.{3 * s + 1}.bias"])
-        x = F.relu(x)
+        x = F.relu(_vnet_bn(x, sd, f"{pre}.conv.{3 * s + 1}", train))
     return x
 
 
-def _vnet_down(x, sd, pre):
+def _vnet_down(x, sd, pre, train=True):
     x = F.conv3d(x, sd[f"{pre}.conv.0.weight"], sd[f"{pre}.conv.0.bias"], stride=2)
-    return F.relu(bn_train(x, sd[f"{pre}.conv.1.weight"], sd[f"{pre}.conv.1.bias"]))
+    return F.relu(_vnet_bn(x, sd, f"{pre}.conv.1", train))
 
 
-def _vnet_up(x, sd, pre):
+def _vnet_up(x, sd, pre, train=True):
     x = F.conv_transpose3d(x, sd[f"{pre}.conv.0.weight"], sd[f"{pre}.conv.0.bias"], stride=2)
-    return F.relu(bn_train(x, sd[f"{pre}.conv.1.weight"], sd[f"{pre}.conv.1.bias"]))
+    return F.relu(_vnet_bn(x, sd, f"{pre}.conv.1", train))
 
 
-def vnet_forward(x, sd):
-    x1 = _vnet_stage(x, sd, "block_one", 1)
-    x2 = _vnet_stage(_vnet_down(x1, sd, "block_one_dw"), sd, "block_two", 2)
-    x3 = _vnet_stage(_vnet_down(x2, sd, "block_two_dw"), sd, "block_three", 3)
-    x4 = _vnet_stage(_vnet_down(x3, sd, "block_three_dw"), sd, "block_four", 3)
-    x5 = _vnet_stage(_vnet_down(x4, sd, "block_four_dw"), sd, "block_five", 3)
-    u5 = _vnet_up(x5, sd, "block_five_up") + x4
-    u6 = _vnet_up(_vnet_stage(u5, sd, "block_six", 3), sd, "block_six_up") + x3
-    u7 = _vnet_up(_vnet_stage(u6, sd, "block_seven", 3), sd, "block_seven_up") + x2
-    u8 = _vnet_up(_vnet_stage(u7, sd, "block_eight", 2), sd, "block_eight_up") + x1
-    x9 = _vnet_stage(u8, sd, "block_nine", 1)
+def vnet_forward(x, sd, train=True):
+    """train=False: net.eval() (BatchNorm on the running statistics), as the evaluation uses it."""
+    t = train
+    x1 = _vnet_stage(x, sd, "block_one", 1, t)
+    x2 = _vnet_stage(_vnet_down(x1, sd, "block_one_dw", t), sd, "block_two", 2, t)
+    x3 = _vnet_stage(_vnet_down(x2, sd, "block_two_dw", t), sd, "block_three", 3, t)
+    x4 = _vnet_stage(_vnet_down(x3, sd, "block_three_dw", t), sd, "block_four", 3, t)
+    x5 = _vnet_stage(_vnet_down(x4, sd, "block_four_dw", t), sd, "block_five", 3, t)
+    u5 = _vnet_up(x5, sd, "block_five_up", t) + x4
+    u6 = _vnet_up(_vnet_stage(u5, sd, "block_six", 3, t), sd, "block_six_up", t) + x3
+    u7 = _vnet_up(_vnet_stage(u6, sd, "block_seven", 3, t), sd, "block_seven_up", t) + x2
+    u8 = _vnet_up(_vnet_stage(u7, sd, "block_eight", 2, t), sd, "block_eight_up", t) + x1
+    x9 = _vnet_stage(u8, sd, "block_nine", 1, t)
     out = F.conv3d(x9, sd["out_conv.weight"], sd["out_conv.bias"])
     fmap = [u5, u6, u7, u8, x9]
     return out, fmap[0], fmap
@@ -454,6 +462,61 @@ def test_single_volume(image, label, sd, classes, patch=(256, 256)):
             out = torch.argmax(torch.softmax(unet_forward(inp, sd, train=False)[0], dim=1), dim=1).squeeze(0).numpy()
         prediction[ind] = zoom(out, (x / patch[0], y / patch[1]), order=0)
     return [dice_jaccard(prediction == i, label == i) for i in range(1, classes)], prediction
+
+
+def test_single_case(net_fn, image, stride_xy, stride_z, patch_size, num_classes=1):
+    """test_util.py:139-211: sliding-window inference of one [w,h,d] volume.  `net_fn(patch [1,1,px,py,pz]) -> logits`
+    (eval mode).  Pads volumes smaller than the patch symmetrically with zeros, visits windows in (x, y, z) order with
+    the last window clamped to the border, averages the softmax scores over the windows covering a voxel, arg-max."""
+    import math
+    w, h, d = image.shape
+    pads = []
+    for sz, p in zip((w, h, d), patch_size):
+        tot = max(p - sz, 0)
+        pads.append((tot // 2, tot - tot // 2))
+    add_pad = any(a + b > 0 for a, b in pads)
+    if add_pad:
+        image = np.pad(image, pads, mode='constant', constant_values=0)
+    ww, hh, dd = image.shape
+    sx = math.ceil((ww - patch_size[0]) / stride_xy) + 1
+    sy = math.ceil((hh - patch_size[1]) / stride_xy) + 1
+    sz = math.ceil((dd - patch_size[2]) / stride_z) + 1
+    score_map = np.zeros((num_classes,) + image.shape, dtype=np.float32)
+    cnt = np.zeros(image.shape, dtype=np.float32)
+    for x in range(sx):
+        xs = min(stride_xy * x, ww - patch_size[0])
+        for y in range(sy):
+            ys = min(stride_xy * y, hh - patch_size[1])
+            for z in range(sz):
+                zs = min(stride_z * z, dd - patch_size[2])
+                sl = (slice(xs, xs + patch_size[0]), slice(ys, ys + patch_size[1]), slice(zs, zs + patch_size[2]))
+                patch = torch.from_numpy(image[sl][None, None].astype(np.float32))
+                with torch.no_grad():
+                    prob = torch.softmax(net_fn(patch), dim=1)[0].numpy()
+                score_map[(slice(None),) + sl] += prob
+                cnt[sl] += 1
+    score_map = score_map / cnt[None]
+    label_map = np.argmax(score_map, axis=0)
+    if add_pad:
+        (wl, _), (hl, _), (dl, _) = pads
+        label_map = label_map[wl:wl + w, hl:hl + h, dl:dl + d]
+        score_map = score_map[:, wl:wl + w, hl:hl + h, dl:dl + d]
+    return label_map, score_map
+
+
+def surface_metrics(pred, gt):
+    """(hd95, asd) of medpy.metric.binary (medpy==0.4.0, environment.yml:301; absent here - restated from its published
+    algorithm, PARITY UNPINNED against medpy itself; pinned only by analytic cases in tests/).  Border = X ^ erode(X)
+    with the cross structuring element; distances from distance_transform_edt of the other border's complement."""
+    from scipy.ndimage import binary_erosion, distance_transform_edt, generate_binary_structure
+    a, b = np.asarray(pred).astype(bool), np.asarray(gt).astype(bool)
+    fp = generate_binary_structure(a.ndim, 1)
+
+    def sd(u, v):
+        ub, vb = u ^ binary_erosion(u, structure=fp, iterations=1), v ^ binary_erosion(v, structure=fp, iterations=1)
+        return distance_transform_edt(~vb)[ub]
+    d1, d2 = sd(a, b), sd(b, a)
+    return float(np.percentile(np.hstack((d1, d2)), 95)), float(d1.mean())
 
 
 # --------------------------------------------------------------------------

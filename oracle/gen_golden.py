@@ -396,11 +396,34 @@ def gen_eqv():
     print("g5_eqv", len(out))
 
 
+# ---------------------------------------------------------------- G6 3-D sliding-window evaluation
+def gen_eval3d(mods):
+    """test_util.test_single_case (test_util.py:139-211), pulled out of the source text (the module imports h5py /
+    nibabel / medpy / skimage, absent here), run on the reference V-Net (networks/vnetWithArgs.py) in eval mode."""
+    import math
+    path = os.path.join(ref_shim.REF, "test_util.py")
+    ns, _ = _pull_functions(path, {"test_single_case"})
+    ns["math"] = math
+    VNet = mods["networks.vnetWithArgs"].VNet
+    out = {}
+    for tag, (shape, patch, sxy, sz, C, nf, seed) in fx.EVAL3D_CASES.items():
+        net = VNet(n_channels=1, n_classes=C, n_filters=nf, normalization='batchnorm', has_dropout=False)
+        net.load_state_dict(fx.randomize_running_stats(fx.vnet_state(seed, 1, C, nf), seed + 1))
+        net.eval()
+        image = fx.eval3d_volume(seed + 2, shape)
+        label_map, score_map = ns["test_single_case"](lambda p: net(p)[0], image, sxy, sz, patch, num_classes=C)
+        out[f"{tag}_label"] = label_map.astype(np.int8)
+        out[f"{tag}_score"] = score_map.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "g6_eval3d.npz"), **out)
+    print("g6_eval3d", len(out))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
     if "g4" in which: gen_glue()
     if "g5" in which: gen_eqv()
+    if "g6" in which: gen_eval3d(mods)

@@ -198,3 +198,27 @@ def vnet_state(seed, in_chns=1, n_cls=2, nf=16):
 def image_batch(seed, b, c, spatial):
     rs = np.random.RandomState(seed)
     return torch.from_numpy(rs.uniform(size=(b, c, *spatial)).astype(np.float32))
+
+
+def randomize_running_stats(sd, seed):
+    """Non-trivial BatchNorm running statistics (eval-mode cases), drawn in key order."""
+    rs = np.random.RandomState(seed)
+    for k in sorted(sd):
+        if k.endswith("running_mean"):
+            sd[k] = torch.from_numpy((0.2 * rs.standard_normal(sd[k].shape)).astype(np.float32))
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(rs.uniform(0.5, 1.5, size=sd[k].shape).astype(np.float32))
+    return sd
+
+
+# 3-D sliding-window evaluation cases (g6): tag -> (volume shape, patch, stride_xy, stride_z, classes, nf, seed)
+EVAL3D_CASES = {
+    "ragged": ((20, 22, 18), (16, 16, 16), 6, 4, 2, 4, 31),       # clamped last windows on every axis
+    "padded": ((12, 16, 10), (16, 16, 16), 8, 8, 3, 4, 32),       # volume smaller than the patch: symmetric zero pad
+    "exact": ((32, 16, 16), (16, 16, 16), 16, 16, 2, 4, 33),      # non-overlapping windows
+}
+
+
+def eval3d_volume(seed, shape):
+    rs = np.random.RandomState(seed)
+    return rs.uniform(size=shape).astype(np.float32)

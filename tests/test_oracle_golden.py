@@ -235,3 +235,38 @@ def test_eqv_oracle_vs_reference(g5, tag):
     loss.backward()
     np.testing.assert_allclose(loss.item(), float(g5[f"{tag}_loss"]), rtol=1e-6)
     np.testing.assert_allclose(p.grad.numpy(), g5[f"{tag}_grad"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", sorted(fx.EVAL3D_CASES))
+def test_eval3d_oracle_vs_reference(tag):
+    """Sliding-window inference (test_util.py:139-211) of the oracle vs outputs of the reference function on the
+    reference V-Net in eval mode (g6, oracle/gen_golden.py)."""
+    g6 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_eval3d.npz"))
+    shape, patch, sxy, sz, C, nf, seed = fx.EVAL3D_CASES[tag]
+    sd = fx.randomize_running_stats(fx.vnet_state(seed, 1, C, nf), seed + 1)
+    image = fx.eval3d_volume(seed + 2, shape)
+    label, score = orc.test_single_case(lambda p: orc.vnet_forward(p, sd, train=False)[0], image, sxy, sz, patch, num_classes=C)
+    assert label.shape == tuple(shape) and score.shape == (C, *shape)
+    np.testing.assert_allclose(score, g6[f"{tag}_score"], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(label, g6[f"{tag}_label"].astype(np.int64))
+    assert len(np.unique(label)) > 1                      # not a degenerate all-one-class prediction
+
+
+def test_surface_metrics_analytic():
+    """hd95 / asd (medpy.metric.binary restated): cases with known surface distances."""
+    from arco_amd.utils import metrics
+    a = np.zeros((20, 20, 20), bool); a[4:10, 4:10, 4:10] = True
+    b = np.zeros_like(a); b[7:13, 4:10, 4:10] = True                 # the same cube shifted by 3 along x
+    hd, asd = orc.surface_metrics(a, b)
+    assert abs(metrics.binary.hd95(a, b) - hd) < 1e-12 and abs(metrics.binary.asd(a, b) - asd) < 1e-12
+    assert hd == 3.0                                                  # the far faces are 3 apart
+    assert 0 < asd < 3.0
+    assert metrics.binary.hd95(a, a) == 0.0 and metrics.binary.asd(a, a) == 0.0
+    # a single voxel vs a single voxel: both metrics are the Euclidean distance
+    p = np.zeros((9, 9), bool); p[1, 1] = True
+    q = np.zeros((9, 9), bool); q[4, 5] = True
+    assert abs(metrics.binary.hd95(p, q) - 5.0) < 1e-12 and abs(metrics.binary.asd(p, q) - 5.0) < 1e-12
+    assert metrics.binary.dc(a, b) == 2 * 108 / 432 and abs(metrics.binary.jc(a, b) - 108 / 324) < 1e-12
+    with pytest.raises(RuntimeError):
+        metrics.binary.hd95(np.zeros((3, 3)), p[:3, :3])
+    np.testing.assert_allclose(metrics.cal_dice(np.array([0, 1, 1, 2]), np.array([0, 1, 2, 2]), 3), [2 / 3, 2 / 3])
