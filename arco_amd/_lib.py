@@ -32,6 +32,8 @@ _SIGS = {
     "arco_pack_conv_weight": [_P, _I, _I, _I, _I, _P, _P],
     "arco_pack_many": [_P, _I, _L, _P],
     "arco_overlap_counts": [_P, _P, _L, _I, _P, _P],
+    "arco_mix_unsup": [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
+    "arco_label_presence": [_P, _I, _L, _P, _P],
     "arco_window_accumulate": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "arco_score_finalize": [_P, _P, _I, _L, _P, _P],
     "arco_tps_grid": [_P, _P, _I, _L, _I, _P, _P],

@@ -1,0 +1,126 @@
+"""Mixing strategies of the unlabeled stream on the GPU (first part) - the names of the reference's
+code/augment.py: `generate_cutout_mask` (:230-244), `generate_class_mask` (:247-252), `generate_unsup_data` (:284-313),
+and of code/augment_3d.py: `generate_cutout_mask_3d` (:182-198), `generate_unsup_data_3d` (:228-257).
+
+The random choices are the reference's, drawn from the same host generators in the same order (numpy's global
+RandomState for the boxes, torch's CPU generator for classmix's randperm), so a seeded run mixes the same pixels;
+the mixing itself is one launch over the whole batch instead of a Python loop of per-image tensor expressions, and
+nothing leaves the GPU (classmix reads back one 64-bit label set per image, where the reference syncs on torch.unique).
+
+NOT here: `batch_transform` (tensor -> PIL -> ColorJitter / GaussianBlur -> tensor, augment.py:133-227,255-281) - its
+arithmetic is PIL's / torchvision's 8-bit image code, neither importable here, so no parity could be pinned."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_MODES = {"cutmix": 0, "cutout": 1, "classmix": 2}
+
+
+def _cutout_box(img_size, ratio=2):
+    """The zero box of generate_cutout_mask / _3d as (y0, y1, x0, x1[, z0, z1]) - same draws, same order."""
+    cutout_area = img_size[0] * img_size[1] / ratio
+    w = np.random.randint(img_size[1] / ratio + 1, img_size[1])
+    h = np.round(cutout_area / w)
+    x_start = np.random.randint(0, img_size[1] - w + 1)
+    y_start = np.random.randint(0, img_size[0] - h + 1)
+    box = [int(y_start), int(y_start + h), int(x_start), int(x_start + w)]
+    if len(img_size) == 3:
+        z_start = np.random.randint(0, img_size[2] - 20 + 1)
+        box += [int(z_start), int(z_start + 10)]
+    return box
+
+
+def _box_mask(img_size, box):
+    mask = torch.ones(list(img_size))
+    if len(img_size) == 3:
+        mask[box[0]:box[1], box[2]:box[3], box[4]:box[5]] = 0
+    else:
+        mask[box[0]:box[1], box[2]:box[3]] = 0
+    return mask.float()
+
+
+def generate_cutout_mask(img_size, ratio=2):
+    """[H, W] float mask, 0 inside a random rectangle of area H*W/ratio (augment.py:230-244)."""
+    return _box_mask(img_size, _cutout_box(img_size, ratio))
+
+
+def generate_cutout_mask_3d(img_size, ratio=2, dep=80):
+    """[H, W, Z] float mask, 0 inside a random box 10 slices deep (augment_3d.py:182-198)."""
+    return _box_mask(img_size, _cutout_box(img_size, ratio))
+
+
+def _label_sets(target):
+    """Per image: sorted list of the labels present (torch.unique) - one kernel + one small read-back."""
+    B = int(target.shape[0])
+    pres = torch.empty(B, dtype=torch.int64, device=target.device)
+    L.call("arco_label_presence", L.ptr(target), B, target[0].numel(), L.ptr(pres))
+    out = []
+    for v in pres.cpu().tolist():
+        v &= (1 << 64) - 1
+        out.append([c for c in range(64) if (v >> c) & 1])
+    return out
+
+
+def _select_half(labels):
+    """labels[torch.randperm(len(labels))][:len(labels) // 2] (augment.py:249) as a bit set."""
+    perm = torch.randperm(len(labels)).tolist()
+    sel = 0
+    for k in perm[:len(labels) // 2]:
+        sel |= 1 << labels[k]
+    return sel
+
+
+def generate_class_mask(pseudo_labels):
+    """Float mask selecting a random half of the labels present in ONE label map (augment.py:247-252)."""
+    L.require_gpu(pseudo_labels)
+    t = pseudo_labels.to(torch.int64).contiguous()
+    sel = _select_half(_label_sets(t.unsqueeze(0))[0])
+    table = torch.tensor([(sel >> c) & 1 for c in range(64)], dtype=torch.float32, device=t.device)
+    return table[t.clamp(0, 63)] * (t >= 0)
+
+
+def _mix(data, target, logits, mode):
+    L.require_gpu(data, target, logits)
+    if mode not in _MODES:                                   # reference: mask of ones -> the inputs unchanged
+        return data, target.long(), logits
+    B, Cimg = int(data.shape[0]), int(data.shape[1])
+    sp = tuple(int(v) for v in data.shape[2:])
+    H, W, Z = sp[0], sp[1], (sp[2] if len(sp) == 3 else 1)
+    data = data.to(torch.float32).contiguous()
+    logits = logits.to(torch.float32).contiguous()
+    tgt = target.to(torch.int64).contiguous()
+    desc = np.zeros((B, 8), dtype=np.int32)
+    desc[:, 5] = 1
+    if mode == "classmix":
+        sets = _label_sets(tgt)
+        for i in range(B):
+            sel = _select_half(sets[i])
+            desc[i, 6], desc[i, 7] = np.uint32(sel & 0xFFFFFFFF).astype(np.int32), np.uint32(sel >> 32).astype(np.int32)
+    else:
+        for i in range(B):
+            box = _cutout_box(list(sp), ratio=2)
+            desc[i, :len(box)] = box
+    odata, otarget, ologits = torch.empty_like(data), torch.empty_like(tgt), torch.empty_like(logits)
+    L.call("arco_mix_unsup", L.ptr(data), Cimg, L.ptr(tgt), L.ptr(logits), B, H, W, Z, desc.ctypes.data_as(ctypes.c_void_p), _MODES[mode], L.ptr(odata),
+           L.ptr(otarget), L.ptr(ologits))
+    if mode == "cutout" and target.dtype == torch.int64 and target.is_contiguous():
+        target.copy_(otarget)                                # the reference writes the -1s into the caller's target (:292)
+    return odata, otarget, ologits
+
+
+def generate_unsup_data(data, target, logits, mode='cutout'):
+    """(new_data [b,c,H,W], new_target int64 [b,H,W], new_logits [b,H,W]) - augment.py:284-313.
+    cutout: data, logits zeroed and target = -1 inside a random half-area rectangle per image; cutmix: that rectangle
+    is filled from image (i+1) % b; classmix: a random half of image i's labels keep their pixels, the rest comes from
+    image (i+1) % b.  Any other mode returns the inputs."""
+    assert data.dim() == 4, data.shape
+    return _mix(data, target, logits, mode)
+
+
+def generate_unsup_data_3d(data, target, logits, mode='cutout'):
+    """Volume variant (augment_3d.py:228-257): the box is 10 slices deep along the last axis."""
+    assert data.dim() == 5, data.shape
+    return _mix(data, target, logits, mode)

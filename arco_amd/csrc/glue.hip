@@ -1,6 +1,7 @@
 // Step glue of the trainer (train_arco_2d.py:284-286,342-393,492-498):
 // class softmax / max / argmax / entropy, one-hot labels, exact np.percentile (linear) of the
 // entropy via radix select, and the low/high entropy masks.  HBM-bound, one pixel per lane.
+#include <cstring>
 #include "common.h"
 
 #define GL_MAXC 32
@@ -452,6 +453,73 @@ int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, cons
                       const double* ws, const float* g, float* dP, long ldo, void* stream) {
   hipLaunchKernelGGL(eqv_loss_bwd_kernel, dim3(gl_grid((long)B * P)), dim3(256), 0, as_stream(stream), P_, ldp, Q_, ldq, mask, P,
                      (long)B * P, C, B, ws + 64l * 2 * B, g, dP, ldo);
+  return arco_launch_status();
+}
+
+// ---- A  mixing strategies of the unlabeled stream (augment.py:284-313 generate_unsup_data) ----
+// desc[i] = {y0, y1, x0, x1, z0, z1, sel_lo, sel_hi}: the zero box of the cutout mask (augment.py:230-244; volumes
+// augment_3d.py:182-198, Z = 1 and z = [0, 1) in 2-D) for modes 0/1, or the 64-bit set of selected labels
+// (generate_class_mask, :247-252) for mode 2.  mask = 1 outside the box / where the
+// pixel's label is selected.   mode 0 (cutmix) and 2 (classmix): out_i = mask ? src_i : src_{(i+1) % B}
+// mode 1 (cutout): data, logits *= mask; target = -1 where mask == 0.       data is NC[spatial] (the loader's layout).
+struct MixDescs { int d[32][8]; };     // by value in the kernel arguments: no H2D copy, no host synchronisation
+__global__ void mix_unsup_kernel(const float* __restrict__ data, int Cimg, const int64_t* __restrict__ target,
+                                 const float* __restrict__ logits, int B, int H, int W, int Z, MixDescs dd, int i0, int nimg, int mode,
+                                 float* __restrict__ odata, int64_t* __restrict__ otarget, float* __restrict__ ologits) {
+  const long HW = (long)H * W * Z, n = (long)nimg * HW;
+  for (long tt = (long)blockIdx.x * blockDim.x + threadIdx.x; tt < n; tt += (long)gridDim.x * blockDim.x) {
+    const int il = tt / HW, i = i0 + il; const long p = tt - (long)il * HW, t = (long)i * HW + p;
+    const int z = p % Z; const long q = p / Z; const int y = q / W, x = q - (long)y * W;
+    const int* d = dd.d[il];
+    bool keep;
+    if (mode == 2) {
+      const int64_t lab = target[t];
+      const unsigned long long sel = ((unsigned long long)(unsigned)d[7] << 32) | (unsigned)d[6];
+      keep = lab >= 0 && lab < 64 && ((sel >> lab) & 1ull);
+    } else keep = !(y >= d[0] && y < d[1] && x >= d[2] && x < d[3] && z >= d[4] && z < d[5]);
+    if (mode == 1) {
+      for (int c = 0; c < Cimg; ++c) { const long o = ((long)i * Cimg + c) * HW + p; odata[o] = keep ? data[o] : 0.f; }
+      otarget[t] = keep ? target[t] : -1;
+      ologits[t] = keep ? logits[t] : 0.f;
+    } else {
+      const int j = keep ? i : (i + 1) % B;
+      for (int c = 0; c < Cimg; ++c) odata[((long)i * Cimg + c) * HW + p] = data[((long)j * Cimg + c) * HW + p];
+      otarget[t] = target[(long)j * HW + p];
+      ologits[t] = logits[(long)j * HW + p];
+    }
+  }
+}
+// presence[i] = 64-bit set of the labels occurring in target[i] (torch.unique per image, labels in [0, 64))
+__global__ void label_presence_kernel(const int64_t* __restrict__ target, long HW, unsigned long long* __restrict__ presence) {
+  unsigned long long m = 0;
+  const int64_t* t = target + (long)blockIdx.y * HW;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+    const int64_t l = t[p];
+    if (l >= 0 && l < 64) m |= 1ull << l;
+  }
+  for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o);
+  if ((threadIdx.x & 63) == 0 && m) atomicOr(&presence[blockIdx.y], m);
+}
+int arco_mix_unsup(const float* data, int Cimg, const int64_t* target, const float* logits, int B, int H, int W, int Z,
+                   const int* desc_host, int mode, float* odata, int64_t* otarget, float* ologits, void* stream) {
+  ARCO_CHECK_ARG(data && target && logits && desc_host && odata && otarget && ologits && B > 0 && H > 0 && W > 0 && Z > 0 &&
+                 Cimg > 0 && mode >= 0 && mode <= 2);
+  for (int i0 = 0; i0 < B; i0 += 32) {
+    const int nimg = B - i0 < 32 ? B - i0 : 32;
+    MixDescs dd;
+    memcpy(dd.d, desc_host + 8l * i0, sizeof(int) * 8 * nimg);
+    hipLaunchKernelGGL(mix_unsup_kernel, dim3(gl_grid((long)nimg * H * W * Z)), dim3(256), 0, as_stream(stream), data, Cimg, target,
+                       logits, B, H, W, Z, dd, i0, nimg, mode, odata, otarget, ologits);
+  }
+  return arco_launch_status();
+}
+int arco_label_presence(const int64_t* target, int B, long HW, uint64_t* presence, void* stream) {
+  ARCO_CHECK_ARG(target && presence && B > 0 && HW > 0);
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(presence, 0, (size_t)B * 8, st) != hipSuccess) return -2;
+  long g = (HW + 255) / 256; if (g > 64) g = 64;
+  hipLaunchKernelGGL(label_presence_kernel, dim3((unsigned)g, B), dim3(256), 0, st, target, HW,
+                     reinterpret_cast<unsigned long long*>(presence));
   return arco_launch_status();
 }
 

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import dist as adist
 from . import _contrast as C_
-from . import glue, graphs, head, ops, optim
+from . import augment, glue, graphs, head, ops, optim
 from .tps import RandTPS
 from .model_2D import ISD, FeatureExtractor
 
@@ -191,8 +191,8 @@ class ArcoStep2D:
         return ops.conv(x, self.q_representation[1].weight)
 
     def step(self, l_data, l_label, u_data, epoch_num=0, max_epoch=1):
-        """One iteration.  Augmentations (augment.py; CPU/PIL, out of scope) are the identity here:
-        train_u_aug_* = (u_data, pseudo_labels, pseudo_logits), images_cj2_l = l_data.
+        """One iteration.  The mixing strategy of --apply_aug (augment.generate_unsup_data) runs on the GPU; the PIL colour
+        jitter / blur of batch_transform (augment.py; CPU/PIL, out of scope) is the identity here: images_cj2_l = l_data.
 
         Same operations and results as train_arco_2d.py:284-435 restricted to the hot-path loss term;
         the ORDER is arranged for the GPU: everything the host sampler needs (3*C counters) is
@@ -207,7 +207,9 @@ class ArcoStep2D:
         with torch.no_grad():                                            # :284-286
             pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
-        u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits
+        # randomGeneratorWithLogits (:292-293) is a same-size zoom(order=0) = the identity; then the mixing strategy
+        # (:296-297) on the GPU with the reference's host draws; other --apply_aug values leave the batch unchanged
+        u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
         self.k_fe_ema.update(0.99)                                      # :306-308
         batched = self.batched_passes and l_data.shape == u_aug.shape
         if batched:

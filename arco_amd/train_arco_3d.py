@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _contrast as C_
 from . import dist as adist
-from . import glue, graphs, head, ops, optim
+from . import augment, glue, graphs, head, ops, optim
 from .tps.rand_tps_3d import RandTPS as RandTPS3D
 from .model_3D import ISD_3d, FeatureExtractor_3d
 from .train_arco_2d import build_parser as _build_parser_2d
@@ -113,7 +113,8 @@ class ArcoStep3D:
         with torch.no_grad():                                            # :260-262
             pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
-        u_aug, u_aug_label, u_aug_logits = u_data, pseudo_labels, pseudo_logits   # :268-278 (identity transforms)
+        # :268-278: the mixing strategy of --apply_aug on the GPU (train_arco_3d.py:270-271); the PIL transforms are identity
+        u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data_3d(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
         self.k_fe_ema.update(0.99)                                      # :279-281
         batched = self.batched_passes and l_data.shape == u_aug.shape
         if batched:     # labelled + unlabelled volumes as one pass with two BatchNorm groups (see train_arco_2d.py)

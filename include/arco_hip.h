@@ -174,6 +174,13 @@ int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, cons
                       const double* ws, const float* g, float* dP, long ldo, void* stream);
 /* ---- V  evaluation (test_2D.py:52-66): out[c] = {|pred==c|, |gt==c|, |pred==c & gt==c|} as int64[C][3]          */
 int arco_overlap_counts(const int64_t* pred, const int64_t* gt, long n, int C, int64_t* out, void* stream);
+/* ---- A  mixing strategies of the unlabeled stream (augment.py:284-313 generate_unsup_data, masks :230-252; volumes
+ *      augment_3d.py:182-257).  desc_host[B][8] = {y0, y1, x0, x1, z0, z1, sel_lo, sel_hi} in HOST memory (the host
+ *      draws it; it travels in the kernel arguments); Z = 1 in 2-D; mode 0 cutmix, 1 cutout, 2 classmix; data NC[spatial] */
+int arco_mix_unsup(const float* data, int Cimg, const int64_t* target, const float* logits, int B, int H, int W, int Z,
+                   const int* desc_host, int mode, float* odata, int64_t* otarget, float* ologits, void* stream);
+/*      presence[i] = bit set of the labels occurring in target[i] (torch.unique of augment.py:248), labels < 64          */
+int arco_label_presence(const int64_t* target, int B, long HW, uint64_t* presence, void* stream);
 /* ---- V  3-D sliding-window evaluation (test_util.py:139-211): score[C][ww][hh][dd] += prob[C][px][py][pz] at (xs, ys, zs),
  *      cnt += 1 (test_util.py:196-199); then score /= cnt, label = argmax over classes (:200-201)                    */
 int arco_window_accumulate(const float* prob, int C, int px, int py, int pz, float* score, float* cnt, int ww, int hh, int dd,

@@ -520,6 +520,63 @@ def surface_metrics(pred, gt):
 
 
 # --------------------------------------------------------------------------
+# A  mixing strategies: augment.py:230-252,284-313; augment_3d.py:182-206,228-257
+# --------------------------------------------------------------------------
+
+
+def cutout_mask(img_size, ratio=2):
+    """generate_cutout_mask (augment.py:230-244) / generate_cutout_mask_3d (augment_3d.py:182-198): ones with a zero
+    box of area H*W/ratio (10 slices deep for volumes); draws from numpy's global RandomState: w, x_start, y_start
+    [, z_start]."""
+    area = img_size[0] * img_size[1] / ratio
+    w = np.random.randint(img_size[1] / ratio + 1, img_size[1])
+    h = np.round(area / w)
+    x0 = np.random.randint(0, img_size[1] - w + 1)
+    y0 = np.random.randint(0, img_size[0] - h + 1)
+    mask = np.ones(img_size, dtype=np.float32)
+    if len(img_size) == 3:
+        z0 = np.random.randint(0, img_size[2] - 20 + 1)
+        mask[int(y0):int(y0 + h), int(x0):int(x0 + w), int(z0):int(z0 + 10)] = 0
+    else:
+        mask[int(y0):int(y0 + h), int(x0):int(x0 + w)] = 0
+    return mask
+
+
+def class_mask(labels_map):
+    """generate_class_mask (augment.py:247-252): a random half (torch.randperm on the CPU generator) of the labels
+    present keeps its pixels."""
+    labels = np.unique(labels_map)
+    perm = torch.randperm(len(labels)).numpy()
+    chosen = labels[perm][:len(labels) // 2]
+    return np.isin(labels_map, chosen).astype(np.float32)
+
+
+def generate_unsup_data(data, target, logits, mode='cutout'):
+    """generate_unsup_data / _3d on numpy arrays: data [b,c,*sp] float32, target [b,*sp] int64, logits [b,*sp] float32
+    -> (new_data, new_target int64, new_logits).  cutout also writes the -1s into `target` (augment.py:292)."""
+    b = data.shape[0]
+    sp = list(data.shape[2:])
+    nd, nt, nl = [], [], []
+    for i in range(b):
+        j = (i + 1) % b
+        if mode == 'cutout':
+            m = cutout_mask(sp, ratio=2)
+            target[i][m == 0] = -1
+            nd.append(data[i] * m); nt.append(target[i].copy()); nl.append(logits[i] * m)
+            continue
+        if mode == 'cutmix':
+            m = cutout_mask(sp)
+        elif mode == 'classmix':
+            m = class_mask(target[i])
+        else:
+            m = np.ones(sp, dtype=np.float32)
+        nd.append(data[i] * m + data[j] * (1 - m))
+        nt.append(target[i] * m + target[j] * (1 - m))
+        nl.append(logits[i] * m + logits[j] * (1 - m))
+    return np.stack(nd).astype(np.float32), np.stack(nt).astype(np.int64), np.stack(nl).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
 # E  equivariance loss (SURVEY §8f row 1): tps/rand_tps.py:48-153, tps_stn_pytorch/tps_grid_gen.py:9-71,
 #    tps/grid_sample.py:11-20, train_arco_2d.py:404-423
 # --------------------------------------------------------------------------

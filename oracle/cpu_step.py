@@ -22,10 +22,13 @@ def make_state(unet_sd, fe_sd, qrep_w):
 
 
 def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20.0, k1=0.01, lr=0.01,
-         delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7):
+         delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7, apply_aug='none'):
     with torch.no_grad():
         pred_u0, _, _ = orc.unet_forward(u_data, st["teacher"])
         pseudo_logits, pseudo_labels = torch.max(torch.softmax(pred_u0, 1), 1)
+        if apply_aug in ('cutout', 'cutmix', 'classmix'):      # train_arco_2d.py:296-297 (generate_unsup_data)
+            mixed = orc.generate_unsup_data(u_data.numpy(), pseudo_labels.numpy().copy(), pseudo_logits.numpy(), apply_aug)
+            u_data, pseudo_labels, pseudo_logits = (torch.from_numpy(v) for v in mixed)
         for k in st["k_fe"]:
             st["k_fe"][k] = st["k_fe"][k] * 0.99 + st["q_fe"][k].detach() * 0.01
     pred_l, _, l_fm = orc.unet_forward(l_data, st["student"])
@@ -95,5 +98,5 @@ def timed_sample(b=2, patch=(256, 256), n_cls=4, seed=1337, qsize=4096):
     lab = torch.from_numpy(fx.blob_labels(rs, b, patch, n_cls))
     bank, ptr, qs = fx.fresh_bank(n_cls, 496, qsize, 'zeros')
     t0 = time.time()
-    step(st, l, lab, u, bank, ptr, qs, n_cls)
+    step(st, l, lab, u, bank, ptr, qs, n_cls, apply_aug='cutmix')      # the trainer's default --apply_aug
     return time.time() - t0, torch.get_num_threads()

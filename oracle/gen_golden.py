@@ -418,12 +418,34 @@ def gen_eval3d(mods):
     print("g6_eval3d", len(out))
 
 
+# ---------------------------------------------------------------- G7 mixing strategies
+def gen_mix():
+    """generate_unsup_data (augment.py:284-313) and generate_unsup_data_3d (augment_3d.py:228-257) with their mask
+    generators, pulled out of the source text (the modules import h5py / torchvision, absent here)."""
+    ns2, _ = _pull_functions(os.path.join(ref_shim.REF, "augment.py"),
+                             {"generate_cutout_mask", "generate_class_mask", "generate_unsup_data"})
+    ns3, _ = _pull_functions(os.path.join(ref_shim.REF, "augment_3d.py"),
+                             {"generate_cutout_mask_3d", "generate_class_mask", "generate_unsup_data_3d"})
+    out = {}
+    for tag, (mode, b, c, spatial, n_cls, seed) in fx.MIX_CASES.items():
+        data, target, logits = fx.mix_inputs(seed, b, c, spatial, n_cls)
+        seed_all(seed + 1)
+        fn = ns2["generate_unsup_data"] if len(spatial) == 2 else ns3["generate_unsup_data_3d"]
+        nd, nt, nl = fn(data, target, logits, mode=mode)
+        out[f"{tag}_data"], out[f"{tag}_target"], out[f"{tag}_logits"] = nd.numpy().copy(), nt.numpy().astype(np.int8), nl.numpy().copy()
+        out[f"{tag}_target_after"] = target.numpy().astype(np.int8)         # cutout writes -1 into the caller's tensor
+        out[f"{tag}_probe"] = np.array((rng_probe(), float(np.random.uniform()), random.random()), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g7_mix.npz"), **out)
+    print("g7_mix", len(out))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
     if "g4" in which: gen_glue()
     if "g5" in which: gen_eqv()
     if "g6" in which: gen_eval3d(mods)
+    if "g7" in which: gen_mix()

@@ -222,3 +222,23 @@ EVAL3D_CASES = {
 def eval3d_volume(seed, shape):
     rs = np.random.RandomState(seed)
     return rs.uniform(size=shape).astype(np.float32)
+
+
+# mixing-strategy cases (g7): tag -> (mode, batch, channels, spatial, classes, seed)
+MIX_CASES = {
+    "cutmix2d": ("cutmix", 4, 1, (24, 32), 4, 41),
+    "cutout2d": ("cutout", 3, 3, (32, 32), 4, 42),
+    "classmix2d": ("classmix", 4, 1, (24, 24), 6, 43),
+    "none2d": ("none", 2, 1, (8, 8), 3, 44),
+    "cutmix3d": ("cutmix", 2, 1, (16, 16, 24), 2, 45),
+    "cutout3d": ("cutout", 2, 1, (12, 16, 22), 3, 46),
+    "classmix3d": ("classmix", 3, 1, (8, 8, 21), 5, 47),
+}
+
+
+def mix_inputs(seed, b, c, spatial, n_cls):
+    rs = np.random.RandomState(seed)
+    data = torch.from_numpy(rs.uniform(size=(b, c, *spatial)).astype(np.float32))
+    target = torch.from_numpy(rs.randint(0, n_cls, size=(b, *spatial)).astype(np.int64))
+    logits = torch.from_numpy(rs.uniform(size=(b, *spatial)).astype(np.float32))
+    return data, target, logits

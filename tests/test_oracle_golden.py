@@ -270,3 +270,34 @@ def test_surface_metrics_analytic():
     with pytest.raises(RuntimeError):
         metrics.binary.hd95(np.zeros((3, 3)), p[:3, :3])
     np.testing.assert_allclose(metrics.cal_dice(np.array([0, 1, 1, 2]), np.array([0, 1, 2, 2]), 3), [2 / 3, 2 / 3])
+
+
+@pytest.mark.parametrize("tag", sorted(fx.MIX_CASES))
+def test_mix_oracle_vs_reference(tag):
+    """generate_unsup_data(_3d) of the oracle vs the reference functions' outputs (g7): bit-exact tensors and the
+    same consumption of the numpy / torch / python generators."""
+    g7 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_mix.npz"))
+    mode, b, c, spatial, n_cls, seed = fx.MIX_CASES[tag]
+    data, target, logits = (t.numpy() for t in fx.mix_inputs(seed, b, c, spatial, n_cls))
+    random.seed(seed + 1); np.random.seed(seed + 1); torch.manual_seed(seed + 1)
+    nd, nt, nl = orc.generate_unsup_data(data, target, logits, mode)
+    np.testing.assert_array_equal(nd, g7[f"{tag}_data"])
+    np.testing.assert_array_equal(nt, g7[f"{tag}_target"].astype(np.int64))
+    np.testing.assert_array_equal(nl, g7[f"{tag}_logits"])
+    np.testing.assert_array_equal(target, g7[f"{tag}_target_after"].astype(np.int64))
+    probe = (int(torch.randint(1 << 30, (1,))), float(np.random.uniform()), random.random())
+    np.testing.assert_array_equal(np.array(probe, dtype=np.float64), g7[f"{tag}_probe"])
+    if mode != "none":
+        assert not np.array_equal(nd, data)               # the case mixes something
+
+
+def test_cutout_mask_host_draws_match_oracle():
+    """arco_amd.augment draws its boxes on the host (no GPU needed): same mask as the oracle for the same numpy seed."""
+    from arco_amd import augment
+    for size in ([256, 256], [37, 53], [112, 112, 80], [16, 16, 24]):
+        np.random.seed(5)
+        exp = orc.cutout_mask(list(size))
+        np.random.seed(5)
+        got = augment.generate_cutout_mask(size) if len(size) == 2 else augment.generate_cutout_mask_3d(size)
+        np.testing.assert_array_equal(got.numpy(), exp)
+        assert float(np.random.uniform()) == float((np.random.seed(5), orc.cutout_mask(list(size)), np.random.uniform())[2])

@@ -18,8 +18,11 @@ def _drop_off(m):
             mod.p = 0.0
 
 
-@pytest.mark.parametrize("variant", [dict(dense_head=1, k2=0.0), dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0),
-                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0)])
+@pytest.mark.parametrize("variant", [dict(dense_head=1, k2=0.0, apply_aug="none"),
+                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0, apply_aug="cutmix"),
+                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutmix"),
+                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutout"),
+                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0, apply_aug="classmix")])
 def test_two_steps_vs_cpu_oracle(variant):
     from arco_amd import train_arco_2d as T
     b, patch, C, Q, Nn, qs = 2, (64, 64), 4, 64, 32, 300
@@ -49,7 +52,8 @@ def test_two_steps_vs_cpu_oracle(variant):
         u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
         lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
-        cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn, k2=variant["k2"])
+        cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn, k2=variant["k2"],
+                      apply_aug=variant["apply_aug"])
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
         st_g.step(l.cuda(), lab.cuda(), u.cuda())
         to, tg = st_o["last_terms"], st_g.last_terms
