@@ -45,7 +45,8 @@ _SIGS = {
     "arco_conv_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "arco_colsum": [_P, _L, _L, _I, _P, _P, _I, _P],
     "arco_transpose2d": [_P, _L, _I, _I, _P, _L, _P],
-    "arco_bn_finalize": [_P, _P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _I, _P],
+    "arco_bn_finalize": [_P, _P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P],
+    "arco_bn_apply_deferred": [_P, _I, _P],
     "arco_chan_stats": [_P, _L, _L, _I, _P, _P, _I, _P],
     "arco_bn_act_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _L, _P, _I, _P],
     "arco_bn_act_bwd": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _P, _P, _I, _P, _L, _P, _I, _P],
@@ -86,6 +87,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_chan_stats_blocks": ([_L], _I),
     "arco_sel_state_bytes": ([], _L),
     "arco_pack_desc_bytes": ([], _L),
+    "arco_bn_defer_desc_bytes": ([], _L),
     "arco_seg_ws_doubles": ([_L, _I, _I], _L),
     # host-side native sampler replay (no GPU work)
     "arco_grid_sample": ([_P, _L, _L, _L, _I, _I, _P], _L),

@@ -22,11 +22,16 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
                                    double count, float eps, float momentum, float* __restrict__ mean,
                                    float* __restrict__ istd, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked, int groups) {
+                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked, int groups,
+                                   int defer_from, float* __restrict__ deferred) {
   // groups > 1: the batch is `groups` independent BN batches (e.g. the labelled and the unlabelled half of one
   // launch); group g owns the slabs [g*nblk/groups, ...), has `count` elements per channel, gets mean/istd row g,
   // and the running statistics receive the groups' updates one after the other (as separate forwards would).
   // One 4-wave block per channel (the 3-D levels have up to 31 360 slabs per channel), fixed summation order.
+  // deferred != null: groups g >= defer_from do NOT touch the running statistics; their update terms (mean, unbiased
+  // variance) go to deferred[g - defer_from][2][C] (+ a "pending" flag behind them) and are applied later by
+  // bn_apply_deferred_kernel - the trainer runs forwards in a different order than the reference, the momentum
+  // updates must still land in the reference's order.
   __shared__ double sh[2][4];
   const int c = blockIdx.x, npg = nblk / groups, w = threadIdx.x >> 6;
   if (c == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += groups;
@@ -46,11 +51,36 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
       istd[(long)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
       if (running_mean) {
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
-        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        if (deferred && g >= defer_from) {
+          deferred[((long)(g - defer_from) * 2 + 0) * C + c] = (float)m;
+          deferred[((long)(g - defer_from) * 2 + 1) * C + c] = (float)unb;
+          if (c == 0) deferred[(long)(groups - defer_from) * 2 * C] = 1.f;
+        } else {
+          running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+          running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        }
       }
     }
   }
+}
+
+// ---- postponed running-statistics updates of many BN layers in one launch (one block per layer)
+struct BnDeferDesc { float* running_mean; float* running_var; float* deferred; int C, n; float momentum; int pad; };
+__global__ void bn_apply_deferred_kernel(const BnDeferDesc* __restrict__ desc) {
+  const BnDeferDesc d = desc[blockIdx.x];
+  float* flag = d.deferred + (long)d.n * 2 * d.C;
+  const bool pending = *flag != 0.f;
+  __syncthreads();
+  if (!pending) return;
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    double rm = d.running_mean[c], rv = d.running_var[c];
+    for (int g = 0; g < d.n; ++g) {
+      rm = (float)((1.0 - d.momentum) * rm + d.momentum * (double)d.deferred[((long)g * 2 + 0) * d.C + c]);
+      rv = (float)((1.0 - d.momentum) * rv + d.momentum * (double)d.deferred[((long)g * 2 + 1) * d.C + c]);
+    }
+    d.running_mean[c] = (float)rm; d.running_var[c] = (float)rv;
+  }
+  if (threadIdx.x == 0) *flag = 0.f;
 }
 
 // ---- generic per-channel (sum, sumsq) partials of a channels-last tensor (for
@@ -783,12 +813,21 @@ extern "C" {
 
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
                      float* mean, float* istd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                     int groups, void* stream) {
+                     int groups, int defer_from, float* deferred, void* stream) {
   if (groups < 1) groups = 1;
-  ARCO_CHECK_ARG(C > 0 && nblk > 0 && count > 0 && nblk % groups == 0 && count % groups == 0);
+  ARCO_CHECK_ARG(C > 0 && nblk > 0 && count > 0 && nblk % groups == 0 && count % groups == 0 &&
+                 (!deferred || (defer_from >= 0 && defer_from < groups)));
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), ssum, ssq, nblk, C,
                      (double)(count / groups), eps, momentum, mean, istd, running_mean, running_var, num_batches_tracked,
-                     groups);
+                     groups, defer_from, deferred);
+  return arco_launch_status();
+}
+long arco_bn_defer_desc_bytes() { return (long)sizeof(BnDeferDesc); }
+// desc: device array of n_layers BnDeferDesc {running_mean*, running_var*, deferred*, C, n, momentum, pad}
+int arco_bn_apply_deferred(const void* desc, int n_layers, void* stream) {
+  if (n_layers <= 0) return ARCO_OK;
+  ARCO_CHECK_ARG(desc);
+  hipLaunchKernelGGL(bn_apply_deferred_kernel, dim3(n_layers), dim3(256), 0, as_stream(stream), (const BnDeferDesc*)desc);
   return arco_launch_status();
 }
 

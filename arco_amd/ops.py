@@ -36,6 +36,64 @@ class bn_groups:
         BN_GROUPS = self.prev
 
 
+BN_DEFER = None       # see bn_defer()
+_DEFERRED = {}        # running_mean.data_ptr() -> dict(rm, rv, buf, C, n, momentum), in registration order
+_DEFER_TABLE = None   # (keys, device descriptor table) of the last apply_deferred_bn()
+
+
+class bn_defer:
+    """`with ops.bn_defer(g0):` - inside, the groups >= g0 of every train-mode BatchNorm forward compute and use their
+    batch statistics as usual but POSTPONE their running-statistics momentum update; `ops.apply_deferred_bn()` applies
+    the postponed updates later (one launch for all layers).  The momentum updates do not commute: the reference
+    runs model(l), model(cj2_l), model(u) (train_arco_2d.py:310-312) while the trainer here runs (l, u) as one grouped
+    pass and cj2_l afterwards - with the u group deferred behind the cj2_l pass the running statistics receive the
+    three updates in the reference's order."""
+
+    def __init__(self, from_group=0):
+        self.g0 = int(from_group)
+
+    def __enter__(self):
+        global BN_DEFER
+        self.prev, BN_DEFER = BN_DEFER, self.g0
+
+    def __exit__(self, *exc):
+        global BN_DEFER
+        BN_DEFER = self.prev
+
+
+def _defer_args(running_mean, running_var, co, G, momentum):
+    """(defer_from, deferred buffer or None) for the arco_bn_finalize call of one BN layer."""
+    global _DEFER_TABLE
+    if BN_DEFER is None or running_mean is None or BN_DEFER >= G:
+        return 0, None
+    n = G - BN_DEFER
+    key = running_mean.data_ptr()
+    e = _DEFERRED.get(key)
+    if e is None or e["n"] != n or e["C"] != co:
+        e = dict(rm=running_mean, rv=running_var, C=co, n=n, momentum=float(momentum),
+                 buf=torch.zeros(n * 2 * co + 1, dtype=torch.float32, device=running_mean.device))
+        _DEFERRED[key] = e
+        _DEFER_TABLE = None
+    return BN_DEFER, e["buf"]
+
+
+def apply_deferred_bn():
+    """Apply every postponed running-statistics update (see bn_defer); layers with nothing pending are skipped on the
+    device (a flag per layer), so calling it when nothing was deferred is harmless."""
+    global _DEFER_TABLE
+    if not _DEFERRED:
+        return
+    keys = tuple(_DEFERRED)
+    if _DEFER_TABLE is None or _DEFER_TABLE[0] != keys:
+        import struct
+        raw = b"".join(struct.pack("<QQQiifi", e["rm"].data_ptr(), e["rv"].data_ptr(), e["buf"].data_ptr(), e["C"], e["n"],
+                                   e["momentum"], 0) for e in _DEFERRED.values())
+        assert len(raw) == len(keys) * L.query("arco_bn_defer_desc_bytes")
+        dev = next(iter(_DEFERRED.values()))["buf"].device
+        _DEFER_TABLE = (keys, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev))
+    L.call("arco_bn_apply_deferred", L.ptr(_DEFER_TABLE[1]), len(keys))
+
+
 def _next_seed():
     """Dropout seeds come from a private generator so the torch CPU default generator
     (which defines the bit-exact sampler sequence) is never touched."""
@@ -378,8 +436,9 @@ class ConvBnActFn(torch.autograd.Function):
                                        stat_groups=G)
         mean = torch.empty(G * co, dtype=torch.float32, device=x.device)      # [G][co]
         istd = torch.empty(G * co, dtype=torch.float32, device=x.device)
+        d0, dbuf = _defer_args(running_mean, running_var, co, G, momentum)
         L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
-               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G)
+               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G, d0, L.ptr(dbuf))
         seed = _next_seed() if p > 0 else 0
         if cat_room:        # leave room behind the channels for a later in-place channel concat (ops.upcat)
             buf = new_act_nd(nv, co + int(cat_room), sp, x.device)
@@ -449,8 +508,9 @@ class BnActFn(torch.autograd.Function):
             L.call("arco_chan_stats", L.ptr(zr), ldz, m, co, L.ptr(ssum), L.ptr(ssq), G)
             mean = torch.empty(G * co, dtype=torch.float32, device=z.device)
             istd = torch.empty(G * co, dtype=torch.float32, device=z.device)
+            d0, dbuf = _defer_args(running_mean, running_var, co, G, momentum)
             L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), G * nblk, co, m, float(eps), float(momentum), L.ptr(mean),
-                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G)
+                   L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G, d0, L.ptr(dbuf))
         seed = _next_seed() if p > 0 else 0
         a = new_act_nd(int(z.shape[0]), co, sp, z.device)
         ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a, None, G)

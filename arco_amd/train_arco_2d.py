@@ -218,12 +218,15 @@ class ArcoStep2D:
             # results as two passes, every conv / BN / pooling launch works on twice the pixels (the mid and deep
             # U-Net levels are too small to fill the GPU at b images: 20-35 % less kernel time), one backward.
             lu = torch.cat((l_data, u_aug))
-            with ops.bn_groups(2):
+            # The u half postpones its running-statistics update (ops.bn_defer) until the images_cj2_l pass below has
+            # made its own: the momentum updates then land in the reference's order l, cj2_l, u (:310-312).
+            with ops.bn_groups(2), ops.bn_defer(1):
                 pred_all, _, fm_all = self.s_train_lu(lu)
             nb_l = int(l_data.shape[0])
             pred_l, pred_u = pred_all[:nb_l], pred_all[nb_l:]
         else:
-            pred_u, _, u_fm = self.s_train_u(u_aug)                      # :312 (needed first: entropy masks)
+            with ops.bn_defer(0):                                        # running statistics: applied after l and cj2_l
+                pred_u, _, u_fm = self.s_train_u(u_aug)                  # :312 (needed first: entropy masks)
         with torch.no_grad():                                            # teacher params carry no grad (:158-160)
             if batched:
                 with ops.bn_groups(2):
@@ -251,6 +254,7 @@ class ArcoStep2D:
             # :319,326) are never read.  One graph launch (~1 ms of GPU work) queued BEFORE the host sync: work for
             # the GPU while the host replays the samplers (14.8 vs 15.1 ms/step when queued after the sync).
             self.s_fwd_stats(l_data)
+            ops.apply_deferred_bn()                                      # the u pass's running-statistics update (:312)
             # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
             if not batched:
                 fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]

@@ -124,7 +124,8 @@ class ArcoStep3D:
                 pred_all, _, fm_s = self.s_train_lu(lu)                  # :283-284
             pred_l, pred_u = pred_all[:nb_l], pred_all[nb_l:]
         else:
-            pred_u, _, u_fm = self.s_train_u(u_aug)                      # :284
+            with ops.bn_defer(0):                                        # running statistics: l first (:283), then u
+                pred_u, _, u_fm = self.s_train_u(u_aug)                  # :284
         with torch.no_grad():
             if batched:
                 with ops.bn_groups(2):
@@ -144,6 +145,7 @@ class ArcoStep3D:
         dense = getattr(a, "dense_head", 0)
         if not batched:
             pred_l, _, l_fm = self.s_train_l(l_data)                     # :283
+            ops.apply_deferred_bn()
             fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
             fm_s = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]
         kfe, qfe = self.k_feature_extractor, self.q_feature_extractor

@@ -103,7 +103,16 @@ int arco_transpose2d(const float* x, long ldx, int rows, int cols, float* y, lon
  *      unetWithArgs.py:36-44; vnetWithArgs.py:16-25)                                                      */
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
                      float* mean, float* istd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                     int groups /* mean/istd rows: [groups][C] */, void* stream);
+                     int groups /* mean/istd rows: [groups][C] */,
+                     int defer_from, float* deferred /* nullable: groups >= defer_from postpone their running-statistics
+                     update into deferred[groups - defer_from][2][C] (+1 flag float), see arco_bn_apply_deferred */,
+                     void* stream);
+/*      postponed momentum updates of many BN layers, one launch: desc = device array of n_layers records
+ *      {float* running_mean, running_var, deferred; int C, n; float momentum; int pad} (arco_bn_defer_desc_bytes() each).
+ *      The reference runs model(l), model(cj2_l), model(u) (train_arco_2d.py:310-312); the build runs (l, u) as one
+ *      grouped pass and cj2_l afterwards - the running statistics must still receive the updates in the reference's order */
+long arco_bn_defer_desc_bytes(void);
+int arco_bn_apply_deferred(const void* desc, int n_layers, void* stream);
 int arco_chan_stats_blocks(long M);
 int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, int groups, void* stream);
 int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,

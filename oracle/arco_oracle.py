@@ -268,14 +268,17 @@ def bn_train(x, w, b, rm=None, rv=None, momentum=0.1, eps=1e-5):
     return F.batch_norm(x, rm, rv, w, b, True, momentum, eps)
 
 
-def conv_block_2d(x, sd, pre, slope=0.01, train=True):
+def conv_block_2d(x, sd, pre, slope=0.01, train=True, track=False):
     """networks/unetWithArgs.py:31-47 with Dropout disabled (p forced to 0).  train=False: net.eval()
-    (BatchNorm on the running statistics, test_2D.py:78)."""
+    (BatchNorm on the running statistics, test_2D.py:78).  track=True: train mode that also makes the momentum
+    update of sd's running statistics in place, as nn.BatchNorm2d does."""
     for k in ("0", "4"):
         x = F.conv2d(x, sd[f"{pre}.conv_conv.{k}.weight"], sd[f"{pre}.conv_conv.{k}.bias"], padding=1)
         bnk = str(int(k) + 1)
         if train:
-            x = bn_train(x, sd[f"{pre}.conv_conv.{bnk}.weight"], sd[f"{pre}.conv_conv.{bnk}.bias"])
+            rm = sd[f"{pre}.conv_conv.{bnk}.running_mean"] if track else None
+            rv = sd[f"{pre}.conv_conv.{bnk}.running_var"] if track else None
+            x = bn_train(x, sd[f"{pre}.conv_conv.{bnk}.weight"], sd[f"{pre}.conv_conv.{bnk}.bias"], rm, rv)
         else:
             x = F.batch_norm(x, sd[f"{pre}.conv_conv.{bnk}.running_mean"], sd[f"{pre}.conv_conv.{bnk}.running_var"],
                              sd[f"{pre}.conv_conv.{bnk}.weight"], sd[f"{pre}.conv_conv.{bnk}.bias"], False, 0.1, 1e-5)
@@ -283,21 +286,21 @@ def conv_block_2d(x, sd, pre, slope=0.01, train=True):
     return x
 
 
-def unet_forward(x, sd, train=True):
+def unet_forward(x, sd, train=True, track=False):
     """networks/unetWithArgs.py:109-116 (Encoder), :142-158 (Decoder), :345-348 (UNet);
     dropout off.  NB the Decoder constructs UpBlock WITHOUT passing `bilinear`
     (:130-137), so UpBlock's default bilinear=True applies (:66): the up-path is
     conv1x1 (bias) -> x2 bilinear upsample align_corners=True (:72-75,80-83), not
     ConvTranspose2d, whatever params['bilinear'] (:317) says."""
-    feats = [conv_block_2d(x, sd, "encoder.in_conv", train=train)]
+    feats = [conv_block_2d(x, sd, "encoder.in_conv", train=train, track=track)]
     for i in range(1, 5):
-        feats.append(conv_block_2d(F.max_pool2d(feats[-1], 2), sd, f"encoder.down{i}.maxpool_conv.1", train=train))
+        feats.append(conv_block_2d(F.max_pool2d(feats[-1], 2), sd, f"encoder.down{i}.maxpool_conv.1", train=train, track=track))
     x = feats[4]
     fmap = [x]
     for i, skip in zip(range(1, 5), (feats[3], feats[2], feats[1], feats[0])):
         up = F.conv2d(x, sd[f"decoder.up{i}.conv1x1.weight"], sd[f"decoder.up{i}.conv1x1.bias"])
         up = F.interpolate(up, scale_factor=2, mode='bilinear', align_corners=True)
-        x = conv_block_2d(torch.cat([skip, up], 1), sd, f"decoder.up{i}.conv", train=train)
+        x = conv_block_2d(torch.cat([skip, up], 1), sd, f"decoder.up{i}.conv", train=train, track=track)
         fmap.append(x)
     out = F.conv2d(x, sd["decoder.out_conv.weight"], sd["decoder.out_conv.bias"], padding=1)
     return out, feats[4], fmap

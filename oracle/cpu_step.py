@@ -24,20 +24,22 @@ def make_state(unet_sd, fe_sd, qrep_w):
 def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20.0, k1=0.01, lr=0.01,
          delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7, apply_aug='none'):
     with torch.no_grad():
-        pred_u0, _, _ = orc.unet_forward(u_data, st["teacher"])
+        pred_u0, _, _ = orc.unet_forward(u_data, st["teacher"], track=True)
         pseudo_logits, pseudo_labels = torch.max(torch.softmax(pred_u0, 1), 1)
         if apply_aug in ('cutout', 'cutmix', 'classmix'):      # train_arco_2d.py:296-297 (generate_unsup_data)
             mixed = orc.generate_unsup_data(u_data.numpy(), pseudo_labels.numpy().copy(), pseudo_logits.numpy(), apply_aug)
             u_data, pseudo_labels, pseudo_logits = (torch.from_numpy(v) for v in mixed)
         for k in st["k_fe"]:
             st["k_fe"][k] = st["k_fe"][k] * 0.99 + st["q_fe"][k].detach() * 0.01
-    pred_l, _, l_fm = orc.unet_forward(l_data, st["student"])
+    # train-mode forwards in the reference's order (train_arco_2d.py:310-315); track=True: the BatchNorm running
+    # statistics receive their momentum updates in that order (they do not commute)
+    pred_l, _, l_fm = orc.unet_forward(l_data, st["student"], track=True)
     with torch.no_grad():
-        orc.unet_forward(l_data, st["student"])
-    pred_u, _, u_fm = orc.unet_forward(u_data, st["student"])
+        orc.unet_forward(l_data, st["student"], track=True)          # images_cj2_l (:311): running statistics only
+    pred_u, _, u_fm = orc.unet_forward(u_data, st["student"], track=True)
     with torch.no_grad():
-        pred_l_t, _, l_fm_t = orc.unet_forward(l_data, st["teacher"])
-        pred_u_t, _, u_fm_t = orc.unet_forward(u_data, st["teacher"])
+        pred_l_t, _, l_fm_t = orc.unet_forward(l_data, st["teacher"], track=True)
+        pred_u_t, _, u_fm_t = orc.unet_forward(u_data, st["teacher"], track=True)
         rep_t = orc.feature_extractor_forward([torch.cat((a, b)) for a, b in zip(l_fm_t, u_fm_t)], st["k_fe"])
     feat = orc.feature_extractor_forward([torch.cat((a, b)) for a, b in zip(l_fm, u_fm)], st["q_fe"])
     rep = F.conv2d(F.conv2d(feat, st["q_rep"][0]), st["q_rep"][1])
@@ -66,7 +68,7 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
             images_tps = orc.grid_sample(torch.cat((l_data, u_data)), grid)
             mask_tps = orc.grid_sample(mask, grid)
             org = orc.grid_sample(torch.cat((pred_l.detach(), pred_u.detach())), grid)
-        pred_tps = orc.unet_forward(images_tps, st["student"])[0]
+        pred_tps = orc.unet_forward(images_tps, st["student"], track=True)[0]
         eqv = orc.eqv_loss(pred_tps, org, mask_tps)
         loss = loss + k2 * eqv
     leaves = [v for v in st["student"].values() if v.requires_grad] + list(st["q_rep"]) + list(st["q_fe"].values())
@@ -81,10 +83,10 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
             if v.requires_grad:
                 st["teacher"][k] = st["teacher"][k] * 0.99 + v.detach() * 0.01
     st["it"] += 1
-    st["last_terms"] = dict(ce=float(ce), dice=float(dice), unsup=float(unsup), reco=float(reco))
+    st["last_terms"] = dict(ce=float(ce.detach()), dice=float(dice.detach()), unsup=float(unsup.detach()), reco=float(reco.detach()))
     if eqv is not None:
-        st["last_terms"]["eqv"] = float(eqv)
-    return float(loss), float(reco)
+        st["last_terms"]["eqv"] = float(eqv.detach())
+    return float(loss.detach()), float(reco.detach())
 
 
 def timed_sample(b=2, patch=(256, 256), n_cls=4, seed=1337, qsize=4096):

@@ -85,6 +85,13 @@ def test_two_steps_vs_cpu_oracle(variant):
     for k, v in st_o["teacher"].items():
         if v.is_floating_point() and "running" not in k:
             assert float((sd_t[k].cpu() - v).abs().max()) / max(1e-6, float(v.abs().max())) < 2e-3, k
+    # BatchNorm running statistics: the momentum updates of the train-mode forwards must land in the reference's order
+    # (student: l, cj2_l, u [, tps]; teacher: u, l, u_aug) although the trainer runs the forwards in another order
+    for name, sd_ref, sd_got in (("student", st_o["student"], sd_g), ("teacher", st_o["teacher"], sd_t)):
+        for k, v in sd_ref.items():
+            if "running" in k:
+                np.testing.assert_allclose(sd_got[k].cpu().numpy(), v.numpy(), rtol=3e-4, atol=1e-4 * float(v.abs().max()),
+                                           err_msg=f"{name} {k}")
 
 
 def test_cityscapes_shaped_step_runs():
