@@ -154,3 +154,86 @@ class _EqvLossFn(torch.autograd.Function):
 def eqv_loss(pred_tps, pred_tps_org, mask_tps):
     """train_arco_2d.py:419-423: mean over images of the masked mean of KL(softmax(pred_tps_org) || softmax(pred_tps))."""
     return _EqvLossFn.apply(pred_tps, pred_tps_org, mask_tps)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# revisiting loss (SURVEY §8f row 1; train_arco_2d.py:108-136,156-159,334,398-400).  It has NO gradient path (the
+# distances that enter the loss come from the teacher's representation), so it only changes the logged loss value; it
+# needs the DENSE student and teacher representations of the unlabeled images, which the default row-sparse step
+# never materialises - the trainers compute it only under --revisit 1 (which switches the dense head / teacher on).
+# ---------------------------------------------------------------------------------------------------------------
+class RevisitPool:
+    """random_pool of train_arco_2d.py:156-159: K unit vectors of length D*prod(spatial), drawn with torch.randn on the
+    CPU generator in the reference's [K, D, *spatial] order, kept on the GPU in the channels-last order of the
+    representations ([K, prod(spatial), D] flattened; a dot product does not care as long as both sides agree) with the
+    row count padded to a multiple of 16 for the GEMM kernel (extra rows are zero)."""
+
+    def __init__(self, K, D, spatial, device, values=None):
+        self.K, self.D, self.spatial = int(K), int(D), tuple(int(v) for v in spatial)
+        n = self.D
+        for v in self.spatial:
+            n *= v
+        self.n = n
+        if values is None:
+            g = torch.randn(self.K, self.D, *self.spatial)                       # :156 (same draw from the CPU generator)
+            g = torch.nn.functional.normalize(g.view(self.K, -1), dim=1)         # :157-158
+            nd = len(self.spatial)
+            values = g.view(self.K, self.D, *self.spatial).permute(0, *range(2, 2 + nd), 1).reshape(self.K, -1)
+        kpad = (self.K + 15) // 16 * 16
+        self.rows = torch.zeros((kpad, n), dtype=torch.float32, device=device)
+        self.rows[:self.K].copy_(values)
+        self.ptr = torch.zeros(1, dtype=torch.long)                              # random_pool_ptr (:159)
+
+    def channels_first(self):
+        """[K, D*prod(spatial)] in the reference's flattening order (for checks)."""
+        nd = len(self.spatial)
+        return self.rows[:self.K].view(self.K, *self.spatial, self.D).permute(0, 1 + nd, *range(1, 1 + nd)).reshape(self.K, -1)
+
+
+def _flat_rows(rep):
+    """[b, n] view of a channels-last dense representation [b, D, *spatial] (rows of one image are contiguous)."""
+    r, ld = rows_view(rep.detach())
+    b = int(rep.shape[0])
+    if ld != int(rep.shape[1]) or not r.is_contiguous():
+        raise RuntimeError("arco_amd: the revisiting loss needs dense, unpadded channels-last representations")
+    return r.reshape(b, -1)
+
+
+@torch.no_grad()
+def _pool_dots(pool, flat):
+    """dots[b, K] = flat[b, :] . pool.rows[k, :] - one split-K GEMM launch (a [b x K] output over a 10^7-long K)."""
+    b, n = int(flat.shape[0]), int(flat.shape[1])
+    assert n == pool.n and n % 16 == 0, (n, pool.n)
+    kpad = int(pool.rows.shape[0])
+    splits = max(1, min(2048, n // 8192))
+    out = torch.empty((b, kpad), dtype=torch.float32, device=flat.device)
+    ws = torch.empty((splits, b, kpad), dtype=torch.float32, device=flat.device)
+    L.call("arco_gemm_splitk", L.ptr(flat), n, n, L.ptr(pool.rows), pool.K, L.ptr(out), kpad, b, splits, L.ptr(ws))
+    return out[:, :pool.K]
+
+
+@torch.no_grad()
+def get_revisiting_loss(random_pool, rep_u, rep_u_teacher, topk=5):
+    """train_arco_2d.py:126-136: normalise the flattened student / teacher representations of the unlabeled images,
+    dist = 2 - 2 <rep, pool_k>; the student picks its topk nearest pool entries, the loss is the teacher's mean distance
+    to those.  Returns a 0-d tensor without a graph (the reference's value has no gradient path either)."""
+    L.require_gpu(rep_u, rep_u_teacher)
+    fu, ft = _flat_rows(rep_u), _flat_rows(rep_u_teacher)
+    eps = 1e-12
+    dist_t = 2 - 2 * _pool_dots(random_pool, fu) / torch.linalg.vector_norm(fu, dim=1).clamp_min(eps)[:, None]
+    dist_q = 2 - 2 * _pool_dots(random_pool, ft) / torch.linalg.vector_norm(ft, dim=1).clamp_min(eps)[:, None]
+    _, nn_index = dist_t.topk(topk, dim=1, largest=False)
+    nn_dist_q = torch.gather(dist_q, 1, nn_index)
+    return (nn_dist_q.sum(dim=1) / topk).mean()
+
+
+@torch.no_grad()
+def revisit_enqueue(rep_u_teacher, random_pool):
+    """_dequeue_and_enqueue of train_arco_2d.py:108-119 with the normalised teacher rows (:398-400): overwrite pool rows
+    [ptr, ptr + b), ptr = (ptr + b) % K; like the reference it requires K % b == 0."""
+    ft = _flat_rows(rep_u_teacher)
+    b = int(ft.shape[0])
+    ptr = int(random_pool.ptr)
+    assert random_pool.K % b == 0
+    torch.div(ft, torch.linalg.vector_norm(ft, dim=1).clamp_min(1e-12)[:, None], out=random_pool.rows[ptr:ptr + b])
+    random_pool.ptr[0] = (ptr + b) % random_pool.K

@@ -9,9 +9,10 @@ student U-Net with the reference's key names (:462-470, :509-511).
 The step itself (train_arco_2d.py:284-435) is `ArcoStep2D.step`: hot path (SURVEY §8a rows
 N1-N5, T1, L1-L6, O1) on hand-written HIP kernels.  One process per GPU; with WORLD_SIZE>1
 gradients are all-reduced and new negative keys all-gathered over RCCL (arco_amd/dist.py).
-Not built here (SURVEY §8 "next"/out of scope): dataset readers, CPU augmentation
-(identity on the synthetic path), the TPS equivariance and revisiting loss terms (the supervised CE+Dice
-and the unsupervised CE terms ARE part of the step).
+Every loss term of the reference step is here: contrastive (k1), unsupervised CE (k3), CE + Dice, the TPS
+equivariance term (k2) and - opt-in, --revisit 1, it has no gradient path - the revisiting loss (k4); so is the mixing
+strategy of --apply_aug (arco_amd/augment.py).  Not built (SURVEY §8 out of scope / "next"): dataset readers and
+the PIL colour jitter / blur of batch_transform (identity on the synthetic path).
 """
 import argparse
 import logging
@@ -94,6 +95,11 @@ def build_parser():
     p.add_argument('--dense_teacher', type=int, default=0, help='1: materialise the dense teacher representation')
     p.add_argument('--head_levels', type=int, default=2, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
+    p.add_argument('--revisit', type=int, default=0,
+                   help='1: also compute k4*loss_q, the revisiting loss (train_arco_2d.py:126-136,334,398-400). It has no '
+                        'gradient path (it only changes the logged loss) and needs the dense student and teacher '
+                        'representations, so it switches --dense_head and --dense_teacher on; --K must be a multiple of '
+                        '--batch_size, as in the reference')
     return p
 
 
@@ -122,6 +128,12 @@ class ArcoStep2D:
         self.args = args
         self.dev = torch.device(device)
         C = args.num_classes
+        self.random_pool = None
+        if getattr(args, "revisit", 0):
+            # random_pool (:156-159) is drawn before the models are created, like the reference (same CPU-generator order)
+            args.dense_head = args.dense_teacher = 1
+            assert args.K % args.batch_size == 0, "--K must be a multiple of --batch_size (train_arco_2d.py:113)"
+            self.random_pool = glue.RevisitPool(args.K, 256 + 128 + 64 + 32 + 16, args.patch_size, self.dev)
         # memory banks (train_arco_2d.py:147-154); device resident from the first enqueue on
         self.memobank, self.queue_ptrlis, self.queue_size = [], [], []
         for i in range(C):
@@ -285,7 +297,8 @@ class ArcoStep2D:
                             lazy_teacher=lazy_t, defer_anchor_pix=True)
         ev2[1].record()
         # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340); the equivariance
-        # term follows the sampler draw below.  Not built: k4*loss_q (revisiting loss; no gradient path to any parameter).
+        # term follows the sampler draw below.  k4*loss_q (revisiting loss; no gradient path to any parameter) only with
+        # --revisit 1.
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)
         unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
         C_.contrast_draw(plan, a.func)
@@ -328,9 +341,16 @@ class ArcoStep2D:
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)   # :394-398 (temp default)
         ev3[1].record()
         self.loss_events.append((ev, ev2, ev3))      # masks | lists, prototypes, keys, banks | anchors, head, InfoNCE
-        loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426 (k4*loss_q: no gradient path)
+        loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
         if loss_eqv is not None:
             loss = loss + a.k2 * loss_eqv
+        loss_q = None
+        if self.random_pool is not None:
+            # :334 (computed before the pool is updated) and :398-400; a constant w.r.t. every parameter
+            nb_l = int(l_data.shape[0])
+            loss_q = glue.get_revisiting_loss(self.random_pool, rep_all[nb_l:], rep_all_teacher[nb_l:], topk=a.topk)
+            glue.revisit_enqueue(rep_all_teacher[nb_l:], self.random_pool)
+            loss = loss + a.k4 * loss_q
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()
         adist.allreduce_grads(self.optimizer)
@@ -346,6 +366,8 @@ class ArcoStep2D:
                                reco=reco_loss.detach())
         if loss_eqv is not None:
             self.last_terms["eqv"] = loss_eqv.detach()
+        if loss_q is not None:
+            self.last_terms["loss_q"] = loss_q
         return loss.detach(), reco_loss.detach()
 
 

@@ -51,6 +51,11 @@ class ArcoStep3D:
             self.queue_ptrlis.append(torch.zeros(1, dtype=torch.long))
         if args.queue_size <= 0:
             self.queue_size[0] = 50000
+        self.random_pool = None
+        if getattr(args, "revisit", 0):                                   # :153-156 (drawn right after the banks)
+            args.dense_head = 1
+            assert args.K % args.batch_size == 0, "--K must be a multiple of --batch_size (train_arco_3d.py:110)"
+            self.random_pool = glue.RevisitPool(args.K, REP_DIM_3D, args.patch_size, self.dev)
         self.isd = ISD_3d(K=args.K, m=0.99, Ts=0.01, Tt=0.1, num_classes=C,
                           latent_pooling_size=args.latent_pooling_size, latent_feature_size=args.latent_feature_size,
                           output_pooling_size=args.output_pooling_size, train_encoder=True, train_decoder=True).to(self.dev)
@@ -196,7 +201,14 @@ class ArcoStep3D:
         if self.iter_num == 0 and loss_eqv is not None:
             loss = unsup_loss + (loss_dice + loss_ce) + loss_eqv         # :393 (iter_num / max_iterations == 0)
         else:
-            loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q: no gradient path, not built)
+            loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q only with --revisit 1)
+        loss_q = None
+        if self.random_pool is not None:      # :304 (before the pool update) and :365; constant w.r.t. every parameter
+            nb_l = int(l_data.shape[0])
+            loss_q = glue.get_revisiting_loss(self.random_pool, rep_all[nb_l:], rep_all_teacher[nb_l:], topk=a.topk)
+            glue.revisit_enqueue(rep_all_teacher[nb_l:], self.random_pool)
+            if not (self.iter_num == 0 and loss_eqv is not None):
+                loss = loss + a.k4 * loss_q
         self.optimizer.zero_grad()
         loss.backward()
         adist.allreduce_grads(self.optimizer)
@@ -210,6 +222,8 @@ class ArcoStep3D:
                                reco=reco_loss.detach())
         if loss_eqv is not None:
             self.last_terms["eqv"] = loss_eqv.detach()
+        if loss_q is not None:
+            self.last_terms["loss_q"] = loss_q
         return loss.detach(), reco_loss.detach()
 
 

@@ -523,6 +523,30 @@ def surface_metrics(pred, gt):
 
 
 # --------------------------------------------------------------------------
+# R  revisiting loss: train_arco_2d.py:108-136
+# --------------------------------------------------------------------------
+
+
+def get_revisiting_loss(random_pool, rep_u, rep_u_teacher, topk=5):
+    """train_arco_2d.py:126-136.  random_pool [K, n] unit rows; rep_* [b, D, *spatial]."""
+    ru = F.normalize(rep_u.reshape(rep_u.shape[0], -1), dim=-1)
+    rt = F.normalize(rep_u_teacher.reshape(rep_u_teacher.shape[0], -1), dim=-1)
+    dist_t = 2 - 2 * ru @ random_pool.t()
+    dist_q = 2 - 2 * rt @ random_pool.t()
+    _, nn_index = dist_t.topk(topk, dim=1, largest=False)
+    return (torch.gather(dist_q, 1, nn_index).sum(dim=1) / topk).mean()
+
+
+def pool_enqueue(keys, queue, queue_ptr, K):
+    """_dequeue_and_enqueue (train_arco_2d.py:108-119): queue[ptr:ptr+b] = keys; ptr = (ptr + b) % K (K % b == 0)."""
+    b = keys.shape[0]
+    ptr = int(queue_ptr)
+    assert K % b == 0
+    queue[ptr:ptr + b] = keys
+    queue_ptr[0] = (ptr + b) % K
+
+
+# --------------------------------------------------------------------------
 # A  mixing strategies (SURVEY §8f row 2): augment.py:230-252,284-313; augment_3d.py:182-206,228-257
 # --------------------------------------------------------------------------
 

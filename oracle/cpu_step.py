@@ -22,7 +22,7 @@ def make_state(unet_sd, fe_sd, qrep_w):
 
 
 def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20.0, k1=0.01, lr=0.01,
-         delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7, apply_aug='none'):
+         delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7, apply_aug='none', pool=None, k4=1.0, topk=5):
     with torch.no_grad():
         pred_u0, _, _ = orc.unet_forward(u_data, st["teacher"], track=True)
         pseudo_logits, pseudo_labels = torch.max(torch.softmax(pred_u0, 1), 1)
@@ -53,6 +53,14 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
     ce, dice = orc.supervised_loss(pred_l, l_label, n_cls)
     unsup = orc.compute_unsupervised_loss(pred_u, pseudo_labels, pseudo_logits, 0.97)
     loss = k1 * reco + unsup + (ce + dice)
+    loss_q = None
+    if pool is not None:         # revisiting loss (:334) and pool update (:398-400); pool = dict(rows [K, n], ptr)
+        nb = int(l_data.shape[0])
+        with torch.no_grad():
+            loss_q = orc.get_revisiting_loss(pool["rows"], rep[nb:].detach(), rep_t[nb:], topk)
+            orc.pool_enqueue(F.normalize(rep_t[nb:].reshape(rep_t.shape[0] - nb, -1), dim=-1), pool["rows"], pool["ptr"],
+                             int(pool["rows"].shape[0]))
+        loss = loss + k4 * loss_q
     eqv = None
     if k2 != 0:      # train_arco_2d.py:404-423; the warp is drawn after the samplers (same torch-generator order)
         H, W = int(l_data.shape[2]), int(l_data.shape[3])
@@ -86,6 +94,8 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
     st["last_terms"] = dict(ce=float(ce.detach()), dice=float(dice.detach()), unsup=float(unsup.detach()), reco=float(reco.detach()))
     if eqv is not None:
         st["last_terms"]["eqv"] = float(eqv.detach())
+    if loss_q is not None:
+        st["last_terms"]["loss_q"] = float(loss_q)
     return float(loss.detach()), float(reco.detach())
 
 

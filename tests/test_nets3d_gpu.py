@@ -285,3 +285,38 @@ def test_bn_groups_3d_equal_separate_passes():
             torch.testing.assert_close(v, state_sep[k], rtol=1e-3, atol=1e-5, msg=k)
         else:
             assert int(v) == int(state_sep[k]), k
+
+
+def test_revisiting_loss_3d_matches_oracle():
+    """--revisit 1 on the 3-D step: loss_q and the pool update vs the oracle's restatement of get_revisiting_loss /
+    _dequeue_and_enqueue (train_arco_3d.py:105-133,304,365) fed the step's own dense representations."""
+    import random
+    import arco_oracle as orc
+    from arco_amd import glue, train_arco_3d as T3
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    args = T3.build_parser().parse_args(["--batch_size", "1", "--queue_size", "256", "--synthetic", "1", "--num_classes", "2",
+                                         "--num_queries", "64", "--num_negatives", "32", "--revisit", "1", "--K", "3",
+                                         "--topk", "2", "--eqv_pass", "0"])
+    args.patch_size = [32, 32, 32]
+    st = T3.ArcoStep3D(args, "cuda:0")
+    assert st.random_pool is not None and args.dense_head == 1
+    seen = {}
+    real = glue.get_revisiting_loss
+
+    def spy(pool, ru, rt, topk=5):
+        seen["pool"], seen["ru"], seen["rt"] = pool.channels_first().cpu().clone(), ru.detach().cpu().clone(), rt.detach().cpu().clone()
+        return real(pool, ru, rt, topk=topk)
+    glue.get_revisiting_loss = spy
+    try:
+        for i in range(3):
+            l_img, l_lab = T3.synthetic_volume_batch(1, args.patch_size, 2, 10 + i, "cuda:0")
+            u_img, _ = T3.synthetic_volume_batch(1, args.patch_size, 2, 20 + i, "cuda:0")
+            st.step(l_img, l_lab, u_img)
+            exp = orc.get_revisiting_loss(seen["pool"], seen["ru"], seen["rt"], topk=2)
+            np.testing.assert_allclose(float(st.last_terms["loss_q"]), float(exp), rtol=2e-5)
+            pool_o, ptr_o = seen["pool"].clone(), torch.tensor([i % 3])
+            orc.pool_enqueue(torch.nn.functional.normalize(seen["rt"].reshape(1, -1), dim=-1), pool_o, ptr_o, 3)
+            np.testing.assert_allclose(st.random_pool.channels_first().cpu().numpy(), pool_o.numpy(), rtol=1e-5, atol=1e-9)
+            assert int(st.random_pool.ptr) == int(ptr_o) == (i + 1) % 3
+    finally:
+        glue.get_revisiting_loss = real

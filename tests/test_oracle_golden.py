@@ -188,6 +188,16 @@ def test_trainer_glue(golden):
         p, buf = orc.sgd_nesterov_step(p, torch.from_numpy(g["sgd_g"][it]), buf, lr)
         np.testing.assert_allclose(p.numpy(), g[f"sgd_p{it}"], rtol=1e-6, atol=1e-7)
         lr = orc.poly_lr(0.01, it, 30000)
+    # revisiting loss + pool enqueue (train_arco_2d.py:108-136): the generator drew these inputs right after logits_u
+    K, feat = 6, 3 * 8 * 8
+    pool = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((K, feat)).astype(np.float32)), dim=1)
+    ru = torch.from_numpy(rs.standard_normal((2, 3, 8, 8)).astype(np.float32))
+    rt = torch.from_numpy(rs.standard_normal((2, 3, 8, 8)).astype(np.float32))
+    np.testing.assert_allclose(orc.get_revisiting_loss(pool, ru, rt, topk=3).item(), float(g["revisit_loss"]), rtol=1e-6)
+    ptr, pool2 = torch.zeros(1, dtype=torch.long), pool.clone()
+    orc.pool_enqueue(torch.nn.functional.normalize(rt.view(2, -1), dim=-1), pool2, ptr, K)
+    np.testing.assert_array_equal(pool2.numpy(), g["pool_after"])
+    assert int(ptr) == int(g["pool_ptr"]) == 2
 
 
 def test_dice_jaccard_conventions():

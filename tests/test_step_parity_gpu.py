@@ -22,7 +22,8 @@ def _drop_off(m):
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0, apply_aug="cutmix"),
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutmix"),
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutout"),
-                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0, apply_aug="classmix")])
+                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0, apply_aug="classmix"),
+                                     dict(revisit=1, K=4, topk=2, k2=0.0, apply_aug="cutmix")])
 def test_two_steps_vs_cpu_oracle(variant):
     from arco_amd import train_arco_2d as T
     b, patch, C, Q, Nn, qs = 2, (64, 64), 4, 64, 32, 300
@@ -46,6 +47,12 @@ def test_two_steps_vs_cpu_oracle(variant):
         _drop_off(m)
     st_o = cpu_step.make_state(unet_sd, fe_sd, qrep_w)
     bank_o, ptr_o, qsz = fx.fresh_bank(C, 496, qs, 'zeros')
+    pool_o = None
+    if variant.get("revisit"):              # the oracle starts from the trainer's pool (reference flattening order)
+        assert st_g.random_pool is not None and args.dense_head == 1 and args.dense_teacher == 1
+        rows0 = st_g.random_pool.channels_first().cpu().clone()
+        np.testing.assert_allclose(rows0.norm(dim=1).numpy(), 1.0, rtol=1e-5)
+        pool_o = dict(rows=rows0, ptr=torch.zeros(1, dtype=torch.long))
     rs = np.random.RandomState(3)
     for it in range(2):
         l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
@@ -53,10 +60,14 @@ def test_two_steps_vs_cpu_oracle(variant):
         lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
         cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn, k2=variant["k2"],
-                      apply_aug=variant["apply_aug"])
+                      apply_aug=variant["apply_aug"], pool=pool_o, topk=variant.get("topk", 5))
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
         st_g.step(l.cuda(), lab.cuda(), u.cuda())
         to, tg = st_o["last_terms"], st_g.last_terms
+        if pool_o is not None:
+            np.testing.assert_allclose(float(tg["loss_q"]), to["loss_q"], rtol=1e-3, err_msg=f"step {it} loss_q")
+            np.testing.assert_allclose(st_g.random_pool.channels_first().cpu().numpy(), pool_o["rows"].numpy(), rtol=2e-3, atol=2e-6)
+            assert int(st_g.random_pool.ptr) == int(pool_o["ptr"]) == (b * (it + 1)) % 4
         for k in ("ce", "dice", "unsup", "reco") + (("eqv",) if variant["k2"] else ()):
             np.testing.assert_allclose(float(tg[k]), to[k], rtol=2e-3, atol=1e-5, err_msg=f"step {it} {k}")
         for bo, bg in zip(bank_o, st_g.memobank):
