@@ -625,6 +625,89 @@ __global__ __launch_bounds__(256) void conv3x3_image_kernel(IgemmArgs a) {
     }
   }
 }
+// ---------------------------------------------------------------------------
+// 3x3x3 convolution of a ONE-channel volume (the V-Net's first layer, 1 -> 16): the generic kernel pads Cin to 16
+// and spends the MFMA time of a 16 -> 16 layer on 15/16 zeros.  Here the 27 taps ARE the reduction dimension
+// (K = 27 -> 28): D[cout][voxel] = W[cout][tap] * im2col[tap][voxel], the im2col operand read straight from a
+// three-plane halo tile in LDS (one float per lane and MFMA), the weights live in 7 registers per lane.
+// Persistent workgroups over 16 x 16 tiles of a plane; a lane ends up with 4 consecutive output channels of one
+// voxel (16-byte stores); per-channel (sum, sum of squares) partials for the BatchNorm that follows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3d_image_kernel(IgemmArgs a) {
+  constexpr int TH = 16, TW = 16, HW_ = TW + 2, NP = (TH + 2) * HW_;
+  __shared__ float Xs[3 * NP];           // [depth tap][halo position]
+  __shared__ float red[2][4][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
+  float wk[7]; int off[7];
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int t = 4 * s + g;                                     // tap = dz*9 + dy*3 + dx
+    wk[s] = (t < 27 && li < a.N) ? a.Wp[((long)t * a.Npad + li) * a.Kpad] : 0.f;
+    off[s] = t < 27 ? (t / 9) * NP + ((t % 9) / 3) * HW_ + t % 3 : 0;
+  }
+  f32x4 bias4 = {0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) if (a.bias && 4 * g + e < a.N) bias4[e] = a.bias[4 * g + e];
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const long n_tiles = (long)a.NB * tiles_y * tiles_x;
+  f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+  const int n_grp = a.stat_groups > 1 ? a.stat_groups : 1, bpg = gridDim.x / n_grp;      // one BN group per workgroup
+  const long tpg = n_tiles / n_grp, t_end = (blockIdx.x / bpg + 1) * tpg;
+  for (long t = (blockIdx.x / bpg) * tpg + blockIdx.x % bpg; t < t_end; t += bpg) {
+    const int tx = t % tiles_x; const long r = t / tiles_x; const int ty = r % tiles_y; const int pl = r / tiles_y;
+    const int xd = pl % a.D3;                                    // plane index inside its volume
+    __syncthreads();
+    for (int u = tid; u < 3 * NP; u += 256) {
+      const int k = u / NP, hp = u - k * NP, hy = hp / HW_, hx = hp - hy * HW_;
+      const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1, pz = xd + k - 1;
+      Xs[u] = (pz >= 0 && pz < a.D3 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                  ? a.A[(((long)(pl + k - 1) * a.H + gy) * a.W + gx) * a.lda] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {                             // wave w: tile rows 4w .. 4w+3, lane li = column
+      const int py = 4 * w + rg;
+      const float* xb = Xs + py * HW_ + li;
+      f32x4 acc = bias4;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[s], xb[off[s]], acc, 0, 0, 0);
+      const int gy = ty * TH + py, gx = tx * TW + li;
+      if (gy < a.H && gx < a.W && 4 * g < a.N) {
+        const long pix = ((long)pl * a.H + gy) * a.W + gx;
+        *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + 4 * g) = acc;
+        s1 += acc; s2 += acc * acc;
+      }
+    }
+  }
+  if (a.stat_sum) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v1 = s1[e], v2 = s2[e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+      if (li == 0) { red[0][w][4 * g + e] = v1; red[1][w][4 * g + e] = v2; }
+    }
+    __syncthreads();
+    if (tid < 16 && tid < a.N) {
+      a.stat_sum[(long)tid * a.n_mblocks + blockIdx.x] = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+      a.stat_sq[(long)tid * a.n_mblocks + blockIdx.x] = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+    }
+  }
+}
+static bool image_conv3d_eligible(const IgemmArgs& a) {
+  return a.K == 1 && a.Npad == 16 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && a.R == nullptr && a.D3 >= 1;
+}
+static int launch_image_conv3d(const IgemmArgs& a, hipStream_t st, int* q) {
+  const long n_tiles = (long)a.NB * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+  const int n_grp = a.stat_groups > 1 ? a.stat_groups : 1;
+  if (a.NB % n_grp != 0) return ARCO_ERR_ARG;
+  long bpg = 2048 / n_grp; if (bpg > n_tiles / n_grp) bpg = n_tiles / n_grp; if (bpg < 1) bpg = 1;
+  const long blocks = bpg * n_grp;
+  if (q) { q[0] = (int)blocks; q[1] = 27 * 1000000 + 800000 + 1000 + 16; q[2] = 10; return ARCO_OK; }
+  IgemmArgs b = a; b.n_mblocks = (int)blocks; b.n_nblocks = 1;
+  hipLaunchKernelGGL(conv3d_image_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+  return arco_launch_status();
+}
 static bool image_conv_eligible(const IgemmArgs& a) {
   return a.K <= 4 && a.Npad == 16 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && a.R == nullptr;
 }
@@ -649,6 +732,7 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
     if ((a.Npad + 223) / 224 * 224 < (a.Npad + 127) / 128 * 128) return launch_igemm<1, 64, 224, 2, 2, 16, true>(a, st, nmb);
     return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
   }
+  if (taps == 27 && image_conv3d_eligible(a)) return launch_image_conv3d(a, st, nmb);   // one-channel volume (first layer)
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
   if (taps == 9 && image_conv_eligible(a)) return launch_image_conv(a, st, nmb);
   if (taps == 9) return halo_eligible(a) ? dispatch_halo(a, st, nmb) : dispatch_spatial<1>(a, st, nmb);
@@ -951,6 +1035,58 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
   }
 }
 
+// Weight gradient of the one-channel 3x3x3 layer: dW[co][tap] = sum_vox dZ[vox][co] * X[vox + tap].
+// D[tap][co] = im2col^T [tap][vox] * dZ [vox][co]: M = 27 taps (two 16-row MFMA tiles), N = 16, K = voxels; the im2col
+// operand comes from a three-plane halo tile in LDS, dZ is read once straight from HBM (64 B per voxel, coalesced).
+// Persistent over 16 x 16 tiles; the four waves split a tile's voxels; one slab [27][CoutPad][CinPad] per workgroup
+// in the layout of the generic kernels (only ci = 0 is used) -> wgrad_reduce_kernel finishes.
+__global__ __launch_bounds__(256) void wgrad_image3d_kernel(WgradArgs a) {
+  constexpr int TH = 16, TW = 16, HW_ = TW + 2, NP = (TH + 2) * HW_;
+  __shared__ float Xs[3 * NP];
+  __shared__ float red[4][2][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int t0 = li, t1 = li + 16;                                // the two taps this lane feeds as the A operand
+  const int off0 = (t0 / 9) * NP + ((t0 % 9) / 3) * HW_ + t0 % 3;
+  const int off1 = t1 < 27 ? (t1 / 9) * NP + ((t1 % 9) / 3) * HW_ + t1 % 3 : 0;
+  const float m1 = t1 < 27 ? 1.f : 0.f;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const long n_tiles = (long)a.NB * tiles_y * tiles_x;
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tx = t % tiles_x; const long r = t / tiles_x; const int ty = r % tiles_y; const int pl = r / tiles_y;
+    const int xd = pl % a.D3;
+    __syncthreads();
+    for (int u = tid; u < 3 * NP; u += 256) {
+      const int k = u / NP, hp = u - k * NP, hy = hp / HW_, hx = hp - hy * HW_;
+      const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1, pz = xd + k - 1;
+      Xs[u] = (pz >= 0 && pz < a.D3 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                  ? a.Ain[(((long)(pl + k - 1) * a.H + gy) * a.W + gx) * a.lda] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {                               // wave w: voxels 64w .. 64w+63 of the tile, 4 per step
+      const int p = 64 * w + 4 * s + g, py = p >> 4, px = p & 15;
+      const int gy = ty * TH + py, gx = tx * TW + px;
+      float z = 0.f;
+      if (gy < a.H && gx < a.W && li < a.Cout) z = a.dZ[(((long)pl * a.H + gy) * a.W + gx) * a.ldz + li];
+      const float* xb = Xs + py * HW_ + px;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[off0], z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[off1] * m1, z, acc1, 0, 0, 0);
+    }
+  }
+  // lane holds D[tap = 16*h + 4g + r][co = li]; sum the four waves, then one slab per workgroup
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { red[w][0][(4 * g + r) * 16 + li] = acc0[r]; red[w][1][(4 * g + r) * 16 + li] = acc1[r]; }
+  __syncthreads();
+  for (int u = tid; u < 512; u += 256) {
+    const int h = u >> 8, e = u & 255, tap = 16 * h + (e >> 4), co = e & 15;
+    if (tap < 27) {
+      const float v = (red[0][h][e] + red[1][h][e]) + (red[2][h][e] + red[3][h][e]);
+      a.partial[(((long)blockIdx.x * a.taps + tap) * a.CoutPad + co) * a.CinPad] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int taps, int CoutPad, int CinPad,
                                     int Cout, int Cin, float* __restrict__ dW, int accumulate) {
   // block = 64 consecutive slab elements (coalesced) x 8 slab groups; slab layout [tap][co][ci], dW torch layout.
@@ -1150,6 +1286,16 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
   a.n_tiles = taps >= 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
   hipStream_t st = as_stream(stream);
+  if (taps == 27 && Cin == 1 && Cout <= 16) {       // one-channel volume (the V-Net's first layer): taps as the M dimension
+    a.CoutPad = 16; a.CinPad = 16;
+    const long tiles = (long)NB * ((H + 15) / 16) * ((W + 15) / 16);
+    const long chunks = tiles < 512 ? tiles : 512;              // <= the slab count arco_wgrad_ws_floats reserves
+    hipLaunchKernelGGL(wgrad_image3d_kernel, dim3((unsigned)chunks), dim3(256), 0, st, a);
+    const long tot = (long)Cout * Cin * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(512), 0, st, ws, (int)chunks, taps, a.CoutPad,
+                       a.CinPad, Cout, Cin, dW, accumulate);
+    return arco_launch_status();
+  }
   if (taps >= 9) {       // spatial kernels: all taps of a plane per block, operands staged once (halo in LDS)
     const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
     a.CoutPad = (Cout + hco - 1) / hco * hco; a.CinPad = (Cin + hci - 1) / hci * hci;
