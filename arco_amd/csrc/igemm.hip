@@ -633,17 +633,19 @@ __global__ __launch_bounds__(256) void conv3x3_image_kernel(IgemmArgs a) {
 // Persistent workgroups over 16 x 16 tiles of a plane; a lane ends up with 4 consecutive output channels of one
 // voxel (16-byte stores); per-channel (sum, sum of squares) partials for the BatchNorm that follows.
 // ---------------------------------------------------------------------------
+// DEPTH = 1: the same for a one-channel IMAGE (3 x 3 taps, K = 9 -> 12; the U-Net's first layer).
+template <int DEPTH>
 __global__ __launch_bounds__(256) void conv3d_image_kernel(IgemmArgs a) {
-  constexpr int TH = 16, TW = 16, HW_ = TW + 2, NP = (TH + 2) * HW_;
-  __shared__ float Xs[3 * NP];           // [depth tap][halo position]
+  constexpr int TH = 16, TW = 16, HW_ = TW + 2, NP = (TH + 2) * HW_, NT = 9 * DEPTH, KS = (NT + 3) / 4;
+  __shared__ float Xs[DEPTH * NP];       // [depth tap][halo position]
   __shared__ float red[2][4][16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
-  float wk[7]; int off[7];
+  float wk[KS]; int off[KS];
 #pragma unroll
-  for (int s = 0; s < 7; ++s) {
+  for (int s = 0; s < KS; ++s) {
     const int t = 4 * s + g;                                     // tap = dz*9 + dy*3 + dx
-    wk[s] = (t < 27 && li < a.N) ? a.Wp[((long)t * a.Npad + li) * a.Kpad] : 0.f;
-    off[s] = t < 27 ? (t / 9) * NP + ((t % 9) / 3) * HW_ + t % 3 : 0;
+    wk[s] = (t < NT && li < a.N) ? a.Wp[((long)t * a.Npad + li) * a.Kpad] : 0.f;
+    off[s] = t < NT ? (t / 9) * NP + ((t % 9) / 3) * HW_ + t % 3 : 0;
   }
   f32x4 bias4 = {0, 0, 0, 0};
 #pragma unroll
@@ -657,11 +659,11 @@ __global__ __launch_bounds__(256) void conv3d_image_kernel(IgemmArgs a) {
     const int tx = t % tiles_x; const long r = t / tiles_x; const int ty = r % tiles_y; const int pl = r / tiles_y;
     const int xd = pl % a.D3;                                    // plane index inside its volume
     __syncthreads();
-    for (int u = tid; u < 3 * NP; u += 256) {
+    for (int u = tid; u < DEPTH * NP; u += 256) {
       const int k = u / NP, hp = u - k * NP, hy = hp / HW_, hx = hp - hy * HW_;
-      const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1, pz = xd + k - 1;
+      const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1, dk = k - DEPTH / 2, pz = xd + dk;
       Xs[u] = (pz >= 0 && pz < a.D3 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                  ? a.A[(((long)(pl + k - 1) * a.H + gy) * a.W + gx) * a.lda] : 0.f;
+                  ? a.A[(((long)(pl + dk) * a.H + gy) * a.W + gx) * a.lda] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(256) void conv3d_image_kernel(IgemmArgs a) {
       const float* xb = Xs + py * HW_ + li;
       f32x4 acc = bias4;
 #pragma unroll
-      for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[s], xb[off[s]], acc, 0, 0, 0);
+      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[s], xb[off[s]], acc, 0, 0, 0);
       const int gy = ty * TH + py, gx = tx * TW + li;
       if (gy < a.H && gx < a.W && 4 * g < a.N) {
         const long pix = ((long)pl * a.H + gy) * a.W + gx;
@@ -697,15 +699,17 @@ __global__ __launch_bounds__(256) void conv3d_image_kernel(IgemmArgs a) {
 static bool image_conv3d_eligible(const IgemmArgs& a) {
   return a.K == 1 && a.Npad == 16 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && a.R == nullptr && a.D3 >= 1;
 }
+template <int DEPTH>
 static int launch_image_conv3d(const IgemmArgs& a, hipStream_t st, int* q) {
   const long n_tiles = (long)a.NB * ((a.H + 15) / 16) * ((a.W + 15) / 16);
   const int n_grp = a.stat_groups > 1 ? a.stat_groups : 1;
   if (a.NB % n_grp != 0) return ARCO_ERR_ARG;
   long bpg = 2048 / n_grp; if (bpg > n_tiles / n_grp) bpg = n_tiles / n_grp; if (bpg < 1) bpg = 1;
   const long blocks = bpg * n_grp;
-  if (q) { q[0] = (int)blocks; q[1] = 27 * 1000000 + 800000 + 1000 + 16; q[2] = 10; return ARCO_OK; }
+  if (q) { q[0] = (int)blocks; q[1] = 9 * DEPTH * 1000000 + 700000 + 1000 + 16; q[2] = 10; return ARCO_OK; }
   IgemmArgs b = a; b.n_mblocks = (int)blocks; b.n_nblocks = 1;
-  hipLaunchKernelGGL(conv3d_image_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+  if (DEPTH == 1) b.D3 = 1;
+  hipLaunchKernelGGL(conv3d_image_kernel<DEPTH>, dim3((unsigned)blocks), dim3(256), 0, st, b);
   return arco_launch_status();
 }
 static bool image_conv_eligible(const IgemmArgs& a) {
@@ -732,7 +736,8 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
     if ((a.Npad + 223) / 224 * 224 < (a.Npad + 127) / 128 * 128) return launch_igemm<1, 64, 224, 2, 2, 16, true>(a, st, nmb);
     return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
   }
-  if (taps == 27 && image_conv3d_eligible(a)) return launch_image_conv3d(a, st, nmb);   // one-channel volume (first layer)
+  if (taps == 27 && image_conv3d_eligible(a)) return launch_image_conv3d<3>(a, st, nmb);   // one-channel volume (first layer)
+  if (taps == 9 && image_conv3d_eligible(a)) return launch_image_conv3d<1>(a, st, nmb);     // one-channel image
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
   if (taps == 9 && image_conv_eligible(a)) return launch_image_conv(a, st, nmb);
   if (taps == 9) return halo_eligible(a) ? dispatch_halo(a, st, nmb) : dispatch_spatial<1>(a, st, nmb);
@@ -1040,15 +1045,21 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
 // operand comes from a three-plane halo tile in LDS, dZ is read once straight from HBM (64 B per voxel, coalesced).
 // Persistent over 16 x 16 tiles; the four waves split a tile's voxels; one slab [27][CoutPad][CinPad] per workgroup
 // in the layout of the generic kernels (only ci = 0 is used) -> wgrad_reduce_kernel finishes.
+// DEPTH = 1: one-channel image, 9 taps (one MFMA tile of taps).
+template <int DEPTH>
 __global__ __launch_bounds__(256) void wgrad_image3d_kernel(WgradArgs a) {
-  constexpr int TH = 16, TW = 16, HW_ = TW + 2, NP = (TH + 2) * HW_;
-  __shared__ float Xs[3 * NP];
+  constexpr int TH = 16, TW = 16, HW_ = TW + 2, NP = (TH + 2) * HW_, NT = 9 * DEPTH;
+  __shared__ float Xs[DEPTH * NP];
+  __shared__ __attribute__((aligned(16))) float Zs[256 * 16];   // dZ tile [voxel][co], zero outside the plane
   __shared__ float red[4][2][256];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int t0 = li, t1 = li + 16;                                // the two taps this lane feeds as the A operand
+  // Both MFMA operands come straight from LDS reads (as in every other kernel here).  Taps >= NT (rows of D nobody
+  // reads) simply alias tap 0.  NB: a first version masked them with a VALU multiply and zero-initialised dZ in a
+  // register before a predicated load; hipcc (ROCm 7.2, gfx950) then scheduled VALU writes of the operand registers
+  // right around the MFMA and the single-accumulator (DEPTH = 1) chain produced wrong rows on the hardware.
+  const int t0 = li < NT ? li : 0, t1 = li + 16 < NT ? li + 16 : 0;
   const int off0 = (t0 / 9) * NP + ((t0 % 9) / 3) * HW_ + t0 % 3;
-  const int off1 = t1 < 27 ? (t1 / 9) * NP + ((t1 % 9) / 3) * HW_ + t1 % 3 : 0;
-  const float m1 = t1 < 27 ? 1.f : 0.f;
+  const int off1 = (t1 / 9) * NP + ((t1 % 9) / 3) * HW_ + t1 % 3;
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const long n_tiles = (long)a.NB * tiles_y * tiles_x;
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
@@ -1056,22 +1067,28 @@ __global__ __launch_bounds__(256) void wgrad_image3d_kernel(WgradArgs a) {
     const int tx = t % tiles_x; const long r = t / tiles_x; const int ty = r % tiles_y; const int pl = r / tiles_y;
     const int xd = pl % a.D3;
     __syncthreads();
-    for (int u = tid; u < 3 * NP; u += 256) {
+    for (int u = tid; u < DEPTH * NP; u += 256) {
       const int k = u / NP, hp = u - k * NP, hy = hp / HW_, hx = hp - hy * HW_;
-      const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1, pz = xd + k - 1;
+      const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1, dk = k - DEPTH / 2, pz = xd + dk;
       Xs[u] = (pz >= 0 && pz < a.D3 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                  ? a.Ain[(((long)(pl + k - 1) * a.H + gy) * a.W + gx) * a.lda] : 0.f;
+                  ? a.Ain[(((long)(pl + dk) * a.H + gy) * a.W + gx) * a.lda] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = tid + 256 * i, p = u >> 2, q = u & 3;
+      const int gy = ty * TH + (p >> 4), gx = tx * TW + (p & 15);
+      f32x4 v = {0, 0, 0, 0};
+      if (gy < a.H && gx < a.W && 4 * q < a.Cout) v = *reinterpret_cast<const f32x4*>(a.dZ + (((long)pl * a.H + gy) * a.W + gx) * a.ldz + 4 * q);
+      *reinterpret_cast<f32x4*>(&Zs[p * 16 + 4 * q]) = v;
     }
     __syncthreads();
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {                               // wave w: voxels 64w .. 64w+63 of the tile, 4 per step
-      const int p = 64 * w + 4 * s + g, py = p >> 4, px = p & 15;
-      const int gy = ty * TH + py, gx = tx * TW + px;
-      float z = 0.f;
-      if (gy < a.H && gx < a.W && li < a.Cout) z = a.dZ[(((long)pl * a.H + gy) * a.W + gx) * a.ldz + li];
-      const float* xb = Xs + py * HW_ + px;
+      const int p = 64 * w + 4 * s + g;
+      const float z = Zs[p * 16 + li];
+      const float* xb = Xs + (p >> 4) * HW_ + (p & 15);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[off0], z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[off1] * m1, z, acc1, 0, 0, 0);
+      if (DEPTH == 3) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[off1], z, acc1, 0, 0, 0);
     }
   }
   // lane holds D[tap = 16*h + 4g + r][co = li]; sum the four waves, then one slab per workgroup
@@ -1080,7 +1097,7 @@ __global__ __launch_bounds__(256) void wgrad_image3d_kernel(WgradArgs a) {
   __syncthreads();
   for (int u = tid; u < 512; u += 256) {
     const int h = u >> 8, e = u & 255, tap = 16 * h + (e >> 4), co = e & 15;
-    if (tap < 27) {
+    if (tap < NT) {
       const float v = (red[0][h][e] + red[1][h][e]) + (red[2][h][e] + red[3][h][e]);
       a.partial[(((long)blockIdx.x * a.taps + tap) * a.CoutPad + co) * a.CinPad] = v;
     }
@@ -1286,11 +1303,13 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
   a.n_tiles = taps >= 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
   hipStream_t st = as_stream(stream);
-  if (taps == 27 && Cin == 1 && Cout <= 16) {       // one-channel volume (the V-Net's first layer): taps as the M dimension
+  if (taps >= 9 && Cin == 1 && Cout <= 16 && (Cout & 3) == 0 && (ld_dz & 3) == 0) {   // one-channel input (first layer of both nets): taps as M
     a.CoutPad = 16; a.CinPad = 16;
+    if (taps == 9) a.D3 = 1;
     const long tiles = (long)NB * ((H + 15) / 16) * ((W + 15) / 16);
     const long chunks = tiles < 512 ? tiles : 512;              // <= the slab count arco_wgrad_ws_floats reserves
-    hipLaunchKernelGGL(wgrad_image3d_kernel, dim3((unsigned)chunks), dim3(256), 0, st, a);
+    if (taps == 27) hipLaunchKernelGGL(wgrad_image3d_kernel<3>, dim3((unsigned)chunks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_image3d_kernel<1>, dim3((unsigned)chunks), dim3(256), 0, st, a);
     const long tot = (long)Cout * Cin * taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(512), 0, st, ws, (int)chunks, taps, a.CoutPad,
                        a.CinPad, Cout, Cin, dW, accumulate);
