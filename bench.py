@@ -40,18 +40,18 @@ PMC_TRAFFIC_BYTES = {(9, 65536, 64, 64): 3.526e7, (9, 65536, 64, 128): 5.322e7,
 
 
 def cpu_baseline_child():
-    """Runs in a child process (all host cores, no GPU): one full oracle step at --batch_size 2."""
+    """Runs in a child process (all host cores, no GPU): three chained oracle steps at --batch_size 2."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_step
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     cpu_step.timed_sample(b=1, patch=(64, 64))          # warm the thread pool / allocator
-    secs, threads = cpu_step.timed_sample(b=2)
-    print(json.dumps({"secs": secs, "threads": threads}))
+    secs, threads = cpu_step.timed_sample(b=2, steps=3)
+    print(json.dumps({"secs": secs, "threads": threads, "steps": 3}))
 
 
 def cpu_baseline():
-    """CPU oracle (port) timed on this box's host cores: one full step at --batch_size 2 (4 images)."""
+    """CPU oracle (port) timed on this box's host cores: three chained full steps at --batch_size 2 (4 images)."""
     env = dict(os.environ, ARCO_CPU_BASELINE_CHILD="1")
     env.pop("OMP_NUM_THREADS", None); env.pop("MKL_NUM_THREADS", None)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu_baseline_child"], env=env,
@@ -60,8 +60,8 @@ def cpu_baseline():
     secs, threads = r["secs"], r["threads"]
     # a 16-image step is 4x the 4-image sample (per-image work is constant)
     return {"value": round(1.0 / (4.0 * secs), 5), "unit": "steps/s (16-image steps)", "cores": threads, "kind": "port",
-            "sample": f"1 full oracle step at --batch_size 2 (4 images, 256x256, C=4, D=496) = {secs:.1f} s on "
-                      f"{threads} threads; scaled x4 to the 16-image step"}
+            "sample": f"{r.get('steps', 1)} chained full oracle steps at --batch_size 2 (4 images, 256x256, C=4, D=496, cutmix), "
+                      f"{secs:.1f} s per step on {threads} threads; scaled x4 to the 16-image step"}
 
 
 def main():

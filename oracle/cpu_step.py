@@ -99,16 +99,20 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
     return float(loss.detach()), float(reco.detach())
 
 
-def timed_sample(b=2, patch=(256, 256), n_cls=4, seed=1337, qsize=4096):
-    """One full CPU step at --batch_size b; returns (seconds, threads)."""
+def timed_sample(b=2, patch=(256, 256), n_cls=4, seed=1337, qsize=4096, steps=1):
+    """`steps` chained full CPU steps at --batch_size b (fresh synthetic batches, the banks fill as they would in
+    training, so the later steps run the real grid samplers); returns (mean seconds per step, threads)."""
     import fixture_inputs as fx
     torch.manual_seed(seed)
     st = make_state(fx.unet_state(21, 1, n_cls), fx.fe_state(31), [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]])
     rs = np.random.RandomState(seed)
-    l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
-    u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
-    lab = torch.from_numpy(fx.blob_labels(rs, b, patch, n_cls))
     bank, ptr, qs = fx.fresh_bank(n_cls, 496, qsize, 'zeros')
-    t0 = time.time()
-    step(st, l, lab, u, bank, ptr, qs, n_cls, apply_aug='cutmix')      # the trainer's default --apply_aug
-    return time.time() - t0, torch.get_num_threads()
+    total = 0.0
+    for _ in range(steps):
+        l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        lab = torch.from_numpy(fx.blob_labels(rs, b, patch, n_cls))
+        t0 = time.time()
+        step(st, l, lab, u, bank, ptr, qs, n_cls, apply_aug='cutmix')      # the trainer's default --apply_aug
+        total += time.time() - t0
+    return total / steps, torch.get_num_threads()
