@@ -27,6 +27,7 @@ struct IgemmArgs {
   long M;                            // total pixels
   int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
   int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
+  int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3 only)
 };
 
 // FLAT (3x3 only): the M-tile is BM consecutive positions of the plane stored with a padded row stride Wp = W + 2
@@ -34,7 +35,20 @@ struct IgemmArgs {
 // position, rows need no tiling, and the padding waste is 2 / (W + 2) instead of rounding BOTH plane dimensions up
 // to the tile: 7x7 planes waste 23 % instead of 62 %, 28x28 planes 7 % instead of 23 % (the V-Net's deep levels).
 constexpr int IGEMM_FLAT_WPMAX = 64;
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH, bool FLAT = false>
+// MMA = 1 / 2 (BASELINE.json configs[4], "fp16 MFMA conv"): tensors stay fp32 in HBM and LDS; the four consecutive K
+// values a lane reads per fragment are rounded to f16 / bf16 in registers and fed to ONE v_mfma_f32_16x16x16_{f16,bf16}
+// (same K-to-lane mapping as four 16x16x4 fp32 MFMAs), fp32 accumulation: 1/16 of the matrix-core time, so the 3x3x3
+// levels become LDS/HBM-bound.  Opt-in (--conv_mma), tolerance 1e-2; never the default or the benchmark.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 to_f16x4(f32x4 v) { return __builtin_convertvector(v, f16x4); }
+__device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
+  s16x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const __bf16 b = (__bf16)v[e]; r[e] = __builtin_bit_cast(short, b); }
+  return r;
+}
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH, bool FLAT = false, int MMA = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int TH = BM / 16;
   constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * IGEMM_FLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
@@ -196,13 +210,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
           const int row = tap * BN + (wn * C_T + ct) * 16 + li;
           bf[ct] = *reinterpret_cast<const f32x4*>(&Bs[row * LDK + kk * 16 + 4 * g]);
         }
+        if constexpr (MMA == 1) {
+          f16x4 ah[A_T], bh[C_T];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int at = 0; at < A_T; ++at) ah[at] = to_f16x4(af[at]);
+#pragma unroll
+          for (int ct = 0; ct < C_T; ++ct) bh[ct] = to_f16x4(bf[ct]);
 #pragma unroll
           for (int at = 0; at < A_T; ++at)
 #pragma unroll
             for (int ct = 0; ct < C_T; ++ct)
-              acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[at][j], bf[ct][j], acc[at][ct], 0, 0, 0);
+              acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[at], bh[ct], acc[at][ct], 0, 0, 0);
+        } else if constexpr (MMA == 2) {
+          s16x4 ah[A_T], bh[C_T];
+#pragma unroll
+          for (int at = 0; at < A_T; ++at) ah[at] = to_bf16x4(af[at]);
+#pragma unroll
+          for (int ct = 0; ct < C_T; ++ct) bh[ct] = to_bf16x4(bf[ct]);
+#pragma unroll
+          for (int at = 0; at < A_T; ++at)
+#pragma unroll
+            for (int ct = 0; ct < C_T; ++ct)
+              acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[at], bh[ct], acc[at][ct], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int at = 0; at < A_T; ++at)
+#pragma unroll
+              for (int ct = 0; ct < C_T; ++ct)
+                acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[at][j], bf[ct][j], acc[at][ct], 0, 0, 0);
+        }
       }
     }
   };
@@ -297,7 +335,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 }
 
-template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH, bool FLAT = false>
+template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH, bool FLAT = false, int MMA = 0>
 static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   constexpr int TH = BM / 16;
   constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * IGEMM_FLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
@@ -315,7 +353,7 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   size_t sh = (size_t)(DB ? 2 : 1) * (AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
-  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC, DEPTH, FLAT>;
+  auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC, DEPTH, FLAT, MMA>;
   static bool attr_set = false;      // once per instantiation (never inside a stream capture after warm-up)
   if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
   IgemmArgs b = a;
@@ -329,6 +367,10 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
 template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, int DEPTH = 1, bool FLAT = false>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   const bool vec = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
+  if constexpr (DEPTH == 3) {          // reduced-precision MFMA operands: the 3x3x3 kernels only (vector-load instantiations)
+    if (vec && a.mma == 1) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH, FLAT, 1>(a, st, n_mblocks_out);
+    if (vec && a.mma == 2) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH, FLAT, 2>(a, st, n_mblocks_out);
+  }
   if (vec) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH, FLAT>(a, st, n_mblocks_out);
   return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, false, DEPTH, FLAT>(a, st, n_mblocks_out);
 }
@@ -1216,7 +1258,7 @@ int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode,
 
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
-                    int NV, int D3, int H, int W, int stat_groups, void* stream);
+                    int NV, int D3, int H, int W, int stat_groups, int mma, void* stream);
 // desc: device array of n_desc PackDesc records (arco_pack_desc_bytes() each, see igemm.hip); total = sum of packed sizes
 long arco_pack_desc_bytes() { return (long)sizeof(PackDesc); }
 int arco_pack_many(const void* desc, int n_desc, long total, void* stream) {
@@ -1249,15 +1291,15 @@ int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, fl
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                   int NB, int H, int W, void* stream) {
   return arco_conv3d_fwd(in, ld_in, K, Wp, N, out, ld_out, bias, residual, ld_res, stat_sum, stat_sq, taps, NB, 1, H, W,
-                         1, stream);
+                         1, 0, stream);
 }
 
 // 3-D generalisation: NV volumes of D3 planes of H x W; taps in {1, 9 (per plane), 27 (3x3x3, pad 1)}
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
-                    int NV, int D3, int H, int W, int stat_groups, void* stream) {
+                    int NV, int D3, int H, int W, int stat_groups, int mma, void* stream) {
   const int NB = NV * D3;
-  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0);
+  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0 && mma >= 0 && mma <= 2);
   IgemmArgs a{};
   a.A = in; a.lda = ld_in; a.Wp = Wp; a.N = N; a.K = K;
   a.Npad = (N + 15) / 16 * 16; a.Kpad = (K + 15) / 16 * 16;
@@ -1265,6 +1307,7 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
   a.stat_sum = stat_sum; a.stat_sq = stat_sq;
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = D3;
   a.stat_groups = stat_groups > 1 ? stat_groups : 1;
+  a.mma = mma;
   ARCO_CHECK_ARG(NV % a.stat_groups == 0);
   return dispatch_igemm(a, taps, as_stream(stream), nullptr);
 }

@@ -15,6 +15,8 @@ SEED_DEV = None     # device uint64 salt for dropout masks of graph-captured for
 PROFILE = None       # bench.py sets a dict: kernel instantiation id -> {n, flop, timed: [(ev0, ev1, flop, (taps, M, N, K))]}
 _cfg_cache = {}
 BN_GROUPS = 1         # see bn_groups()
+CONV_MMA = 0          # 0: fp32 MFMA everywhere (default, the parity path).  1 / 2: the 3x3x3 convolutions (forward and data
+                      # gradient) round their MFMA operands to f16 / bf16 in registers, fp32 accumulate - train_arco_3d --conv_mma
 PROFILE_EVERY = 1    # time every n-th conv launch of an instantiation (bench.py: 7, prime vs the per-step launch counts)
 
 
@@ -283,7 +285,7 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
             prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             prof[0].record()
     L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
-           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1)
+           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1, CONV_MMA if taps == 27 else 0)
     if prof is not None:
         prof[1].record()
         PROFILE[cfg]["timed"].append((prof[0], prof[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))

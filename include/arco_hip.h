@@ -89,7 +89,9 @@ int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, fl
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                     int NV, int D3, int H, int W,
-                    int stat_groups /* BN groups: volumes [g*NV/G,..) feed stat slabs [g*nmb/G,..); 1 = one batch */, void* stream);
+                    int stat_groups /* BN groups: volumes [g*NV/G,..) feed stat slabs [g*nmb/G,..); 1 = one batch */, int mma /* 0: fp32 MFMA (default, parity); 1 / 2: 3x3x3 operands rounded to f16 / bf16 in registers, fp32 accumulate
+                               (BASELINE.json configs[4] "fp16 MFMA conv"; tolerance 1e-2; opt-in) */,
+                    void* stream);
 int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
                       int D3, int H, int W, float* ws, float* dW, int accumulate, void* stream);
 long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M);

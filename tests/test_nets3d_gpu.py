@@ -322,3 +322,60 @@ def test_revisiting_loss_3d_matches_oracle():
             assert int(st.random_pool.ptr) == int(ptr_o) == (i + 1) % 3
     finally:
         glue.get_revisiting_loss = real
+
+
+@pytest.mark.parametrize("mma,tol", [(1, 4e-3), (2, 2e-2)])
+@pytest.mark.parametrize("nb,ci,co,d,h,w", [(2, 16, 16, 6, 16, 16), (1, 32, 64, 4, 14, 10), (1, 128, 128, 3, 7, 5), (1, 16, 32, 3, 20, 48)])
+def test_conv3d_reduced_precision_mma(mma, tol, nb, ci, co, d, h, w):
+    """--conv_mma f16 / bf16 (BASELINE.json configs[4]): the 3x3x3 forward and data-gradient kernels with MFMA operands
+    rounded to f16 / bf16 and fp32 accumulation vs torch fp32 - inside the 1e-2 budget of that config (error measured
+    against the largest output, as sums of ~27*Cin rounded products are)."""
+    from arco_amd import ops
+    rs = np.random.RandomState(ci + co + d + mma)
+    x = rnd(rs, nb, ci, d, h, w)
+    wt = rnd(rs, co, ci, 3, 3, 3, scale=1 / np.sqrt(ci * 27))
+    gy = rnd(rs, nb, co, d, h, w)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, padding=1)
+    yr.backward(gy)
+    ops.CONV_MMA = mma
+    try:
+        xg, wg = cl3(x).requires_grad_(True), wt.cuda().requires_grad_(True)
+        yg = ops.conv(xg, wg, None)
+        yg.backward(cl3(gy))
+    finally:
+        ops.CONV_MMA = 0
+    for got, ref in ((yg, yr), (xg.grad, xr.grad)):
+        err = float((got.detach().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
+        assert 1e-6 < err < tol, err                      # really reduced precision, and inside the budget
+    close(wg.grad, wr.grad, rtol=5e-4, atol=5e-4 * float(wr.grad.abs().max()))    # the weight gradient stays fp32
+
+
+def test_3d_step_with_f16_mma_tracks_fp32():
+    import random
+    from arco_amd import ops, train_arco_3d as T3
+    out = {}
+    for mode in ("f32", "f16", "bf16"):
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        ops.reseed_dropout(11)
+        args = T3.build_parser().parse_args(["--batch_size", "1", "--queue_size", "256", "--synthetic", "1", "--num_classes", "2",
+                                             "--num_queries", "64", "--num_negatives", "32", "--k1", "1.0", "--conv_mma", mode,
+                                             "--eqv_pass", "0"])
+        args.patch_size = [32, 32, 32]
+        st = T3.ArcoStep3D(args, "cuda:0")
+        assert ops.CONV_MMA == {"f32": 0, "f16": 1, "bf16": 2}[mode]
+        for m in (st.model, st.ema_model):
+            m.has_dropout = False
+        losses = []
+        for i in range(3):
+            l_img, l_lab = T3.synthetic_volume_batch(1, args.patch_size, 2, 10 + i, "cuda:0")
+            u_img, _ = T3.synthetic_volume_batch(1, args.patch_size, 2, 20 + i, "cuda:0")
+            loss, reco = st.step(l_img, l_lab, u_img)
+            losses.append((float(st.last_terms["ce"]), float(st.last_terms["dice"])))
+        out[mode] = np.array(losses)
+    ops.CONV_MMA = 0
+    for mode in ("f16", "bf16"):
+        assert np.all(np.isfinite(out[mode]))
+        np.testing.assert_allclose(out[mode][0], out["f32"][0], rtol=1e-2)       # first step: same weights, 1e-2 budget
+        np.testing.assert_allclose(out[mode], out["f32"], rtol=5e-2)             # trajectories stay together
+        assert not np.array_equal(out[mode], out["f32"])
