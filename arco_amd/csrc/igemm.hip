@@ -842,6 +842,7 @@ struct WgradArgs {
   int taps, NB, H, W, D3; long M;
   float* partial;      // [chunks][taps][CoutPad][CinPad]
   int CoutPad, CinPad, n_tiles;
+  int mma;             // 0 fp32 MFMA; 2: bf16 operands (halo kernels, 3x3x3 only), fp32 accumulate
 };
 
 template <int CO_B, int CI_B>
@@ -966,7 +967,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // reduction, 36 accumulator registers instead of 144; 16x32 / 32x16: two waves per sub-tile, 64 pixels each;
 // 16x16: four waves, 32 pixels each), partners are summed once per LAUNCH through LDS.
 // FLAT: tiles are 128 consecutive positions of the plane stored with padded row stride W + 2 (see igemm_kernel FLAT)
-template <int CO_B, int CI_B, bool FLAT = false>
+// MMA = 2: 16 pixels per step instead of 4 - a lane converts 4 consecutive pixels of dZ and of each tap's input
+// to bf16 and issues one v_mfma_f32_16x16x16_bf16 per tap (see igemm_kernel's MMA note; gradients use bf16, not f16:
+// dZ values of 1e-6 would flush in f16).
+template <int CO_B, int CI_B, bool FLAT = false, int MMA = 0>
 __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
   constexpr int LDZ = (CO_B % 32 == 0) ? CO_B + 16 : CO_B;
   constexpr int LDA = (CI_B % 32 == 0) ? CI_B + 16 : CI_B;
@@ -1040,6 +1044,25 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
     __syncthreads();
     const int next = t + gridDim.x;
     if (next < a.n_tiles) fetch(next);
+    if constexpr (MMA == 2) {
+#pragma unroll 2
+      for (int k4 = 0; k4 < KSTEPS / 4; ++k4) {
+        const int p0 = (part * KSTEPS + 4 * k4) * 4 + 4 * g, py = p0 >> 4, pxx = p0 & 15;   // pixels p0 .. p0+3: one tile row
+        f32x4 zv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zv[j] = Zs[(p0 + j) * LDZ + wi * 16 + li];
+        const s16x4 zh = to_bf16x4(zv);
+        const float* xrow = Xs + (FLAT ? p0 : py * 18 + pxx) * LDA + wj * 16 + li;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int toff = (FLAT ? (tap / 3) * Wp + tap % 3 : (tap / 3) * 18 + tap % 3) * LDA;
+          f32x4 xv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xv[j] = xrow[toff + j * LDA];
+          acc[tap] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(zh, to_bf16x4(xv), acc[tap], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll 4
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int p = (part * KSTEPS + ks) * 4 + g, py = p >> 4, pxx = p & 15;
@@ -1048,6 +1071,7 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap)
         acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf, xrow[(FLAT ? (tap / 3) * Wp + tap % 3 : (tap / 3) * 18 + tap % 3) * LDA], acc[tap], 0, 0, 0);
+    }
     }
     __syncthreads();
     t = next;
@@ -1313,7 +1337,7 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
 }
 
 int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
-                      int D3, int H, int W, float* ws, float* dW, int accumulate, void* stream);
+                      int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, void* stream);
 long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M) {
   const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
   const int CoutPad = (Cout + co_b - 1) / co_b * co_b, CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
@@ -1331,15 +1355,15 @@ long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M) {
 
 int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NB,
                     int H, int W, float* ws, float* dW, int accumulate, void* stream) {
-  return arco_conv3d_wgrad(dZ, ld_dz, Cout, in, ld_in, Cin, taps, NB, 1, H, W, ws, dW, accumulate, stream);
+  return arco_conv3d_wgrad(dZ, ld_dz, Cout, in, ld_in, Cin, taps, NB, 1, H, W, ws, dW, accumulate, 0, stream);
 }
 
 int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
-                      int D3, int H, int W, float* ws, float* dW, int accumulate, void* stream) {
+                      int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, void* stream) {
   const int NB = NV * D3;
-  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9 || taps == 27));
+  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9 || taps == 27) && mma >= 0 && mma <= 2);
   WgradArgs a{};
-  a.D3 = D3;
+  a.D3 = D3; a.mma = (taps == 27 && mma) ? 2 : 0;            // gradients: bf16 operands whichever reduced mode is on
   a.dZ = dZ; a.ldz = ld_dz; a.Cout = Cout; a.Ain = in; a.lda = ld_in; a.Cin = Cin; a.taps = taps;
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.partial = ws;
   const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
@@ -1373,11 +1397,16 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
       constexpr int LZ = (COB % 32 == 0) ? COB + 16 : COB, LA = (CIB % 32 == 0) ? CIB + 16 : CIB; \
       size_t sh = (size_t)(128 * LZ + (flat ? 128 + 2 * (W + 2) + 2 : 180) * LA) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4;  \
       if (sh < rd && (COB / 16) * (CIB / 16) < 4) sh = rd;                                        \
-      if (flat) {                                                                                 \
+      if (flat && a.mma == 2) {                                                                   \
+        static bool attr_set2 = false;                                                            \
+        if (!attr_set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo2_kernel<COB, CIB, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 * LZ + (128 + 2 * IGEMM_FLAT_WPMAX + 2) * LA) * 4); attr_set2 = true; } \
+        hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB, true, 2>), hgrid, dim3(256), sh, st, a); \
+      } else if (flat) {                                                                          \
         static bool attr_set = false;                                                             \
         if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo2_kernel<COB, CIB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 * LZ + (128 + 2 * IGEMM_FLAT_WPMAX + 2) * LA) * 4); attr_set = true; } \
         hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB, true>), hgrid, dim3(256), sh, st, a);    \
-      } else hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);     \
+      } else if (a.mma == 2) hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB, false, 2>), hgrid, dim3(256), sh, st, a); \
+      else hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);       \
     } while (0)
     if (hco == 32 && hci == 32) WH(32, 32);
     else if (hco == 32 && hci == 16) WH(32, 16);

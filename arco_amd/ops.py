@@ -255,7 +255,7 @@ def pack_weight(weight, taps, mode):
 
 
 def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1, sp=None,
-             stat_groups=1):
+             stat_groups=1, grad=False):
     """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out channels-last, stat slabs or None).
     2-D: nb images of h x w -> out [nb,n,h,w].  3-D (d3 > 1): nb volumes of d3 planes -> out [nb,n,d3,h,w]."""
     if sp is not None:
@@ -285,7 +285,8 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
             prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             prof[0].record()
     L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
-           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1, CONV_MMA if taps == 27 else 0)
+           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1,
+           ((2 if grad else CONV_MMA) if (CONV_MMA and taps == 27) else 0))       # gradients as operands: bf16 (range), never f16
     if prof is not None:
         prof[1].record()
         PROFILE[cfg]["timed"].append((prof[0], prof[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
@@ -298,7 +299,7 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
 
     def compute(out, accumulate):
         L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
-               accumulate)
+               accumulate, 2 if (CONV_MMA and taps == 27) else 0)
     return _grad_into(like, compute)
 
 
@@ -371,7 +372,7 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wd = pack_weight(weight, taps, 1)
-            dx, _ = conv_raw(dyr, ldy, co, wd, ci, nv, h, w, taps, residual=dyr if ctx.residual else None,
+            dx, _ = conv_raw(dyr, ldy, co, wd, ci, nv, h, w, taps, grad=True, residual=dyr if ctx.residual else None,
                              ld_res=ldy if ctx.residual else 0, d3=d3, sp=sp)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
@@ -469,7 +470,7 @@ class ConvBnActFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wd = pack_weight(weight, taps, 1)
-            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3, sp=sp)
+            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3, sp=sp, grad=True)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if has_bias and ctx.needs_input_grad[2]:

@@ -93,7 +93,8 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
                                (BASELINE.json configs[4] "fp16 MFMA conv"; tolerance 1e-2; opt-in) */,
                     void* stream);
 int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
-                      int D3, int H, int W, float* ws, float* dW, int accumulate, void* stream);
+                      int D3, int H, int W, float* ws, float* dW, int accumulate,
+                      int mma /* 0 exact fp32; != 0: 3x3x3 halo kernels with bf16 MFMA operands, fp32 accumulate */, void* stream);
 long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M);
 /* dW[co][ci][tap] (+)= sum_pix dZ[pix][co] * in[pix+tap][ci]   (torch weight layout)                      */
 int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NB,

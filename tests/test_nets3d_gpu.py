@@ -345,10 +345,10 @@ def test_conv3d_reduced_precision_mma(mma, tol, nb, ci, co, d, h, w):
         yg.backward(cl3(gy))
     finally:
         ops.CONV_MMA = 0
-    for got, ref in ((yg, yr), (xg.grad, xr.grad)):
+    # forward: the selected type; both gradients use bf16 operands (dZ magnitudes of 1e-6 would flush in f16)
+    for got, ref, t in ((yg, yr, tol), (xg.grad, xr.grad, 2e-2), (wg.grad, wr.grad, 2e-2)):
         err = float((got.detach().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
-        assert 1e-6 < err < tol, err                      # really reduced precision, and inside the budget
-    close(wg.grad, wr.grad, rtol=5e-4, atol=5e-4 * float(wr.grad.abs().max()))    # the weight gradient stays fp32
+        assert 1e-6 < err < t, err                        # really reduced precision, and inside the budget
 
 
 def test_3d_step_with_f16_mma_tracks_fp32():
