@@ -27,7 +27,7 @@ struct IgemmArgs {
   long M;                            // total pixels
   int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
   int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
-  int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3 only)
+  int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3, 1x1x1)
 };
 
 // FLAT (3x3 only): the M-tile is BM consecutive positions of the plane stored with a padded row stride Wp = W + 2
@@ -367,7 +367,7 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
 template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, int DEPTH = 1, bool FLAT = false>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   const bool vec = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
-  if constexpr (DEPTH == 3) {          // reduced-precision MFMA operands: the 3x3x3 kernels only (vector-load instantiations)
+  if constexpr (DEPTH == 3 || TAPS == 1) {   // reduced-precision MFMA operands: the 3x3x3 kernels and the 1x1x1 GEMMs (vector loads)
     if (vec && a.mma == 1) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH, FLAT, 1>(a, st, n_mblocks_out);
     if (vec && a.mma == 2) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH, FLAT, 2>(a, st, n_mblocks_out);
   }

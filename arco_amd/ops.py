@@ -286,7 +286,7 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
             prof[0].record()
     L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
            L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1,
-           ((2 if grad else CONV_MMA) if (CONV_MMA and taps == 27) else 0))       # gradients as operands: bf16 (range), never f16
+           ((2 if grad else CONV_MMA) if (CONV_MMA and taps in (1, 27) and d3 > 1) else 0))   # gradient operands: bf16 (range)
     if prof is not None:
         prof[1].record()
         PROFILE[cfg]["timed"].append((prof[0], prof[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))

@@ -379,3 +379,27 @@ def test_3d_step_with_f16_mma_tracks_fp32():
         np.testing.assert_allclose(out[mode][0], out["f32"][0], rtol=1e-2)       # first step: same weights, 1e-2 budget
         np.testing.assert_allclose(out[mode], out["f32"], rtol=5e-2)             # trajectories stay together
         assert not np.array_equal(out[mode], out["f32"])
+
+
+@pytest.mark.parametrize("mma,tol", [(1, 4e-3), (2, 2e-2)])
+def test_conv1x1x1_reduced_precision_mma(mma, tol):
+    """The 1x1x1 GEMMs of volumes (FeatureExtractor_3d, k2s2 convs in GEMM form) in the reduced-precision mode."""
+    from arco_amd import ops
+    rs = np.random.RandomState(3 + mma)
+    x = rnd(rs, 1, 240, 4, 12, 16)
+    wt = rnd(rs, 240, 240, 1, 1, 1, scale=1 / np.sqrt(240))
+    gy = rnd(rs, 1, 240, 4, 12, 16)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None)
+    yr.backward(gy)
+    ops.CONV_MMA = mma
+    try:
+        xg, wg = cl3(x).requires_grad_(True), wt.cuda().requires_grad_(True)
+        yg = ops.conv(xg, wg, None)
+        yg.backward(cl3(gy))
+    finally:
+        ops.CONV_MMA = 0
+    for got, ref, t in ((yg, yr, tol), (xg.grad, xr.grad, 2e-2)):
+        err = float((got.detach().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
+        assert 1e-6 < err < t, err
+    close(wg.grad, wr.grad, rtol=5e-4, atol=5e-4 * float(wr.grad.abs().max()))     # 1x1x1 weight gradients stay fp32
