@@ -1,0 +1,35 @@
+"""Slice datasets of the 2-D trainer - `BaseDataSetsWithIndex` of code/build_dataset.py:18-69:
+`<base_dir>/train_slices.list` (ACDC) or `train_slices.txt` (MM) names the training slices under
+`<base_dir>/data/slices/<case>.{h5,npz}`; the first `index` entries form the labeled set (label_type=1), the rest the
+unlabeled set; `val.list` names whole volumes under `<base_dir>/data/`."""
+from torch.utils.data.dataset import Dataset
+
+from .dataloaders._io import read_case, read_list
+
+
+class BaseDataSetsWithIndex(Dataset):
+    def __init__(self, base_dir=None, split='train', num=None, transform=None, index=16, label_type=0):
+        self._base_dir, self.index, self.split, self.transform = base_dir, index, split, transform
+        self.sample_list = []
+        if split == 'train' and ('ACDC' in base_dir or 'MM' in base_dir):
+            acdc = 'ACDC' in base_dir
+            names = read_list(base_dir + ('/train_slices.list' if acdc else '/train_slices.txt'), strip='' if acdc else '.h5')
+            self.sample_list = names[:index] if label_type == 1 else names[index:]
+        elif split == 'val':
+            self.sample_list = read_list(base_dir + '/val.list')
+        if num is not None and split == 'train':
+            self.sample_list = self.sample_list[:num - index]
+        print("total {} samples".format(len(self.sample_list)))
+
+    def __len__(self):
+        return len(self.sample_list)
+
+    def __getitem__(self, idx):
+        case = self.sample_list[idx]
+        sub = "/data/slices/" if self.split == "train" else "/data/"
+        image, label = read_case(self._base_dir + sub + case)
+        sample = {'image': image, 'label': label}
+        if self.split == "train" and self.transform is not None:
+            sample = self.transform(sample)
+        sample["idx"] = idx
+        return sample

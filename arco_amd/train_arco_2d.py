@@ -385,22 +385,63 @@ def synthetic_batch(b, patch, n_cls, seed, device, in_chns=1):
     return img.to(device), torch.from_numpy(lab).to(device)
 
 
+def build_loaders(args):
+    """The two training loaders of train_arco_2d.py:161-215 (ACDC / MM slice datasets): the first
+    patients_to_slices(exp, labeled_num) slices are the labeled stream, the rest the unlabeled one; RandomGenerator per
+    sample; each loader draws with replacement and drops the last incomplete batch.  The Synapse / LiTS / JHU npz
+    datasets of the other --exp branches (dataloaders/dataset_synapse.py) are not built."""
+    from torch.utils.data import ConcatDataset, DataLoader
+    from torch.utils.data.sampler import RandomSampler
+    from .build_dataset import BaseDataSetsWithIndex
+    from .dataloaders import Compose
+    from .dataloaders.dataset import RandomGenerator
+    if any(k in args.exp for k in ("Syn", "syn", "Lits", "LiTS", "jhu", "JHU")):
+        raise NotImplementedError("only the ACDC / MM slice datasets (BaseDataSetsWithIndex) are built")
+    n_lab = patients_to_slices(args.exp, args.labeled_num)
+    sets = [BaseDataSetsWithIndex(base_dir=args.root_path, split="train", num=None,
+                                  transform=Compose([RandomGenerator(args.patch_size)]), index=n_lab, label_type=t) for t in (1, 0)]
+    db_l, db_u = sets
+    while len(db_l) < len(db_u):                                           # :196-197
+        db_l = ConcatDataset([db_l, db_l])
+    mk = lambda ds: DataLoader(ds, batch_size=args.batch_size, sampler=RandomSampler(data_source=ds, replacement=True),
+                               drop_last=True, pin_memory=True)
+    return mk(db_l), mk(db_u)
+
+
 def train(args, snapshot_path):
-    if not args.synthetic:
-        raise NotImplementedError(
-            "dataset readers (build_dataset.py / dataloaders/, h5py) are outside the hot path (SURVEY §8f row 4); "
-            "run with --synthetic 1")
     rank, world = adist.init()
     dev = torch.device("cuda", adist.local_rank())
     torch.cuda.set_device(dev)
     stepper = ArcoStep2D(args, dev)
     b = args.batch_size
-    iters_per_epoch = 100
+    loaders = None
+    if args.synthetic:
+        iters_per_epoch = 100
+    else:
+        loaders = build_loaders(args)
+        iters_per_epoch = len(loaders[1])                              # :217 iterations per epoch = unlabeled batches
+        logging.info("{} iterations per epoch".format(iters_per_epoch))
+        resume = "../model/{}_{}_labeledfinal/{}/iter_30000.pth".format(args.resume, args.labeled_num, args.model)
+        if os.path.exists(resume):                                      # stage-1 weights (:222-225), when present
+            sd = torch.load(resume, map_location="cpu")
+            stepper.isd.model.load_state_dict(sd); stepper.isd.ema_model.load_state_dict(sd)
+            for pl in stepper.plans:                                    # packed weights are stale now
+                pl.valid = False
+        else:
+            logging.info("no stage-1 checkpoint at {}: training from the random initialisation".format(resume))
     max_epoch = args.max_iterations // iters_per_epoch + 1
+    l_iter = u_iter = None
     while stepper.iter_num < args.max_iterations:
         it = stepper.iter_num
-        l_img, l_lab = synthetic_batch(b, args.patch_size, args.num_classes, 2 * it * world + rank, dev)
-        u_img, _ = synthetic_batch(b, args.patch_size, args.num_classes, (2 * it + 1) * world + rank, dev)
+        if args.synthetic:
+            l_img, l_lab = synthetic_batch(b, args.patch_size, args.num_classes, 2 * it * world + rank, dev)
+            u_img, _ = synthetic_batch(b, args.patch_size, args.num_classes, (2 * it + 1) * world + rank, dev)
+        else:
+            if it % iters_per_epoch == 0:                               # :268-270 fresh iterators every epoch
+                l_iter, u_iter = iter(loaders[0]), iter(loaders[1])
+            l_next, u_next = next(l_iter), next(u_iter)
+            l_img, l_lab = l_next['image'].to(dev, non_blocking=True), l_next['label'].to(dev, non_blocking=True).long()
+            u_img = u_next['image'].to(dev, non_blocking=True)
         loss, reco = stepper.step(l_img, l_lab, u_img, it // iters_per_epoch, max_epoch)
         if rank == 0:
             logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))

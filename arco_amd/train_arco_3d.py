@@ -246,21 +246,57 @@ def synthetic_volume_batch(b, patch, n_cls, seed, device):
     return img.to(device), torch.from_numpy(lab).to(device)
 
 
+def build_loaders(args):
+    """The two training loaders of train_arco_3d.py:158-190: LAHeartWithIndex (first --labeled_num cases labeled, the
+    rest unlabeled) with RandomRotFlip -> RandomCrop(patch) -> ToTensor, drawn with replacement, last batch dropped."""
+    from torch.utils.data import ConcatDataset, DataLoader
+    from torch.utils.data.sampler import RandomSampler
+    from .dataloaders import Compose
+    from .dataloaders.la_heart import LAHeartWithIndex, RandomCrop, RandomRotFlip, ToTensor
+    tf = lambda: Compose([RandomRotFlip(), RandomCrop(args.patch_size), ToTensor()])
+    db_l = LAHeartWithIndex(base_dir=args.root_path, split="train", num=None, transform=tf(), index=args.labeled_num, label_type=1)
+    db_u = LAHeartWithIndex(base_dir=args.root_path, split="train", num=None, transform=tf(), index=args.labeled_num, label_type=0)
+    while len(db_l) < len(db_u):                                           # :171-172
+        db_l = ConcatDataset([db_l, db_l])
+    mk = lambda ds: DataLoader(ds, batch_size=args.batch_size, sampler=RandomSampler(data_source=ds, replacement=True),
+                               drop_last=True, pin_memory=True)
+    return mk(db_l), mk(db_u)
+
+
 def train(args, snapshot_path):
-    if not args.synthetic:
-        raise NotImplementedError("dataset readers (dataloaders/la_heart.py, h5py) are outside the hot path "
-                                  "(SURVEY §8f row 4); run with --synthetic 1")
     rank, world = adist.init()
     dev = torch.device("cuda", adist.local_rank())
     torch.cuda.set_device(dev)
     stepper = ArcoStep3D(args, dev)
     b = args.batch_size
-    iters_per_epoch = 100
+    loaders = None
+    if args.synthetic:
+        iters_per_epoch = 100
+    else:
+        loaders = build_loaders(args)
+        iters_per_epoch = len(loaders[1])
+        logging.info("{} iterations per epoch".format(iters_per_epoch))
+        resume = "../model/{}_{}_labeledfinal/{}/iter_30000.pth".format(args.resume, args.labeled_num, args.model)
+        if os.path.exists(resume):                                      # stage-1 weights (:198-201), when present
+            sd = torch.load(resume, map_location="cpu")
+            stepper.isd.model.load_state_dict(sd); stepper.isd.ema_model.load_state_dict(sd)
+            for pl in stepper.plans:
+                pl.valid = False
+        else:
+            logging.info("no stage-1 checkpoint at {}: training from the random initialisation".format(resume))
     max_epoch = args.max_iterations // iters_per_epoch + 1
+    l_iter = u_iter = None
     while stepper.iter_num < args.max_iterations:
         it = stepper.iter_num
-        l_img, l_lab = synthetic_volume_batch(b, args.patch_size, args.num_classes, 2 * it * world + rank, dev)
-        u_img, _ = synthetic_volume_batch(b, args.patch_size, args.num_classes, (2 * it + 1) * world + rank, dev)
+        if args.synthetic:
+            l_img, l_lab = synthetic_volume_batch(b, args.patch_size, args.num_classes, 2 * it * world + rank, dev)
+            u_img, _ = synthetic_volume_batch(b, args.patch_size, args.num_classes, (2 * it + 1) * world + rank, dev)
+        else:
+            if it % iters_per_epoch == 0:
+                l_iter, u_iter = iter(loaders[0]), iter(loaders[1])
+            l_next, u_next = next(l_iter), next(u_iter)
+            l_img, l_lab = l_next['image'].to(dev, non_blocking=True), l_next['label'].to(dev, non_blocking=True).long()
+            u_img = u_next['image'].to(dev, non_blocking=True)
         loss, reco = stepper.step(l_img, l_lab, u_img, it // iters_per_epoch, max_epoch)
         if rank == 0:
             logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))

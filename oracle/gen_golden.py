@@ -245,13 +245,14 @@ def gen_nets(mods):
 
 
 # ---------------------------------------------------------------- G4 trainer glue
-def _pull_functions(path, names):
-    """exec selected top-level functions of a reference script without importing it."""
+def _pull_functions(path, names, extra=None):
+    """exec selected top-level functions / classes of a reference script without importing it."""
     src = open(path).read()
     tree = ast.parse(src)
     ns = {"torch": torch, "np": np, "F": torch.nn.functional, "nn": torch.nn}
+    ns.update(extra or {})
     for node in tree.body:
-        if isinstance(node, ast.FunctionDef) and node.name in names:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
             exec(compile(ast.Module([node], []), path, "exec"), ns)
     return ns, src.splitlines()
 
@@ -439,9 +440,47 @@ def gen_mix():
     print("g7_mix", len(out))
 
 
+# ---------------------------------------------------------------- G8 data ingest transforms
+def gen_ingest():
+    """The per-sample transforms and the two-stream sampler of dataloaders/dataset.py and dataloaders/la_heart.py,
+    pulled out of the source text (the modules import h5py / torchvision, absent here)."""
+    import itertools
+    from scipy import ndimage
+    from scipy.ndimage import zoom
+    from torch.utils.data.sampler import Sampler
+    extra = dict(ndimage=ndimage, zoom=zoom, random=random, itertools=itertools, Sampler=Sampler)
+    d2, _ = _pull_functions(os.path.join(ref_shim.REF, "dataloaders", "dataset.py"),
+                            {"random_rot_flip", "random_rotate", "random_crop", "RandomGenerator", "TwoStreamBatchSampler",
+                             "iterate_once", "iterate_eternally", "grouper"}, extra)
+    d3, _ = _pull_functions(os.path.join(ref_shim.REF, "dataloaders", "la_heart.py"), {"RandomCrop", "RandomRotFlip", "ToTensor"}, extra)
+    out = {}
+    for seed in fx.INGEST_SEEDS:
+        img, lab = fx.ingest_slice(seed)
+        seed_all(seed)
+        r = d2["RandomGenerator"]([32, 40])({'image': img, 'label': lab})
+        out[f"gen{seed}_image"], out[f"gen{seed}_label"] = r['image'].numpy(), r['label'].numpy()
+        out[f"gen{seed}_probe"] = np.array((float(np.random.uniform()), random.random()))
+        vol, vlab = fx.ingest_volume(seed)
+        seed_all(seed)
+        r = d3["ToTensor"]()(d3["RandomRotFlip"]()(d3["RandomCrop"]((16, 12, 16))({'image': vol, 'label': vlab})))
+        out[f"vol{seed}_image"], out[f"vol{seed}_label"] = r['image'].numpy(), r['label'].numpy().astype(np.int8)
+        out[f"vol{seed}_probe"] = np.array((float(np.random.uniform()), random.random()))
+    for name in ("random_rot_flip", "random_rotate", "random_crop"):
+        img, lab = fx.ingest_slice(99, (40, 36))
+        seed_all(3)
+        a, b = d2[name](img, lab)
+        out[f"{name}_image"], out[f"{name}_label"] = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    seed_all(11)
+    smp = d2["TwoStreamBatchSampler"](list(range(7)), list(range(7, 30)), 6, 4)
+    out["two_stream"] = np.array([list(b) for _ in range(3) for b in smp], dtype=np.int64)
+    out["two_stream_len"] = np.array(len(smp))
+    np.savez_compressed(os.path.join(OUT, "g8_ingest.npz"), **out)
+    print("g8_ingest", len(out))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
@@ -449,3 +488,4 @@ if __name__ == "__main__":
     if "g5" in which: gen_eqv()
     if "g6" in which: gen_eval3d(mods)
     if "g7" in which: gen_mix()
+    if "g8" in which: gen_ingest()

@@ -242,3 +242,17 @@ def mix_inputs(seed, b, c, spatial, n_cls):
     target = torch.from_numpy(rs.randint(0, n_cls, size=(b, *spatial)).astype(np.int64))
     logits = torch.from_numpy(rs.uniform(size=(b, *spatial)).astype(np.float32))
     return data, target, logits
+
+
+# data-ingest cases (g8): slices / volumes the reference's transforms are run on
+INGEST_SEEDS = [0, 1, 2, 3, 4, 5, 6, 7]
+
+
+def ingest_slice(seed, shape=(50, 44), n_cls=4):
+    rs = np.random.RandomState(1000 + seed)
+    return rs.uniform(size=shape).astype(np.float32), blob_labels(rs, 1, shape, n_cls)[0].astype(np.uint8)
+
+
+def ingest_volume(seed, shape=(20, 18, 14)):
+    rs = np.random.RandomState(2000 + seed)
+    return rs.uniform(size=shape).astype(np.float32), (rs.uniform(size=shape) > 0.7).astype(np.uint8)
