@@ -11,8 +11,9 @@ N1-N5, T1, L1-L6, O1) on hand-written HIP kernels.  One process per GPU; with WO
 gradients are all-reduced and new negative keys all-gathered over RCCL (arco_amd/dist.py).
 Every loss term of the reference step is here: contrastive (k1), unsupervised CE (k3), CE + Dice, the TPS
 equivariance term (k2) and - opt-in, --revisit 1, it has no gradient path - the revisiting loss (k4); so is the mixing
-strategy of --apply_aug (arco_amd/augment.py).  Not built (SURVEY §8 out of scope / "next"): dataset readers and
-the PIL colour jitter / blur of batch_transform (identity on the synthetic path).
+strategy of --apply_aug (arco_amd/augment.py) and, with --synthetic 0, the ACDC / MM slice loaders (build_loaders).
+Not built (SURVEY §8 out of scope / "next"): the Synapse / LiTS / JHU datasets and the PIL colour jitter / blur of
+batch_transform (the identity here).
 """
 import argparse
 import logging

@@ -2,10 +2,11 @@
 code/train_arco_3d.py.  Every flag of train_arco_3d.py:26-87 is accepted with the same name / type /
 default (they equal the 2-D trainer's except --patch_size [112,112,80], --func asmc, --k5 0.1).
 
-`ArcoStep3D.step` follows train_arco_3d.py:257-415 restricted to the hot-path loss term: V-Net student /
-teacher forwards, FeatureExtractor_3d, the two 1x1x1 q_representation convs (D=16), the 5-D contrastive
-loss (arco_amd.loss_helper), SGD-Nesterov, EMA.  batch_transform is the identity in the reference's 3-D
-pipeline (augment_3d.py:133-159), cutmix/TPS/other loss terms are outside the hot path.
+`ArcoStep3D.step` follows train_arco_3d.py:257-415: V-Net student / teacher forwards, FeatureExtractor_3d, the two
+1x1x1 q_representation convs (D=16), the 5-D contrastive loss (arco_amd.loss_helper), CE + Dice, unsupervised CE, the
+mixing strategy of --apply_aug, the equivariance block (--eqv_pass), the opt-in revisiting loss (--revisit),
+SGD-Nesterov, EMA.  batch_transform is the identity in the reference's 3-D pipeline (augment_3d.py:133-159).
+--synthetic 0 trains from an LA dataset directory (build_loaders); --conv_mma selects reduced-precision MFMA operands.
 """
 import logging
 import os
