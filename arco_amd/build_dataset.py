@@ -2,6 +2,9 @@
 `<base_dir>/train_slices.list` (ACDC) or `train_slices.txt` (MM) names the training slices under
 `<base_dir>/data/slices/<case>.{h5,npz}`; the first `index` entries form the labeled set (label_type=1), the rest the
 unlabeled set; `val.list` names whole volumes under `<base_dir>/data/`."""
+import os
+
+import numpy as np
 from torch.utils.data.dataset import Dataset
 
 from .dataloaders._io import read_case, read_list
@@ -32,4 +35,37 @@ class BaseDataSetsWithIndex(Dataset):
         if self.split == "train" and self.transform is not None:
             sample = self.transform(sample)
         sample["idx"] = idx
+        return sample
+
+
+class Synapse_datasetWithIndex(Dataset):
+    """npz slice datasets of the Synapse / LiTS / JHU experiments (code/build_dataset.py:159-200): `<list_dir>/<split>.txt`
+    (`<split>_40.txt` for LiTS, `<split>_vol.txt` for test / val volumes) names the cases, training slices are
+    `<base_dir>/<name>.npz` with 'image' / 'label'; the first `index` entries are the labeled set (label_type=1)."""
+
+    def __init__(self, base_dir, list_dir, split, transform=None, index=221, label_type=1):
+        self.transform, self.split, self.data_dir, self.index, self.label_type = transform, split, base_dir, index, label_type
+        if 'Lits' in list_dir:
+            name = split + '_40.txt'
+        elif split in ("test", "val"):
+            name = split + '_vol.txt'
+        else:
+            name = split + '.txt'
+        names = read_list(os.path.join(list_dir, name))
+        self.sample_list = names[:index] if label_type == 1 else names[index:]
+
+    def __len__(self):
+        return len(self.sample_list)
+
+    def __getitem__(self, idx):
+        name = self.sample_list[idx]
+        if self.split == "train":
+            with np.load(os.path.join(self.data_dir, name + '.npz')) as data:
+                image, label = data['image'], data['label']
+        else:
+            image, label = read_case(self.data_dir + "/{}.npy".format(name))        # <name>.npy.h5 volumes
+        sample = {'image': image, 'label': label}
+        if self.transform:
+            sample = self.transform(sample)
+        sample['case_name'] = name
         return sample

@@ -12,8 +12,8 @@ gradients are all-reduced and new negative keys all-gathered over RCCL (arco_amd
 Every loss term of the reference step is here: contrastive (k1), unsupervised CE (k3), CE + Dice, the TPS
 equivariance term (k2) and - opt-in, --revisit 1, it has no gradient path - the revisiting loss (k4); so is the mixing
 strategy of --apply_aug (arco_amd/augment.py) and, with --synthetic 0, the ACDC / MM slice loaders (build_loaders).
-Not built (SURVEY §8 out of scope / "next"): the Synapse / LiTS / JHU datasets and the PIL colour jitter / blur of
-batch_transform (the identity here).
+Not built (SURVEY §8 out of scope / "next"): the PIL colour jitter / blur of batch_transform (the identity here) and
+the stage-1 pre-training script.
 """
 import argparse
 import logging
@@ -96,6 +96,7 @@ def build_parser():
     p.add_argument('--dense_teacher', type=int, default=0, help='1: materialise the dense teacher representation')
     p.add_argument('--head_levels', type=int, default=2, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
+    p.add_argument('--list_dir', type=str, default='', help='list directory of the npz experiments (default: the reference\'s hard-wired paths)')
     p.add_argument('--revisit', type=int, default=0,
                    help='1: also compute k4*loss_q, the revisiting loss (train_arco_2d.py:126-136,334,398-400). It has no '
                         'gradient path (it only changes the logged loss) and needs the dense student and teacher '
@@ -389,18 +390,30 @@ def synthetic_batch(b, patch, n_cls, seed, device, in_chns=1):
 def build_loaders(args):
     """The two training loaders of train_arco_2d.py:161-215 (ACDC / MM slice datasets): the first
     patients_to_slices(exp, labeled_num) slices are the labeled stream, the rest the unlabeled one; RandomGenerator per
-    sample; each loader draws with replacement and drops the last incomplete batch.  The Synapse / LiTS / JHU npz
-    datasets of the other --exp branches (dataloaders/dataset_synapse.py) are not built."""
+    sample; each loader draws with replacement and drops the last incomplete batch.  The Synapse / LiTS / JHU branches
+    use the npz slice dataset with the reference's hard-wired list directories (--list_dir overrides them)."""
     from torch.utils.data import ConcatDataset, DataLoader
     from torch.utils.data.sampler import RandomSampler
-    from .build_dataset import BaseDataSetsWithIndex
+    from .build_dataset import BaseDataSetsWithIndex, Synapse_datasetWithIndex
     from .dataloaders import Compose
     from .dataloaders.dataset import RandomGenerator
-    if any(k in args.exp for k in ("Syn", "syn", "Lits", "LiTS", "jhu", "JHU")):
-        raise NotImplementedError("only the ACDC / MM slice datasets (BaseDataSetsWithIndex) are built")
     n_lab = patients_to_slices(args.exp, args.labeled_num)
-    sets = [BaseDataSetsWithIndex(base_dir=args.root_path, split="train", num=None,
-                                  transform=Compose([RandomGenerator(args.patch_size)]), index=n_lab, label_type=t) for t in (1, 0)]
+    tf = lambda: Compose([RandomGenerator(args.patch_size)])
+    # npz experiments (:162-187): (sub-directory of --root_path, the reference's hard-wired list directory)
+    npz = None
+    if "Syn" in args.exp or "syn" in args.exp:
+        npz = ('/data/Synapse/train_npz', '/data/data/Synapse/data/lists_Synapse')
+    elif "Lits" in args.exp or "LiTS" in args.exp:
+        npz = ('/train_npz_40', '/data/data/Lits')
+    elif "jhu" in args.exp or "JHU" in args.exp:
+        npz = ('', '/data/data/JHUData')
+    if npz is not None:
+        list_dir = getattr(args, "list_dir", "") or npz[1]
+        sets = [Synapse_datasetWithIndex(base_dir=args.root_path + npz[0], split="train", transform=tf(), index=n_lab, label_type=t,
+                                         list_dir=list_dir) for t in (1, 0)]
+    else:
+        sets = [BaseDataSetsWithIndex(base_dir=args.root_path, split="train", num=None, transform=tf(), index=n_lab, label_type=t)
+                for t in (1, 0)]
     db_l, db_u = sets
     while len(db_l) < len(db_u):                                           # :196-197
         db_l = ConcatDataset([db_l, db_l])

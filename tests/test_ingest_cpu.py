@@ -121,3 +121,30 @@ def test_la_dataset_reads(tmp_path):
     _seed(0)
     s = ds_u[1]
     assert tuple(s["image"].shape) == (1, 16, 16, 12) and s["label"].dtype == torch.int64 and s["idx"] == 1
+
+
+def test_npz_slice_dataset(tmp_path):
+    """Synapse / LiTS / JHU style npz datasets (build_dataset.py:159-200): list naming rules and the labeled split."""
+    from arco_amd.build_dataset import Synapse_datasetWithIndex
+    from arco_amd.dataloaders import Compose
+    from arco_amd.dataloaders.dataset import RandomGenerator
+    data, lists = tmp_path / "train_npz_40", tmp_path / "Lits"
+    os.makedirs(data); os.makedirs(lists)
+    names = [f"case{i:04d}_slice{i:03d}" for i in range(9)]
+    for i, n in enumerate(names):
+        img, lab = fx.ingest_slice(400 + i, (30, 34), n_cls=3)
+        np.savez(data / (n + ".npz"), image=img, label=lab)
+    (lists / "train_40.txt").write_text("\n".join(names) + "\n")
+    lab_set = Synapse_datasetWithIndex(base_dir=str(data), list_dir=str(lists), split="train", index=3, label_type=1,
+                                       transform=Compose([RandomGenerator([32, 32])]))
+    unl_set = Synapse_datasetWithIndex(base_dir=str(data), list_dir=str(lists), split="train", index=3, label_type=0)
+    assert lab_set.sample_list == names[:3] and unl_set.sample_list == names[3:] and len(unl_set) == 6
+    _seed(2)
+    s = lab_set[1]
+    assert s["case_name"] == names[1] and s["image"].dtype == torch.float32 and s["label"].dtype == torch.uint8
+    raw = unl_set[0]
+    np.testing.assert_array_equal(raw["image"], fx.ingest_slice(403, (30, 34), n_cls=3)[0])
+    other = tmp_path / "lists_Synapse"
+    os.makedirs(other)
+    (other / "train.txt").write_text("\n".join(names[:4]) + "\n")
+    assert len(Synapse_datasetWithIndex(base_dir=str(data), list_dir=str(other), split="train", index=1, label_type=0)) == 3
