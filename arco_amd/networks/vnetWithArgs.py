@@ -82,7 +82,8 @@ class UpsamplingDeconvBlock(nn.Module):
         conv, bn = self.conv[0], self.conv[1]
         ci, co = conv.weight.shape[0], conv.weight.shape[1]
         w2 = conv.weight.permute(2, 3, 4, 1, 0).reshape(8 * co, ci, 1, 1, 1)      # [(dx,dy,dz), co][ci]
-        y = ops.conv(x, w2, conv.bias.repeat(8))
+        # training: the bias only shifts the input of the train-mode BN below -> analytically zero gradient
+        y = ops.conv(x, w2, conv.bias.repeat(8), bias_grad_zero=self.training)
         z = ops.depth_to_space3(y)
         if self.training:
             return ops.bn_act(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, momentum=bn.momentum,

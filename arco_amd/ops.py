@@ -344,8 +344,9 @@ class ConvFn(torch.autograd.Function):
     nn.Conv3d in vnetWithArgs.py:182, model_3D.py:25-35, train_arco_3d.py:206-209."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual):
+    def forward(ctx, x, weight, bias, residual, bias_grad_zero=False):
         L.require_gpu(x, weight)
+        ctx.bias_grad_zero = bool(bias_grad_zero)
         taps = _taps(weight)
         xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
@@ -377,8 +378,10 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dyr, ldy, nv * d3 * h * w, co)
-        return dx, dw, db, (dy if ctx.res_tensor and ctx.needs_input_grad[3] else None)
+            # bias_grad_zero: the output feeds a train-mode BatchNorm, whose backward makes the column sums of dy
+            # exactly zero in exact arithmetic (see ConvBnActFn.backward) - no pass over dy for rounding noise
+            db = _zeros_cached((co,), dy.device) if ctx.bias_grad_zero else colsum(dyr, ldy, nv * d3 * h * w, co)
+        return dx, dw, db, (dy if ctx.res_tensor and ctx.needs_input_grad[3] else None), None
 
 
 def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out, ld_out=None, groups=1):
@@ -622,8 +625,10 @@ class BilinearFn(torch.autograd.Function):
         return dx, None, None
 
 
-def conv(x, weight, bias=None, residual=False):
-    return ConvFn.apply(x, weight, bias, residual)
+def conv(x, weight, bias=None, residual=False, bias_grad_zero=False):
+    """bias_grad_zero=True: the caller normalises the result with a train-mode BatchNorm, so the bias gradient is
+    analytically zero and is returned as exact zeros instead of a reduction over the output gradient."""
+    return ConvFn.apply(x, weight, bias, residual, bias_grad_zero)
 
 
 _LAST_CAT_BUF = None
