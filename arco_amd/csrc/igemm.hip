@@ -1215,6 +1215,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
       for (int r = 0; r < rstep; ++r) a += red[(r * q4 + qq) * 4 + e];
       partial[(long)blockIdx.x * C + c] = a;
     }
+  } else if (C <= 256) {
+    // narrow / odd channel counts (the 2-class out_conv of the V-Net: 4 M rows x 2 channels): thread = (row lane, channel)
+    const int rstep = 256 / C, c = threadIdx.x % C, tr = threadIdx.x / C;
+    float s = 0.f;
+    if (tr < rstep)
+      for (long r = r0 + tr; r < r1; r += rstep) s += X[r * ldx + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float a = 0.f;
+      for (int r = 0; r < rstep; ++r) a += red[r * C + threadIdx.x];
+      partial[(long)blockIdx.x * C + threadIdx.x] = a;
+    }
   } else {
     for (int c = threadIdx.x; c < C; c += 256) {
       float s = 0.f;
