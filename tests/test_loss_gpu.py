@@ -124,3 +124,69 @@ def test_no_grad_and_cpu_input_rejected():
         nk, loss = compute_contra_memobank_loss(d["rep"], d["label_l"], d["label_u"], d["prob_l"], d["prob_u"],
                                                 d["low_mask"], d["high_mask"], bank, ptr, qs, d["rep_teacher"], **lkw)
     assert not loss.requires_grad
+
+
+def test_loss_full_size_properties():
+    """BASELINE.json configs[1] size (16 images 256x256, D = 496, 4 classes, 4096-key queues, 256 queries, 512
+    negatives, smc): the oracle needs minutes there, so the HIP path is held to size-independent properties -
+    bit-exact sampled indices against the host sampler replay, FIFO banks made of teacher rows, cosine scale
+    invariance, a gradient that lives on the sampled anchor pixels only and is orthogonal to each anchor row."""
+    from arco_amd import samplers
+    from arco_amd.loss_helper_3d import compute_contra_memobank_loss
+    b, C, D, sp, Q, Nn, qsize = 8, 4, 496, (256, 256), 256, 512, 4096
+    small = fx.loss_inputs(77, b=b, n_cls=C, feat=1, spatial=sp)           # labels / probabilities / masks (CPU, small)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rep = torch.randn((2 * b, *sp, D), device="cuda", generator=g).permute(0, 3, 1, 2)          # channels-last, 2 GB
+    rep_t = torch.randn((2 * b, *sp, D), device="cuda", generator=g).permute(0, 3, 1, 2)
+    d = {k: v.cuda() for k, v in small.items() if k not in ("rep", "rep_teacher")}
+    lkw = dict(func='smc', num_queries=Q, num_negatives=Nn, delta_n=0.97)
+
+    def run(scale, steps=3):
+        bank, ptr, qs = fx.fresh_bank(C, D, qsize, 'zeros')
+        out = []
+        for s in range(steps):
+            seed_all(90 + s)
+            r = (rep * scale).detach().requires_grad_(True)
+            tr = {}
+            nk, loss = compute_contra_memobank_loss(r, d["label_l"], d["label_u"], d["prob_l"], d["prob_u"], d["low_mask"],
+                                                    d["high_mask"], bank, ptr, qs, rep_t, _trace=tr, **lkw)
+            loss.backward()
+            out.append((nk, float(loss.detach()), r.grad, tr))
+        return out, bank, ptr
+
+    out1, bank, ptr = run(1.0)
+    # banks: FIFO of at most queue_size teacher rows, pointer = queue_size once full
+    tr = out1[-1][3]
+    lists, tot = tr["lists"], tr["totals"]
+    flat_t = rep_t.permute(0, 2, 3, 1).reshape(-1, D)
+    for c in range(C):          # every step enqueues the same key pixels: bank = teacher rows of the last qsize of them
+        n_keys = int(tot[2 * C + c])
+        assert out1[-1][0][c] == n_keys and 3 * n_keys >= qsize, (c, n_keys)
+        assert bank[c][0].shape == (qsize, D) and int(ptr[c]) == qsize and bank[c][0].is_cuda
+        rows = lists[C + c][:n_keys].long()
+        assert torch.equal(bank[c][0], flat_t[torch.cat((rows, rows, rows))[-qsize:]])
+    # sampled indices: bit-exact replay of the host samplers from the same generator state (last step: full banks)
+    seed_all(92)
+    exp_anchor, exp_neg = [], []
+    for c in range(C):
+        n_anchor = int(tot[C + c])
+        exp_anchor.append(samplers.grid_monte_carlo_sample(n_anchor, Q))
+        exp_neg.append(samplers.grid_monte_carlo_sample(qsize, Q * Nn))
+    for c in range(C):
+        assert torch.equal(tr["anchor_idx"][c].cpu(), exp_anchor[c]) and torch.equal(tr["neg_idx"][c].cpu(), exp_neg[c])
+        assert int(tr["anchor_idx"][c].max()) < int(tot[C + c]) and int(tr["neg_idx"][c].max()) < qsize
+    # gradient: non-zero exactly on the sampled anchor pixels, orthogonal to the anchor rows (cosine similarity)
+    grad = out1[-1][2].permute(0, 2, 3, 1).reshape(-1, D)
+    nz = (grad != 0).any(dim=1)
+    pix = torch.cat([lists[c][:tot[C + c]].long()[tr["anchor_idx"][c].cuda()] for c in range(C)])
+    assert set(torch.nonzero(nz).flatten().tolist()) <= set(pix.tolist()) and int(nz.sum()) >= 0.9 * len(set(pix.tolist()))
+    flat_r = rep.permute(0, 2, 3, 1).reshape(-1, D)
+    upix = torch.unique(pix)
+    dots = (grad[upix] * flat_r[upix]).sum(1).abs() / (grad[upix].norm(dim=1) * flat_r[upix].norm(dim=1) + 1e-30)
+    assert float(dots.max()) < 1e-4
+    # cosine similarity: scaling the student representation changes nothing but the gradient's scale
+    out2, _, _ = run(4.0)
+    for (nk1, l1, g1, _), (nk2, l2, g2, _) in zip(out1, out2):
+        assert nk1 == nk2 and abs(l1 - l2) < 2e-5 * max(1.0, abs(l1))
+        np.testing.assert_allclose((4.0 * g2[:, :, ::16, ::16]).cpu().numpy(), g1[:, :, ::16, ::16].cpu().numpy(), rtol=2e-3, atol=1e-9)
+    assert 0.5 < out1[-1][1] < 20.0
