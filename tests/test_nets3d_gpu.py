@@ -403,3 +403,32 @@ def test_conv1x1x1_reduced_precision_mma(mma, tol):
         err = float((got.detach().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
         assert 1e-6 < err < t, err
     close(wg.grad, wr.grad, rtol=5e-4, atol=5e-4 * float(wr.grad.abs().max()))     # 1x1x1 weight gradients stay fp32
+
+
+@pytest.mark.parametrize("ci,co", [(1, 16), (16, 16)])
+def test_conv3d_full_size_properties(ci, co):
+    """BASELINE.json configs[2] size (112x112x80 volumes): linearity and shift equivariance of the 3x3x3 kernels
+    (first-layer taps-as-K kernel and the generic one) where a torch fp32 reference would take minutes on the CPU, plus
+    an exact check of one interior and the eight corner voxels against a direct sum."""
+    from arco_amd import ops
+    rs = np.random.RandomState(ci)
+    sp = (112, 112, 80)
+    g = torch.Generator(device="cuda").manual_seed(ci)
+    x1 = torch.randn((2, *sp, ci), device="cuda", generator=g).permute(0, 4, 1, 2, 3)
+    x2 = torch.randn((2, *sp, ci), device="cuda", generator=g).permute(0, 4, 1, 2, 3)
+    wt = rnd(rs, co, ci, 3, 3, 3, scale=1 / np.sqrt(27 * ci)).cuda()
+    with torch.no_grad():
+        y1, y2 = ops.conv(x1, wt, None), ops.conv(x2, wt, None)
+        y12 = ops.conv((0.5 * x1 + x2).contiguous(memory_format=torch.channels_last_3d), wt, None)
+        np.testing.assert_allclose((0.5 * y1 + y2)[:, :, ::7, ::5, ::3].cpu().numpy(), y12[:, :, ::7, ::5, ::3].cpu().numpy(), rtol=1e-4, atol=2e-5)
+        # shift by one voxel along every axis: interior outputs move with the input
+        xs = torch.roll(x1, shifts=(1, 1, 1), dims=(2, 3, 4)).contiguous(memory_format=torch.channels_last_3d)
+        ys = ops.conv(xs, wt, None)
+        np.testing.assert_allclose(ys[:, :, 3:-2, 3:-2, 3:-2][:, :, ::9, ::9, ::9].cpu().numpy(),
+                                   y1[:, :, 2:-3, 2:-3, 2:-3][:, :, ::9, ::9, ::9].cpu().numpy(), rtol=1e-5, atol=1e-6)
+        # direct sums at the corners (zero padding) and one interior voxel
+        xp = torch.nn.functional.pad(x1[:1].double(), (1, 1, 1, 1, 1, 1))
+        for (a, b, c) in [(0, 0, 0), (111, 0, 0), (0, 111, 0), (0, 0, 79), (111, 111, 79), (111, 0, 79), (0, 111, 79), (111, 111, 0), (50, 60, 33)]:
+            patch = xp[0, :, a:a + 3, b:b + 3, c:c + 3]
+            ref = (wt.double() * patch.unsqueeze(0)).sum(dim=(1, 2, 3, 4))
+            np.testing.assert_allclose(y1[0, :, a, b, c].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
