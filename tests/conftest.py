@@ -11,6 +11,11 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (it is git-ignored): build it once (hipcc cross-compiles without a GPU)
+    lib = os.path.join(ROOT, "arco_amd", "lib", "libarco_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "arco_amd", "csrc")], check=False, capture_output=True)
 
 
 def pytest_collection_modifyitems(config, items):
