@@ -99,14 +99,14 @@ def test_base_dataset_splits_and_reads(tmp_path):
     val = BaseDataSetsWithIndex(base_dir=root, split="val")
     v = val[0]
     assert v["image"].shape == (3, 40, 36) and v["label"].shape == (3, 40, 36)      # whole volume, no transform
+    from arco_amd.dataloaders._io import read_case
     with pytest.raises(FileNotFoundError):
-        BaseDataSetsWithIndex(base_dir=root, split="train", index=0, label_type=0).__class__.__getitem__(
-            type("X", (), {"sample_list": ["missing"], "split": "train", "_base_dir": root, "transform": None})(), 0)
+        read_case(os.path.join(root, "data", "slices", "missing_case"))
 
 
 def test_la_dataset_reads(tmp_path):
     from arco_amd.dataloaders.la_heart import LAHeartWithIndex, RandomCrop, ToTensor
-    from torchvision_free_compose import Compose
+    from arco_amd.dataloaders import Compose
     base = tmp_path / "LA" / "2018LA_Seg_Training Set"
     cases = [f"case{i}" for i in range(5)]
     for i, c in enumerate(cases):
