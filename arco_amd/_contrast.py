@@ -36,6 +36,7 @@ key_gather_hook = None
 count_gather_hook = None
 # callable(keys[n,D], cls, queue_size) -> only the rows that survive the FIFO truncation (rank order)
 tail_gather_hook = None
+proto_reduce_hook = None     # data parallel: (proto [C, D], counts [C]) -> count-weighted mean over ranks (dist.reduce_prototypes)
 
 
 def _ceil(x, m):
@@ -312,6 +313,8 @@ def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace
         for c in range(C):
             key_rows.append(allk[off:off + takes[c]])
             off += takes[c]
+    if proto_reduce_hook is not None:        # class means over the GLOBAL batch (one [C, D+1] all-reduce)
+        pl.proto = proto_reduce_hook(pl.proto, pl.totals[:C])
     pl.D = D
     pl.new_keys = []
     for c in range(C):

@@ -11,8 +11,8 @@ xGMI on ROCm).  SURVEY §8e.  The path shards by batch; three exchange steps exi
     truncation and only those rows are broadcast (gather_tail_keys) - typically the last rank's queue_size
     rows: 8 MB per class instead of world x 8 MB, no host synchronisation.  gather_keys is the generic
     all-gather-v (counts, then rows padded to the max count) behind the public dequeue_and_enqueue.
- 3. (optional) all-reduce of prototype partial sums - not enabled: prototypes are per-rank means,
-    like the per-replica statistics under the reference's nn.DataParallel.
+ 3. all-reduce of the prototype partial sums: one [C, D+1] buffer (count-weighted class means + counts), so the
+    positive of every class is the mean over the GLOBAL batch's valid pixels (reduce_prototypes).
 Works unchanged with backend "gloo" on CPU tensors for the world_size-2 tests.
 """
 import os
@@ -48,6 +48,7 @@ def init(backend=None):
         _contrast.key_gather_hook = gather_keys
         _contrast.count_gather_hook = gather_counts
         _contrast.tail_gather_hook = gather_tail_keys
+        _contrast.proto_reduce_hook = reduce_prototypes
         return td.get_rank(), td.get_world_size()
     return 0, 1
 
@@ -69,6 +70,17 @@ def allreduce_grads(optimizer):
     td.all_reduce(g, op=td.ReduceOp.SUM)
     g.mul_(1.0 / td.get_world_size())
     optimizer._touched.update(range(len(optimizer.params)))
+
+
+@torch.no_grad()
+def reduce_prototypes(proto, counts):
+    """Class prototypes over the global batch: sum_r n_r * proto_r / sum_r n_r with n_r the rank's count of valid
+    pixels of the class (a class absent on a rank contributes nothing; absent everywhere -> NaN, as the reference's
+    mean of an empty selection).  One all-reduce of [C, D+1] floats."""
+    n = counts.to(torch.float32).view(-1, 1)
+    buf = torch.cat((torch.where(n > 0, proto * n, torch.zeros_like(proto)), n), dim=1)
+    td.all_reduce(buf, op=td.ReduceOp.SUM)
+    return (buf[:, :-1] / buf[:, -1:]).contiguous()
 
 
 @torch.no_grad()

@@ -56,6 +56,18 @@ def _worker(rank, world, port, q):
     gathered = [torch.empty_like(bank) for _ in range(world)]
     td.all_gather(gathered, bank)
     assert all(torch.equal(g, bank) for g in gathered)
+    # 5b. prototypes: count-weighted mean over ranks == mean over the concatenated rows; absent classes handled
+    rows = [torch.randn(5 + 3 * rr, 6, generator=torch.Generator().manual_seed(40 + rr)) for rr in range(world)]
+    cls = [torch.tensor([0, 1, 1, 0, 1]), torch.tensor([1, 1, 3, 1, 3, 1, 1, 3])]          # class 0 only on rank 0, 3 only on rank 1, 2 nowhere
+    mine, lab = rows[rank], cls[rank]
+    counts = torch.tensor([int((lab == c).sum()) for c in range(4)])
+    proto = torch.stack([mine[lab == c].mean(0) if counts[c] > 0 else torch.full((6,), float("nan")) for c in range(4)])
+    got = adist.reduce_prototypes(proto, counts)
+    allr, alll = torch.cat(rows), torch.cat(cls)
+    for c in (0, 1, 3):
+        assert torch.allclose(got[c], allr[alll == c].mean(0), atol=1e-6), (rank, c)
+    assert bool(torch.isnan(got[2]).all())
+    assert _contrast.proto_reduce_hook is adist.reduce_prototypes
     # 6. tail gather: only the rows that survive the truncation travel; the bank equals the all-gather-v one
     D = 4
     for qs, n_by_rank in ((8, [20, 3]), (8, [5, 20]), (8, [2, 3]), (8, [0, 5]), (8, [6, 0]), (8, [0, 0]), (5, [5, 5])):
