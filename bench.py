@@ -185,9 +185,9 @@ def main():
             "unit": "steps/s (16-image steps, all GPUs)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ACDC 2D 256x256 bs=16 on 1xMI355X, stratified sampler + 4096-key/class queue "
+            "config": {"workload": f"ACDC 2D 256x256 bs=16 per GPU on {world}xMI355X, stratified sampler + 4096-key/class queue "
                                    "(BASELINE.json configs[1])", "batch_size_per_stream": b, "images_per_step_per_gpu": 2 * b,
-                       "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc",
+                       "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc", "apply_aug": args.apply_aug,
                        "loss_terms": "k1*contrastive + k3*unsupervised + CE + Dice (k2 = 0)",
                        "parallelism": f"dp{world}"},
             "contrastive_loss_fwd_ms_per_step": round(sum(e0.elapsed_time(e1) for evs in stepper.loss_events for e0, e1 in evs)
