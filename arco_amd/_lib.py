@@ -72,6 +72,7 @@ _SIGS = {
     "arco_softmax_rows": [_P, _L, _L, _I, _L, _P, _P, _P, _P, _P],
     "arco_label_onehot": [_P, _L, _I, _L, _P, _P],
     "arco_entropy_masks": [_P, _P, _P, _L, _L, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P],
+    "arco_entropy_masks_phase": [_I, _I, _P, _P, _P, _L, _L, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P],
     "arco_sup_loss_fwd": [_P, _L, _L, _I, _P, _P, _P, _P],
     "arco_sup_loss_bwd": [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _P],
     "arco_unsup_loss_fwd": [_P, _L, _I, _L, _I, _P, _P, _F, _P, _P, _P],
@@ -86,6 +87,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
     "arco_chan_stats_blocks": ([_L], _I),
     "arco_sel_state_bytes": ([], _L),
+    "arco_sel_state_offset": ([_I], _L),
     "arco_pack_desc_bytes": ([], _L),
     "arco_bn_defer_desc_bytes": ([], _L),
     "arco_seg_ws_doubles": ([_L, _I, _I], _L),

@@ -1,6 +1,7 @@
 // Step glue of the trainer (train_arco_2d.py:284-286,342-393,492-498):
 // class softmax / max / argmax / entropy, one-hot labels, exact np.percentile (linear) of the
 // entropy via radix select, and the low/high entropy masks.  HBM-bound, one pixel per lane.
+#include <cstddef>
 #include <cstring>
 #include "common.h"
 
@@ -607,6 +608,32 @@ int arco_unsup_loss_bwd(const float* X, long ld, int B, long P, int C, const int
 }
 
 long arco_sel_state_bytes() { return (long)sizeof(SelState); }
+// byte offsets of the two fields a data-parallel run sums over ranks between the phases below
+long arco_sel_state_offset(int field) { return field == 0 ? (long)offsetof(SelState, n_valid) : (long)offsetof(SelState, hist); }
+
+// The same selection in phases, so that a data-parallel caller can all-reduce the valid count (after phase 0) and the
+// four 256-bin histograms (after every phase 2) across ranks and every rank arrives at the percentiles of the GLOBAL
+// batch.  phase 0: clear + count valid, 1: ranks from the count, 2: histogram of digit `pass`,
+// 3: pick the bucket of digit `pass`, 4: masks.
+int arco_entropy_masks_phase(int phase, int pass, const float* ent, const int64_t* lab_l, const int64_t* lab_u, long n_l,
+                             long n_u, double q_lo, double q_hi, void* state, float* low, float* high, void* stream) {
+  ARCO_CHECK_ARG(n_u > 0 && state && phase >= 0 && phase <= 4 && pass >= 0 && pass < 4);
+  hipStream_t st = as_stream(stream);
+  SelState* s = reinterpret_cast<SelState*>(state);
+  const unsigned g = gl_grid(n_u) > 256 ? 256 : gl_grid(n_u);
+  switch (phase) {
+    case 0:
+      (void)hipMemsetAsync(s, 0, sizeof(SelState), st);
+      hipLaunchKernelGGL(sel_count_kernel, dim3(g), dim3(256), 0, st, lab_u, n_u, s);
+      break;
+    case 1: hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(1), 0, st, s, q_lo, q_hi); break;
+    case 2: hipLaunchKernelGGL(sel_hist_kernel, dim3(g), dim3(256), 0, st, ent, lab_u, n_u, pass, s); break;
+    case 3: hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(64), 0, st, pass, s); break;
+    default:
+      hipLaunchKernelGGL(entropy_masks_kernel, dim3(gl_grid(n_l + n_u)), dim3(256), 0, st, ent, lab_l, lab_u, n_l, n_u, s, low, high);
+  }
+  return arco_launch_status();
+}
 
 // masks from the entropy percentiles q_lo / q_hi over pixels with lab_u >= 0; state = arco_sel_state_bytes() scratch
 int arco_entropy_masks(const float* ent, const int64_t* lab_l, const int64_t* lab_u, long n_l, long n_u, double q_lo,

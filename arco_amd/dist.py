@@ -11,6 +11,8 @@ xGMI on ROCm).  SURVEY §8e.  The path shards by batch; three exchange steps exi
     truncation and only those rows are broadcast (gather_tail_keys) - typically the last rank's queue_size
     rows: 8 MB per class instead of world x 8 MB, no host synchronisation.  gather_keys is the generic
     all-gather-v (counts, then rows padded to the max count) behind the public dequeue_and_enqueue.
+ 4. entropy percentiles of the global batch: the device radix select runs in phases and its valid count and
+    four 256-bin digit histograms are summed over ranks (allreduce_sum) - every rank derives the same thresholds.
  3. all-reduce of the prototype partial sums: one [C, D+1] buffer (count-weighted class means + counts), so the
     positive of every class is the mean over the GLOBAL batch's valid pixels (reduce_prototypes).
 Works unchanged with backend "gloo" on CPU tensors for the world_size-2 tests.
@@ -49,6 +51,8 @@ def init(backend=None):
         _contrast.count_gather_hook = gather_counts
         _contrast.tail_gather_hook = gather_tail_keys
         _contrast.proto_reduce_hook = reduce_prototypes
+        from . import glue
+        glue.state_reduce_hook = allreduce_sum
         return td.get_rank(), td.get_world_size()
     return 0, 1
 
@@ -70,6 +74,14 @@ def allreduce_grads(optimizer):
     td.all_reduce(g, op=td.ReduceOp.SUM)
     g.mul_(1.0 / td.get_world_size())
     optimizer._touched.update(range(len(optimizer.params)))
+
+
+@torch.no_grad()
+def allreduce_sum(t):
+    """In-place sum over ranks of a (contiguous, integer) device tensor - the valid count and the digit histograms of the
+    entropy-percentile selection (thresholds of the global batch)."""
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t
 
 
 @torch.no_grad()

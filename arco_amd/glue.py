@@ -48,6 +48,9 @@ def label_onehot(inputs, num_segments):
     return out
 
 
+state_reduce_hook = None      # data parallel: in-place sum over ranks of an integer device tensor (dist.allreduce_sum)
+
+
 @torch.no_grad()
 def entropy_masks(pred_u, label_l_raw, label_u_raw, alpha_t):
     """low_mask_all / high_mask_all of train_arco_2d.py:352-393: entropy of softmax(pred_u), exact
@@ -63,8 +66,26 @@ def entropy_masks(pred_u, label_l_raw, label_u_raw, alpha_t):
     sp = tuple(pred_u.shape[2:])
     low = torch.empty((int(ll.shape[0]) + b, 1, *sp), dtype=torch.float32, device=dev)
     high = torch.empty_like(low)
-    L.call("arco_entropy_masks", L.ptr(ent), L.ptr(ll), L.ptr(lu), n_l, n_u, float(alpha_t), float(100 - alpha_t),
-           L.ptr(state), L.ptr(low), L.ptr(high))
+    if state_reduce_hook is None:
+        L.call("arco_entropy_masks", L.ptr(ent), L.ptr(ll), L.ptr(lu), n_l, n_u, float(alpha_t), float(100 - alpha_t),
+               L.ptr(state), L.ptr(low), L.ptr(high))
+        return low, high
+    # data parallel: percentiles of the GLOBAL batch - the valid count and every digit histogram are summed over ranks
+    o_cnt, o_hist = L.query("arco_sel_state_offset", 0), L.query("arco_sel_state_offset", 1)
+    cnt = state[o_cnt:o_cnt + 8].view(torch.int64)
+    hist = state[o_hist:o_hist + 4 * 256 * 4].view(torch.int32)
+
+    def phase(ph, ps=0):
+        L.call("arco_entropy_masks_phase", ph, ps, L.ptr(ent), L.ptr(ll), L.ptr(lu), n_l, n_u, float(alpha_t),
+               float(100 - alpha_t), L.ptr(state), L.ptr(low), L.ptr(high))
+    phase(0)
+    state_reduce_hook(cnt)
+    phase(1)
+    for ps in range(4):
+        phase(2, ps)
+        state_reduce_hook(hist)
+        phase(3, ps)
+    phase(4)
     return low, high
 
 

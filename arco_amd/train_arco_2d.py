@@ -97,6 +97,9 @@ def build_parser():
     p.add_argument('--head_levels', type=int, default=2, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
     p.add_argument('--list_dir', type=str, default='', help='list directory of the npz experiments (default: the reference\'s hard-wired paths)')
+    p.add_argument('--dp_local_thresholds', type=int, default=0,
+                   help='data parallel only. 0: entropy percentiles of the global batch (5 small all-reduces per step); '
+                        '1: every rank thresholds its own batch')
     p.add_argument('--revisit', type=int, default=0,
                    help='1: also compute k4*loss_q, the revisiting loss (train_arco_2d.py:126-136,334,398-400). It has no '
                         'gradient path (it only changes the logged loss) and needs the dense student and teacher '
@@ -424,6 +427,8 @@ def build_loaders(args):
 
 def train(args, snapshot_path):
     rank, world = adist.init()
+    if getattr(args, "dp_local_thresholds", 0):
+        glue.state_reduce_hook = None
     dev = torch.device("cuda", adist.local_rank())
     torch.cuda.set_device(dev)
     stepper = ArcoStep2D(args, dev)

@@ -266,6 +266,8 @@ def build_loaders(args):
 
 def train(args, snapshot_path):
     rank, world = adist.init()
+    if getattr(args, "dp_local_thresholds", 0):
+        glue.state_reduce_hook = None
     dev = torch.device("cuda", adist.local_rank())
     torch.cuda.set_device(dev)
     stepper = ArcoStep3D(args, dev)

@@ -210,6 +210,12 @@ long arco_sel_state_bytes();
 /* exact np.percentile(entropy[valid], q) (linear) by device radix select -> low/high masks              */
 int arco_entropy_masks(const float* ent, const int64_t* lab_l, const int64_t* lab_u, long n_l, long n_u, double q_lo,
                        double q_hi, void* state, float* low, float* high, void* stream);
+/*      the same in phases for data-parallel runs: all-reduce the field at arco_sel_state_offset(0) (uint64 valid count)
+ *      after phase 0 and the field at arco_sel_state_offset(1) (uint32 hist[4][256]) after every phase 2; phases:
+ *      0 clear + count, 1 ranks, 2 histogram of digit `pass`, 3 pick digit `pass`, 4 masks                              */
+long arco_sel_state_offset(int field);
+int arco_entropy_masks_phase(int phase, int pass, const float* ent, const int64_t* lab_l, const int64_t* lab_u, long n_l,
+                             long n_u, double q_lo, double q_hi, void* state, float* low, float* high, void* stream);
 
 /* ---- L4  HOST entry points (CPU memory, no stream): native replay of the stratified samplers
  *      grid_monte_carlo_sample / grid_as_monte_carlo_sample (loss_helper_3d.py:120-268) on the
