@@ -9,7 +9,7 @@ random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 eqv = int(os.environ.get("EQV_PASS", "0"))     # 1: with the reference's equivariance block (one more student forward per step)
 args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1", "--num_classes", "2",
-                                     "--eqv_pass", str(eqv), "--conv_mma", os.environ.get("CONV_MMA", "f32")])
+                                     "--eqv_pass", str(eqv), "--conv_mma", os.environ.get("CONV_MMA", "f32"), "--graph_train", os.environ.get("GRAPH_TRAIN", "0")])
 if len(sys.argv) > 4:
     args.patch_size = [int(v) for v in sys.argv[2:5]]
 st = T3.ArcoStep3D(args, "cuda:0")
