@@ -190,7 +190,9 @@ def main():
                        "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc", "apply_aug": args.apply_aug,
                        "loss_terms": "k1*contrastive + k3*unsupervised + CE + Dice (k2 = 0)",
                        "parallelism": f"dp{world}"},
-            "contrastive_loss_fwd_ms_per_step": round(sum(e0.elapsed_time(e1) for evs in stepper.loss_events for e0, e1 in evs)
+            # compute_contra_memobank_loss on the GPU clock: masks | lists, prototypes, keys, banks | anchors, row-sparse head,
+            # InfoNCE INCLUDING its analytic gradient w.r.t. the anchors (the loss's backward is computed in the forward)
+            "contrastive_loss_ms_per_step": round(sum(e0.elapsed_time(e1) for evs in stepper.loss_events for e0, e1 in evs)
                                                       / max(1, len(stepper.loss_events)), 3),
             "roofline": roof,
         }
