@@ -30,7 +30,8 @@ REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
 
 def build_parser():
     p = _build_parser_2d()
-    p.set_defaults(patch_size=[112, 112, 80], func='asmc', k5=0.1, root_path='../data/ACDC')
+    p.set_defaults(patch_size=[112, 112, 80], func='asmc', k5=0.1, exp='LA/example_training', model='vnet', max_iterations=6000,
+                   root_path='/home/weicheng/selfLearning/DTC/data/2018LA_Seg_Training Set')       # train_arco_3d.py:27-36
     p.add_argument('--eqv_pass', type=int, default=1,
                    help='1: run the equivariance block of train_arco_3d.py:368-388 (warp + one more student forward); '
                         'its loss only enters the objective at iteration 0 there (:390-393), afterwards it is a logged '

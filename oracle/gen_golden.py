@@ -478,9 +478,32 @@ def gen_ingest():
     print("g8_ingest", len(out))
 
 
+# ---------------------------------------------------------------- G9 command-line surface
+def gen_flags():
+    """Every add_argument of the two reference trainers (name, default, type) read from their source with ast."""
+    import json
+
+    def flags(path):
+        out = {}
+        for n in ast.walk(ast.parse(open(path).read())):
+            if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "add_argument" and n.args and isinstance(n.args[0], ast.Constant):
+                d = {}
+                for kw in n.keywords:
+                    if kw.arg in ("default", "type", "nargs"):
+                        try:
+                            d[kw.arg] = ast.literal_eval(kw.value)
+                        except Exception:
+                            d[kw.arg] = ast.unparse(kw.value)
+                out[n.args[0].value] = d
+        return out
+    tab = {"2d": flags(os.path.join(ref_shim.REF, "train_arco_2d.py")), "3d": flags(os.path.join(ref_shim.REF, "train_arco_3d.py"))}
+    json.dump(tab, open(os.path.join(OUT, "g9_flags.json"), "w"), indent=0, sort_keys=True)
+    print("g9_flags", len(tab["2d"]), len(tab["3d"]))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
@@ -489,3 +512,4 @@ if __name__ == "__main__":
     if "g6" in which: gen_eval3d(mods)
     if "g7" in which: gen_mix()
     if "g8" in which: gen_ingest()
+    if "g9" in which: gen_flags()

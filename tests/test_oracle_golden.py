@@ -311,3 +311,23 @@ def test_cutout_mask_host_draws_match_oracle():
         got = augment.generate_cutout_mask(size) if len(size) == 2 else augment.generate_cutout_mask_3d(size)
         np.testing.assert_array_equal(got.numpy(), exp)
         assert float(np.random.uniform()) == float((np.random.seed(5), orc.cutout_mask(list(size)), np.random.uniform())[2])
+
+
+@pytest.mark.parametrize("which", ["2d", "3d"])
+def test_trainer_flags_match_reference(which):
+    """every add_argument of train_arco_2d.py / train_arco_3d.py is accepted with the same name, type and
+    default (table read from the reference's source, oracle/gen_golden.py g9)."""
+    import json
+    from arco_amd import train_arco_2d, train_arco_3d
+    tab = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g9_flags.json")))[which]
+    parser = (train_arco_2d if which == "2d" else train_arco_3d).build_parser()
+    mine = {a.option_strings[0]: a for a in parser._actions if a.option_strings}
+    assert len(tab) >= 40
+    for name, d in tab.items():
+        assert name in mine, name
+        if "default" in d:
+            assert mine[name].default == d["default"], (name, mine[name].default, d["default"])
+        if "type" in d:
+            assert getattr(mine[name].type, "__name__", str(mine[name].type)) == d["type"], name
+        if "nargs" in d:
+            assert mine[name].nargs == d["nargs"], name
