@@ -497,8 +497,20 @@ def gen_flags():
                 out[n.args[0].value] = d
         return out
     tab = {"2d": flags(os.path.join(ref_shim.REF, "train_arco_2d.py")), "3d": flags(os.path.join(ref_shim.REF, "train_arco_3d.py"))}
+    # call signatures of the public names the trainers import (parameter names and defaults, in order)
+    import importlib
+    import inspect
+    mods = ref_shim.load()
+    sigs = {}
+    for mod, names in fx.PUBLIC_NAMES.items():
+        m = mods.get(mod) or importlib.import_module(mod)
+        for n in names:
+            o = getattr(m, n)
+            ps = inspect.signature(o.__init__ if inspect.isclass(o) else o).parameters.values()
+            sigs[f"{mod}.{n}"] = [[q.name, None if q.default is inspect.Parameter.empty else repr(q.default)] for q in ps]
+    tab["signatures"] = sigs
     json.dump(tab, open(os.path.join(OUT, "g9_flags.json"), "w"), indent=0, sort_keys=True)
-    print("g9_flags", len(tab["2d"]), len(tab["3d"]))
+    print("g9_flags", len(tab["2d"]), len(tab["3d"]), len(sigs))
 
 
 if __name__ == "__main__":

@@ -256,3 +256,16 @@ def ingest_slice(seed, shape=(50, 44), n_cls=4):
 def ingest_volume(seed, shape=(20, 18, 14)):
     rs = np.random.RandomState(2000 + seed)
     return rs.uniform(size=shape).astype(np.float32), (rs.uniform(size=shape) > 0.7).astype(np.uint8)
+
+
+# public names whose call signatures are pinned to the reference (g9): reference module -> names
+PUBLIC_NAMES = {
+    "loss_helper_3d": ["compute_contra_memobank_loss", "grid_monte_carlo_sample", "grid_as_monte_carlo_sample",
+                       "monte_carlo_sample", "as_monte_carlo_sample", "dequeue_and_enqueue"],
+    "loss_helper": ["compute_contra_memobank_loss", "grid_monte_carlo_sample", "grid_as_monte_carlo_sample",
+                    "monte_carlo_sample", "as_monte_carlo_sample", "dequeue_and_enqueue"],
+    "networks.unetWithArgs": ["UNet", "ConvBlock", "DownBlock", "UpBlock", "Encoder", "Decoder"],
+    "networks.vnetWithArgs": ["VNet", "ConvBlock", "DownsamplingConvBlock", "UpsamplingDeconvBlock"],
+    "model_2D": ["FeatureExtractor", "ISD", "create_model"],
+    "model_3D": ["FeatureExtractor_3d", "ISD_3d", "create_model_3d"],
+}

@@ -331,3 +331,20 @@ def test_trainer_flags_match_reference(which):
             assert getattr(mine[name].type, "__name__", str(mine[name].type)) == d["type"], name
         if "nargs" in d:
             assert mine[name].nargs == d["nargs"], name
+
+
+def test_public_signatures_match_reference():
+    """the names the trainers import keep the reference's parameter lists (names, order, defaults); this
+    package may only APPEND optional parameters (e.g. in_chns=1, _trace=None)."""
+    import importlib
+    import inspect
+    import json
+    sigs = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g9_flags.json")))["signatures"]
+    assert len(sigs) >= 28
+    for key, ref in sigs.items():
+        mod, name = key.rsplit(".", 1)
+        o = getattr(importlib.import_module("arco_amd." + mod), name)
+        ps = list(inspect.signature(o.__init__ if inspect.isclass(o) else o).parameters.values())
+        mine = [[q.name, None if q.default is inspect.Parameter.empty else repr(q.default)] for q in ps]
+        assert mine[:len(ref)] == ref, (key, mine, ref)
+        assert all(d is not None for _, d in mine[len(ref):]), key           # anything extra is optional
