@@ -509,6 +509,11 @@ def gen_flags():
             ps = inspect.signature(o.__init__ if inspect.isclass(o) else o).parameters.values()
             sigs[f"{mod}.{n}"] = [[q.name, None if q.default is inspect.Parameter.empty else repr(q.default)] for q in ps]
     tab["signatures"] = sigs
+    # state_dict keys and shapes (checkpoints load both ways)
+    tab["state_keys"] = {}
+    for mod, name, kw in fx.STATE_CASES:
+        net = getattr(mods.get(mod) or importlib.import_module(mod), name)(**kw)
+        tab["state_keys"][f"{mod}.{name}"] = [[k, list(v.shape)] for k, v in net.state_dict().items()]
     json.dump(tab, open(os.path.join(OUT, "g9_flags.json"), "w"), indent=0, sort_keys=True)
     print("g9_flags", len(tab["2d"]), len(tab["3d"]), len(sigs))
 

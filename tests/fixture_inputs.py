@@ -269,3 +269,16 @@ PUBLIC_NAMES = {
     "model_2D": ["FeatureExtractor", "ISD", "create_model"],
     "model_3D": ["FeatureExtractor_3d", "ISD_3d", "create_model_3d"],
 }
+
+
+# modules whose state_dict keys / shapes are pinned to the reference (g9): (module, class, kwargs)
+STATE_CASES = [
+    ("model_2D", "ISD", dict(K=36, m=0.99, Ts=0.01, Tt=0.1, num_classes=4, latent_pooling_size=1, latent_feature_size=512,
+                             output_pooling_size=8, train_encoder=True, train_decoder=True)),
+    ("model_2D", "FeatureExtractor", dict(fea_dim=[256, 128, 64, 32, 16], output_dim=496)),
+    ("model_3D", "ISD_3d", dict(K=36, m=0.99, Ts=0.01, Tt=0.1, num_classes=2, latent_pooling_size=1, latent_feature_size=512,
+                                output_pooling_size=8, train_encoder=True, train_decoder=True)),
+    ("model_3D", "FeatureExtractor_3d", dict(fea_dim=[128, 64, 32, 16, 16], output_dim=16)),
+    ("networks.vnetWithArgs", "VNet", dict(n_channels=1, n_classes=2, normalization='batchnorm', has_dropout=True)),
+    ("networks.unetWithArgs", "UNet", dict(in_chns=1, class_num=4)),
+]

@@ -348,3 +348,16 @@ def test_public_signatures_match_reference():
         mine = [[q.name, None if q.default is inspect.Parameter.empty else repr(q.default)] for q in ps]
         assert mine[:len(ref)] == ref, (key, mine, ref)
         assert all(d is not None for _, d in mine[len(ref):]), key           # anything extra is optional
+
+
+def test_state_dict_keys_match_reference():
+    """Checkpoints interchange with the reference: same state_dict keys, order and shapes for ISD / ISD_3d (student +
+    teacher + queues), the feature extractors, U-Net and V-Net (g9)."""
+    import importlib
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g9_flags.json")))["state_keys"]
+    for mod, name, kw in fx.STATE_CASES:
+        net = getattr(importlib.import_module("arco_amd." + mod), name)(**kw)
+        mine = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+        assert mine == ref[f"{mod}.{name}"], f"{mod}.{name}"
+    assert len(ref["model_2D.ISD"]) == 300 and len(ref["networks.vnetWithArgs.VNet"]) == 205
