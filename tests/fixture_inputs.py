@@ -268,6 +268,8 @@ PUBLIC_NAMES = {
     "networks.vnetWithArgs": ["VNet", "ConvBlock", "DownsamplingConvBlock", "UpsamplingDeconvBlock"],
     "model_2D": ["FeatureExtractor", "ISD", "create_model"],
     "model_3D": ["FeatureExtractor_3d", "ISD_3d", "create_model_3d"],
+    "tps.rand_tps": ["RandTPS"],
+    "tps.rand_tps_3d": ["RandTPS"],
 }
 
 

@@ -340,7 +340,7 @@ def test_public_signatures_match_reference():
     import inspect
     import json
     sigs = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g9_flags.json")))["signatures"]
-    assert len(sigs) >= 28
+    assert len(sigs) >= 30
     for key, ref in sigs.items():
         mod, name = key.rsplit(".", 1)
         o = getattr(importlib.import_module("arco_amd." + mod), name)
