@@ -772,7 +772,12 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
   if (taps == 1) {
     if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16, true>(a, st, nmb);
     if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 16, true>(a, st, nmb);
-    if (a.M * (long)a.Npad <= 4096l * 1024) return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
+    if (a.M * (long)a.Npad <= 4096l * 1024) {
+      // few-tile GEMMs (<= 1024 anchor rows of the row-sparse head, the 16 x 16 level): 32-row tiles double the workgroups
+      const long tiles64 = ((a.M + 63) / 64) * ((a.Npad + 63) / 64);
+      if (tiles64 < 192 && a.stat_groups <= 1) return launch_igemm<1, 32, 64, 2, 2, 32, true>(a, st, nmb);
+      return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
+    }
     // N-tile 224 (14 sub-tiles, 7 per wave column) when it pads N less than 128 does: 448 = 2 x 224 exactly
     // (64 x 224: 56 accumulator registers, 3 workgroups per CU; 128 x 224 needs 276 registers -> 1 wave per SIMD)
     if ((a.Npad + 223) / 224 * 224 < (a.Npad + 127) / 128 * 128) return launch_igemm<1, 64, 224, 2, 2, 16, true>(a, st, nmb);
