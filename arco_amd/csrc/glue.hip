@@ -109,23 +109,41 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__
     if (c) atomicAdd(&(&st->hist[0][0])[i], c);
   }
 }
-__global__ void sel_pick_kernel(int pass, SelState* st) {
-  const int r = threadIdx.x;
-  if (r < 4) {
-    const int shift = 24 - 8 * pass;
-    unsigned long long k = st->k[r], run = 0;
-    int d = 0;
-    for (; d < 256; ++d) { const unsigned long long c = st->hist[r][d]; if (run + c > k) break; run += c; }
-    if (d > 255) d = 255;
+// one wave per order statistic: lane l owns bins 4l .. 4l+3; inclusive wave scan of the lane sums finds the lane, then
+// the bin, whose cumulative count first exceeds the remaining rank k (the serial 256-bin walk took 20 us per pass)
+__global__ __launch_bounds__(256) void sel_pick_kernel(int pass, SelState* st) {
+  const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int shift = 24 - 8 * pass;
+  const unsigned long long k = st->k[r];
+  unsigned long long c[4], tot = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { c[e] = st->hist[r][4 * lane + e]; tot += c[e]; }
+  unsigned long long incl = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const unsigned long long excl = incl - tot;
+  const bool mine = incl > k && excl <= k;                      // exactly one lane, unless k >= the grand total
+  const unsigned long long any = __ballot(mine);
+  __syncthreads();                                              // every wave has read its histogram row
+  if (any ? mine : lane == 63) {
+    unsigned long long run = excl; int d = 4 * lane;
+    if (any) { for (int e = 0; e < 4; ++e) { if (run + c[e] > k) { d = 4 * lane + e; break; } run += c[e]; } }
+    else { d = 255; run = incl; }                                // k beyond the total (no valid pixel): bin 255, as the serial walk
     st->k[r] = k - run;
     st->prefix[r] |= ((unsigned int)d) << shift;
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) st->hist[r][4 * lane + e] = 0;
   __syncthreads();
-  if (r < 4) for (int d = 0; d < 256; ++d) st->hist[r][d] = 0;
-  if (pass == 3 && r < 2) {      // numpy _lerp in float64
-    const double a = (double)fkey_inv(st->prefix[2 * r]), b = (double)fkey_inv(st->prefix[2 * r + 1]);
-    const double t = st->gamma[r], diff = b - a;
-    st->thr[r] = t >= 0.5 ? b - diff * (1.0 - t) : a + diff * t;
+  if (pass == 3 && threadIdx.x < 2) {      // numpy _lerp in float64
+    const int j = threadIdx.x;
+    __threadfence_block();
+    const double a = (double)fkey_inv(st->prefix[2 * j]), b = (double)fkey_inv(st->prefix[2 * j + 1]);
+    const double t = st->gamma[j], diff = b - a;
+    st->thr[j] = t >= 0.5 ? b - diff * (1.0 - t) : a + diff * t;
   }
 }
 // low/high masks [B,1,P] (train_arco_2d.py:362-393): labeled part = (label_l >= 0); unlabeled part =
@@ -628,7 +646,7 @@ int arco_entropy_masks_phase(int phase, int pass, const float* ent, const int64_
       break;
     case 1: hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(1), 0, st, s, q_lo, q_hi); break;
     case 2: hipLaunchKernelGGL(sel_hist_kernel, dim3(g), dim3(256), 0, st, ent, lab_u, n_u, pass, s); break;
-    case 3: hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(64), 0, st, pass, s); break;
+    case 3: hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(256), 0, st, pass, s); break;
     default:
       hipLaunchKernelGGL(entropy_masks_kernel, dim3(gl_grid(n_l + n_u)), dim3(256), 0, st, ent, lab_l, lab_u, n_l, n_u, s, low, high);
   }
@@ -646,7 +664,7 @@ int arco_entropy_masks(const float* ent, const int64_t* lab_l, const int64_t* la
   hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(1), 0, st, s, q_lo, q_hi);
   for (int pass = 0; pass < 4; ++pass) {
     hipLaunchKernelGGL(sel_hist_kernel, dim3(gl_grid(n_u) > 256 ? 256 : gl_grid(n_u)), dim3(256), 0, st, ent, lab_u, n_u, pass, s);
-    hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(64), 0, st, pass, s);
+    hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(256), 0, st, pass, s);
   }
   hipLaunchKernelGGL(entropy_masks_kernel, dim3(gl_grid(n_l + n_u)), dim3(256), 0, st, ent, lab_l, lab_u, n_l, n_u, s,
                      low, high);
