@@ -173,11 +173,12 @@ __global__ __launch_bounds__(256) void masked_row_sum_kernel(const float* __rest
         for (int e = 0; e < 4; ++e) acc[cc][di][e] += __shfl_xor(acc[cc][di][e], o, 64);
   }
   if (sub == 0) {
-    for (int cc = 0; cc < nc; ++cc)
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc)          // static indices: a runtime-bounded loop sent the accumulators to scratch memory
 #pragma unroll
       for (int di = 0; di < NDI; ++di) {
         const int d = (di * lpr + dl) * 4;
-        if (d < D) *reinterpret_cast<f32x4*>(&red[((long)wid * 8 + cc) * D + d]) = acc[cc][di];
+        if (cc < nc && d < D) *reinterpret_cast<f32x4*>(&red[((long)wid * 8 + cc) * D + d]) = acc[cc][di];
       }
   }
   __syncthreads();
@@ -239,11 +240,12 @@ __global__ __launch_bounds__(256) void weighted_row_sum_kernel(const float* __re
         for (int e = 0; e < 4; ++e) acc[cc][di][e] += __shfl_xor(acc[cc][di][e], o, 64);
   }
   if (sub == 0) {
-    for (int cc = 0; cc < nc; ++cc)
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc)          // static indices: a runtime-bounded loop sent the accumulators to scratch memory
 #pragma unroll
       for (int di = 0; di < NDI; ++di) {
         const int d = (di * lpr + dl) * 4;
-        if (d < D) *reinterpret_cast<f32x4*>(&red[((long)wid * 8 + cc) * D + d]) = acc[cc][di];
+        if (cc < nc && d < D) *reinterpret_cast<f32x4*>(&red[((long)wid * 8 + cc) * D + d]) = acc[cc][di];
       }
   }
   __syncthreads();
