@@ -1175,12 +1175,15 @@ __global__ __launch_bounds__(256) void wgrad_image3d_kernel(WgradArgs a) {
   }
 }
 
+// EL consecutive slab elements x GR slab groups per 512-thread block.  <16, 32> for launches with many slabs (a
+// 9 x 32 x 32 block has only 144 workgroups at 64 elements each, streaming 19 MB: latency-bound at 11 us); <64, 8>
+// when there are few slabs (most of 32 groups would idle).  Slab layout [tap][co][ci], dW torch layout.
+template <int EL, int GR>
 __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int taps, int CoutPad, int CinPad,
                                     int Cout, int Cin, float* __restrict__ dW, int accumulate) {
-  // block = 64 consecutive slab elements (coalesced) x 8 slab groups; slab layout [tap][co][ci], dW torch layout.
-  __shared__ float red[8][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long j = (long)blockIdx.x * 64 + tx;
+  __shared__ float red[GR][EL];
+  const int tx = threadIdx.x % EL, ty = threadIdx.x / EL;
+  const long j = (long)blockIdx.x * EL + tx;
   const long tot = (long)taps * Cout * Cin;
   float s0 = 0.f, s1 = 0.f;
   int ci = 0, co = 0, tap = 0;
@@ -1188,16 +1191,26 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restri
     ci = j % Cin; const long r = j / Cin; co = r % Cout; tap = r / Cout;
     const long off = ((long)tap * CoutPad + co) * CinPad + ci, stride = (long)taps * CoutPad * CinPad;
     int c = ty;
-    for (; c + 8 < chunks; c += 16) { s0 += partial[off + (long)c * stride]; s1 += partial[off + (long)(c + 8) * stride]; }
-    for (; c < chunks; c += 8) s0 += partial[off + (long)c * stride];
+    for (; c + GR < chunks; c += 2 * GR) { s0 += partial[off + (long)c * stride]; s1 += partial[off + (long)(c + GR) * stride]; }
+    for (; c < chunks; c += GR) s0 += partial[off + (long)c * stride];
   }
   red[ty][tx] = s0 + s1;
   __syncthreads();
   if (ty == 0 && j < tot) {
-    const float s = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < GR; g += 4) s += (red[g][tx] + red[g + 1][tx]) + (red[g + 2][tx] + red[g + 3][tx]);
     const long o = ((long)co * Cin + ci) * taps + tap;
     dW[o] = accumulate ? dW[o] + s : s;
   }
+}
+static void launch_wgrad_reduce(hipStream_t st, const float* ws, int chunks, int taps, int CoutPad, int CinPad, int Cout, int Cin,
+                                float* dW, int accumulate) {
+  const long tot = (long)Cout * Cin * taps;
+  if (chunks > 16)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<16, 32>), dim3((tot + 15) / 16), dim3(512), 0, st, ws, chunks, taps, CoutPad, CinPad, Cout, Cin, dW, accumulate);
+  else
+    hipLaunchKernelGGL((wgrad_reduce_kernel<64, 8>), dim3((tot + 63) / 64), dim3(512), 0, st, ws, chunks, taps, CoutPad, CinPad, Cout, Cin, dW, accumulate);
 }
 
 // column sums (bias gradient): out[c] = sum_pix X[pix][c].  float4 lanes along channels,
@@ -1395,9 +1408,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     const long chunks = tiles < 512 ? tiles : 512;              // <= the slab count arco_wgrad_ws_floats reserves
     if (taps == 27) hipLaunchKernelGGL(wgrad_image3d_kernel<3>, dim3((unsigned)chunks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_image3d_kernel<1>, dim3((unsigned)chunks), dim3(256), 0, st, a);
-    const long tot = (long)Cout * Cin * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(512), 0, st, ws, (int)chunks, taps, a.CoutPad,
-                       a.CinPad, Cout, Cin, dW, accumulate);
+    launch_wgrad_reduce(st, ws, (int)chunks, taps, a.CoutPad, a.CinPad, Cout, Cin, dW, accumulate);
     return arco_launch_status();
   }
   if (taps >= 9) {       // spatial kernels: all taps of a plane per block, operands staged once (halo in LDS)
@@ -1431,9 +1442,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     else if (hco == 16 && hci == 32) WH(16, 32);
     else WH(16, 16);
 #undef WH
-    const long tot = (long)Cout * Cin * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(512), 0, st, ws, (int)chunks, taps, a.CoutPad,
-                       a.CinPad, Cout, Cin, dW, accumulate);
+    launch_wgrad_reduce(st, ws, (int)chunks, taps, a.CoutPad, a.CinPad, Cout, Cin, dW, accumulate);
     return arco_launch_status();
   }
   const long yz = (long)(a.CoutPad / co_b) * (a.CinPad / ci_b) * taps;
@@ -1459,9 +1468,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   else if (co_b == 16 && ci_b == 32) WG(16, 32);
   else WG(16, 16);
 #undef WG
-  const long tot = (long)Cout * Cin * taps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(512), 0, st, ws, (int)chunks, taps, a.CoutPad,
-                     a.CinPad, Cout, Cin, dW, accumulate);
+  launch_wgrad_reduce(st, ws, (int)chunks, taps, a.CoutPad, a.CinPad, Cout, Cin, dW, accumulate);
   return arco_launch_status();
 }
 
