@@ -57,6 +57,37 @@ def init(backend=None):
     return 0, 1
 
 
+def anchors_for_rank(num_queries, mode="split"):
+    """Anchors this rank samples per class (SURVEY 8e).  "split": num_queries // world (+1 on the first num_queries % world
+    ranks), so all ranks together draw exactly num_queries queries per class like the single-process reference and the
+    rank-averaged loss is the reference's estimator on the concatenated batch; "full": num_queries on every rank."""
+    if not is_dist() or mode == "full":
+        return int(num_queries)
+    world, rank = td.get_world_size(), td.get_rank()
+    return int(num_queries) // world + (1 if rank < int(num_queries) % world else 0)
+
+
+def seed_data_pipeline(seed, rank=None):
+    """Per-rank seeds for everything that draws DATA (call it after the models exist and their states have been
+    broadcast): python `random`, numpy's global RandomState (RandomGenerator / RandomRotFlip / RandomCrop, cutmix boxes,
+    TPS control points) and torch's CPU default generator (classmix labels, the stratified samplers) get `seed + rank`;
+    returns a torch.Generator seeded the same way for the loaders' RandomSampler.  With one seed on every rank a
+    data-parallel run would feed all ranks the same batches: the all-reduced gradient would equal the single-GPU one and
+    the gathered banks would hold world copies of the same keys.  world == 1 keeps `seed` (single-process runs stay
+    bit-identical to the reference's generator sequence)."""
+    import random
+    import numpy as np
+    if rank is None:
+        rank = td.get_rank() if is_dist() else 0
+    g = torch.Generator()
+    g.manual_seed(int(seed) + int(rank))
+    if rank:
+        random.seed(int(seed) + rank)
+        np.random.seed(int(seed) + rank)
+        torch.manual_seed(int(seed) + rank)
+    return g
+
+
 def broadcast_module_states(modules, src=0):
     """Same initial weights/buffers on every rank."""
     if not is_dist():

@@ -152,3 +152,14 @@ class GraphedTrain:
         from torch.utils import _pytree as pytree
         outs = _GraphedTrainFn.apply(self, x, *self.params)
         return pytree.tree_unflatten(list(outs), self.spec)
+
+
+def set_enabled(owner, flag):
+    """Enable / disable every GraphedForward / GraphedTrain held by `owner` (a trainer step object); returns the previous
+    flags so a caller (bench.py's eager roofline pass: HIP-event timing needs the kernels outside graphs) can restore them."""
+    prev = {}
+    for name, v in vars(owner).items():
+        if isinstance(v, (GraphedForward, GraphedTrain)):
+            prev[name] = v.enabled
+            v.enabled = flag if isinstance(flag, bool) else flag.get(name, v.enabled)
+    return prev

@@ -298,8 +298,20 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
                      device=dzr.device)
 
     def compute(out, accumulate):
+        prof = None
+        if PROFILE is not None and not torch.cuda.is_current_stream_capturing():
+            flop = 2.0 * taps * nb * d3 * h * w * co * ci
+            rec = PROFILE.setdefault(("wgrad", taps, co, ci), {"n": 0, "flop": 0.0, "timed": []})
+            rec["n"] += 1
+            rec["flop"] += flop
+            if rec["n"] % PROFILE_EVERY == 1 % PROFILE_EVERY:
+                prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                prof[0].record()
         L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
                accumulate, 2 if (CONV_MMA and taps == 27) else 0)
+        if prof is not None:
+            prof[1].record()
+            rec["timed"].append((prof[0], prof[1], flop, (taps, nb * d3 * h * w, co, ci)))
     return _grad_into(like, compute)
 
 

@@ -90,9 +90,9 @@ def build_parser():
     p.add_argument('--graphs', type=int, default=1, help='1: replay the no-grad U-Net forwards as HIP graphs')
     p.add_argument('--batched_passes', type=int, default=1,
                    help='1: labelled + unlabelled student (and teacher) forwards as one pass with two BatchNorm groups')
-    p.add_argument('--graph_train', type=int, default=0,
-                   help='1 (with --graphs 1): the student forward+backward passes are HIP graphs too (halves the '
-                        'host work per step; on an unloaded host the eager passes measured 2%% faster, DESIGN.md)')
+    p.add_argument('--graph_train', type=int, default=1,
+                   help='1 (with --graphs 1): the student forward+backward passes are HIP graphs too (a third of the '
+                        'host launch work per step, results identical); 0: eager launches')
     p.add_argument('--dense_teacher', type=int, default=0, help='1: materialise the dense teacher representation')
     p.add_argument('--head_levels', type=int, default=2, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
@@ -100,6 +100,9 @@ def build_parser():
     p.add_argument('--dp_local_thresholds', type=int, default=0,
                    help='data parallel only. 0: entropy percentiles of the global batch (5 small all-reduces per step); '
                         '1: every rank thresholds its own batch')
+    p.add_argument('--anchors_per_rank', type=str, default='split', choices=['split', 'full'],
+                   help='data parallel only (SURVEY 8e). split: every rank samples num_queries/world anchors per class, so the '
+                        'world draws the same total number of queries as the single-process reference; full: num_queries per rank')
     p.add_argument('--revisit', type=int, default=0,
                    help='1: also compute k4*loss_q, the revisiting loss (train_arco_2d.py:126-136,334,398-400). It has no '
                         'gradient path (it only changes the logged loss) and needs the dense student and teacher '
@@ -182,6 +185,10 @@ class ArcoStep2D:
         self.k_fe_ema.plans = [ops.PackPlan([self.k_feature_extractor], False)]
         self.plans = [plan_s] + [pl for pr in pairs for pl in pr.plans] + self.k_fe_ema.plans
         self.iter_num = 0
+        # HIP-event timing of the three contrastive-loss segments: only when a profiler asks for it (bench.py sets
+        # profile_loss); a training run records no events (no stream bubbles, nothing accumulates)
+        self.profile_loss = False
+        self.keep_debug = False          # tests: keep the last step's plan and anchor rows (self.debug)
         self.loss_events = []
         # no-grad forwards replayed as HIP graphs (one graph per call site: outputs are static buffers)
         use_graphs = bool(getattr(args, "graphs", 1))
@@ -197,6 +204,7 @@ class ArcoStep2D:
                                mode='affine', device=device)
         self.batched_passes = bool(getattr(args, "batched_passes", 1))
         self.s_train_lu = graphs.GraphedTrain(self.model, enabled=g_train)
+        self.s_train_tps = graphs.GraphedTrain(self.model, enabled=g_train)  # the equivariance term's student pass (:415)
         self.t_fwd_lu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -258,11 +266,15 @@ class ArcoStep2D:
             prob_l_t = glue.softmax(pred_l_t)
             prob_u_t = glue.softmax(pred_u_t)
             low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
+        prof = self.profile_loss
+        ev = ev2 = ev3 = None
+        if prof:
+            ev, ev2, ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+            ev[0].record()
         plan = C_.contrast_masks(label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all,
                                  delta_n=a.strong_threshold_u2pl)       # :341-401 (counts -> async D2H)
-        ev[1].record()
+        if prof:
+            ev[1].record()
         # ---- large GPU work queued while the host waits for the counters and samples
         if not batched:
             pred_l, _, l_fm = self.s_train_l(l_data)                     # :310
@@ -295,12 +307,14 @@ class ArcoStep2D:
         # ---- host: wait for the counters; everything that needs the COUNTS but not the sampled INDICES is queued
         #      first (row lists, prototypes, key rows, bank append, the supervised / unsupervised loss forwards), so the
         #      GPU has work while the host replays the samplers (bit-exact torch-CPU-generator sequence, ~2 ms)
-        C_.contrast_counts(plan, self.memobank, self.queue_size, a.num_queries, a.num_negatives)
-        ev2 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev2[0].record()
+        C_.contrast_counts(plan, self.memobank, self.queue_size,
+                           adist.anchors_for_rank(a.num_queries, getattr(a, "anchors_per_rank", "split")), a.num_negatives)
+        if prof:
+            ev2[0].record()
         C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size,
                             lazy_teacher=lazy_t, defer_anchor_pix=True)
-        ev2[1].record()
+        if prof:
+            ev2[1].record()
         # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340); the equivariance
         # term follows the sampler draw below.  k4*loss_q (revisiting loss; no gradient path to any parameter) only with
         # --revisit 1.
@@ -325,10 +339,10 @@ class ArcoStep2D:
                 images_tps = self.tps(torch.cat((l_data, u_aug)))        # images_cj2 = the un-augmented pair here
                 mask_tps = self.tps(eq_mask, padding_mode='zeros')
                 pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
-            pred_tps = self.model(images_tps)[0]                         # :415 one more student pass (one BN batch)
+            pred_tps = self.s_train_tps(images_tps)[0]                   # :415 one more student pass (one BN batch)
             loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)   # :419-423
-        ev3 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev3[0].record()
+        if prof:
+            ev3[0].record()
         C_.contrast_anchor_pix(plan)
         if plan.valid_seg <= 1 or not plan.entries:
             reco_loss = self.q_representation[1].weight.sum() * 0.0      # :417-424 zero attached to the graph
@@ -344,8 +358,11 @@ class ArcoStep2D:
                                         self.q_feature_extractor.fea4.weight, self.q_representation[0].weight,
                                         self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)   # :394-398 (temp default)
-        ev3[1].record()
-        self.loss_events.append((ev, ev2, ev3))      # masks | lists, prototypes, keys, banks | anchors, head, InfoNCE
+            if self.keep_debug:
+                self.debug = dict(plan=plan, A_all=A_all.detach(), banks=[m[0] for m in self.memobank])
+        if prof:
+            ev3[1].record()
+            self.loss_events.append((ev, ev2, ev3))  # masks | lists, prototypes, keys, banks | anchors, head, InfoNCE
         loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
         if loss_eqv is not None:
             loss = loss + a.k2 * loss_eqv
@@ -390,7 +407,7 @@ def synthetic_batch(b, patch, n_cls, seed, device, in_chns=1):
     return img.to(device), torch.from_numpy(lab).to(device)
 
 
-def build_loaders(args):
+def build_loaders(args, generator=None):
     """The two training loaders of train_arco_2d.py:161-215 (ACDC / MM slice datasets): the first
     patients_to_slices(exp, labeled_num) slices are the labeled stream, the rest the unlabeled one; RandomGenerator per
     sample; each loader draws with replacement and drops the last incomplete batch.  The Synapse / LiTS / JHU branches
@@ -420,7 +437,7 @@ def build_loaders(args):
     db_l, db_u = sets
     while len(db_l) < len(db_u):                                           # :196-197
         db_l = ConcatDataset([db_l, db_l])
-    mk = lambda ds: DataLoader(ds, batch_size=args.batch_size, sampler=RandomSampler(data_source=ds, replacement=True),
+    mk = lambda ds: DataLoader(ds, batch_size=args.batch_size, sampler=RandomSampler(data_source=ds, replacement=True, generator=generator),
                                drop_last=True, pin_memory=True)
     return mk(db_l), mk(db_u)
 
@@ -437,7 +454,8 @@ def train(args, snapshot_path):
     if args.synthetic:
         iters_per_epoch = 100
     else:
-        loaders = build_loaders(args)
+        # data parallel: every rank draws its own samples / augmentations (seed + rank), after the weight broadcast above
+        loaders = build_loaders(args, generator=adist.seed_data_pipeline(args.seed) if world > 1 else None)
         iters_per_epoch = len(loaders[1])                              # :217 iterations per epoch = unlabeled batches
         logging.info("{} iterations per epoch".format(iters_per_epoch))
         resume = "../model/{}_{}_labeledfinal/{}/iter_30000.pth".format(args.resume, args.labeled_num, args.model)
@@ -466,7 +484,8 @@ def train(args, snapshot_path):
             logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))
             if stepper.iter_num % 1000 == 0:                           # :462-470
                 path = os.path.join(snapshot_path, 'iter_' + str(stepper.iter_num) + '.pth')
-                torch.save(stepper.isd.model.state_dict(), path)
+                # parameters are views into the optimiser's flat buffer: save private copies, not the shared storage
+                torch.save({k: v.detach().clone() for k, v in stepper.isd.model.state_dict().items()}, path)
                 logging.info("save model to {}".format(path))
     return "Training Finished!"
 

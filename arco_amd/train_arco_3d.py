@@ -96,6 +96,7 @@ class ArcoStep3D:
         self.k_fe_ema.plans = [ops.PackPlan([self.k_feature_extractor], False)]
         self.plans = [plan_s] + [pl for pr in pairs for pl in pr.plans] + self.k_fe_ema.plans
         self.iter_num = 0
+        self.keep_debug = False          # tests: keep the last step's plan and anchor rows (self.debug)
         use_graphs = bool(getattr(args, "graphs", 1))
         g_train = use_graphs and bool(getattr(args, "graph_train", 0))
         self.s_train_u = graphs.GraphedTrain(self.model, enabled=g_train)    # student passes: fwd + bwd graphs
@@ -171,7 +172,8 @@ class ArcoStep3D:
         else:
             x2p, f3, f4 = qfe.forward_lowres2(fm_s)
         # counters -> [sample-independent GPU work] -> sampler replay on the host -> anchors (see train_arco_2d.py)
-        C_.contrast_counts(plan, self.memobank, self.queue_size, a.num_queries, a.num_negatives)
+        C_.contrast_counts(plan, self.memobank, self.queue_size,
+                           adist.anchors_for_rank(a.num_queries, getattr(a, "anchors_per_rank", "split")), a.num_negatives)
         C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size, lazy_teacher=lazy_t,
                             defer_anchor_pix=True)
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
@@ -205,6 +207,8 @@ class ArcoStep3D:
             A_all = head.lazy_head3d(x2p, f3, f4, qfe.fea3.weight, qfe.fea4.weight, self.q_representation[0].weight,
                                      self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
+        if self.keep_debug and plan.valid_seg > 1 and plan.entries:
+            self.debug = dict(plan=plan, A_all=A_all.detach(), banks=[m[0] for m in self.memobank])
         if self.iter_num == 0 and loss_eqv is not None:
             loss = unsup_loss + (loss_dice + loss_ce) + loss_eqv         # :393 (iter_num / max_iterations == 0)
         else:
@@ -248,7 +252,7 @@ def synthetic_volume_batch(b, patch, n_cls, seed, device):
     return img.to(device), torch.from_numpy(lab).to(device)
 
 
-def build_loaders(args):
+def build_loaders(args, generator=None):
     """The two training loaders of train_arco_3d.py:158-190: LAHeartWithIndex (first --labeled_num cases labeled, the
     rest unlabeled) with RandomRotFlip -> RandomCrop(patch) -> ToTensor, drawn with replacement, last batch dropped."""
     from torch.utils.data import ConcatDataset, DataLoader
@@ -260,7 +264,7 @@ def build_loaders(args):
     db_u = LAHeartWithIndex(base_dir=args.root_path, split="train", num=None, transform=tf(), index=args.labeled_num, label_type=0)
     while len(db_l) < len(db_u):                                           # :171-172
         db_l = ConcatDataset([db_l, db_l])
-    mk = lambda ds: DataLoader(ds, batch_size=args.batch_size, sampler=RandomSampler(data_source=ds, replacement=True),
+    mk = lambda ds: DataLoader(ds, batch_size=args.batch_size, sampler=RandomSampler(data_source=ds, replacement=True, generator=generator),
                                drop_last=True, pin_memory=True)
     return mk(db_l), mk(db_u)
 
@@ -277,7 +281,8 @@ def train(args, snapshot_path):
     if args.synthetic:
         iters_per_epoch = 100
     else:
-        loaders = build_loaders(args)
+        # data parallel: every rank draws its own samples / augmentations (seed + rank), after the weight broadcast above
+        loaders = build_loaders(args, generator=adist.seed_data_pipeline(args.seed) if world > 1 else None)
         iters_per_epoch = len(loaders[1])
         logging.info("{} iterations per epoch".format(iters_per_epoch))
         resume = "../model/{}_{}_labeledfinal/{}/iter_30000.pth".format(args.resume, args.labeled_num, args.model)
@@ -306,7 +311,8 @@ def train(args, snapshot_path):
             logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))
             if stepper.iter_num % 1000 == 0:                           # :441-449
                 path = os.path.join(snapshot_path, 'iter_' + str(stepper.iter_num) + '.pth')
-                torch.save(stepper.isd.model.state_dict(), path)
+                # parameters are views into the optimiser's flat buffer: save private copies, not the shared storage
+                torch.save({k: v.detach().clone() for k, v in stepper.isd.model.state_dict().items()}, path)
     return "Training Finished!"
 
 

@@ -1,19 +1,27 @@
 """Benchmark of the ARCO 2-D hot-path training step on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-(N>1: launched by torchrun, one rank per GPU over RCCL.)  Prints ONE JSON line (rank 0).
+N > 1 without a torchrun environment: this process spawns `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ...` (one rank per GPU over RCCL) BEFORE touching the GPU and relays rank 0's JSON line; under
+torchrun (WORLD_SIZE set) it is one rank.  A world size different from --gpus is an error (exit code 2).
+Prints ONE JSON line (rank 0).
 
-Workload = BASELINE.json configs[1]: ACDC-shaped 2-D 256x256, --batch_size 8 per stream
-(16 images/step/GPU), C=4, D=496, stratified sampler (smc) + 4096-key/class queue, nq=256,
-nn=512, temp 0.5; synthetic data and random-init weights resident in HBM before timing.
-A step = SURVEY §8a rows N1-N5, T1, L1-L6, O1 (U-Net x6 forwards incl. teacher, FeatureExtractor,
-q_representation, masks, sampler, bank, InfoNCE, backward, SGD-Nesterov, EMA) plus the supervised CE+Dice and
-unsupervised CE terms of §8f row 1.  Weak scaling:
-per-GPU work is fixed; value = N*K 16-image steps / wall time.
+Workload = BASELINE.json configs[1]: ACDC-shaped 2-D 256x256, --batch_size 8 per stream (16 images/step/GPU), C=4,
+D=496, stratified sampler (smc) + 4096-key/class queue, nq=256, nn=512, temp 0.5; synthetic data and random-init weights
+resident in HBM before timing; every other flag at the trainer's (= the reference's) default, in particular --k2 1.0:
+a step = SURVEY §8a rows N1-N5, T1, L1-L6, O1 plus the §8f row-1 terms the reference trains with by default (CE + Dice,
+unsupervised CE, the TPS equivariance term with its extra student pass) and the cutmix mixing of --apply_aug.
+Weak scaling: per-GPU work is fixed; value = N*K 16-image steps / wall time (max over ranks).
+
+The timed region runs the product configuration with NO instrumentation.  Afterwards, outside the timed region:
+a sustained run (>= --sustain_s seconds), a k2 = 0 run (the north-star path alone), an eager pass with HIP events
+around the conv / weight-gradient launches for the roofline objects (graphs off: the kernels must be visible to the
+events), sub-records for BASELINE.json configs[2..4] (each in a child process) and the CPU baseline.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -24,6 +32,7 @@ import time
 if os.environ.get("ARCO_CPU_BASELINE_CHILD") != "1":
     os.environ.setdefault("OMP_NUM_THREADS", "4")
     os.environ.setdefault("MKL_NUM_THREADS", "4")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 
@@ -31,7 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
-# HBM bytes per launch from the PMC passes in profiles/r01_pmc_gemm_traffic.md (FETCH_SIZE x2 + WRITE_SIZE), by (M, N, K)
+PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16/bf16 MFMA (MI355X_MICROARCH.md); --conv_mma f16 launches are priced against it
+PEAK_HBM_TBS = 8.0
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes):
 # profiles/r01_pmc_conv_traffic.md (3x3 backbone kernel) and profiles/r01_pmc_gemm_traffic.md; key (taps, M, N, K)
 PMC_TRAFFIC_BYTES = {(9, 65536, 64, 64): 3.526e7, (9, 65536, 64, 128): 5.322e7,
@@ -40,13 +50,13 @@ PMC_TRAFFIC_BYTES = {(9, 65536, 64, 64): 3.526e7, (9, 65536, 64, 128): 5.322e7,
 
 
 def cpu_baseline_child():
-    """Runs in a child process (all host cores, no GPU): three chained oracle steps at --batch_size 2."""
+    """Runs in a child process (all host cores, no GPU): chained oracle steps at --batch_size 2, default loss terms."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_step
     torch.set_num_threads(min(64, os.cpu_count() or 1))
-    cpu_step.timed_sample(b=1, patch=(64, 64))          # warm the thread pool / allocator
-    secs, threads = cpu_step.timed_sample(b=2, steps=3)
+    cpu_step.timed_sample(b=1, patch=(64, 64), k2=1.0)          # warm the thread pool / allocator
+    secs, threads = cpu_step.timed_sample(b=2, steps=3, k2=1.0)
     print(json.dumps({"secs": secs, "threads": threads, "steps": 3}))
 
 
@@ -55,45 +65,236 @@ def cpu_baseline():
     env = dict(os.environ, ARCO_CPU_BASELINE_CHILD="1")
     env.pop("OMP_NUM_THREADS", None); env.pop("MKL_NUM_THREADS", None)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu_baseline_child"], env=env,
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=1200)
     r = json.loads(out.stdout.strip().splitlines()[-1])
     secs, threads = r["secs"], r["threads"]
     # a 16-image step is 4x the 4-image sample (per-image work is constant)
     return {"value": round(1.0 / (4.0 * secs), 5), "unit": "steps/s (16-image steps)", "cores": threads, "kind": "port",
-            "sample": f"{r.get('steps', 1)} chained full oracle steps at --batch_size 2 (4 images, 256x256, C=4, D=496, cutmix), "
-                      f"{secs:.1f} s per step on {threads} threads; scaled x4 to the 16-image step"}
+            "sample": f"{r.get('steps', 1)} chained full oracle steps at --batch_size 2 (4 images, 256x256, C=4, D=496, cutmix, "
+                      f"k2 = 1 equivariance term on, like the GPU headline), {secs:.1f} s per step on {threads} threads; "
+                      "scaled x4 to the 16-image step"}
+
+
+def spawn_ranks(a, argv):
+    """--gpus N > 1 outside torchrun: launch N ranks as children (nothing here has touched the GPU), relay rank 0's line."""
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU runtime
+    if n_dev < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+        return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if p.returncode != 0 or line is None:
+        sys.stdout.write(p.stdout)
+        print(f"bench.py: the {a.gpus}-rank launch failed (rc={p.returncode})", file=sys.stderr)
+        return p.returncode or 1
+    if json.loads(line).get("n_gpus") != a.gpus:
+        print(f"bench.py: world size {json.loads(line).get('n_gpus')} != --gpus {a.gpus}", file=sys.stderr)
+        return 2
+    print(line)
+    return 0
+
+
+def _kernel_name(key):
+    if isinstance(key, tuple):
+        return f"wgrad<taps={key[1]},co={key[2]},ci={key[3]}> (weight gradient, fp32 MFMA 16x16x4)"
+    if key >= 9900000:
+        return f"conv3x3_halo_kernel<{(key - 9900000) // 1000},{key % 1000},..> (fp32 MFMA 16x16x4 implicit GEMM)"
+    return f"igemm_kernel<{key // 1000000},{key // 1000 % 1000},{key % 1000},...> (fp32 MFMA 16x16x4 implicit GEMM)"
+
+
+def roofline_from_profile(prof, n_steps, step_ms, peak=PEAK_F32_MFMA_TFLOPS, mma="f32"):
+    """Roofline objects from ops.PROFILE of an eager pass over n_steps steps (every conv / weight-gradient launch
+    counted, every PROFILE_EVERY-th bracketed by HIP events on the launch stream).
+    dominant kernel = the 3x3 backbone instantiation with the largest total time (rocprofv3's top MFMA row for the same
+    command); achieved = its algorithmic FLOP per launch / its average launch duration.  `step_ms` is the step time of
+    the UN-instrumented product run: shares and the whole-step figure are quoted against it."""
+    if not prof:
+        return None, None
+    avg = {c: sum(s_.elapsed_time(e_) for s_, e_, _, _ in v["timed"]) / max(1, len(v["timed"])) for c, v in prof.items()}
+    tot = {c: avg[c] * v["n"] for c, v in prof.items()}
+    is3 = lambda c: (not isinstance(c, tuple)) and c // 1000000 == 9
+    cand = {c: t for c, t in tot.items() if is3(c)} or tot
+    cfg = max(cand, key=cand.get)
+    rec = prof[cfg]
+    launches = rec["timed"]
+    avg_ms = avg[cfg]
+    avg_flop = sum(f for _, _, f, _ in launches) / len(launches)
+    ach = avg_flop / (avg_ms * 1e-3) / 1e12
+    shapes = {}
+    for s_, e_, f, shp in launches:
+        d_ = shapes.setdefault(shp, [0, 0.0, f]); d_[0] += 1; d_[1] += s_.elapsed_time(e_)
+    (taps, m, n, k), (cnt, ms_sum, f) = max(shapes.items(), key=lambda kv: kv[1][1])
+    fam_ms = sum(tot.values()); fam_flop = sum(v["flop"] for v in prof.values())
+    wg_ms = sum(t for c, t in tot.items() if isinstance(c, tuple)); wg_flop = sum(v["flop"] for c, v in prof.items() if isinstance(c, tuple))
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get((taps, m, n, k)) if mma == "f32" else None,
+            "kernel": _kernel_name(cfg), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(rec["n"] / n_steps, 1),
+            "launches_timed": len(launches), "avg_flop_per_launch": avg_flop,
+            "share_of_step": round(tot[cfg] / n_steps / step_ms, 4),
+            "largest_shape": {"taps": taps, "M": m, "N": n, "K": k, "launches_timed": cnt,
+                              "tflops": round(f / (ms_sum / cnt * 1e-3) / 1e12, 2)},
+            "method": "eager pass outside the timed region, HIP events on the launch stream around every 7th launch"}
+    top = sorted(tot.items(), key=lambda kv: -kv[1])[:8]
+    whole = {"mfma_flop_per_step": fam_flop / n_steps, "ms_per_step": round(step_ms, 3),
+             "tflops_over_whole_step": round(fam_flop / n_steps / (step_ms * 1e-3) / 1e12, 2),
+             "frac_of_fp32_mfma_peak": round(fam_flop / n_steps / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+             "mfma_kernels": {"ms_per_step": round(fam_ms / n_steps, 3), "tflops": round(fam_flop / (fam_ms * 1e-3) / 1e12, 2)},
+             "weight_gradient_kernels": {"ms_per_step": round(wg_ms / n_steps, 3),
+                                         "tflops": round(wg_flop / max(wg_ms * 1e-3, 1e-9) / 1e12, 2)},
+             "top_kernels": [{"kernel": _kernel_name(c).split(" (")[0], "ms_per_step": round(t / n_steps, 3),
+                              "tflops": round(prof[c]["flop"] / (t * 1e-3) / 1e12, 1)} for c, t in top],
+             "note": "FLOP = MFMA work actually launched (forward + data gradient + weight gradient of every conv / GEMM, "
+                     "incl. the passes that are graph-replayed in the product run); SURVEY 8d's 7.4 TFLOP/step counts the "
+                     "dense reference dataflow (the row-sparse head and lazy teacher remove ~3.3 TFLOP of it, DESIGN.md 4)"}
+    return roof, whole
+
+
+def eager_profile(stepper, run_steps, n_steps):
+    """n_steps steps with every graph off and HIP-event instrumentation on; returns ops.PROFILE."""
+    from arco_amd import graphs, ops
+    prev = graphs.set_enabled(stepper, False)
+    run_steps(2)
+    torch.cuda.synchronize()
+    ops.PROFILE, ops.PROFILE_EVERY = {}, 7
+    run_steps(n_steps)
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    graphs.set_enabled(stepper, prev)
+    return prof
+
+
+def timed(run_steps, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(n)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sub-records: BASELINE.json configs[2..4] on ONE GPU, each in a child process (`bench.py --sub NAME`)
+# ---------------------------------------------------------------------------------------------------------------
+SUBS = {
+    "config3d_la_vnet": dict(kind="3d", batch_size=2, patch=[112, 112, 80], classes=2, mma="f32",
+                             workload="LA 3D V-Net 112x112x80, --batch_size 2 (4 volumes/step), C=2, D=16, asmc "
+                                      "(BASELINE.json configs[2])"),
+    "cityscapes_19c_512x1024": dict(kind="2d", batch_size=1, patch=[512, 1024], classes=19, in_chns=3,
+                                    workload="Cityscapes-shaped 19-class 3x512x1024, 2 images/GPU (--batch_size 1), D=496, "
+                                             "4096-key/class queue (the per-GPU shard of BASELINE.json configs[3])"),
+    "lits_160x160x96_f16": dict(kind="3d", batch_size=1, patch=[160, 160, 96], classes=2, mma="f16",
+                                workload="LiTS-shaped 3D 2-class 160x160x96, 1+1 volumes/GPU, --conv_mma f16 "
+                                         "(the per-GPU shard of BASELINE.json configs[4])"),
+}
+
+
+def run_sub(name, steps):
+    import random
+    import numpy as np
+    from arco_amd import ops
+    cfg = SUBS[name]
+    random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    b = cfg["batch_size"]
+    if cfg["kind"] == "3d":
+        from arco_amd import train_arco_3d as T3
+        args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1",
+                                             "--num_classes", str(cfg["classes"]), "--conv_mma", cfg["mma"]])
+        args.patch_size = cfg["patch"]
+        st = T3.ArcoStep3D(args, dev)
+        l, ll = T3.synthetic_volume_batch(b, args.patch_size, cfg["classes"], 1, dev)
+        u, _ = T3.synthetic_volume_batch(b, args.patch_size, cfg["classes"], 2, dev)
+    else:
+        from arco_amd import train_arco_2d as T
+        args = T.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1",
+                                            "--num_classes", str(cfg["classes"]), "--in_chns", str(cfg["in_chns"])])
+        args.patch_size = cfg["patch"]
+        st = T.ArcoStep2D(args, dev)
+        l, ll = T.synthetic_batch(b, args.patch_size, cfg["classes"], 1, dev, in_chns=cfg["in_chns"])
+        u, _ = T.synthetic_batch(b, args.patch_size, cfg["classes"], 2, dev, in_chns=cfg["in_chns"])
+
+    def run_steps(n):
+        for _ in range(n):
+            st.step(l, ll, u, 0, 100)
+    run_steps(5)
+    ms = timed(run_steps, steps)
+    mem = torch.cuda.max_memory_allocated() / 1e9
+    prof = eager_profile(st, run_steps, 2)
+    peak = PEAK_F32_MFMA_TFLOPS if cfg["mma"] == "f32" else PEAK_F16_MFMA_TFLOPS
+    roof, whole = roofline_from_profile(prof, 2, ms, peak=peak, mma=cfg["mma"])
+    if roof is not None and cfg["mma"] != "f32":
+        roof["kernel"] = roof["kernel"].replace("fp32 MFMA 16x16x4", "f16/bf16-operand MFMA 16x16x16, fp32 accumulate")
+    terms = {k: round(float(v), 5) for k, v in st.last_terms.items()}
+    print(json.dumps({"sub": name, "workload": cfg["workload"], "ms_per_step": round(ms, 3), "steps_per_s": round(1e3 / ms, 3),
+                      "steps": steps, "dtype": "f32" if cfg["mma"] == "f32" else "f32 storage, f16/bf16 MFMA operands",
+                      "flags": "trainer defaults" + ("" if cfg["kind"] == "2d" else " (--eqv_pass 1)"),
+                      "peak_mem_gb": round(mem, 2), "loss_terms": terms, "roofline": roof, "whole_step": whole}))
+
+
+def sub_record(name, steps):
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--sub", name, "--sub_steps", str(steps)],
+                             capture_output=True, text=True, timeout=600)
+        for ln in reversed(out.stdout.splitlines()):
+            if ln.startswith("{") and '"sub"' in ln:
+                return json.loads(ln)
+        return {"sub": name, "error": (out.stderr or out.stdout)[-400:]}
+    except Exception as e:                                       # a sub-record must never take the headline down
+        return {"sub": name, "error": repr(e)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch_size", type=int, default=8)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_subs", action="store_true", help="skip the configs[2..4] sub-records")
     ap.add_argument("--dense_head", type=int, default=0)
     ap.add_argument("--graphs", type=int, default=1)
-    ap.add_argument("--graph_train", type=int, default=0)
+    ap.add_argument("--graph_train", type=int, default=-1, help="-1: the trainer's default")
     ap.add_argument("--batched_passes", type=int, default=1)
-    ap.add_argument("--eqv_steps", type=int, default=10, help="extra steps timed with the equivariance term on (0: skip)")
+    ap.add_argument("--k2", type=float, default=1.0, help="weight of the equivariance term (reference default 1.0)")
+    ap.add_argument("--k2_0_steps", type=int, default=10, help="extra steps timed with k2 = 0, the north-star path alone (0: skip)")
+    ap.add_argument("--sustain_s", type=float, default=3.0, help="length of the extra sustained run (0: skip)")
     ap.add_argument("--dense_teacher", type=int, default=0)
     ap.add_argument("--cpu_baseline_child", action="store_true")
+    ap.add_argument("--sub", type=str, default="")
+    ap.add_argument("--sub_steps", type=int, default=6)
     a = ap.parse_args()
     if a.cpu_baseline_child:
         return cpu_baseline_child()
+    if a.sub:
+        return run_sub(a.sub, a.sub_steps)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a, sys.argv[1:]))
 
     from arco_amd import dist as adist
     from arco_amd import ops
     from arco_amd import train_arco_2d as T
     rank, world = adist.init()
+    if world != a.gpus:
+        print(f"bench.py: launched with world size {world} but --gpus {a.gpus}", file=sys.stderr)
+        sys.exit(2)
     dev = torch.device("cuda", adist.local_rank())
     torch.cuda.set_device(dev)
     import random
     import numpy as np
     random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 
-    args = T.build_parser().parse_args(["--batch_size", str(a.batch_size), "--queue_size", "4096", "--func", "smc",
-                                        "--synthetic", "1", "--dense_head", str(a.dense_head), "--graphs", str(a.graphs), "--graph_train", str(a.graph_train), "--batched_passes", str(a.batched_passes), "--k2", "0", "--dense_teacher", str(a.dense_teacher)])
+    flags = ["--batch_size", str(a.batch_size), "--queue_size", "4096", "--func", "smc", "--synthetic", "1",
+             "--dense_head", str(a.dense_head), "--graphs", str(a.graphs), "--batched_passes", str(a.batched_passes),
+             "--k2", str(a.k2), "--dense_teacher", str(a.dense_teacher)]
+    if a.graph_train >= 0:
+        flags += ["--graph_train", str(a.graph_train)]
+    args = T.build_parser().parse_args(flags)
     stepper = T.ArcoStep2D(args, dev)
     b = a.batch_size
     batches = []
@@ -101,107 +302,91 @@ def main():
         l_img, l_lab = T.synthetic_batch(b, args.patch_size, args.num_classes, 100 + 2 * i * world + rank, dev)
         u_img, _ = T.synthetic_batch(b, args.patch_size, args.num_classes, 101 + 2 * i * world + rank, dev)
         batches.append((l_img, l_lab, u_img))
+    cursor = [0]
 
-    def run(n, base):
-        for i in range(n):
-            l_img, l_lab, u_img = batches[(base + i) % len(batches)]
+    def run(n):
+        for _ in range(n):
+            l_img, l_lab, u_img = batches[cursor[0] % len(batches)]
+            cursor[0] += 1
             stepper.step(l_img, l_lab, u_img, 0, 100)
 
-    # HIP-graph capture of the no-grad passes happens on their third call: make sure it lies before the timed region
+    # HIP-graph capture happens on a pass's third call: make sure it lies before the timed region
     # whatever --warmup is (extra untimed steps only)
-    run(max(0, 4 - a.warmup), 0)
-    run(a.warmup, 0)
+    run(max(0, 5 - a.warmup))
+    run(a.warmup)
+    stepper.profile_loss = True          # 3 event pairs per step around the contrastive-loss segments (the metric's 2nd half)
+    stepper.loss_events = []
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    stepper.loss_events = []
-    # HIP-event timing of the conv kernels on the launch stream: every launch counted, every 7th timed (an event
-    # pair around each of the ~350 eager conv launches per step costs ~1.5 ms/step of stream bubbles)
-    ops.PROFILE, ops.PROFILE_EVERY = {}, 7
     t0 = time.perf_counter()
-    run(a.steps, a.warmup)
+    run(a.steps)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    # secondary figure: the same step with the reference's equivariance term on (k2 = 1: RandTPS warp + one more
-    # student pass over the 16 images + masked KL).  The headline workload is the north-star path
-    # (contrastive + supervised + unsupervised terms), timed above with k2 = 0.
-    eqv_ms = None
-    if world == 1 and a.eqv_steps > 0:
-        stepper.args.k2 = 1.0
-        run(3, 0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run(a.eqv_steps, 3)
-        torch.cuda.synchronize()
-        eqv_ms = (time.perf_counter() - t1) / a.eqv_steps * 1e3
-        stepper.args.k2 = 0.0
+    loss_ms = (sum(e0.elapsed_time(e1) for evs in stepper.loss_events for e0, e1 in evs) / max(1, len(stepper.loss_events)))
+    stepper.profile_loss = False
+    stepper.loss_events = []
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    step_ms = dt / a.steps * 1e3
+
+    sustained = k2_0 = roof = whole = None
+    if world == 1:
+        if a.sustain_s > 0:              # clocks settle lower under sustained load: a >= 3 s figure beside the K-step one
+            n_s = max(a.steps, int(a.sustain_s * 1e3 / step_ms) + 1)
+            ms_s = timed(run, n_s)
+            sustained = {"steps": n_s, "ms_per_step": round(ms_s, 3), "steps_per_s": round(1e3 / ms_s, 3),
+                         "seconds": round(n_s * ms_s / 1e3, 2)}
+        if a.k2_0_steps > 0 and a.k2 != 0:
+            stepper.args.k2 = 0.0
+            run(4)
+            ms0 = timed(run, a.k2_0_steps)
+            stepper.args.k2 = a.k2
+            k2_0 = {"ms_per_step": round(ms0, 3), "steps_per_s": round(1e3 / ms0, 3), "steps": a.k2_0_steps,
+                    "note": "--k2 0: the north-star path alone (contrastive + supervised + unsupervised terms), no "
+                            "equivariance pass; round 1's headline configuration"}
+        prof = eager_profile(stepper, run, 3)
+        roof, whole = roofline_from_profile(prof, 3, step_ms)
 
     if rank == 0:
-        # dominant kernel = the igemm_kernel<TAPS,BM,BN,...> instantiation with the largest total time in the
-        # timed region (one row of rocprofv3's kernel stats); achieved = its algorithmic FLOP per launch / its
-        # average launch duration, both averaged over its launches (HIP events on the launch stream).
-        roof = None
-        if prof:
-            # per instantiation: average timed launch duration x number of launches = its time in the timed region
-            avg = {c: sum(s_.elapsed_time(e_) for s_, e_, _, _ in v["timed"]) / max(1, len(v["timed"])) for c, v in prof.items()}
-            tot = {c: avg[c] * v["n"] for c, v in prof.items()}
-            # dominant kernel: the 3x3 backbone instantiation with the most time (rocprofv3's top MFMA row for the
-            # same command, profiles/r01_*); the many tiny 1x1 head GEMMs (<4 % of the step) are not candidates
-            cand = {c: t for c, t in tot.items() if c // 1000000 == 9} or tot
-            cfg = max(cand, key=cand.get)
-            rec = prof[cfg]
-            launches = rec["timed"]
-            avg_ms = avg[cfg]
-            avg_flop = sum(f for _, _, f, _ in launches) / len(launches)
-            ach = avg_flop / (avg_ms * 1e-3) / 1e12
-            shapes = {}
-            for s_, e_, f, shp in launches:
-                d_ = shapes.setdefault(shp, [0, 0.0, f]); d_[0] += 1; d_[1] += s_.elapsed_time(e_)
-            top = max(shapes.items(), key=lambda kv: kv[1][1])
-            (taps, m, n, k), (cnt, ms_sum, f) = top
-            fam_ms = sum(tot.values()); fam_flop = sum(v["flop"] for v in prof.values())
-            kid = (f"conv3x3_halo_kernel<{(cfg - 9900000) // 1000},{cfg % 1000},..>" if cfg >= 9900000
-                   else f"igemm_kernel<{cfg // 1000000},{cfg // 1000 % 1000},{cfg % 1000},...>")
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get((taps, m, n, k)),
-                    "kernel": kid + " (fp32 MFMA 16x16x4 implicit GEMM)",
-                    "avg_launch_ms": round(avg_ms, 4), "launches": rec["n"], "launches_timed": len(launches),
-                    "avg_flop_per_launch": avg_flop, "share_of_step": round(tot[cfg] / (dt * 1e3), 4),
-                    "largest_shape": {"taps": taps, "M": m, "N": n, "K": k, "launches_timed": cnt,
-                                      "tflops": round(f / (ms_sum / cnt * 1e-3) / 1e12, 2)},
-                    "conv_family": {"tflops": round(fam_flop / (fam_ms * 1e-3) / 1e12, 2),
-                                    "share_of_step": round(fam_ms / (dt * 1e3), 4),
-                                    "flop_per_step": fam_flop / a.steps}}
         out = {
-            "metric": "train steps/sec, ACDC 2D 256x256 bs=16 (hot-path step)", "value": round(world * a.steps / dt, 4),
+            "metric": "train steps/sec, ACDC 2D 256x256 bs=16", "value": round(world * a.steps / dt, 4),
             "unit": "steps/s (16-image steps, all GPUs)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ACDC 2D 256x256 bs=16 per GPU on {world}xMI355X, stratified sampler + 4096-key/class queue "
-                                   "(BASELINE.json configs[1])", "batch_size_per_stream": b, "images_per_step_per_gpu": 2 * b,
+                                   "(BASELINE.json configs[1]), reference-default flags",
+                       "batch_size_per_stream": b, "images_per_step_per_gpu": 2 * b,
                        "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc", "apply_aug": args.apply_aug,
-                       "loss_terms": "k1*contrastive + k3*unsupervised + CE + Dice (k2 = 0)",
-                       "parallelism": f"dp{world}"},
+                       "loss_terms": f"k1*contrastive + k3*unsupervised + CE + Dice + k2*equivariance (k2 = {a.k2:g})",
+                       "graph_train": int(bool(getattr(args, "graph_train", 0))), "parallelism": f"dp{world}"},
             # compute_contra_memobank_loss on the GPU clock: masks | lists, prototypes, keys, banks | anchors, row-sparse head,
             # InfoNCE INCLUDING its analytic gradient w.r.t. the anchors (the loss's backward is computed in the forward)
-            "contrastive_loss_ms_per_step": round(sum(e0.elapsed_time(e1) for evs in stepper.loss_events for e0, e1 in evs)
-                                                      / max(1, len(stepper.loss_events)), 3),
+            "contrastive_loss_ms_per_step": round(loss_ms, 3),
             "roofline": roof,
         }
-        if eqv_ms is not None:
-            out["with_equivariance_term"] = {"ms_per_step": round(eqv_ms, 3), "steps_per_s": round(1e3 / eqv_ms, 3),
-                                             "steps": a.eqv_steps, "note": "k2 = 1: + RandTPS warp, one more student pass, masked KL"}
+        if whole is not None:
+            out["whole_step"] = whole
+        if sustained is not None:
+            out["sustained"] = sustained
+        if k2_0 is not None:
+            out["north_star_path_only_k2_0"] = k2_0
+        if world == 1 and not a.no_subs:
+            del stepper
+            batches.clear()
+            torch.cuda.empty_cache()
+            out["configs"] = [sub_record(n, a.sub_steps) for n in SUBS]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,266 @@
+"""BASELINE.json configs[2..4] on the HIP path AT THEIR FULL SIZES (-m gpu), plus oracle parity of the Cityscapes-shaped
+configuration (19 classes, RGB, non-square) at a size the CPU oracle finishes in seconds.
+
+At full size the CPU oracle needs minutes per step, so the whole training step is held to checks that do not need it:
+ * the sampled anchor / negative indices of the step are a bit-exact replay of the host samplers from the seeded
+   torch-CPU-generator state, and lie inside the candidate lists / banks;
+ * the contrastive loss of the step equals a plain PyTorch fp32 restatement of loss_helper_3d.py:478-509 (cosine
+   similarity over [Q, 1 + Nn, D], cross-entropy at temp 0.5) evaluated on the step's own anchor rows, prototypes and banks;
+ * banks are FIFO tensors of at most queue_size rows with the reference's pointer arithmetic;
+ * the default row-sparse head + lazy teacher give the loss terms and updated weights of the dense reference dataflow
+   (--dense_head 1 --dense_teacher 1) from equal state;
+ * configs[4]: the f16-MFMA step stays inside its 1e-2 budget of the fp32 step at 160x160x96.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cpu_step
+import fixture_inputs as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def seed_all(s):
+    random.seed(s); np.random.seed(s); torch.manual_seed(s)
+
+
+def _drop_off(st):
+    for m in (st.model, st.ema_model):
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.Dropout, torch.nn.Dropout3d)):
+                mod.p = 0.0
+        if hasattr(m, "has_dropout"):
+            m.has_dropout = False
+
+
+def _torch_infonce(dbg, temp=0.5):
+    """loss_helper_3d.py:478-509 in plain PyTorch on the step's own anchors / prototypes / banks."""
+    pl, A_all = dbg["plan"], dbg["A_all"]
+    Q, Nn = pl.Q, pl.Nn
+    loss = torch.zeros((), device=A_all.device)
+    for e, (k, vc, a_dev, n_dev) in enumerate(pl.entries):
+        A = A_all[e * Q:(e + 1) * Q]
+        bank = dbg["banks"][vc]
+        neg = bank[n_dev].view(Q, Nn, -1)
+        pos = pl.proto[k].view(1, 1, -1).expand(Q, 1, -1)
+        logits = F.cosine_similarity(A[:, None, :], torch.cat((pos, neg), dim=1), dim=2)
+        loss = loss + F.cross_entropy(logits / temp, torch.zeros(Q, dtype=torch.long, device=A.device))
+    return loss / pl.valid_seg
+
+
+def _check_step_invariants(st, func, qsize, D, seed):
+    """After a step seeded with `seed`: index replay, torch InfoNCE, bank shape / pointer checks."""
+    from arco_amd import samplers
+    dbg = st.debug
+    pl = dbg["plan"]
+    C, Q, Nn = pl.C, pl.Q, pl.Nn
+    draw = samplers.grid_as_monte_carlo_sample if func == "asmc" else samplers.grid_monte_carlo_sample
+    assert pl.valid_seg > 1 and len(pl.entries) >= 2
+    # 1. bit-exact replay of the host samplers from the seeded generator (the mixing strategy draws from numpy only)
+    torch.manual_seed(seed)
+    for (k, vc, a_dev, n_dev) in pl.entries:
+        n_anchor, blen = int(pl.n_anchor[k]), int(pl.bank_len[vc])
+        exp_a, exp_n = draw(n_anchor, Q), draw(blen, Q * Nn)
+        assert torch.equal(a_dev.cpu(), exp_a) and torch.equal(n_dev.cpu(), exp_n), (k, vc)
+        assert int(a_dev.max()) < n_anchor and int(n_dev.max()) < blen
+    # 2. the loss against the PyTorch restatement
+    ref = float(_torch_infonce(dbg))
+    got = float(st.last_terms["reco"])
+    assert abs(got - ref) <= 1e-3 * max(1.0, abs(ref)), (got, ref)          # north_star: 1e-3 fp32
+    # 3. banks: FIFO, at most queue_size rows of D floats on the device, pointer arithmetic of loss_helper_3d.py:24-30
+    for c in range(C):
+        b = st.memobank[c][0]
+        assert b.is_cuda and b.shape[1] == D and 1 <= b.shape[0] <= qsize and bool(torch.isfinite(b).all())
+        assert b.shape[0] == pl.bank_len[c]
+        if b.shape[0] == qsize:
+            assert int(st.queue_ptrlis[c]) == qsize or int(pl.n_neg_all[c]) == 0
+    for k_, v in st.last_terms.items():
+        assert np.isfinite(float(v)), k_
+
+
+def _copy_state(dst, src):
+    from arco_amd import ops
+    with torch.no_grad():
+        dst.optimizer.flat_p.copy_(src.optimizer.flat_p)
+        for md, ms in ((dst.model, src.model), (dst.ema_model, src.ema_model), (dst.k_feature_extractor, src.k_feature_extractor)):
+            for (kd, vd), (ks, vs) in zip(md.state_dict().items(), ms.state_dict().items()):
+                assert kd == ks
+                vd.copy_(vs)
+    ops.bump_weight_epoch()
+
+
+def _sparse_vs_dense(make, batch, steps=1):
+    """One step from equal state, dropout off: default row-sparse head + lazy teacher vs the dense reference dataflow."""
+    st_s = make([])
+    st_d = make(["--dense_head", "1", "--dense_teacher", "1"])
+    _copy_state(st_d, st_s)
+    _drop_off(st_s); _drop_off(st_d)
+    out = []
+    for st in (st_s, st_d):
+        for it in range(steps):
+            seed_all(400 + it)
+            st.step(*batch)
+        out.append(({k: float(v) for k, v in st.last_terms.items()}, st.optimizer.flat_p.clone(),
+                    [m[0].clone() for m in st.memobank]))
+    (t_s, p_s, b_s), (t_d, p_d, b_d) = out
+    for k in t_d:
+        np.testing.assert_allclose(t_s[k], t_d[k], rtol=2e-4, atol=1e-5, err_msg=k)
+    assert float((p_s - p_d).abs().max()) <= 2e-4 * float(p_d.abs().max())
+    for x, y in zip(b_s, b_d):
+        assert x.shape == y.shape
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-3, atol=2e-4 * float(y.abs().max()))
+    del st_s, st_d
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[2]: LA V-Net 112x112x80, --batch_size 2 (4 volumes per step), C = 2, D = 16, asmc
+# ------------------------------------------------------------------------------------------------------------------
+def _make3d(extra, patch=(112, 112, 80), b=2, mma="f32"):
+    from arco_amd import train_arco_3d as T3
+    args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1", "--num_classes", "2",
+                                         "--conv_mma", mma, "--k1", "1.0"] + list(extra))
+    args.patch_size = list(patch)
+    seed_all(7)
+    return T3.ArcoStep3D(args, "cuda:0")
+
+
+def test_cfg3_la_vnet_step_at_full_size():
+    from arco_amd import train_arco_3d as T3
+    st = _make3d([])
+    st.keep_debug = True
+    for it in range(4):                     # step 0 is the reference's "equivariance only" objective; graphs replay from step 3
+        l, ll = T3.synthetic_volume_batch(2, (112, 112, 80), 2, 10 + it, "cuda:0")
+        u, _ = T3.synthetic_volume_batch(2, (112, 112, 80), 2, 20 + it, "cuda:0")
+        seed_all(300 + it)
+        loss, reco = st.step(l, ll, u)
+        assert bool(torch.isfinite(loss))
+    _check_step_invariants(st, "asmc", 4096, 16, 303)
+    assert all(m[0].shape == (4096, 16) for m in st.memobank)        # 4 M voxels: the banks are full after the first step
+    assert "eqv" in st.last_terms                                     # --eqv_pass 1 (reference default) ran at size
+    del st
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_sparse_head_equals_dense_dataflow_at_full_size():
+    from arco_amd import train_arco_3d as T3
+    l, ll = T3.synthetic_volume_batch(2, (112, 112, 80), 2, 31, "cuda:0")
+    u, _ = T3.synthetic_volume_batch(2, (112, 112, 80), 2, 32, "cuda:0")
+    _sparse_vs_dense(lambda extra: _make3d(["--eqv_pass", "0"] + extra), (l, ll, u))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[3]: Cityscapes-shaped, 19 classes, 3 x 512 x 1024, 2 images per GPU (--batch_size 1), 4096-key queues
+# ------------------------------------------------------------------------------------------------------------------
+def _make_city(extra, patch=(512, 1024), b=1, qsize=4096, nq=256, nn_=512):
+    from arco_amd import train_arco_2d as T
+    args = T.build_parser().parse_args(["--batch_size", str(b), "--queue_size", str(qsize), "--synthetic", "1",
+                                        "--num_classes", "19", "--in_chns", "3", "--num_queries", str(nq),
+                                        "--num_negatives", str(nn_), "--k1", "1.0"] + list(extra))
+    args.patch_size = list(patch)
+    seed_all(9)
+    return T.ArcoStep2D(args, "cuda:0")
+
+
+def test_cfg4_cityscapes_step_at_full_size():
+    from arco_amd import train_arco_2d as T
+    st = _make_city([])
+    st.keep_debug = True
+    for it in range(4):
+        l, ll = T.synthetic_batch(1, (512, 1024), 19, 40 + it, "cuda:0", in_chns=3)
+        u, _ = T.synthetic_batch(1, (512, 1024), 19, 50 + it, "cuda:0", in_chns=3)
+        seed_all(500 + it)
+        loss, reco = st.step(l, ll, u)
+        assert bool(torch.isfinite(loss))
+    _check_step_invariants(st, "smc", 4096, 496, 503)
+    assert len(st.memobank) == 19 and "eqv" in st.last_terms          # default flags: k2 = 1
+    assert st.debug["plan"].valid_seg >= 10                           # most of the 19 classes are present
+    del st
+    torch.cuda.empty_cache()
+
+
+def test_cfg4_sparse_head_equals_dense_dataflow_at_full_size():
+    from arco_amd import train_arco_2d as T
+    l, ll = T.synthetic_batch(1, (512, 1024), 19, 61, "cuda:0", in_chns=3)
+    u, _ = T.synthetic_batch(1, (512, 1024), 19, 62, "cuda:0", in_chns=3)
+    _sparse_vs_dense(lambda extra: _make_city(["--k2", "0", "--graphs", "0"] + extra), (l, ll, u))
+
+
+def test_cfg4_cityscapes_shape_vs_cpu_oracle():
+    """RGB input, 19 classes, 64 x 128, 256 queries: two chained steps (default loss terms incl. the equivariance term,
+    cutmix) against the CPU oracle step - every loss term, the 19 banks and pointers, updated student weights."""
+    from arco_amd import train_arco_2d as T
+    b, patch, C, Q, Nn, qs = 1, (64, 128), 19, 256, 64, 256
+    unet_sd, fe_sd = fx.unet_state(23, 3, C), fx.fe_state(31)
+    qrep_w = [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]]
+    st_g = _make_city(["--base_lr", "0.01", "--graphs", "0"], patch=patch, b=b, qsize=qs, nq=Q, nn_=Nn)
+    st_g.model.load_state_dict(unet_sd, strict=True)
+    st_g.ema_model.load_state_dict(unet_sd, strict=True)
+    st_g.q_feature_extractor.load_state_dict(fe_sd, strict=True)
+    st_g.k_feature_extractor.load_state_dict(fe_sd, strict=True)
+    with torch.no_grad():
+        st_g.q_representation[0].weight.copy_(qrep_w[0])
+        st_g.q_representation[1].weight.copy_(qrep_w[1])
+    _drop_off(st_g)
+    from arco_amd import ops
+    ops.bump_weight_epoch()
+    st_o = cpu_step.make_state(unet_sd, fe_sd, qrep_w)
+    bank_o, ptr_o, qsz = fx.fresh_bank(C, 496, qs, 'zeros')
+    rs = np.random.RandomState(4)
+    for it in range(2):
+        l = torch.from_numpy(rs.uniform(size=(b, 3, *patch)).astype(np.float32))
+        u = torch.from_numpy(rs.uniform(size=(b, 3, *patch)).astype(np.float32))
+        lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
+        seed_all(10 + it)
+        cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn, k2=1.0, apply_aug="cutmix")
+        seed_all(10 + it)
+        st_g.step(l.cuda(), lab.cuda(), u.cuda())
+        to, tg = st_o["last_terms"], st_g.last_terms
+        for k in ("ce", "dice", "unsup", "reco", "eqv"):
+            np.testing.assert_allclose(float(tg[k]), to[k], rtol=2e-3, atol=1e-5, err_msg=f"step {it} {k}")
+        for bo, bg in zip(bank_o, st_g.memobank):
+            assert bo[0].shape == bg[0].shape
+            np.testing.assert_allclose(bg[0].cpu().numpy(), bo[0].numpy(), rtol=2e-3, atol=2e-4)
+        assert [int(p) for p in ptr_o] == [int(p) for p in st_g.queue_ptrlis]
+    sd_g = st_g.model.state_dict()
+    for k, v in st_o["student"].items():
+        if v.requires_grad:
+            ref = v.detach()
+            assert float((sd_g[k].cpu() - ref).abs().max()) <= 2e-3 * max(1e-6, float(ref.abs().max())), k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[4]: LiTS-shaped 160 x 160 x 96, 1 + 1 volumes per GPU, f16 MFMA operands (tolerance 1e-2)
+# ------------------------------------------------------------------------------------------------------------------
+def test_cfg5_lits_f16_step_at_full_size_tracks_fp32():
+    from arco_amd import ops, train_arco_3d as T3
+    sp = (160, 160, 96)
+    out = {}
+    try:
+        for mode in ("f32", "f16"):
+            st = _make3d(["--eqv_pass", "0"], patch=sp, b=1, mma=mode)
+            assert ops.CONV_MMA == {"f32": 0, "f16": 1}[mode]
+            _drop_off(st)
+            st.keep_debug = True
+            terms = []
+            for it in range(3):
+                l, ll = T3.synthetic_volume_batch(1, sp, 2, 70 + it, "cuda:0")
+                u, _ = T3.synthetic_volume_batch(1, sp, 2, 80 + it, "cuda:0")
+                seed_all(600 + it)
+                st.step(l, ll, u)
+                terms.append([float(st.last_terms[k]) for k in ("ce", "dice", "unsup", "reco")])
+            if mode == "f16":
+                _check_step_invariants(st, "asmc", 4096, 16, 602)
+            out[mode] = np.array(terms)
+            del st
+            torch.cuda.empty_cache()
+    finally:
+        ops.CONV_MMA = 0
+    assert np.all(np.isfinite(out["f16"]))
+    np.testing.assert_allclose(out["f16"][0, :2], out["f32"][0, :2], rtol=1e-2)      # first step, same weights: CE / Dice at 1e-2
+    np.testing.assert_allclose(out["f16"][:, :2], out["f32"][:, :2], rtol=5e-2)      # trajectories stay together
+    assert not np.array_equal(out["f16"], out["f32"])                                # the reduced-precision kernels really ran
