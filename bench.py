@@ -180,11 +180,11 @@ def timed(run_steps, n):
 # ---------------------------------------------------------------------------------------------------------------
 # sub-records: BASELINE.json configs[2..4] on ONE GPU, each in a child process (`bench.py --sub NAME`)
 # ---------------------------------------------------------------------------------------------------------------
-SUBS = {
+SUBS = {   # every entry: kind, batch_size, patch, classes, mma (+ in_chns for 2-D)
     "config3d_la_vnet": dict(kind="3d", batch_size=2, patch=[112, 112, 80], classes=2, mma="f32",
                              workload="LA 3D V-Net 112x112x80, --batch_size 2 (4 volumes/step), C=2, D=16, asmc "
                                       "(BASELINE.json configs[2])"),
-    "cityscapes_19c_512x1024": dict(kind="2d", batch_size=1, patch=[512, 1024], classes=19, in_chns=3,
+    "cityscapes_19c_512x1024": dict(kind="2d", batch_size=1, patch=[512, 1024], classes=19, in_chns=3, mma="f32",
                                     workload="Cityscapes-shaped 19-class 3x512x1024, 2 images/GPU (--batch_size 1), D=496, "
                                              "4096-key/class queue (the per-GPU shard of BASELINE.json configs[3])"),
     "lits_160x160x96_f16": dict(kind="3d", batch_size=1, patch=[160, 160, 96], classes=2, mma="f16",

@@ -63,7 +63,9 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
         loss = loss + k4 * loss_q
     eqv = None
     if k2 != 0:      # train_arco_2d.py:404-423; the warp is drawn after the samplers (same torch-generator order)
-        H, W = int(l_data.shape[2]), int(l_data.shape[3])
+        # the trainer builds RandTPS(patch_size[0], patch_size[1]) = RandTPS(width, height) (:255-256): the grid has
+        # HEIGHT patch_size[1] and WIDTH patch_size[0], so a non-square patch comes out of the warp transposed in size
+        H, W = int(l_data.shape[3]), int(l_data.shape[2])
         if "tps" not in st:
             st["tps"] = orc.tps_constants(H, W)
         tcp, inv, rep = st["tps"]
