@@ -20,11 +20,14 @@ Only the anchor ROWS of `rep` enter the loss, so `rep` is touched through a row 
 backward is a row scatter; a trainer may instead feed anchor rows computed lazily
 (arco_amd.head) - same values, no dense 496-channel tensor.
 """
+import ctypes
+
 import torch
 
 from . import _lib as L
 from . import samplers
 
+GROUPED = True      # all classes of the InfoNCE loop per launch (False: the per-class launch sequence; tests compare the two)
 EPS = 1e-8          # torch.cosine_similarity eps
 DELTA_P = 0.3       # current_class_threshold      (loss_helper_3d.py:316)
 LOW_RANK, HIGH_RANK = 3, 20                        # (loss_helper_3d.py:318)
@@ -233,6 +236,7 @@ def contrast_draw(pl, func='asmc', _trace=None):
     else:
         draw, q_arg, n_arg = torch.randint, (pl.Q,), (pl.Q * pl.Nn,)
     pl.entries = []
+    pl.idx_all, pl.idx_stride = None, 0       # packed [anchors(Q) | negatives(Q*Nn)] per entry, when drawn in one native call
     if pl.valid_seg > 1:
         ks = [k for k in range(pl.valid_seg)                               # :435-476, k = LOOP COUNTER
               if not (pl.n_anchor[k] == 0 or pl.bank_len[pl.valid_classes[k]] == 0)]
@@ -249,6 +253,7 @@ def contrast_draw(pl, func='asmc', _trace=None):
             dev_all = torch.empty(total, dtype=torch.int64, device=pl.dev)
             dev_all.copy_(host[:total], non_blocking=True)
             pl._host_idx = host                                           # keep the staging buffer alive until used
+            pl.idx_all, pl.idx_stride = dev_all, pl.Q + pl.Q * pl.Nn
             off = 0
             for i, k in enumerate(ks):
                 a_dev = dev_all[off:off + pl.Q]; off += pl.Q
@@ -333,11 +338,23 @@ def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace
     return pl
 
 
+def _pack_indices(pl):
+    """Sampled indices of all entries in one int64 buffer, [anchors(Q) | negatives(Q*Nn)] per entry (the native draw already
+    produces this layout; the torch.randint / trace-replay paths are packed here)."""
+    if getattr(pl, "idx_all", None) is None:
+        pl.idx_all = torch.cat([torch.cat((a_dev.reshape(-1), n_dev.reshape(-1))) for (k, vc, a_dev, n_dev) in pl.entries]).to(torch.int64)
+        pl.idx_stride = pl.Q + pl.Q * pl.Nn
+
+
 @torch.no_grad()
 def contrast_anchor_pix(pl):
     """global pixel id of every sampled anchor, entries concatenated"""
     if pl.entries:
-        pl.anchor_pix = torch.cat([pl.lists[k][a_dev].to(torch.int64) for (k, vc, a_dev, n_dev) in pl.entries])
+        _pack_indices(pl)
+        E = len(pl.entries)
+        pl.anchor_pix = torch.empty(E * pl.Q, dtype=torch.int64, device=pl.dev)
+        ks = (ctypes.c_int * E)(*[int(k) for (k, vc, a_dev, n_dev) in pl.entries])
+        L.call("arco_anchor_pix", L.ptr(pl.lists), pl.n_pix, ks, E, L.ptr(pl.idx_all), pl.idx_stride, pl.Q, L.ptr(pl.anchor_pix))
     else:
         pl.anchor_pix = torch.empty(0, dtype=torch.int64, device=pl.dev)
     return pl
@@ -346,6 +363,52 @@ def contrast_anchor_pix(pl):
 # ----------------------------------------------------------------------------------------------
 # stage 4 (GPU): InfoNCE over the compact anchor matrix             loss_helper_3d.py:478-513
 # ----------------------------------------------------------------------------------------------
+def _infonce_grouped(pl, A_all, memobank, temp, need_grad):
+    """All entries of the per-class loop (loss_helper_3d.py:435-509) in one launch per stage: normalise anchors /
+    prototypes / banks, batched score GEMM A_c . Bank_c^T on the fp32 matrix cores, fused multiplicity + softmax-CE,
+    batched split-K anchor-gradient GEMM, gradient through the cosine normalisation.  9 launches for any number of classes."""
+    dev, D, Q, Nn, C = pl.dev, pl.D, pl.Q, pl.Nn, pl.C
+    E = len(pl.entries)
+    Dp = _ceil(D, 16)
+    _pack_indices(pl)
+    banks = [memobank[vc][0] for (k, vc, a_dev, n_dev) in pl.entries]
+    lens = [int(b.shape[0]) for b in banks]
+    Lp = _ceil(max(lens), 16)
+    bank_ptrs = (ctypes.c_void_p * E)(*[b.data_ptr() for b in banks])
+    lens_c = (ctypes.c_int * E)(*lens)
+    prow = (ctypes.c_int * E)(*[int(k) for (k, vc, a_dev, n_dev) in pl.entries])      # positive = prototype of LOOP COUNTER k (:480-486)
+    A_det = A_all.detach().contiguous()
+    n = E * Q
+    An = torch.empty((n, Dp), dtype=torch.float32, device=dev)
+    invA = torch.empty(n, dtype=torch.float32, device=dev)
+    L.call("arco_normalize_rows_pad", L.ptr(A_det), D, n, D, Dp, EPS, L.ptr(An), Dp, L.ptr(invA))
+    proto = pl.proto.contiguous()
+    Pn = torch.empty((int(proto.shape[0]), Dp), dtype=torch.float32, device=dev)
+    L.call("arco_normalize_rows_pad", L.ptr(proto), D, int(proto.shape[0]), D, Dp, EPS, L.ptr(Pn), Dp, None)
+    Bn = torch.empty((E, Lp, Dp), dtype=torch.float32, device=dev)
+    Bt = torch.empty((E, Dp, Lp), dtype=torch.float32, device=dev) if need_grad else None
+    L.call("arco_nce_normalize_banks", bank_ptrs, lens_c, E, D, Dp, Lp, EPS, L.ptr(Bn), L.ptr(Bt))
+    S = torch.empty((E, Q, Lp), dtype=torch.float32, device=dev)
+    L.call("arco_gemm_batched", L.ptr(An), Dp, Dp, L.ptr(Bn), Lp, L.ptr(S), Lp, Q, E, Q * Dp, Lp * Dp, Q * Lp, 1, None)
+    W = torch.empty((E, Q, Lp), dtype=torch.float32, device=dev) if need_grad else None
+    gpos = torch.empty(n, dtype=torch.float32, device=dev)
+    loss_q = torch.empty(n, dtype=torch.float32, device=dev)
+    L.call("arco_nce_fused", L.ptr(S), Lp, lens_c, prow, E, L.ptr(pl.idx_all), Q, pl.idx_stride, Q, Nn, L.ptr(An), L.ptr(Pn), Dp,
+           float(temp), L.ptr(W), L.ptr(gpos), L.ptr(loss_q))
+    loss_acc = torch.empty(1, dtype=torch.float32, device=dev)
+    L.call("arco_sum_scale", L.ptr(loss_q), n, 1.0 / (Q * pl.valid_seg), L.ptr(loss_acc), 0)
+    dA_all = None
+    if need_grad:
+        splits = max(1, min(16, Lp // 256))               # Q x D outputs per class, K = bank length: split-K fills the GPU
+        ws = torch.empty((E, splits, Q, Dp), dtype=torch.float32, device=dev) if splits > 1 else None
+        G = torch.empty((n, Dp), dtype=torch.float32, device=dev)
+        L.call("arco_gemm_batched", L.ptr(W), Lp, Lp, L.ptr(Bt), Dp, L.ptr(G), Dp, Q, E, Q * Lp, Dp * Lp, Q * Dp, splits, L.ptr(ws))
+        dA_all = torch.empty((n, D), dtype=torch.float32, device=dev)
+        L.call("arco_nce_anchor_grad", L.ptr(G), L.ptr(An), L.ptr(Pn), prow, E, L.ptr(gpos), L.ptr(invA), Q, D, Dp, EPS,
+               1.0 / (Q * pl.valid_seg), L.ptr(dA_all), D)
+    return loss_acc[0], dA_all
+
+
 def contrast_infonce(pl, A_all, memobank, temp=0.5, momentum_prototype=None, i_iter=0):
     """A_all [len(entries)*Q, D]: the sampled anchor rows (student), entries in plan order.
     Returns (loss, prototype-or-None).  The gradient w.r.t. A_all is computed here (it only needs
@@ -354,6 +417,12 @@ def contrast_infonce(pl, A_all, memobank, temp=0.5, momentum_prototype=None, i_i
     Dp = _ceil(D, 16)
     valid_seg = pl.valid_seg
     need_grad = A_all.requires_grad and torch.is_grad_enabled()
+    if (momentum_prototype is None and pl.entries and GROUPED and Nn < 65536
+            and max(int(memobank[vc][0].shape[0]) for (k, vc, a_, n_) in pl.entries) <= L.query("arco_nce_max_len")):
+        loss, dA_all = _infonce_grouped(pl, A_all, memobank, temp, need_grad)
+        if need_grad:
+            loss = _CompactGrad.apply(A_all, loss, dA_all)
+        return loss, None
     prototype = torch.zeros((C, Q, 1, D), device=dev) if momentum_prototype is not None else None
     loss_acc = torch.zeros(1, dtype=torch.float32, device=dev)
     dA_all = torch.zeros((A_all.shape[0], D), dtype=torch.float32, device=dev) if need_grad else None

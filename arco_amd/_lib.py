@@ -27,6 +27,12 @@ _SIGS = {
     "arco_neg_multiplicity": [_P, _I, _I, _L, _L, _P, _P],
     "arco_infonce_fwd": [_P, _L, _P, _L, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P],
     "arco_infonce_anchor_grad": [_P, _P, _P, _L, _P, _P, _I, _I, _F, _F, _P, _P],
+    "arco_normalize_rows_pad": [_P, _L, _L, _I, _I, _F, _P, _L, _P, _P],
+    "arco_nce_normalize_banks": [_P, _P, _I, _I, _I, _L, _F, _P, _P, _P],
+    "arco_gemm_batched": [_P, _L, _I, _P, _I, _P, _L, _L, _I, _L, _L, _L, _I, _P, _P],
+    "arco_nce_fused": [_P, _L, _P, _P, _I, _P, _L, _L, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P],
+    "arco_nce_anchor_grad": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _F, _P, _L, _P],
+    "arco_anchor_pix": [_P, _L, _P, _I, _P, _L, _I, _P, _P],
     "arco_scatter_add_rows": [_P, _L, _I, _P, _P, _L, _P, _F, _P, _L, _P],
     "arco_sum_scale": [_P, _I, _F, _P, _I, _P],
     "arco_pack_conv_weight": [_P, _I, _I, _I, _I, _P, _P],
@@ -82,6 +88,7 @@ _SIGS = {
 }
 _QUERIES = {   # plain host helpers returning sizes
     "arco_proto_ws_floats": ([_L, _I, _I], _L),
+    "arco_nce_max_len": ([], _L),
     "arco_conv_mblocks": ([_I, _I, _I, _I, _I, _I, _L, _I], _I),
     "arco_conv_config": ([_I, _I, _I, _I, _I, _I, _L, _P], _I),
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),

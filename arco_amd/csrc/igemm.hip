@@ -28,6 +28,7 @@ struct IgemmArgs {
   int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
   int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
   int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3, 1x1x1)
+  int batch; long batchA, batchW, batchC;   // TAPS==1 batched GEMM: blockIdx.z = problem, operands at + z * stride (floats)
 };
 
 // FLAT (3x3 only): the M-tile is BM consecutive positions of the plane stored with a padded row stride Wp = W + 2
@@ -61,6 +62,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int NB_IT = (BROWS * Q4 + 255) / 256;
   constexpr int BUF = (AROWS + BROWS) * LDK;          // floats per LDS buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (TAPS == 1 && a.batch > 1) {       // batched GEMM (grouped InfoNCE: one problem per class)
+    const long z = blockIdx.z;
+    a.A += z * a.batchA; a.Wp += z * a.batchW; a.C += z * a.batchC;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -359,7 +364,8 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   IgemmArgs b = a;
   b.n_mblocks = mblocks;
   b.n_nblocks = (a.Npad + BN - 1) / BN;
-  dim3 grid((unsigned)(mblocks * b.n_nblocks), (unsigned)(TAPS == 1 && a.ksplit > 1 ? a.ksplit : 1));
+  dim3 grid((unsigned)(mblocks * b.n_nblocks), (unsigned)(TAPS == 1 && a.ksplit > 1 ? a.ksplit : 1),
+            (unsigned)(TAPS == 1 && a.batch > 1 ? a.batch : 1));
   hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, b);
   return arco_launch_status();
 }
@@ -1338,6 +1344,39 @@ int arco_gemm_splitk(const float* in, long ld_in, int K, const float* Wp, int N,
   if (rc != ARCO_OK) return rc;
   const long n4 = M * ld_out / 4;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), ws, splits, n4, out);
+  return arco_launch_status();
+}
+
+// `batch` independent GEMMs out_z[M][N] = in_z[M][K] . W_z[N][K]^T in ONE launch (blockIdx.z = z): operand z lives at
+// base + z * stride (floats).  splits > 1: split-K as arco_gemm_splitk - slab (z, y) lands in ws at
+// (z * splits + y) * M * ld_out and the fixed-order slab sum writes out_z; ws may be NULL when splits == 1.
+// The grouped InfoNCE (one problem per class: scores A_c . Bank_c^T and anchor gradients W_c . Bank_c) runs on these.
+__global__ __launch_bounds__(256) void slab_sum_batched_kernel(const float* __restrict__ ws, int splits, long n4, long out_stride4,
+                                                              float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const long z = blockIdx.y;
+  const f32x4* w = reinterpret_cast<const f32x4*>(ws) + z * splits * n4;
+  f32x4 s = w[i];
+  for (int k = 1; k < splits; ++k) s += w[(long)k * n4 + i];
+  reinterpret_cast<f32x4*>(out)[z * out_stride4 + i] = s;
+}
+int arco_gemm_batched(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out, long M,
+                      int batch, long stride_in, long stride_w, long stride_out, int splits, float* ws, void* stream) {
+  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && M > 0 && batch >= 1 && splits >= 1 && (ld_out & 3) == 0);
+  ARCO_CHECK_ARG(splits == 1 || (ws && (stride_out & 3) == 0));
+  IgemmArgs a{};
+  a.A = in; a.lda = ld_in; a.Wp = Wp; a.N = N; a.K = K;
+  a.Npad = (N + 15) / 16 * 16; a.Kpad = (K + 15) / 16 * 16;
+  a.ldc = ld_out; a.NB = 1; a.H = 1; a.W = (int)M; a.M = M; a.D3 = 1;
+  a.batch = batch; a.batchA = stride_in; a.batchW = stride_w;
+  if (splits > 1) { a.C = ws; a.ksplit = splits; a.slab_stride = M * ld_out; a.batchC = (long)splits * M * ld_out; }
+  else { a.C = out; a.batchC = stride_out; }
+  const int rc = dispatch_igemm(a, 1, as_stream(stream), nullptr);
+  if (rc != ARCO_OK || splits == 1) return rc;
+  const long n4 = M * ld_out / 4;
+  hipLaunchKernelGGL(slab_sum_batched_kernel, dim3((unsigned)((n4 + 255) / 256), (unsigned)batch), dim3(256), 0, as_stream(stream),
+                     ws, splits, n4, stride_out / 4, out);
   return arco_launch_status();
 }
 

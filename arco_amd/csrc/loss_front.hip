@@ -411,6 +411,155 @@ __global__ __launch_bounds__(256) void infonce_fwd_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// Grouped InfoNCE: all classes (entries) of a step in one launch per stage (blockIdx.y / z = entry).
+// Per-entry data travels by value in NceTable: bank pointer + length, prototype row, first sampled index.
+// ---------------------------------------------------------------------------
+struct NceTable {
+  const float* bank[ARCO_MAXC];
+  int len[ARCO_MAXC];       // bank rows of the entry
+  int prow[ARCO_MAXC];      // row of the entry's positive in the normalised prototype matrix
+};
+
+// y[j][0..Dp) = x[j] / max(||x[j]||, eps), zero in the pad columns; inv[j] = 1 / max(||x||, eps)
+__global__ __launch_bounds__(256) void normalize_rows_pad_kernel(const float* __restrict__ x, long ldx, long n, int D, int Dp,
+                                                                float eps, float* __restrict__ y, long ldy,
+                                                                float* __restrict__ inv) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const float* s = x + j * ldx;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = s[d]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float iv = 1.0f / fmaxf(sqrtf(ss), eps);
+  if (lane == 0 && inv) inv[j] = iv;
+  for (int d = lane; d < Dp; d += 64) y[j * ldy + d] = d < D ? s[d] * iv : 0.f;
+}
+
+// Bn[e][j][0..Dp) (rows >= len and pad columns zero) and its transpose Bt[e][d][j] (nullable), j < Lp
+__global__ __launch_bounds__(256) void normalize_banks_kernel(NceTable t, int D, int Dp, long Lp, float eps,
+                                                             float* __restrict__ Bn, float* __restrict__ Bt) {
+  const int lane = threadIdx.x & 63, e = blockIdx.y;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= Lp) return;
+  float* y = Bn + ((long)e * Lp + j) * Dp;
+  float* yt = Bt ? Bt + (long)e * Dp * Lp + j : nullptr;
+  if (j >= t.len[e]) {
+    for (int d = lane; d < Dp; d += 64) { y[d] = 0.f; if (yt) yt[(long)d * Lp] = 0.f; }
+    return;
+  }
+  const float* s = t.bank[e] + j * (long)D;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = s[d]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float iv = 1.0f / fmaxf(sqrtf(ss), eps);
+  for (int d = lane; d < Dp; d += 64) {
+    const float v = d < D ? s[d] * iv : 0.f;
+    y[d] = v;
+    if (yt) yt[(long)d * Lp] = v;
+  }
+}
+
+// One block per (query, entry): negative multiplicities built in LDS (16-bit counters, two per word) from the entry's
+// Nn sampled indices, then exactly the arithmetic of infonce_fwd_kernel.  idx of entry e: idx_all + e*idx_stride + idx_off.
+__global__ __launch_bounds__(256) void infonce_fused_kernel(const float* __restrict__ S, long ld, NceTable t,
+                                                           const int64_t* __restrict__ idx_all, long idx_off, long idx_stride,
+                                                           int Q, int Nn, const float* __restrict__ An,
+                                                           const float* __restrict__ Pn_all, int Dp, float inv_temp,
+                                                           float* __restrict__ W, float* __restrict__ gpos,
+                                                           float* __restrict__ loss_q) {
+  extern __shared__ uint32_t cnt[];                  // ceil(L / 2) words
+  const int q = blockIdx.x, e = blockIdx.y;
+  const long L = t.len[e];
+  const long row = (long)e * Q + q;
+  const float* s = S + row * ld;
+  const float* An_q = An + row * Dp;
+  const float* Pn = Pn_all + (long)t.prow[e] * Dp;
+  for (long k = threadIdx.x; k < (L + 1) / 2; k += 256) cnt[k] = 0u;
+  __syncthreads();
+  const int64_t* idx = idx_all + (long)e * idx_stride + idx_off + (long)q * Nn;
+  for (int i = threadIdx.x; i < Nn; i += 256) {
+    long k = idx[i];
+    if (k < 0) k += L;
+    atomicAdd(&cnt[k >> 1], 1u << (16 * (int)(k & 1)));
+  }
+  __shared__ float sh[8];
+  float dp = 0.f;
+  for (int d = threadIdx.x; d < Dp; d += 256) dp += An_q[d] * Pn[d];
+  dp = wave_sum(dp);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dp;
+  __syncthreads();
+  const float pos = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  float mx = pos * inv_temp;
+  for (long k = threadIdx.x; k < L; k += 256)
+    if ((cnt[k >> 1] >> (16 * (int)(k & 1))) & 0xffffu) mx = fmaxf(mx, s[k] * inv_temp);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  double se = 0.0;
+  for (long k = threadIdx.x; k < L; k += 256) {
+    const uint32_t mk = (cnt[k >> 1] >> (16 * (int)(k & 1))) & 0xffffu;
+    if (mk) se += (double)mk * (double)expf(s[k] * inv_temp - mx);
+  }
+  se = wave_sum_d(se);
+  __shared__ double shd[4];
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = se;
+  __syncthreads();
+  const double tot = ((shd[0] + shd[1]) + (shd[2] + shd[3])) + (double)expf(pos * inv_temp - mx);
+  const float lse = mx + (float)log(tot);
+  if (threadIdx.x == 0) {
+    loss_q[row] = lse - pos * inv_temp;
+    gpos[row] = (expf(pos * inv_temp - lse) - 1.0f) * inv_temp;
+  }
+  if (W) {
+    float* w = W + row * ld;
+    for (long k = threadIdx.x; k < ld; k += 256) {       // the whole padded row: columns >= L are zero (GEMM K range)
+      uint32_t mk = 0;
+      if (k < L) mk = (cnt[k >> 1] >> (16 * (int)(k & 1))) & 0xffffu;
+      w[k] = mk ? (float)mk * expf(s[k] * inv_temp - lse) * inv_temp : 0.f;
+    }
+  }
+}
+
+// anchor gradient of every entry in one launch: row r = e*Q + q uses the entry's positive; writes dA[r][0..D) (row stride ldd)
+__global__ __launch_bounds__(256) void infonce_anchor_grad_batched_kernel(const float* __restrict__ G, const float* __restrict__ An,
+                                                                         const float* __restrict__ Pn_all, NceTable t,
+                                                                         const float* __restrict__ gpos, const float* __restrict__ inv,
+                                                                         int Q, long n_rows, int D, int Dp, float eps, float scale,
+                                                                         float* __restrict__ dA, long ldd) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const float* Pn = Pn_all + (long)t.prow[r / Q] * Dp;
+  const float gp = gpos[r], iv = inv[r];
+  float dot = 0.f;
+  for (int d = lane; d < Dp; d += 64) {
+    const float g = G[r * Dp + d] + gp * Pn[d];
+    dot += g * An[r * Dp + d];
+  }
+  dot = wave_sum(dot);
+  const bool clamped = iv >= 1.0f / eps;
+  for (int d = lane; d < D; d += 64) {
+    const float g = G[r * Dp + d] + gp * Pn[d];
+    const float v = clamped ? g * iv : iv * (g - An[r * Dp + d] * dot);
+    dA[r * ldd + d] = v * scale;
+  }
+}
+
+// out[e*Q + q] = lists[k_e][ idx_e[q] ]  (global pixel id of every sampled anchor, entries back to back)
+struct PixTable { int k[ARCO_MAXC]; };
+__global__ void anchor_pix_kernel(const int32_t* __restrict__ lists, long n_pix, PixTable t, const int64_t* __restrict__ idx_all,
+                                  long idx_stride, int Q, int E, int64_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q * E) return;
+  const int e = i / Q, q = i - e * Q;
+  out[i] = (int64_t)lists[(long)t.k[e] * n_pix + idx_all[(long)e * idx_stride + q]];
+}
+
 // anchor gradient through the normalisation:  dAhat = G + gpos*Pn ;
 // dA = inv*(dAhat - Ahat*(Ahat.dAhat)) if ||A||>eps else dAhat/eps ; scaled by `scale`
 __global__ __launch_bounds__(256) void infonce_anchor_grad_kernel(const float* __restrict__ G, const float* __restrict__ An,
@@ -630,6 +779,73 @@ int arco_scatter_add_rows(const float* src, long ld_src, int D, const int32_t* l
   if (n == 0) return ARCO_OK;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), src, ld_src, D, list, idx, n,
                      alpha_dev, alpha, dst, ld_dst);
+  return arco_launch_status();
+}
+
+// ---- grouped InfoNCE (all classes of a step per launch); host arrays: banks[E] device pointers, lens[E], prow[E] -------------
+static int fill_table(NceTable& t, const void* const* banks, const int* lens, const int* prow, int E) {
+  if (E < 1 || E > ARCO_MAXC) return ARCO_ERR_ARG;
+  for (int e = 0; e < E; ++e) {
+    t.bank[e] = banks ? reinterpret_cast<const float*>(banks[e]) : nullptr;
+    t.len[e] = lens ? lens[e] : 0; t.prow[e] = prow ? prow[e] : 0;
+  }
+  return ARCO_OK;
+}
+int arco_normalize_rows_pad(const float* x, long ldx, long n, int D, int Dp, float eps, float* y, long ldy, float* inv,
+                            void* stream) {
+  ARCO_CHECK_ARG(n >= 0 && D > 0 && Dp >= D && y);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(normalize_rows_pad_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), x, ldx, n, D, Dp, eps, y, ldy, inv);
+  return arco_launch_status();
+}
+// Bn [E][Lp][Dp] (+ Bt [E][Dp][Lp], nullable): normalised rows of every entry's bank, zero padded (loss_helper_3d.py:503)
+int arco_nce_normalize_banks(const void* const* banks, const int* lens, int E, int D, int Dp, long Lp, float eps, float* Bn,
+                             float* Bt, void* stream) {
+  NceTable t;
+  ARCO_CHECK_ARG(fill_table(t, banks, lens, nullptr, E) == ARCO_OK && D > 0 && Dp >= D && Lp > 0 && Bn);
+  for (int e = 0; e < E; ++e) ARCO_CHECK_ARG(t.bank[e] && t.len[e] > 0 && t.len[e] <= Lp);
+  hipLaunchKernelGGL(normalize_banks_kernel, dim3((unsigned)((Lp + 3) / 4), (unsigned)E), dim3(256), 0, as_stream(stream), t, D, Dp,
+                     Lp, eps, Bn, Bt);
+  return arco_launch_status();
+}
+// S / W: [E][Q][ld]; An [E*Q][Dp]; Pn_all [*][Dp] (row prow[e] = the entry's positive); idx_all: int64 indices, the Q*Nn
+// negatives of entry e start at idx_all + e*idx_stride + idx_off; gpos / loss_q [E*Q].  loss_helper_3d.py:503-509.
+long arco_nce_max_len() { return 2l * ((160 * 1024 - 512) / 4); }      // longest bank arco_nce_fused accepts: 16-bit counters in <= 160 KB of LDS
+int arco_nce_fused(const float* S, long ld, const int* lens, const int* prow, int E, const int64_t* idx_all, long idx_off,
+                   long idx_stride, int Q, int Nn, const float* An, const float* Pn_all, int Dp, float temp, float* W,
+                   float* gpos, float* loss_q, void* stream) {
+  NceTable t;
+  ARCO_CHECK_ARG(fill_table(t, nullptr, lens, prow, E) == ARCO_OK && Q > 0 && Nn > 0 && Nn < 65536 && temp > 0.f && S && An && Pn_all);
+  long Lmax = 0;
+  for (int e = 0; e < E; ++e) { ARCO_CHECK_ARG(t.len[e] > 0 && t.len[e] <= ld); if (t.len[e] > Lmax) Lmax = t.len[e]; }
+  const size_t sh = (size_t)((Lmax + 1) / 2) * sizeof(uint32_t);
+  ARCO_CHECK_ARG(sh <= (size_t)(160 * 1024 - 512));
+  static bool attr_set = false;
+  if (sh > 48 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(infonce_fused_kernel, dim3((unsigned)Q, (unsigned)E), dim3(256), sh, as_stream(stream), S, ld, t, idx_all,
+                     idx_off, idx_stride, Q, Nn, An, Pn_all, Dp, 1.0f / temp, W, gpos, loss_q);
+  return arco_launch_status();
+}
+int arco_nce_anchor_grad(const float* G, const float* An, const float* Pn_all, const int* prow, int E, const float* gpos,
+                         const float* inv, int Q, int D, int Dp, float eps, float scale, float* dA, long ld_dA, void* stream) {
+  NceTable t;
+  ARCO_CHECK_ARG(fill_table(t, nullptr, nullptr, prow, E) == ARCO_OK && Q > 0 && D > 0 && Dp >= D);
+  const long n = (long)E * Q;
+  hipLaunchKernelGGL(infonce_anchor_grad_batched_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), G, An, Pn_all,
+                     t, gpos, inv, Q, n, D, Dp, eps, scale, dA, ld_dA);
+  return arco_launch_status();
+}
+// out[e*Q + q] = lists[k[e]][idx_all[e*idx_stride + q]]: pixel ids of the sampled anchors (loss_helper_3d.py:455-457)
+int arco_anchor_pix(const int32_t* lists, long n_pix, const int* k, int E, const int64_t* idx_all, long idx_stride, int Q,
+                    int64_t* out, void* stream) {
+  ARCO_CHECK_ARG(lists && k && idx_all && out && E >= 1 && E <= ARCO_MAXC && Q > 0);
+  PixTable t;
+  for (int e = 0; e < E; ++e) t.k[e] = k[e];
+  hipLaunchKernelGGL(anchor_pix_kernel, dim3((unsigned)((Q * E + 255) / 256)), dim3(256), 0, as_stream(stream), lists, n_pix, t, idx_all,
+                     idx_stride, Q, E, out);
   return arco_launch_status();
 }
 

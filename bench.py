@@ -327,6 +327,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     loss_ms = (sum(e0.elapsed_time(e1) for evs in stepper.loss_events for e0, e1 in evs) / max(1, len(stepper.loss_events)))
+    loss_seg = [round(sum(evs[i][0].elapsed_time(evs[i][1]) for evs in stepper.loss_events) / max(1, len(stepper.loss_events)), 3)
+                for i in range(3)]
     stepper.profile_loss = False
     stepper.loss_events = []
     if world > 1:
@@ -368,6 +370,8 @@ def main():
             # compute_contra_memobank_loss on the GPU clock: masks | lists, prototypes, keys, banks | anchors, row-sparse head,
             # InfoNCE INCLUDING its analytic gradient w.r.t. the anchors (the loss's backward is computed in the forward)
             "contrastive_loss_ms_per_step": round(loss_ms, 3),
+            "contrastive_loss_segments_ms": {"masks_counts": loss_seg[0], "lists_prototypes_keys_banks": loss_seg[1],
+                                             "anchors_head_infonce": loss_seg[2]},
             "roofline": roof,
         }
         if whole is not None:

@@ -61,6 +61,31 @@ int arco_infonce_fwd(const float* S, long ld, const uint32_t* M, long L, const f
 /* ... dA = scale * d(loss)/dA through the cosine normalisation (G = W @ Bn)                                */
 int arco_infonce_anchor_grad(const float* G, const float* An, const float* Pn, long ldp, const float* gpos,
                              const float* inv, int Q, int D, float eps, float scale, float* dA, void* stream);
+/* ---- L5-L6 grouped: every class ("entry") of the per-class loop of loss_helper_3d.py:435-509 in ONE launch per stage.
+   Host arrays of E <= 21 entries: banks[e] (device pointer of memobank[valid_classes[k]][0]), lens[e] (its rows),
+   prow[e] (row of seg_proto[k] in the normalised prototype matrix), k[e] (loop counter = row-list index).              */
+/* y = x / max(||x||, eps) written with zeroed pad columns [D, Dp) (anchors, prototypes)                                 */
+int arco_normalize_rows_pad(const float* x, long ldx, long n, int D, int Dp, float eps, float* y, long ldy, float* inv,
+                            void* stream);
+/* Bn[E][Lp][Dp] = normalised bank rows (zero beyond lens[e] / D), Bt[E][Dp][Lp] = their transposes (nullable)          */
+int arco_nce_normalize_banks(const void* const* banks, const int* lens, int E, int D, int Dp, long Lp, float eps, float* Bn,
+                             float* Bt, void* stream);
+/* batch independent GEMMs out_z = in_z . W_z^T (operand z at base + z*stride floats), optional split-K through ws:
+   the cosine scores A_c . Bank_c^T (loss_helper_3d.py:503-505) and the anchor-gradient GEMMs W_c . Bank_c              */
+int arco_gemm_batched(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out, long M,
+                      int batch, long stride_in, long stride_w, long stride_out, int splits, float* ws, void* stream);
+/* per (query, entry): multiplicities of the sampled negatives (LDS), loss_q = logsumexp([pos, S[q, idx]]/T) - pos/T,
+   W = d loss_q / dS over the whole padded row, gpos = d loss_q / d pos (loss_helper_3d.py:478-509)                      */
+long arco_nce_max_len(void);
+int arco_nce_fused(const float* S, long ld, const int* lens, const int* prow, int E, const int64_t* idx_all, long idx_off,
+                   long idx_stride, int Q, int Nn, const float* An, const float* Pn_all, int Dp, float temp, float* W,
+                   float* gpos, float* loss_q, void* stream);
+/* dA[e*Q+q][0..D) = scale * d loss / d anchor through the cosine normalisation, all entries                            */
+int arco_nce_anchor_grad(const float* G, const float* An, const float* Pn_all, const int* prow, int E, const float* gpos,
+                         const float* inv, int Q, int D, int Dp, float eps, float scale, float* dA, long ld_dA, void* stream);
+/* out[e*Q+q] = lists[k[e]][idx_all[e*idx_stride + q]]: pixel id of every sampled anchor (loss_helper_3d.py:455-457)     */
+int arco_anchor_pix(const int32_t* lists, long n_pix, const int* k, int E, const int64_t* idx_all, long idx_stride, int Q,
+                    int64_t* out, void* stream);
 /* dst[list?list[idx[j]]:idx[j]] += alpha * (alpha_dev?*alpha_dev:1) * src[j]  (backward of the anchor gather) */
 int arco_scatter_add_rows(const float* src, long ld_src, int D, const int32_t* list, const int64_t* idx, long n,
                           const float* alpha_dev, float alpha, float* dst, long ld_dst, void* stream);

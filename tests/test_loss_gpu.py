@@ -190,3 +190,37 @@ def test_loss_full_size_properties():
         assert nk1 == nk2 and abs(l1 - l2) < 2e-5 * max(1.0, abs(l1))
         np.testing.assert_allclose((4.0 * g2[:, :, ::16, ::16]).cpu().numpy(), g1[:, :, ::16, ::16].cpu().numpy(), rtol=2e-3, atol=1e-9)
     assert 0.5 < out1[-1][1] < 20.0
+
+
+@pytest.mark.parametrize("cfg", [dict(b=2, n_cls=4, feat=64, spatial=(32, 32), Q=64, Nn=32, qs=300),
+                                 dict(b=1, n_cls=19, feat=496, spatial=(32, 48), Q=32, Nn=64, qs=100),
+                                 dict(b=1, n_cls=2, feat=16, spatial=(8, 12, 10), Q=48, Nn=16, qs=40)])
+def test_grouped_infonce_equals_per_class_launches(cfg):
+    """The grouped InfoNCE (all classes per launch: batched MFMA GEMMs, LDS multiplicities) against the per-class launch
+    sequence on chained steps with ragged bank lengths: same loss (1e-6), same gradient, identical banks."""
+    from arco_amd import _contrast as C_
+    from arco_amd.loss_helper_3d import compute_contra_memobank_loss
+    inp = to_dev(fx.loss_inputs(11, b=cfg["b"], n_cls=cfg["n_cls"], feat=cfg["feat"], spatial=cfg["spatial"]))
+    out = {}
+    try:
+        for grouped in (True, False):
+            C_.GROUPED = grouped
+            bank, ptr, qs = fx.fresh_bank(cfg["n_cls"], cfg["feat"], cfg["qs"], 'zeros')
+            res = []
+            for s in range(3):
+                seed_all(40 + s)
+                r = inp["rep"].clone().requires_grad_(True)
+                nk, loss = compute_contra_memobank_loss(r, inp["label_l"], inp["label_u"], inp["prob_l"], inp["prob_u"], inp["low_mask"],
+                                                        inp["high_mask"], bank, ptr, qs, inp["rep_teacher"], func='smc',
+                                                        num_queries=cfg["Q"], num_negatives=cfg["Nn"], delta_n=0.97)
+                loss.backward()
+                res.append((nk, float(loss.detach()), r.grad.clone()))
+            out[grouped] = (res, [b[0].clone() for b in bank])
+    finally:
+        C_.GROUPED = True
+    for (nk1, l1, g1), (nk2, l2, g2) in zip(out[True][0], out[False][0]):
+        assert nk1 == nk2 and abs(l1 - l2) <= 2e-6 * max(1.0, abs(l2)), (l1, l2)
+        np.testing.assert_allclose(g1.cpu().numpy(), g2.cpu().numpy(), rtol=1e-4, atol=1e-9)
+    for b1, b2 in zip(out[True][1], out[False][1]):
+        assert torch.equal(b1, b2)
+    assert abs(out[True][0][-1][1]) > 1e-3
