@@ -28,6 +28,7 @@ struct IgemmArgs {
   int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
   int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
   int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3, 1x1x1)
+  int Kg;                            // mma == 3: 16-k groups per packed weight row (= ceil32(K) / 16)
   int batch; long batchA, batchW, batchC;   // TAPS==1 batched GEMM: blockIdx.z = problem, operands at + z * stride (floats)
 };
 
@@ -40,6 +41,35 @@ constexpr int IGEMM_FLAT_WPMAX = 64;
 // values a lane reads per fragment are rounded to f16 / bf16 in registers and fed to ONE v_mfma_f32_16x16x16_{f16,bf16}
 // (same K-to-lane mapping as four 16x16x4 fp32 MFMAs), fp32 accumulation: 1/16 of the matrix-core time, so the 3x3x3
 // levels become LDS/HBM-bound.  Opt-in (--conv_mma), tolerance 1e-2; never the default or the benchmark.
+// MMA = 3 ("3 x bf16", the DEFAULT of the trainers): fp32-accurate products on the bf16 matrix cores.  An fp32 value is
+// EXACTLY x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (3 x 8 significand bits, RNE
+// remainders are signed), so x*y = x0y0 + (x0y1 + x1y0) + (x0y2 + x1y1 + x2y0) + O(2^-24 |xy|): six
+// v_mfma_f32_16x16x32_bf16 (each product exact, fp32 accumulate) replace eight v_mfma_f32_16x16x4_f32 per 32 k:
+// 96 matrix-core cycles instead of 256 (measured issue rates, tools/micro/mfma_rate.hip: 16 vs 32 cycles), error per
+// product <= 2^-23 relative - the size of one fp32 rounding (tests/test_split_mma_gpu.py compares both modes with fp64).
+// The split is done ONCE: weights are packed pre-split (pack kernels, format "split": [tap][Npad][Kpad32/16][3][16] bf16),
+// activations are split when a tile is staged into LDS (3 bf16 planes per row, 24 dwords per 16 k - with this stride the
+// ds_read_b128 fragment reads are bank-conflict free without padding).  3x3: KC = 16, a K = 32 MFMA step covers the 16
+// channels of TWO taps (lanes g = 0,1 read tap 2s, g = 2,3 tap 2s+1; the 10th half-step multiplies a zero weight row);
+// 1x1: KC = 32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_bf16x4(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+  unsigned short h[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 b0 = (__bf16)v[e];
+    const float r1 = v[e] - (float)b0;
+    const __bf16 b1 = (__bf16)r1;
+    const float r2 = r1 - (float)b1;
+    const __bf16 b2 = (__bf16)r2;
+    h[0][e] = __builtin_bit_cast(unsigned short, b0); h[1][e] = __builtin_bit_cast(unsigned short, b1);
+    h[2][e] = __builtin_bit_cast(unsigned short, b2);
+  }
+  p0 = u32x2{(unsigned)h[0][0] | ((unsigned)h[0][1] << 16), (unsigned)h[0][2] | ((unsigned)h[0][3] << 16)};
+  p1 = u32x2{(unsigned)h[1][0] | ((unsigned)h[1][1] << 16), (unsigned)h[1][2] | ((unsigned)h[1][3] << 16)};
+  p2 = u32x2{(unsigned)h[2][0] | ((unsigned)h[2][1] << 16), (unsigned)h[2][2] | ((unsigned)h[2][3] << 16)};
+}
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16x4 to_f16x4(f32x4 v) { return __builtin_convertvector(v, f16x4); }
@@ -52,15 +82,18 @@ __device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
 template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH, bool FLAT = false, int MMA = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int TH = BM / 16;
+  constexpr bool X3 = MMA == 3;
+  static_assert(!X3 || (TAPS == 9 ? KC == 16 : KC == 32), "split-bf16 mode: KC = 16 (3x3, tap pairs) or 32 (1x1)");
   constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * IGEMM_FLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
   constexpr int BROWS = TAPS * BN;
-  constexpr int LDK = KC + 4;
+  constexpr int LDK = X3 ? (KC / 16) * 24 + (KC == 32 ? 8 : 0) : KC + 4;     // dwords per LDS row
   constexpr int A_T = BM / 16 / WAVES_M;
   constexpr int C_T = BN / 16 / WAVES_N;
   constexpr int Q4 = KC / 4;
+  constexpr int PB = X3 ? (KC / 16) * 6 : Q4;          // 16-byte pieces per staged weight row
   constexpr int NA_IT = (AROWS * Q4 + 255) / 256;
-  constexpr int NB_IT = (BROWS * Q4 + 255) / 256;
-  constexpr int BUF = (AROWS + BROWS) * LDK;          // floats per LDS buffer
+  constexpr int NB_IT = (BROWS * PB + 255) / 256;
+  constexpr int BUF = (AROWS + BROWS + (X3 ? 1 : 0)) * LDK;          // floats per LDS buffer (X3: + one zero weight row)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (TAPS == 1 && a.batch > 1) {       // batched GEMM (grouped InfoNCE: one problem per class)
     const long z = blockIdx.z;
@@ -137,7 +170,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         const long m = m0 + row;
         if (m < m_lim) pix = m;
       }
-      ldsA[it] = row * LDK + 4 * q; kA[it] = 4 * q;
+      ldsA[it] = X3 ? row * LDK + (q / 4) * 24 + (q % 4) * 2 : row * LDK + 4 * q; kA[it] = 4 * q;
       if (pix >= 0) srcA[it] = a.A + pix * a.lda + 4 * q;
     }
   }
@@ -146,27 +179,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   for (int it = 0; it < NB_IT; ++it) {
     const int idx = tid + it * 256;
     srcB[it] = nullptr; ldsB[it] = -1; kB[it] = 0;
-    if (idx < BROWS * Q4) {
-      const int row = idx / Q4, q = idx - row * Q4;
+    if (idx < BROWS * PB) {
+      const int row = idx / PB, q = idx - row * PB;
       const int tap = row / BN, n = row - tap * BN;
-      ldsB[it] = AROWS * LDK + row * LDK + 4 * q; kB[it] = 4 * q;
-      if (n0 + n < a.Npad) srcB[it] = a.Wp + ((long)tap * a.Npad + n0 + n) * a.Kpad + 4 * q;
+      ldsB[it] = AROWS * LDK + row * LDK + 4 * q; kB[it] = X3 ? (q / 6) * 16 : 4 * q;
+      if (n0 + n < a.Npad)      // X3: packed split rows, 24 dwords per 16 k
+        srcB[it] = X3 ? a.Wp + ((long)tap * a.Npad + n0 + n) * a.Kg * 24 + 4 * q
+                      : a.Wp + ((long)tap * a.Npad + n0 + n) * a.Kpad + 4 * q;
     }
   }
 
   // 3-D (DEPTH==3): a 3x3x3 conv is the sum over the depth tap dd of a 3x3 conv of input plane x+dd-1
   // with weight slice Wp[dd*9 .. dd*9+8]; the K loop simply runs DEPTH times over shifted planes.
-  const int nchunks = (a.Kpad + KC - 1) / KC;
+  const int nchunks = (a.Kpad + KC - 1) / KC;        // (X3: Kpad = ceil16(K) for 3x3, ceil32(K) for 1x1, set by the entry point)
   const int plane = DEPTH == 3 ? img % a.D3 : 0;
   const long plane_elems = (long)a.H * a.W * a.lda;
-  const long wslice = (long)9 * a.Npad * a.Kpad;
+  const long wslice = X3 ? (long)9 * a.Npad * a.Kg * 24 : (long)9 * a.Npad * a.Kpad;
   f32x4 ra[NA_IT], rb[NB_IT];
   auto load_chunk = [&](int itc) {
     const int dd = DEPTH == 3 ? itc / nchunks : 0;
     const int kc0 = (DEPTH == 3 ? itc - dd * nchunks : itc) * KC;
     const bool plane_ok = DEPTH == 3 ? (plane + dd - 1 >= 0 && plane + dd - 1 < a.D3) : true;
     const long aoff = DEPTH == 3 ? (long)(dd - 1) * plane_elems + kc0 : kc0;
-    const long boff = DEPTH == 3 ? (long)dd * wslice + kc0 : kc0;
+    const long bk0 = X3 ? (long)(kc0 / 16) * 24 : kc0;
+    const long boff = DEPTH == 3 ? (long)dd * wslice + bk0 : bk0;
 #pragma unroll
     for (int it = 0; it < NA_IT; ++it) {
       f32x4 v = f32x4{0, 0, 0, 0};
@@ -192,12 +228,61 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   };
   auto store_chunk = [&](float* buf) {
 #pragma unroll
-    for (int it = 0; it < NA_IT; ++it) if (ldsA[it] >= 0) *reinterpret_cast<f32x4*>(&buf[ldsA[it]]) = ra[it];
+    for (int it = 0; it < NA_IT; ++it) if (ldsA[it] >= 0) {
+      if constexpr (X3) {      // activations: split into the three bf16 planes of the row's 16-k group
+        u32x2 p0, p1, p2;
+        split3_bf16x4(ra[it], p0, p1, p2);
+        unsigned int* d = reinterpret_cast<unsigned int*>(buf) + ldsA[it];
+        *reinterpret_cast<u32x2*>(d) = p0; *reinterpret_cast<u32x2*>(d + 8) = p1; *reinterpret_cast<u32x2*>(d + 16) = p2;
+      } else {
+        *reinterpret_cast<f32x4*>(&buf[ldsA[it]]) = ra[it];
+      }
+    }
 #pragma unroll
     for (int it = 0; it < NB_IT; ++it) if (ldsB[it] >= 0) *reinterpret_cast<f32x4*>(&buf[ldsB[it]]) = rb[it];
   };
   auto compute = [&](const float* buf) {
     const float* As = buf; const float* Bs = buf + AROWS * LDK;
+    if constexpr (X3) {
+      constexpr int NSTEP = TAPS == 9 ? 5 : 1;
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        const int tapL = TAPS == 9 ? 2 * st + (g >> 1) : 0;
+        const bool zt = tapL > 8;                       // the 10th half-step: zero weight row
+        const int tapA = zt ? 8 : tapL;
+        const int dy = TAPS == 9 ? tapA / 3 : 0, dx = TAPS == 9 ? tapA % 3 : 0;
+        const int koff = TAPS == 9 ? (g & 1) * 4 : (g >> 1) * 24 + (g & 1) * 4;
+        bf16x8 fa[A_T][3];
+#pragma unroll
+        for (int at = 0; at < A_T; ++at) {
+          const int s = wm * A_T + at;
+          const int row = TAPS == 9 ? (FLAT ? s * 16 + li + dy * Wp + dx : (s + dy) * 18 + li + dx) : s * 16 + li;
+          const float* p = &As[row * LDK + koff];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fa[at][pl] = *reinterpret_cast<const bf16x8*>(p + 8 * pl);
+        }
+#pragma unroll
+        for (int ct = 0; ct < C_T; ++ct) {
+          const int row = zt ? BROWS : tapA * BN + (wn * C_T + ct) * 16 + li;
+          const float* p = &Bs[row * LDK + koff];
+          bf16x8 fb[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(p + 8 * pl);
+#pragma unroll
+          for (int at = 0; at < A_T; ++at) {       // small terms first
+            f32x4 c = acc[at][ct];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][2], fb[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][1], fb[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][1], fb[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[0], c, 0, 0, 0);
+            acc[at][ct] = c;
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
@@ -258,6 +343,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     c_first = blockIdx.y * per;
     niter = min(nchunks, c_first + per);
     a.C += (long)blockIdx.y * a.slab_stride;
+  }
+  if constexpr (X3) {       // the zero weight row behind the staged rows (both buffers)
+    for (int i = tid; i < LDK * (DB ? 2 : 1); i += 256) smem[(i / LDK) * BUF + (AROWS + BROWS) * LDK + i % LDK] = 0.f;
   }
   if (c_first < niter) {
     load_chunk(c_first);
@@ -355,7 +443,8 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
     n_mblocks_out[2] = KC * 100 + DEPTH * 10 + (DB ? 1 : 0);
     return ARCO_OK;
   }
-  size_t sh = (size_t)(DB ? 2 : 1) * (AROWS + TAPS * BN) * (KC + 4) * sizeof(float);
+  constexpr int LDKL = MMA == 3 ? (KC / 16) * 24 + (KC == 32 ? 8 : 0) : KC + 4;
+  size_t sh = (size_t)(DB ? 2 : 1) * (AROWS + TAPS * BN + (MMA == 3 ? 1 : 0)) * LDKL * sizeof(float);
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
   auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC, DEPTH, FLAT, MMA>;
@@ -373,6 +462,10 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
 template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, int DEPTH = 1, bool FLAT = false>
 static int launch_igemm(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out) {
   const bool vec = ((a.K & 3) == 0) && ((a.lda & 3) == 0);
+  if constexpr ((TAPS == 9 && KC == 16) || (TAPS == 1 && KC == 32)) {   // split-bf16 (fp32-accurate) mode
+    if (vec && a.mma == 3) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, (TAPS == 1 && BM * BN > 64 * 64) ? false : DB, true, DEPTH, FLAT, 3>(a, st, n_mblocks_out);
+  }
+  if (a.mma == 3) return ARCO_ERR_UNSUPPORTED;   // the caller asks arco_conv_split_ok() first
   if constexpr (DEPTH == 3 || TAPS == 1) {   // reduced-precision MFMA operands: the 3x3x3 kernels and the 1x1x1 GEMMs (vector loads)
     if (vec && a.mma == 1) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH, FLAT, 1>(a, st, n_mblocks_out);
     if (vec && a.mma == 2) return launch_igemm_v<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, true, DEPTH, FLAT, 2>(a, st, n_mblocks_out);
@@ -775,6 +868,17 @@ static int launch_image_conv(const IgemmArgs& a, hipStream_t st, int* q) {
   return arco_launch_status();
 }
 static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb) {
+  if (taps == 1 && a.mma == 3) {      // split-bf16 GEMMs: K chunks of 32
+    if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 32, false>(a, st, nmb);
+    if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 32, false>(a, st, nmb);
+    if (a.M * (long)a.Npad <= 4096l * 1024) {
+      const long tiles64 = ((a.M + 63) / 64) * ((a.Npad + 63) / 64);
+      if (tiles64 < 192 && a.stat_groups <= 1) return launch_igemm<1, 32, 64, 2, 2, 32, true>(a, st, nmb);
+      return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
+    }
+    if ((a.Npad + 223) / 224 * 224 < (a.Npad + 127) / 128 * 128) return launch_igemm<1, 64, 224, 2, 2, 32, false>(a, st, nmb);
+    return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
+  }
   if (taps == 1) {
     if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 16, true>(a, st, nmb);
     if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 16, true>(a, st, nmb);
@@ -802,6 +906,16 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
 //   mode 0 (forward):  Wp[tap][co][ci] = W[co][ci][tap]
 //   mode 1 (dgrad):    Wp[tap][ci][co] = W[co][ci][TAPS-1-tap]   (flipped, transposed)
 // ---------------------------------------------------------------------------
+//   mode | 2 ("split", the operand format of the MMA = 3 kernels): element (tap, n, k) is stored as its three bf16 terms
+//   x0 + x1 + x2 at ((tap*Npad + n) * Kpad/16 + k/16) * 48 + p*16 + k%16 (bf16 units), Kpad = ceil32(K)
+__device__ __forceinline__ void store_split3(float v, unsigned short* __restrict__ dst, long r, int k, int Kpad) {
+  const __bf16 b0 = (__bf16)v; const float r1 = v - (float)b0;
+  const __bf16 b1 = (__bf16)r1; const float r2 = r1 - (float)b1;
+  const __bf16 b2 = (__bf16)r2;
+  unsigned short* d = dst + (r * (Kpad / 16) + k / 16) * 48 + (k & 15);
+  d[0] = __builtin_bit_cast(unsigned short, b0); d[16] = __builtin_bit_cast(unsigned short, b1);
+  d[32] = __builtin_bit_cast(unsigned short, b2);
+}
 __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int Cin, int taps, int mode, int Npad,
                                    int Kpad, float* __restrict__ Wp) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -809,9 +923,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int Ci
   if (i >= tot) return;
   const int k = i % Kpad; const long r = i / Kpad; const int n = r % Npad; const int tap = r / Npad;
   float v = 0.f;
-  if (mode == 0) { if (n < Cout && k < Cin) v = W[((long)n * Cin + k) * taps + tap]; }
+  if ((mode & 1) == 0) { if (n < Cout && k < Cin) v = W[((long)n * Cin + k) * taps + tap]; }
   else { if (n < Cin && k < Cout) v = W[((long)k * Cin + n) * taps + (taps - 1 - tap)]; }
-  Wp[i] = v;
+  if (mode & 2) store_split3(v, reinterpret_cast<unsigned short*>(Wp), r, k, Kpad);
+  else Wp[i] = v;
 }
 
 // out = sum over slabs (fixed order), float4 lanes
@@ -833,9 +948,10 @@ __global__ void pack_many_kernel(const PackDesc* __restrict__ desc, int n_desc, 
     const long j = i - d.first;
     const int k = j % d.Kpad; const long r = j / d.Kpad; const int n = r % d.Npad; const int tap = r / d.Npad;
     float v = 0.f;
-    if (d.mode == 0) { if (n < d.Cout && k < d.Cin) v = d.src[((long)n * d.Cin + k) * d.taps + tap]; }
+    if ((d.mode & 1) == 0) { if (n < d.Cout && k < d.Cin) v = d.src[((long)n * d.Cin + k) * d.taps + tap]; }
     else { if (n < d.Cin && k < d.Cout) v = d.src[((long)k * d.Cin + n) * d.taps + (d.taps - 1 - tap)]; }
-    d.dst[j] = v;
+    if (d.mode & 2) store_split3(v, reinterpret_cast<unsigned short*>(d.dst), r, k, d.Kpad);
+    else d.dst[j] = v;
   }
 }
 
@@ -1307,10 +1423,24 @@ int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_
   return q[1];
 }
 
+// 1 when a convolution of this shape runs on the split-bf16 (mma = 3) kernels - the caller then passes mma = 3 and the
+// split-packed weights (mode | 2); 0: it runs on a kernel that only takes the fp32 format (one- / few-channel image
+// kernels, the halo kernel of the shallow 2-D levels, scalar-load shapes)
+int arco_conv_split_ok(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in) {
+  IgemmArgs a{};
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in;
+  if ((Cin & 3) != 0 || (ld_in & 3) != 0) return 0;
+  if (taps == 1) return 1;
+  if (taps == 27) return image_conv3d_eligible(a) ? 0 : 1;
+  if (taps == 9) return (image_conv3d_eligible(a) || image_conv_eligible(a) || halo_eligible(a)) ? 0 : 1;
+  return 0;
+}
+
 int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream) {
-  ARCO_CHECK_ARG(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9 || taps == 27) && (mode == 0 || mode == 1));
-  const int N = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
-  const int Npad = (N + 15) / 16 * 16, Kpad = (K + 15) / 16 * 16;
+  ARCO_CHECK_ARG(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9 || taps == 27) && mode >= 0 && mode <= 3);
+  const int N = (mode & 1) == 0 ? Cout : Cin, K = (mode & 1) == 0 ? Cin : Cout;
+  const int Npad = (N + 15) / 16 * 16, Kpad = (mode & 2) ? (K + 31) / 32 * 32 : (K + 15) / 16 * 16;   // split: Wp holds 3 bf16 per element
   const long tot = (long)taps * Npad * Kpad;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), W, Cout, Cin, taps,
                      mode, Npad, Kpad, Wp);
@@ -1393,7 +1523,7 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                     int NV, int D3, int H, int W, int stat_groups, int mma, void* stream) {
   const int NB = NV * D3;
-  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0 && mma >= 0 && mma <= 2);
+  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0 && mma >= 0 && mma <= 3);
   IgemmArgs a{};
   a.A = in; a.lda = ld_in; a.Wp = Wp; a.N = N; a.K = K;
   a.Npad = (N + 15) / 16 * 16; a.Kpad = (K + 15) / 16 * 16;
@@ -1402,6 +1532,10 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = D3;
   a.stat_groups = stat_groups > 1 ? stat_groups : 1;
   a.mma = mma;
+  if (mma == 3) {       // split-bf16: Wp is the pre-split packed format (arco_pack_conv_weight_split / arco_pack_many fmt 1)
+    a.Kg = (K + 31) / 32 * 2;
+    a.Kpad = taps == 1 ? a.Kg * 16 : (K + 15) / 16 * 16;
+  }
   ARCO_CHECK_ARG(NV % a.stat_groups == 0);
   return dispatch_igemm(a, taps, as_stream(stream), nullptr);
 }

@@ -15,8 +15,12 @@ SEED_DEV = None     # device uint64 salt for dropout masks of graph-captured for
 PROFILE = None       # bench.py sets a dict: kernel instantiation id -> {n, flop, timed: [(ev0, ev1, flop, (taps, M, N, K))]}
 _cfg_cache = {}
 BN_GROUPS = 1         # see bn_groups()
-CONV_MMA = 0          # 0: fp32 MFMA everywhere (default, the parity path).  1 / 2: the 3x3x3 convolutions (forward and data
-                      # gradient) round their MFMA operands to f16 / bf16 in registers, fp32 accumulate - train_arco_3d --conv_mma
+CONV_MMA = 3          # MFMA mode of the convolutions / GEMMs (forward and data gradient; --conv_mma of the trainers):
+                      # 3 (default, "f32x3"): fp32-accurate products on the bf16 matrix cores - every fp32 operand is split
+                      #    exactly into three bf16 terms and six v_mfma_f32_16x16x32_bf16 replace eight v_mfma_f32_16x16x4_f32
+                      #    (error per product <= 2^-23, the size of one fp32 rounding; csrc/igemm.hip, MMA = 3);
+                      # 0 ("f32"): the native fp32 MFMA (bitwise an fma chain);
+                      # 1 / 2 ("f16" / "bf16"): the 3x3x3 convolutions round their operands to f16 / bf16 (BASELINE configs[4])
 PROFILE_EVERY = 1    # time every n-th conv launch of an instantiation (bench.py: 7, prime vs the per-step launch counts)
 
 
@@ -186,14 +190,19 @@ class PackPlan:
             if taps not in (1, 9, 27):
                 continue
             for mode in ((0, 1) if with_dgrad and w.requires_grad else (0,)):
-                if mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0:
-                    continue                       # served zero-copy by pack_weight
                 n, k = (co, ci) if mode == 0 else (ci, co)
                 npad, kpad = _ceil16(n), _ceil16(k)
-                buf = torch.empty((taps, npad, kpad), dtype=torch.float32, device=dev)
-                recs.append((w, buf, co, ci, taps, mode, npad, kpad, total))
-                total += buf.numel()
-                self.entries.append((w, mode, buf))
+                buf = sbuf = None
+                if not (mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0):   # else served zero-copy by pack_weight
+                    buf = torch.empty((taps, npad, kpad), dtype=torch.float32, device=dev)
+                    recs.append((w, buf, co, ci, taps, mode, npad, kpad, total))
+                    total += buf.numel()
+                if CONV_MMA == 3 and k % 4 == 0:       # split-bf16 operand format (3 bf16 per element, K padded to 32)
+                    kp32 = (k + 31) // 32 * 32
+                    sbuf = torch.empty((taps, npad, kp32 * 3 // 2), dtype=torch.float32, device=dev)
+                    recs.append((w, sbuf, co, ci, taps, mode | 2, npad, kp32, total))
+                    total += taps * npad * kp32
+                self.entries.append((w, mode, buf, sbuf))
         self.total, self.n = total, len(recs)
         self.valid = False
         _plans.append(self)
@@ -203,12 +212,12 @@ class PackPlan:
             assert len(raw) == self.n * L.query("arco_pack_desc_bytes")
             self.desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
             self.ptrs = [(w.data_ptr(), w) for (w, *_r) in recs]
-            for w, mode, buf in self.entries:
+            for w, mode, buf, sbuf in self.entries:
                 d = getattr(w, "_arco_plan", None)
                 if d is None:
                     d = {}
                     w._arco_plan = d
-                d[mode] = (self, buf)
+                d[mode] = (self, buf, sbuf)
 
     def refresh(self):
         """Re-pack every weight of the plan (one launch).  Called by whoever changed the weights."""
@@ -221,27 +230,49 @@ class PackPlan:
         self.valid = True
 
 
+def _split_ok(taps, nbd, h, w, k, n, ld):
+    key = ("split", taps, nbd, h, w, k, n, ld)
+    r = _cfg_cache.get(key)
+    if r is None:
+        r = _cfg_cache[key] = bool(L.query("arco_conv_split_ok", taps, nbd, h, w, k, n, ld))
+    return r
+
+
+def _pack_now(w, co, ci, taps, mode, split):
+    n, k = (co, ci) if mode == 0 else (ci, co)
+    if split:
+        wp = torch.empty((taps, _ceil16(n), (k + 31) // 32 * 32 * 3 // 2), dtype=torch.float32, device=w.device)
+    else:
+        wp = torch.empty((taps, _ceil16(n), _ceil16(k)), dtype=torch.float32, device=w.device)
+    L.call("arco_pack_conv_weight", L.ptr(w), co, ci, taps, mode | (2 if split else 0), L.ptr(wp))
+    return wp
+
+
 def pack_weight(weight, taps, mode):
     """torch [Cout, Cin, kh, kw] -> Wp[taps][Npad][Kpad]; mode 0 forward, 1 dgrad (flipped+transposed).
-    Served from the module's PackPlan when one is valid, else cached per weight-epoch."""
+    Served from the module's PackPlan when one is valid, else cached per weight-epoch.  With CONV_MMA == 3 the returned
+    tensor carries `_arco_split`: the same weights in the split-bf16 operand format (conv_raw picks the one the kernel takes)."""
     co, ci = int(weight.shape[0]), int(weight.shape[1])
     w = weight.detach()
-    if mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0 and w.is_contiguous():
-        return w.view(co, ci)                      # already [N][K]
+    want_split = CONV_MMA == 3 and (ci if mode == 0 else co) % 4 == 0
+    zero_copy = mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0 and w.is_contiguous()
     plan = getattr(weight, "_arco_plan", None)
     if plan is not None and mode in plan and plan[mode][0].valid:
-        return plan[mode][1]
+        _, buf, sbuf = plan[mode]
+        if (buf is not None or zero_copy) and (sbuf is not None or not want_split):
+            wp = buf if buf is not None else w.view(co, ci)
+            wp._arco_split = sbuf if want_split else None
+            return wp
     capturing = torch.cuda.is_current_stream_capturing()
     cache = getattr(weight, "_arco_pack", None)
-    key = (mode, weight._version)
+    key = (mode, weight._version, want_split)
     if cache is not None and not capturing:
         hit = cache.get(key)
         if hit is not None and hit[0] == WEIGHT_EPOCH:
             return hit[1]
     w = w.contiguous()
-    n, k = (co, ci) if mode == 0 else (ci, co)
-    wp = torch.empty((taps, _ceil16(n), _ceil16(k)), dtype=torch.float32, device=w.device)
-    L.call("arco_pack_conv_weight", L.ptr(w), co, ci, taps, mode, L.ptr(wp))
+    wp = w.view(co, ci) if zero_copy else _pack_now(w, co, ci, taps, mode, False)      # zero copy: already [N][K]
+    wp._arco_split = _pack_now(w, co, ci, taps, mode, True) if want_split else None
     if not capturing:
         if cache is None:
             cache = {}
@@ -284,9 +315,15 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         if rec["n"] % PROFILE_EVERY == 1 % PROFILE_EVERY:
             prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             prof[0].record()
+    mma = 0
+    if CONV_MMA == 3:
+        sp = getattr(wp, "_arco_split", None)
+        if sp is not None and _split_ok(taps, nb * d3, h, w, k, n, ld):
+            wp, mma = sp, 3
+    elif CONV_MMA and taps in (1, 27) and d3 > 1:
+        mma = 2 if grad else CONV_MMA                     # gradient operands: bf16 (range)
     L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
-           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1,
-           ((2 if grad else CONV_MMA) if (CONV_MMA and taps in (1, 27) and d3 > 1) else 0))   # gradient operands: bf16 (range)
+           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1, mma)
     if prof is not None:
         prof[1].record()
         PROFILE[cfg]["timed"].append((prof[0], prof[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
@@ -308,7 +345,7 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
                 prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 prof[0].record()
         L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
-               accumulate, 2 if (CONV_MMA and taps == 27) else 0)
+               accumulate, 2 if (CONV_MMA in (1, 2) and taps == 27) else 0)
         if prof is not None:
             prof[1].record()
             rec["timed"].append((prof[0], prof[1], flop, (taps, nb * d3 * h * w, co, ci)))

@@ -100,6 +100,12 @@ def build_parser():
     p.add_argument('--dp_local_thresholds', type=int, default=0,
                    help='data parallel only. 0: entropy percentiles of the global batch (5 small all-reduces per step); '
                         '1: every rank thresholds its own batch')
+    p.add_argument('--conv_mma', type=str, default='f32x3', choices=['f32x3', 'f32', 'f16', 'bf16'],
+                   help='matrix-core mode of the convolutions / GEMMs (forward and data gradient).  f32x3 (default): fp32-accurate '
+                        'products on the bf16 matrix cores - each fp32 operand is split exactly into three bf16 terms, six bf16 '
+                        'MFMAs per 32 k instead of eight fp32 MFMAs per 16 k (2.7x fewer matrix-core cycles, error per product '
+                        '<= 2^-23); f32: the native fp32 MFMA (bitwise an fma chain); f16 / bf16 (3-D trainer): operands of the '
+                        '3x3x3 convolutions rounded to f16 / bf16, fp32 accumulate (BASELINE configs[4], tolerance 1e-2)')
     p.add_argument('--anchors_per_rank', type=str, default='split', choices=['split', 'full'],
                    help='data parallel only (SURVEY 8e). split: every rank samples num_queries/world anchors per class, so the '
                         'world draws the same total number of queries as the single-process reference; full: num_queries per rank')
@@ -136,6 +142,7 @@ class ArcoStep2D:
         self.args = args
         self.dev = torch.device(device)
         C = args.num_classes
+        ops.CONV_MMA = {"f32": 0, "f16": 0, "bf16": 0, "f32x3": 3}[getattr(args, "conv_mma", "f32x3")]   # (f16 / bf16: 3-D only)
         self.random_pool = None
         if getattr(args, "revisit", 0):
             # random_pool (:156-159) is drawn before the models are created, like the reference (same CPU-generator order)

@@ -36,10 +36,6 @@ def build_parser():
                    help='1: run the equivariance block of train_arco_3d.py:368-388 (warp + one more student forward); '
                         'its loss only enters the objective at iteration 0 there (:390-393), afterwards it is a logged '
                         'value and a BatchNorm running-statistics update')
-    p.add_argument('--conv_mma', type=str, default='f32', choices=['f32', 'f16', 'bf16'],
-                   help='MFMA operand type of the 3x3x3 convolutions (forward + data gradient): f32 = exact path (default); '
-                        'f16 / bf16 = operands rounded in registers, fp32 accumulate, fp32 tensors (BASELINE configs[4], '
-                        'tolerance 1e-2; the reference has no reduced-precision mode)')
     return p
 
 
@@ -50,7 +46,7 @@ class ArcoStep3D:
         self.args = args
         self.dev = torch.device(device)
         C = args.num_classes
-        ops.CONV_MMA = {"f32": 0, "f16": 1, "bf16": 2}[getattr(args, "conv_mma", "f32")]
+        ops.CONV_MMA = {"f32": 0, "f16": 1, "bf16": 2, "f32x3": 3}[getattr(args, "conv_mma", "f32x3")]
         self.memobank, self.queue_ptrlis, self.queue_size = [], [], []
         for i in range(C):                                                # :144-151
             self.memobank.append([torch.randn(1, REP_DIM_3D)])

@@ -91,6 +91,9 @@ int arco_scatter_add_rows(const float* src, long ld_src, int D, const int32_t* l
                           const float* alpha_dev, float alpha, float* dst, long ld_dst, void* stream);
 int arco_sum_scale(const float* x, int n, float scale, float* out, int accumulate, void* stream);
 
+/* 1 when a conv of this shape runs on the split-bf16 kernels (mma = 3: every fp32 operand = 3 bf16 terms, six bf16 MFMAs
+   per 32 k, fp32-accurate) and therefore takes the split-packed weights (arco_pack_conv_weight mode | 2); else 0      */
+int arco_conv_split_ok(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in);
 /* ---- N1-N4  convolutions on the fp32 matrix cores (nn.Conv2d 3x3 / 1x1: unetWithArgs.py:36-44,72,139;
  *      model_2D.py:25-33; train_arco_2d.py:231-234).  Wp = packed weights [taps][ceil16(N)][ceil16(K)].    */
 int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream);

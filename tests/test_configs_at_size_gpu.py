@@ -261,7 +261,7 @@ def test_cfg5_lits_f16_step_at_full_size_tracks_fp32():
             del st
             torch.cuda.empty_cache()
     finally:
-        ops.CONV_MMA = 0
+        ops.CONV_MMA = 3
     assert np.all(np.isfinite(out["f16"]))
     np.testing.assert_allclose(out["f16"][0, :2], out["f32"][0, :2], rtol=1e-2)      # first step, same weights: CE / Dice at 1e-2
     np.testing.assert_allclose(out["f16"][:, :2], out["f32"][:, :2], rtol=5e-2)      # trajectories stay together

@@ -344,7 +344,7 @@ def test_conv3d_reduced_precision_mma(mma, tol, nb, ci, co, d, h, w):
         yg = ops.conv(xg, wg, None)
         yg.backward(cl3(gy))
     finally:
-        ops.CONV_MMA = 0
+        ops.CONV_MMA = 3
     # forward: the selected type; both gradients use bf16 operands (dZ magnitudes of 1e-6 would flush in f16)
     for got, ref, t in ((yg, yr, tol), (xg.grad, xr.grad, 2e-2), (wg.grad, wr.grad, 2e-2)):
         err = float((got.detach().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
@@ -373,7 +373,7 @@ def test_3d_step_with_f16_mma_tracks_fp32():
             loss, reco = st.step(l_img, l_lab, u_img)
             losses.append((float(st.last_terms["ce"]), float(st.last_terms["dice"])))
         out[mode] = np.array(losses)
-    ops.CONV_MMA = 0
+    ops.CONV_MMA = 3
     for mode in ("f16", "bf16"):
         assert np.all(np.isfinite(out[mode]))
         np.testing.assert_allclose(out[mode][0], out["f32"][0], rtol=1e-2)       # first step: same weights, 1e-2 budget
@@ -398,7 +398,7 @@ def test_conv1x1x1_reduced_precision_mma(mma, tol):
         yg = ops.conv(xg, wg, None)
         yg.backward(cl3(gy))
     finally:
-        ops.CONV_MMA = 0
+        ops.CONV_MMA = 3
     for got, ref, t in ((yg, yr, tol), (xg.grad, xr.grad, 2e-2)):
         err = float((got.detach().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
         assert 1e-6 < err < t, err

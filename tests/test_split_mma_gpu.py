@@ -1,0 +1,84 @@
+"""The default matrix-core mode (--conv_mma f32x3: every fp32 operand split exactly into three bf16 terms, six
+v_mfma_f32_16x16x32_bf16 per 32 k, fp32 accumulate) against the native fp32 MFMA (--conv_mma f32) and an fp64 reference:
+the split mode must be as accurate as fp32 arithmetic itself - its error against fp64 within a small factor of the native
+fp32 kernel's error and far inside the 1e-3 budget of BASELINE.json's north_star (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(x):
+    return x.cuda().contiguous(memory_format=torch.channels_last if x.dim() == 4 else torch.channels_last_3d)
+
+
+def _run(mode, x, wt, gy):
+    from arco_amd import ops
+    prev = ops.CONV_MMA
+    ops.CONV_MMA = mode
+    try:
+        xg, wg = _cl(x).requires_grad_(True), wt.cuda().requires_grad_(True)
+        y = ops.conv(xg, wg, None)
+        y.backward(_cl(gy))
+        return y.detach().cpu().double(), xg.grad.detach().cpu().double()
+    finally:
+        ops.CONV_MMA = prev
+
+
+@pytest.mark.parametrize("shape", [dict(nb=2, ci=64, co=64, sp=(32, 32), k=3), dict(nb=1, ci=128, co=256, sp=(16, 16), k=3),
+                                   dict(nb=1, ci=496, co=496, sp=(32, 64), k=1), dict(nb=2, ci=48, co=80, sp=(24, 40), k=1),
+                                   dict(nb=1, ci=16, co=32, sp=(6, 20, 24), k=3), dict(nb=1, ci=240, co=240, sp=(4, 12, 16), k=1),
+                                   dict(nb=1, ci=64, co=64, sp=(5, 14, 10), k=3)])
+@pytest.mark.parametrize("data", ["normal", "wide_range"])
+def test_split_bf16_is_fp32_accurate(shape, data):
+    from arco_amd import _lib as L
+    rs = np.random.RandomState(shape["ci"] + shape["co"])
+    nd = len(shape["sp"])
+    kk = (shape["k"],) * nd
+    x = rs.standard_normal((shape["nb"], shape["ci"], *shape["sp"])).astype(np.float32)
+    wt = (rs.standard_normal((shape["co"], shape["ci"], *kk)) / np.sqrt(shape["ci"] * shape["k"] ** nd)).astype(np.float32)
+    gy = rs.standard_normal((shape["nb"], shape["co"], *shape["sp"])).astype(np.float32)
+    if data == "wide_range":          # six decades of magnitudes and exact zeros: nothing may depend on operand scale
+        x = x * (10.0 ** rs.uniform(-3, 3, size=x.shape)).astype(np.float32)
+        x[rs.uniform(size=x.shape) < 0.2] = 0.0
+        wt = wt * (10.0 ** rs.uniform(-2, 2, size=wt.shape)).astype(np.float32)
+    x, wt, gy = torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(gy)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    x64, w64 = x.double().requires_grad_(True), wt.double()
+    y64 = conv(x64, w64, None, padding=shape["k"] // 2)
+    y64.backward(gy.double())
+    ld = shape["ci"]
+    taps = shape["k"] ** nd
+    nbd = shape["nb"] * (shape["sp"][0] if nd == 3 else 1)
+    assert L.query("arco_conv_split_ok", taps, nbd, shape["sp"][-2], shape["sp"][-1], shape["ci"], shape["co"], ld) == 1
+    y3, dx3 = _run(3, x, wt, gy)
+    y0, dx0 = _run(0, x, wt, gy)
+    # error measured against the magnitude a term-by-term fp32 evaluation can resolve: sum |x||w| per output
+    scale_y = conv(x64.detach().abs(), w64.abs(), None, padding=shape["k"] // 2)
+    scale_dx = torch.autograd.grad(conv(x64, w64.abs(), None, padding=shape["k"] // 2), x64, gy.double().abs())[0]
+    for got3, got0, ref, sc in ((y3, y0, y64.detach(), scale_y), (dx3, dx0, x64.grad, scale_dx)):
+        e3 = float(((got3 - ref).abs() / (sc + 1e-30)).max())
+        e0 = float(((got0 - ref).abs() / (sc + 1e-30)).max())
+        assert e3 < 3e-6, (e3, e0)                      # fp32-level: a few ulp relative to sum |x||w| (grows ~sqrt(K) like any fp32 sum)
+        assert e3 <= 1.5 * e0 + 6e-8, (e3, e0)          # never meaningfully worse than the native fp32 MFMA (measured: equal or better)
+    assert not torch.equal(y3, y0)                      # the two modes really are different kernels
+
+
+def test_split_weights_pack_is_an_exact_decomposition():
+    """The split pack format holds x0 + x1 + x2 == x bit for bit (three bf16 terms of every weight)."""
+    from arco_amd import _lib as L
+    rs = np.random.RandomState(0)
+    co, ci, taps = 40, 24, 9
+    w = torch.from_numpy((rs.standard_normal((co, ci, 3, 3)) * 10.0 ** rs.uniform(-4, 4, size=(co, ci, 3, 3))).astype(np.float32)).cuda()
+    npad, kp32 = 48, 32
+    sp = torch.zeros((taps, npad, kp32 * 3 // 2), dtype=torch.float32, device="cuda")
+    L.call("arco_pack_conv_weight", L.ptr(w), co, ci, taps, 2, L.ptr(sp))
+    torch.cuda.synchronize()
+    planes = sp.view(torch.int16).view(taps, npad, kp32 // 16, 3, 16).cpu()
+    f = (planes.to(torch.int32) << 16).view(torch.float32).double()              # bf16 bits -> fp32 value
+    rec = f.sum(dim=3).permute(0, 1, 2, 3).reshape(taps, npad, kp32)             # x0 + x1 + x2
+    exp = torch.zeros((taps, npad, kp32), dtype=torch.float64)
+    exp[:, :co, :ci] = w.cpu().double().reshape(co, ci, taps).permute(2, 0, 1)
+    assert torch.equal(rec, exp)
