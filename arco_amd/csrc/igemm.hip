@@ -485,8 +485,13 @@ static long conv_blocks(const IgemmArgs& a, int bm, int bn) {
 static long flat_blocks(const IgemmArgs& a, int bm, int bn) {
   return (long)a.NB * ((a.H * (a.W + 2) + bm - 1) / bm) * ((a.Npad + bn - 1) / bn);
 }
+static long want_blocks(const IgemmArgs& a) {      // A/B knob: ARCO_IGEMM_WANT / ARCO_IGEMM_WANT3 (split-bf16 launches)
+  static const long w0 = getenv("ARCO_IGEMM_WANT") ? atol(getenv("ARCO_IGEMM_WANT")) : 512;
+  static const long w3 = getenv("ARCO_IGEMM_WANT3") ? atol(getenv("ARCO_IGEMM_WANT3")) : 512;
+  return a.mma == 3 ? w3 : w0;
+}
 static int dispatch_flat3(const IgemmArgs& a, hipStream_t st, int* nmb) {
-  const long want = 512;
+  const long want = want_blocks(a);
   if (a.Npad <= 16) return launch_igemm<9, 128, 16, 4, 1, 16, false, 3, true>(a, st, nmb);
   if (a.Npad <= 32) {
     if (flat_blocks(a, 128, 32) >= want) return launch_igemm<9, 128, 32, 4, 1, 16, false, 3, true>(a, st, nmb);
@@ -499,7 +504,7 @@ static int dispatch_flat3(const IgemmArgs& a, hipStream_t st, int* nmb) {
 }
 template <int DEPTH>
 static int dispatch_spatial(const IgemmArgs& a, hipStream_t st, int* nmb) {
-  const long want = 512;
+  const long want = want_blocks(a);
   if (DEPTH == 3 && (a.W & 15) != 0 && a.W + 2 <= IGEMM_FLAT_WPMAX) return dispatch_flat3(a, st, nmb);
   if (a.Npad <= 16) {
     if (DEPTH == 1 && conv_blocks(a, 256, 16) >= want) return launch_igemm<9, 256, 16, 4, 1, 16, false, DEPTH>(a, st, nmb);
@@ -897,7 +902,8 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
   if (taps == 9 && image_conv3d_eligible(a)) return launch_image_conv3d<1>(a, st, nmb);     // one-channel image
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
   if (taps == 9 && image_conv_eligible(a)) return launch_image_conv(a, st, nmb);
-  if (taps == 9) return halo_eligible(a) ? dispatch_halo(a, st, nmb) : dispatch_spatial<1>(a, st, nmb);
+  // split-bf16 launches (the caller asked arco_conv_split_ok) never take the fp32-only halo kernel
+  if (taps == 9) return (a.mma != 3 && halo_eligible(a)) ? dispatch_halo(a, st, nmb) : dispatch_spatial<1>(a, st, nmb);
   return ARCO_ERR_UNSUPPORTED;
 }
 
@@ -1410,6 +1416,17 @@ int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld
   if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
   return q[0];
 }
+// the same for a launch in matrix-core mode `mma` (3: the split-bf16 kernels tile differently from the fp32 halo kernel)
+int arco_conv_mblocks_mma(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups, int mma) {
+  IgemmArgs a{};
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in;
+  a.stat_groups = stat_groups > 1 ? stat_groups : 1;
+  a.mma = mma;
+  int q[3] = {0, 0, 0};
+  if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
+  return q[0];
+}
 
 // which igemm_kernel<TAPS,BM,BN,..> instantiation a launch uses: returns TAPS*1e6 + BM*1e3 + BN (kernel-tap form:
 // 9 for both 3x3 and 3x3x3); *kc_depth_db = KC*100 + DEPTH*10 + DB
@@ -1420,6 +1437,14 @@ int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_
   int q[3] = {0, 0, 0};
   if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
   if (kc_depth_db) *kc_depth_db = q[2];
+  return q[1];
+}
+int arco_conv_config_mma(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int mma) {   // ... in matrix-core mode mma
+  IgemmArgs a{};
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in; a.mma = mma;
+  int q[3] = {0, 0, 0};
+  if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
   return q[1];
 }
 
@@ -1433,7 +1458,9 @@ int arco_conv_split_ok(int taps, int NB, int H, int W, int Cin, int Cout, long l
   if ((Cin & 3) != 0 || (ld_in & 3) != 0) return 0;
   if (taps == 1) return 1;
   if (taps == 27) return image_conv3d_eligible(a) ? 0 : 1;
-  if (taps == 9) return (image_conv3d_eligible(a) || image_conv_eligible(a) || halo_eligible(a)) ? 0 : 1;
+  // of the shallow 2-D levels only 16 -> 16 stays on the fp32 halo kernel (HBM-bound either way, measured faster there);
+  // 16 -> 32, 32 -> 16 and 32 -> 32 run 10-25 % faster on the split-bf16 implicit GEMM
+  if (taps == 9) return (image_conv3d_eligible(a) || image_conv_eligible(a) || (halo_eligible(a) && a.K == 16 && a.Npad <= 16)) ? 0 : 1;
   return 0;
 }
 

@@ -15,7 +15,7 @@ SEED_DEV = None     # device uint64 salt for dropout masks of graph-captured for
 PROFILE = None       # bench.py sets a dict: kernel instantiation id -> {n, flop, timed: [(ev0, ev1, flop, (taps, M, N, K))]}
 _cfg_cache = {}
 BN_GROUPS = 1         # see bn_groups()
-CONV_MMA = 3          # MFMA mode of the convolutions / GEMMs (forward and data gradient; --conv_mma of the trainers):
+CONV_MMA = int(__import__('os').environ.get('ARCO_CONV_MMA', '3'))          # MFMA mode of the convolutions / GEMMs (forward and data gradient; --conv_mma of the trainers):
                       # 3 (default, "f32x3"): fp32-accurate products on the bf16 matrix cores - every fp32 operand is split
                       #    exactly into three bf16 terms and six v_mfma_f32_16x16x32_bf16 replace eight v_mfma_f32_16x16x4_f32
                       #    (error per product <= 2^-23, the size of one fp32 rounding; csrc/igemm.hip, MMA = 3);
@@ -295,33 +295,33 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         out = new_act_nd(nb, n, (d3, h, w), xr.device)
     else:
         out = new_act(nb, n, h, w, xr.device)
+    mma = 0
+    if CONV_MMA == 3:
+        sp_ = getattr(wp, "_arco_split", None)
+        if sp_ is not None and _split_ok(taps, nb * d3, h, w, k, n, ld):
+            wp, mma = sp_, 3
+    elif CONV_MMA and taps in (1, 27) and d3 > 1:
+        mma = 2 if grad else CONV_MMA                     # gradient operands: bf16 (range)
     ssum = ssq = None
     nmb = 0
     if stats:
-        nmb = L.query("arco_conv_mblocks", taps, nb * d3, h, w, k, n, ld, stat_groups)
+        nmb = L.query("arco_conv_mblocks_mma", taps, nb * d3, h, w, k, n, ld, stat_groups, mma)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
     prof = cfg = None
     if PROFILE is not None and not torch.cuda.is_current_stream_capturing():
         # every launch is counted; every PROFILE_EVERY-th one is bracketed by HIP events on the launch stream
         # (an event pair per launch costs ~1.5 ms/step of stream bubbles at ~350 conv launches per step)
-        key = (taps, nb * d3, h, w, k, n, ld)
+        key = (taps, nb * d3, h, w, k, n, ld, mma)
         cfg = _cfg_cache.get(key)
-        if cfg is None:
-            cfg = _cfg_cache[key] = L.query("arco_conv_config", *key, None)       # kernel instantiation id
+        if cfg is None:        # kernel instantiation id + 1e8 * matrix-core mode
+            cfg = _cfg_cache[key] = L.query("arco_conv_config_mma", *key) + 100000000 * mma
         rec = PROFILE.setdefault(cfg, {"n": 0, "flop": 0.0, "timed": []})
         rec["n"] += 1
         rec["flop"] += 2.0 * taps * nb * d3 * h * w * n * k
         if rec["n"] % PROFILE_EVERY == 1 % PROFILE_EVERY:
             prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             prof[0].record()
-    mma = 0
-    if CONV_MMA == 3:
-        sp = getattr(wp, "_arco_split", None)
-        if sp is not None and _split_ok(taps, nb * d3, h, w, k, n, ld):
-            wp, mma = sp, 3
-    elif CONV_MMA and taps in (1, 27) and d3 > 1:
-        mma = 2 if grad else CONV_MMA                     # gradient operands: bf16 (range)
     L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
            L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1, mma)
     if prof is not None:

@@ -41,12 +41,17 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16/bf16 MFMA (MI355X_MICROARCH.md); --conv_mma f16 launches are priced against it
+PEAK_SPLIT_TFLOPS = 2500.0 / 6.0     # split-bf16 mode: 6 bf16 MFMAs per fp32-accurate product -> 416.7 TFLOP/s of ALGORITHMIC fp32 work
+PEAK_BY_MMA = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_F16_MFMA_TFLOPS, 2: PEAK_F16_MFMA_TFLOPS, 3: PEAK_SPLIT_TFLOPS}
 PEAK_HBM_TBS = 8.0
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes):
 # profiles/r01_pmc_conv_traffic.md (3x3 backbone kernel) and profiles/r01_pmc_gemm_traffic.md; key (taps, M, N, K)
 PMC_TRAFFIC_BYTES = {(9, 65536, 64, 64): 3.526e7, (9, 65536, 64, 128): 5.322e7,
                      (9, 32768, 64, 64): 1.840e7, (9, 32768, 64, 128): 2.797e7,
                      (1, 1048576, 496, 496): 5.595e9, (1, 262144, 480, 480): 1.240e9}
+
+
+PMC_TRAFFIC_SPLIT = {}    # (taps, M, N, K) -> HBM bytes per launch of the split-bf16 kernels (profiles/r02_pmc_*.md)
 
 
 def cpu_baseline_child():
@@ -100,12 +105,17 @@ def spawn_ranks(a, argv):
     return 0
 
 
+MMA_NAMES = {0: "fp32 MFMA 16x16x4", 1: "f16-operand MFMA 16x16x16, fp32 accumulate", 2: "bf16-operand MFMA 16x16x16, fp32 accumulate",
+             3: "split-bf16 (3 x bf16 = exact fp32 operands) MFMA 16x16x32, fp32 accumulate"}
+
+
 def _kernel_name(key):
     if isinstance(key, tuple):
         return f"wgrad<taps={key[1]},co={key[2]},ci={key[3]}> (weight gradient, fp32 MFMA 16x16x4)"
+    mma, key = key // 100000000, key % 100000000
     if key >= 9900000:
-        return f"conv3x3_halo_kernel<{(key - 9900000) // 1000},{key % 1000},..> (fp32 MFMA 16x16x4 implicit GEMM)"
-    return f"igemm_kernel<{key // 1000000},{key // 1000 % 1000},{key % 1000},...> (fp32 MFMA 16x16x4 implicit GEMM)"
+        return f"conv3x3_halo_kernel<{(key - 9900000) // 1000},{key % 1000},..> ({MMA_NAMES[mma]} implicit GEMM)"
+    return f"igemm_kernel<{key // 1000000},{key // 1000 % 1000},{key % 1000},...,MMA={mma}> ({MMA_NAMES[mma]} implicit GEMM)"
 
 
 def roofline_from_profile(prof, n_steps, step_ms, peak=PEAK_F32_MFMA_TFLOPS, mma="f32"):
@@ -118,7 +128,7 @@ def roofline_from_profile(prof, n_steps, step_ms, peak=PEAK_F32_MFMA_TFLOPS, mma
         return None, None
     avg = {c: sum(s_.elapsed_time(e_) for s_, e_, _, _ in v["timed"]) / max(1, len(v["timed"])) for c, v in prof.items()}
     tot = {c: avg[c] * v["n"] for c, v in prof.items()}
-    is3 = lambda c: (not isinstance(c, tuple)) and c // 1000000 == 9
+    is3 = lambda c: (not isinstance(c, tuple)) and c % 100000000 // 1000000 == 9
     cand = {c: t for c, t in tot.items() if is3(c)} or tot
     cfg = max(cand, key=cand.get)
     rec = prof[cfg]
@@ -132,8 +142,11 @@ def roofline_from_profile(prof, n_steps, step_ms, peak=PEAK_F32_MFMA_TFLOPS, mma
     (taps, m, n, k), (cnt, ms_sum, f) = max(shapes.items(), key=lambda kv: kv[1][1])
     fam_ms = sum(tot.values()); fam_flop = sum(v["flop"] for v in prof.values())
     wg_ms = sum(t for c, t in tot.items() if isinstance(c, tuple)); wg_flop = sum(v["flop"] for c, v in prof.items() if isinstance(c, tuple))
-    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get((taps, m, n, k)) if mma == "f32" else None,
+    k_mma = 0 if isinstance(cfg, tuple) else cfg // 100000000
+    peak = PEAK_BY_MMA[k_mma]
+    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get((taps, m, n, k)) if k_mma == 0 else PMC_TRAFFIC_SPLIT.get((taps, m, n, k)),
+            "peak_note": {0: "fp32 MFMA peak", 3: "dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32-accurate product); the native fp32 MFMA peak is 157.3"}.get(k_mma, "dense f16/bf16 MFMA peak"),
             "kernel": _kernel_name(cfg), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(rec["n"] / n_steps, 1),
             "launches_timed": len(launches), "avg_flop_per_launch": avg_flop,
             "share_of_step": round(tot[cfg] / n_steps / step_ms, 4),

@@ -106,9 +106,11 @@ int arco_pack_many(const void* desc, int n_desc, long total, void* stream);
 int arco_gemm_splitk(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out, long M,
                      int splits, float* ws, void* stream);
 int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups);
+int arco_conv_mblocks_mma(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups, int mma);   /* ... for a launch in matrix-core mode mma (arco_conv3d_fwd) */
 /* which kernel instantiation a launch uses: igemm_kernel<TAPS,BM,BN,..> -> TAPS*1e6 + BM*1e3 + BN;
  * conv3x3_halo_kernel<CIN,COUT,..> -> 9.9e6 + CIN*1e3 + COUT */
 int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int* kc_depth_db);
+int arco_conv_config_mma(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int mma);
 /* out = conv(in) (+bias)(+residual); optional per-channel (sum, sumsq) block partials for train-mode BN. */
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
