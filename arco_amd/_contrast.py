@@ -39,6 +39,7 @@ key_gather_hook = None
 count_gather_hook = None
 # callable(keys[n,D], cls, queue_size) -> only the rows that survive the FIFO truncation (rank order)
 tail_gather_hook = None
+tail_gather_all_hook = None  # the same for all classes at once: (list of key rows per class, queue sizes) -> list (one broadcast per rank)
 proto_reduce_hook = None     # data parallel: (proto [C, D], counts [C]) -> count-weighted mean over ranks (dist.reduce_prototypes)
 
 
@@ -322,9 +323,13 @@ def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace
         pl.proto = proto_reduce_hook(pl.proto, pl.totals[:C])
     pl.D = D
     pl.new_keys = []
+    if tail_gather_all_hook is not None:     # data parallel: every class's surviving rows in one broadcast per contributing rank
+        key_rows = tail_gather_all_hook([k.contiguous() for k in key_rows], [int(q) for q in queue_size])
     for c in range(C):
         keys = key_rows[c]
-        if tail_gather_hook is not None:
+        if tail_gather_all_hook is not None:
+            pass
+        elif tail_gather_hook is not None:
             keys = tail_gather_hook(keys.contiguous(), c, int(queue_size[c]))
         elif key_gather_hook is not None:
             keys = key_gather_hook(keys.contiguous())

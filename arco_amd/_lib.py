@@ -44,6 +44,9 @@ _SIGS = {
     "arco_score_finalize": [_P, _P, _I, _L, _P, _P],
     "arco_tps_grid": [_P, _P, _I, _L, _I, _P, _P],
     "arco_grid_sample_fwd": [_P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _L, _P],
+    "arco_field_axpb": [_P, _F, _F, _P, _F, _I, _I, _I, _I, _P, _P],
+    "arco_field_smooth": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "arco_field_resize": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "arco_eqv_loss_fwd": [_P, _L, _P, _L, _P, _I, _L, _I, _P, _P, _P],
     "arco_eqv_loss_bwd": [_P, _L, _P, _L, _P, _I, _L, _I, _P, _P, _P, _L, _P],
     "arco_gemm_splitk": [_P, _L, _I, _P, _I, _P, _L, _L, _I, _P, _P],

@@ -357,6 +357,67 @@ __global__ __launch_bounds__(256) void tps_grid_kernel(const float* __restrict__
     }
   }
 }
+// ---- A2  AdvMorph (adv_morph.py:310-580): random diffeomorphic warp of the unlabeled stream -------------------------------
+// 2-channel fields are kept channels-last [B, H, W, 2] = (x, y) per pixel, i.e. a field IS a grid_sample grid:
+// applyComposition2D(f1, f2) (adv_morph.py:297-307) is grid_sample_fwd_kernel with X = f1, grid = f2, border padding.
+// base grid value of pixel (i, j): (linspace(-1, 1, W)[j], linspace(-1, 1, H)[i])  (get_base_grid, adv_morph.py:184-207);
+// torch.linspace fills from both ends: start + i*step for i < n/2, end - (n-1-i)*step otherwise.
+__device__ __forceinline__ float linspace_m11(int i, int n) {
+  if (n == 1) return -1.f;
+  const float step = 2.f / (float)(n - 1);
+  return i < n / 2 ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
+}
+// out = alpha * in + beta * base_grid + gamma * in2  (in / in2 may be NULL), optionally clamped to [-1, 1]
+__global__ void field_axpb_kernel(const float* __restrict__ in, float alpha, float beta, const float* __restrict__ in2, float gamma,
+                                  int B, int H, int W, int clamp, float* __restrict__ out) {
+  const long tot = (long)B * H * W * 2;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(t & 1); const long p = t >> 1; const int x = (int)(p % W), y = (int)((p / W) % H);
+    const float g = c == 0 ? linspace_m11(x, W) : linspace_m11(y, H);
+    float v = beta * g;
+    if (in) v = alpha * in[t] + v;
+    if (in2) v = v + gamma * in2[t];
+    if (clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+    out[t] = v;
+  }
+}
+// depthwise KS x KS filter with zero padding (gaussian_smooth / get_gaussian_kernel, adv_morph.py:445-497); weights by value
+struct SmoothW { float w[81]; };
+__global__ void field_smooth_kernel(const float* __restrict__ in, int B, int H, int W, int C, int KS, SmoothW sw,
+                                    float* __restrict__ out) {
+  const long tot = (long)B * H * W * C;
+  const int r = KS / 2;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C); const long p = t / C; const int x = (int)(p % W), y = (int)((p / W) % H); const long n = p / ((long)W * H);
+    float acc = 0.f;
+    for (int dy = 0; dy < KS; ++dy) {
+      const int yy = y + dy - r;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = 0; dx < KS; ++dx) {
+        const int xx = x + dx - r;
+        if (xx < 0 || xx >= W) continue;
+        acc += sw.w[dy * KS + dx] * in[((n * H + yy) * W + xx) * C + c];
+      }
+    }
+    out[t] = acc;
+  }
+}
+// F.interpolate(mode='bilinear', align_corners=False) of a channels-last field (DemonsCompose, adv_morph.py:507-508)
+__global__ void field_resize_kernel(const float* __restrict__ in, int B, int h, int w, int C, int H, int W, float* __restrict__ out) {
+  const long tot = (long)B * H * W * C;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C); const long p = t / C; const int X = (int)(p % W), Y = (int)((p / W) % H); const long n = p / ((long)W * H);
+    float fy = sy * ((float)Y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = sx * ((float)X + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = in + n * (long)h * w * C + c;
+    out[t] = hy * (hx * b[((long)y0 * w + x0) * C] + lx * b[((long)y0 * w + x1) * C]) +
+             ly * (hx * b[((long)y1 * w + x0) * C] + lx * b[((long)y1 * w + x1) * C]);
+  }
+}
 // F.grid_sample(mode='bilinear', align_corners=True), channels-last rows; padding 0: zeros, 1: border.
 // D3 > 1: the same 2-D warp applied to every slice z of a volume [NB, H, W, D3, C] (tps/rand_tps_3d.py:147-166)
 __global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __restrict__ X, long ldx, int NB, int H, int W, int D3, int C,
@@ -466,6 +527,26 @@ int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int D3,
   ARCO_CHECK_ARG(X && grid && Y && NB > 0 && H > 0 && W > 0 && D3 > 0 && C > 0 && Ho > 0 && Wo > 0);
   hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(gl_grid((long)NB * Ho * Wo * D3 * C)), dim3(256), 0, as_stream(stream), X, ldx,
                      NB, H, W, D3, C, grid, Ho, Wo, border, Y, ldy);
+  return arco_launch_status();
+}
+/* AdvMorph fields (adv_morph.py:184-207, 260-307, 445-532), channels-last [B, H, W, 2] */
+int arco_field_axpb(const float* in, float alpha, float beta, const float* in2, float gamma, int B, int H, int W, int clamp,
+                    float* out, void* stream) {
+  ARCO_CHECK_ARG(out && B > 0 && H > 0 && W > 0);
+  hipLaunchKernelGGL(field_axpb_kernel, dim3(gl_grid((long)B * H * W * 2)), dim3(256), 0, as_stream(stream), in, alpha, beta, in2,
+                     gamma, B, H, W, clamp, out);
+  return arco_launch_status();
+}
+int arco_field_smooth(const float* in, int B, int H, int W, int C, int ks, const float* weights_host, float* out, void* stream) {
+  ARCO_CHECK_ARG(in && out && weights_host && ks >= 1 && ks <= 9 && (ks & 1) && B > 0 && H > 0 && W > 0 && C > 0);
+  SmoothW sw;
+  for (int i = 0; i < ks * ks; ++i) sw.w[i] = weights_host[i];
+  hipLaunchKernelGGL(field_smooth_kernel, dim3(gl_grid((long)B * H * W * C)), dim3(256), 0, as_stream(stream), in, B, H, W, C, ks, sw, out);
+  return arco_launch_status();
+}
+int arco_field_resize(const float* in, int B, int h, int w, int C, int H, int W, float* out, void* stream) {
+  ARCO_CHECK_ARG(in && out && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0);
+  hipLaunchKernelGGL(field_resize_kernel, dim3(gl_grid((long)B * H * W * C)), dim3(256), 0, as_stream(stream), in, B, h, w, C, H, W, out);
   return arco_launch_status();
 }
 // ws: 64*2*B + B doubles; out[0] = loss_eqv

@@ -50,6 +50,7 @@ def init(backend=None):
         _contrast.key_gather_hook = gather_keys
         _contrast.count_gather_hook = gather_counts
         _contrast.tail_gather_hook = gather_tail_keys
+        _contrast.tail_gather_all_hook = gather_tail_keys_all
         _contrast.proto_reduce_hook = reduce_prototypes
         from . import glue
         glue.state_reduce_hook = allreduce_sum
@@ -187,3 +188,43 @@ def gather_tail_keys(keys, cls, queue_size):
     if not pieces:
         return keys[:0]
     return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=0)
+
+
+@torch.no_grad()
+def gather_tail_keys_all(key_rows, queue_size):
+    """gather_tail_keys for EVERY class with one broadcast per contributing rank (instead of one per class and rank): a rank
+    that owns surviving rows sends them for all classes back to back in one message - typically only the last one or two
+    ranks contribute (their queue_size newest keys fill the banks), so a step costs 1-2 broadcasts of <= C x queue_size rows.
+    key_rows[c] = this rank's last min(n_c, queue_size[c]) new keys of class c; returns the per-class surviving rows in rank
+    order, exactly what gather_tail_keys returns class by class."""
+    world, rank = td.get_world_size(), td.get_rank()
+    C = len(key_rows)
+    D = int(key_rows[0].shape[1])
+    dev, dt = key_rows[0].device, key_rows[0].dtype
+    take = [[0] * world for _ in range(C)]
+    rows = [[0] * world for _ in range(C)]
+    for c in range(C):
+        need = int(queue_size[c])
+        for r in range(world):
+            rows[c][r] = min(int(_rank_counts[r][c]), int(queue_size[c]))
+        assert rows[c][rank] == int(key_rows[c].shape[0]), (c, rows[c], rank, key_rows[c].shape)
+        for r in range(world - 1, -1, -1):
+            take[c][r] = min(rows[c][r], need)
+            need -= take[c][r]
+    pieces = [[] for _ in range(C)]
+    for r in range(world):
+        tot = sum(take[c][r] for c in range(C))
+        if tot == 0:
+            continue
+        if r == rank:
+            buf = torch.cat([key_rows[c][rows[c][r] - take[c][r]:] for c in range(C) if take[c][r] > 0]).contiguous()
+        else:
+            buf = torch.empty((tot, D), dtype=dt, device=dev)
+        td.broadcast(buf, src=r)
+        off = 0
+        for c in range(C):
+            if take[c][r]:
+                pieces[c].append(buf[off:off + take[c][r]])
+                off += take[c][r]
+    return [key_rows[c][:0] if not pieces[c] else (pieces[c][0] if len(pieces[c]) == 1 else torch.cat(pieces[c], dim=0))
+            for c in range(C)]

@@ -210,6 +210,14 @@ int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, v
 int arco_tps_grid(const float* rep, const float* mapping, int B, long HW, int NR, float* grid, void* stream);
 int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int D3 /* slices per volume, 1 in 2-D */, int C,
                          const float* grid, int Ho, int Wo, int border, float* Y, long ldy, void* stream);
+/* ---- A2 AdvMorph (adv_morph.py:310-580): 2-channel fields kept channels-last [B,H,W,2] (a field is a grid_sample grid;
+   applyComposition2D = arco_grid_sample_fwd with border padding).  out = alpha*in + beta*base_grid (get_base_grid, :184-207),
+   optional clamp to [-1,1]; depthwise ks x ks filter with zero padding (gaussian_smooth, :445-497; weights: host array);
+   F.interpolate(bilinear, align_corners=False) (:507-508)                                                              */
+int arco_field_axpb(const float* in, float alpha, float beta, const float* in2, float gamma, int B, int H, int W, int clamp,
+                    float* out, void* stream);   /* out = alpha*in + beta*base_grid + gamma*in2 */
+int arco_field_smooth(const float* in, int B, int H, int W, int C, int ks, const float* weights_host, float* out, void* stream);
+int arco_field_resize(const float* in, int B, int h, int w, int C, int H, int W, float* out, void* stream);
 int arco_eqv_loss_fwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C, double* ws,
                       float* out, void* stream);
 int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C,

@@ -686,3 +686,55 @@ def eqv_loss(pred_tps, pred_tps_org, mask_tps):
     kl = F.kl_div(F.log_softmax(pred_tps, dim=1), F.softmax(pred_tps_org, dim=1), reduction='none')
     per = (kl * mask_tps).flatten(1).sum(1) / (mask_tps.flatten(1).sum(1) + 1e-7)
     return per.mean()
+
+
+# --------------------------------------------------------------------------
+# A2  AdvMorph: adv_morph.py:184-207 (base grid), 260-307 (scaling and squaring, composition),
+#     445-532 (Gaussian smoothing, DemonsCompose), 363-388 / 559-577 (forward, transform)
+# --------------------------------------------------------------------------
+
+
+def _morph_base_grid(b, h, w):
+    y, x = torch.meshgrid([torch.linspace(-1, 1, h), torch.linspace(-1, 1, w)], indexing='ij')
+    return torch.stack((x, y), 0).unsqueeze(0).repeat(b, 1, 1, 1)                     # [B, 2, H, W] = (x, y)
+
+
+def _morph_gaussian(x, kernel_size=3, sigma=1):
+    """gaussian_smooth + get_gaussian_kernel: depthwise filter, zero padding; kernel_size is raised to 2*int(3.5*sigma)+1."""
+    import math
+    if kernel_size < 2 * int(3.5 * sigma) + 1:
+        kernel_size = 2 * int(3.5 * sigma) + 1
+    c = torch.arange(kernel_size)
+    xg = c.repeat(kernel_size).view(kernel_size, kernel_size)
+    xy = torch.stack([xg, xg.t()], dim=-1).float()
+    mean, var = (kernel_size - 1) / 2., sigma ** 2.
+    k = (1. / (2. * math.pi * var)) * torch.exp(-torch.sum((xy - mean) ** 2., dim=-1) / (2 * var))
+    k = (k / torch.sum(k)).view(1, 1, kernel_size, kernel_size).repeat(x.shape[1], 1, 1, 1)
+    return F.conv2d(x, k, padding=kernel_size // 2, groups=x.shape[1])
+
+
+def _morph_compose(f1, f2):
+    return F.grid_sample(f1, f2.permute(0, 2, 3, 1), padding_mode='border', align_corners=True)
+
+
+def adv_morph_grid(param, data_size, epsilon=1.5, num_steps=8):
+    """AdvMorph.get_deformation_displacement_field(duv = epsilon * param): the sampling grid [B, 2, H, W], clamped to [-1, 1]."""
+    b, h, w = data_size[0], data_size[2], data_size[3]
+    base = _morph_base_grid(b, h, w)
+    duv = _morph_gaussian(epsilon * param)
+    duv = F.interpolate(duv, size=(h, w), mode='bilinear', align_corners=False)
+    phi0 = base + duv / (2.0 ** num_steps)
+    phi = phi0
+    for _ in range(num_steps):
+        phi = _morph_compose(phi, phi)
+    # reference quirk: integrate_by_add (adv_morph.py:246-259) adds IN PLACE, so the `grid_wh` that
+    # vectorFieldExponentiation2D subtracts at the end (:294) is the initial phi = grid + duv / 2^n, not the identity grid
+    off = phi - phi0
+    comp = _morph_compose(base, off + base)
+    comp = _morph_gaussian(comp - base) + base
+    return torch.clamp(comp, -1, 1)
+
+
+def adv_morph_forward(data, param, epsilon=1.5):
+    grid = adv_morph_grid(param, list(data.shape), epsilon)
+    return F.grid_sample(data, grid.permute(0, 2, 3, 1), mode='bilinear', align_corners=True)

@@ -518,9 +518,34 @@ def gen_flags():
     print("g9_flags", len(tab["2d"]), len(tab["3d"]), len(sigs))
 
 
+# ---------------------------------------------------------------- G10 AdvMorph
+def gen_morph():
+    """AdvMorph (adv_morph.py:310-580) run from the reference class on CPU: for given velocity fields (numpy draws) the
+    sampling grid of get_deformation_displacement_field and the warped images of forward()."""
+    import importlib
+    am = importlib.import_module("adv_morph")
+    out = {}
+    for tag, B, C, H, W, seed in fx.MORPH_CASES:
+        data, param = fx.morph_inputs(seed, B, C, H, W)
+        aug = am.AdvMorph(config_dict={'epsilon': 1.5, 'xi': 0.5, 'data_size': [B, C, H, W], 'vector_size': [W // 8, W // 8],
+                                       'interpolator_mode': 'bilinear'}, debug=False, use_gpu=False)
+        aug.init_parameters()                                  # builds base_grid_wh (and draws a velocity we overwrite)
+        aug.param = aug.unit_normalize(param.clone())
+        with torch.no_grad():
+            warped = aug.forward(data.clone())
+            grid, disp = aug.get_deformation_displacement_field(duv=aug.epsilon * aug.param)
+        st = fx.MORPH_STRIDE if H * W > 10000 else 1           # the 256 x 256 case is stored subsampled
+        out[f"{tag}_param"] = aug.param.numpy()
+        out[f"{tag}_grid"] = grid.numpy()[:, :, ::st, ::st]
+        out[f"{tag}_warped"] = warped.numpy()[:, :, ::st, ::st]
+        out[f"{tag}_maxdisp"] = np.array([float(disp.abs().max())])
+    np.savez_compressed(os.path.join(OUT, "g10_morph.npz"), **out)
+    print("g10_morph", len(out))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
@@ -530,3 +555,4 @@ if __name__ == "__main__":
     if "g7" in which: gen_mix()
     if "g8" in which: gen_ingest()
     if "g9" in which: gen_flags()
+    if "g10" in which: gen_morph()

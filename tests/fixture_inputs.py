@@ -284,3 +284,17 @@ STATE_CASES = [
     ("networks.vnetWithArgs", "VNet", dict(n_channels=1, n_classes=2, normalization='batchnorm', has_dropout=True)),
     ("networks.unetWithArgs", "UNet", dict(in_chns=1, class_num=4)),
 ]
+
+
+# AdvMorph cases: (tag, B, C, H, W, seed); the velocity field has the trainer's size [B, 2, W//8, W//8] (augment.py:274)
+MORPH_CASES = [("a", 2, 1, 64, 64, 3), ("b", 1, 3, 48, 80, 4), ("c", 3, 1, 256, 256, 5)]
+
+
+MORPH_STRIDE = 5
+
+
+def morph_inputs(seed, B, C, H, W):
+    rs = np.random.RandomState(9000 + seed)
+    data = torch.from_numpy(rs.uniform(size=(B, C, H, W)).astype(np.float32))
+    param = torch.from_numpy((rs.uniform(size=(B, 2, W // 8, W // 8)) * 2 - 1).astype(np.float32))
+    return data, param

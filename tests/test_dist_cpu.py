@@ -83,6 +83,15 @@ def _worker(rank, world, port, q):
         assert torch.equal(banks[0], banks[1]), (rank, qs, n_by_rank)
         assert n_all >= 0
         assert tail.shape[0] == min(qs, sum(min(m, qs) for m in n_by_rank))
+    # 7. the all-classes form (one broadcast per contributing rank) returns what the per-class form returns
+    for qs, table in ((8, [[20, 3], [0, 5], [2, 3]]), (5, [[5, 5], [0, 0], [9, 1]]), (6, [[1, 0], [0, 2], [0, 0]])):
+        counts = [t[rank] for t in table]
+        adist.gather_counts(counts)
+        mine = [(torch.arange(n * D, dtype=torch.float32).view(n, D) + 1000 * rank + 100 * c)[max(0, n - qs):] for c, n in enumerate(counts)]
+        per_class = [adist.gather_tail_keys(m, c, qs) for c, m in enumerate(mine)]
+        batched = adist.gather_tail_keys_all(mine, [qs] * len(table))
+        assert all(torch.equal(a, b) for a, b in zip(per_class, batched)), (rank, qs, table)
+    assert _contrast.tail_gather_all_hook is adist.gather_tail_keys_all
     td.barrier()
     q.put((rank, "ok"))
 

@@ -361,3 +361,19 @@ def test_state_dict_keys_match_reference():
         mine = [[k, list(v.shape)] for k, v in net.state_dict().items()]
         assert mine == ref[f"{mod}.{name}"], f"{mod}.{name}"
     assert len(ref["model_2D.ISD"]) == 300 and len(ref["networks.vnetWithArgs.VNet"]) == 205
+
+
+@pytest.mark.parametrize("case", fx.MORPH_CASES)
+def test_adv_morph_oracle_vs_reference(case):
+    """AdvMorph restatement (oracle.adv_morph_grid / adv_morph_forward) vs the reference class run on CPU (g10)."""
+    import arco_oracle as orc
+    g10 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g10_morph.npz"))
+    tag, B, C, H, W, seed = case
+    data, _ = fx.morph_inputs(seed, B, C, H, W)
+    param = torch.from_numpy(g10[f"{tag}_param"])
+    st = fx.MORPH_STRIDE if H * W > 10000 else 1
+    grid = orc.adv_morph_grid(param, [B, C, H, W])
+    warped = orc.adv_morph_forward(data, param)
+    np.testing.assert_allclose(grid.numpy()[:, :, ::st, ::st], g10[f"{tag}_grid"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(warped.numpy()[:, :, ::st, ::st], g10[f"{tag}_warped"], rtol=0, atol=2e-5)
+    assert float(g10[f"{tag}_maxdisp"][0]) > 1e-3                       # a real deformation
