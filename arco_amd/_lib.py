@@ -44,6 +44,8 @@ _SIGS = {
     "arco_score_finalize": [_P, _P, _I, _L, _P, _P],
     "arco_tps_grid": [_P, _P, _I, _L, _I, _P, _P],
     "arco_grid_sample_fwd": [_P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _L, _P],
+    "arco_jitter_blur": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "arco_quantize8": [_P, _L, _P, _P],
     "arco_field_axpb": [_P, _F, _F, _P, _F, _I, _I, _I, _I, _P, _P],
     "arco_field_smooth": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     "arco_field_resize": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
@@ -92,6 +94,7 @@ _SIGS = {
 _QUERIES = {   # plain host helpers returning sizes
     "arco_proto_ws_floats": ([_L, _I, _I], _L),
     "arco_nce_max_len": ([], _L),
+    "arco_jitter_desc_bytes": ([], _L),
     "arco_conv_mblocks": ([_I, _I, _I, _I, _I, _I, _L, _I], _I),
     "arco_conv_mblocks_mma": ([_I, _I, _I, _I, _I, _I, _L, _I, _I], _I),
     "arco_conv_config": ([_I, _I, _I, _I, _I, _I, _L, _P], _I),

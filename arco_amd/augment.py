@@ -7,8 +7,9 @@ RandomState for the boxes, torch's CPU generator for classmix's randperm), so a 
 the mixing itself is one launch over the whole batch instead of a Python loop of per-image tensor expressions, and
 nothing leaves the GPU (classmix reads back one 64-bit label set per image, where the reference syncs on torch.unique).
 
-NOT here: `batch_transform` (tensor -> PIL -> ColorJitter / GaussianBlur -> tensor, augment.py:133-227,255-281) - its
-arithmetic is PIL's / torchvision's 8-bit image code, neither importable here, so no parity could be pinned."""
+`batch_transform` (tensor -> PIL -> ColorJitter / GaussianBlur -> tensor -> AdvMorph, augment.py:133-227,255-281) is at
+the end of this file: Pillow's 8-bit integer arithmetic as HIP kernels (csrc/augment.hip), pinned bit for bit against
+Pillow (tests/golden/g12_jitter.npz), AdvMorph pinned against the reference class (arco_amd/adv_morph.py, g10)."""
 import ctypes
 
 import numpy as np
@@ -124,3 +125,88 @@ def generate_unsup_data_3d(data, target, logits, mode='cutout'):
     """Volume variant (augment_3d.py:228-257): the box is 10 slices deep along the last axis."""
     assert data.dim() == 5, data.shape
     return _mix(data, target, logits, mode)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batch_transform (augment.py:255-281): per-image PIL round trip (8-bit quantisation), ColorJitter + GaussianBlur with
+# probability 0.5 each when apply_augmentation, then AdvMorph on the whole batch with probability 0.5
+# ---------------------------------------------------------------------------------------------------------------------
+def _gaussian_blur_radius(sigma, passes=3):
+    """Pillow's _gaussian_blur_radius (BoxBlur.c): fractional box radius of the 3-pass box approximation of a Gaussian."""
+    import math
+    sigma2 = float(np.float32(sigma)) * float(np.float32(sigma)) / passes
+    Lb = math.sqrt(12.0 * sigma2 + 1.0)
+    l = math.floor((Lb - 1.0) / 2.0)
+    a = (2 * l + 1) * (l * (l + 1) - 3 * sigma2)
+    a /= 6 * (sigma2 - (l + 1) * (l + 1))
+    return float(np.float32(l + a))
+
+
+def draw_batch_transform_params(n_images, apply_augmentation, scale_size=(1.0, 1.0)):
+    """The host draws of batch_transform in the reference's order (python `random`, torch CPU generator): per image
+    random.uniform(*scale_size) (transform, augment.py:134), then with apply_augmentation torch.rand(1) [-> torchvision
+    ColorJitter.get_params: torch.randperm(4) and four torch.empty(1).uniform_ draws] and torch.rand(1) [-> python
+    random.uniform(0.15, 1.15)]; after the loop one torch.rand(1) for AdvMorph - drawn even without augmentation
+    (`torch.rand(1) > 0.5 and apply_augmentation`, :271).  Returns (list of per-image dicts, morph flag)."""
+    import random
+    out = []
+    for _ in range(n_images):
+        random.uniform(scale_size[0], scale_size[1])
+        d = dict(order=None, factors=None, sigma=None)
+        if apply_augmentation:
+            if float(torch.rand(1)) > 0.5:
+                d["order"] = [int(v) for v in torch.randperm(4)]
+                d["factors"] = tuple(float(torch.empty(1).uniform_(lo, hi))
+                                     for lo, hi in ((0.75, 1.25), (0.75, 1.25), (0.75, 1.25), (-0.25, 0.25)))
+            if float(torch.rand(1)) > 0.5:
+                d["sigma"] = random.uniform(0.15, 1.15)
+        out.append(d)
+    morph = bool(float(torch.rand(1)) > 0.5) and bool(apply_augmentation)
+    return out, morph
+
+
+def jitter_blur(data, params):
+    """to_tensor(GaussianBlur(ColorJitter(to_pil_image(x)))) for every image of data [B, C, H, W] (C = 1 or 3) with the
+    per-image parameters of draw_batch_transform_params - one launch sequence for the batch, Pillow's 8-bit integer
+    arithmetic (csrc/augment.hip)."""
+    import struct
+    L.require_gpu(data)
+    x = data.to(torch.float32).contiguous()
+    B, C, H, W = (int(v) for v in x.shape)
+    assert len(params) == B and L.query("arco_jitter_desc_bytes") == 44
+    raw = b""
+    for p in params:
+        order = p["order"] if p["order"] is not None else [0, 1, 2, 3]
+        f = p["factors"] if p["factors"] is not None else (1.0, 1.0, 1.0, 0.0)
+        raw += struct.pack("<4i4fiif", *order, *f, int(p["order"] is not None), int(p["sigma"] is not None),
+                           _gaussian_blur_radius(p["sigma"]) if p["sigma"] is not None else 0.0)
+    out = torch.empty_like(x)
+    for b0 in range(0, B, 32):                         # (the descriptor table holds 32 images)
+        nb = min(32, B - b0)
+        ws = torch.empty(2 * nb + nb * C * H * W, dtype=torch.float32, device=x.device)
+        L.call("arco_jitter_blur", L.ptr(x[b0:b0 + nb]), nb, C, H, W, raw[44 * b0:44 * (b0 + nb)], L.ptr(ws), L.ptr(out[b0:b0 + nb]))
+    return out
+
+
+def batch_transform(data, label, logits, crop_size, scale_size, apply_augmentation):
+    """augment.batch_transform (augment.py:255-281) on the GPU for the trainers' use (crop_size == image size,
+    scale_size == (1.0, 1.0): the resize / pad / crop of `transform` are the identity and RandomCrop.get_params draws
+    nothing).  Returns (data, label, logits) like the reference: data through the 8-bit PIL round trip (+ ColorJitter /
+    GaussianBlur / AdvMorph when apply_augmentation), labels unchanged (their /255 -> byte -> *255 round trip is exact,
+    255 -> -1), logits quantised to k/255.  Generator consumption = the reference's (draw_batch_transform_params)."""
+    from .adv_morph import AdvMorph
+    B = int(data.shape[0])
+    if tuple(scale_size) != (1.0, 1.0) or (crop_size != -1 and tuple(int(v) for v in crop_size) != tuple(int(v) for v in data.shape[-2:])):
+        raise NotImplementedError("arco_amd.batch_transform: only the trainers' configuration (same-size crop, scale 1.0)")
+    params, morph = draw_batch_transform_params(B, apply_augmentation, scale_size)
+    data_t = jitter_blur(data, params)
+    lg = logits.to(torch.float32).contiguous()
+    logits_t = torch.empty_like(lg)
+    L.call("arco_quantize8", L.ptr(lg), lg.numel(), L.ptr(logits_t))
+    if morph:                                                          # :271-279
+        ds = list(data.shape)
+        aug = AdvMorph(config_dict={'epsilon': 1.5, 'xi': 0.5, 'data_size': ds, 'vector_size': [ds[-1] // 8, ds[-1] // 8],
+                                    'interpolator_mode': 'bilinear'}, debug=False, use_gpu=True)
+        aug.init_parameters()
+        data_t = aug.forward(data_t).contiguous()
+    return data_t, label, logits_t

@@ -12,8 +12,7 @@ gradients are all-reduced and new negative keys all-gathered over RCCL (arco_amd
 Every loss term of the reference step is here: contrastive (k1), unsupervised CE (k3), CE + Dice, the TPS
 equivariance term (k2) and - opt-in, --revisit 1, it has no gradient path - the revisiting loss (k4); so is the mixing
 strategy of --apply_aug (arco_amd/augment.py) and, with --synthetic 0, the ACDC / MM slice loaders (build_loaders).
-Not built (SURVEY §8 out of scope / "next"): the PIL colour jitter / blur of batch_transform (the identity here) and
-the stage-1 pre-training script.
+Also built: batch_transform (PIL round trip, ColorJitter, GaussianBlur, AdvMorph; --batch_transform).
 """
 import argparse
 import logging
@@ -100,6 +99,10 @@ def build_parser():
     p.add_argument('--dp_local_thresholds', type=int, default=0,
                    help='data parallel only. 0: entropy percentiles of the global batch (5 small all-reduces per step); '
                         '1: every rank thresholds its own batch')
+    p.add_argument('--batch_transform', type=int, default=1,
+                   help='1 (reference behaviour): batch_transform of train_arco_2d.py:287-304 - 8-bit PIL round trip of the '
+                        'images / confidences, ColorJitter + GaussianBlur + AdvMorph on the unlabeled stream - on the GPU; '
+                        '0: the identity (no generator draws)')
     p.add_argument('--conv_mma', type=str, default='f32x3', choices=['f32x3', 'f32', 'f16', 'bf16'],
                    help='matrix-core mode of the convolutions / GEMMs (forward and data gradient).  f32x3 (default): fp32-accurate '
                         'products on the bf16 matrix cores - each fp32 operand is split exactly into three bf16 terms, six bf16 '
@@ -223,8 +226,8 @@ class ArcoStep2D:
         return ops.conv(x, self.q_representation[1].weight)
 
     def step(self, l_data, l_label, u_data, epoch_num=0, max_epoch=1):
-        """One iteration.  The mixing strategy of --apply_aug (augment.generate_unsup_data) runs on the GPU; the PIL colour
-        jitter / blur of batch_transform (augment.py; CPU/PIL, out of scope) is the identity here: images_cj2_l = l_data.
+        """One iteration.  The mixing strategy of --apply_aug (augment.generate_unsup_data) and batch_transform (8-bit PIL
+        round trip, ColorJitter, GaussianBlur, AdvMorph: augment.batch_transform) run on the GPU with the reference's host draws.
 
         Same operations and results as train_arco_2d.py:284-435 restricted to the hot-path loss term;
         the ORDER is arranged for the GPU: everything the host sampler needs (3*C counters) is
@@ -241,7 +244,17 @@ class ArcoStep2D:
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         # randomGeneratorWithLogits (:292-293) is a same-size zoom(order=0) = the identity; then the mixing strategy
         # (:296-297) on the GPU with the reference's host draws; other --apply_aug values leave the batch unchanged
+        bt = bool(getattr(a, "batch_transform", 1))
+        cj2_l = l_data
+        if bt:      # :287-290: two calls without augmentation - images_cj1_logits_l (the constant 255 -> 1.0) and images_cj2_l
+            augment.draw_batch_transform_params(int(l_data.shape[0]), False)         # (only its generator draws matter)
+            cj2_l, _, _ = augment.batch_transform(l_data, l_label, torch.ones_like(l_label, dtype=torch.float32), a.patch_size,
+                                                  (1.0, 1.0), False)
         u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
+        cj2_u = u_aug
+        if bt:      # :299-304: two independent strong augmentations of the mixed unlabeled batch
+            cj2_u, _, _ = augment.batch_transform(u_aug, u_aug_label, u_aug_logits, a.patch_size, (1.0, 1.0), True)
+            u_aug, u_aug_label, u_aug_logits = augment.batch_transform(u_aug, u_aug_label, u_aug_logits, a.patch_size, (1.0, 1.0), True)
         self.k_fe_ema.update(0.99)                                      # :306-308
         batched = self.batched_passes and l_data.shape == u_aug.shape
         if batched:
@@ -289,7 +302,7 @@ class ArcoStep2D:
             # images_cj2_l forward (:311): BN running statistics only - its FE/q_rep outputs (l_feature_map_2,
             # :319,326) are never read.  One graph launch (~1 ms of GPU work) queued BEFORE the host sync: work for
             # the GPU while the host replays the samplers (14.8 vs 15.1 ms/step when queued after the sync).
-            self.s_fwd_stats(l_data)
+            self.s_fwd_stats(cj2_l)
             ops.apply_deferred_bn()                                      # the u pass's running-statistics update (:312)
             # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
             if not batched:
@@ -343,7 +356,7 @@ class ArcoStep2D:
                 logits_all = torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits))
                 eq_mask = glue.eqv_mask(labels_all, logits_all, a.weak_threshold)
                 self.tps.reset_control_points()                          # :412
-                images_tps = self.tps(torch.cat((l_data, u_aug)))        # images_cj2 = the un-augmented pair here
+                images_tps = self.tps(torch.cat((cj2_l, cj2_u)))         # :411-413 images_cj2
                 mask_tps = self.tps(eq_mask, padding_mode='zeros')
                 pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
             pred_tps = self.s_train_tps(images_tps)[0]                   # :415 one more student pass (one BN batch)

@@ -210,6 +210,14 @@ int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, v
 int arco_tps_grid(const float* rep, const float* mapping, int B, long HW, int NR, float* grid, void* stream);
 int arco_grid_sample_fwd(const float* X, long ldx, int NB, int H, int W, int D3 /* slices per volume, 1 in 2-D */, int C,
                          const float* grid, int Ho, int Wo, int border, float* Y, long ldy, void* stream);
+/* ---- A3 photometric augmentation of batch_transform (augment.py:148-225, 255-281): Pillow's 8-bit integer arithmetic
+   (to_pil_image quantisation, ImageEnhance blends of torchvision's ColorJitter in fn_idx order, convert L / HSV,
+   ImagingGaussianBlur = 3 box passes per direction, to_tensor).  data / out [B,C,H,W] fp32, C = 1 or 3, B <= 32;
+   desc: HOST array of B records {int order[4]; float f[4]; int jitter, blur; float blur_r;} (arco_jitter_desc_bytes() each);
+   ws: B uint64 + B*C*H*W floats.  arco_quantize8: floor(x*255)/255 (the confidence map's PIL round trip).               */
+long arco_jitter_desc_bytes(void);
+int arco_jitter_blur(const float* data, int B, int C, int H, int W, const void* desc_host, void* ws, float* out, void* stream);
+int arco_quantize8(const float* x, long n, float* out, void* stream);
 /* ---- A2 AdvMorph (adv_morph.py:310-580): 2-channel fields kept channels-last [B,H,W,2] (a field is a grid_sample grid;
    applyComposition2D = arco_grid_sample_fwd with border padding).  out = alpha*in + beta*base_grid (get_base_grid, :184-207),
    optional clamp to [-1,1]; depthwise ks x ks filter with zero padding (gaussian_smooth, :445-497; weights: host array);

@@ -738,3 +738,137 @@ def adv_morph_grid(param, data_size, epsilon=1.5, num_steps=8):
 def adv_morph_forward(data, param, epsilon=1.5):
     grid = adv_morph_grid(param, list(data.shape), epsilon)
     return F.grid_sample(data, grid.permute(0, 2, 3, 1), mode='bilinear', align_corners=True)
+
+
+# --------------------------------------------------------------------------
+# A3  photometric augmentation of batch_transform (augment.py:148-225): torchvision 0.13.1's ColorJitter on PIL images
+#     (transforms.ColorJitter.forward / functional_pil.adjust_brightness|contrast|saturation|hue, published source) and
+#     Pillow's ImageEnhance / ImagingConvert (L, HSV) / ImagingGaussianBlur, restated in numpy INTEGER arithmetic.
+#     Pinned bit for bit against Pillow itself (tests/golden/g12_jitter.npz).
+# --------------------------------------------------------------------------
+
+
+def q8(x):
+    """to_pil_image of a float tensor: pic.mul(255).byte() (truncation)."""
+    return np.clip(np.asarray(x, np.float32) * np.float32(255.0), 0, 255).astype(np.uint8)
+
+
+def _blend8(d, v, f):
+    t = d.astype(np.float32) + np.float32(f) * (v.astype(np.float32) - d.astype(np.float32))
+    return np.clip(t, 0, 255).astype(np.uint8)
+
+
+def _lum8(a):
+    return ((a[0].astype(np.int64) * 19595 + a[1].astype(np.int64) * 38470 + a[2].astype(np.int64) * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def _rgb2hsv8(a):
+    f32, f64 = np.float32, np.float64
+    r, g, b = (a[i].astype(np.int32) for i in range(3))
+    maxc, minc = np.maximum(np.maximum(r, g), b), np.minimum(np.minimum(r, g), b)
+    cr = (maxc - minc).astype(f32)
+    with np.errstate(all='ignore'):
+        s = cr / maxc.astype(f32)
+        rc, gc, bc = ((maxc - c).astype(f32) / cr for c in (r, g, b))
+        h = np.where(r == maxc, bc.astype(f64) - gc.astype(f64),
+                     np.where(g == maxc, 2.0 + rc.astype(f64) - bc.astype(f64), 4.0 + gc.astype(f64) - rc.astype(f64))).astype(f32)
+        t = np.fmod(h.astype(f64) / 6.0 + 1.0, 1.0).astype(f32)
+        uh = np.nan_to_num(t.astype(f64) * 255.0).astype(np.int32)
+        us = np.nan_to_num(s.astype(f64) * 255.0).astype(np.int32)
+    grey = maxc == minc
+    return (np.where(grey, 0, np.clip(uh, 0, 255)).astype(np.uint8), np.where(grey, 0, np.clip(us, 0, 255)).astype(np.uint8),
+            maxc.astype(np.uint8))
+
+
+def _hsv2rgb8(h, s, v):
+    f32 = np.float32
+    vi = v.astype(np.float64)
+    fs = s.astype(f32) / f32(255.0)
+    hh = h.astype(f32) * f32(6.0) / f32(255.0)
+    fi = np.floor(hh)
+    f = hh - fi
+    rnd = lambda t: np.clip(np.rint(t), 0, 255).astype(np.int32)
+    p = rnd(vi * (f32(1.0) - fs).astype(np.float64))
+    q = rnd(vi * (f32(1.0) - fs * f).astype(np.float64))
+    t = rnd(vi * (f32(1.0) - fs * (f32(1.0) - f)).astype(np.float64))
+    i = fi.astype(np.int32) % 6
+    vv = v.astype(np.int32)
+    out = np.stack([np.choose(i, [vv, q, p, p, t, vv]), np.choose(i, [t, vv, vv, q, p, p]), np.choose(i, [p, p, t, vv, vv, q])])
+    return np.where((s == 0)[None], vv[None].repeat(3, 0), out).astype(np.uint8)
+
+
+def color_jitter_u8(a, order, factors):
+    """a: uint8 [C, H, W] (C = 1: mode 'L', 3: 'RGB'); order: fn_idx of ColorJitter.get_params; factors = (b, c, s, h)."""
+    a = a.copy()
+    C = a.shape[0]
+    for op in order:
+        f = factors[op]
+        if op == 0:
+            a = _blend8(np.zeros_like(a), a, f)
+        elif op == 1:
+            lum = _lum8(a) if C == 3 else a[0]
+            mean = int(lum.astype(np.float64).mean() + 0.5)
+            a = _blend8(np.full_like(a, mean), a, f)
+        elif op == 2 and C == 3:
+            a = _blend8(_lum8(a)[None].repeat(3, 0), a, f)
+        elif op == 3 and C == 3:
+            h, s, v = _rgb2hsv8(a)
+            h = (h.astype(np.int32) + (int(np.float32(f) * np.float32(255.0)) & 0xff)).astype(np.uint8)      # uint8 wrap
+            a = _hsv2rgb8(h, s, v)
+    return a
+
+
+def gaussian_blur_radius(sigma, passes=3):
+    """Pillow's _gaussian_blur_radius: fractional box radius of the 3-pass box approximation."""
+    import math
+    sigma2 = float(np.float32(sigma)) * float(np.float32(sigma)) / passes
+    L = math.sqrt(12.0 * sigma2 + 1.0)
+    l = math.floor((L - 1.0) / 2.0)
+    a = (2 * l + 1) * (l * (l + 1) - 3 * sigma2)
+    a /= 6 * (sigma2 - (l + 1) * (l + 1))
+    return float(np.float32(l + a))
+
+
+def _box_pass(x, fr):
+    r = int(fr)
+    ww = int(np.float32(1 << 24) / (np.float32(fr) * np.float32(2.0) + np.float32(1.0)))
+    fw = ((1 << 24) - (r * 2 + 1) * ww) // 2
+    n = x.shape[-1]
+    idx = np.arange(n)
+    acc = np.zeros(x.shape, np.int64)
+    for d in range(-r, r + 1):
+        acc += x[..., np.clip(idx + d, 0, n - 1)].astype(np.int64) * ww
+    acc += (x[..., np.clip(idx - r - 1, 0, n - 1)].astype(np.int64) + x[..., np.clip(idx + r + 1, 0, n - 1)].astype(np.int64)) * fw
+    return ((acc + (1 << 23)) >> 24).astype(np.uint8)
+
+
+def gaussian_blur_u8(a, sigma):
+    """ImageFilter.GaussianBlur(radius=sigma) on uint8 [C, H, W]: three horizontal box passes, then three vertical."""
+    fr = gaussian_blur_radius(sigma)
+    x = a
+    for _ in range(3):
+        x = _box_pass(x, fr)
+    x = np.swapaxes(x, -1, -2)
+    for _ in range(3):
+        x = _box_pass(x, fr)
+    return np.ascontiguousarray(np.swapaxes(x, -1, -2))
+
+
+def batch_transform_params(n_images, apply_augmentation, scale_size=(1.0, 1.0)):
+    """The generator draws of batch_transform (augment.py:255-281 -> transform :131-225 -> torchvision ColorJitter.get_params),
+    in order, for same-size crops: per image python random.uniform(scale), [torch.rand(1) -> randperm(4) + 4 uniform_],
+    [torch.rand(1) -> python random.uniform(0.15, 1.15)]; after the loop torch.rand(1) for AdvMorph (drawn even when
+    apply_augmentation is False: `torch.rand(1) > 0.5 and apply_augmentation`).  Returns (per-image dicts, morph flag)."""
+    out = []
+    for _ in range(n_images):
+        random.uniform(scale_size[0], scale_size[1])
+        d = dict(order=None, factors=None, sigma=None)
+        if apply_augmentation:
+            if float(torch.rand(1)) > 0.5:
+                d["order"] = [int(v) for v in torch.randperm(4)]
+                d["factors"] = tuple(float(torch.empty(1).uniform_(lo, hi)) for lo, hi in ((0.75, 1.25), (0.75, 1.25), (0.75, 1.25), (-0.25, 0.25)))
+            if float(torch.rand(1)) > 0.5:
+                d["sigma"] = random.uniform(0.15, 1.15)
+        out.append(d)
+    morph = bool(float(torch.rand(1)) > 0.5) and bool(apply_augmentation)
+    return out, morph

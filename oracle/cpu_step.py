@@ -21,21 +21,53 @@ def make_state(unet_sd, fe_sd, qrep_w):
     return st
 
 
+def batch_transform(data, label, logits, apply_augmentation, morph_velocity=None):
+    """augment.batch_transform (augment.py:255-281) for the trainers' same-size configuration, from the oracle's pieces:
+    generator draws (orc.batch_transform_params), 8-bit round trip, ColorJitter / GaussianBlur in Pillow's integer
+    arithmetic, AdvMorph with the velocity field supplied by `morph_velocity(B, h, w)` (the reference draws it on the
+    device generator, which has no CPU counterpart)."""
+    params, morph = orc.batch_transform_params(int(data.shape[0]), apply_augmentation)
+    out = []
+    for k, p in enumerate(params):
+        a = orc.q8(data[k].numpy())
+        if p["order"] is not None:
+            a = orc.color_jitter_u8(a, p["order"], p["factors"])
+        if p["sigma"] is not None:
+            a = orc.gaussian_blur_u8(a, p["sigma"])
+        out.append(torch.from_numpy(a.astype(np.float32) / np.float32(255.0)))
+    data_t = torch.stack(out)
+    logits_t = torch.from_numpy(orc.q8(logits.numpy()).astype(np.float32) / np.float32(255.0))
+    if morph:
+        B, _, H, W = data_t.shape
+        v = morph_velocity(B, W // 8, W // 8)
+        v = v / (v.reshape(B, -1).norm(dim=1).view(-1, 1, 1, 1) + 1e-20)
+        data_t = orc.adv_morph_forward(data_t, v)
+    return data_t, label, logits_t
+
+
 def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20.0, k1=0.01, lr=0.01,
-         delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7, apply_aug='none', pool=None, k4=1.0, topk=5):
+         delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7, apply_aug='none', pool=None, k4=1.0, topk=5,
+         bt=False, morph_velocity=None):
     with torch.no_grad():
         pred_u0, _, _ = orc.unet_forward(u_data, st["teacher"], track=True)
         pseudo_logits, pseudo_labels = torch.max(torch.softmax(pred_u0, 1), 1)
         if apply_aug in ('cutout', 'cutmix', 'classmix'):      # train_arco_2d.py:296-297 (generate_unsup_data)
             mixed = orc.generate_unsup_data(u_data.numpy(), pseudo_labels.numpy().copy(), pseudo_logits.numpy(), apply_aug)
             u_data, pseudo_labels, pseudo_logits = (torch.from_numpy(v) for v in mixed)
+        cj2_l, cj2_u = l_data, None
+        if bt:       # train_arco_2d.py:287-304: batch_transform x2 on the labeled (no augmentation), x2 on the mixed unlabeled batch
+            batch_transform(l_data, l_label, torch.ones(l_label.shape), False)
+            cj2_l, _, _ = batch_transform(l_data, l_label, torch.ones(l_label.shape), False)
+        if bt:
+            cj2_u, _, _ = batch_transform(u_data, pseudo_labels, pseudo_logits, True, morph_velocity)
+            u_data, pseudo_labels, pseudo_logits = batch_transform(u_data, pseudo_labels, pseudo_logits, True, morph_velocity)
         for k in st["k_fe"]:
             st["k_fe"][k] = st["k_fe"][k] * 0.99 + st["q_fe"][k].detach() * 0.01
     # train-mode forwards in the reference's order (train_arco_2d.py:310-315); track=True: the BatchNorm running
     # statistics receive their momentum updates in that order (they do not commute)
     pred_l, _, l_fm = orc.unet_forward(l_data, st["student"], track=True)
     with torch.no_grad():
-        orc.unet_forward(l_data, st["student"], track=True)          # images_cj2_l (:311): running statistics only
+        orc.unet_forward(cj2_l, st["student"], track=True)           # images_cj2_l (:311): running statistics only
     pred_u, _, u_fm = orc.unet_forward(u_data, st["student"], track=True)
     with torch.no_grad():
         pred_l_t, _, l_fm_t = orc.unet_forward(l_data, st["teacher"], track=True)
@@ -75,7 +107,7 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
             logits_all = torch.cat((torch.ones(l_label.shape), pseudo_logits))
             mask = orc.eqv_mask(labels_all, logits_all, weak_threshold)
             grid = orc.tps_grid(orc.rand_tps_source_points(tcp, nb2, tps_sigma), inv, rep, H, W)
-            images_tps = orc.grid_sample(torch.cat((l_data, u_data)), grid)
+            images_tps = orc.grid_sample(torch.cat((cj2_l, u_data if cj2_u is None else cj2_u)), grid)
             mask_tps = orc.grid_sample(mask, grid)
             org = orc.grid_sample(torch.cat((pred_l.detach(), pred_u.detach())), grid)
         pred_tps = orc.unet_forward(images_tps, st["student"], track=True)[0]

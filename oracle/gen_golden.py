@@ -543,9 +543,89 @@ def gen_morph():
     print("g10_morph", len(out))
 
 
+# ---------------------------------------------------------------- G12 ColorJitter / GaussianBlur on PIL images
+def gen_jitter():
+    """The photometric half of batch_transform (augment.py:167-178): torchvision 0.13.1 is not installed here, so its
+    glue (ColorJitter.forward applies functional_pil.adjust_brightness / contrast / saturation / hue in fn_idx order;
+    adjust_hue shifts the H channel of img.convert('HSV') with uint8 wrap) is restated on top of PILLOW, which does every
+    pixel operation: ImageEnhance.Brightness / Contrast / Color, Image.convert, ImageFilter.GaussianBlur."""
+    from PIL import Image, ImageEnhance, ImageFilter
+    out = {}
+    for tag, (C, H, W, seed, order, factors, sigma) in fx.JITTER_CASES.items():
+        x = fx.jitter_image(seed, C, H, W)
+        u8 = torch.from_numpy(x).mul(255).byte().numpy()                                   # to_pil_image
+        img = Image.fromarray(u8[0], 'L') if C == 1 else Image.fromarray(np.ascontiguousarray(u8.transpose(1, 2, 0)), 'RGB')
+        if order is not None:
+            for op in order:
+                f = factors[op]
+                if op == 0:
+                    img = ImageEnhance.Brightness(img).enhance(f)
+                elif op == 1:
+                    img = ImageEnhance.Contrast(img).enhance(f)
+                elif op == 2:
+                    img = ImageEnhance.Color(img).enhance(f)
+                elif op == 3 and img.mode == 'RGB':                                        # F_pil.adjust_hue ('L': unchanged)
+                    h, s_, v = img.convert('HSV').split()
+                    np_h = np.array(h, dtype=np.uint8)
+                    np_h = (np_h.astype(np.int32) + (int(np.float32(f) * np.float32(255.0)) & 0xff)).astype(np.uint8)   # np_h += np.uint8(f * 255), wrap
+                    img = Image.merge('HSV', (Image.fromarray(np_h, 'L'), s_, v)).convert('RGB')
+        if sigma is not None:
+            img = img.filter(ImageFilter.GaussianBlur(radius=sigma))
+        arr = np.array(img)
+        out[tag] = arr[None] if C == 1 else np.ascontiguousarray(arr.transpose(2, 0, 1))
+    np.savez_compressed(os.path.join(OUT, "g12_jitter.npz"), **out)
+    print("g12_jitter", len(out))
+
+
+# ---------------------------------------------------------------- G11 2-D evaluation (SURVEY 8f row 3)
+def gen_eval2d(mods):
+    """test_2D.test_single_volume (test_2D.py:67-103) pulled out of the source text (the module imports medpy / h5py /
+    SimpleITK, absent here) and run on the reference U-Net in eval mode.  Stand-ins are DATA plumbing only: an in-memory
+    object for h5py.File, no-op SimpleITK writers; calculate_metric_percase (medpy) is replaced by a recorder - the pinned
+    quantity is the function's per-slice prediction volume (zoom order 0 -> net -> argmax -> zoom back)."""
+    from scipy.ndimage import zoom
+    UNet = mods["networks.unetWithArgs"].UNet
+    out = {}
+    for tag, (shape, C, seed) in fx.EVAL2D_CASES.items():
+        image, label = fx.eval2d_volume(seed, shape, C)
+        store = {"image": image, "label": label}
+
+        class _File(dict):
+            def __init__(self, *a, **k):
+                super().__init__(store)
+
+        class _Sitk:
+            @staticmethod
+            def GetImageFromArray(a):
+                return types.SimpleNamespace(SetSpacing=lambda s: None)
+
+            @staticmethod
+            def WriteImage(*a):
+                return None
+
+        seen = []
+
+        def record(pred, gt):
+            seen.append((pred.copy(), gt.copy()))
+            return (0, 0, 0, 0)
+        ns, _ = _pull_functions(os.path.join(ref_shim.REF, "test_2D.py"), {"test_single_volume"},
+                                dict(h5py=types.SimpleNamespace(File=_File), sitk=_Sitk, zoom=zoom, calculate_metric_percase=record))
+        net = UNet(in_chns=1, class_num=C)
+        net.load_state_dict(fx.randomize_running_stats(fx.unet_state(seed, 1, C), seed + 1))
+        flags = types.SimpleNamespace(root_path="", model="unet")
+        ns["test_single_volume"]("case", net, C, "", flags)
+        pred = np.zeros_like(label)
+        for i, (p, g) in enumerate(seen, start=1):
+            pred[p] = i
+            assert np.array_equal(g, label == i)
+        out[f"{tag}_pred"] = pred.astype(np.int8)
+    np.savez_compressed(os.path.join(OUT, "g11_eval2d.npz"), **out)
+    print("g11_eval2d", len(out))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
@@ -556,3 +636,5 @@ if __name__ == "__main__":
     if "g8" in which: gen_ingest()
     if "g9" in which: gen_flags()
     if "g10" in which: gen_morph()
+    if "g11" in which: gen_eval2d(mods)
+    if "g12" in which: gen_jitter()

@@ -298,3 +298,37 @@ def morph_inputs(seed, B, C, H, W):
     data = torch.from_numpy(rs.uniform(size=(B, C, H, W)).astype(np.float32))
     param = torch.from_numpy((rs.uniform(size=(B, 2, W // 8, W // 8)) * 2 - 1).astype(np.float32))
     return data, param
+
+
+# 2-D evaluation cases: tag -> (volume shape [slices, x, y], classes, seed); slices are zoomed to 256 x 256 by the function
+EVAL2D_CASES = {"a": ((3, 40, 36), 4, 61), "b": ((2, 300, 280), 4, 62)}
+
+
+def eval2d_volume(seed, shape, n_cls):
+    rs = np.random.RandomState(7000 + seed)
+    image = rs.uniform(size=shape).astype(np.float32)
+    label = blob_labels(rs, shape[0], shape[1:], n_cls).astype(np.uint8)
+    image += 0.5 * (label > 0)                   # some structure for the network to follow
+    return image, label
+
+
+# ColorJitter / GaussianBlur cases (g12): tag -> (C, H, W, seed, order, (brightness, contrast, saturation, hue), blur sigma or None)
+JITTER_CASES = {
+    "l_bc": (1, 40, 52, 1, (0, 1, 2, 3), (1.2, 0.8, 1.1, 0.1), None),
+    "l_cb_blur": (1, 64, 48, 2, (1, 3, 0, 2), (0.76, 1.24, 0.9, -0.2), 0.9),
+    "l_blur_only": (1, 33, 70, 3, None, None, 0.15),
+    "l_blur_big": (1, 50, 50, 4, (2, 0, 3, 1), (1.25, 0.75, 1.0, 0.0), 1.15),
+    "rgb_all": (3, 36, 44, 5, (3, 1, 2, 0), (0.9, 1.2, 0.8, -0.25), None),
+    "rgb_hue_sat_blur": (3, 48, 40, 6, (2, 3, 1, 0), (1.1, 0.85, 1.25, 0.25), 0.6),
+    "rgb_blur_r1": (3, 40, 40, 7, None, None, 2.2),           # integer box radius 1 (outside the trainer's sigma range)
+}
+
+
+def jitter_image(seed, C, H, W):
+    """float image in [0, 1] with some exact grey / saturated pixels (HSV corner cases)."""
+    rs = np.random.RandomState(8000 + seed)
+    x = rs.uniform(size=(C, H, W)).astype(np.float32)
+    x[:, 0, :6] = np.array([[0.0, 1.0, 0.5, 0.25, 1.0, 0.0]], dtype=np.float32)
+    if C == 3:
+        x[:, 1, 0] = (1.0, 0.0, 0.0); x[:, 1, 1] = (0.0, 1.0, 0.0); x[:, 1, 2] = (0.0, 0.0, 1.0); x[:, 1, 3] = (0.2, 0.2, 0.2)
+    return x

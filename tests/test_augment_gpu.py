@@ -72,3 +72,59 @@ def test_full_size_cutmix_properties():
         assert abs(repl.sum() - H * W / 2) <= W
         r = torch.from_numpy(repl).cuda()
         assert bool((nt[i][r] == target[(i + 1) % b][r]).all()) and bool((nl[i][~r] == logits[i][~r]).all())
+
+
+@pytest.mark.parametrize("tag", list(fx.JITTER_CASES))
+def test_jitter_blur_kernels_vs_pillow(tag):
+    """arco_jitter_blur (Pillow's 8-bit integer arithmetic on the GPU) vs Pillow's own output (g12): bit exact."""
+    import os
+    from arco_amd import augment
+    g12 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g12_jitter.npz"))
+    C, H, W, seed, order, factors, sigma = fx.JITTER_CASES[tag]
+    x = torch.from_numpy(fx.jitter_image(seed, C, H, W)).unsqueeze(0)
+    # a batch of three images with different parameters: the case, an untouched image, the case again
+    data = torch.cat((x, x.flip(-1), x)).cuda()
+    p = dict(order=list(order) if order is not None else None, factors=factors, sigma=sigma)
+    out = augment.jitter_blur(data, [p, dict(order=None, factors=None, sigma=None), p])
+    got = torch.round(out * 255).to(torch.uint8).cpu().numpy()
+    np.testing.assert_array_equal(got[0], g12[tag])
+    np.testing.assert_array_equal(got[2], g12[tag])
+    np.testing.assert_array_equal(got[1], (x.flip(-1)[0] * 255).to(torch.uint8).numpy())     # plain 8-bit round trip
+    assert torch.equal(out * 255, torch.round(out * 255))                                     # exact k / 255 values
+
+
+def test_batch_transform_draws_and_outputs_match_oracle():
+    """augment.batch_transform vs the oracle's restatement (cpu_step.batch_transform): same consumption of the python /
+    torch CPU generators, identical 8-bit images and confidences, AdvMorph on the same velocity field."""
+    import random
+    import cpu_step
+    from arco_amd import augment
+    from arco_amd.adv_morph import AdvMorph
+    rs = np.random.RandomState(3)
+    data = torch.from_numpy(rs.uniform(size=(6, 1, 64, 64)).astype(np.float32))
+    label = torch.from_numpy(rs.randint(-1, 4, size=(6, 64, 64)).astype(np.int64))
+    logits = torch.from_numpy(rs.uniform(size=(6, 64, 64)).astype(np.float32))
+    vel = lambda B, h, w: torch.from_numpy(np.random.RandomState(11).uniform(-1, 1, size=(B, 2, h, w)).astype(np.float32))
+    real = AdvMorph.init_velocity
+    AdvMorph.init_velocity = lambda self, batch_size, height, width, use_zero=False: self.unit_normalize(vel(batch_size, height, width).cuda())
+    try:
+        n_morph = 0
+        for seed in range(6):                         # several seeds: jitter / blur / morph on and off
+            for aug in (True, False):
+                random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+                d_o, l_o, g_o = cpu_step.batch_transform(data, label, logits, aug, vel)
+                probe_o = (random.random(), float(torch.rand(1)))
+                random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+                d_g, l_g, g_g = augment.batch_transform(data.cuda(), label.cuda(), logits.cuda(), [64, 64], (1.0, 1.0), aug)
+                probe_g = (random.random(), float(torch.rand(1)))
+                assert probe_o == probe_g, (seed, aug)                       # same generator consumption
+                assert torch.equal(l_g.cpu(), l_o) and torch.equal(g_g.cpu(), g_o)
+                morphed = not torch.equal(d_o * 255, torch.round(d_o * 255))
+                n_morph += int(morphed)
+                if morphed:
+                    np.testing.assert_allclose(d_g.cpu().numpy(), d_o.numpy(), atol=2e-4)
+                else:
+                    assert torch.equal(d_g.cpu(), d_o), (seed, aug)
+        assert n_morph >= 1
+    finally:
+        AdvMorph.init_velocity = real

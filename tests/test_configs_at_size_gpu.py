@@ -60,8 +60,14 @@ def _check_step_invariants(st, func, qsize, D, seed):
     C, Q, Nn = pl.C, pl.Q, pl.Nn
     draw = samplers.grid_as_monte_carlo_sample if func == "asmc" else samplers.grid_monte_carlo_sample
     assert pl.valid_seg > 1 and len(pl.entries) >= 2
-    # 1. bit-exact replay of the host samplers from the seeded generator (the mixing strategy draws from numpy only)
-    torch.manual_seed(seed)
+    # 1. bit-exact replay of the host samplers from the seeded generator: the mixing strategy draws from numpy only, the
+    #    2-D step's batch_transform calls (2 x labeled without, 2 x unlabeled with augmentation) from python / torch first
+    random.seed(seed); torch.manual_seed(seed)
+    if getattr(st.args, "batch_transform", 0) and len(pl.spatial) == 2:
+        from arco_amd import augment
+        nb = pl.n_img // 2
+        for aug in (False, False, True, True):
+            augment.draw_batch_transform_params(nb, aug)
     for (k, vc, a_dev, n_dev) in pl.entries:
         n_anchor, blen = int(pl.n_anchor[k]), int(pl.bank_len[vc])
         exp_a, exp_n = draw(n_anchor, Q), draw(blen, Q * Nn)
@@ -199,7 +205,7 @@ def test_cfg4_cityscapes_shape_vs_cpu_oracle():
     b, patch, C, Q, Nn, qs = 1, (64, 128), 19, 256, 64, 256
     unet_sd, fe_sd = fx.unet_state(23, 3, C), fx.fe_state(31)
     qrep_w = [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]]
-    st_g = _make_city(["--base_lr", "0.01", "--graphs", "0"], patch=patch, b=b, qsize=qs, nq=Q, nn_=Nn)
+    st_g = _make_city(["--base_lr", "0.01", "--graphs", "0", "--batch_transform", "0"], patch=patch, b=b, qsize=qs, nq=Q, nn_=Nn)
     st_g.model.load_state_dict(unet_sd, strict=True)
     st_g.ema_model.load_state_dict(unet_sd, strict=True)
     st_g.q_feature_extractor.load_state_dict(fe_sd, strict=True)

@@ -102,3 +102,27 @@ def test_all_case_3d_metrics():
     assert 0 < d < 1 and 0 < j < d and abs(hd - hd_o) < 1e-9 and abs(asd - asd_o) < 1e-9
     cc = test_util.getLargestCC(pred)
     assert cc.dtype == bool and 0 < cc.sum() <= (pred > 0).sum()
+
+
+@pytest.mark.parametrize("tag", list(fx.EVAL2D_CASES))
+def test_single_volume_matches_reference_function(tag):
+    """arco_amd.test_2D.test_single_volume vs the prediction volume of the reference's own test_single_volume
+    (tests/golden/g11_eval2d.npz: pulled out of test_2D.py:67-103 and run on the reference U-Net in eval mode)."""
+    import os
+    from arco_amd import test_2D
+    from arco_amd.networks.unetWithArgs import UNet
+    g11 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_eval2d.npz"))
+    shape, C, seed = fx.EVAL2D_CASES[tag]
+    image, label = fx.eval2d_volume(seed, shape, C)
+    net = UNet(in_chns=1, class_num=C).cuda()
+    net.load_state_dict(fx.randomize_running_stats(fx.unet_state(seed, 1, C), seed + 1))
+    pred = test_2D.predict_volume(image, net)
+    exp = g11[f"{tag}_pred"].astype(np.int64)
+    assert pred.shape == exp.shape and float((pred != exp).mean()) < 1e-3, float((pred != exp).mean())
+    got = test_2D.test_single_volume(image, label, net, C)
+    for c in range(1, C):                          # Dice / Jaccard of the reference's prediction vs the product's
+        p, g = exp == c, label == c
+        inter = float(np.logical_and(p, g).sum())
+        if p.sum() > 0 and g.sum() > 0:
+            np.testing.assert_allclose(got[c - 1][0], 2 * inter / (p.sum() + g.sum()), atol=5e-3)
+            np.testing.assert_allclose(got[c - 1][1], inter / np.logical_or(p, g).sum(), atol=5e-3)

@@ -377,3 +377,30 @@ def test_adv_morph_oracle_vs_reference(case):
     np.testing.assert_allclose(grid.numpy()[:, :, ::st, ::st], g10[f"{tag}_grid"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(warped.numpy()[:, :, ::st, ::st], g10[f"{tag}_warped"], rtol=0, atol=2e-5)
     assert float(g10[f"{tag}_maxdisp"][0]) > 1e-3                       # a real deformation
+
+
+@pytest.mark.parametrize("tag", list(fx.EVAL2D_CASES))
+def test_eval2d_oracle_vs_reference_function(tag):
+    """oracle.test_single_volume vs the prediction volume of the reference's own test_2D.test_single_volume (g11: pulled
+    out of the source text and run on the reference U-Net in eval mode): identical label maps."""
+    g11 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_eval2d.npz"))
+    shape, C, seed = fx.EVAL2D_CASES[tag]
+    image, label = fx.eval2d_volume(seed, shape, C)
+    sd = fx.randomize_running_stats(fx.unet_state(seed, 1, C), seed + 1)
+    metrics, pred = orc.test_single_volume(image, label, sd, C)
+    exp = g11[f"{tag}_pred"].astype(pred.dtype)
+    assert pred.shape == exp.shape and float((pred != exp).mean()) < 2e-4          # (argmax ties at float noise level)
+    assert len(metrics) == C - 1 and len(np.unique(exp)) > 1
+
+
+@pytest.mark.parametrize("tag", list(fx.JITTER_CASES))
+def test_color_jitter_blur_oracle_vs_pillow(tag):
+    """The integer restatement of ColorJitter / GaussianBlur on 8-bit images vs Pillow's own output (g12): bit exact."""
+    g12 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g12_jitter.npz"))
+    C, H, W, seed, order, factors, sigma = fx.JITTER_CASES[tag]
+    a = orc.q8(fx.jitter_image(seed, C, H, W))
+    if order is not None:
+        a = orc.color_jitter_u8(a, order, factors)
+    if sigma is not None:
+        a = orc.gaussian_blur_u8(a, sigma)
+    np.testing.assert_array_equal(a, g12[tag])

@@ -23,7 +23,8 @@ def _drop_off(m):
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutmix"),
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutout"),
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0, apply_aug="classmix"),
-                                     dict(revisit=1, K=4, topk=2, k2=0.0, apply_aug="cutmix")])
+                                     dict(revisit=1, K=4, topk=2, k2=0.0, apply_aug="cutmix"),
+                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutmix", batch_transform=1)])
 def test_two_steps_vs_cpu_oracle(variant):
     from arco_amd import train_arco_2d as T
     b, patch, C, Q, Nn, qs = 2, (64, 64), 4, 64, 32, 300
@@ -31,8 +32,15 @@ def test_two_steps_vs_cpu_oracle(variant):
     qrep_w = [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]]
     argv = ["--batch_size", str(b), "--queue_size", str(qs), "--synthetic", "1", "--num_queries", str(Q),
             "--num_negatives", str(Nn), "--k1", "1.0", "--base_lr", "0.01", "--graphs", "0"]
-    for k, v in variant.items():
+    variant = dict(variant)
+    bt = variant.setdefault("batch_transform", 0)        # the reference's batch_transform: its own variant (AdvMorph's velocity
+    for k, v in variant.items():                         # field comes from the device generator: both sides get the same one)
         argv += [f"--{k}", str(v)]
+    from arco_amd.adv_morph import AdvMorph
+    vel = lambda B, h, w: torch.from_numpy(np.random.RandomState(17).uniform(-1, 1, size=(B, 2, h, w)).astype(np.float32))
+    real_velocity = AdvMorph.init_velocity
+    if bt:
+        AdvMorph.init_velocity = lambda self, batch_size, height, width, use_zero=False: self.unit_normalize(vel(batch_size, height, width).cuda())
     args = T.build_parser().parse_args(argv)
     args.patch_size = list(patch)
     st_g = T.ArcoStep2D(args, "cuda:0")
@@ -60,7 +68,7 @@ def test_two_steps_vs_cpu_oracle(variant):
         lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
         cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn, k2=variant["k2"],
-                      apply_aug=variant["apply_aug"], pool=pool_o, topk=variant.get("topk", 5))
+                      apply_aug=variant["apply_aug"], pool=pool_o, topk=variant.get("topk", 5), bt=bool(bt), morph_velocity=vel)
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
         st_g.step(l.cuda(), lab.cuda(), u.cuda())
         to, tg = st_o["last_terms"], st_g.last_terms
@@ -74,6 +82,7 @@ def test_two_steps_vs_cpu_oracle(variant):
             assert bo[0].shape == bg[0].shape
             np.testing.assert_allclose(bg[0].cpu().numpy(), bo[0].numpy(), rtol=2e-3, atol=2e-4)
         assert [int(p) for p in ptr_o] == [int(p) for p in st_g.queue_ptrlis]
+    AdvMorph.init_velocity = real_velocity
     # updated weights: student U-Net (by name), heads, teacher
     sd_g = st_g.model.state_dict()
     worst = 0.0
