@@ -5,6 +5,8 @@
 // formulas, ImagingGaussianBlur = three box-blur passes per direction with 24-bit fixed-point weights) - pinned bit for
 // bit against Pillow itself (tests/golden/g12_jitter.npz, oracle/gen_golden.py g12).
 #include "common.h"
+// Pillow rounds every float operation separately: no fused multiply-add in this file
+#pragma clang fp contract(off)
 
 #define ARCO_MAX_IMG 32
 struct JitDesc {
