@@ -161,5 +161,5 @@ def set_enabled(owner, flag):
     for name, v in vars(owner).items():
         if isinstance(v, (GraphedForward, GraphedTrain)):
             prev[name] = v.enabled
-            v.enabled = flag if isinstance(flag, bool) else flag.get(name, v.enabled)
+            v.enabled = flag if isinstance(flag, bool) else bool(flag.get(name, v.enabled))
     return prev

@@ -5,7 +5,7 @@ import torch
 from arco_amd import train_arco_2d as T, _contrast as C_, glue, head
 import cProfile, pstats
 
-args = T.build_parser().parse_args(["--batch_size", "8", "--queue_size", "4096", "--synthetic", "1"])
+args = T.build_parser().parse_args(["--batch_size", "8", "--queue_size", "4096", "--synthetic", "1", "--conv_mma", os.environ.get("MMA", "f32x3")])
 st = T.ArcoStep2D(args, "cuda:0")
 l, ll = T.synthetic_batch(8, args.patch_size, 4, 1, "cuda:0")
 u, _ = T.synthetic_batch(8, args.patch_size, 4, 2, "cuda:0")
