@@ -54,6 +54,13 @@ constexpr int IGEMM_FLAT_WPMAX = 64;
 // 1x1: KC = 32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// LDS words are written as packed bf16 pairs and read back as MFMA operands: every such type-punned access goes through a
+// may_alias type (without it the compiler may assume that the loads cannot see the stores - observed: a B fragment built
+// from one repeated dword)
+typedef unsigned int u32x2_ma __attribute__((ext_vector_type(2), may_alias));
+typedef unsigned int u32x4_ma __attribute__((ext_vector_type(4), may_alias));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_bf16x8(const void* p) { return __builtin_bit_cast(bf16x8, u32x4(*reinterpret_cast<const u32x4_ma*>(p))); }
 __device__ __forceinline__ void split3_bf16x4(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
   unsigned short h[3][4];
 #pragma unroll
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         u32x2 p0, p1, p2;
         split3_bf16x4(ra[it], p0, p1, p2);
         unsigned int* d = reinterpret_cast<unsigned int*>(buf) + ldsA[it];
-        *reinterpret_cast<u32x2*>(d) = p0; *reinterpret_cast<u32x2*>(d + 8) = p1; *reinterpret_cast<u32x2*>(d + 16) = p2;
+        *reinterpret_cast<u32x2_ma*>(d) = p0; *reinterpret_cast<u32x2_ma*>(d + 8) = p1; *reinterpret_cast<u32x2_ma*>(d + 16) = p2;
       } else {
         *reinterpret_cast<f32x4*>(&buf[ldsA[it]]) = ra[it];
       }
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
           const int row = TAPS == 9 ? (FLAT ? s * 16 + li + dy * Wp + dx : (s + dy) * 18 + li + dx) : s * 16 + li;
           const float* p = &As[row * LDK + koff];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) fa[at][pl] = *reinterpret_cast<const bf16x8*>(p + 8 * pl);
+          for (int pl = 0; pl < 3; ++pl) fa[at][pl] = lds_bf16x8(p + 8 * pl);
         }
 #pragma unroll
         for (int ct = 0; ct < C_T; ++ct) {
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
           const float* p = &Bs[row * LDK + koff];
           bf16x8 fb[3];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(p + 8 * pl);
+          for (int pl = 0; pl < 3; ++pl) fb[pl] = lds_bf16x8(p + 8 * pl);
 #pragma unroll
           for (int at = 0; at < A_T; ++at) {       // small terms first
             f32x4 c = acc[at][ct];
@@ -1239,6 +1246,172 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split-bf16 weight gradient of the 3x3 / 3x3x3 convolutions (the MMA = 3 counterpart of wgrad_halo2_kernel):
+//   dW[tap][co][ci] = sum_pix dZ[pix][co] * X[pix + tap][ci],   M = co, N = ci, K = PIXELS.
+// v_mfma_f32_16x16x32_bf16 wants 8 consecutive k (= pixels) per lane, so both operands are staged TRANSPOSED in LDS, as
+// three bf16 planes [plane][channel][pixel]: a staging thread loads 4 consecutive pixels x 4 channels (four 16-byte global
+// loads), splits every value into its three bf16 terms and writes, per channel and plane, the 4 pixels as one 8-byte word.
+// One K step = 32 pixels = two rows of the 8 x 16 tile; lane (li, g) supplies channel li, row 2s + (g >> 1), columns
+// 8 (g & 1) .. + 7.  The input operand of tap (dy, dx) is the halo tile shifted by dx columns: a lane reads the 12 columns
+// 8h .. 8h + 11 of row r + dy once (ds_read_b128 + ds_read_b64) and forms the three dx windows in registers (dx = 1: four
+// v_alignbit_b32, dx = 2: the next dwords) - 18 LDS reads feed the 54 MFMAs of a K step.  Persistent over tiles with the
+// next tile's global loads in flight during the MFMAs; partial layout / reduction identical to wgrad_halo2_kernel.
+// ---------------------------------------------------------------------------
+template <int CO_B, int CI_B>
+__global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
+  constexpr int QZ = CO_B / 4, QA = CI_B / 4;
+  constexpr int ZU = 32 * QZ, XU = 50 * QA;                 // staging units (4 pixels x 4 channels)
+  constexpr int NZU = (ZU + 255) / 256, NXU = (XU + 255) / 256;
+  constexpr int CSZ = 68, CSX = 124;                        // dwords per (plane, channel) row: 128 px / 10 x 24 halo px (+ pad)
+  constexpr int CI_T = CI_B / 16, NSUB = (CO_B / 16) * CI_T, WPS = 4 / NSUB, KS = 4 / WPS;
+  extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
+  unsigned int* Zs = smem_u;                                // [3][CO_B][CSZ]
+  unsigned int* Xs = smem_u + 3 * CO_B * CSZ;               // [3][CI_B][CSX]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int sub = wid / WPS, part = wid % WPS, wi = sub / CI_T, wj = sub % CI_T;
+  const int dd = blockIdx.z;
+  const int dpl = a.taps == 27 ? dd - 1 : 0;
+  const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
+  const int ci_tiles = a.CinPad / CI_B;
+  const int co0 = (blockIdx.y / ci_tiles) * CO_B, ci0 = (blockIdx.y % ci_tiles) * CI_B;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
+  f32x4 pz[NZU][4], px_[NXU][4];
+  auto fetch = [&](int t) {
+    int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; const int img = tt / tiles_y;
+    const int y0 = ty * 8, x0 = tx * 16;
+    const int pl = a.taps == 27 ? img % a.D3 + dpl : 0;
+    const bool plane_ok = pl >= 0 && pl < a.D3;
+#pragma unroll
+    for (int i = 0; i < NZU; ++i) {
+      const int u = tid + i * 256, pg = u / QZ, q = u % QZ, r = pg >> 2, cg = pg & 3;
+      const int y = y0 + r, c = co0 + 4 * q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = x0 + 4 * cg + j;
+        f32x4 v = f32x4{0, 0, 0, 0};
+        if (u < ZU && y < a.H && x < a.W && plane_ok && c < a.Cout) v = *reinterpret_cast<const f32x4*>(a.dZ + (((long)img * a.H + y) * a.W + x) * a.ldz + c);
+        pz[i][j] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) {
+      const int u = tid + i * 256, pg = u / QA, q = u % QA, hr = pg / 5, hg = pg % 5;
+      const int y = y0 + hr - 1, c = ci0 + 4 * q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = x0 - 1 + 4 * hg + j;
+        f32x4 v = f32x4{0, 0, 0, 0};
+        if (u < XU && y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok && c < a.Cin)
+          v = *reinterpret_cast<const f32x4*>(a.Ain + (((long)(img + dpl) * a.H + y) * a.W + x) * a.lda + c);
+        px_[i][j] = v;
+      }
+    }
+  };
+  // 4 pixels x 4 channels -> per channel and plane one 8-byte word of 4 bf16 pixels
+  auto stage = [&](const f32x4 (&v)[4], unsigned int* base, int nchan, int chan0, int cs, int off) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      u32x2 p0, p1, p2;
+      split3_bf16x4(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, p0, p1, p2);
+      unsigned int* d = base + (long)(chan0 + e) * cs + off;
+      *reinterpret_cast<u32x2_ma*>(d) = p0;
+      *reinterpret_cast<u32x2_ma*>(d + (long)nchan * cs) = p1;
+      *reinterpret_cast<u32x2_ma*>(d + 2l * nchan * cs) = p2;
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < a.n_tiles) fetch(t);
+  while (t < a.n_tiles) {
+#pragma unroll
+    for (int i = 0; i < NZU; ++i) {
+      const int u = tid + i * 256, pg = u / QZ, q = u % QZ, r = pg >> 2, cg = pg & 3;
+      if (u < ZU) stage(pz[i], Zs, CO_B, 4 * q, CSZ, r * 8 + cg * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) {
+      const int u = tid + i * 256, pg = u / QA, q = u % QA, hr = pg / 5, hg = pg % 5;
+      if (u < XU) stage(px_[i], Xs, CI_B, 4 * q, CSX, hr * 12 + hg * 2);
+    }
+    __syncthreads();
+    const int next = t + gridDim.x;
+    if (next < a.n_tiles) fetch(next);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int s = part * KS + ks, rr = 2 * s + (g >> 1), h = g & 1;
+      bf16x8 za[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) za[p] = lds_bf16x8(&Zs[(p * CO_B + wi * 16 + li) * CSZ + rr * 8 + h * 4]);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        unsigned int w[3][6];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned int* src = &Xs[(p * CI_B + wj * 16 + li) * CSX + (rr + dy) * 12 + h * 4];
+          const u32x4 lo = *reinterpret_cast<const u32x4_ma*>(src);
+          const u32x2 hi = *reinterpret_cast<const u32x2_ma*>(src + 4);
+          w[p][0] = lo[0]; w[p][1] = lo[1]; w[p][2] = lo[2]; w[p][3] = lo[3];
+          w[p][4] = hi[0]; w[p][5] = hi[1];
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          bf16x8 xb[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            unsigned int d4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              d4[i] = dx == 0 ? w[p][i] : (dx == 2 ? w[p][i + 1] : __builtin_amdgcn_alignbit(w[p][i + 1], w[p][i], 16));
+            xb[p] = __builtin_bit_cast(bf16x8, u32x4{d4[0], d4[1], d4[2], d4[3]});
+          }
+          f32x4 c = acc[dy * 3 + dx];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[2], xb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0], xb[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[1], xb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[1], xb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0], xb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0], xb[0], c, 0, 0, 0);
+          acc[dy * 3 + dx] = c;
+        }
+      }
+    }
+    __syncthreads();
+    t = next;
+  }
+  if (WPS > 1) {                      // sum the pixel-split partner waves (once per launch)
+    float* red = reinterpret_cast<float*>(smem_u);                // [4 waves][9][256]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wid * 9 + tap) * 256 + r * 64 + lane] = acc[tap][r];
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[tap][r];
+#pragma unroll
+          for (int w2 = 1; w2 < WPS; ++w2) v += red[((wid + w2) * 9 + tap) * 256 + r * 64 + lane];
+          acc[tap][r] = v;
+        }
+    }
+  }
+  if (part == 0) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      float* out = a.partial + (((long)blockIdx.x * a.taps + dd * 9 + tap) * a.CoutPad) * a.CinPad;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(long)(co0 + wi * 16 + 4 * g + r) * a.CinPad + ci0 + wj * 16 + li] = acc[tap][r];
+    }
+  }
+}
+
 // Weight gradient of the one-channel 3x3x3 layer: dW[co][tap] = sum_vox dZ[vox][co] * X[vox + tap].
 // D[tap][co] = im2col^T [tap][vox] * dZ [vox][co]: M = 27 taps (two 16-row MFMA tiles), N = 16, K = voxels; the im2col
 // operand comes from a three-plane halo tile in LDS, dZ is read once straight from HBM (64 B per voxel, coalesced).
@@ -1592,9 +1765,9 @@ int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long
 int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
                       int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, void* stream) {
   const int NB = NV * D3;
-  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9 || taps == 27) && mma >= 0 && mma <= 2);
+  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9 || taps == 27) && mma >= 0 && mma <= 3);
   WgradArgs a{};
-  a.D3 = D3; a.mma = (taps == 27 && mma) ? 2 : 0;            // gradients: bf16 operands whichever reduced mode is on
+  a.D3 = D3; a.mma = mma == 3 ? 3 : ((taps == 27 && mma) ? 2 : 0);   // 1 / 2: bf16 operands (gradients: range); 3: split-bf16 (fp32-accurate)
   a.dZ = dZ; a.ldz = ld_dz; a.Cout = Cout; a.Ain = in; a.lda = ld_in; a.Cin = Cin; a.taps = taps;
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.partial = ws;
   const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
@@ -1637,10 +1810,26 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
       } else if (a.mma == 2) hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB, false, 2>), hgrid, dim3(256), sh, st, a); \
       else hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);       \
     } while (0)
-    if (hco == 32 && hci == 32) WH(32, 32);
+    const bool split = a.mma == 3 && !flat && (Cout & 3) == 0 && (Cin & 3) == 0 && (ld_dz & 3) == 0 && (ld_in & 3) == 0;
+#define WS(COB, CIB)                                                                              \
+    do {                                                                                          \
+      size_t sh = (size_t)(3 * COB * 68 + 3 * CIB * 124) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4; \
+      if (sh < rd && (COB / 16) * (CIB / 16) < 4) sh = rd;                                        \
+      static bool attr_s = false;                                                                 \
+      if (sh > 64 * 1024 && !attr_s) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<COB, CIB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_s = true; } \
+      hipLaunchKernelGGL((wgrad_split_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);            \
+    } while (0)
+    if (split) {
+      if (hco == 32 && hci == 32) WS(32, 32);
+      else if (hco == 32 && hci == 16) WS(32, 16);
+      else if (hco == 16 && hci == 32) WS(16, 32);
+      else WS(16, 16);
+    }
+    else if (hco == 32 && hci == 32) WH(32, 32);
     else if (hco == 32 && hci == 16) WH(32, 16);
     else if (hco == 16 && hci == 32) WH(16, 32);
     else WH(16, 16);
+#undef WS
 #undef WH
     launch_wgrad_reduce(st, ws, (int)chunks, taps, a.CoutPad, a.CinPad, Cout, Cin, dW, accumulate);
     return arco_launch_status();

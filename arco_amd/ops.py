@@ -345,7 +345,7 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
                 prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 prof[0].record()
         L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
-               accumulate, 2 if (CONV_MMA in (1, 2) and taps == 27) else 0)
+               accumulate, 3 if (CONV_MMA == 3 and taps in (9, 27)) else (2 if (CONV_MMA in (1, 2) and taps == 27) else 0))
         if prof is not None:
             prof[1].record()
             rec["timed"].append((prof[0], prof[1], flop, (taps, nb * d3 * h * w, co, ci)))

@@ -22,7 +22,7 @@ def _run(mode, x, wt, gy):
         xg, wg = _cl(x).requires_grad_(True), wt.cuda().requires_grad_(True)
         y = ops.conv(xg, wg, None)
         y.backward(_cl(gy))
-        return y.detach().cpu().double(), xg.grad.detach().cpu().double()
+        return y.detach().cpu().double(), xg.grad.detach().cpu().double(), wg.grad.detach().cpu().double()
     finally:
         ops.CONV_MMA = prev
 
@@ -53,8 +53,15 @@ def test_split_bf16_is_fp32_accurate(shape, data):
     taps = shape["k"] ** nd
     nbd = shape["nb"] * (shape["sp"][0] if nd == 3 else 1)
     assert L.query("arco_conv_split_ok", taps, nbd, shape["sp"][-2], shape["sp"][-1], shape["ci"], shape["co"], ld) == 1
-    y3, dx3 = _run(3, x, wt, gy)
-    y0, dx0 = _run(0, x, wt, gy)
+    y3, dx3, dw3 = _run(3, x, wt, gy)
+    y0, dx0, dw0 = _run(0, x, wt, gy)
+    # weight gradient (3x3 / 3x3x3: the split-bf16 kernel with pixel-major operands; 1x1: fp32 MFMA in both modes)
+    w64g = w64.clone().requires_grad_(True)
+    conv(x64.detach(), w64g, None, padding=shape["k"] // 2).backward(gy.double())
+    scale_dw = torch.autograd.grad(conv(x64.detach().abs(), w64g, None, padding=shape["k"] // 2), w64g, gy.double().abs())[0]
+    ew3 = float(((dw3 - w64g.grad).abs() / (scale_dw + 1e-30)).max())
+    ew0 = float(((dw0 - w64g.grad).abs() / (scale_dw + 1e-30)).max())
+    assert ew3 < 3e-6 and ew3 <= 1.5 * ew0 + 6e-8, (ew3, ew0)
     # error measured against the magnitude a term-by-term fp32 evaluation can resolve: sum |x||w| per output
     scale_y = conv(x64.detach().abs(), w64.abs(), None, padding=shape["k"] // 2)
     scale_dx = torch.autograd.grad(conv(x64, w64.abs(), None, padding=shape["k"] // 2), x64, gy.double().abs())[0]
