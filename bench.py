@@ -51,7 +51,8 @@ PMC_TRAFFIC_BYTES = {(9, 65536, 64, 64): 3.526e7, (9, 65536, 64, 128): 5.322e7,
                      (1, 1048576, 496, 496): 5.595e9, (1, 262144, 480, 480): 1.240e9}
 
 
-PMC_TRAFFIC_SPLIT = {}    # (taps, M, N, K) -> HBM bytes per launch of the split-bf16 kernels (profiles/r02_pmc_*.md)
+# (taps, M, N, K) -> HBM bytes per launch of the split-bf16 kernels (profiles/r02_pmc_conv_traffic.md)
+PMC_TRAFFIC_SPLIT = {(9, 65536, 64, 64): 3.591e7, (9, 65536, 64, 128): 5.446e7, (9, 32768, 64, 64): 1.905e7, (9, 32768, 64, 128): 2.920e7}
 
 
 def cpu_baseline_child():
@@ -118,7 +119,7 @@ def _kernel_name(key):
     return f"igemm_kernel<{key // 1000000},{key // 1000 % 1000},{key % 1000},...,MMA={mma}> ({MMA_NAMES[mma]} implicit GEMM)"
 
 
-def roofline_from_profile(prof, n_steps, step_ms, peak=PEAK_F32_MFMA_TFLOPS, mma="f32"):
+def roofline_from_profile(prof, n_steps, step_ms):
     """Roofline objects from ops.PROFILE of an eager pass over n_steps steps (every conv / weight-gradient launch
     counted, every PROFILE_EVERY-th bracketed by HIP events on the launch stream).
     dominant kernel = the 3x3 backbone instantiation with the largest total time (rocprofv3's top MFMA row for the same
@@ -194,10 +195,10 @@ def timed(run_steps, n):
 # sub-records: BASELINE.json configs[2..4] on ONE GPU, each in a child process (`bench.py --sub NAME`)
 # ---------------------------------------------------------------------------------------------------------------
 SUBS = {   # every entry: kind, batch_size, patch, classes, mma (+ in_chns for 2-D)
-    "config3d_la_vnet": dict(kind="3d", batch_size=2, patch=[112, 112, 80], classes=2, mma="f32",
+    "config3d_la_vnet": dict(kind="3d", batch_size=2, patch=[112, 112, 80], classes=2, mma="f32x3",
                              workload="LA 3D V-Net 112x112x80, --batch_size 2 (4 volumes/step), C=2, D=16, asmc "
                                       "(BASELINE.json configs[2])"),
-    "cityscapes_19c_512x1024": dict(kind="2d", batch_size=1, patch=[512, 1024], classes=19, in_chns=3, mma="f32",
+    "cityscapes_19c_512x1024": dict(kind="2d", batch_size=1, patch=[512, 1024], classes=19, in_chns=3, mma="f32x3",
                                     workload="Cityscapes-shaped 19-class 3x512x1024, 2 images/GPU (--batch_size 1), D=496, "
                                              "4096-key/class queue (the per-GPU shard of BASELINE.json configs[3])"),
     "lits_160x160x96_f16": dict(kind="3d", batch_size=1, patch=[160, 160, 96], classes=2, mma="f16",
@@ -226,7 +227,7 @@ def run_sub(name, steps):
     else:
         from arco_amd import train_arco_2d as T
         args = T.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1",
-                                            "--num_classes", str(cfg["classes"]), "--in_chns", str(cfg["in_chns"])])
+                                            "--num_classes", str(cfg["classes"]), "--in_chns", str(cfg["in_chns"]), "--conv_mma", cfg["mma"]])
         args.patch_size = cfg["patch"]
         st = T.ArcoStep2D(args, dev)
         l, ll = T.synthetic_batch(b, args.patch_size, cfg["classes"], 1, dev, in_chns=cfg["in_chns"])
@@ -239,13 +240,10 @@ def run_sub(name, steps):
     ms = timed(run_steps, steps)
     mem = torch.cuda.max_memory_allocated() / 1e9
     prof = eager_profile(st, run_steps, 2)
-    peak = PEAK_F32_MFMA_TFLOPS if cfg["mma"] == "f32" else PEAK_F16_MFMA_TFLOPS
-    roof, whole = roofline_from_profile(prof, 2, ms, peak=peak, mma=cfg["mma"])
-    if roof is not None and cfg["mma"] != "f32":
-        roof["kernel"] = roof["kernel"].replace("fp32 MFMA 16x16x4", "f16/bf16-operand MFMA 16x16x16, fp32 accumulate")
+    roof, whole = roofline_from_profile(prof, 2, ms)
     terms = {k: round(float(v), 5) for k, v in st.last_terms.items()}
     print(json.dumps({"sub": name, "workload": cfg["workload"], "ms_per_step": round(ms, 3), "steps_per_s": round(1e3 / ms, 3),
-                      "steps": steps, "dtype": "f32" if cfg["mma"] == "f32" else "f32 storage, f16/bf16 MFMA operands",
+                      "steps": steps, "dtype": {"f32": "f32", "f32x3": "f32 (split-bf16 matrix-core mode, fp32-accurate)"}.get(cfg["mma"], "f32 storage, f16/bf16 MFMA operands"),
                       "flags": "trainer defaults" + ("" if cfg["kind"] == "2d" else " (--eqv_pass 1)"),
                       "peak_mem_gb": round(mem, 2), "loss_terms": terms, "roofline": roof, "whole_step": whole}))
 
