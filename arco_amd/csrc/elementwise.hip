@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
 // gradient goes to the first maximum in window scan order (torch's saved argmax)
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ X, long ldx, int NB, int H, int W,
                                                           int C, const float* __restrict__ dY, long ldy,
-                                                          float* __restrict__ dX, long ldo) {
+                                                          float* __restrict__ dX, long ldo,
+                                                          const float* __restrict__ add, long lda) {
   const int q4 = C / 4, Ho = H / 2, Wo = W / 2;
   const long tot = (long)NB * Ho * Wo * q4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
@@ -386,6 +387,10 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
       for (int k = 1; k < 4; ++k) if (v[k][e] > bv) { bv = v[k][e]; best = k; }
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k][e] = k == best ? g[e] : 0.f;
+    }
+    if (add) {           // + the gradient of the other consumer of x (the decoder's skip connection): no separate add kernel
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] += *reinterpret_cast<const f32x4*>(add + off[k] * lda + c);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dX + off[k] * ldo + c) = o[k];
@@ -898,7 +903,15 @@ int arco_maxpool2_bwd(const float* X, long ldx, int NB, int H, int W, int C, con
                       long ldo, void* stream) {
   ARCO_CHECK_ARG((C & 3) == 0 && (H & 1) == 0 && (W & 1) == 0);
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid((long)NB * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
-                     as_stream(stream), X, ldx, NB, H, W, C, dY, ldy, dX, ldo);
+                     as_stream(stream), X, ldx, NB, H, W, C, dY, ldy, dX, ldo, (const float*)nullptr, 0l);
+  return arco_launch_status();
+}
+// dX = maxpool2_bwd(dY) + add  (add: the gradient x receives from its other consumer, e.g. the U-Net skip connection)
+int arco_maxpool2_bwd_add(const float* X, long ldx, int NB, int H, int W, int C, const float* dY, long ldy, const float* add,
+                          long ld_add, float* dX, long ldo, void* stream) {
+  ARCO_CHECK_ARG((C & 3) == 0 && (H & 1) == 0 && (W & 1) == 0 && add && (ld_add & 3) == 0);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid((long)NB * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     as_stream(stream), X, ldx, NB, H, W, C, dY, ldy, dX, ldo, add, ld_add);
   return arco_launch_status();
 }
 

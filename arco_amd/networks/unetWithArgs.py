@@ -63,6 +63,11 @@ class DownBlock(nn.Module):
     def forward(self, x):
         return self.maxpool_conv[1](ops.maxpool2(x))
 
+    def forward_skip(self, x):
+        """(block output, x as the decoder's skip connection): the two gradients of x are summed inside the max-pool backward."""
+        pooled, skip = ops.maxpool2_skip(x)
+        return self.maxpool_conv[1](pooled), skip
+
 
 class UpBlock(nn.Module):
     """Upsampling followed by ConvBlock (unetWithArgs.py:64-85).  The reference Decoder never
@@ -111,6 +116,12 @@ class Encoder(nn.Module):
     def forward(self, x):
         x = ops.to_channels_last(x.to(torch.float32))
         x0 = self.in_conv(x)
+        if torch.is_grad_enabled() and x0.requires_grad:       # training: skip gradients fused into the pooling backward
+            x1, x0 = self.down1.forward_skip(x0)
+            x2, x1 = self.down2.forward_skip(x1)
+            x3, x2 = self.down3.forward_skip(x2)
+            x4, x3 = self.down4.forward_skip(x3)
+            return [x0, x1, x2, x3, x4]
         x1 = self.down1(x0)
         x2 = self.down2(x1)
         x3 = self.down3(x2)

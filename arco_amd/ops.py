@@ -654,6 +654,35 @@ class MaxPool2Fn(torch.autograd.Function):
         return dx
 
 
+class MaxPoolSkipFn(torch.autograd.Function):
+    """(maxpool2(x), x) for an activation that feeds BOTH the next DownBlock and the decoder's skip concat
+    (unetWithArgs.py:109-116,142-158): the backward adds the two incoming gradients inside the max-pool backward kernel
+    instead of a separate full-tensor add (4 levels x every student pass)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xr, ld, nb, c, h, w = _geom(x)
+        y = new_act(nb, c, h // 2, w // 2, x.device)
+        L.call("arco_maxpool2_fwd", L.ptr(xr), ld, nb, h, w, c, L.ptr(y), c)
+        ctx.save_for_backward(x)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        (x,) = ctx.saved_tensors
+        xr, ld, nb, c, h, w = _geom(x)
+        if dy is None:
+            return dskip
+        dyr, ldy = rows_view(dy)
+        dx = new_act(nb, c, h, w, x.device)
+        if dskip is None:
+            L.call("arco_maxpool2_bwd", L.ptr(xr), ld, nb, h, w, c, L.ptr(dyr), ldy, L.ptr(dx), c)
+        else:
+            sr, lds = rows_view(dskip)
+            L.call("arco_maxpool2_bwd_add", L.ptr(xr), ld, nb, h, w, c, L.ptr(dyr), ldy, L.ptr(sr), lds, L.ptr(dx), c)
+        return dx
+
+
 class BilinearFn(torch.autograd.Function):
     """nn.Upsample(size, mode='bilinear', align_corners=True) (model_2D.py:43-52, unetWithArgs.py:74-75)."""
 
@@ -769,6 +798,16 @@ def trilinear(x, size):
 
 def maxpool2(x):
     return MaxPool2Fn.apply(x)
+
+
+def maxpool2_skip(x):
+    """(maxpool2(x), x-as-skip): use the returned alias as the skip connection so that both gradients of x meet inside one
+    kernel (MaxPoolSkipFn).  The concat room of x (conv_bn_act(cat_room=...)) travels with the alias."""
+    y, skip = MaxPoolSkipFn.apply(x)
+    buf = getattr(x, "_arco_cat_buf", None)
+    if buf is not None:
+        skip._arco_cat_buf = buf
+    return y, skip
 
 
 def bilinear(x, size):

@@ -160,6 +160,10 @@ int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
 int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, float* Y, long ldy, void* stream);
 int arco_maxpool2_bwd(const float* X, long ldx, int NB, int H, int W, int C, const float* dY, long ldy, float* dX,
                       long ldo, void* stream);
+/* ... fused with the gradient x receives from its second consumer (unetWithArgs.py:109-116,142-158: x_i feeds both the
+   next DownBlock and the decoder's skip concat): dX = maxpool2_bwd(dY) + add                                          */
+int arco_maxpool2_bwd_add(const float* X, long ldx, int NB, int H, int W, int C, const float* dY, long ldy, const float* add,
+                          long ld_add, float* dX, long ldo, void* stream);
 int arco_bilinear_fwd(const float* X, long ldx, int NB, int Hi, int Wi, int C, int Ho, int Wo, float* Y, long ldy,
                       void* stream);
 int arco_bilinear_bwd(const float* dY, long ldy, int NB, int Hi, int Wi, int C, int Ho, int Wo, float* dX, long ldx,
