@@ -61,8 +61,8 @@ def cpu_baseline_child():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_step
     torch.set_num_threads(min(64, os.cpu_count() or 1))
-    cpu_step.timed_sample(b=1, patch=(64, 64), k2=1.0)          # warm the thread pool / allocator
-    secs, threads = cpu_step.timed_sample(b=2, steps=3, k2=1.0)
+    cpu_step.timed_sample(b=1, patch=(64, 64), k2=1.0, bt=True)          # warm the thread pool / allocator
+    secs, threads = cpu_step.timed_sample(b=2, steps=3, k2=1.0, bt=True)
     print(json.dumps({"secs": secs, "threads": threads, "steps": 3}))
 
 
@@ -77,7 +77,7 @@ def cpu_baseline():
     # a 16-image step is 4x the 4-image sample (per-image work is constant)
     return {"value": round(1.0 / (4.0 * secs), 5), "unit": "steps/s (16-image steps)", "cores": threads, "kind": "port",
             "sample": f"{r.get('steps', 1)} chained full oracle steps at --batch_size 2 (4 images, 256x256, C=4, D=496, cutmix, "
-                      f"k2 = 1 equivariance term on, like the GPU headline), {secs:.1f} s per step on {threads} threads; "
+                      f"k2 = 1 equivariance term and batch_transform on, like the GPU headline), {secs:.1f} s per step on {threads} threads; "
                       "scaled x4 to the 16-image step"}
 
 

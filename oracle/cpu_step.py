@@ -133,7 +133,7 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
     return float(loss.detach()), float(reco.detach())
 
 
-def timed_sample(b=2, patch=(256, 256), n_cls=4, seed=1337, qsize=4096, steps=1, k2=0.0):
+def timed_sample(b=2, patch=(256, 256), n_cls=4, seed=1337, qsize=4096, steps=1, k2=0.0, bt=False):
     """`steps` chained full CPU steps at --batch_size b (fresh synthetic batches, the banks fill as they would in
     training, so the later steps run the real grid samplers); returns (mean seconds per step, threads)."""
     import fixture_inputs as fx
@@ -147,6 +147,7 @@ def timed_sample(b=2, patch=(256, 256), n_cls=4, seed=1337, qsize=4096, steps=1,
         u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
         lab = torch.from_numpy(fx.blob_labels(rs, b, patch, n_cls))
         t0 = time.time()
-        step(st, l, lab, u, bank, ptr, qs, n_cls, apply_aug='cutmix', k2=k2)      # the trainer's default --apply_aug; k2 = 1: the default equivariance term
+        vel = lambda B, h, w: torch.from_numpy(rs.uniform(-1, 1, size=(B, 2, h, w)).astype(np.float32))
+        step(st, l, lab, u, bank, ptr, qs, n_cls, apply_aug='cutmix', k2=k2, bt=bt, morph_velocity=vel)      # trainer defaults: cutmix, k2 = 1, batch_transform
         total += time.time() - t0
     return total / steps, torch.get_num_threads()
