@@ -257,25 +257,28 @@ __global__ __launch_bounds__(256) void weighted_row_sum_kernel(const float* __re
   }
 }
 // out[(c0+cc)*ldo + d] = (sum over slabs) * (totals ? 1/totals[c0+cc] : 1)
-__global__ void row_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nc, int D, int c0,
+__global__ __launch_bounds__(1024) void row_sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nc, int D, int c0,
                                         const int64_t* __restrict__ totals, float* __restrict__ out, long ldo) {
-  // block = 64 outputs x 4 slab segments (threadIdx.y), combined through LDS in a fixed order
+  // block = 64 outputs x 16 slab segments (threadIdx.y): segment y sums slabs y, y+16, ... (two chains in flight), the 16
+  // partial sums are combined through LDS in a fixed order (deterministic)
   const int i = blockIdx.x * 64 + threadIdx.x;
   const bool ok = i < nc * D;
   const int cc = ok ? i / D : 0, d = ok ? i % D : 0;
   double s0 = 0.0, s1 = 0.0;
   if (ok) {
     int b = threadIdx.y;
-    for (; b + 4 < nblk; b += 8) {
-      s0 += (double)partial[((long)b * nc + cc) * D + d]; s1 += (double)partial[((long)(b + 4) * nc + cc) * D + d];
+    for (; b + 16 < nblk; b += 32) {
+      s0 += (double)partial[((long)b * nc + cc) * D + d]; s1 += (double)partial[((long)(b + 16) * nc + cc) * D + d];
     }
-    for (; b < nblk; b += 4) s0 += (double)partial[((long)b * nc + cc) * D + d];
+    for (; b < nblk; b += 16) s0 += (double)partial[((long)b * nc + cc) * D + d];
   }
-  __shared__ double sh[4][64];
+  __shared__ double sh[16][64];
   sh[threadIdx.y][threadIdx.x] = s0 + s1;
   __syncthreads();
   if (threadIdx.y != 0 || !ok) return;
-  double s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  double s = 0.0;
+#pragma unroll
+  for (int y = 0; y < 16; y += 4) s += (sh[y][threadIdx.x] + sh[y + 1][threadIdx.x]) + (sh[y + 2][threadIdx.x] + sh[y + 3][threadIdx.x]);
   if (totals) s /= (double)totals[c0 + cc];
   out[(long)(c0 + cc) * ldo + d] = (float)s;
 }
@@ -437,27 +440,41 @@ __global__ __launch_bounds__(256) void normalize_rows_pad_kernel(const float* __
   for (int d = lane; d < Dp; d += 64) y[j * ldy + d] = d < D ? s[d] * iv : 0.f;
 }
 
-// Bn[e][j][0..Dp) (rows >= len and pad columns zero) and its transpose Bt[e][d][j] (nullable), j < Lp
+// Bn[e][j][0..Dp) (rows >= len and pad columns zero) and its transpose Bt[e][d][j] (nullable), j < Lp.
+// One block = 16 bank rows: each wave normalises 4 rows (coalesced row writes), the 16 x Dp tile goes through LDS so that the
+// transposed copy is written as 64-byte segments along j (it was one 4-byte store per element at stride Lp: 82 -> ~25 us).
 __global__ __launch_bounds__(256) void normalize_banks_kernel(NceTable t, int D, int Dp, long Lp, float eps,
                                                              float* __restrict__ Bn, float* __restrict__ Bt) {
-  const int lane = threadIdx.x & 63, e = blockIdx.y;
-  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= Lp) return;
-  float* y = Bn + ((long)e * Lp + j) * Dp;
-  float* yt = Bt ? Bt + (long)e * Dp * Lp + j : nullptr;
-  if (j >= t.len[e]) {
-    for (int d = lane; d < Dp; d += 64) { y[d] = 0.f; if (yt) yt[(long)d * Lp] = 0.f; }
-    return;
+  extern __shared__ float tile[];                    // [16][Dp + 1]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, e = blockIdx.y;
+  const long j0 = (long)blockIdx.x * 16;
+  const int LT = Dp + 1;
+  for (int r = 0; r < 4; ++r) {
+    const int jj = 4 * w + r;
+    const long j = j0 + jj;
+    if (j >= Lp) break;
+    float* y = Bn + ((long)e * Lp + j) * Dp;
+    if (j >= t.len[e]) {
+      for (int d = lane; d < Dp; d += 64) { y[d] = 0.f; tile[jj * LT + d] = 0.f; }
+      continue;
+    }
+    const float* s = t.bank[e] + j * (long)D;
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) { const float v = s[d]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float iv = 1.0f / fmaxf(sqrtf(ss), eps);
+    for (int d = lane; d < Dp; d += 64) {
+      const float v = d < D ? s[d] * iv : 0.f;
+      y[d] = v;
+      tile[jj * LT + d] = v;
+    }
   }
-  const float* s = t.bank[e] + j * (long)D;
-  float ss = 0.f;
-  for (int d = lane; d < D; d += 64) { const float v = s[d]; ss += v * v; }
-  ss = wave_sum(ss);
-  const float iv = 1.0f / fmaxf(sqrtf(ss), eps);
-  for (int d = lane; d < Dp; d += 64) {
-    const float v = d < D ? s[d] * iv : 0.f;
-    y[d] = v;
-    if (yt) yt[(long)d * Lp] = v;
+  if (!Bt) return;
+  __syncthreads();
+  float* bt = Bt + (long)e * Dp * Lp;
+  for (int idx = threadIdx.x; idx < Dp * 16; idx += 256) {
+    const int d = idx >> 4, jj = idx & 15;
+    if (j0 + jj < Lp) bt[(long)d * Lp + j0 + jj] = tile[jj * LT + d];
   }
 }
 
@@ -713,7 +730,7 @@ int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, l
       hipLaunchKernelGGL(weighted_row_sum_kernel<2>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
     else
       hipLaunchKernelGGL(weighted_row_sum_kernel<4>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
-    hipLaunchKernelGGL(row_sum_finalize_kernel, dim3((nc * D + 63) / 64), dim3(64, 4), 0, as_stream(stream), partial,
+    hipLaunchKernelGGL(row_sum_finalize_kernel, dim3((nc * D + 63) / 64), dim3(64, 16), 0, as_stream(stream), partial,
                        (int)grid, nc, D, c0, totals, out, ldo);
   }
   return arco_launch_status();
@@ -804,8 +821,8 @@ int arco_nce_normalize_banks(const void* const* banks, const int* lens, int E, i
   NceTable t;
   ARCO_CHECK_ARG(fill_table(t, banks, lens, nullptr, E) == ARCO_OK && D > 0 && Dp >= D && Lp > 0 && Bn);
   for (int e = 0; e < E; ++e) ARCO_CHECK_ARG(t.bank[e] && t.len[e] > 0 && t.len[e] <= Lp);
-  hipLaunchKernelGGL(normalize_banks_kernel, dim3((unsigned)((Lp + 3) / 4), (unsigned)E), dim3(256), 0, as_stream(stream), t, D, Dp,
-                     Lp, eps, Bn, Bt);
+  hipLaunchKernelGGL(normalize_banks_kernel, dim3((unsigned)((Lp + 15) / 16), (unsigned)E), dim3(256), (size_t)16 * (Dp + 1) * sizeof(float),
+                     as_stream(stream), t, D, Dp, Lp, eps, Bn, Bt);
   return arco_launch_status();
 }
 // S / W: [E][Q][ld]; An [E*Q][Dp]; Pn_all [*][Dp] (row prow[e] = the entry's positive); idx_all: int64 indices, the Q*Nn
