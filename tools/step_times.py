@@ -10,7 +10,7 @@ st = T.ArcoStep2D(args, "cuda:0")
 bs = [(T.synthetic_batch(8, args.patch_size, 4, 100 + 2 * i, "cuda:0"), T.synthetic_batch(8, args.patch_size, 4, 101 + 2 * i, "cuda:0")[0]) for i in range(4)]
 import gc
 if os.environ.get("NOGC"): gc.disable()
-N = 80
+N = int(os.environ.get("N", 80))
 if os.environ.get("SYNC"):
     ts = []
     for i in range(N):
