@@ -1,0 +1,399 @@
+// Software-pipelined split-bf16 3x3 convolution for the wide 2-D levels (ConvBlock, unetWithArgs.py:31-47; forward and,
+// with flipped+transposed packed weights, the data gradient) - the same arithmetic as igemm_kernel<9,...,MMA=3>
+// (igemm.hip: six v_mfma_f32_16x16x32_bf16 per fp32-accurate product, fp32 accumulate), restructured around what
+// bounded that kernel (profiles/README.md, round 2 ablation: its staging phases and its matrix phases did not overlap):
+//
+//   * ONE persistent workgroup per CU (4 waves, one per SIMD, the whole register file), walking its tiles in a
+//     flattened (tile, 16-channel chunk, tap-pair step) sequence, so the next tile's loads run under this tile's MFMAs
+//     and the output stores of a tile drain under the next one's.
+//   * a wave owns A_T x C_T MFMA tiles (64 pixels x 64 channels at 4 x 4): one A or B fragment read from LDS feeds
+//     four MFMA groups instead of two - LDS fragment traffic per MFMA drops by a third.
+//   * the pre-split weights never touch a register: global_load_lds_dwordx4 (LDS-DMA) fills a RING of five slots, one
+//     per tap-pair step; the slot a step has finished with is refilled with the next chunk's weights of that step while
+//     the following four steps compute.  Counted s_waitcnt vmcnt(N) + raw s_barrier keep the DMA in flight across the
+//     step barriers (a __syncthreads() would drain it).
+//   * the activation halo tile of the NEXT chunk is loaded to registers a chunk ahead, split into its three bf16 planes
+//     and written to the second A buffer in thirds at the head of steps 1-3, under the MFMAs of the current chunk.
+//   * the fragments of step s+1 (A of the next tap pair, the first B group of slot s+1) are read while step s is on the
+//     matrix cores: the barrier of step s certifies slots s AND s+1.
+//   * D = W . X^T orientation: a lane ends up with 4 consecutive output channels of one pixel -> 16-byte stores.
+//
+// LDS: [2][AROWS][24] A planes + [5][slot] B ring + [2][4][BN] statistics scratch + N bias floats
+//      (A_T = 4, C_T = 4: 62,208 + 61,440 + 2,048 + 1,024 bytes).
+// Shapes taken (conv_sp_dispatch): K % 16 == 0, N % 64 == 0, H % 16 == 0, W % 16 == 0, 16-byte aligned rows, and
+// enough tiles to give most CUs one; everything else stays on igemm_kernel.
+#include "igemm_args.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+__device__ __attribute__((aligned(64))) unsigned int conv_sp_zero_row[32];      // zero-initialised: the "tap 9" weights
+
+template <int A_T, int C_T>
+struct SpGeom {
+  static constexpr int TH = 4 * A_T, HR = TH + 2, AROWS = HR * 18, BN = C_T * 16;
+  static constexpr int A_DW = AROWS * 24;                       // dwords per A buffer
+  static constexpr int NBI = (2 * BN * 6 + 255) / 256;          // LDS-DMA instructions per thread and slot
+  static constexpr int SLOT_DW = NBI * 256 * 4;                 // slot stride in dwords (whole wave-instructions)
+  static constexpr int NA_IT = (AROWS * 4 + 255) / 256;         // 16-byte activation loads per thread and chunk
+  static constexpr int RED_DW = 2 * 4 * BN;
+  static constexpr int BIAS_DW = 256;
+  static constexpr size_t LDS_BYTES = (size_t)(2 * A_DW + 5 * SLOT_DW + RED_DW + BIAS_DW) * 4;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// lgkmcnt(0) through the builtin: hipcc models the instruction, so it knows the fragment registers read in the previous
+// step have landed (after an asm wait it re-waits lgkmcnt(0) in front of the first MFMA, behind 24 fresh reads)
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {      // v + (v of the lane the DPP control names)
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {    // sum over the 16 lanes of a DPP row, in every lane
+  v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);     // row_half_mirror
+  return dpp_add<0x140>(v);  // row_mirror
+}
+
+// The accumulators are pinned in AGPRs ("+a"): left to itself hipcc keeps them in VGPRs next to 150 fragment registers,
+// runs out, and shuttles every accumulator through a scratch AGPR quad around each MFMA chain (4 v_accvgpr_write + hazard
+// nops per chain).  The s_nop covers an operand a VALU instruction has just written (hipcc pads nothing inside asm).
+__device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& x, const bf16x8& y) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(x), "v"(y));
+}
+
+__device__ __forceinline__ void mfma_first(f32x4& c, const bf16x8& x, const bf16x8& y) {     // c = x . y (a tile's first product)
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(x), "v"(y));
+}
+
+template <int A_T, int C_T>
+__global__ __launch_bounds__(256) void conv3x3_sp_kernel(IgemmArgs a) {
+  using G = SpGeom<A_T, C_T>;
+  constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT, NB = G::NBI, NE = A_T * C_T;
+  constexpr int NA3 = (NA + 2) / 3;                              // activation pieces split + written per staging step
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned* const As = reinterpret_cast<unsigned*>(smem);
+  unsigned* const Bs = As + 2 * G::A_DW;
+  float* const red = reinterpret_cast<float*>(Bs + 5 * G::SLOT_DW);
+  float* const bias_s = red + G::RED_DW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int tiles_x = a.W >> 4, tiles_y = a.H / TH, tiles_img = tiles_x * tiles_y;
+  const int nchunks = a.K >> 4;
+  const int total_tiles = a.n_mblocks * a.n_nblocks;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total_gc = my_tiles * nchunks;
+  const bool has_stats = a.stat_sum != nullptr;
+
+  // chunk descriptors (tile ordinal j of this workgroup, 16-channel chunk c), advanced incrementally: the divisions of the
+  // tile decode run once per tile, not once per load
+  struct Desc { int j, c, img, y0, x0, nblk, mblk; };
+  auto decode = [&](Desc& d) {
+    const int v = (int)blockIdx.x + d.j * (int)gridDim.x;
+    d.mblk = v / a.n_nblocks; d.nblk = v - d.mblk * a.n_nblocks;
+    d.img = d.mblk / tiles_img;
+    const int r = d.mblk - d.img * tiles_img, ty = r / tiles_x;
+    d.y0 = ty * TH; d.x0 = (r - ty * tiles_x) * 16;
+  };
+  auto advance = [&](Desc& d) { if (++d.c == nchunks) { d.c = 0; ++d.j; decode(d); } };
+  Desc d0{0, 0, 0, 0, 0, 0, 0};
+  decode(d0);
+  Desc d1 = d0; advance(d1);
+  Desc d2 = d1; advance(d2);
+
+  // ---- per-thread staging geometry (constant over the launch)
+  const int qA = tid & 3;
+  int hyA[NA], hxA[NA], ldsA[NA], toff[NA];
+#pragma unroll
+  for (int it = 0; it < NA; ++it) {
+    const int row = (tid + it * 256) >> 2;
+    hyA[it] = row / 18; hxA[it] = row - hyA[it] * 18;
+    ldsA[it] = row < G::AROWS ? row * 24 + qA * 2 : -1;
+    toff[it] = (hyA[it] * a.W + hxA[it]) * (int)a.lda + qA * 4;
+  }
+  int woff[NB], wq[NB], wtap[NB];                 // weight piece of LDS-DMA instruction i: dword offset, piece of the row, local tap (2 = padding)
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int p = (i * 4 + wid) * 64 + lane;
+    const int tl_ = p / (BN * 6), rem = p - tl_ * (BN * 6), n = rem / 6, q6 = rem - n * 6;
+    wtap[i] = tl_ < 2 ? tl_ : 2;
+    woff[i] = tl_ < 2 ? ((tl_ * a.Npad + n) * a.Kg) * 24 + q6 * 4 : 0;
+    wq[i] = q6 * 4;
+  }
+  const long wslot2 = (long)2 * a.Npad * a.Kg * 24;          // two taps of packed weights (dwords)
+  const float* const zrow = reinterpret_cast<const float*>(conv_sp_zero_row);
+
+  // Activation loads of a chunk.  Every lane loads (clamped address, the mask zeroes at the split), and the loads are asm
+  // statements: hipcc, which drains the LDS-DMA queue (vmcnt(0)) at the use of any load it knows of, does not see them.
+  // They sit in the per-wave VMEM order right behind a refill, so the step-1 wait (at most 2 NB younger instructions
+  // in flight) certifies them; ra_fence() then orders every reader behind that wait.
+  f32x4 ra[NA]; unsigned okm = 0;
+  auto load_A = [&](const Desc& d) {
+    const long base = (((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16;
+    const float* pa[NA];
+    okm = 0;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int y = d.y0 + hyA[it] - 1, x = d.x0 + hxA[it] - 1;
+      const bool ok = ldsA[it] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      pa[it] = ok ? a.A + base + toff[it] : a.A;
+      okm |= ok ? (1u << it) : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(pa[it]) : "memory");
+  };
+  auto ra_fence = [&]() {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[it])::"memory");
+  };
+  // split of one fp32 element into its three bf16 terms (the per-element half of split3_bf16x4)
+  auto split_elem = [&](float x, unsigned short (&h)[3]) {
+    const __bf16 b0 = (__bf16)x; const float r1 = x - (float)b0;
+    const __bf16 b1 = (__bf16)r1; const float r2 = r1 - (float)b1;
+    const __bf16 b2 = (__bf16)r2;
+    h[0] = __builtin_bit_cast(unsigned short, b0); h[1] = __builtin_bit_cast(unsigned short, b1); h[2] = __builtin_bit_cast(unsigned short, b2);
+  };
+  auto write_A = [&](unsigned* buf, int it, const unsigned short (&h)[4][3]) {     // the three planes of piece `it`
+    if (ldsA[it] >= 0) {
+      unsigned* d = buf + ldsA[it];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<u32x2_ma*>(d + 8 * p) = u32x2{(unsigned)h[0][p] | ((unsigned)h[1][p] << 16), (unsigned)h[2][p] | ((unsigned)h[3][p] << 16)};
+    }
+  };
+  auto store_A = [&](unsigned* buf, int it) {      // split piece `it` into its three bf16 planes (zero outside the image)
+    const f32x4 v = ((okm >> it) & 1u) ? ra[it] : f32x4{0, 0, 0, 0};
+    unsigned short h[4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_elem(v[e], h[e]);
+    write_A(buf, it, h);
+  };
+  auto refill = [&](int slot, const Desc& d) {     // LDS-DMA: weights of step `slot` of chunk d -> ring slot
+    const float* base = a.Wp + slot * wslot2 + ((long)d.nblk * BN * a.Kg + d.c) * 24;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const bool zero = wtap[i] == 2 || (slot == 4 && wtap[i] == 1);
+      const float* src = zero ? zrow + wq[i] : base + woff[i];
+      unsigned* dst = Bs + slot * G::SLOT_DW + (i * 4 + wid) * 256;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addressing: lanes g = 0,1 take tap 2s, g = 2,3 tap 2s+1 (step 4: tap 8 and the zero tap)
+  const int tl = g >> 1;
+  int aoff[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + tl > 8 ? 8 : 2 * s + tl;
+    aoff[s] = ((tap / 3) * 18 + tap % 3) * 24;
+  }
+  const int laneA = (wid * A_T * 18 + li) * 24 + (g & 1) * 4;
+  const int laneB = (tl * BN + li) * 24 + (g & 1) * 4;
+  auto load_fa = [&](const unsigned* Ab, int s, bf16x8 (&fa)[A_T][3]) {
+#pragma unroll
+    for (int at = 0; at < A_T; ++at)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fa[at][pl] = lds_bf16x8(Ab + laneA + aoff[s] + at * 18 * 24 + 8 * pl);
+  };
+  auto load_fb = [&](int s, int ct, bf16x8 (&fb)[3]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) fb[pl] = lds_bf16x8(Bs + s * G::SLOT_DW + laneB + ct * 16 * 24 + 8 * pl);
+  };
+
+  f32x4 acc[A_T][C_T];       // AGPRs for the whole launch; a tile's first MFMA of every chain starts from the constant 0
+
+  // ---- prologue.  Per-wave VMEM order, the one the step waits count on: A0 | R0 R1 R2 | A1 | R3
+  for (int i = tid; i < G::BIAS_DW; i += 256) bias_s[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
+  load_A(d0);
+  refill(0, d0); refill(1, d0); refill(2, d0);
+  wait_vm<3 * NB>();                  // chunk 0's activations (the DMA behind them stays in flight)
+  ra_fence();
+#pragma unroll
+  for (int it = 0; it < NA; ++it) store_A(As, it);
+  if (total_gc > 1) load_A(d1);
+  refill(3, d0);
+  wait_vm<NA + 2 * NB>();             // slots 0 and 1 landed (own DMA); the barrier makes it everyone's
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+  bf16x8 fa[A_T][3], fb0[3];
+  load_fa(As, 0, fa);
+  load_fb(0, 0, fb0);
+
+  for (int gc = 0; gc < total_gc; ++gc) {
+    const bool more = gc + 1 < total_gc;          // a next chunk exists (its A buffer and slots are being filled)
+    const bool tail = gc + 2 >= total_gc;         // the steady-state instruction counts no longer hold: drain instead
+    const bool post = gc > 0 && d0.c == 0;        // first chunk behind a tile's output stores (they count in vmcnt)
+    const unsigned* Acur = As + (gc & 1) * G::A_DW;
+    unsigned* Anxt = As + ((gc + 1) & 1) * G::A_DW;
+
+    auto step = [&](auto S_, auto F_) {
+      constexpr int S = decltype(S_)::value;
+      constexpr bool FIRST = decltype(F_)::value;
+      // VMEM instructions younger than what this barrier (and, at step 1, the activation split) needs; order per chunk:
+      // s0 R4 | s1 R0' | s2 R1' | s3 R2' A' | s4 R3'
+      constexpr int NS = (S == 0 || S == 4) ? NA + 2 * NB : 2 * NB;
+      constexpr int NP = S <= 2 ? NE : 0;          // + a tile's output (and 2 statistics) stores in front of steps 0-2
+      if (tail) wait_vm<0>();
+      else if (!post || NP == 0) wait_vm<NS>();
+      else if (has_stats) wait_vm<NS + NP + 2>();
+      else wait_vm<NS + NP>();
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
+      if (S == 0) refill(4, d0);                   // the slot the previous step has finished with
+      else if (more) refill(S - 1, d1);
+      if (S == 1) ra_fence();
+      // this step's remaining B groups, then the next step's fragments, all issued ahead of the MFMAs
+      bf16x8 fbs[C_T > 1 ? C_T - 1 : 1][3];
+#pragma unroll
+      for (int ct = 1; ct < C_T; ++ct) load_fb(S, ct, fbs[ct - 1]);
+      __builtin_amdgcn_sched_barrier(0);           // (LDS returns in order: what this step needs comes back first)
+      bf16x8 fan[A_T][3], fbn[3];
+      load_fa(S < 4 ? Acur : Anxt, (S + 1) % 5, fan);      // (last chunk, step 4: read and never used)
+      load_fb((S + 1) % 5, 0, fbn);
+      // left to itself the scheduler sinks every fragment read to just above its first use (register pressure), exposing
+      // the LDS latency 24 times per step: nothing crosses this line, the reads stay in front of the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      // staging in the shadow of the matrix pipe (steps 1-3): PPC activation pieces of the next chunk per MFMA group, one
+      // element split behind every 6-MFMA chain (the asm MFMAs keep their order, so the VALU work is interleaved by hand;
+      // with no next chunk the writes land in the idle buffer)
+      constexpr int PPC = (NA3 + C_T - 1) / C_T;
+      static_assert(A_T >= 4 * PPC, "one element split per MFMA chain");
+#pragma unroll
+      for (int ct = 0; ct < C_T; ++ct) {
+        unsigned short hh[PPC][4][3];
+        f32x4 pv[PPC];
+#pragma unroll
+        for (int p = 0; p < PPC; ++p) {
+          const int it = (S - 1) * NA3 + ct * PPC + p;
+          const bool on = S >= 1 && S <= 3 && ct * PPC + p < NA3 && it < NA;
+          pv[p] = (on && ((okm >> (on ? it : 0)) & 1u)) ? ra[on ? it : 0] : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int at = 0; at < A_T; ++at) {          // D = W . X^T; small terms first
+          const bf16x8 b0 = ct == 0 ? fb0[0] : fbs[ct > 0 ? ct - 1 : 0][0];
+          const bf16x8 b1 = ct == 0 ? fb0[1] : fbs[ct > 0 ? ct - 1 : 0][1];
+          const bf16x8 b2 = ct == 0 ? fb0[2] : fbs[ct > 0 ? ct - 1 : 0][2];
+          if (FIRST) mfma_first(acc[at][ct], b0, fa[at][2]);
+          else mfma_acc(acc[at][ct], b0, fa[at][2]);
+          mfma_acc(acc[at][ct], b2, fa[at][0]);
+          mfma_acc(acc[at][ct], b1, fa[at][1]);
+          mfma_acc(acc[at][ct], b0, fa[at][1]);
+          mfma_acc(acc[at][ct], b1, fa[at][0]);
+          mfma_acc(acc[at][ct], b0, fa[at][0]);
+          if (S >= 1 && S <= 3 && at < 4 * PPC) {
+            split_elem(pv[at / 4][at % 4], hh[at / 4][at % 4]);
+            __builtin_amdgcn_sched_barrier(0);       // (or the scheduler sinks the split into one block behind the group)
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PPC; ++p) {
+          const int it = (S - 1) * NA3 + ct * PPC + p;
+          if (S >= 1 && S <= 3 && ct * PPC + p < NA3 && it < NA) write_A(Anxt, it, hh[p]);
+        }
+      }
+      if (S == 3 && !tail) load_A(d2);
+#pragma unroll
+      for (int at = 0; at < A_T; ++at)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fa[at][pl] = fan[at][pl];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fb0[pl] = fbn[pl];
+    };
+    if (d0.c == 0) step(std::integral_constant<int, 0>{}, std::true_type{});
+    else step(std::integral_constant<int, 0>{}, std::false_type{});
+    step(std::integral_constant<int, 1>{}, std::false_type{});
+    step(std::integral_constant<int, 2>{}, std::false_type{});
+    step(std::integral_constant<int, 3>{}, std::false_type{});
+    step(std::integral_constant<int, 4>{}, std::false_type{});
+
+    if (d0.c + 1 == nchunks) {         // ---- tile done: bias, store, BN partial statistics; accumulators back to zero
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results (asm: no hazard padding by hipcc)
+      const int n0 = d0.nblk * BN;
+      float s1[C_T][4], s2[C_T][4];
+#pragma unroll
+      for (int ct = 0; ct < C_T; ++ct) {
+        const int n = n0 + ct * 16 + 4 * g;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; }
+#pragma unroll
+        for (int at = 0; at < A_T; ++at) {
+          const long pix = ((long)d0.img * a.H + d0.y0 + wid * A_T + at) * a.W + d0.x0 + li;
+          f32x4 v = acc[at][ct] + bv;
+          if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + pix * a.ldr + n);
+          *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + n) = v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[ct][r] += v[r]; s2[ct][r] += v[r] * v[r]; }
+        }
+      }
+      if (has_stats) {
+#pragma unroll
+        for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v1 = row16_sum(s1[ct][r]), v2 = row16_sum(s2[ct][r]);
+            if (li == 0) {
+              red[(0 * 4 + wid) * BN + ct * 16 + 4 * g + r] = v1;
+              red[(1 * 4 + wid) * BN + ct * 16 + 4 * g + r] = v2;
+            }
+          }
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+        // every wave issues the two stores (waves beyond BN / 16 repeat an earlier wave's channels: same values, same
+        // addresses) so that the per-wave VMEM instruction count the step waits rely on is uniform
+        const int nl = (wid * 16 + li) % BN;
+        if (g == 0) {
+          float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { v1 += red[(0 * 4 + w) * BN + nl]; v2 += red[(1 * 4 + w) * BN + nl]; }
+          a.stat_sum[(long)(n0 + nl) * a.n_mblocks + d0.mblk] = v1;
+          a.stat_sq[(long)(n0 + nl) * a.n_mblocks + d0.mblk] = v2;
+        }
+      }
+    }
+    d0 = d1; d1 = d2; advance(d2);
+  }
+}
+
+static int conv_sp_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int A_T, int C_T>
+static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
+  using G = SpGeom<A_T, C_T>;
+  const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
+  if (q) { q[0] = mblocks; q[1] = 9800000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
+  if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
+  auto kern = conv3x3_sp_kernel<A_T, C_T>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
+  IgemmArgs b = a;
+  b.n_mblocks = mblocks; b.n_nblocks = a.Npad / G::BN;
+  const int total = mblocks * b.n_nblocks, cus = conv_sp_cus();
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(256), G::LDS_BYTES, st, b);
+  return arco_launch_status();
+}
+
+// A/B knob: ARCO_CONV_SP=0 / arco_conv_sp_set(0) keeps every shape on igemm_kernel
+static int& conv_sp_flag() { static int on = !(getenv("ARCO_CONV_SP") && atoi(getenv("ARCO_CONV_SP")) == 0); return on; }
+static bool conv_sp_on() { return conv_sp_flag() != 0; }
+extern "C" int arco_conv_sp_set(int on) { const int prev = conv_sp_flag(); conv_sp_flag() = on ? 1 : 0; return prev; }
+
+int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
+  if (!conv_sp_on() || a.mma != 3 || a.D3 != 1) return -1;
+  if ((a.K & 15) != 0 || a.K < 16 || (a.N & 63) != 0 || a.N != a.Npad || a.N > 256 || (a.lda & 3) != 0 || (a.W & 15) != 0 || (a.H & 15) != 0) return -1;
+  // 64-channel output blocks only: with 32 (C_T = 2) a step has 48 MFMAs per wave against the same per-step issue costs
+  // (LDS-DMA, 18 fragment reads, barrier) and measures 10-25 % slower than igemm_kernel<9,128,32> (tools/micro/conv_sp_check.py)
+  const long tiles = (long)a.NB * (a.H / 16) * (a.W / 16);
+  if (tiles * (a.N / 64) < 192) return -1;
+  return launch_sp<4, 4>(a, st, q);
+}

@@ -11,26 +11,9 @@
 // weight slab of every tap are staged in LDS with rows padded to KC+4 floats, so the
 // ds_read_b128 fragment reads (4 consecutive k per lane) are bank-conflict free.
 // A b128 fragment feeds 4 MFMAs: lane (i, g) holds k = 4g+j for j = 0..3.
-#include "common.h"
+#include "igemm_args.h"
 #include <stdlib.h>
 
-struct IgemmArgs {
-  const float* A; long lda;
-  const float* Wp; int Npad, Kpad, N, K;
-  float* C; long ldc;
-  const float* bias;
-  const float* R; long ldr;
-  float* stat_sum; float* stat_sq;   // [N][n_mblocks] block partials (nullable)
-  int n_mblocks; int n_nblocks;
-  int NB, H, W;                      // images (planes for 3-D), rows, cols (TAPS==9); TAPS==1 uses M only
-  int D3;                            // 3-D: planes per volume (depth taps active when DEPTH==3); 2-D: 1
-  long M;                            // total pixels
-  int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
-  int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
-  int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3, 1x1x1)
-  int Kg;                            // mma == 3: 16-k groups per packed weight row (= ceil32(K) / 16)
-  int batch; long batchA, batchW, batchC;   // TAPS==1 batched GEMM: blockIdx.z = problem, operands at + z * stride (floats)
-};
 
 // FLAT (3x3 only): the M-tile is BM consecutive positions of the plane stored with a padded row stride Wp = W + 2
 // (one halo column each side) instead of a TH x 16 pixel rectangle.  A tap is then a uniform shift dy*Wp + dx of the
@@ -52,40 +35,6 @@ constexpr int IGEMM_FLAT_WPMAX = 64;
 // ds_read_b128 fragment reads are bank-conflict free without padding).  3x3: KC = 16, a K = 32 MFMA step covers the 16
 // channels of TWO taps (lanes g = 0,1 read tap 2s, g = 2,3 tap 2s+1; the 10th half-step multiplies a zero weight row);
 // 1x1: KC = 32.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// LDS words are written as packed bf16 pairs and read back as MFMA operands: every such type-punned access goes through a
-// may_alias type (without it the compiler may assume that the loads cannot see the stores - observed: a B fragment built
-// from one repeated dword)
-typedef unsigned int u32x2_ma __attribute__((ext_vector_type(2), may_alias));
-typedef unsigned int u32x4_ma __attribute__((ext_vector_type(4), may_alias));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 lds_bf16x8(const void* p) { return __builtin_bit_cast(bf16x8, u32x4(*reinterpret_cast<const u32x4_ma*>(p))); }
-__device__ __forceinline__ void split3_bf16x4(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
-  unsigned short h[3][4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 b0 = (__bf16)v[e];
-    const float r1 = v[e] - (float)b0;
-    const __bf16 b1 = (__bf16)r1;
-    const float r2 = r1 - (float)b1;
-    const __bf16 b2 = (__bf16)r2;
-    h[0][e] = __builtin_bit_cast(unsigned short, b0); h[1][e] = __builtin_bit_cast(unsigned short, b1);
-    h[2][e] = __builtin_bit_cast(unsigned short, b2);
-  }
-  p0 = u32x2{(unsigned)h[0][0] | ((unsigned)h[0][1] << 16), (unsigned)h[0][2] | ((unsigned)h[0][3] << 16)};
-  p1 = u32x2{(unsigned)h[1][0] | ((unsigned)h[1][1] << 16), (unsigned)h[1][2] | ((unsigned)h[1][3] << 16)};
-  p2 = u32x2{(unsigned)h[2][0] | ((unsigned)h[2][1] << 16), (unsigned)h[2][2] | ((unsigned)h[2][3] << 16)};
-}
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f16x4 to_f16x4(f32x4 v) { return __builtin_convertvector(v, f16x4); }
-__device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
-  s16x4 r;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { const __bf16 b = (__bf16)v[e]; r[e] = __builtin_bit_cast(short, b); }
-  return r;
-}
 template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, bool VEC, int DEPTH, bool FLAT = false, int MMA = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int TH = BM / 16;
@@ -909,6 +858,10 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
   if (taps == 9 && image_conv3d_eligible(a)) return launch_image_conv3d<1>(a, st, nmb);     // one-channel image
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
   if (taps == 9 && image_conv_eligible(a)) return launch_image_conv(a, st, nmb);
+  if (taps == 9 && a.mma == 3) {     // wide 2-D levels: the software-pipelined kernel of conv_sp.hip
+    const int r = conv_sp_dispatch(a, st, nmb);
+    if (r != -1) return r;
+  }
   // split-bf16 launches (the caller asked arco_conv_split_ok) never take the fp32-only halo kernel
   if (taps == 9) return (a.mma != 3 && halo_eligible(a)) ? dispatch_halo(a, st, nmb) : dispatch_spatial<1>(a, st, nmb);
   return ARCO_ERR_UNSUPPORTED;

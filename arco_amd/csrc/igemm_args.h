@@ -1,0 +1,62 @@
+// Argument block and split-bf16 helpers shared by the implicit-GEMM kernels (igemm.hip) and the pipelined 3x3 kernel
+// (conv_sp.hip).
+#pragma once
+#include "common.h"
+
+struct IgemmArgs {
+  const float* A; long lda;
+  const float* Wp; int Npad, Kpad, N, K;
+  float* C; long ldc;
+  const float* bias;
+  const float* R; long ldr;
+  float* stat_sum; float* stat_sq;   // [N][n_mblocks] block partials (nullable)
+  int n_mblocks; int n_nblocks;
+  int NB, H, W;                      // images (planes for 3-D), rows, cols (TAPS==9); TAPS==1 uses M only
+  int D3;                            // 3-D: planes per volume (depth taps active when DEPTH==3); 2-D: 1
+  long M;                            // total pixels
+  int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
+  int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
+  int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3, 1x1x1)
+  int Kg;                            // mma == 3: 16-k groups per packed weight row (= ceil32(K) / 16)
+  int batch; long batchA, batchW, batchC;   // TAPS==1 batched GEMM: blockIdx.z = problem, operands at + z * stride (floats)
+};
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// LDS words are written as packed bf16 pairs and read back as MFMA operands: every such type-punned access goes through a
+// may_alias type (without it the compiler may assume that the loads cannot see the stores - observed: a B fragment built
+// from one repeated dword)
+typedef unsigned int u32x2_ma __attribute__((ext_vector_type(2), may_alias));
+typedef unsigned int u32x4_ma __attribute__((ext_vector_type(4), may_alias));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_bf16x8(const void* p) { return __builtin_bit_cast(bf16x8, u32x4(*reinterpret_cast<const u32x4_ma*>(p))); }
+__device__ __forceinline__ void split3_bf16x4(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+  unsigned short h[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 b0 = (__bf16)v[e];
+    const float r1 = v[e] - (float)b0;
+    const __bf16 b1 = (__bf16)r1;
+    const float r2 = r1 - (float)b1;
+    const __bf16 b2 = (__bf16)r2;
+    h[0][e] = __builtin_bit_cast(unsigned short, b0); h[1][e] = __builtin_bit_cast(unsigned short, b1);
+    h[2][e] = __builtin_bit_cast(unsigned short, b2);
+  }
+  p0 = u32x2{(unsigned)h[0][0] | ((unsigned)h[0][1] << 16), (unsigned)h[0][2] | ((unsigned)h[0][3] << 16)};
+  p1 = u32x2{(unsigned)h[1][0] | ((unsigned)h[1][1] << 16), (unsigned)h[1][2] | ((unsigned)h[1][3] << 16)};
+  p2 = u32x2{(unsigned)h[2][0] | ((unsigned)h[2][1] << 16), (unsigned)h[2][2] | ((unsigned)h[2][3] << 16)};
+}
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 to_f16x4(f32x4 v) { return __builtin_convertvector(v, f16x4); }
+__device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
+  s16x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const __bf16 b = (__bf16)v[e]; r[e] = __builtin_bit_cast(short, b); }
+  return r;
+}
+
+// conv_sp.hip: the software-pipelined split-bf16 3x3 kernel.  Returns -1 when the shape is not one it takes (the caller
+// then falls through to igemm_kernel), otherwise the launch status; q != nullptr: query only (q[0] = M-tiles = BN stat
+// slabs per channel, q[1] = instantiation id, q[2] = KC*100 + DEPTH*10).
+int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q);

@@ -111,6 +111,10 @@ int arco_conv_mblocks_mma(int taps, int NB, int H, int W, int Cin, int Cout, lon
  * conv3x3_halo_kernel<CIN,COUT,..> -> 9.9e6 + CIN*1e3 + COUT */
 int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int* kc_depth_db);
 int arco_conv_config_mma(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int mma);
+/* A/B switch of the software-pipelined split-bf16 3x3 kernel (conv_sp.hip; ids 9.8e6 + A_T*1e3 + BN): on = 1 (default,
+ * or ARCO_CONV_SP=0 in the environment for off) lets the eligible wide 2-D shapes take it, 0 keeps every shape on
+ * igemm_kernel.  Returns the previous setting.  Tile counts differ: query arco_conv_mblocks_mma after switching.   */
+int arco_conv_sp_set(int on);
 /* out = conv(in) (+bias)(+residual); optional per-channel (sum, sumsq) block partials for train-mode BN. */
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,

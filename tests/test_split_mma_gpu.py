@@ -89,3 +89,38 @@ def test_split_weights_pack_is_an_exact_decomposition():
     exp = torch.zeros((taps, npad, kp32), dtype=torch.float64)
     exp[:, :co, :ci] = w.cpu().double().reshape(co, ci, taps).permute(2, 0, 1)
     assert torch.equal(rec, exp)
+
+
+@pytest.mark.parametrize("shape", [dict(nb=16, ci=64, co=64, s=64), dict(nb=12, ci=32, co=128, s=64), dict(nb=3, ci=16, co=64, s=128),
+                                   dict(nb=17, ci=128, co=64, s=64)])
+def test_pipelined_3x3_kernel_equals_igemm_kernel(shape):
+    """conv_sp.hip (persistent workgroups, LDS-DMA weight ring, software-pipelined fragment reads) computes the same
+    products in the same order as igemm_kernel<9,..,MMA=3>: outputs bit-identical, BN partial sums equal to fp32
+    rounding of a different slab partition, both within fp32 rounding of an fp64 convolution.  Several tiles per
+    workgroup (nb=17: 272 > 256 tiles, ragged), one chunk (K = 16) and two N-blocks (N = 128) are covered."""
+    from arco_amd import _lib as L, ops
+    nb, ci, co, s = shape["nb"], shape["ci"], shape["co"], shape["s"]
+    g = torch.Generator().manual_seed(ci * 1000 + co)
+    x = _cl(torch.randn(nb, ci, s, s, generator=g))
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
+    bias = torch.randn(co, generator=g).cuda()
+    wp = ops.pack_weight(wt, 9, 0)
+    xr, ldx = ops.rows_view(x)
+    res = {}
+    prev = L.load().arco_conv_sp_set(1)
+    try:
+        for on in (0, 1):
+            L.load().arco_conv_sp_set(on)
+            cfg = L.query("arco_conv_config_mma", 9, nb, s, s, ci, co, ldx, 3)
+            assert (9800000 <= cfg < 9900000) == bool(on), cfg
+            out, (ssum, ssq, nmb) = ops.conv_raw(xr, ldx, ci, wp, co, nb, s, s, 9, bias=bias, stats=True)
+            assert ssum.shape == (co, nmb)
+            res[on] = (out.clone(), ssum.double().sum(1), ssq.double().sum(1))
+    finally:
+        L.load().arco_conv_sp_set(prev)
+    assert torch.equal(res[0][0], res[1][0])
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    assert float((res[1][0].double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    for k in (1, 2):
+        assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[1][1], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
