@@ -90,6 +90,7 @@ _SIGS = {
     "arco_unsup_loss_fwd": [_P, _L, _I, _L, _I, _P, _P, _F, _P, _P, _P],
     "arco_unsup_loss_bwd": [_P, _L, _I, _L, _I, _P, _P, _P, _P, _L, _P],
     "arco_sgd_nesterov": [_P, _P, _P, _L, _F, _F, _F, _I, _P],
+    "arco_sgd_momentum": [_P, _P, _P, _L, _F, _F, _F, _I, _P],
     "arco_ema": [_P, _P, _L, _F, _P],
 }
 _QUERIES = {   # plain host helpers returning sizes

@@ -796,9 +796,9 @@ __global__ __launch_bounds__(256) void sgd_nesterov_kernel(float* __restrict__ p
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float pv = p[i];
     const float gv = g[i] + wd * pv;
-    const float b = first ? gv : mom * buf[i] + gv;
+    const float b = (first & 1) ? gv : mom * buf[i] + gv;
     buf[i] = b;
-    p[i] = pv - lr * (gv + mom * b);
+    p[i] = pv - lr * ((first & 2) ? b : gv + mom * b);       // bit 1: plain momentum (torch.optim.SGD, nesterov=False)
   }
 }
 // k = k*m + q*(1-m)
@@ -1027,6 +1027,13 @@ int arco_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, fl
                       int first, void* stream) {
   hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), p, g, buf, n, lr, momentum,
                      weight_decay, first);
+  return arco_launch_status();
+}
+// torch.optim.SGD(momentum, weight_decay, nesterov=False): the stage-1 trainers' optimizer (pretrain_2D.py:193-195)
+int arco_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                      int first, void* stream) {
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), p, g, buf, n, lr, momentum,
+                     weight_decay, (first ? 1 : 0) | 2);
   return arco_launch_status();
 }
 int arco_ema(float* k, const float* q, long n, float m, void* stream) {

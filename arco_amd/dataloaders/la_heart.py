@@ -70,3 +70,47 @@ class ToTensor(object):
         if 'onehot_label' in sample:
             out['onehot_label'] = torch.from_numpy(sample['onehot_label']).long()
         return out
+
+
+class RandomColorJitter(object):
+    """code/dataloaders/la_heart.py:254-273: with probability p every X-Y slice image[j, :, :, :, t] of every volume goes
+    through torchvision's tensor-mode ColorJitter (one channel: brightness / contrast blends), in place - one set of
+    generator draws per slice."""
+
+    def __init__(self, color=(0.04, 0.04, 0.04, 0.01), p=0.1):
+        self.color, self.p = color, p
+
+    def __call__(self, sample):
+        import numpy as np
+        from .dataset_withAug import _jitter_params, jitter_gray_
+        if np.random.uniform(low=0, high=1, size=1) > self.p:
+            return sample
+        image, label = sample['image'], sample['label']
+        for j in range(image.shape[0]):
+            for t in range(image.shape[-1]):
+                order, fac = _jitter_params(self.color)
+                jitter_gray_(image[j, :, :, :, t], order, fac)
+        return {'image': image, 'label': label}
+
+
+class RandomNoise(object):
+    """code/dataloaders/la_heart.py:276-294: with probability p every X-Y slice is blurred as an 8-bit PIL image, in
+    place, and - as in the reference, which drops ToTensor's /255 here - stored back as the BYTE values 0..255."""
+
+    def __init__(self, p=0.5):
+        self.p = p
+
+    def __call__(self, sample):
+        import random
+        import numpy as np
+        import torch
+        from .. import augment
+        if np.random.uniform(low=0, high=1, size=1) > self.p:
+            return sample
+        image, label = sample['image'], sample['label']
+        sigma = random.uniform(0.15, 1.15)
+        for i in range(image.shape[0]):
+            sl = image[i, 0].permute(2, 0, 1).unsqueeze(1).float().contiguous()          # [Z, 1, X, Y]
+            out = augment.jitter_blur(sl, [dict(order=None, factors=None, sigma=sigma)] * int(sl.shape[0]))
+            image[i, 0] = torch.round(out[:, 0] * 255.0).permute(1, 2, 0).to(image.dtype)
+        return {'image': image, 'label': label}

@@ -4,14 +4,15 @@ create_model (:57-64), ISD (:115-198).  Same names, constructor arguments, attri
 
 FeatureExtractor is five bias-free 1x1 convolutions = fp32 MFMA GEMMs over channels-last
 pixels with the residual add fused in the GEMM epilogue, chained by align_corners bilinear
-resizes.  The MoCo-style heads ISD owns (latent/outputs heads, predictors, queues) are only
-used by stage-1 pre-training; they are kept as parameter containers because
-_momentum_update_key_encoder (model_2D.py:176-182) EMA-updates them every step.
+resizes.  The MoCo-style heads ISD owns (latent/outputs heads, predictors, queues) are used by
+stage-1 pre-training only (ISD.forward, arco_amd/pretrain_2D.py): a few 4- and 256-wide layers
+on pooled maps, run as plain tensor ops around the two HIP U-Nets; _momentum_update_key_encoder
+(model_2D.py:176-182) EMA-updates them every step in both stages.
 """
 import torch
 import torch.nn as nn
 
-from . import ops, optim
+from . import ops, optim, stage1
 from .networks.net_factory_args import net_factory
 
 
@@ -148,8 +149,19 @@ class ISD(nn.Module):
     def _unwrap(m):
         return m.module if hasattr(m, "module") else m
 
+    def forward(self, im_q, im_k=None, Ts=None, Tt=None):
+        """Stage-1 forward (model_2D.py:215-305), see arco_amd.stage1.isd_forward; eval mode: (outputs, latent)."""
+        return stage1.isd_forward(self, im_q, im_k, Ts, Tt)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys, queue, queue_ptr):
+        stage1.dequeue_and_enqueue(self.K, keys, queue, queue_ptr)
+
     @torch.no_grad()
     def data_parallel(self):
         """The reference wraps sub-modules in nn.DataParallel (model_2D.py:188-198).  On MI355X
         scaling is one process per GPU over RCCL (arco_amd.dist); inside one process this is a no-op."""
         return self
+
+
+from .stage1 import get_shuffle_ids, compute_logits   # noqa: E402,F401  (module-level names of the reference's model_2D.py)

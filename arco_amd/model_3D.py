@@ -123,3 +123,13 @@ class ISD_3d(nn.Module):
     def data_parallel(self):
         """nn.DataParallel wrapping of the reference (model_3D.py:284-292) is replaced by one process per GPU."""
         return self
+
+    def forward(self, im_q, im_k=None, Ts=None, Tt=None):
+        """Stage-1 forward (model_3D.py:309-403), see arco_amd.stage1.isd_forward; eval mode: (outputs, latent)."""
+        from . import stage1
+        return stage1.isd_forward(self, im_q, im_k, Ts, Tt)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys, queue, queue_ptr):
+        from . import stage1
+        stage1.dequeue_and_enqueue(self.K, keys, queue, queue_ptr)

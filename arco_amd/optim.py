@@ -45,17 +45,24 @@ class EmaPair:
         tp = list(teacher.parameters()) if hasattr(teacher, "parameters") else list(teacher)
         assert len(sp) == len(tp)
         self.sp, self.tp = sp, tp
-        self.flat_t = flatten_params(tp)
+        # the teacher may already live in an optimiser's flat buffer (stage 1: the key heads are trained too)
+        self.flat_t = self._flat_of(tp)
+        if self.flat_t is None:
+            self.flat_t = flatten_params(tp)
         self.flat_s = None
 
     def _student_flat(self):
-        # the student may already live in an optimiser's flat buffer (contiguous views in order)
-        first = self.sp[0]
-        n = sum(p.numel() for p in self.sp)
+        return self._flat_of(self.sp)
+
+    @staticmethod
+    def _flat_of(params):
+        # contiguous views, in order, of ONE storage -> that stretch as a flat tensor; else None
+        first = params[0]
+        n = sum(p.numel() for p in params)
         base = first.data.untyped_storage()
         contiguous = True
         off = first.data.storage_offset()
-        for p in self.sp:
+        for p in params:
             if p.data.untyped_storage().data_ptr() != base.data_ptr() or p.data.storage_offset() != off \
                     or not p.data.is_contiguous():
                 contiguous = False
@@ -70,6 +77,10 @@ class EmaPair:
         s = self._student_flat()
         if s is None:
             s = torch.cat([p.data.reshape(-1) for p in self.sp])
+        t = self._flat_of(self.tp)          # (an optimiser built after this pair may have re-homed the teacher)
+        if t is None:
+            t = flatten_params(self.tp)
+        self.flat_t = t
         L.call("arco_ema", L.ptr(self.flat_t), L.ptr(s), self.flat_t.numel(), float(m))
         self._weights_changed()
 
@@ -84,7 +95,8 @@ class SGDNesterov:
     is honoured like the reference's poly-LR loop (train_arco_2d.py:433-435)."""
 
     def __init__(self, params, lr, momentum=0.9, weight_decay=0.0001, nesterov=True):
-        assert nesterov and momentum > 0
+        assert momentum > 0
+        self._kernel = "arco_sgd_nesterov" if nesterov else "arco_sgd_momentum"     # nesterov=False: the stage-1 trainers
         self.params = [p for p in params]
         self.flat_p = flatten_params(self.params)
         self.flat_g = torch.zeros_like(self.flat_p)
@@ -140,7 +152,7 @@ class SGDNesterov:
         for a, b, first in runs:
             off = self.offsets[a][0]
             n = self.offsets[b - 1][0] + self.offsets[b - 1][1] - off
-            L.call("arco_sgd_nesterov", L.ptr(self.flat_p[off:]), L.ptr(self.flat_g[off:]), L.ptr(self.flat_buf[off:]),
+            L.call(self._kernel, L.ptr(self.flat_p[off:]), L.ptr(self.flat_g[off:]), L.ptr(self.flat_buf[off:]),
                    n, float(g['lr']), float(g['momentum']), float(g['weight_decay']), 1 if first else 0)
             for i in range(a, b):
                 self._started[i] = True

@@ -205,6 +205,9 @@ int arco_nhwc_to_nchw(const float* X, long ldx, int NB, int C, long P, float* Y,
  *      model_2D.py:176-182)                                                                                */
 int arco_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
                       int first, void* stream);
+/* the same with nesterov=False (stage-1 pre-training: pretrain_2D.py:193-195, pretrain_3D.py) */
+int arco_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                      int first, void* stream);
 int arco_ema(float* k, const float* q, long n, float m, void* stream);
 
 /* ---- T1  trainer glue (train_arco_2d.py:284-286,342-393,492-498)                                        */

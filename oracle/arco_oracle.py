@@ -872,3 +872,130 @@ def batch_transform_params(n_images, apply_augmentation, scale_size=(1.0, 1.0)):
         out.append(d)
     morph = bool(float(torch.rand(1)) > 0.5) and bool(apply_augmentation)
     return out, morph
+
+
+# --------------------------------------------------------------------------
+# S1  stage-1 pre-training: ISD.forward of model_2D.py:215-305 and the losses / optimizer of
+#     pretrain_2D.py:235-252, functional over plain state dicts (dropout off)
+# --------------------------------------------------------------------------
+def isd_compute_logits(z_anchor, z_positive, temp_fac):
+    """model_2D.py:320-331"""
+    return torch.matmul(F.normalize(z_anchor, dim=1), F.normalize(z_positive, dim=1).T) / temp_fac
+
+
+def isd_mlp(x, hd, pooling=1):
+    """MLP.forward / MLP_3d.forward, model_2D.py:105-112 (hd: f1.weight / f1.bias / f2.weight / f2.bias)."""
+    y = (F.adaptive_avg_pool2d if x.dim() == 4 else F.adaptive_avg_pool3d)(x, pooling).reshape(x.shape[0], -1)
+    return F.linear(F.linear(y, hd["f1.weight"], hd["f1.bias"]), hd["f2.weight"], hd["f2.bias"])
+
+
+def isd_projection(x, hd, pool):
+    """ProjectionHead 'convmlp', model_2D.py:66-85 (hd: proj.1.* / proj.2.*)."""
+    conv = F.conv2d if x.dim() == 4 else F.conv3d
+    y = (F.adaptive_avg_pool2d if x.dim() == 4 else F.adaptive_avg_pool3d)(x, pool)
+    return conv(conv(y, hd["proj.1.weight"], hd["proj.1.bias"]), hd["proj.2.weight"], hd["proj.2.bias"])
+
+
+def isd_stage1_forward(st, im_q, im_k, Ts, Tt, patch_size, pool, K, m=0.99, net=None):
+    """ISD.forward / ISD_3d.forward (model_3D.py:309-403; net = the V-Net forward, 5-D inputs) in training mode.  st: dict with 'model' / 'ema_model' (U-Net state dicts; the student's parameters
+    may require grad), 'q_latent_head', 'k_latent_head', 'latent_predictor' ({'0.weight', ...}), 'q_outputs_head',
+    'k_outputs_head', 'outputs_predictor', 'queue' [K, F], 'queue_mask' [K, 49, C*pool^2], 'queue_ptr', 'mask_queue_ptr'.
+    Teacher parameters, BN running statistics of both nets and the queues are updated in place, as the module does.
+    The shuffle permutation comes from the torch CPU generator (get_shuffle_ids, :308-318)."""
+    b = im_q.shape[0]
+    if net is None:
+        net = lambda x, sd: unet_forward(x, sd, train=True, track=True)
+    conv = F.conv2d if im_q.dim() == 4 else F.conv3d
+    outputs, latent, _ = net(im_q, st["model"])
+    with torch.no_grad():
+        ema_output_tmp, _, _ = net(im_k, st["ema_model"])
+        # _momentum_update_key_encoder (:176-182): parameters only, three module pairs
+        for q_name, k_name in (("model", "ema_model"), ("q_outputs_head", "k_outputs_head"), ("q_latent_head", "k_latent_head")):
+            for key, q in st[q_name].items():
+                if "running_" in key or "num_batches" in key:
+                    continue
+                rg = st[k_name][key].requires_grad          # param_k.data = ...: the Parameter (and its requires_grad) stays
+                st[k_name][key] = (st[k_name][key].detach() * m + q.detach() * (1.0 - m)).requires_grad_(rg)
+        fwd = torch.randperm(b).long()
+        bwd = torch.zeros(b).long()
+        bwd.index_copy_(0, fwd, torch.arange(b).long())
+        ema_output, ema_latent, _ = net(im_k[fwd], st["ema_model"])
+        ema_latent, ema_output = ema_latent[bwd], ema_output[bwd]
+    queue = st["queue"].clone()
+    queue_mask = st["queue_mask"].clone().transpose(0, 1).contiguous()
+    step = patch_size // 2
+    stu, tea = [], []
+    import itertools
+    for org in itertools.product(*[range(0, outputs.shape[2 + d] - patch_size + 1, step) for d in range(outputs.dim() - 2)]):
+        win = (slice(None), slice(None)) + tuple(slice(o, o + patch_size) for o in org)
+        y = isd_projection(outputs[win], st["q_outputs_head"], pool)
+        y = conv(conv(y, st["outputs_predictor"]["0.weight"], st["outputs_predictor"]["0.bias"]),
+                 st["outputs_predictor"]["1.weight"], st["outputs_predictor"]["1.bias"])
+        stu.append(y)
+        # NOT under no_grad in the reference (:268): the key heads sit in the autograd graph of the KLD *targets*
+        tea.append(isd_projection(ema_output[win], st["k_outputs_head"], pool))
+    shp = tuple(stu[0].shape[1:])
+    stu = torch.cat(stu).reshape(b, -1, *shp).contiguous()
+    tea = torch.cat(tea).reshape(b, -1, *shp).contiguous()
+    lat_k = isd_mlp(ema_latent, st["k_latent_head"])                 # (:282, with gradient, see above)
+    lat_q = isd_mlp(latent, st["q_latent_head"])
+    lat_q = F.linear(F.linear(lat_q, st["latent_predictor"]["0.weight"], st["latent_predictor"]["0.bias"]),
+                     st["latent_predictor"]["1.weight"], st["latent_predictor"]["1.bias"])
+    tea_tmp = tea.reshape(tea.shape[0], tea.shape[1], -1).contiguous()
+    stu = stu.reshape((stu.shape[1], b, -1)).contiguous()
+    tea = tea.reshape((tea.shape[1], b, -1)).contiguous()
+    stu = stu.reshape(-1, stu.shape[0]).contiguous()
+    tea = tea.reshape(-1, tea.shape[0]).contiguous()
+    queue_mask = queue_mask.reshape(-1, queue_mask.shape[0]).contiguous()
+    out = (outputs, ema_output_tmp, isd_compute_logits(lat_k, queue, Tt), isd_compute_logits(lat_q, queue, Ts),
+           isd_compute_logits(tea, queue_mask, Tt), isd_compute_logits(stu, queue_mask, Ts))
+    for keys, qn, pn in ((lat_k, "queue", "queue_ptr"), (tea_tmp, "queue_mask", "mask_queue_ptr")):
+        ptr = int(st[pn])
+        assert K % b == 0
+        st[qn][ptr:ptr + b] = keys.detach()
+        st[pn][0] = (ptr + b) % K
+    return out
+
+
+def kld_batchmean(inputs, targets):
+    """KLD of pretrain_2D.py:99-103"""
+    return F.kl_div(F.log_softmax(inputs, dim=1), F.softmax(targets, dim=1), reduction='batchmean')
+
+
+def sgd_momentum_step(p, g, buf, lr, momentum=0.9, wd=1e-4):
+    """torch.optim.SGD(momentum, weight_decay), nesterov off (pretrain_2D.py:193-195). buf None on the first step."""
+    g = g + wd * p
+    buf = g.clone() if buf is None else momentum * buf + g
+    return p - lr * buf, buf
+
+
+# every parameter with requires_grad goes to the optimizer (pretrain_2D.py:192) - that includes the KEY heads: they are
+# EMA-updated from the query heads inside the forward AND trained through the KLD targets (F.kl_div differentiates its
+# target), weight decay and momentum included.  Only ema_model is frozen (create_model(ema=True) detaches it).
+STAGE1_TRAINED = ("model", "k_latent_head", "q_latent_head", "latent_predictor", "k_outputs_head", "q_outputs_head", "outputs_predictor")
+
+
+def isd_stage1_step(st, bufs, im_q, im_k, label, labeled_bs, n_cls, lr, Ts, Tt, patch_size, pool, K, k1=1.0, k2=1.0, net=None,
+                    sup_scale=1.0):
+    """One iteration of pretrain_2D.py:235-252 with train_encoder = train_decoder = 1: forward, supervised CE + Dice on
+    the labeled part, the two KLD terms, SGD(momentum) on every trainable tensor.  Returns the loss terms and the
+    forward's outputs; st / bufs (momentum buffers by (group, key)) are updated in place."""
+    trained = [(g, k) for g in STAGE1_TRAINED for k in st[g] if "running_" not in k and "num_batches" not in k]
+    for g, k in trained:
+        st[g][k] = st[g][k].detach().requires_grad_(True)
+    out = isd_stage1_forward(st, im_q, im_k, Ts, Tt, patch_size, pool, K, net=net)
+    outputs, _, ema_latent_logits, latent_logits, ema_output_logits, output_logits = out
+    ce, dice = supervised_loss(outputs[:labeled_bs], label[:labeled_bs], n_cls)
+    l_lat = kld_batchmean(latent_logits, ema_latent_logits)
+    l_out = kld_batchmean(output_logits, ema_output_logits)
+    loss = sup_scale * (dice + ce) + k1 * l_lat + k2 * l_out          # (pretrain_3D.py:218: sup_scale = 0.5)
+    grads = torch.autograd.grad(loss, [st[g][k] for g, k in trained], allow_unused=True)
+    with torch.no_grad():
+        for (g, k), gr in zip(trained, grads):
+            if gr is None:
+                st[g][k] = st[g][k].detach()
+                continue
+            p, bufs[(g, k)] = sgd_momentum_step(st[g][k].detach(), gr, bufs.get((g, k)), lr)
+            st[g][k] = p
+    return dict(loss=float(loss.detach()), ce=float(ce.detach()), dice=float(dice.detach()), latent=float(l_lat.detach()), output=float(l_out.detach())), out, \
+        {gk: gr for gk, gr in zip(trained, grads)}

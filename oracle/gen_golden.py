@@ -17,6 +17,8 @@ import types
 
 import numpy as np
 import torch
+import torch.nn as nn
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -496,7 +498,8 @@ def gen_flags():
                             d[kw.arg] = ast.unparse(kw.value)
                 out[n.args[0].value] = d
         return out
-    tab = {"2d": flags(os.path.join(ref_shim.REF, "train_arco_2d.py")), "3d": flags(os.path.join(ref_shim.REF, "train_arco_3d.py"))}
+    tab = {"2d": flags(os.path.join(ref_shim.REF, "train_arco_2d.py")), "3d": flags(os.path.join(ref_shim.REF, "train_arco_3d.py")),
+           "pre2d": flags(os.path.join(ref_shim.REF, "pretrain_2D.py")), "pre3d": flags(os.path.join(ref_shim.REF, "pretrain_3D.py"))}
     # call signatures of the public names the trainers import (parameter names and defaults, in order)
     import importlib
     import inspect
@@ -623,9 +626,123 @@ def gen_eval2d(mods):
     print("g11_eval2d", len(out))
 
 
+# ---------------------------------------------------------------- G13 stage-1 pre-training (ISD.forward + pretrain_2D losses)
+def _param_sums(named):
+    names, s1, s2 = [], [], []
+    for n, p in named:
+        names.append(n); s1.append(p.double().sum().item()); s2.append(p.double().abs().sum().item())
+    return np.array(names), np.array(s1), np.array(s2)
+
+
+def _small(t):
+    """whole tensor up to 20 000 elements, else every 4th row and column (the per-tensor sums cover the rest)"""
+    t = t.detach()
+    return (t if t.numel() <= 20000 else t[::4, ::4]).numpy().copy()
+
+
+def gen_pretrain(mods, three_d=False):
+    """Two iterations of pretrain_2D.py:235-252 (pretrain_3D.py:209-232 with three_d) on the imported reference ISD /
+    ISD_3d (model_2D.py:115-305, model_3D.py:219-403) at the small configurations fixture_inputs.STAGE1_CFG(_3D): seeded
+    states, dropout off, torch.optim.SGD(momentum 0.9, wd 1e-4).  The KLD module, the loss combination and the optimizer
+    settings are the trainers' (the trainers themselves parse argv and need tensorboardX / torchvision / h5py at import,
+    none of them installed here); DiceLoss is the reference's utils/losses.py class, pulled out of its source file.  3-D:
+    the queue_mask buffer (700 patches hard-wired for 112 x 112 x 80 volumes) is replaced by one with the test volume's
+    27 patches - the forward only reads its shape."""
+    cfg = fx.STAGE1_CFG_3D if three_d else fx.STAGE1_CFG
+    seed_all(5)
+    kw = dict(K=cfg["K"], m=0.99, Ts=cfg["Ts"], Tt=cfg["Tt"], num_classes=cfg["num_classes"],
+              latent_pooling_size=cfg["latent_pooling_size"], latent_feature_size=cfg["latent_feature_size"],
+              output_pooling_size=cfg["output_pooling_size"], train_encoder=1, train_decoder=1, patch_size=cfg["patch_size"])
+    if three_d:
+        isd = mods["model_3D"].ISD_3d(**kw)
+        isd.model.load_state_dict(fx.vnet_state(31), strict=True)
+        isd.ema_model.load_state_dict(fx.vnet_state(32), strict=True)
+        heads = fx.isd3d_head_state(33)
+        isd.queue_mask = heads["queue_mask"].clone()
+    else:
+        isd = mods["model_2D"].ISD(**kw)
+        isd.model.load_state_dict(fx.unet_state(31), strict=True)
+        isd.ema_model.load_state_dict(fx.unet_state(32), strict=True)
+        heads = fx.isd_head_state(33)
+    missing, unexpected = isd.load_state_dict(heads, strict=False)
+    assert not unexpected and all(k.startswith(("model.", "ema_model.")) for k in missing), (missing, unexpected)
+    zero_dropout(isd); isd.train()
+    ns, _ = _pull_functions(os.path.join(ref_shim.REF, "utils", "losses.py"), {"DiceLoss"}, {"torch": torch, "nn": nn, "F": F, "np": np})
+    dice_loss = ns["DiceLoss"](cfg["num_classes"])
+    ce_loss = nn.CrossEntropyLoss()
+
+    class KLD(nn.Module):                       # pretrain_2D.py:99-103
+        def forward(self, inputs, targets):
+            inputs = F.log_softmax(inputs, dim=1)
+            targets = F.softmax(targets, dim=1)
+            return F.kl_div(inputs, targets, reduction='batchmean')
+
+    params = [p for p in isd.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=cfg["lr"], momentum=0.9, weight_decay=0.0001)
+    out = {}
+    lb = cfg["labeled_bs"]
+    sub = (slice(None), slice(None)) + (slice(None, None, 2),) * (3 if three_d else 2)
+    first_w, last_w = ("block_one.conv.0.weight", "out_conv.weight") if three_d else \
+        ("encoder.in_conv.conv_conv.0.weight", "decoder.out_conv.weight")
+    for it in range(cfg["steps"]):
+        im_q, im_k, lab = (fx.stage1_batch_3d if three_d else fx.stage1_batch)(40, it)
+        seed_all(100 + it)
+        outputs, ema_output, ema_ll, ll, ema_ol, ol = isd(im_q, im_k)
+        outputs_soft = torch.softmax(outputs, dim=1)
+        loss_ce = ce_loss(outputs[:lb], lab[:lb].long())
+        loss_dice = dice_loss(outputs_soft[:lb], lab[:lb].unsqueeze(1))
+        kld = KLD()
+        loss_latent = kld(inputs=ll, targets=ema_ll)
+        loss_output = kld(inputs=ol, targets=ema_ol)
+        loss = (0.5 if three_d else 1.0) * (loss_dice + loss_ce) + 1.0 * loss_latent + 1.0 * loss_output     # pretrain_3D.py:218
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            n, a, b_ = _param_sums([(k, p.grad) for k, p in isd.named_parameters() if p.grad is not None])
+            out["grad_names"], out["grad_sum"], out["grad_abs"] = n, a, b_
+            named = dict(isd.named_parameters())
+            for k, p in named.items():
+                if p.grad is not None and not k.startswith("model."):
+                    out["grad::" + k] = _small(p.grad)
+            for w in (first_w, last_w):
+                out["grad::model." + w] = named["model." + w].grad.numpy().copy()
+        opt.step()
+        out[f"s{it}_terms"] = np.array([loss.item(), loss_ce.item(), loss_dice.item(), loss_latent.item(), loss_output.item()])
+        out[f"s{it}_outputs"] = outputs.detach()[sub].numpy().copy()          # every other pixel; sums of all below
+        out[f"s{it}_ema_output"] = ema_output.detach()[sub].numpy().copy()
+        out[f"s{it}_outputs_sums"] = np.array([outputs.double().sum().item(), outputs.double().abs().sum().item(),
+                                               ema_output.double().sum().item(), ema_output.double().abs().sum().item()])
+        out[f"s{it}_ema_latent_logits"] = ema_ll.detach().numpy()
+        out[f"s{it}_latent_logits"] = ll.detach().numpy()
+        for tag, t in (("ema_output_logits", ema_ol), ("output_logits", ol)):
+            t = t.detach()
+            out[f"s{it}_{tag}_shape"] = np.array(t.shape)
+            out[f"s{it}_{tag}_sums"] = np.array([t.double().sum().item(), t.double().abs().sum().item()])
+            out[f"s{it}_{tag}_sample"] = t[::7, ::13].numpy().copy()
+    sd = isd.state_dict()
+    for k in ("queue", "queue_mask", "queue_ptr", "mask_queue_ptr"):
+        out["final::" + k] = sd[k].numpy().copy()
+    for k, v in sd.items():
+        if not k.startswith(("model.", "ema_model.", "queue", "mask_queue")):
+            out["final::" + k] = _small(v)
+    for pre in ("model.", "ema_model.", ""):
+        n, a, b_ = _param_sums([(k, v.float()) for k, v in sd.items() if k.startswith(pre) and "num_batches" not in k
+                                and (pre or not k.startswith(("model.", "ema_model.")))])
+        out[f"final_{pre}names"], out[f"final_{pre}sum"], out[f"final_{pre}abs"] = n, a, b_
+    bn1 = "block_one.conv.1" if three_d else "encoder.in_conv.conv_conv.1"
+    mid = "block_one.conv.0.weight" if three_d else "encoder.in_conv.conv_conv.4.weight"
+    for k in ("model." + last_w, "model." + mid, "ema_model." + last_w.replace("weight", "bias"),
+              f"ema_model.{bn1}.running_mean", f"ema_model.{bn1}.running_var", f"model.{bn1}.running_var",
+              f"ema_model.{bn1}.num_batches_tracked"):
+        out["final::" + k] = sd[k].numpy().copy()
+    name = "g14_pretrain3d" if three_d else "g13_pretrain"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, len(out), {k: out[f"s{k}_terms"] for k in range(cfg["steps"])})
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
@@ -638,3 +755,5 @@ if __name__ == "__main__":
     if "g10" in which: gen_morph()
     if "g11" in which: gen_eval2d(mods)
     if "g12" in which: gen_jitter()
+    if "g13" in which: gen_pretrain(mods)
+    if "g14" in which: gen_pretrain(mods, three_d=True)

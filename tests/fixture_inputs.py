@@ -332,3 +332,88 @@ def jitter_image(seed, C, H, W):
     if C == 3:
         x[:, 1, 0] = (1.0, 0.0, 0.0); x[:, 1, 1] = (0.0, 1.0, 0.0); x[:, 1, 2] = (0.0, 0.0, 1.0); x[:, 1, 3] = (0.2, 0.2, 0.2)
     return x
+
+
+# ---- stage-1 pre-training (oracle/gen_golden.py g13, tests/test_pretrain_*.py): a small ISD configuration
+STAGE1_CFG = dict(K=12, Ts=0.1, Tt=0.1, num_classes=4, latent_pooling_size=1, latent_feature_size=32, output_pooling_size=4,
+                  patch_size=16, b=4, labeled_bs=2, size=(64, 64), lr=0.01, steps=2)
+
+
+def isd_head_state(seed, cfg=STAGE1_CFG):
+    """Seeded parameters of the ISD heads and the two queues, keyed like ISD.state_dict() minus the two U-Nets."""
+    rs = np.random.RandomState(seed)
+    C, Fd, P = cfg["num_classes"], cfg["latent_feature_size"], cfg["output_pooling_size"]
+
+    def t(*shape, scale=0.2):
+        return torch.from_numpy((scale * rs.standard_normal(shape)).astype(np.float32))
+
+    sd = {}
+    for h in ("k_latent_head", "q_latent_head"):
+        sd[h + ".f1.weight"], sd[h + ".f1.bias"] = t(256, 256 * cfg["latent_pooling_size"] ** 2, scale=0.05), t(256)
+        sd[h + ".f2.weight"], sd[h + ".f2.bias"] = t(Fd, 256, scale=0.05), t(Fd)
+    for i in (0, 1):
+        sd[f"latent_predictor.{i}.weight"], sd[f"latent_predictor.{i}.bias"] = t(Fd, Fd), t(Fd)
+    for h in ("k_outputs_head", "q_outputs_head"):
+        sd[h + ".proj.1.weight"], sd[h + ".proj.1.bias"] = t(2 * C, C, 1, 1, scale=0.5), t(2 * C)
+        sd[h + ".proj.2.weight"], sd[h + ".proj.2.bias"] = t(C, 2 * C, 1, 1, scale=0.5), t(C)
+    for i in (0, 1):
+        sd[f"outputs_predictor.{i}.weight"], sd[f"outputs_predictor.{i}.bias"] = t(C, C, 1, 1, scale=0.5), t(C)
+    q = t(cfg["K"], Fd, scale=1.0)
+    qm = t(cfg["K"], 49, C * P * P, scale=1.0)
+    sd["queue"] = q / q.norm(dim=0, keepdim=True)
+    sd["queue_mask"] = qm / qm.norm(dim=0, keepdim=True)
+    sd["queue_ptr"] = torch.zeros(1, dtype=torch.long)
+    sd["mask_queue_ptr"] = torch.zeros(1, dtype=torch.long)
+    return sd
+
+
+def stage1_batch(seed, it, cfg=STAGE1_CFG):
+    """(student images, teacher images, labels) of iteration `it`."""
+    rs = np.random.RandomState(seed + 17 * it)
+    b, size = cfg["b"], cfg["size"]
+    im_q = torch.from_numpy(rs.uniform(size=(b, 1, *size)).astype(np.float32))
+    im_k = (im_q + torch.from_numpy((0.05 * rs.standard_normal((b, 1, *size))).astype(np.float32))).clamp(0, 1)
+    lab = torch.from_numpy(blob_labels(rs, b, size, cfg["num_classes"]))
+    return im_q, im_k, lab
+
+
+STAGE1_CFG_3D = dict(K=4, Ts=0.1, Tt=0.1, num_classes=2, latent_pooling_size=1, latent_feature_size=16, output_pooling_size=2,
+                     patch_size=16, b=2, labeled_bs=1, size=(32, 32, 32), lr=0.01, steps=2, n_patches=27)
+
+
+def isd3d_head_state(seed, cfg=STAGE1_CFG_3D):
+    """Seeded parameters of the ISD_3d heads and queues (queue_mask with the patch count of the small test volume: the
+    constructor hard-wires 700 = the 20-voxel patches of a 112 x 112 x 80 volume)."""
+    rs = np.random.RandomState(seed)
+    C, Fd, P = cfg["num_classes"], cfg["latent_feature_size"], cfg["output_pooling_size"]
+
+    def t(*shape, scale=0.2):
+        return torch.from_numpy((scale * rs.standard_normal(shape)).astype(np.float32))
+
+    sd = {}
+    for h in ("k_latent_head", "q_latent_head"):
+        sd[h + ".f1.weight"], sd[h + ".f1.bias"] = t(128, 128 * cfg["latent_pooling_size"] ** 2, scale=0.05), t(128)
+        sd[h + ".f2.weight"], sd[h + ".f2.bias"] = t(Fd, 128, scale=0.05), t(Fd)
+    for i in (0, 1):
+        sd[f"latent_predictor.{i}.weight"], sd[f"latent_predictor.{i}.bias"] = t(Fd, Fd), t(Fd)
+    for h in ("k_outputs_head", "q_outputs_head"):
+        sd[h + ".proj.1.weight"], sd[h + ".proj.1.bias"] = t(2 * C, C, 1, 1, 1, scale=0.5), t(2 * C)
+        sd[h + ".proj.2.weight"], sd[h + ".proj.2.bias"] = t(C, 2 * C, 1, 1, 1, scale=0.5), t(C)
+    for i in (0, 1):
+        sd[f"outputs_predictor.{i}.weight"], sd[f"outputs_predictor.{i}.bias"] = t(C, C, 1, 1, 1, scale=0.5), t(C)
+    q = t(cfg["K"], Fd, scale=1.0)
+    qm = t(cfg["K"], cfg["n_patches"], C * P ** 3, scale=1.0)
+    sd["queue"] = q / q.norm(dim=-1, keepdim=True)
+    sd["queue_mask"] = qm / qm.norm(dim=-1, keepdim=True)
+    sd["queue_ptr"] = torch.zeros(1, dtype=torch.long)
+    sd["mask_queue_ptr"] = torch.zeros(1, dtype=torch.long)
+    return sd
+
+
+def stage1_batch_3d(seed, it, cfg=STAGE1_CFG_3D):
+    rs = np.random.RandomState(seed + 17 * it)
+    b, size = cfg["b"], cfg["size"]
+    im_q = torch.from_numpy(rs.uniform(size=(b, 1, *size)).astype(np.float32))
+    im_k = (im_q + torch.from_numpy((0.05 * rs.standard_normal((b, 1, *size))).astype(np.float32))).clamp(0, 1)
+    lab = torch.from_numpy(blob_labels(rs, b, size, cfg["num_classes"]))
+    return im_q, im_k, lab

@@ -313,16 +313,17 @@ def test_cutout_mask_host_draws_match_oracle():
         assert float(np.random.uniform()) == float((np.random.seed(5), orc.cutout_mask(list(size)), np.random.uniform())[2])
 
 
-@pytest.mark.parametrize("which", ["2d", "3d"])
+@pytest.mark.parametrize("which", ["2d", "3d", "pre2d", "pre3d"])
 def test_trainer_flags_match_reference(which):
-    """every add_argument of train_arco_2d.py / train_arco_3d.py is accepted with the same name, type and
-    default (table read from the reference's source, oracle/gen_golden.py g9)."""
+    """every add_argument of train_arco_2d.py / train_arco_3d.py (and of the stage-1 trainers pretrain_2D.py /
+    pretrain_3D.py) is accepted with the same name, type and default (table read from the reference's source,
+    oracle/gen_golden.py g9)."""
     import json
-    from arco_amd import train_arco_2d, train_arco_3d
+    from arco_amd import pretrain_2D, pretrain_3D, train_arco_2d, train_arco_3d
     tab = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g9_flags.json")))[which]
-    parser = (train_arco_2d if which == "2d" else train_arco_3d).build_parser()
+    parser = {"2d": train_arco_2d, "3d": train_arco_3d, "pre2d": pretrain_2D, "pre3d": pretrain_3D}[which].build_parser()
     mine = {a.option_strings[0]: a for a in parser._actions if a.option_strings}
-    assert len(tab) >= 40
+    assert len(tab) >= (40 if which in ("2d", "3d") else 28)
     for name, d in tab.items():
         assert name in mine, name
         if "default" in d:
