@@ -61,17 +61,17 @@ __device__ __forceinline__ float row16_sum(float v) {    // sum over the 16 lane
 // runs out, and shuttles every accumulator through a scratch AGPR quad around each MFMA chain (4 v_accvgpr_write + hazard
 // nops per chain).  The s_nop covers an operand a VALU instruction has just written (hipcc pads nothing inside asm).
 __device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& x, const bf16x8& y) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(x), "v"(y));
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(x), "v"(y));
 }
 
 __device__ __forceinline__ void mfma_first(f32x4& c, const bf16x8& x, const bf16x8& y) {     // c = x . y (a tile's first product)
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(x), "v"(y));
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(x), "v"(y));
 }
 
 template <int A_T, int C_T>
-__global__ __launch_bounds__(256) void conv3x3_sp_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
   using G = SpGeom<A_T, C_T>;
-  constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT, NB = G::NBI, NE = A_T * C_T;
+  constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT, NB = G::NBI;
   constexpr int NA3 = (NA + 2) / 3;                              // activation pieces split + written per staging step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned* const As = reinterpret_cast<unsigned*>(smem);
@@ -79,7 +79,12 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(IgemmArgs a) {
   float* const red = reinterpret_cast<float*>(Bs + 5 * G::SLOT_DW);
   float* const bias_s = red + G::RED_DW;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  // 8 waves: 0-3 consume (fragment reads + MFMAs, one per SIMD), 4-7 produce (LDS-DMA refills, activation loads, split and
+  // LDS writes).  A SIMD then always has a wave that can issue while the other waits - on a single wave per SIMD the
+  // issue cost of the DMA instructions and the split VALU work sat between the MFMAs.  Both roles pass the same
+  // barriers: one before the first step, one per step, one per tile with BN statistics.
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const bool producer = threadIdx.x >= 256;
   const int tiles_x = a.W >> 4, tiles_y = a.H / TH, tiles_img = tiles_x * tiles_y;
   const int nchunks = a.K >> 4;
   const int total_tiles = a.n_mblocks * a.n_nblocks;
@@ -100,88 +105,125 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(IgemmArgs a) {
   auto advance = [&](Desc& d) { if (++d.c == nchunks) { d.c = 0; ++d.j; decode(d); } };
   Desc d0{0, 0, 0, 0, 0, 0, 0};
   decode(d0);
-  Desc d1 = d0; advance(d1);
-  Desc d2 = d1; advance(d2);
 
-  // ---- per-thread staging geometry (constant over the launch)
-  const int qA = tid & 3;
-  int hyA[NA], hxA[NA], ldsA[NA], toff[NA];
-#pragma unroll
-  for (int it = 0; it < NA; ++it) {
-    const int row = (tid + it * 256) >> 2;
-    hyA[it] = row / 18; hxA[it] = row - hyA[it] * 18;
-    ldsA[it] = row < G::AROWS ? row * 24 + qA * 2 : -1;
-    toff[it] = (hyA[it] * a.W + hxA[it]) * (int)a.lda + qA * 4;
-  }
-  int woff[NB], wq[NB], wtap[NB];                 // weight piece of LDS-DMA instruction i: dword offset, piece of the row, local tap (2 = padding)
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int p = (i * 4 + wid) * 64 + lane;
-    const int tl_ = p / (BN * 6), rem = p - tl_ * (BN * 6), n = rem / 6, q6 = rem - n * 6;
-    wtap[i] = tl_ < 2 ? tl_ : 2;
-    woff[i] = tl_ < 2 ? ((tl_ * a.Npad + n) * a.Kg) * 24 + q6 * 4 : 0;
-    wq[i] = q6 * 4;
-  }
-  const long wslot2 = (long)2 * a.Npad * a.Kg * 24;          // two taps of packed weights (dwords)
-  const float* const zrow = reinterpret_cast<const float*>(conv_sp_zero_row);
-
-  // Activation loads of a chunk.  Every lane loads (clamped address, the mask zeroes at the split), and the loads are asm
-  // statements: hipcc, which drains the LDS-DMA queue (vmcnt(0)) at the use of any load it knows of, does not see them.
-  // They sit in the per-wave VMEM order right behind a refill, so the step-1 wait (at most 2 NB younger instructions
-  // in flight) certifies them; ra_fence() then orders every reader behind that wait.
-  f32x4 ra[NA]; unsigned okm = 0;
-  auto load_A = [&](const Desc& d) {
-    const long base = (((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16;
-    const float* pa[NA];
-    okm = 0;
+  if (producer) {
+    // ================================================================ producer waves
+    Desc d1 = d0; advance(d1);
+    Desc d2 = d1; advance(d2);
+    const int qA = tid & 3;
+    int hyA[NA], hxA[NA], ldsA[NA], toff[NA];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
-      const int y = d.y0 + hyA[it] - 1, x = d.x0 + hxA[it] - 1;
-      const bool ok = ldsA[it] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      pa[it] = ok ? a.A + base + toff[it] : a.A;
-      okm |= ok ? (1u << it) : 0u;
+      const int row = (tid + it * 256) >> 2;
+      hyA[it] = row / 18; hxA[it] = row - hyA[it] * 18;
+      ldsA[it] = row < G::AROWS ? row * 24 + qA * 2 : -1;
+      toff[it] = (hyA[it] * a.W + hxA[it]) * (int)a.lda + qA * 4;
     }
-#pragma unroll
-    for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(pa[it]) : "memory");
-  };
-  auto ra_fence = [&]() {
-#pragma unroll
-    for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[it])::"memory");
-  };
-  // split of one fp32 element into its three bf16 terms (the per-element half of split3_bf16x4)
-  auto split_elem = [&](float x, unsigned short (&h)[3]) {
-    const __bf16 b0 = (__bf16)x; const float r1 = x - (float)b0;
-    const __bf16 b1 = (__bf16)r1; const float r2 = r1 - (float)b1;
-    const __bf16 b2 = (__bf16)r2;
-    h[0] = __builtin_bit_cast(unsigned short, b0); h[1] = __builtin_bit_cast(unsigned short, b1); h[2] = __builtin_bit_cast(unsigned short, b2);
-  };
-  auto write_A = [&](unsigned* buf, int it, const unsigned short (&h)[4][3]) {     // the three planes of piece `it`
-    if (ldsA[it] >= 0) {
-      unsigned* d = buf + ldsA[it];
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<u32x2_ma*>(d + 8 * p) = u32x2{(unsigned)h[0][p] | ((unsigned)h[1][p] << 16), (unsigned)h[2][p] | ((unsigned)h[3][p] << 16)};
-    }
-  };
-  auto store_A = [&](unsigned* buf, int it) {      // split piece `it` into its three bf16 planes (zero outside the image)
-    const f32x4 v = ((okm >> it) & 1u) ? ra[it] : f32x4{0, 0, 0, 0};
-    unsigned short h[4][3];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split_elem(v[e], h[e]);
-    write_A(buf, it, h);
-  };
-  auto refill = [&](int slot, const Desc& d) {     // LDS-DMA: weights of step `slot` of chunk d -> ring slot
-    const float* base = a.Wp + slot * wslot2 + ((long)d.nblk * BN * a.Kg + d.c) * 24;
+    int woff[NB], wq[NB], wtap[NB];               // weight piece of LDS-DMA instruction i: dword offset, piece of the row, local tap (2 = padding)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const bool zero = wtap[i] == 2 || (slot == 4 && wtap[i] == 1);
-      const float* src = zero ? zrow + wq[i] : base + woff[i];
-      unsigned* dst = Bs + slot * G::SLOT_DW + (i * 4 + wid) * 256;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+      const int p = (i * 4 + wid) * 64 + lane;
+      const int tl_ = p / (BN * 6), rem = p - tl_ * (BN * 6), n = rem / 6, q6 = rem - n * 6;
+      wtap[i] = tl_ < 2 ? tl_ : 2;
+      woff[i] = tl_ < 2 ? ((tl_ * a.Npad + n) * a.Kg) * 24 + q6 * 4 : 0;
+      wq[i] = q6 * 4;
     }
-  };
+    const long wslot2 = (long)2 * a.Npad * a.Kg * 24;        // two taps of packed weights (dwords)
+    const float* const zrow = reinterpret_cast<const float*>(conv_sp_zero_row);
 
-  // ---- fragment addressing: lanes g = 0,1 take tap 2s, g = 2,3 tap 2s+1 (step 4: tap 8 and the zero tap)
+    // Activation loads of a chunk.  Every lane loads (clamped address, the mask zeroes at the split), and the loads are asm
+    // statements: hipcc, which drains the LDS-DMA queue (vmcnt(0)) at the use of any load it knows of, does not see
+    // them.  They sit in the per-wave VMEM order right behind a refill, so the step-1 wait (at most 2 NB younger
+    // instructions in flight) certifies them; ra_fence() then orders every reader behind that wait.
+    f32x4 ra[NA]; unsigned okm = 0;
+    auto load_A = [&](const Desc& d, bool real) {
+      const long base = (((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16;
+      const float* pa[NA];
+      okm = 0;
+#pragma unroll
+      for (int it = 0; it < NA; ++it) {
+        const int y = d.y0 + hyA[it] - 1, x = d.x0 + hxA[it] - 1;
+        const bool ok = real && ldsA[it] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        pa[it] = ok ? a.A + base + toff[it] : a.A;
+        okm |= ok ? (1u << it) : 0u;
+      }
+#pragma unroll
+      for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(pa[it]) : "memory");
+    };
+    auto ra_fence = [&]() {
+#pragma unroll
+      for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[it])::"memory");
+    };
+    auto store_A = [&](unsigned* buf, int it) {    // split piece `it` into its three bf16 planes (zero outside the image)
+      const f32x4 v = ((okm >> it) & 1u) ? ra[it] : f32x4{0, 0, 0, 0};
+      u32x2 p0, p1, p2;
+      split3_bf16x4(v, p0, p1, p2);
+      if (ldsA[it] >= 0) {
+        unsigned* d = buf + ldsA[it];
+        *reinterpret_cast<u32x2_ma*>(d) = p0; *reinterpret_cast<u32x2_ma*>(d + 8) = p1; *reinterpret_cast<u32x2_ma*>(d + 16) = p2;
+      }
+    };
+    auto refill = [&](int slot, const Desc& d) {   // LDS-DMA: weights of step `slot` of chunk d -> ring slot
+      const float* base = a.Wp + slot * wslot2 + ((long)d.nblk * BN * a.Kg + d.c) * 24;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const bool zero = wtap[i] == 2 || (slot == 4 && wtap[i] == 1);
+        const float* src = zero ? zrow + wq[i] : base + woff[i];
+        unsigned* dst = Bs + slot * G::SLOT_DW + (i * 4 + wid) * 256;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+      }
+    };
+
+    // prologue.  Per-wave VMEM order, the one the step waits count on: A0 | R0 R1 R2 | A1 | R3
+    for (int i = tid; i < G::BIAS_DW; i += 256) bias_s[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
+    load_A(d0, true);
+    refill(0, d0); refill(1, d0); refill(2, d0);
+    wait_vm<3 * NB>();                // chunk 0's activations (the DMA behind them stays in flight)
+    ra_fence();
+#pragma unroll
+    for (int it = 0; it < NA; ++it) store_A(As, it);
+    load_A(d1, total_gc > 1);         // (every wave issues every instruction, real or not: the counts below are exact)
+    refill(3, d0);
+    wait_vm<NA + 2 * NB>();           // slots 0 and 1 landed (own DMA); the barrier makes it everyone's
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+
+    for (int gc = 0; gc < total_gc; ++gc) {
+      const bool more = gc + 1 < total_gc;
+      unsigned* Anxt = As + ((gc + 1) & 1) * G::A_DW;
+      auto step = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        // VMEM instructions younger than what this barrier (and, at step 1, the activation split) needs; order per chunk:
+        // s0 R4 | s1 R0' | s2 R1' | s3 R2' A' | s4 R3'   (the last chunk issues the same instructions on dummy addresses)
+        constexpr int NS = (S == 0 || S == 4) ? NA + 2 * NB : 2 * NB;
+        wait_vm<NS>();
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+        refill(S == 0 ? 4 : S - 1, S == 0 ? d0 : (more ? d1 : d0));     // the slot the previous step has finished with
+        if (S == 1) ra_fence();
+        if (S >= 1 && S <= 3) {
+#pragma unroll
+          for (int it = (S - 1) * NA3; it < S * NA3 && it < NA; ++it) store_A(Anxt, it);
+        }
+        if (S == 3) load_A(d2, gc + 2 < total_gc);
+      };
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+      if (d0.c + 1 == nchunks && has_stats) {       // the consumers' statistics barrier
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+      }
+      d0 = d1; d1 = d2; advance(d2);
+    }
+    wait_vm<0>();
+    return;
+  }
+
+  // ================================================================== consumer waves
+  // fragment addressing: lanes g = 0,1 take tap 2s, g = 2,3 tap 2s+1 (step 4: tap 8 and the zero tap)
   const int tl = g >> 1;
   int aoff[5];
 #pragma unroll
@@ -191,169 +233,126 @@ __global__ __launch_bounds__(256) void conv3x3_sp_kernel(IgemmArgs a) {
   }
   const int laneA = (wid * A_T * 18 + li) * 24 + (g & 1) * 4;
   const int laneB = (tl * BN + li) * 24 + (g & 1) * 4;
-  auto load_fa = [&](const unsigned* Ab, int s, bf16x8 (&fa)[A_T][3]) {
+  // Fragment registers: two A sets used alternately by consecutive steps (a chunk has five steps, so the roles of the sets
+  // swap from chunk to chunk: the chunk body exists once per parity - no register copies between steps), and two B sets of
+  // ONE 16-channel group each, used alternately by consecutive groups: group k+1 (the next group of this step, or the
+  // first group of the next step) is read while group k is on the matrix cores.
+  bf16x8 fa[2][A_T][3], fb[2][3];
+  f32x4 acc[A_T][C_T];
 #pragma unroll
-    for (int at = 0; at < A_T; ++at)
+  for (int i = 0; i < A_T; ++i)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa[at][pl] = lds_bf16x8(Ab + laneA + aoff[s] + at * 18 * 24 + 8 * pl);
-  };
-  auto load_fb = [&](int s, int ct, bf16x8 (&fb)[3]) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) fb[pl] = lds_bf16x8(Bs + s * G::SLOT_DW + laneB + ct * 16 * 24 + 8 * pl);
-  };
+    for (int j = 0; j < C_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  f32x4 acc[A_T][C_T];       // AGPRs for the whole launch; a tile's first MFMA of every chain starts from the constant 0
-
-  // ---- prologue.  Per-wave VMEM order, the one the step waits count on: A0 | R0 R1 R2 | A1 | R3
-  for (int i = tid; i < G::BIAS_DW; i += 256) bias_s[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
-  load_A(d0);
-  refill(0, d0); refill(1, d0); refill(2, d0);
-  wait_vm<3 * NB>();                  // chunk 0's activations (the DMA behind them stays in flight)
-  ra_fence();
+  __builtin_amdgcn_s_barrier();          // the producers' prologue barrier: chunk 0's activations, slots 0 and 1
 #pragma unroll
-  for (int it = 0; it < NA; ++it) store_A(As, it);
-  if (total_gc > 1) load_A(d1);
-  refill(3, d0);
-  wait_vm<NA + 2 * NB>();             // slots 0 and 1 landed (own DMA); the barrier makes it everyone's
-  wait_lgkm0();
-  __builtin_amdgcn_s_barrier();
-  bf16x8 fa[A_T][3], fb0[3];
-  load_fa(As, 0, fa);
-  load_fb(0, 0, fb0);
+  for (int at = 0; at < A_T; ++at)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) fa[0][at][pl] = lds_bf16x8(As + laneA + aoff[0] + at * 18 * 24 + 8 * pl);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) fb[0][pl] = lds_bf16x8(Bs + laneB + 8 * pl);
 
-  for (int gc = 0; gc < total_gc; ++gc) {
-    const bool more = gc + 1 < total_gc;          // a next chunk exists (its A buffer and slots are being filled)
-    const bool tail = gc + 2 >= total_gc;         // the steady-state instruction counts no longer hold: drain instead
-    const bool post = gc > 0 && d0.c == 0;        // first chunk behind a tile's output stores (they count in vmcnt)
+  auto chunk = [&](auto CP_, int gc) {
+    constexpr int CP = decltype(CP_)::value;             // parity of the chunk = A set holding step 0's fragments
     const unsigned* Acur = As + (gc & 1) * G::A_DW;
-    unsigned* Anxt = As + ((gc + 1) & 1) * G::A_DW;
-
-    auto step = [&](auto S_, auto F_) {
+    const unsigned* Anxt = As + ((gc + 1) & 1) * G::A_DW;
+    auto step = [&](auto S_) {
       constexpr int S = decltype(S_)::value;
-      constexpr bool FIRST = decltype(F_)::value;
-      // VMEM instructions younger than what this barrier (and, at step 1, the activation split) needs; order per chunk:
-      // s0 R4 | s1 R0' | s2 R1' | s3 R2' A' | s4 R3'
-      constexpr int NS = (S == 0 || S == 4) ? NA + 2 * NB : 2 * NB;
-      constexpr int NP = S <= 2 ? NE : 0;          // + a tile's output (and 2 statistics) stores in front of steps 0-2
-      if (tail) wait_vm<0>();
-      else if (!post || NP == 0) wait_vm<NS>();
-      else if (has_stats) wait_vm<NS + NP + 2>();
-      else wait_vm<NS + NP>();
+      constexpr int P = (CP + S) & 1, Q = P ^ 1;
       wait_lgkm0();
       __builtin_amdgcn_s_barrier();
-      if (S == 0) refill(4, d0);                   // the slot the previous step has finished with
-      else if (more) refill(S - 1, d1);
-      if (S == 1) ra_fence();
-      // this step's remaining B groups, then the next step's fragments, all issued ahead of the MFMAs
-      bf16x8 fbs[C_T > 1 ? C_T - 1 : 1][3];
-#pragma unroll
-      for (int ct = 1; ct < C_T; ++ct) load_fb(S, ct, fbs[ct - 1]);
-      __builtin_amdgcn_sched_barrier(0);           // (LDS returns in order: what this step needs comes back first)
-      bf16x8 fan[A_T][3], fbn[3];
-      load_fa(S < 4 ? Acur : Anxt, (S + 1) % 5, fan);      // (last chunk, step 4: read and never used)
-      load_fb((S + 1) % 5, 0, fbn);
-      // left to itself the scheduler sinks every fragment read to just above its first use (register pressure), exposing
-      // the LDS latency 24 times per step: nothing crosses this line, the reads stay in front of the MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      // staging in the shadow of the matrix pipe (steps 1-3): PPC activation pieces of the next chunk per MFMA group, one
-      // element split behind every 6-MFMA chain (the asm MFMAs keep their order, so the VALU work is interleaved by hand;
-      // with no next chunk the writes land in the idle buffer)
-      constexpr int PPC = (NA3 + C_T - 1) / C_T;
-      static_assert(A_T >= 4 * PPC, "one element split per MFMA chain");
+      // LDS reads in the shadow of the MFMA chains: at the head of every group the three fragments of the NEXT group, and
+      // behind the first chains the next step's A fragments (set Q), APC per chain.  Nothing crosses the sched_barriers,
+      // so the reads stay where they are put (LDS returns in order, hipcc counts the waits).
+      constexpr int NCH = A_T * C_T;
+      constexpr int APC = (A_T * 3 + (NCH - 2) - 1) / (NCH - 2 > 0 ? NCH - 2 : 1);
+      const unsigned* An = S < 4 ? Acur : Anxt;
 #pragma unroll
       for (int ct = 0; ct < C_T; ++ct) {
-        unsigned short hh[PPC][4][3];
-        f32x4 pv[PPC];
+        constexpr int GB = (C_T & 1) ? (CP + S) : 0;       // group parity base (an odd group count flips it per step)
+        const int BPc = (GB + ct) & 1, BPn = BPc ^ 1;
+        const bool last = ct + 1 == C_T;
 #pragma unroll
-        for (int p = 0; p < PPC; ++p) {
-          const int it = (S - 1) * NA3 + ct * PPC + p;
-          const bool on = S >= 1 && S <= 3 && ct * PPC + p < NA3 && it < NA;
-          pv[p] = (on && ((okm >> (on ? it : 0)) & 1u)) ? ra[on ? it : 0] : f32x4{0, 0, 0, 0};
-        }
+        for (int pl = 0; pl < 3; ++pl)
+          fb[BPn][pl] = lds_bf16x8(Bs + (last ? (S + 1) % 5 : S) * G::SLOT_DW + laneB + (last ? 0 : ct + 1) * 16 * 24 + 8 * pl);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int at = 0; at < A_T; ++at) {          // D = W . X^T; small terms first
-          const bf16x8 b0 = ct == 0 ? fb0[0] : fbs[ct > 0 ? ct - 1 : 0][0];
-          const bf16x8 b1 = ct == 0 ? fb0[1] : fbs[ct > 0 ? ct - 1 : 0][1];
-          const bf16x8 b2 = ct == 0 ? fb0[2] : fbs[ct > 0 ? ct - 1 : 0][2];
-          if (FIRST) mfma_first(acc[at][ct], b0, fa[at][2]);
-          else mfma_acc(acc[at][ct], b0, fa[at][2]);
-          mfma_acc(acc[at][ct], b2, fa[at][0]);
-          mfma_acc(acc[at][ct], b1, fa[at][1]);
-          mfma_acc(acc[at][ct], b0, fa[at][1]);
-          mfma_acc(acc[at][ct], b1, fa[at][0]);
-          mfma_acc(acc[at][ct], b0, fa[at][0]);
-          if (S >= 1 && S <= 3 && at < 4 * PPC) {
-            split_elem(pv[at / 4][at % 4], hh[at / 4][at % 4]);
-            __builtin_amdgcn_sched_barrier(0);       // (or the scheduler sinks the split into one block behind the group)
-          }
-        }
+          mfma_acc(acc[at][ct], fb[BPc][0], fa[P][at][2]);
+          mfma_acc(acc[at][ct], fb[BPc][2], fa[P][at][0]);
+          mfma_acc(acc[at][ct], fb[BPc][1], fa[P][at][1]);
+          mfma_acc(acc[at][ct], fb[BPc][0], fa[P][at][1]);
+          mfma_acc(acc[at][ct], fb[BPc][1], fa[P][at][0]);
+          mfma_acc(acc[at][ct], fb[BPc][0], fa[P][at][0]);
+          const int chain = ct * A_T + at;
 #pragma unroll
-        for (int p = 0; p < PPC; ++p) {
-          const int it = (S - 1) * NA3 + ct * PPC + p;
-          if (S >= 1 && S <= 3 && ct * PPC + p < NA3 && it < NA) write_A(Anxt, it, hh[p]);
+          for (int k = chain * APC; k < (chain + 1) * APC && k < A_T * 3; ++k)
+            fa[Q][k / 3][k % 3] = lds_bf16x8(An + laneA + aoff[(S + 1) % 5] + (k / 3) * 18 * 24 + 8 * (k % 3));
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (S == 3 && !tail) load_A(d2);
-#pragma unroll
-      for (int at = 0; at < A_T; ++at)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fa[at][pl] = fan[at][pl];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fb0[pl] = fbn[pl];
     };
-    if (d0.c == 0) step(std::integral_constant<int, 0>{}, std::true_type{});
-    else step(std::integral_constant<int, 0>{}, std::false_type{});
-    step(std::integral_constant<int, 1>{}, std::false_type{});
-    step(std::integral_constant<int, 2>{}, std::false_type{});
-    step(std::integral_constant<int, 3>{}, std::false_type{});
-    step(std::integral_constant<int, 4>{}, std::false_type{});
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+  };
 
-    if (d0.c + 1 == nchunks) {         // ---- tile done: bias, store, BN partial statistics; accumulators back to zero
-      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results (asm: no hazard padding by hipcc)
-      const int n0 = d0.nblk * BN;
-      float s1[C_T][4], s2[C_T][4];
+  auto tile_end = [&]() {              // ---- tile done: bias, store, BN partial statistics; accumulators back to zero
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the last MFMAs' results (asm: no hazard padding by hipcc)
+    const int n0 = d0.nblk * BN;
+    float s1[C_T][4], s2[C_T][4];
 #pragma unroll
-      for (int ct = 0; ct < C_T; ++ct) {
-        const int n = n0 + ct * 16 + 4 * g;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n);
+    for (int ct = 0; ct < C_T; ++ct) {
+      const int n = n0 + ct * 16 + 4 * g;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; }
+      for (int r = 0; r < 4; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; }
 #pragma unroll
-        for (int at = 0; at < A_T; ++at) {
-          const long pix = ((long)d0.img * a.H + d0.y0 + wid * A_T + at) * a.W + d0.x0 + li;
-          f32x4 v = acc[at][ct] + bv;
-          if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + pix * a.ldr + n);
-          *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + n) = v;
+      for (int at = 0; at < A_T; ++at) {
+        const long pix = ((long)d0.img * a.H + d0.y0 + wid * A_T + at) * a.W + d0.x0 + li;
+        f32x4 v = acc[at][ct] + bv;
+        if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + pix * a.ldr + n);
+        *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + n) = v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { s1[ct][r] += v[r]; s2[ct][r] += v[r] * v[r]; }
-        }
-      }
-      if (has_stats) {
-#pragma unroll
-        for (int ct = 0; ct < C_T; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v1 = row16_sum(s1[ct][r]), v2 = row16_sum(s2[ct][r]);
-            if (li == 0) {
-              red[(0 * 4 + wid) * BN + ct * 16 + 4 * g + r] = v1;
-              red[(1 * 4 + wid) * BN + ct * 16 + 4 * g + r] = v2;
-            }
-          }
-        wait_lgkm0();
-        __builtin_amdgcn_s_barrier();
-        // every wave issues the two stores (waves beyond BN / 16 repeat an earlier wave's channels: same values, same
-        // addresses) so that the per-wave VMEM instruction count the step waits rely on is uniform
-        const int nl = (wid * 16 + li) % BN;
-        if (g == 0) {
-          float v1 = 0.f, v2 = 0.f;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) { v1 += red[(0 * 4 + w) * BN + nl]; v2 += red[(1 * 4 + w) * BN + nl]; }
-          a.stat_sum[(long)(n0 + nl) * a.n_mblocks + d0.mblk] = v1;
-          a.stat_sq[(long)(n0 + nl) * a.n_mblocks + d0.mblk] = v2;
-        }
+        for (int r = 0; r < 4; ++r) { s1[ct][r] += v[r]; s2[ct][r] += v[r] * v[r]; }
+        acc[at][ct] = f32x4{0, 0, 0, 0};
       }
     }
-    d0 = d1; d1 = d2; advance(d2);
+    if (has_stats) {
+#pragma unroll
+      for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v1 = row16_sum(s1[ct][r]), v2 = row16_sum(s2[ct][r]);
+          if (li == 0) {
+            red[(0 * 4 + wid) * BN + ct * 16 + 4 * g + r] = v1;
+            red[(1 * 4 + wid) * BN + ct * 16 + 4 * g + r] = v2;
+          }
+        }
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
+      for (int nl = tid; nl < BN; nl += 256) {
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { v1 += red[(0 * 4 + w) * BN + nl]; v2 += red[(1 * 4 + w) * BN + nl]; }
+        a.stat_sum[(long)(n0 + nl) * a.n_mblocks + d0.mblk] = v1;
+        a.stat_sq[(long)(n0 + nl) * a.n_mblocks + d0.mblk] = v2;
+      }
+    }
+  };
+
+  // two chunks per trip: the A sets are back in their roles at the loop edge
+  for (int gc = 0; gc < total_gc; gc += 2) {
+    chunk(std::integral_constant<int, 0>{}, gc);
+    if (d0.c + 1 == nchunks) tile_end();
+    advance(d0);
+    if (gc + 1 < total_gc) {
+      chunk(std::integral_constant<int, 1>{}, gc + 1);
+      if (d0.c + 1 == nchunks) tile_end();
+      advance(d0);
+    }
   }
 }
 
@@ -371,7 +370,7 @@ template <int A_T, int C_T>
 static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
   using G = SpGeom<A_T, C_T>;
   const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
-  if (q) { q[0] = mblocks; q[1] = 9800000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
+  if (q) { q[0] = mblocks; q[1] = 9600000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
   if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
   auto kern = conv3x3_sp_kernel<A_T, C_T>;
   static bool attr_set = false;
@@ -379,7 +378,7 @@ static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
   IgemmArgs b = a;
   b.n_mblocks = mblocks; b.n_nblocks = a.Npad / G::BN;
   const int total = mblocks * b.n_nblocks, cus = conv_sp_cus();
-  hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(256), G::LDS_BYTES, st, b);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), G::LDS_BYTES, st, b);
   return arco_launch_status();
 }
 
@@ -388,12 +387,24 @@ static int& conv_sp_flag() { static int on = !(getenv("ARCO_CONV_SP") && atoi(ge
 static bool conv_sp_on() { return conv_sp_flag() != 0; }
 extern "C" int arco_conv_sp_set(int on) { const int prev = conv_sp_flag(); conv_sp_flag() = on ? 1 : 0; return prev; }
 
+template <int C_T>
+static int dispatch_rows(const IgemmArgs& a, hipStream_t st, int* q, int min_tiles) {
+  // the tallest tile (4 A_T rows x 16 columns per workgroup) that still gives min_tiles work items: the deep levels have
+  // few pixels (32 x 32, 16 x 16 per image) and many channels
+  const long cols = (long)a.NB * (a.W / 16) * (a.N / (16 * C_T));
+  if (cols * (a.H / 16) >= min_tiles) return launch_sp<4, C_T>(a, st, q);
+  if ((a.H & 7) == 0 && cols * (a.H / 8) >= min_tiles) return launch_sp<2, C_T>(a, st, q);
+  if ((a.H & 3) == 0 && cols * (a.H / 4) >= min_tiles) return launch_sp<1, C_T>(a, st, q);
+  return -1;
+}
+
 int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   if (!conv_sp_on() || a.mma != 3 || a.D3 != 1) return -1;
-  if ((a.K & 15) != 0 || a.K < 16 || (a.N & 63) != 0 || a.N != a.Npad || a.N > 256 || (a.lda & 3) != 0 || (a.W & 15) != 0 || (a.H & 15) != 0) return -1;
-  // 64-channel output blocks only: with 32 (C_T = 2) a step has 48 MFMAs per wave against the same per-step issue costs
-  // (LDS-DMA, 18 fragment reads, barrier) and measures 10-25 % slower than igemm_kernel<9,128,32> (tools/micro/conv_sp_check.py)
-  const long tiles = (long)a.NB * (a.H / 16) * (a.W / 16);
-  if (tiles * (a.N / 64) < 192) return -1;
-  return launch_sp<4, 4>(a, st, q);
+  if ((a.K & 15) != 0 || a.K < 16 || (a.N & 15) != 0 || a.N != a.Npad || a.N > 256 || (a.lda & 3) != 0 || (a.W & 15) != 0 || (a.H & 3) != 0) return -1;
+  static const int min_tiles = getenv("ARCO_CONV_SP_TILES") ? atoi(getenv("ARCO_CONV_SP_TILES")) : 192;
+  static const int min_n = getenv("ARCO_CONV_SP_MINN") ? atoi(getenv("ARCO_CONV_SP_MINN")) : 32;
+  if (a.N < min_n) return -1;
+  if ((a.N & 63) == 0) return dispatch_rows<4>(a, st, q, min_tiles);
+  if ((a.N & 31) == 0) return dispatch_rows<2>(a, st, q, min_tiles);
+  return (a.H & 15) == 0 ? launch_sp<4, 1>(a, st, q) : -1;
 }

@@ -18,9 +18,12 @@ def timeit(fn, reps=40):
 
 torch.manual_seed(0)
 shapes = [(16, 64, 64, 64), (16, 32, 32, 128), (16, 128, 64, 64), (16, 32, 64, 64), (16, 64, 32, 128), (16, 64, 128, 64), (8, 64, 64, 64),
-          (16, 16, 32, 128), (16, 16, 32, 256), (16, 32, 32, 256), (16, 128, 128, 32), (3, 64, 64, 64), (16, 32, 64, 128)]
+          (16, 16, 32, 128), (16, 16, 32, 256), (16, 32, 32, 256), (16, 128, 128, 32), (3, 64, 64, 64), (16, 32, 64, 128),
+          (16, 16, 16, 256), (16, 32, 16, 256), (8, 16, 16, 256), (16, 32, 16, 128), (8, 32, 32, 128), (16, 256, 128, 32), (16, 128, 256, 32),
+          (16, 256, 256, 16), (8, 128, 128, 32), (8, 256, 256, 16), (16, 128, 256, 16), (16, 256, 128, 16), (8, 64, 64, 64), (8, 128, 64, 64),
+          (16, 64, 128, 32), (8, 64, 128, 32)]
 if len(sys.argv) > 1:
-    shapes = shapes[:int(sys.argv[1])]
+    shapes = shapes[int(sys.argv[2]) if len(sys.argv) > 2 else 0:int(sys.argv[1])]
 bad = 0
 for nb, ci, co, s in shapes:
     x = torch.randn(nb, s, s, ci, device="cuda").permute(0, 3, 1, 2)
