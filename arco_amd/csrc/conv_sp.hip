@@ -110,6 +110,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     // ================================================================ producer waves
     Desc d1 = d0; advance(d1);
     Desc d2 = d1; advance(d2);
+    Desc d3 = d2; advance(d3);
     const int qA = tid & 3;
     int hyA[NA], hxA[NA], ldsA[NA], toff[NA];
 #pragma unroll
@@ -135,11 +136,13 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     // statements: hipcc, which drains the LDS-DMA queue (vmcnt(0)) at the use of any load it knows of, does not see
     // them.  They sit in the per-wave VMEM order right behind a refill, so the step-1 wait (at most 2 NB younger
     // instructions in flight) certifies them; ra_fence() then orders every reader behind that wait.
-    f32x4 ra[NA]; unsigned okm = 0;
-    auto load_A = [&](const Desc& d, bool real) {
+    // Two register sets, loaded TWO chunks ahead (set = parity of the chunk the data belongs to): with 32-channel blocks
+    // a chunk lasts ~2 us, less than an HBM miss under load.
+    f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
+    auto load_A = [&](const Desc& d, bool real, int set) {
       const long base = (((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16;
       const float* pa[NA];
-      okm = 0;
+      unsigned okm = 0;
 #pragma unroll
       for (int it = 0; it < NA; ++it) {
         const int y = d.y0 + hyA[it] - 1, x = d.x0 + hxA[it] - 1;
@@ -147,15 +150,16 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
         pa[it] = ok ? a.A + base + toff[it] : a.A;
         okm |= ok ? (1u << it) : 0u;
       }
+      okm2[set] = okm;
 #pragma unroll
-      for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(pa[it]) : "memory");
+      for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set][it]) : "v"(pa[it]) : "memory");
     };
-    auto ra_fence = [&]() {
+    auto ra_fence = [&](int set) {
 #pragma unroll
-      for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[it])::"memory");
+      for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[set][it])::"memory");
     };
-    auto store_A = [&](unsigned* buf, int it) {    // split piece `it` into its three bf16 planes (zero outside the image)
-      const f32x4 v = ((okm >> it) & 1u) ? ra[it] : f32x4{0, 0, 0, 0};
+    auto store_A = [&](unsigned* buf, int it, int set) {    // split piece `it` into its three bf16 planes (zero outside the image)
+      const f32x4 v = ((okm2[set] >> it) & 1u) ? ra[set][it] : f32x4{0, 0, 0, 0};
       u32x2 p0, p1, p2;
       split3_bf16x4(v, p0, p1, p2);
       if (ldsA[it] >= 0) {
@@ -174,38 +178,41 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
       }
     };
 
-    // prologue.  Per-wave VMEM order, the one the step waits count on: A0 | R0 R1 R2 | A1 | R3
+    // prologue.  Per-wave VMEM order, the one the step waits count on: A0 | R0 R1 R2 | A1 A2 | R3
     for (int i = tid; i < G::BIAS_DW; i += 256) bias_s[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
-    load_A(d0, true);
+    load_A(d0, true, 0);
     refill(0, d0); refill(1, d0); refill(2, d0);
     wait_vm<3 * NB>();                // chunk 0's activations (the DMA behind them stays in flight)
-    ra_fence();
+    ra_fence(0);
 #pragma unroll
-    for (int it = 0; it < NA; ++it) store_A(As, it);
-    load_A(d1, total_gc > 1);         // (every wave issues every instruction, real or not: the counts below are exact)
+    for (int it = 0; it < NA; ++it) store_A(As, it, 0);
+    load_A(d1, total_gc > 1, 1);      // (every wave issues every instruction, real or not: the counts below are exact)
+    load_A(d2, total_gc > 2, 0);
     refill(3, d0);
     wait_vm<NA + 2 * NB>();           // slots 0 and 1 landed (own DMA); the barrier makes it everyone's
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();
 
-    for (int gc = 0; gc < total_gc; ++gc) {
+    auto pchunk = [&](auto SET_, int gc) {
+      constexpr int SET = decltype(SET_)::value;          // register set of chunk gc + 1 (= its parity)
       const bool more = gc + 1 < total_gc;
       unsigned* Anxt = As + ((gc + 1) & 1) * G::A_DW;
       auto step = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
-        // VMEM instructions younger than what this barrier (and, at step 1, the activation split) needs; order per chunk:
-        // s0 R4 | s1 R0' | s2 R1' | s3 R2' A' | s4 R3'   (the last chunk issues the same instructions on dummy addresses)
-        constexpr int NS = (S == 0 || S == 4) ? NA + 2 * NB : 2 * NB;
+        // VMEM instructions younger than what this barrier needs; order per chunk:
+        // s0 R4 | s1 R0' | s2 R1' | s3 R2' A+3 | s4 R3'   (the last chunks issue the same instructions on dummy addresses).
+        // The activations split at steps 1-3 were loaded two chunks ago: older than anything these waits leave in flight.
+        constexpr int NS = (S == 0 || S == 1 || S == 4) ? NA + 2 * NB : 2 * NB;
         wait_vm<NS>();
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();
         refill(S == 0 ? 4 : S - 1, S == 0 ? d0 : (more ? d1 : d0));     // the slot the previous step has finished with
-        if (S == 1) ra_fence();
+        if (S == 1) ra_fence(SET);
         if (S >= 1 && S <= 3) {
 #pragma unroll
-          for (int it = (S - 1) * NA3; it < S * NA3 && it < NA; ++it) store_A(Anxt, it);
+          for (int it = (S - 1) * NA3; it < S * NA3 && it < NA; ++it) store_A(Anxt, it, SET);
         }
-        if (S == 3) load_A(d2, gc + 2 < total_gc);
+        if (S == 3) load_A(d3, gc + 3 < total_gc, SET);
       };
       step(std::integral_constant<int, 0>{});
       step(std::integral_constant<int, 1>{});
@@ -216,7 +223,11 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();
       }
-      d0 = d1; d1 = d2; advance(d2);
+      d0 = d1; d1 = d2; d2 = d3; advance(d3);
+    };
+    for (int gc = 0; gc < total_gc; gc += 2) {
+      pchunk(std::integral_constant<int, 1>{}, gc);
+      if (gc + 1 < total_gc) pchunk(std::integral_constant<int, 0>{}, gc + 1);
     }
     wait_vm<0>();
     return;

@@ -114,8 +114,10 @@ def _kernel_name(key):
     if isinstance(key, tuple):
         return f"wgrad<taps={key[1]},co={key[2]},ci={key[3]}> (weight gradient, fp32 MFMA 16x16x4)"
     mma, key = key // 100000000, key % 100000000
+    if 9700000 <= key < 9900000:
+        return f"conv3x3_image_kernel<Cin={key % 100000 // 1000}> (few-channel input: the taps are the reduction dimension; {MMA_NAMES[mma]})"
     if 9600000 <= key < 9700000:
-        return f"conv3x3_sp_kernel<A_T={(key - 9600000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}, LDS-DMA weight ring, persistent workgroups)"
+        return f"conv3x3_sp_kernel<A_T={(key - 9600000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, LDS-DMA weight ring)"
     if key >= 9900000:
         return f"conv3x3_halo_kernel<{(key - 9900000) // 1000},{key % 1000},..> ({MMA_NAMES[mma]} implicit GEMM)"
     return f"igemm_kernel<{key // 1000000},{key // 1000 % 1000},{key % 1000},...,MMA={mma}> ({MMA_NAMES[mma]} implicit GEMM)"
