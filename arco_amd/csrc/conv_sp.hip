@@ -18,8 +18,7 @@
 //     matrix cores: the barrier of step s certifies slots s AND s+1.
 //   * D = W . X^T orientation: a lane ends up with 4 consecutive output channels of one pixel -> 16-byte stores.
 //
-// LDS: [2][AROWS][24] A planes + [5][slot] B ring + [2][4][BN] statistics scratch + N bias floats
-//      (A_T = 4, C_T = 4: 62,208 + 61,440 + 2,048 + 1,024 bytes).
+// LDS: [2][AROWS][24] A planes + [5][slot] B ring + N bias floats (A_T = 4, C_T = 4: 62,208 + 61,440 + 1,024 bytes).
 // Shapes taken (conv_sp_dispatch): K % 16 == 0, N % 64 == 0, H % 16 == 0, W % 16 == 0, 16-byte aligned rows, and
 // enough tiles to give most CUs one; everything else stays on igemm_kernel.
 #include "igemm_args.h"
@@ -37,9 +36,8 @@ struct SpGeom {
   static constexpr int NBI = (2 * BN * 6 + 255) / 256;          // LDS-DMA instructions per thread and slot
   static constexpr int SLOT_DW = NBI * 256 * 4;                 // slot stride in dwords (whole wave-instructions)
   static constexpr int NA_IT = (AROWS * 4 + 255) / 256;         // 16-byte activation loads per thread and chunk
-  static constexpr int RED_DW = 2 * 4 * BN;
   static constexpr int BIAS_DW = 256;
-  static constexpr size_t LDS_BYTES = (size_t)(2 * A_DW + 5 * SLOT_DW + RED_DW + BIAS_DW) * 4;
+  static constexpr size_t LDS_BYTES = (size_t)(2 * A_DW + 5 * SLOT_DW + BIAS_DW) * 4;
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -72,17 +70,16 @@ template <int A_T, int C_T>
 __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
   using G = SpGeom<A_T, C_T>;
   constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT, NB = G::NBI;
-  constexpr int NA3 = (NA + 2) / 3;                              // activation pieces split + written per staging step
+  constexpr int NA4 = (NA + 3) / 4;                              // activation pieces split + written per staging step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned* const As = reinterpret_cast<unsigned*>(smem);
   unsigned* const Bs = As + 2 * G::A_DW;
-  float* const red = reinterpret_cast<float*>(Bs + 5 * G::SLOT_DW);
-  float* const bias_s = red + G::RED_DW;
+  float* const bias_s = reinterpret_cast<float*>(Bs + 5 * G::SLOT_DW);
 
   // 8 waves: 0-3 consume (fragment reads + MFMAs, one per SIMD), 4-7 produce (LDS-DMA refills, activation loads, split and
   // LDS writes).  A SIMD then always has a wave that can issue while the other waits - on a single wave per SIMD the
   // issue cost of the DMA instructions and the split VALU work sat between the MFMAs.  Both roles pass the same
-  // barriers: one before the first step, one per step, one per tile with BN statistics.
+  // barriers: one before the first step, one per step.
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
   const bool producer = threadIdx.x >= 256;
   const int tiles_x = a.W >> 4, tiles_y = a.H / TH, tiles_img = tiles_x * tiles_y;
@@ -178,7 +175,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
       }
     };
 
-    // prologue.  Per-wave VMEM order, the one the step waits count on: A0 | R0 R1 R2 | A1 A2 | R3
+    // prologue.  Per-wave VMEM order: A0 | R0 R1 R2 | R3 | A1 A2  (the steady state's "... R3' A+3" tail)
     for (int i = tid; i < G::BIAS_DW; i += 256) bias_s[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
     load_A(d0, true, 0);
     refill(0, d0); refill(1, d0); refill(2, d0);
@@ -186,10 +183,10 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     ra_fence(0);
 #pragma unroll
     for (int it = 0; it < NA; ++it) store_A(As, it, 0);
+    refill(3, d0);
     load_A(d1, total_gc > 1, 1);      // (every wave issues every instruction, real or not: the counts below are exact)
     load_A(d2, total_gc > 2, 0);
-    refill(3, d0);
-    wait_vm<NA + 2 * NB>();           // slots 0 and 1 landed (own DMA); the barrier makes it everyone's
+    wait_vm<NA>();                    // chunk 1's activations (split from step 0 on) and with them slots 0-3
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();
 
@@ -200,29 +197,25 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
       auto step = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
         // VMEM instructions younger than what this barrier needs; order per chunk:
-        // s0 R4 | s1 R0' | s2 R1' | s3 R2' A+3 | s4 R3'   (the last chunks issue the same instructions on dummy addresses).
-        // The activations split at steps 1-3 were loaded two chunks ago: older than anything these waits leave in flight.
-        constexpr int NS = (S == 0 || S == 1 || S == 4) ? NA + 2 * NB : 2 * NB;
+        // s0 R4 | s1 R0' | s2 R1' | s3 R2' | s4 R3' A+3   (the last chunks issue the same instructions on dummy addresses).
+        // The activations split at steps 0-3 were loaded two chunks ago: older than anything these waits leave in flight.
+        constexpr int NS = S <= 2 ? NA + 2 * NB : 2 * NB;
         wait_vm<NS>();
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();
         refill(S == 0 ? 4 : S - 1, S == 0 ? d0 : (more ? d1 : d0));     // the slot the previous step has finished with
-        if (S == 1) ra_fence(SET);
-        if (S >= 1 && S <= 3) {
+        if (S == 0) ra_fence(SET);
+        if (S <= 3) {                  // a quarter of the next chunk's activation tile per step, the loads in the fifth
 #pragma unroll
-          for (int it = (S - 1) * NA3; it < S * NA3 && it < NA; ++it) store_A(Anxt, it, SET);
+          for (int it = S * NA4; it < (S + 1) * NA4 && it < NA; ++it) store_A(Anxt, it, SET);
         }
-        if (S == 3) load_A(d3, gc + 3 < total_gc, SET);
+        if (S == 4) load_A(d3, gc + 3 < total_gc, SET);
       };
       step(std::integral_constant<int, 0>{});
       step(std::integral_constant<int, 1>{});
       step(std::integral_constant<int, 2>{});
       step(std::integral_constant<int, 3>{});
       step(std::integral_constant<int, 4>{});
-      if (d0.c + 1 == nchunks && has_stats) {       // the consumers' statistics barrier
-        wait_lgkm0();
-        __builtin_amdgcn_s_barrier();
-      }
       d0 = d1; d1 = d2; d2 = d3; advance(d3);
     };
     for (int gc = 0; gc < total_gc; gc += 2) {
@@ -331,26 +324,18 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
         acc[at][ct] = f32x4{0, 0, 0, 0};
       }
     }
-    if (has_stats) {
+    if (has_stats) {       // one partial per WAVE (4 slabs per tile): no LDS round trip, no barrier inside the pipeline
+      const long slab = (long)d0.mblk * 4 + wid, nslab = (long)a.n_mblocks * 4;
 #pragma unroll
       for (int ct = 0; ct < C_T; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v1 = row16_sum(s1[ct][r]), v2 = row16_sum(s2[ct][r]);
           if (li == 0) {
-            red[(0 * 4 + wid) * BN + ct * 16 + 4 * g + r] = v1;
-            red[(1 * 4 + wid) * BN + ct * 16 + 4 * g + r] = v2;
+            a.stat_sum[(n0 + ct * 16 + 4 * g + r) * nslab + slab] = v1;
+            a.stat_sq[(n0 + ct * 16 + 4 * g + r) * nslab + slab] = v2;
           }
         }
-      wait_lgkm0();
-      __builtin_amdgcn_s_barrier();
-      for (int nl = tid; nl < BN; nl += 256) {
-        float v1 = 0.f, v2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { v1 += red[(0 * 4 + w) * BN + nl]; v2 += red[(1 * 4 + w) * BN + nl]; }
-        a.stat_sum[(long)(n0 + nl) * a.n_mblocks + d0.mblk] = v1;
-        a.stat_sq[(long)(n0 + nl) * a.n_mblocks + d0.mblk] = v2;
-      }
     }
   };
 
@@ -381,7 +366,7 @@ template <int A_T, int C_T>
 static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
   using G = SpGeom<A_T, C_T>;
   const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
-  if (q) { q[0] = mblocks; q[1] = 9600000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
+  if (q) { q[0] = 4 * mblocks; q[1] = 9600000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }      // 4 stat slabs per tile
   if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
   auto kern = conv3x3_sp_kernel<A_T, C_T>;
   static bool attr_set = false;

@@ -100,12 +100,27 @@ def test_feature_extractor_vs_golden(golden, tag, dims, od):
             np.testing.assert_allclose(f.grad.double().abs().sum().item(), g[tag + f"_dx{i}_sum"][1], rtol=2e-3)
 
 
-@pytest.mark.parametrize("nb,H,W,grads", [(4, 64, 96, True), (8, 256, 256, False)])
-def test_bn_groups_equal_separate_passes(nb, H, W, grads):
+@pytest.mark.parametrize("nb,H,W,grads,sp", [(4, 64, 96, True, 0), (4, 64, 96, True, 1), (8, 256, 256, False, 1)])
+def test_bn_groups_equal_separate_passes(nb, H, W, grads, sp):
     """`with ops.bn_groups(2)`: one pass over cat(xa, xb) == a pass over xa then a pass over xb (outputs, every
     parameter gradient, BN running statistics and num_batches_tracked), dropout off.  Second case: BASELINE.json
     configs[1] size (8 + 8 images of 256 x 256) - outputs and running statistics (gradients through ~1e7 LeakyReLU
-    kinks are compared at the small size only)."""
+    kinks are compared at the small size only).  sp = 0: every conv on igemm_kernel in both runs - the grouping logic
+    alone, gradients to 2e-3 of their scale; sp = 1 (the default dispatch): the 8-image launch and the 4-image launches
+    take different kernels (conv_sp.hip tile heights, igemm_kernel), whose BN partial sums are partitioned differently
+    - outputs still agree to 2e-4; a pre-activation within rounding distance of a LeakyReLU kink then falls on different
+    sides in the two runs (one flipped element among the 96 pixels of the deepest level moves a weight gradient by ~1 %),
+    so the gradients are compared in the L2 norm over all parameters (2e-2) instead of element by element."""
+    import torch
+    from arco_amd import ops, _lib as L_
+    prev_sp = L_.load().arco_conv_sp_set(sp)
+    try:
+        _bn_groups_case(nb, H, W, grads, 2e-3 if sp == 0 else None)
+    finally:
+        L_.load().arco_conv_sp_set(prev_sp)
+
+
+def _bn_groups_case(nb, H, W, grads, gtol):
     import torch
     from arco_amd import ops
     from arco_amd.networks import unetWithArgs as U
@@ -136,12 +151,18 @@ def test_bn_groups_equal_separate_passes(nb, H, W, grads):
     for f, a, b in zip(fm, fa, fb):
         torch.testing.assert_close(f[:nb], a.detach(), rtol=2e-4, atol=2e-5)
         torch.testing.assert_close(f[nb:], b.detach(), rtol=2e-4, atol=2e-5)
+    num = den = 0.0
     for (n, _), gs, gg in zip(m.named_parameters(), g_sep, g_grp if grads else ()):
         if gs is None:
             assert gg is None or float(gg.abs().max()) == 0.0, n
             continue
         scale = float(gs.abs().max()) + 1e-12
-        assert float((gs - gg).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((gs - gg).abs().max()), scale)
+        if gtol is None:
+            num += float(((gs - gg).double() ** 2).sum()); den += float((gs.double() ** 2).sum())
+            continue
+        assert float((gs - gg).abs().max()) <= gtol * scale + 1e-7, (n, float((gs - gg).abs().max()), scale)
+    if gtol is None and grads:
+        assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
     for k, v in m.state_dict().items():
         if v.is_floating_point():
             torch.testing.assert_close(v, state_sep[k], rtol=1e-4, atol=1e-6, msg=k)
