@@ -85,15 +85,23 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
   const int tiles_x = a.W >> 4, tiles_y = a.H / TH, tiles_img = tiles_x * tiles_y;
   const int nchunks = a.K >> 4;
   const int total_tiles = a.n_mblocks * a.n_nblocks;
-  const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so XCD x gets the x-th
+  // CONTIGUOUS eighth of the tiles - neighbouring tiles (shared halo rows, the N-blocks of one pixel tile) meet in one L2
+  const bool xcd_map = (gridDim.x & 7) == 0;
+  const int G8 = xcd_map ? (int)gridDim.x >> 3 : (int)gridDim.x;
+  const int T8 = xcd_map ? (total_tiles + 7) >> 3 : total_tiles;
+  const int tile0 = xcd_map ? ((int)blockIdx.x & 7) * T8 + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int tile_end_x = xcd_map ? min(total_tiles, (((int)blockIdx.x & 7) + 1) * T8) : total_tiles;
+  const int my_tiles = tile0 < tile_end_x ? (tile_end_x - tile0 + G8 - 1) / G8 : 0;
   const int total_gc = my_tiles * nchunks;
+  if (my_tiles == 0) return;
   const bool has_stats = a.stat_sum != nullptr;
 
   // chunk descriptors (tile ordinal j of this workgroup, 16-channel chunk c), advanced incrementally: the divisions of the
   // tile decode run once per tile, not once per load
   struct Desc { int j, c, img, y0, x0, nblk, mblk; };
   auto decode = [&](Desc& d) {
-    const int v = (int)blockIdx.x + d.j * (int)gridDim.x;
+    const int v = tile0 + d.j * G8;
     d.mblk = v / a.n_nblocks; d.nblk = v - d.mblk * a.n_nblocks;
     d.img = d.mblk / tiles_img;
     const int r = d.mblk - d.img * tiles_img, ty = r / tiles_x;

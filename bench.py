@@ -52,7 +52,9 @@ PMC_TRAFFIC_BYTES = {(9, 65536, 64, 64): 3.526e7, (9, 65536, 64, 128): 5.322e7,
 
 
 # (taps, M, N, K) -> HBM bytes per launch of the split-bf16 kernels (profiles/r02_pmc_conv_traffic.md)
-PMC_TRAFFIC_SPLIT = {(9, 65536, 64, 64): 3.591e7, (9, 65536, 64, 128): 5.446e7, (9, 32768, 64, 64): 1.905e7, (9, 32768, 64, 128): 2.920e7}
+# conv3x3_sp_kernel launches, profiles/r02_pmc_conv_sp_traffic.md (keys: taps, M, N, K)
+PMC_TRAFFIC_SPLIT = {(9, 65536, 64, 64): 3.647e7, (9, 65536, 64, 128): 5.502e7, (9, 262144, 32, 32): 6.904e7, (9, 262144, 32, 64): 1.0304e8,
+                     (9, 1048576, 32, 16): 2.0646e8, (9, 16384, 128, 128): 2.479e7, (9, 32768, 64, 64): 1.948e7}
 
 
 def cpu_baseline_child():
