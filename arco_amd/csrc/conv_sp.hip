@@ -370,6 +370,279 @@ static int conv_sp_cus() {
   return n;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Resident-weights variant for the shallow levels (K <= 32 input channels, N = 16 or 32 outputs: the 256^2 and 128^2 planes
+// of the U-Net).  All packed weights of the launch (at most 61 KB: 2 chunks x 10 tap rows x 32 channels x 96 B) are copied to
+// LDS once by LDS-DMA, so a step needs no ring slot, no refill and NO barrier: the consumer streams a chunk's 5 steps
+// back to back and meets the producers once per chunk (at the head of step 4: "the other activation buffer is complete,
+// this one is free from now on"), instead of five times.  With 24-48 MFMAs per wave and step the per-step barrier and DMA
+// issue of conv3x3_sp_kernel cost as much as the MFMAs themselves at these widths.
+// Pixel-tile-major MFMA order: ONE A fragment set - the chains of a 16-pixel tile run over the step's B groups back to
+// back, then the next step's fragments of that tile are read into the registers just released - and two sets of a step's
+// B groups, used alternately by consecutive steps.  Producers as in conv3x3_sp_kernel (asm loads two chunks ahead, split
+// to bf16 planes), a whole chunk time per tile.  LDS: [2][AROWS][24] A planes + [nchunks][10][BN][24] weights + bias.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int A_T, int C_T>
+struct RwGeom {
+  static constexpr int TH = 4 * A_T, AROWS = (TH + 2) * 18, BN = C_T * 16;
+  static constexpr int A_DW = AROWS * 24;
+  static constexpr int WCH_DW = 10 * BN * 24;                   // one chunk of weights: 9 taps + the zero tap
+  static constexpr int NA_IT = (AROWS * 4 + 255) / 256;
+  static constexpr int BIAS_DW = 64;
+  static size_t lds_bytes(int nchunks) { return (size_t)(2 * A_DW + nchunks * WCH_DW + BIAS_DW) * 4; }
+};
+
+template <int A_T, int C_T>
+__global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
+  using G = RwGeom<A_T, C_T>;
+  constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned* const As = reinterpret_cast<unsigned*>(smem);
+  const int nchunks = a.K >> 4;
+  unsigned* const Ws = As + 2 * G::A_DW;
+  float* const bias_s = reinterpret_cast<float*>(Ws + nchunks * G::WCH_DW);
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const bool producer = threadIdx.x >= 256;
+  const int tiles_x = a.W >> 4, tiles_y = a.H / TH, tiles_img = tiles_x * tiles_y;
+  const int total_tiles = a.n_mblocks;                        // (one N-block: N == BN)
+  const bool xcd_map = (gridDim.x & 7) == 0;
+  const int G8 = xcd_map ? (int)gridDim.x >> 3 : (int)gridDim.x;
+  const int T8 = xcd_map ? (total_tiles + 7) >> 3 : total_tiles;
+  const int tile0 = xcd_map ? ((int)blockIdx.x & 7) * T8 + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int tile_end_x = xcd_map ? min(total_tiles, (((int)blockIdx.x & 7) + 1) * T8) : total_tiles;
+  const int my_tiles = tile0 < tile_end_x ? (tile_end_x - tile0 + G8 - 1) / G8 : 0;
+  const int total_gc = my_tiles * nchunks;
+  if (my_tiles == 0) return;
+  const bool has_stats = a.stat_sum != nullptr;
+  struct Desc { int j, c, img, y0, x0, mblk; };
+  auto decode = [&](Desc& d) {
+    d.mblk = tile0 + d.j * G8;
+    d.img = d.mblk / tiles_img;
+    const int r = d.mblk - d.img * tiles_img, ty = r / tiles_x;
+    d.y0 = ty * TH; d.x0 = (r - ty * tiles_x) * 16;
+  };
+  auto advance = [&](Desc& d) { if (++d.c == nchunks) { d.c = 0; ++d.j; decode(d); } };
+  Desc d0{0, 0, 0, 0, 0, 0};
+  decode(d0);
+
+  if (producer) {
+    // ---- weights: [chunk][step][tapL][n][24 dwords]; the zero tap (step 4, tapL 1) comes from the zero row
+    const float* const zrow = reinterpret_cast<const float*>(conv_sp_zero_row);
+    const int wpieces = nchunks * 10 * BN * 6;
+    for (int p0 = wid * 64; p0 < wpieces; p0 += 256) {        // one wave-instruction = 64 pieces = 1 KB, contiguous in LDS
+      const int p = p0 + lane;
+      const int q6 = p % 6, row = p / 6, n = row % BN, tp = (row / BN) % 10, c = row / (BN * 10);
+      const float* src = (tp < 9 && p < wpieces) ? a.Wp + (((long)tp * a.Npad + n) * a.Kg + c) * 24 + q6 * 4 : zrow + q6 * 4;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(Ws + p0 * 4), 16, 0, 0);
+    }
+    for (int i = tid; i < G::BIAS_DW; i += 256) bias_s[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
+    Desc d1 = d0; advance(d1);
+    Desc d2 = d1; advance(d2);
+    Desc d3 = d2; advance(d3);
+    const int qA = tid & 3;
+    int hyA[NA], hxA[NA], ldsA[NA], toff[NA];
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int row = (tid + it * 256) >> 2;
+      hyA[it] = row / 18; hxA[it] = row - hyA[it] * 18;
+      ldsA[it] = row < G::AROWS ? row * 24 + qA * 2 : -1;
+      toff[it] = (hyA[it] * a.W + hxA[it]) * (int)a.lda + qA * 4;
+    }
+    f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
+    auto load_A = [&](const Desc& d, bool real, int set) {
+      const long base = (((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16;
+      const float* pa[NA];
+      unsigned okm = 0;
+#pragma unroll
+      for (int it = 0; it < NA; ++it) {
+        const int y = d.y0 + hyA[it] - 1, x = d.x0 + hxA[it] - 1;
+        const bool ok = real && ldsA[it] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        pa[it] = ok ? a.A + base + toff[it] : a.A;
+        okm |= ok ? (1u << it) : 0u;
+      }
+      okm2[set] = okm;
+#pragma unroll
+      for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set][it]) : "v"(pa[it]) : "memory");
+    };
+    auto store_all = [&](unsigned* buf, int set) {
+#pragma unroll
+      for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[set][it])::"memory");
+#pragma unroll
+      for (int it = 0; it < NA; ++it) {
+        const f32x4 v = ((okm2[set] >> it) & 1u) ? ra[set][it] : f32x4{0, 0, 0, 0};
+        u32x2 p0, p1, p2;
+        split3_bf16x4(v, p0, p1, p2);
+        if (ldsA[it] >= 0) {
+          unsigned* d = buf + ldsA[it];
+          *reinterpret_cast<u32x2_ma*>(d) = p0; *reinterpret_cast<u32x2_ma*>(d + 8) = p1; *reinterpret_cast<u32x2_ma*>(d + 16) = p2;
+        }
+      }
+    };
+    // chunk 0 -> buffer 0, chunk 1 -> buffer 1 (both before the first barrier), chunks 2 and 3 in flight
+    load_A(d0, true, 0);
+    load_A(d1, total_gc > 1, 1);
+    wait_vm<0>();                      // (the weight DMA too)
+    store_all(As, 0);
+    store_all(As + G::A_DW, 1);
+    load_A(d2, total_gc > 2, 0);
+    load_A(d3, total_gc > 3, 1);
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();      // B0: weights, bias, buffers 0 and 1
+    // barrier k (k = 0 .. total_gc - 1; the consumer passes it at the head of step 4 of chunk k): buffer k & 1 is free,
+    // buffer (k + 1) & 1 is complete.  Behind it: chunk k + 2 -> buffer k & 1, then the loads of chunk k + 4.
+    Desc dn = d3; advance(dn);         // chunk k + 4
+    for (int k = 0; k < total_gc; k += 2) {          // two chunks per trip: the register sets keep their roles at the loop edge
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
+      wait_vm<NA>();                   // chunk k + 2 has landed (only the loads of chunk k + 3 are younger)
+      store_all(As, 0);
+      load_A(dn, k + 4 < total_gc, 0);
+      advance(dn);
+      if (k + 1 < total_gc) {
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+        wait_vm<NA>();
+        store_all(As + G::A_DW, 1);
+        load_A(dn, k + 5 < total_gc, 1);
+        advance(dn);
+      }
+    }
+    wait_vm<0>();
+    return;
+  }
+
+  // ================================================================== consumer waves
+  const int tl = g >> 1;
+  int aoff[5];
+#pragma unroll
+  for (int s_ = 0; s_ < 5; ++s_) {
+    const int tap = 2 * s_ + tl > 8 ? 8 : 2 * s_ + tl;
+    aoff[s_] = ((tap / 3) * 18 + tap % 3) * 24;
+  }
+  const int laneA = (wid * A_T * 18 + li) * 24 + (g & 1) * 4;
+  const int laneB = (tl * BN + li) * 24 + (g & 1) * 4;             // within a step's [tapL][n] block
+  bf16x8 fa[A_T][3], fb[2][C_T][3];
+  f32x4 acc[A_T][C_T];
+#pragma unroll
+  for (int i = 0; i < A_T; ++i)
+#pragma unroll
+    for (int j = 0; j < C_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  __builtin_amdgcn_s_barrier();        // B0
+#pragma unroll
+  for (int at = 0; at < A_T; ++at)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) fa[at][pl] = lds_bf16x8(As + laneA + aoff[0] + at * 18 * 24 + 8 * pl);
+#pragma unroll
+  for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) fb[0][ct][pl] = lds_bf16x8(Ws + laneB + ct * 16 * 24 + 8 * pl);
+
+  auto chunk = [&](auto CP_, int gc, int c, bool more) {
+    constexpr int CP = decltype(CP_)::value;               // B set of step 0 (5 steps per chunk: alternates per chunk)
+    const unsigned* Acur = As + (gc & 1) * G::A_DW;
+    const unsigned* Anxt = As + ((gc + 1) & 1) * G::A_DW;
+    const unsigned* Wc = Ws + c * G::WCH_DW;
+    const unsigned* Wn = Ws + (c + 1 == nchunks ? 0 : c + 1) * G::WCH_DW;
+    auto step = [&](auto S_) {
+      constexpr int S = decltype(S_)::value;
+      constexpr int P = (CP + S) & 1, Q = P ^ 1;
+      if (S == 4) {                    // the one rendezvous of the chunk: the next chunk's activations are complete
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+      }
+      constexpr int BPA = (C_T * 3 + A_T - 1) / A_T;        // next-step B reads per pixel tile
+      const unsigned* An = S < 4 ? Acur : Anxt;
+      const unsigned* Wb = (S < 4 ? Wc : Wn) + ((S + 1) % 5) * (2 * BN * 24);
+#pragma unroll
+      for (int at = 0; at < A_T; ++at) {
+#pragma unroll
+        for (int ct = 0; ct < C_T; ++ct) {                  // D = W . X^T; small terms first
+          mfma_acc(acc[at][ct], fb[P][ct][0], fa[at][2]);
+          mfma_acc(acc[at][ct], fb[P][ct][2], fa[at][0]);
+          mfma_acc(acc[at][ct], fb[P][ct][1], fa[at][1]);
+          mfma_acc(acc[at][ct], fb[P][ct][0], fa[at][1]);
+          mfma_acc(acc[at][ct], fb[P][ct][1], fa[at][0]);
+          mfma_acc(acc[at][ct], fb[P][ct][0], fa[at][0]);
+        }
+        if (S < 4 || more) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fa[at][pl] = lds_bf16x8(An + laneA + aoff[(S + 1) % 5] + at * 18 * 24 + 8 * pl);
+        }
+#pragma unroll
+        for (int k = at * BPA; k < (at + 1) * BPA && k < C_T * 3; ++k)
+          fb[Q][k / 3][k % 3] = lds_bf16x8(Wb + laneB + (k / 3) * 16 * 24 + 8 * (k % 3));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+  };
+  auto tile_end = [&]() {
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float s1[C_T][4], s2[C_T][4];
+#pragma unroll
+    for (int ct = 0; ct < C_T; ++ct) {
+      const int n = ct * 16 + 4 * g;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; }
+#pragma unroll
+      for (int at = 0; at < A_T; ++at) {
+        const long pix = ((long)d0.img * a.H + d0.y0 + wid * A_T + at) * a.W + d0.x0 + li;
+        f32x4 v = acc[at][ct] + bv;
+        if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + pix * a.ldr + n);
+        *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + n) = v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[ct][r] += v[r]; s2[ct][r] += v[r] * v[r]; }
+        acc[at][ct] = f32x4{0, 0, 0, 0};
+      }
+    }
+    if (has_stats) {
+      const long slab = (long)d0.mblk * 4 + wid, nslab = (long)a.n_mblocks * 4;
+#pragma unroll
+      for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v1 = row16_sum(s1[ct][r]), v2 = row16_sum(s2[ct][r]);
+          if (li == 0) {
+            a.stat_sum[(ct * 16 + 4 * g + r) * nslab + slab] = v1;
+            a.stat_sq[(ct * 16 + 4 * g + r) * nslab + slab] = v2;
+          }
+        }
+    }
+  };
+  for (int gc = 0; gc < total_gc; gc += 2) {
+    chunk(std::integral_constant<int, 0>{}, gc, d0.c, gc + 1 < total_gc);
+    if (d0.c + 1 == nchunks) tile_end();
+    advance(d0);
+    if (gc + 1 < total_gc) {
+      chunk(std::integral_constant<int, 1>{}, gc + 1, d0.c, gc + 2 < total_gc);
+      if (d0.c + 1 == nchunks) tile_end();
+      advance(d0);
+    }
+  }
+}
+
+template <int A_T, int C_T>
+static int launch_rw(const IgemmArgs& a, hipStream_t st, int* q) {
+  using G = RwGeom<A_T, C_T>;
+  const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
+  if (q) { q[0] = 4 * mblocks; q[1] = 9650000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
+  if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
+  auto kern = conv3x3_rw_kernel<A_T, C_T>;
+  const size_t lds = G::lds_bytes(a.K >> 4);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  IgemmArgs b = a;
+  b.n_mblocks = mblocks; b.n_nblocks = 1;
+  const int cus = conv_sp_cus();
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3(512), lds, st, b);
+  return arco_launch_status();
+}
+
 template <int A_T, int C_T>
 static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
   using G = SpGeom<A_T, C_T>;
@@ -406,8 +679,13 @@ int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   if (!conv_sp_on() || a.mma != 3 || a.D3 != 1) return -1;
   if ((a.K & 15) != 0 || a.K < 16 || (a.N & 15) != 0 || a.N != a.Npad || a.N > 256 || (a.lda & 3) != 0 || (a.W & 15) != 0 || (a.H & 3) != 0) return -1;
   static const int min_tiles = getenv("ARCO_CONV_SP_TILES") ? atoi(getenv("ARCO_CONV_SP_TILES")) : 192;
-  static const int min_n = getenv("ARCO_CONV_SP_MINN") ? atoi(getenv("ARCO_CONV_SP_MINN")) : 32;
+  static const int min_n = getenv("ARCO_CONV_SP_MINN") ? atoi(getenv("ARCO_CONV_SP_MINN")) : 16;
   if (a.N < min_n) return -1;
+  static const int rw = getenv("ARCO_CONV_RW") ? atoi(getenv("ARCO_CONV_RW")) : 1;
+  if (rw && a.K <= 32 && (a.N == 16 || a.N == 32)) {            // shallow levels: resident weights, one rendezvous per chunk
+    if (a.N == 32 && (a.H & 15) == 0 && (long)a.NB * (a.H / 16) * (a.W / 16) >= min_tiles) return launch_rw<4, 2>(a, st, q);
+    if (a.N == 16 && (a.H & 31) == 0 && (long)a.NB * (a.H / 32) * (a.W / 16) >= min_tiles) return launch_rw<8, 1>(a, st, q);
+  }
   if ((a.N & 63) == 0) return dispatch_rows<4>(a, st, q, min_tiles);
   if ((a.N & 31) == 0) return dispatch_rows<2>(a, st, q, min_tiles);
   return (a.H & 15) == 0 ? launch_sp<4, 1>(a, st, q) : -1;

@@ -118,6 +118,8 @@ def _kernel_name(key):
     mma, key = key // 100000000, key % 100000000
     if 9700000 <= key < 9900000:
         return f"conv3x3_image_kernel<Cin={key % 100000 // 1000}> (few-channel input: the taps are the reduction dimension; {MMA_NAMES[mma]})"
+    if 9650000 <= key < 9700000:
+        return f"conv3x3_rw_kernel<A_T={(key - 9650000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, weights resident in LDS)"
     if 9600000 <= key < 9700000:
         return f"conv3x3_sp_kernel<A_T={(key - 9600000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, LDS-DMA weight ring)"
     if key >= 9900000:

@@ -94,13 +94,16 @@ def test_split_weights_pack_is_an_exact_decomposition():
 @pytest.mark.parametrize("shape", [dict(nb=16, ci=64, co=64, s=64), dict(nb=12, ci=32, co=128, s=64), dict(nb=3, ci=16, co=64, s=128),
                                    dict(nb=17, ci=128, co=64, s=64), dict(nb=16, ci=32, co=32, s=128), dict(nb=5, ci=16, co=32, s=256),
                                    dict(nb=16, ci=128, co=128, s=32), dict(nb=16, ci=256, co=256, s=16), dict(nb=8, ci=48, co=96, s=64),
-                                   dict(nb=12, ci=64, co=64, s=32)])
+                                   dict(nb=12, ci=64, co=64, s=32), dict(nb=16, ci=32, co=16, s=256), dict(nb=8, ci=32, co=16, s=128),
+                                   dict(nb=16, ci=32, co=32, s=256), dict(nb=7, ci=16, co=32, s=128)])
 def test_pipelined_3x3_kernel_equals_igemm_kernel(shape):
     """conv_sp.hip (persistent workgroups of 4 MFMA + 4 loader waves, LDS-DMA weight ring, software-pipelined fragment
     reads) computes the same products in the same order as igemm_kernel<9,..,MMA=3>: outputs bit-identical, BN partial
     sums equal to fp32 rounding of a different slab partition, both within fp32 rounding of an fp64 convolution.  Covered:
     several tiles per workgroup (nb=17: 272 > 256 tiles, ragged; odd and even chunk counts per workgroup), one chunk
-    (K = 16), 32- and 64-channel blocks, two to four N-blocks, the 8- and 4-row tiles of the deep levels, N = 96 (32-blocks)."""
+    (K = 16), 32- and 64-channel blocks, two to four N-blocks, the 8- and 4-row tiles of the deep levels, N = 96 (32-blocks),
+    and the resident-weights kernel of the shallow levels (conv3x3_rw_kernel: K <= 32, N = 16 / 32; one and two chunks, odd
+    and even chunk counts, 16+ tiles per workgroup)."""
     from arco_amd import _lib as L, ops
     nb, ci, co, s = shape["nb"], shape["ci"], shape["co"], shape["s"]
     g = torch.Generator().manual_seed(ci * 1000 + co)
