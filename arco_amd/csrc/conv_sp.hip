@@ -630,7 +630,7 @@ template <int A_T, int C_T>
 static int launch_rw(const IgemmArgs& a, hipStream_t st, int* q) {
   using G = RwGeom<A_T, C_T>;
   const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
-  if (q) { q[0] = 4 * mblocks; q[1] = 9650000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
+  if (q) { q[0] = 4 * mblocks; q[1] = 9350000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
   if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
   auto kern = conv3x3_rw_kernel<A_T, C_T>;
   const size_t lds = G::lds_bytes(a.K >> 4);
@@ -647,7 +647,7 @@ template <int A_T, int C_T>
 static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
   using G = SpGeom<A_T, C_T>;
   const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
-  if (q) { q[0] = 4 * mblocks; q[1] = 9600000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }      // 4 stat slabs per tile
+  if (q) { q[0] = 4 * mblocks; q[1] = 9300000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }      // 4 stat slabs per tile
   if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
   auto kern = conv3x3_sp_kernel<A_T, C_T>;
   static bool attr_set = false;

@@ -348,11 +348,14 @@ __global__ __launch_bounds__(256) void tps_grid_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < B * NR * 2; i += 256) mp[i] = mapping[i];
   __syncthreads();
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    float r[32];
-    for (int k = 0; k < NR; ++k) r[k] = rep[p * NR + k];
+    float r[32];                         // (static indexing: registers, no scratch - a scratch-using kernel's first launch
+#pragma unroll                           //  waits ~28 ms for the runtime to set the scratch arena up)
+    for (int k = 0; k < 32; ++k) r[k] = k < NR ? rep[p * NR + k] : 0.f;
     for (int b = 0; b < B; ++b) {
       float gx = 0.f, gy = 0.f;
-      for (int k = 0; k < NR; ++k) { gx += r[k] * mp[(b * NR + k) * 2]; gy += r[k] * mp[(b * NR + k) * 2 + 1]; }
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k < NR) { gx += r[k] * mp[(b * NR + k) * 2]; gy += r[k] * mp[(b * NR + k) * 2 + 1]; }
       grid[((long)b * HW + p) * 2] = gx; grid[((long)b * HW + p) * 2 + 1] = gy;
     }
   }

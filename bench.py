@@ -118,10 +118,12 @@ def _kernel_name(key):
     mma, key = key // 100000000, key % 100000000
     if 9700000 <= key < 9900000:
         return f"conv3x3_image_kernel<Cin={key % 100000 // 1000}> (few-channel input: the taps are the reduction dimension; {MMA_NAMES[mma]})"
-    if 9650000 <= key < 9700000:
-        return f"conv3x3_rw_kernel<A_T={(key - 9650000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, weights resident in LDS)"
-    if 9600000 <= key < 9700000:
-        return f"conv3x3_sp_kernel<A_T={(key - 9600000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, LDS-DMA weight ring)"
+    if 9500000 <= key < 9700000:        # flat-position tiles of the 3x3x3 kernels (narrow planes)
+        return f"igemm_kernel<9,{(key - 9500000) // 1000},{key % 1000},...,FLAT,MMA={mma}> ({MMA_NAMES[mma]} implicit GEMM, 3x3x3 depth taps looped)"
+    if 9350000 <= key < 9400000:
+        return f"conv3x3_rw_kernel<A_T={(key - 9350000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, weights resident in LDS)"
+    if 9300000 <= key < 9350000:
+        return f"conv3x3_sp_kernel<A_T={(key - 9300000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, LDS-DMA weight ring)"
     if key >= 9900000:
         return f"conv3x3_halo_kernel<{(key - 9900000) // 1000},{key % 1000},..> ({MMA_NAMES[mma]} implicit GEMM)"
     return f"igemm_kernel<{key // 1000000},{key // 1000 % 1000},{key % 1000},...,MMA={mma}> ({MMA_NAMES[mma]} implicit GEMM)"

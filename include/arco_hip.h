@@ -111,7 +111,7 @@ int arco_conv_mblocks_mma(int taps, int NB, int H, int W, int Cin, int Cout, lon
  * conv3x3_halo_kernel<CIN,COUT,..> -> 9.9e6 + CIN*1e3 + COUT */
 int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int* kc_depth_db);
 int arco_conv_config_mma(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int mma);
-/* A/B switch of the software-pipelined split-bf16 3x3 kernel (conv_sp.hip; ids 9.6e6 + A_T*1e3 + BN): on = 1 (default,
+/* A/B switch of the software-pipelined split-bf16 3x3 kernel (conv_sp.hip; ids 9.3e6 + A_T*1e3 + BN, resident-weights form 9.35e6 + ...): on = 1 (default,
  * or ARCO_CONV_SP=0 in the environment for off) lets the eligible wide 2-D shapes take it, 0 keeps every shape on
  * igemm_kernel.  Returns the previous setting.  Tile counts differ: query arco_conv_mblocks_mma after switching.   */
 int arco_conv_sp_set(int on);
