@@ -157,6 +157,95 @@ def lazy_head2(x2p, f3, f4, fea3_weight, fea4_weight, q1_weight, q2_weight, pix)
     return LazyHead2Fn.apply(x2p, f3, f4, fea3_weight, fea4_weight, q1_weight, q2_weight, pix)
 
 
+def _fea_rows(X, w, mode):
+    """fea_i(X) + X on rows (mode 0) / its data gradient W^T dY + dY (mode 1): the 1x1 conv with the residual in the GEMM epilogue."""
+    k = int(X.shape[1])
+    y, _ = ops.conv_raw(X, k, k, ops.pack_weight(w, 1, mode), k, 1, 1, int(X.shape[0]), 1, residual=X, ld_res=k)
+    return y.permute(0, 2, 3, 1).reshape(int(X.shape[0]), k)
+
+
+class LazyHead3Fn(torch.autograd.Function):
+    """Three-level row-sparse head: fea2 (the 64 x 64 level), fea3 and fea4 are all evaluated only where the anchors need
+    them - the 4 neighbours at 128 x 128 of every anchor and the 4 neighbours at 64 x 64 of each of those (16 n rows of
+    448 channels instead of the 65 536 rows of the dense 64 x 64 map: ~1000 anchors per step).  Inputs: x1p =
+    fea1(x)+x [B,384,32,32] (dense), f2 [B,64,64,64], f3 [B,32,128,128], f4 [B,16,256,256].  Same kernels as the two-level
+    head, applied once more; d loss / d x1p becomes dense again from the 32 x 32 level down.  The dense fea2 GEMM
+    (65 536 x 448 x 64 + the upsampled 117 MB residual), its data and weight gradients and the 64 x 64 bilinear backward
+    leave the student path."""
+
+    @staticmethod
+    def forward(ctx, x1p, f2, f3, f4, w2, w3, w4, w1, wq2, pix):
+        dev = x1p.device
+        n = int(pix.shape[0])
+        nb, c1, h1, w1_ = (int(v) for v in x1p.shape)
+        c2, h2, w2_ = int(f2.shape[1]), int(f2.shape[2]), int(f2.shape[3])
+        c3, h3, w3_ = int(f3.shape[1]), int(f3.shape[2]), int(f3.shape[3])
+        c4, h4, w4_ = int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3])
+        lo1, ld1 = rows_view(x1p)
+        r2, ld2 = rows_view(f2)
+        r3, ld3 = rows_view(f3)
+        r4, ld4 = rows_view(f4)
+        nb4 = torch.empty(4 * n, dtype=torch.int64, device=dev)
+        lylx4 = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        L.call("arco_up_neighbors", L.ptr(pix), n, h3, w3_, h4, w4_, L.ptr(nb4), L.ptr(lylx4))
+        nb16 = torch.empty(16 * n, dtype=torch.int64, device=dev)
+        lylx3 = torch.empty(8 * n, dtype=torch.float32, device=dev)
+        L.call("arco_up_neighbors", L.ptr(nb4), 4 * n, h2, w2_, h3, w3_, L.ptr(nb16), L.ptr(lylx3))
+        k2, k3, k4 = c1 + c2, c1 + c2 + c3, c1 + c2 + c3 + c4
+        X2 = torch.empty((16 * n, k2), dtype=torch.float32, device=dev)
+        L.call("arco_gather_upcat_rows", L.ptr(lo1), ld1, c1, h1, w1_, L.ptr(r2), ld2, c2, h2, w2_, L.ptr(nb16), 16 * n,
+               L.ptr(X2), k2)
+        X2p = _fea_rows(X2, w2, 0)
+        X3 = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
+        L.call("arco_lerp4_cat_rows", L.ptr(X2p), k2, k2, L.ptr(lylx3), L.ptr(r3), ld3, c3, L.ptr(nb4), 4 * n, L.ptr(X3), k3)
+        X3p = _fea_rows(X3, w3, 0)
+        X4 = torch.empty((n, k4), dtype=torch.float32, device=dev)
+        L.call("arco_lerp4_cat_rows", L.ptr(X3p), k3, k3, L.ptr(lylx4), L.ptr(r4), ld4, c4, L.ptr(pix), n, L.ptr(X4), k4)
+        h0 = _gemm(X4, w4)
+        hh = _gemm(h0, w1)
+        a = _gemm(hh, wq2)
+        ctx.save_for_backward(X2, X3, X4, h0, hh, w2, w3, w4, w1, wq2, pix, nb4, nb16, lylx3, lylx4)
+        ctx.geom = (nb, c1, h1, w1_, c2, h2, w2_, c3, h3, w3_, c4, h4, w4_)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        X2, X3, X4, h0, hh, w2, w3, w4, w1, wq2, pix, nb4, nb16, lylx3, lylx4 = ctx.saved_tensors
+        nb, c1, h1, w1_, c2, h2, w2_, c3, h3, w3_, c4, h4, w4_ = ctx.geom
+        dev = da.device
+        n = int(pix.shape[0])
+        k2, k3 = c1 + c2, c1 + c2 + c3
+        da = da.contiguous()
+        dwq2 = _wgrad(da, hh, wq2)
+        dhh = _gemm_t(da, wq2)
+        dw1 = _wgrad(dhh, h0, w1)
+        dh0 = _gemm_t(dhh, w1)
+        dw4 = _wgrad(dh0, X4, w4)
+        dX4 = _gemm_t(dh0, w4)
+        dX3p = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
+        df4 = torch.zeros((nb, h4, w4_, c4), dtype=torch.float32, device=dev)
+        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX4), k3 + c4, k3, L.ptr(lylx4), L.ptr(pix), n, L.ptr(dX3p), k3,
+               L.ptr(df4), c4, c4)
+        dw3 = _wgrad(dX3p, X3, w3)
+        dX3 = _fea_rows(dX3p, w3, 1)
+        dX2p = torch.empty((16 * n, k2), dtype=torch.float32, device=dev)
+        df3 = torch.zeros((nb, h3, w3_, c3), dtype=torch.float32, device=dev)
+        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX3), k3, k2, L.ptr(lylx3), L.ptr(nb4), 4 * n, L.ptr(dX2p), k2,
+               L.ptr(df3), c3, c3)
+        dw2 = _wgrad(dX2p, X2, w2)
+        dX2 = _fea_rows(dX2p, w2, 1)
+        dx1p = torch.zeros((nb, h1, w1_, c1), dtype=torch.float32, device=dev)
+        df2 = torch.zeros((nb, h2, w2_, c2), dtype=torch.float32, device=dev)
+        L.call("arco_scatter_upcat_rows", L.ptr(dX2), k2, L.ptr(nb16), 16 * n, L.ptr(dx1p), c1, c1, h1, w1_, L.ptr(df2), c2,
+               c2, h2, w2_)
+        return (dx1p.permute(0, 3, 1, 2), df2.permute(0, 3, 1, 2), df3.permute(0, 3, 1, 2), df4.permute(0, 3, 1, 2),
+                dw2, dw3, dw4, dw1, dwq2, None)
+
+
+def lazy_head3(x1p, f2, f3, f4, fea2_weight, fea3_weight, fea4_weight, q1_weight, q2_weight, pix):
+    return LazyHead3Fn.apply(x1p, f2, f3, f4, fea2_weight, fea3_weight, fea4_weight, q1_weight, q2_weight, pix)
+
+
 def _class_weights(pl):
     """low-valid bits of every pixel as float rows [n_pix, Cp] (Cp = C padded to 4)."""
     Cp = _ceil(pl.C, 4)

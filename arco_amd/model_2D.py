@@ -42,6 +42,18 @@ class FeatureExtractor(nn.Module):
             x = ops.conv(x, fea.weight, None, residual=True)               # fea_i(x) + x
         return x, f[4]
 
+    def forward_lowres1(self, fea_list):
+        """Up to fea1 (second level): returns (fea1(x)+x, f2, f3, f4) for the three-level row-sparse head
+        (arco_amd.head.lazy_head3); the same commuted evaluation as forward_lowres2's first level."""
+        f = [ops.to_channels_last(t) for t in fea_list]
+        x = ops.conv(f[0], self.fea0.weight, None, residual=True)
+        c = int(x.shape[1])
+        n = c + int(f[1].shape[1])
+        w = self.fea1.weight.view(n, n) + torch.eye(n, dtype=torch.float32, device=x.device)
+        lo = ops.conv(x, w[:, :c].contiguous().view(n, c, 1, 1))
+        x = ops.conv(f[1], w[:, c:].contiguous().view(n, n - c, 1, 1), None, residual=ops.bilinear(lo, f[1].shape[-2:]))
+        return x, f[2], f[3], f[4]
+
     def forward_lowres2(self, fea_list):
         """Up to fea2 (third level): returns (fea2(x)+x, f3, f4) for the two-level row-sparse head.
 

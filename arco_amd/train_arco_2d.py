@@ -93,7 +93,7 @@ def build_parser():
                    help='1 (with --graphs 1): the student forward+backward passes are HIP graphs too (a third of the '
                         'host launch work per step, results identical); 0: eager launches')
     p.add_argument('--dense_teacher', type=int, default=0, help='1: materialise the dense teacher representation')
-    p.add_argument('--head_levels', type=int, default=2, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64')
+    p.add_argument('--head_levels', type=int, default=3, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64, 3 = from 32x32')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
     p.add_argument('--list_dir', type=str, default='', help='list directory of the npz experiments (default: the reference\'s hard-wired paths)')
     p.add_argument('--dp_local_thresholds', type=int, default=0,
@@ -309,7 +309,7 @@ class ArcoStep2D:
                 fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
             if getattr(a, "dense_teacher", 0) or dense:
                 rep_all_teacher, lazy_t = self.k_feature_extractor(fm_t), None
-            elif getattr(a, "head_levels", 2) == 1:
+            elif getattr(a, "head_levels", 3) == 1:
                 x3p_t, f4_t = self.k_feature_extractor.forward_lowres(fm_t)
                 rep_all_teacher, lazy_t = None, head.LazyTeacher2D(x3p_t, f4_t, self.k_feature_extractor.fea4.weight)
             else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys/class
@@ -320,8 +320,10 @@ class ArcoStep2D:
             fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]     # :317-318
         if dense:
             rep_all = self.q_rep(self.q_feature_extractor(fm_all))       # :324-325,330
-        elif getattr(a, "head_levels", 2) == 1:
+        elif getattr(a, "head_levels", 3) == 1:
             x3p, f4 = self.q_feature_extractor.forward_lowres(fm_all)
+        elif getattr(a, "head_levels", 3) == 3:
+            x1p, f2, f3, f4 = self.q_feature_extractor.forward_lowres1(fm_all)
         else:
             x2p, f3, f4 = self.q_feature_extractor.forward_lowres2(fm_all)
         # ---- host: wait for the counters; everything that needs the COUNTS but not the sampled INDICES is queued
@@ -369,10 +371,14 @@ class ArcoStep2D:
         else:
             if dense:
                 A_all = C_.GatherRowsFn.apply(rep_all, plan.anchor_pix)
-            elif getattr(a, "head_levels", 2) == 1:
+            elif getattr(a, "head_levels", 3) == 1:
                 A_all = head.lazy_head(x3p, f4, self.q_feature_extractor.fea4.weight,
                                        self.q_representation[0].weight, self.q_representation[1].weight,
                                        plan.anchor_pix)
+            elif getattr(a, "head_levels", 3) == 3:
+                qfe = self.q_feature_extractor
+                A_all = head.lazy_head3(x1p, f2, f3, f4, qfe.fea2.weight, qfe.fea3.weight, qfe.fea4.weight,
+                                        self.q_representation[0].weight, self.q_representation[1].weight, plan.anchor_pix)
             else:
                 A_all = head.lazy_head2(x2p, f3, f4, self.q_feature_extractor.fea3.weight,
                                         self.q_feature_extractor.fea4.weight, self.q_representation[0].weight,

@@ -292,6 +292,7 @@ def main():
     ap.add_argument("--dense_teacher", type=int, default=0)
     ap.add_argument("--batch_transform", type=int, default=1, help="the reference's batch_transform (PIL round trip, jitter, blur, AdvMorph); 0: off")
     ap.add_argument("--conv_mma", type=str, default="f32x3", help="matrix-core mode: f32x3 (default, split-bf16, fp32-accurate) or f32 (native fp32 MFMA)")
+    ap.add_argument("--head_levels", type=int, default=-1, help="row-sparse head depth of the trainer (default: the trainer's)")
     ap.add_argument("--settle_s", type=float, default=2.5, help="untimed steps for this many seconds before the warmup (clock settling)")
     ap.add_argument("--cpu_baseline_child", action="store_true")
     ap.add_argument("--sub", type=str, default="")
@@ -323,6 +324,8 @@ def main():
              "--conv_mma", a.conv_mma]
     if a.graph_train >= 0:
         flags += ["--graph_train", str(a.graph_train)]
+    if a.head_levels > 0:
+        flags += ["--head_levels", str(a.head_levels)]
     args = T.build_parser().parse_args(flags)
     stepper = T.ArcoStep2D(args, dev)
     b = a.batch_size

@@ -30,7 +30,7 @@ def _run(dense, steps=2, levels=2, dense_teacher=1):
     return losses, params, teacher, banks
 
 
-@pytest.mark.parametrize("levels", [1, 2])
+@pytest.mark.parametrize("levels", [1, 2, 3])
 def test_lazy_head_matches_dense_step(levels):
     l_d, p_d, t_d, b_d = _run(1)
     l_s, p_s, t_s, b_s = _run(0, levels=levels)
@@ -48,8 +48,10 @@ def test_lazy_teacher_matches_dense_teacher():
     """Linear-prototype + lazy-key teacher path vs the dense teacher representation (same sparse student head)."""
     l_d, p_d, t_d, b_d = _run(0, dense_teacher=1)
     l_s, p_s, t_s, b_s = _run(0, dense_teacher=0)
-    np.testing.assert_allclose(l_s, l_d, rtol=5e-5, atol=1e-6)
+    # (both runs scatter row gradients with float atomics - DESIGN.md 7 - so step 2 sees weights that differ in the last
+    #  bits from run to run; the tolerances leave room for that: one run in ~6 crossed 5e-5 / 2e-5)
+    np.testing.assert_allclose(l_s, l_d, rtol=2e-4, atol=1e-6)
     for x, y in zip(b_s, b_d):
         assert x.shape == y.shape
         np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(p_s.numpy(), p_d.numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(p_s.numpy(), p_d.numpy(), rtol=1e-3, atol=5e-5)

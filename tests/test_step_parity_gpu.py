@@ -24,7 +24,8 @@ def _drop_off(m):
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutout"),
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0, apply_aug="classmix"),
                                      dict(revisit=1, K=4, topk=2, k2=0.0, apply_aug="cutmix"),
-                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutmix", batch_transform=1)])
+                                     dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutmix", batch_transform=1),
+                                     dict(dense_head=0, head_levels=3, dense_teacher=0, k2=1.0, apply_aug="cutmix")])
 def test_two_steps_vs_cpu_oracle(variant):
     from arco_amd import train_arco_2d as T
     b, patch, C, Q, Nn, qs = 2, (64, 64), 4, 64, 32, 300

@@ -5,7 +5,7 @@ os.environ.setdefault("OMP_NUM_THREADS", "4")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from arco_amd import train_arco_2d as T
-args = T.build_parser().parse_args(["--batch_size", "8", "--queue_size", "4096", "--func", "smc", "--synthetic", "1", "--conv_mma", os.environ.get("MMA", "f32x3")])
+args = T.build_parser().parse_args(["--batch_size", "8", "--queue_size", "4096", "--func", "smc", "--synthetic", "1", "--conv_mma", os.environ.get("MMA", "f32x3"), "--head_levels", os.environ.get("HEAD_LEVELS", "2")])
 st = T.ArcoStep2D(args, "cuda:0")
 bs = [(T.synthetic_batch(8, args.patch_size, 4, 100 + 2 * i, "cuda:0"), T.synthetic_batch(8, args.patch_size, 4, 101 + 2 * i, "cuda:0")[0]) for i in range(4)]
 import gc
