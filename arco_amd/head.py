@@ -164,6 +164,39 @@ def _fea_rows(X, w, mode):
     return y.permute(0, 2, 3, 1).reshape(int(X.shape[0]), k)
 
 
+def _rows3lvl_forward(x1p, f2, f3, f4, w2, w3, w4, pix):
+    """Three-level row path: the 4 neighbours at f3's resolution of every anchor, the 4 neighbours at f2's resolution of
+    each of those; X2 = cat(bilinear(x1p), f2) on the 16 n rows, X2p = fea2(X2)+X2, X3 = cat(4-way lerp of X2p, f3 rows),
+    X3p = fea3(X3)+X3, X4 = cat(4-way lerp of X3p, f4[pix]).  Returns (X2, X3, X4, nb4, nb16, lylx3, lylx4, fea4(X4))."""
+    dev = x1p.device
+    n = int(pix.shape[0])
+    nb, c1, h1, w1_ = (int(v) for v in x1p.shape)
+    c2, h2, w2_ = int(f2.shape[1]), int(f2.shape[2]), int(f2.shape[3])
+    c3, h3, w3_ = int(f3.shape[1]), int(f3.shape[2]), int(f3.shape[3])
+    c4, h4, w4_ = int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3])
+    lo1, ld1 = rows_view(x1p)
+    r2, ld2 = rows_view(f2)
+    r3, ld3 = rows_view(f3)
+    r4, ld4 = rows_view(f4)
+    nb4 = torch.empty(4 * n, dtype=torch.int64, device=dev)
+    lylx4 = torch.empty(2 * n, dtype=torch.float32, device=dev)
+    L.call("arco_up_neighbors", L.ptr(pix), n, h3, w3_, h4, w4_, L.ptr(nb4), L.ptr(lylx4))
+    nb16 = torch.empty(16 * n, dtype=torch.int64, device=dev)
+    lylx3 = torch.empty(8 * n, dtype=torch.float32, device=dev)
+    L.call("arco_up_neighbors", L.ptr(nb4), 4 * n, h2, w2_, h3, w3_, L.ptr(nb16), L.ptr(lylx3))
+    k2, k3, k4 = c1 + c2, c1 + c2 + c3, c1 + c2 + c3 + c4
+    X2 = torch.empty((16 * n, k2), dtype=torch.float32, device=dev)
+    L.call("arco_gather_upcat_rows", L.ptr(lo1), ld1, c1, h1, w1_, L.ptr(r2), ld2, c2, h2, w2_, L.ptr(nb16), 16 * n,
+           L.ptr(X2), k2)
+    X2p = _fea_rows(X2, w2, 0)
+    X3 = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
+    L.call("arco_lerp4_cat_rows", L.ptr(X2p), k2, k2, L.ptr(lylx3), L.ptr(r3), ld3, c3, L.ptr(nb4), 4 * n, L.ptr(X3), k3)
+    X3p = _fea_rows(X3, w3, 0)
+    X4 = torch.empty((n, k4), dtype=torch.float32, device=dev)
+    L.call("arco_lerp4_cat_rows", L.ptr(X3p), k3, k3, L.ptr(lylx4), L.ptr(r4), ld4, c4, L.ptr(pix), n, L.ptr(X4), k4)
+    return X2, X3, X4, nb4, nb16, lylx3, lylx4, _gemm(X4, w4)
+
+
 class LazyHead3Fn(torch.autograd.Function):
     """Three-level row-sparse head: fea2 (the 64 x 64 level), fea3 and fea4 are all evaluated only where the anchors need
     them - the 4 neighbours at 128 x 128 of every anchor and the 4 neighbours at 64 x 64 of each of those (16 n rows of
@@ -175,37 +208,13 @@ class LazyHead3Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1p, f2, f3, f4, w2, w3, w4, w1, wq2, pix):
-        dev = x1p.device
-        n = int(pix.shape[0])
-        nb, c1, h1, w1_ = (int(v) for v in x1p.shape)
-        c2, h2, w2_ = int(f2.shape[1]), int(f2.shape[2]), int(f2.shape[3])
-        c3, h3, w3_ = int(f3.shape[1]), int(f3.shape[2]), int(f3.shape[3])
-        c4, h4, w4_ = int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3])
-        lo1, ld1 = rows_view(x1p)
-        r2, ld2 = rows_view(f2)
-        r3, ld3 = rows_view(f3)
-        r4, ld4 = rows_view(f4)
-        nb4 = torch.empty(4 * n, dtype=torch.int64, device=dev)
-        lylx4 = torch.empty(2 * n, dtype=torch.float32, device=dev)
-        L.call("arco_up_neighbors", L.ptr(pix), n, h3, w3_, h4, w4_, L.ptr(nb4), L.ptr(lylx4))
-        nb16 = torch.empty(16 * n, dtype=torch.int64, device=dev)
-        lylx3 = torch.empty(8 * n, dtype=torch.float32, device=dev)
-        L.call("arco_up_neighbors", L.ptr(nb4), 4 * n, h2, w2_, h3, w3_, L.ptr(nb16), L.ptr(lylx3))
-        k2, k3, k4 = c1 + c2, c1 + c2 + c3, c1 + c2 + c3 + c4
-        X2 = torch.empty((16 * n, k2), dtype=torch.float32, device=dev)
-        L.call("arco_gather_upcat_rows", L.ptr(lo1), ld1, c1, h1, w1_, L.ptr(r2), ld2, c2, h2, w2_, L.ptr(nb16), 16 * n,
-               L.ptr(X2), k2)
-        X2p = _fea_rows(X2, w2, 0)
-        X3 = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
-        L.call("arco_lerp4_cat_rows", L.ptr(X2p), k2, k2, L.ptr(lylx3), L.ptr(r3), ld3, c3, L.ptr(nb4), 4 * n, L.ptr(X3), k3)
-        X3p = _fea_rows(X3, w3, 0)
-        X4 = torch.empty((n, k4), dtype=torch.float32, device=dev)
-        L.call("arco_lerp4_cat_rows", L.ptr(X3p), k3, k3, L.ptr(lylx4), L.ptr(r4), ld4, c4, L.ptr(pix), n, L.ptr(X4), k4)
-        h0 = _gemm(X4, w4)
+        X2, X3, X4, nb4, nb16, lylx3, lylx4, h0 = _rows3lvl_forward(x1p, f2, f3, f4, w2, w3, w4, pix)
         hh = _gemm(h0, w1)
         a = _gemm(hh, wq2)
         ctx.save_for_backward(X2, X3, X4, h0, hh, w2, w3, w4, w1, wq2, pix, nb4, nb16, lylx3, lylx4)
-        ctx.geom = (nb, c1, h1, w1_, c2, h2, w2_, c3, h3, w3_, c4, h4, w4_)
+        ctx.geom = (int(x1p.shape[0]), int(x1p.shape[1]), int(x1p.shape[2]), int(x1p.shape[3]),
+                    int(f2.shape[1]), int(f2.shape[2]), int(f2.shape[3]), int(f3.shape[1]), int(f3.shape[2]), int(f3.shape[3]),
+                    int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3]))
         return a
 
     @staticmethod
@@ -431,3 +440,49 @@ class LazyTeacher2DL2:
     @torch.no_grad()
     def rows(self, pix):
         return _rows2d_forward(self.x2p, self.f3, self.f4, self.w3, self.w4, pix)[4]
+
+
+class LazyTeacher2DL3:
+    """Three-level lazy teacher (with --head_levels 3): fea2 is never evaluated densely either.  prototype_c =
+    W4 . cat((W3+I) . cat((W2+I) . mean_c(cat(up(x1p), f2)), mean_c(f3)), mean_c(f4)): every map is linear in the feature
+    maps, so the class mask is pushed through THREE bilinear adjoints (256^2 -> 128^2 -> 64^2 -> 32^2) and the weighted row
+    sums run on x1p, f2, f3, f4 (66 MB of reads instead of the dense 117 MB fea2 output, which is not built at all); key
+    rows through the three-level row path."""
+
+    def __init__(self, x1p, f2, f3, f4, w2, w3, w4):
+        self.x1p, self.f2, self.f3, self.f4, self.w2, self.w3, self.w4 = x1p, f2, f3, f4, w2, w3, w4
+
+    @torch.no_grad()
+    def prototypes(self, pl):
+        lo, ldlo = rows_view(self.x1p)
+        r2, ld2 = rows_view(self.f2)
+        r3, ld3 = rows_view(self.f3)
+        r4, ld4 = rows_view(self.f4)
+        nb, c1, h1, w1_ = (int(v) for v in self.x1p.shape)
+        c2, h2, w2_ = (int(v) for v in self.f2.shape[1:])
+        c3, h3, w3_ = (int(v) for v in self.f3.shape[1:])
+        c4, h4, w4_ = (int(v) for v in self.f4.shape[1:])
+        C, k2 = pl.C, c1 + c2
+        k3 = k2 + c3
+        wm, Cp = _class_weights(pl)
+        w3l = torch.empty((nb * h3 * w3_, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_bilinear_bwd", L.ptr(wm), Cp, nb, h3, w3_, Cp, h4, w4_, L.ptr(w3l), Cp, 0)
+        w2l = torch.empty((nb * h2 * w2_, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_bilinear_bwd", L.ptr(w3l), Cp, nb, h2, w2_, Cp, h3, w3_, L.ptr(w2l), Cp, 0)
+        w1l = torch.empty((nb * h1 * w1_, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_bilinear_bwd", L.ptr(w2l), Cp, nb, h1, w1_, Cp, h2, w2_, L.ptr(w1l), Cp, 0)
+        R = _ceil(C, 16)
+        S2 = torch.zeros((R, k2), dtype=torch.float32, device=pl.dev)
+        _wsum(lo, ldlo, w1l, Cp, nb * h1 * w1_, C, c1, pl.totals, S2, k2)
+        _wsum(r2, ld2, w2l, Cp, nb * h2 * w2_, C, c2, pl.totals, S2[:, c1:], k2)
+        S3 = torch.zeros((R, k3), dtype=torch.float32, device=pl.dev)
+        S3[:, :k2] = _fea_rows(S2, self.w2, 0)
+        _wsum(r3, ld3, w3l, Cp, nb * h3 * w3_, C, c3, pl.totals, S3[:, k2:], k3)
+        S4 = torch.zeros((R, k3 + c4), dtype=torch.float32, device=pl.dev)
+        S4[:, :k3] = _fea_rows(S3, self.w3, 0)
+        _wsum(r4, ld4, wm, Cp, pl.n_pix, C, c4, pl.totals, S4[:, k3:], k3 + c4)
+        return _gemm(S4, self.w4)[:C].contiguous()
+
+    @torch.no_grad()
+    def rows(self, pix):
+        return _rows3lvl_forward(self.x1p, self.f2, self.f3, self.f4, self.w2, self.w3, self.w4, pix)[7]

@@ -93,6 +93,9 @@ def build_parser():
                    help='1 (with --graphs 1): the student forward+backward passes are HIP graphs too (a third of the '
                         'host launch work per step, results identical); 0: eager launches')
     p.add_argument('--dense_teacher', type=int, default=0, help='1: materialise the dense teacher representation')
+    p.add_argument('--teacher_levels', type=int, default=2,
+                   help='lazy teacher depth: 2 = dense fea2 output, prototypes pushed through two bilinear adjoints (measured as '
+                        'fast as 3); 3 = no dense fea2 output either')
     p.add_argument('--head_levels', type=int, default=3, help='row-sparse head depth: 1 = from the 128x128 level, 2 = from 64x64, 3 = from 32x32')
     p.add_argument('--dense_head', type=int, default=0, help='1: materialise the dense 496-ch student rep (reference dataflow)')
     p.add_argument('--list_dir', type=str, default='', help='list directory of the npz experiments (default: the reference\'s hard-wired paths)')
@@ -312,6 +315,10 @@ class ArcoStep2D:
             elif getattr(a, "head_levels", 3) == 1:
                 x3p_t, f4_t = self.k_feature_extractor.forward_lowres(fm_t)
                 rep_all_teacher, lazy_t = None, head.LazyTeacher2D(x3p_t, f4_t, self.k_feature_extractor.fea4.weight)
+            elif getattr(a, "teacher_levels", 2) == 3:
+                kfe = self.k_feature_extractor
+                rep_all_teacher = None
+                lazy_t = head.LazyTeacher2DL3(*kfe.forward_lowres1(fm_t), kfe.fea2.weight, kfe.fea3.weight, kfe.fea4.weight)
             else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys/class
                 kfe = self.k_feature_extractor
                 rep_all_teacher = None
