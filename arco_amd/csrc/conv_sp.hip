@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
   constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned* const As = reinterpret_cast<unsigned*>(smem);
-  const int nchunks = a.K >> 4;
+  const int nchunks = (a.K + 15) >> 4;                        // (K = 4 / 8 / 12: one chunk, the missing channels read as zero)
   unsigned* const Ws = As + 2 * G::A_DW;
   float* const bias_s = reinterpret_cast<float*>(Ws + nchunks * G::WCH_DW);
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
 #pragma unroll
       for (int it = 0; it < NA; ++it) {
         const int y = d.y0 + hyA[it] - 1, x = d.x0 + hxA[it] - 1;
-        const bool ok = real && ldsA[it] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const bool ok = real && ldsA[it] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W && d.c * 16 + qA * 4 < a.K;
         pa[it] = ok ? a.A + base + toff[it] : a.A;
         okm |= ok ? (1u << it) : 0u;
       }
@@ -593,8 +593,10 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
       for (int at = 0; at < A_T; ++at) {
         const long pix = ((long)d0.img * a.H + d0.y0 + wid * A_T + at) * a.W + d0.x0 + li;
         f32x4 v = acc[at][ct] + bv;
-        if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + pix * a.ldr + n);
-        *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + n) = v;
+        if (n < a.N) {                                       // (N = 4 / 8 / 12 of the 16-wide block: the other lane groups idle)
+          if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + pix * a.ldr + n);
+          *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + n) = v;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[ct][r] += v[r]; s2[ct][r] += v[r] * v[r]; }
         acc[at][ct] = f32x4{0, 0, 0, 0};
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v1 = row16_sum(s1[ct][r]), v2 = row16_sum(s2[ct][r]);
-          if (li == 0) {
+          if (li == 0 && ct * 16 + 4 * g < a.N) {
             a.stat_sum[(ct * 16 + 4 * g + r) * nslab + slab] = v1;
             a.stat_sq[(ct * 16 + 4 * g + r) * nslab + slab] = v2;
           }
@@ -633,7 +635,7 @@ static int launch_rw(const IgemmArgs& a, hipStream_t st, int* q) {
   if (q) { q[0] = 4 * mblocks; q[1] = 9350000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
   if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
   auto kern = conv3x3_rw_kernel<A_T, C_T>;
-  const size_t lds = G::lds_bytes(a.K >> 4);
+  const size_t lds = G::lds_bytes((a.K + 15) >> 4);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   IgemmArgs b = a;
@@ -677,14 +679,20 @@ static int dispatch_rows(const IgemmArgs& a, hipStream_t st, int* q, int min_til
 
 int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   if (!conv_sp_on() || a.mma != 3 || a.D3 != 1) return -1;
-  if ((a.K & 15) != 0 || a.K < 16 || (a.N & 15) != 0 || a.N != a.Npad || a.N > 256 || (a.lda & 3) != 0 || (a.W & 15) != 0 || (a.H & 3) != 0) return -1;
+  if ((a.lda & 3) != 0 || (a.W & 15) != 0 || (a.H & 3) != 0) return -1;
   static const int min_tiles = getenv("ARCO_CONV_SP_TILES") ? atoi(getenv("ARCO_CONV_SP_TILES")) : 192;
   static const int min_n = getenv("ARCO_CONV_SP_MINN") ? atoi(getenv("ARCO_CONV_SP_MINN")) : 16;
-  if (a.N < min_n) return -1;
   static const int rw = getenv("ARCO_CONV_RW") ? atoi(getenv("ARCO_CONV_RW")) : 1;
-  if (rw && a.K <= 32 && (a.N == 16 || a.N == 32)) {            // shallow levels: resident weights, one rendezvous per chunk
-    if (a.N == 32 && (a.H & 15) == 0 && (long)a.NB * (a.H / 16) * (a.W / 16) >= min_tiles) return launch_rw<4, 2>(a, st, q);
-    if (a.N == 16 && (a.H & 31) == 0 && (long)a.NB * (a.H / 32) * (a.W / 16) >= min_tiles) return launch_rw<8, 1>(a, st, q);
+  static const int narrow = getenv("ARCO_CONV_RW_NARROW") ? atoi(getenv("ARCO_CONV_RW_NARROW")) : 1;
+  // one 16-wide output block from at most 32 inputs: also the few-channel ends of the network (the 16 -> 4 logits layer, its
+  // 4 -> 16 data gradient) - HBM-bound launches, the idle MFMA columns / zero channels cost nothing
+  if (rw && a.Npad == 16 && (a.N & 3) == 0 && (a.N == 16 || narrow) && a.K <= 32 && (a.K & 3) == 0 && ((a.K & 15) == 0 || (a.K < 16 && narrow)) &&
+      (a.H & 31) == 0 && (long)a.NB * (a.H / 32) * (a.W / 16) >= min_tiles)
+    return launch_rw<8, 1>(a, st, q);
+  if ((a.K & 15) != 0 || a.K < 16 || (a.N & 15) != 0 || a.N != a.Npad || a.N > 256) return -1;
+  if (a.N < min_n) return -1;
+  if (rw && a.K <= 32 && a.N == 32) {                           // shallow levels: resident weights, one rendezvous per chunk
+    if ((a.H & 15) == 0 && (long)a.NB * (a.H / 16) * (a.W / 16) >= min_tiles) return launch_rw<4, 2>(a, st, q);
   }
   if ((a.N & 63) == 0) return dispatch_rows<4>(a, st, q, min_tiles);
   if ((a.N & 31) == 0) return dispatch_rows<2>(a, st, q, min_tiles);

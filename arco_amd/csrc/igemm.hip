@@ -857,11 +857,11 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
   if (taps == 27 && image_conv3d_eligible(a)) return launch_image_conv3d<3>(a, st, nmb);   // one-channel volume (first layer)
   if (taps == 9 && image_conv3d_eligible(a)) return launch_image_conv3d<1>(a, st, nmb);     // one-channel image
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
-  if (taps == 9 && image_conv_eligible(a)) return launch_image_conv(a, st, nmb);
-  if (taps == 9 && a.mma == 3) {     // wide 2-D levels: the software-pipelined kernel of conv_sp.hip
+  if (taps == 9 && a.mma == 3) {     // 2-D levels with enough tiles: the software-pipelined kernels of conv_sp.hip
     const int r = conv_sp_dispatch(a, st, nmb);
     if (r != -1) return r;
   }
+  if (taps == 9 && image_conv_eligible(a)) return a.mma == 3 ? ARCO_ERR_UNSUPPORTED : launch_image_conv(a, st, nmb);
   // split-bf16 launches (the caller asked arco_conv_split_ok) never take the fp32-only halo kernel
   if (taps == 9) return (a.mma != 3 && halo_eligible(a)) ? dispatch_halo(a, st, nmb) : dispatch_spatial<1>(a, st, nmb);
   return ARCO_ERR_UNSUPPORTED;
@@ -1586,7 +1586,18 @@ int arco_conv_split_ok(int taps, int NB, int H, int W, int Cin, int Cout, long l
   if (taps == 27) return image_conv3d_eligible(a) ? 0 : 1;
   // of the shallow 2-D levels only 16 -> 16 stays on the fp32 halo kernel (HBM-bound either way, measured faster there);
   // 16 -> 32, 32 -> 16 and 32 -> 32 run 10-25 % faster on the split-bf16 implicit GEMM
-  if (taps == 9) return (image_conv3d_eligible(a) || image_conv_eligible(a) || (halo_eligible(a) && a.K == 16 && a.Npad <= 16)) ? 0 : 1;
+  if (taps == 9) {
+    if (image_conv3d_eligible(a)) return 0;
+    if (image_conv_eligible(a) || (halo_eligible(a) && a.K == 16 && a.Npad <= 16)) {
+      // ... unless the resident-weights pipelined kernel takes the launch (16 x 256^2 planes: HBM-bound there, the halo
+      // kernel is not); A/B switch ARCO_CONV_RW16=0
+      static const bool rw16 = !(getenv("ARCO_CONV_RW16") && atoi(getenv("ARCO_CONV_RW16")) == 0);
+      int q[3];
+      a.mma = 3;
+      return rw16 && conv_sp_dispatch(a, nullptr, q) == ARCO_OK && q[1] == 9358016 ? 1 : 0;     // (conv3x3_rw_kernel<8,1> only)
+    }
+    return 1;
+  }
   return 0;
 }
 

@@ -130,3 +130,41 @@ def test_pipelined_3x3_kernel_equals_igemm_kernel(shape):
     for k in (1, 2):
         assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-6)
     assert torch.allclose(res[1][1], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("shape", [dict(nb=16, s=256), dict(nb=8, s=128), dict(nb=3, s=256), dict(nb=16, s=256, co=4), dict(nb=7, s=128, co=8),
+                                   dict(nb=16, s=256, ci=4), dict(nb=6, s=128, ci=4, co=4)])
+def test_narrow_planes_run_on_the_resident_weights_kernel(shape):
+    """At most 16 outputs from at most 16 inputs at 256^2 / 128^2 (16 -> 16, the 16 -> 4 logits layer, its 4 -> 16 data
+    gradient): one K chunk, one N block on conv3x3_rw_kernel<8,1> (32-row tiles; missing input channels staged as zeros,
+    lane groups beyond N idle in the epilogue); with the pipelined kernels off the fp32 halo / few-channel kernels.  Both
+    within fp32 rounding of an fp64 convolution, BN partial sums equal up to the slab partition."""
+    from arco_amd import _lib as L, ops
+    nb, s, ci, co = shape["nb"], shape["s"], shape.get("ci", 16), shape.get("co", 16)
+    g = torch.Generator().manual_seed(1616 + nb + ci * 7 + co)
+    x = _cl(torch.randn(nb, ci, s, s, generator=g))
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
+    bias = torch.randn(co, generator=g).cuda()
+    wp = ops.pack_weight(wt, 9, 0)
+    xr, ldx = ops.rows_view(x)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    res = {}
+    prev = L.load().arco_conv_sp_set(1)
+    try:
+        for on in (0, 1):
+            L.load().arco_conv_sp_set(on)
+            ops._cfg_cache.clear()
+            split = ops._split_ok(9, nb, s, s, ci, co, ldx)
+            assert split == bool(on)
+            cfg = L.query("arco_conv_config_mma", 9, nb, s, s, ci, co, ldx, 3 if split else 0)
+            assert (cfg == 9358016) == bool(on), cfg
+            out, (ssum, ssq, nmb) = ops.conv_raw(xr, ldx, ci, wp, co, nb, s, s, 9, bias=bias, stats=True)
+            assert out.shape[1] == co and ssum.shape == (co, nmb)
+            res[on] = (out.clone(), ssum.double().sum(1), ssq.double().sum(1))
+            assert float((res[on][0].double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    finally:
+        L.load().arco_conv_sp_set(prev)
+        ops._cfg_cache.clear()
+    for k in (1, 2):
+        assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-5 * nb * s * s / 1024)
+    assert torch.allclose(res[1][1], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
