@@ -62,6 +62,7 @@ _SIGS = {
     "arco_bn_act_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _L, _P, _I, _P],
     "arco_bn_act_bwd": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _P, _P, _I, _P, _L, _P, _I, _P],
     "arco_maxpool2_fwd": [_P, _L, _I, _I, _I, _I, _P, _L, _P],
+    "arco_bn_act_pool_fwd": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _L, _P, _L, _I, _P],
     "arco_maxpool2_bwd": [_P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "arco_maxpool2_bwd_add": [_P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P],
     "arco_bilinear_fwd": [_P, _L, _I, _I, _I, _I, _I, _I, _P, _L, _P],

@@ -363,6 +363,44 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(Y + (((n * Ho) + yo) * Wo + xo) * ldy + c) = o;
   }
 }
+// BN apply + LeakyReLU of a block's last stage AND the 2x2 max-pool of the result in one pass (the ConvBlock output feeds
+// the next DownBlock's nn.MaxPool2d and, unpooled, the decoder's skip: unetWithArgs.py:55-58,109-116): a thread owns a
+// 2x2 pixel window x 4 channels - four Z loads, four A stores, one pooled store; the separate pooling pass re-read A.
+// Same arithmetic per element as bn_act_fwd_kernel (no dropout on this stage) / maxpool2_fwd_kernel.
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ Z, long ldz, int NB, int H, int W, int C,
+                                                             const float* __restrict__ mean, const float* __restrict__ istd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float slope, float* __restrict__ Aout, long lda,
+                                                             float* __restrict__ Pout, long ldp, int img_per_group) {
+  const int q4 = C / 4, Ho = H / 2, Wo = W / 2;
+  const long tot = (long)NB * Ho * Wo * q4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % q4) * 4; long r = i / q4;
+    const int xo = r % Wo; r /= Wo; const int yo = r % Ho; const long n = r / Ho;
+    const int g = (int)(n / img_per_group);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (long)g * C + c), is = *reinterpret_cast<const f32x4*>(istd + (long)g * C + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    const long row = ((n * H) + 2 * yo) * W + 2 * xo;
+    const long rows[4] = {row, row + 1, row + W, row + W + 1};
+    f32x4 z[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) z[u] = *reinterpret_cast<const f32x4*>(Z + rows[u] * ldz + c);
+    f32x4 o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = (z[u][e] - mu[e]) * is[e] * ga[e] + be[e];
+        o[u][e] = y >= 0.f ? y : y * slope;
+      }
+      *reinterpret_cast<f32x4*>(Aout + rows[u] * lda + c) = o[u];
+    }
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(o[0][e], o[1][e]), fmaxf(o[2][e], o[3][e]));
+    *reinterpret_cast<f32x4*>(Pout + (((n * Ho) + yo) * Wo + xo) * ldp + c) = m;
+  }
+}
 // gradient goes to the first maximum in window scan order (torch's saved argmax)
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ X, long ldx, int NB, int H, int W,
                                                           int C, const float* __restrict__ dY, long ldy,
@@ -897,6 +935,16 @@ int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, flo
   ARCO_CHECK_ARG((C & 3) == 0 && (H & 1) == 0 && (W & 1) == 0);
   hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid((long)NB * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
                      as_stream(stream), X, ldx, NB, H, W, C, Y, ldy);
+  return arco_launch_status();
+}
+int arco_bn_act_pool_fwd(const float* Z, long ldz, int NB, int H, int W, int C, const float* mean, const float* istd,
+                         const float* gamma, const float* beta, float slope, float* A, long lda, float* P, long ldp,
+                         int groups, void* stream) {
+  if (groups < 1) groups = 1;
+  ARCO_CHECK_ARG(Z && mean && istd && gamma && beta && A && P && C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 &&
+                 (ldp & 3) == 0 && (H & 1) == 0 && (W & 1) == 0 && NB % groups == 0);
+  hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(ew_grid((long)NB * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     as_stream(stream), Z, ldz, NB, H, W, C, mean, istd, gamma, beta, slope, A, lda, P, ldp, NB / groups);
   return arco_launch_status();
 }
 int arco_maxpool2_bwd(const float* X, long ldx, int NB, int H, int W, int C, const float* dY, long ldy, float* dX,

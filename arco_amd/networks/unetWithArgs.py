@@ -19,13 +19,14 @@ def _bn_eval_stats(bn):
     return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
 
 
-def _stage(x, conv, bn, act, drop_p, training, drop_mode=1, cat_room=0):
+def _stage(x, conv, bn, act, drop_p, training, drop_mode=1, cat_room=0, pool=False):
     slope = getattr(act, "negative_slope", 0.0)
     if training:
         y = ops.conv_bn_act(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                             slope=slope, p=drop_p, drop_mode=drop_mode, momentum=bn.momentum, eps=bn.eps,
-                            num_batches_tracked=bn.num_batches_tracked, cat_room=cat_room)
+                            num_batches_tracked=bn.num_batches_tracked, cat_room=cat_room, pool=pool)
         return y
+    assert not pool
     return ops.conv_bn_act_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 slope=slope, eps=bn.eps)
 
@@ -47,10 +48,11 @@ class ConvBlock(nn.Module):
 
     cat_room = 0      # Encoder sets it on the blocks whose output is a skip connection (see ops.upcat)
 
-    def forward(self, x):
+    def forward(self, x, pool=False):
+        """pool=True (train mode): (block output, its 2x2 max-pool) - the pooling rides on the last BN / activation pass."""
         s = self.conv_conv
         x = _stage(x, s[0], s[1], s[2], s[3].p, self.training)
-        return _stage(x, s[4], s[5], s[6], 0.0, self.training, cat_room=self.cat_room)
+        return _stage(x, s[4], s[5], s[6], 0.0, self.training, cat_room=self.cat_room, pool=pool)
 
 
 class DownBlock(nn.Module):
@@ -115,6 +117,13 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         x = ops.to_channels_last(x.to(torch.float32))
+        if self.training and ops.POOL_FUSE:     # nn.MaxPool2d of each DownBlock fused into the block before it; the two
+            x0, p = self.in_conv(x, pool=True)  # gradients of x_i (skip + pooling) are summed in that block's backward
+            x1, p = self.down1.maxpool_conv[1](p, pool=True)
+            x2, p = self.down2.maxpool_conv[1](p, pool=True)
+            x3, p = self.down3.maxpool_conv[1](p, pool=True)
+            x4 = self.down4.maxpool_conv[1](p)
+            return [x0, x1, x2, x3, x4]
         x0 = self.in_conv(x)
         if torch.is_grad_enabled() and x0.requires_grad:       # training: skip gradients fused into the pooling backward
             x1, x0 = self.down1.forward_skip(x0)

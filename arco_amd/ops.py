@@ -15,6 +15,7 @@ SEED_DEV = None     # device uint64 salt for dropout masks of graph-captured for
 PROFILE = None       # bench.py sets a dict: kernel instantiation id -> {n, flop, timed: [(ev0, ev1, flop, (taps, M, N, K))]}
 _cfg_cache = {}
 BN_GROUPS = 1         # see bn_groups()
+POOL_FUSE = int(__import__('os').environ.get('ARCO_POOL_FUSE', '1'))             # A/B switch: 0 = separate max-pool pass in the U-Net encoder
 CONV_MMA = int(__import__('os').environ.get('ARCO_CONV_MMA', '3'))          # MFMA mode of the convolutions / GEMMs (forward and data gradient; --conv_mma of the trainers):
                       # 3 (default, "f32x3"): fp32-accurate products on the bf16 matrix cores - every fp32 operand is split
                       #    exactly into three bf16 terms and six v_mfma_f32_16x16x32_bf16 replace eight v_mfma_f32_16x16x4_f32
@@ -476,7 +477,7 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps,
-                nbt=None, cat_room=0):
+                nbt=None, cat_room=0, pool=False):
         global _LAST_CAT_BUF
         L.require_gpu(x, weight)
         taps = _taps(weight)
@@ -502,20 +503,44 @@ class ConvBnActFn(torch.autograd.Function):
         else:
             a, ld_a = new_act_nd(nv, co, sp, x.device), co
         zr, ldz = rows_view(z)
-        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w, a,
-                                 ld_a, G)
+        ctx.pool = bool(pool)
         ctx.groups = G
-        ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta)
         ctx.cfg = (taps, float(slope), float(p), int(drop_mode), seed, bias is not None)
         ctx.bias_param = bias
+        if pool:            # the activation AND its 2x2 max-pool in one pass (encoder blocks: next DownBlock + decoder skip)
+            if p > 0 or d3 != 1:
+                raise RuntimeError("arco_amd: conv_bn_act(pool=True) is the 2-D, dropout-free last stage of a ConvBlock")
+            pooled = new_act(nv, co, h // 2, w // 2, x.device)
+            L.call("arco_bn_act_pool_fwd", L.ptr(zr), ldz, nv, h, w, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
+                   float(slope), L.ptr(a), ld_a, L.ptr(pooled), co, G)
+            ctx.seed_dev = None
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta, a)
+            return a, pooled
+        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w, a,
+                                 ld_a, G)
+        ctx.save_for_backward(x, weight, z, mean, istd, gamma, beta)
         return a
 
     @staticmethod
-    def backward(ctx, da):
-        x, weight, z, mean, istd, gamma, beta = ctx.saved_tensors
+    def backward(ctx, da, dpool=None):
+        if ctx.pool:
+            x, weight, z, mean, istd, gamma, beta, a = ctx.saved_tensors
+        else:
+            x, weight, z, mean, istd, gamma, beta = ctx.saved_tensors
         taps, slope, p, drop_mode, seed, has_bias = ctx.cfg
         xr, ldx, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
+        if ctx.pool and dpool is not None:       # d a = d skip + maxpool2_bwd(d pooled), summed inside the pooling backward
+            ar, lda_ = rows_view(a)
+            dpr, ldp = rows_view(dpool)
+            dsum = new_act(nv, co, h, w, x.device)
+            if da is None:
+                L.call("arco_maxpool2_bwd", L.ptr(ar), lda_, nv, h, w, co, L.ptr(dpr), ldp, L.ptr(dsum), co)
+            else:
+                sr, lds = rows_view(da)
+                L.call("arco_maxpool2_bwd_add", L.ptr(ar), lda_, nv, h, w, co, L.ptr(dpr), ldp, L.ptr(sr), lds, L.ptr(dsum), co)
+            da = dsum
         dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, d3 * h * w,
                                          ctx.seed_dev, ctx.groups)
         dzr, ldzz = rows_view(dz)
@@ -535,7 +560,7 @@ class ConvBnActFn(torch.autograd.Function):
                 b._arco_mark()          # += 0 into the flat gradient: nothing to launch, the optimiser still steps it
             else:
                 db = _zeros_cached((co,), da.device)
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 class BnActFn(torch.autograd.Function):
@@ -713,15 +738,16 @@ _LAST_CAT_BUF = None
 
 
 def conv_bn_act(x, weight, bias, gamma, beta, running_mean, running_var, slope=0.01, p=0.0, drop_mode=1,
-                momentum=0.1, eps=1e-5, num_batches_tracked=None, cat_room=0):
+                momentum=0.1, eps=1e-5, num_batches_tracked=None, cat_room=0, pool=False):
     """`num_batches_tracked` (int64 buffer) is incremented inside the BN finalize kernel.
     cat_room > 0: the result is written as the leading channels of a buffer with `cat_room` more channels
-    (`result._arco_cat_buf`), so that `upcat` can append an upsampled tensor behind it without a copy."""
+    (`result._arco_cat_buf`), so that `upcat` can append an upsampled tensor behind it without a copy.
+    pool=True: returns (result, maxpool2(result)) from one apply pass (2-D, p == 0)."""
     global _LAST_CAT_BUF
     y = ConvBnActFn.apply(x, weight, bias, gamma, beta, running_mean, running_var, slope, p, drop_mode,
-                          momentum, eps, num_batches_tracked, cat_room)
+                          momentum, eps, num_batches_tracked, cat_room, pool)
     if cat_room:
-        y._arco_cat_buf, _LAST_CAT_BUF = _LAST_CAT_BUF, None
+        (y[0] if pool else y)._arco_cat_buf, _LAST_CAT_BUF = _LAST_CAT_BUF, None
     return y
 
 

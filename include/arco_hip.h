@@ -162,6 +162,12 @@ int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
 /* ---- N2/N3  nn.MaxPool2d(2) (unetWithArgs.py:55-58); nn.Upsample(bilinear, align_corners=True)
  *      (unetWithArgs.py:74-75, model_2D.py:43-52)                                                          */
 int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, float* Y, long ldy, void* stream);
+/* A = lrelu(BN(Z)) (mean / istd rows [groups][C] as arco_bn_act_fwd, no dropout) and P = maxpool2(A) in one pass: the last
+   stage of a ConvBlock whose output feeds the next DownBlock's nn.MaxPool2d and the decoder's skip (unetWithArgs.py:36-44,
+   55-58,109-116)                                                                                              */
+int arco_bn_act_pool_fwd(const float* Z, long ldz, int NB, int H, int W, int C, const float* mean, const float* istd,
+                         const float* gamma, const float* beta, float slope, float* A, long lda, float* P, long ldp,
+                         int groups, void* stream);
 int arco_maxpool2_bwd(const float* X, long ldx, int NB, int H, int W, int C, const float* dY, long ldy, float* dX,
                       long ldo, void* stream);
 /* ... fused with the gradient x receives from its second consumer (unetWithArgs.py:109-116,142-158: x_i feeds both the

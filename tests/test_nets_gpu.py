@@ -168,3 +168,44 @@ def _bn_groups_case(nb, H, W, grads, gtol):
             torch.testing.assert_close(v, state_sep[k], rtol=1e-4, atol=1e-6, msg=k)
         else:
             assert int(v) == int(state_sep[k]), k
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_pooling_fused_into_the_activation_pass_is_bit_identical(groups):
+    """Encoder in train mode: nn.MaxPool2d of every DownBlock computed by the BN / LeakyReLU pass of the block before it
+    (arco_bn_act_pool_fwd) - same outputs, feature maps and parameter gradients, bit for bit, as the separate pooling pass
+    (ops.POOL_FUSE = 0); also under grouped BN statistics and without autograd (teacher-style forward)."""
+    from arco_amd import ops
+    from arco_amd.networks.net_factory_args import net_factory
+    torch.manual_seed(7)
+    net = net_factory(net_type='unet', in_chns=1, class_num=4).cuda().train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    x = torch.randn(4, 1, 64, 96, generator=torch.Generator().manual_seed(3)).cuda()
+    probe = torch.randn(4, 4, 64, 96, generator=torch.Generator().manual_seed(4)).cuda()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    res = {}
+    prev, prev_g = ops.POOL_FUSE, ops.BN_GROUPS
+    try:
+        ops.BN_GROUPS = groups
+        for fuse in (0, 1):
+            ops.POOL_FUSE = fuse
+            net.load_state_dict(state)
+            net.zero_grad(set_to_none=True)
+            out, x4, fmaps = net(x)
+            ((out * probe).sum() + sum((f ** 2).mean() for f in fmaps)).backward()
+            with torch.no_grad():
+                out_ng = net(x)[0]
+            torch.cuda.synchronize()
+            res[fuse] = ([out.detach().clone(), x4.detach().clone(), out_ng.clone()] + [f.detach().clone() for f in fmaps],
+                         {n: p.grad.clone() for n, p in net.named_parameters()},
+                         {k: v.clone() for k, v in net.state_dict().items() if "running" in k})
+    finally:
+        ops.POOL_FUSE, ops.BN_GROUPS = prev, prev_g
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
