@@ -39,6 +39,7 @@ template <int TAPS, int BM, int BN, int WAVES_M, int WAVES_N, int KC, bool DB, b
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int TH = BM / 16;
   constexpr bool X3 = MMA == 3;
+  constexpr bool SWP = X3 && TAPS == 1 && DEPTH == 1;      // 1x1 split-bf16 GEMMs accumulate D^T (16-byte epilogue accesses)
   static_assert(!X3 || (TAPS == 9 ? KC == 16 : KC == 32), "split-bf16 mode: KC = 16 (3x3, tap pairs) or 32 (1x1)");
   constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * IGEMM_FLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
   constexpr int BROWS = TAPS * BN;
@@ -227,12 +228,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
           for (int at = 0; at < A_T; ++at) {       // small terms first
             f32x4 c = acc[at][ct];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][2], fb[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][1], fb[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][1], fb[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[0], c, 0, 0, 0);
+            if constexpr (SWP) {                   // D = W . X^T: a lane ends up with 4 consecutive channels of one pixel
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[at][2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa[at][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[at][1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[at][1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[at][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[at][0], c, 0, 0, 0);
+            } else {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][2], fb[0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][1], fb[1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][1], fb[0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[at][0], fb[0], c, 0, 0, 0);
+            }
             acc[at][ct] = c;
           }
         }
@@ -322,6 +332,70 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 
   // ---- epilogue: bias, residual, store, BN partial statistics
+  if constexpr (SWP) {
+    // split-bf16 GEMMs (1x1 convs): the accumulators are D^T tiles - lane (li, g) holds channels 4g .. 4g+3 of pixel li:
+    // one 16-byte store (and residual load) per tile instead of four 4-byte ones
+    float t1[C_T][4], t2[C_T][4];
+    const bool v4 = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
+                    (!a.R || (((a.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.R) & 15) == 0)));
+#pragma unroll
+    for (int ct = 0; ct < C_T; ++ct) {
+      const int nb = n0 + (wn * C_T + ct) * 16 + 4 * g;
+      f32x4 bv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { bv[r] = (a.bias && nb + r < a.N) ? a.bias[nb + r] : 0.f; t1[ct][r] = 0.f; t2[ct][r] = 0.f; }
+#pragma unroll
+      for (int at = 0; at < A_T; ++at) {
+        const long m = m0 + (wm * A_T + at) * 16 + li;
+        if (m >= m_lim) continue;
+        f32x4 v = acc[at][ct] + bv;
+        if (v4 && nb + 3 < a.N) {
+          if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + nb);
+          *reinterpret_cast<f32x4*>(a.C + m * a.ldc + nb) = v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { t1[ct][r] += v[r]; t2[ct][r] += v[r] * v[r]; }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nb + r < a.N) {
+              float x = v[r];
+              if (a.R) x += a.R[m * a.ldr + nb + r];
+              a.C[m * a.ldc + nb + r] = x;
+              t1[ct][r] += x; t2[ct][r] += x * x;
+            }
+        }
+      }
+    }
+    if (a.stat_sum) {
+      float* red = smem;   // reuse: [2][WAVES_M][BN]
+      __syncthreads();
+#pragma unroll
+      for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v1 = t1[ct][r], v2 = t2[ct][r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+          if (li == 0) {
+            const int nl = (wn * C_T + ct) * 16 + 4 * g + r;
+            red[(0 * WAVES_M + wm) * BN + nl] = v1;
+            red[(1 * WAVES_M + wm) * BN + nl] = v2;
+          }
+        }
+      __syncthreads();
+      for (int nl = tid; nl < BN; nl += 256) {
+        const int n = n0 + nl;
+        if (n < a.N) {
+          float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES_M; ++w) { v1 += red[(0 * WAVES_M + w) * BN + nl]; v2 += red[(1 * WAVES_M + w) * BN + nl]; }
+          a.stat_sum[(long)n * a.n_mblocks + mblk] = v1;
+          a.stat_sq[(long)n * a.n_mblocks + mblk] = v2;
+        }
+      }
+    }
+    return;
+  }
   float s1[C_T], s2[C_T];
 #pragma unroll
   for (int ct = 0; ct < C_T; ++ct) { s1[ct] = 0.f; s2[ct] = 0.f; }
