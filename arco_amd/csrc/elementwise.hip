@@ -19,6 +19,21 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
 
 // ---- BN statistics finalize: block partial (sum, sumsq) -> mean, istd, running stats.
 //      One 64-lane wave per channel; fp64 tree over the partial slabs.
+// Per-thread partial sums of two slab rows (stride NT): eight independent loads of each row in flight per trip - the
+// rows of the shallow levels have 2048-8192 slabs, one load per trip made these few-block kernels a chain of DRAM latencies.
+template <int NT>
+__device__ __forceinline__ void slab_sums2(const float* __restrict__ pa, const float* __restrict__ pb, int n, double& a, double& b) {
+  int i = threadIdx.x;
+  for (; i + 7 * NT < n; i += 8 * NT) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { va[u] = pa[i + u * NT]; vb[u] = pb[i + u * NT]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+  }
+  for (; i < n; i += NT) { a += (double)pa[i]; b += (double)pb[i]; }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
                                    double count, float eps, float momentum, float* __restrict__ mean,
                                    float* __restrict__ istd, float* __restrict__ running_mean,
@@ -37,7 +52,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   if (c == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += groups;
   for (int g = 0; g < groups; ++g) {
     double s = 0.0, q = 0.0;
-    for (int b = threadIdx.x; b < npg; b += 256) { s += (double)ssum[(long)c * nblk + g * npg + b]; q += (double)ssq[(long)c * nblk + g * npg + b]; }
+    slab_sums2<256>(ssum + (long)c * nblk + g * npg, ssq + (long)c * nblk + g * npg, npg, s, q);
     s = wave_sum_d(s); q = wave_sum_d(q);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = q; }
@@ -261,15 +276,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
   block_channel_totals(s, q, C, red, s_dy, s_dyx, nblk);
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int nblk, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ s_dy, const float* __restrict__ s_dyx, int nblk, int C,
                                        float* __restrict__ sums /*[G][2][C]*/,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int groups) {
-  const int c = blockIdx.x;
+  __shared__ double sh[2][4];
+  const int c = blockIdx.x, w = threadIdx.x >> 6;
   double ga = 0.0, gb = 0.0;
   for (int g = 0; g < groups; ++g) {
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 64) { a += (double)s_dy[((long)g * C + c) * nblk + i]; b += (double)s_dyx[((long)g * C + c) * nblk + i]; }
+    slab_sums2<256>(s_dy + ((long)g * C + c) * nblk, s_dyx + ((long)g * C + c) * nblk, nblk, a, b);
     a = wave_sum_d(a); b = wave_sum_d(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = b; }
+    __syncthreads();
+    a = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]); b = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     if (threadIdx.x == 0) { sums[(2l * g) * C + c] = (float)a; sums[(2l * g + 1) * C + c] = (float)b; }   // this group's sums (apply pass)
     if (groups == 1) { ga = a; gb = b; } else { ga += (double)(float)a; gb += (double)(float)b; }   // = two separate backward passes
   }
@@ -920,7 +940,7 @@ int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
     float* s_dy = ws; float* s_dyx = ws + (long)groups * C * nblk; float* sums = ws + 2l * groups * C * nblk;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk, groups), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, Mg,
                        C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk, seed_dev);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, s_dy, s_dyx, nblk, C, sums, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, s_dy, s_dyx, nblk, C, sums, dgamma,
                        dbeta, accumulate, groups);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, st, dA, ldd, Z, ldz, Mg, C,
                        mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)Mg, dZ, ldo, seed_dev);
