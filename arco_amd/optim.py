@@ -75,6 +75,8 @@ class EmaPair:
     @torch.no_grad()
     def update(self, m):
         s = self._student_flat()
+        if s is None and not any(hasattr(p, "_arco_grad_view") for p in self.sp):
+            s = flatten_params(self.sp)     # no optimiser owns them (stage 2: ISD's query heads): re-home once, no cat per step
         if s is None:
             s = torch.cat([p.data.reshape(-1) for p in self.sp])
         t = self._flat_of(self.tp)          # (an optimiser built after this pair may have re-homed the teacher)

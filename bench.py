@@ -54,7 +54,17 @@ PMC_TRAFFIC_BYTES = {(9, 65536, 64, 64): 3.526e7, (9, 65536, 64, 128): 5.322e7,
 # (taps, M, N, K) -> HBM bytes per launch of the split-bf16 kernels (profiles/r02_pmc_conv_traffic.md)
 # conv3x3_sp_kernel launches, profiles/r02_pmc_conv_sp_traffic.md (keys: taps, M, N, K)
 PMC_TRAFFIC_SPLIT = {(9, 65536, 64, 64): 3.647e7, (9, 65536, 64, 128): 5.502e7, (9, 262144, 32, 32): 6.904e7, (9, 262144, 32, 64): 1.0304e8,
-                     (9, 1048576, 32, 16): 2.0646e8, (9, 16384, 128, 128): 2.479e7, (9, 32768, 64, 64): 1.948e7}
+                     (9, 1048576, 32, 16): 2.0646e8, (9, 16384, 128, 128): 2.479e7, (9, 32768, 64, 64): 1.948e7,
+                     # conv3x3_rw_kernel<8,1> launches, profiles/r02_pmc_conv_rw_traffic.md
+                     (9, 1048576, 16, 16): 1.3612e8, (9, 1048576, 16, 32): 2.0341e8, (9, 1048576, 4, 16): 8.500e7, (9, 1048576, 16, 4): 8.579e7,
+                     (9, 524288, 16, 16): 6.848e7}
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
+
+
+def conv_algorithmic_bytes(taps, m, n, k, mma):
+    """Bytes a conv / GEMM launch must move: the input read once, the output written once (fp32), the packed weights
+    (split-bf16: 6 B per weight, else 4 B)."""
+    return 4.0 * m * (k + n) + (6.0 if mma == 3 else 4.0) * taps * n * k
 
 
 def cpu_baseline_child():
@@ -155,15 +165,29 @@ def roofline_from_profile(prof, n_steps, step_ms):
     wg_ms = sum(t for c, t in tot.items() if isinstance(c, tuple)); wg_flop = sum(v["flop"] for c, v in prof.items() if isinstance(c, tuple))
     k_mma = 0 if isinstance(cfg, tuple) else cfg // 100000000
     peak = PEAK_BY_MMA[k_mma]
-    roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": PMC_TRAFFIC_BYTES.get((taps, m, n, k)) if k_mma == 0 else PMC_TRAFFIC_SPLIT.get((taps, m, n, k)),
+    # which roofline bounds the kernel: its arithmetic intensity (algorithmic FLOP per algorithmic byte, over the timed
+    # launches) against the machine balance peak FLOP/s / peak HBM B/s
+    avg_bytes = sum(conv_algorithmic_bytes(*shp, k_mma) for _, _, _, shp in launches) / len(launches)
+    intensity, balance = avg_flop / avg_bytes, peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if intensity < balance:
+        gbs = avg_bytes / (avg_ms * 1e-3) / 1e9
+        head = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "mfma_tflops": round(ach, 2), "mfma_frac": round(ach / peak, 4)}
+    else:
+        head = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+    head.update({"flop_per_algorithmic_byte": round(intensity, 1), "machine_balance_flop_per_byte": round(balance, 1),
+                 "avg_algorithmic_bytes_per_launch": avg_bytes})
+    roof = {**head, "traffic": PMC_TRAFFIC_BYTES.get((taps, m, n, k)) if k_mma == 0 else PMC_TRAFFIC_SPLIT.get((taps, m, n, k)),
             "peak_note": {0: "fp32 MFMA peak", 3: "dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32-accurate product); the native fp32 MFMA peak is 157.3"}.get(k_mma, "dense f16/bf16 MFMA peak"),
             "kernel": _kernel_name(cfg), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(rec["n"] / n_steps, 1),
             "launches_timed": len(launches), "avg_flop_per_launch": avg_flop,
             "share_of_step": round(tot[cfg] / n_steps / step_ms, 4),
             "largest_shape": {"taps": taps, "M": m, "N": n, "K": k, "launches_timed": cnt,
                               "tflops": round(f / (ms_sum / cnt * 1e-3) / 1e12, 2)},
-            "method": "eager pass outside the timed region, HIP events on the launch stream around every 7th launch"}
+            "method": "eager pass outside the timed region, HIP events on the launch stream around every 5th launch"}
+    if roof["bound"] == "hbm":
+        roof["peak_note"] = ("HBM3E peak ~ 8 TB/s; achieved = algorithmic bytes (input + output + packed weights) / average launch time. "
+                             "mfma_tflops / mfma_frac price the same launches against " + roof["peak_note"])
     top = sorted(tot.items(), key=lambda kv: -kv[1])[:8]
     whole = {"mfma_flop_per_step": fam_flop / n_steps, "ms_per_step": round(step_ms, 3),
              "tflops_over_whole_step": round(fam_flop / n_steps / (step_ms * 1e-3) / 1e12, 2),
@@ -185,7 +209,7 @@ def eager_profile(stepper, run_steps, n_steps):
     prev = graphs.set_enabled(stepper, False)
     run_steps(2)
     torch.cuda.synchronize()
-    ops.PROFILE, ops.PROFILE_EVERY = {}, 7
+    ops.PROFILE, ops.PROFILE_EVERY = {}, 5
     run_steps(n_steps)
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
