@@ -1010,6 +1010,7 @@ struct WgradArgs {
   float* partial;      // [chunks][taps][CoutPad][CinPad]
   int CoutPad, CinPad, n_tiles;
   int mma;             // 0 fp32 MFMA; 2: bf16 operands (halo kernels, 3x3x3 only), fp32 accumulate
+  int abl;             // ablation bits for tools/micro/wgrad_abl.py (0 in the product): 1 no MFMA phase, 2 no staging, 4 no global loads
 };
 
 template <int CO_B, int CI_B>
@@ -1352,8 +1353,9 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
   };
 
   int t = blockIdx.x;
-  if (t < a.n_tiles) fetch(t);
+  if (t < a.n_tiles && !(a.abl & 4)) fetch(t);
   while (t < a.n_tiles) {
+    if (!(a.abl & 2)) {
 #pragma unroll
     for (int i = 0; i < NZU; ++i) {
       const int u = tid + i * 256, pg = u / QZ, q = u % QZ, r = pg >> 2, cg = pg & 3;
@@ -1364,9 +1366,11 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
       const int u = tid + i * 256, pg = u / QA, q = u % QA, hr = pg / 5, hg = pg % 5;
       if (u < XU) stage(px_[i], Xs, CI_B, 4 * q, CSX, hr * 12 + hg * 2);
     }
+    }
     __syncthreads();
     const int next = t + gridDim.x;
-    if (next < a.n_tiles) fetch(next);
+    if (next < a.n_tiles && !(a.abl & 4)) fetch(next);
+    if (!(a.abl & 1))
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int s = part * KS + ks, rr = 2 * s + (g >> 1), h = g & 1;
@@ -1532,10 +1536,48 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restri
     dW[o] = accumulate ? dW[o] + s : s;
   }
 }
+// <16,32> with four consecutive elements (one 16-byte load per slab) per thread: 256-byte runs per slab instead of 64-byte
+// ones, a quarter of the blocks.  Same per-element summation order as wgrad_reduce_kernel<16,32> (bit-identical).
+__global__ __launch_bounds__(512) void wgrad_reduce4_kernel(const float* __restrict__ partial, int chunks, int taps, int CoutPad, int CinPad,
+                                                           int Cout, int Cin, float* __restrict__ dW, int accumulate) {
+  constexpr int EL4 = 16, GR = 32;
+  __shared__ f32x4 red[GR][EL4];
+  const int tx = threadIdx.x % EL4, ty = threadIdx.x / EL4;
+  const long j = ((long)blockIdx.x * EL4 + tx) * 4;
+  const long tot = (long)taps * Cout * Cin;
+  f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+  int ci = 0, co = 0, tap = 0;
+  if (j < tot) {
+    ci = j % Cin; const long r = j / Cin; co = r % Cout; tap = r / Cout;
+    const long off = ((long)tap * CoutPad + co) * CinPad + ci, stride = (long)taps * CoutPad * CinPad;
+    int c = ty;
+    for (; c + GR < chunks; c += 2 * GR) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(partial + off + (long)c * stride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(partial + off + (long)(c + GR) * stride);
+      s0 += v0; s1 += v1;
+    }
+    for (; c < chunks; c += GR) s0 += *reinterpret_cast<const f32x4*>(partial + off + (long)c * stride);
+  }
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty == 0 && j < tot) {
+    f32x4 sv = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < GR; g += 4) sv += (red[g][tx] + red[g + 1][tx]) + (red[g + 2][tx] + red[g + 3][tx]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long o = ((long)co * Cin + ci + e) * taps + tap;
+      dW[o] = accumulate ? dW[o] + sv[e] : sv[e];
+    }
+  }
+}
 static void launch_wgrad_reduce(hipStream_t st, const float* ws, int chunks, int taps, int CoutPad, int CinPad, int Cout, int Cin,
                                 float* dW, int accumulate) {
   const long tot = (long)Cout * Cin * taps;
-  if (chunks > 16)
+  static const bool v4 = !(getenv("ARCO_WGRAD_REDUCE4") && atoi(getenv("ARCO_WGRAD_REDUCE4")) == 0);
+  if (v4 && chunks > 16 && (Cin & 3) == 0 && (CinPad & 3) == 0 && tot >= 64 * 64)
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((tot / 4 + 15) / 16)), dim3(512), 0, st, ws, chunks, taps, CoutPad, CinPad, Cout, Cin, dW, accumulate);
+  else if (chunks > 16)
     hipLaunchKernelGGL((wgrad_reduce_kernel<16, 32>), dim3((tot + 15) / 16), dim3(512), 0, st, ws, chunks, taps, CoutPad, CinPad, Cout, Cin, dW, accumulate);
   else
     hipLaunchKernelGGL((wgrad_reduce_kernel<64, 8>), dim3((tot + 63) / 64), dim3(512), 0, st, ws, chunks, taps, CoutPad, CinPad, Cout, Cin, dW, accumulate);
@@ -1808,6 +1850,8 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   a.D3 = D3; a.mma = mma == 3 ? 3 : ((taps == 27 && mma) ? 2 : 0);   // 1 / 2: bf16 operands (gradients: range); 3: split-bf16 (fp32-accurate)
   a.dZ = dZ; a.ldz = ld_dz; a.Cout = Cout; a.Ain = in; a.lda = ld_in; a.Cin = Cin; a.taps = taps;
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.partial = ws;
+  static const int abl = getenv("ARCO_WGRAD_ABL") ? atoi(getenv("ARCO_WGRAD_ABL")) : 0;
+  a.abl = abl;
   const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
   a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
   a.n_tiles = taps >= 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
@@ -1829,7 +1873,8 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     if (flat) a.n_tiles = NB * ((H * (W + 2) + 127) / 128);
     const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
     // 32x32 blocks run persistent (2 workgroups per CU, several tiles each); the others one slab per ~tile
-    const long target = (hco == 32 && hci == 32) ? 512 : 768;
+    // (16 x 32 blocks of the split kernel: 60.7 KB of LDS, two per CU as well - 768 left a third round at half occupancy)
+    const long target = (hci == 32 && (hco == 32 || a.mma == 3)) ? 512 : 768;
     long chunks = target / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
     dim3 hgrid((unsigned)chunks, ydim, zdim);
 #define WH(COB, CIB)                                                                              \
