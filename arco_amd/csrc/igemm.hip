@@ -1013,10 +1013,14 @@ struct WgradArgs {
   int abl;             // ablation bits for tools/micro/wgrad_abl.py (0 in the product): 1 no MFMA phase, 2 no staging, 4 no global loads
 };
 
+constexpr int WGRAD1_PAD = 8;
 template <int CO_B, int CI_B>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-  constexpr int LDZ = (CO_B % 32 == 0) ? CO_B + 16 : CO_B;
-  constexpr int LDA = (CI_B % 32 == 0) ? CI_B + 16 : CI_B;
+  // row pad 8 (was 16): 64 x 64 blocks take 73.7 KB instead of 82 KB of LDS - TWO workgroups per CU, so one stages while the
+  // other is on the matrix cores (the staging loads are not prefetched); the fragment reads become 2-way bank conflicts,
+  // 8 reads against 16 MFMAs per K step
+  constexpr int LDZ = (CO_B % 32 == 0) ? CO_B + WGRAD1_PAD : CO_B;
+  constexpr int LDA = (CI_B % 32 == 0) ? CI_B + WGRAD1_PAD : CI_B;
   constexpr int CO_T = CO_B / 16, CI_T = CI_B / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Zs = smem;                 // [128][LDZ]
@@ -1036,7 +1040,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < CI_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+  // the next tile's operands travel global -> registers while this tile is on the matrix cores (fetch), registers -> LDS
+  // behind the barrier (stage): unprefetched staging loads were 100 of the 180 us of the 16 384 x 448 x 448 head gradient
+  constexpr int NZ = 128 * (CO_B / 4) / 256, NX = 128 * (CI_B / 4) / 256;
+  f32x4 rz[NZ], rx[NX];
+  auto fetch = [&](int t) {
     int img = 0, y0 = 0, x0 = 0; long m0 = 0;
     if (sp) {
       int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; img = tt / tiles_y;
@@ -1044,9 +1052,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     } else {
       m0 = (long)t * 128;
     }
-    __syncthreads();
-    // stage dZ tile and (shifted) input tile; 128 pixels each
-    for (int idx = tid; idx < 128 * (CO_B / 4); idx += 256) {
+#pragma unroll
+    for (int it = 0; it < NZ; ++it) {
+      const int idx = tid + it * 256;
       const int p = idx / (CO_B / 4), q = idx % (CO_B / 4);
       long pix = -1;
       if (sp) { const int y = y0 + p / 16, x = x0 + p % 16; if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x; }
@@ -1061,9 +1069,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
           for (int e = 0; e < 4; ++e) if (c + e < a.Cout) v[e] = src[e];
         }
       }
-      *reinterpret_cast<f32x4*>(&Zs[p * LDZ + 4 * q]) = v;
+      rz[it] = v;
     }
-    for (int idx = tid; idx < 128 * (CI_B / 4); idx += 256) {
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int idx = tid + it * 256;
       const int p = idx / (CI_B / 4), q = idx % (CI_B / 4);
       long pix = -1;
       if (sp) {
@@ -1083,9 +1093,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
           for (int e = 0; e < 4; ++e) if (c + e < a.Cin) v[e] = src[e];
         }
       }
-      *reinterpret_cast<f32x4*>(&Xs[p * LDA + 4 * q]) = v;
+      rx[it] = v;
+    }
+  };
+  int t = blockIdx.x;
+  if (t < a.n_tiles) fetch(t);
+  for (; t < a.n_tiles; t += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NZ; ++it) {
+      const int idx = tid + it * 256;
+      *reinterpret_cast<f32x4*>(&Zs[(idx / (CO_B / 4)) * LDZ + 4 * (idx % (CO_B / 4))]) = rz[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int idx = tid + it * 256;
+      *reinterpret_cast<f32x4*>(&Xs[(idx / (CI_B / 4)) * LDA + 4 * (idx % (CI_B / 4))]) = rx[it];
     }
     __syncthreads();
+    if (t + (int)gridDim.x < a.n_tiles) fetch(t + gridDim.x);
     const int pw = wid * 32;
 #pragma unroll 4
     for (int ks = 0; ks < 8; ++ks) {
@@ -1918,11 +1944,12 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     return arco_launch_status();
   }
   const long yz = (long)(a.CoutPad / co_b) * (a.CinPad / ci_b) * taps;
-  long chunks = 2048 / yz; if (chunks < 1) chunks = 1; if (chunks > a.n_tiles) chunks = a.n_tiles;
+  static const long target1 = getenv("ARCO_WGRAD1_TARGET") ? atol(getenv("ARCO_WGRAD1_TARGET")) : 512;   // two resident workgroups per CU, 6-13 tiles each (2048: 3 tiles each, a third of them behind an exposed first fetch; 4x the slabs)
+  long chunks = target1 / yz; if (chunks < 1) chunks = 1; if (chunks > a.n_tiles) chunks = a.n_tiles;
   dim3 grid((unsigned)chunks, a.CoutPad / co_b, (a.CinPad / ci_b) * taps);
 #define WG(COB, CIB)                                                                              \
   do {                                                                                            \
-    constexpr int LZ = (COB % 32 == 0) ? COB + 16 : COB, LA = (CIB % 32 == 0) ? CIB + 16 : CIB;   \
+    constexpr int LZ = (COB % 32 == 0) ? COB + WGRAD1_PAD : COB, LA = (CIB % 32 == 0) ? CIB + WGRAD1_PAD : CIB;   \
     size_t sh = (size_t)128 * (LZ + LA) * 4; const size_t rd = (size_t)4 * COB * CIB * 4;         \
     if (sh < rd) sh = rd;                                                                         \
     auto kern = wgrad_kernel<COB, CIB>;                                                           \
