@@ -1003,6 +1003,13 @@ __global__ void pack_many_kernel(const PackDesc* __restrict__ desc, int n_desc, 
 // pixels); each wave reduces 32 pixels per tile; partial slabs are summed in fixed
 // order by wgrad_reduce_kernel (deterministic).
 // ---------------------------------------------------------------------------
+// ablation bits of tools/micro/wgrad_abl.py / wgrad1_bench.py: compiled in only with -DARCO_WGRAD_ABLATION (as run-time
+// branches they cost wgrad_split_kernel<16,16> 8 VGPRs and 56 % of its speed)
+#ifdef ARCO_WGRAD_ABLATION
+#define WGRAD_ABL(a) ((a).abl)
+#else
+#define WGRAD_ABL(a) 0
+#endif
 struct WgradArgs {
   const float* dZ; long ldz; int Cout;
   const float* Ain; long lda; int Cin;
@@ -1379,9 +1386,9 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
   };
 
   int t = blockIdx.x;
-  if (t < a.n_tiles && !(a.abl & 4)) fetch(t);
+  if (t < a.n_tiles && !(WGRAD_ABL(a) & 4)) fetch(t);
   while (t < a.n_tiles) {
-    if (!(a.abl & 2)) {
+    if (!(WGRAD_ABL(a) & 2)) {
 #pragma unroll
     for (int i = 0; i < NZU; ++i) {
       const int u = tid + i * 256, pg = u / QZ, q = u % QZ, r = pg >> 2, cg = pg & 3;
@@ -1395,8 +1402,8 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
     }
     __syncthreads();
     const int next = t + gridDim.x;
-    if (next < a.n_tiles && !(a.abl & 4)) fetch(next);
-    if (!(a.abl & 1))
+    if (next < a.n_tiles && !(WGRAD_ABL(a) & 4)) fetch(next);
+    if (!(WGRAD_ABL(a) & 1))
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int s = part * KS + ks, rr = 2 * s + (g >> 1), h = g & 1;

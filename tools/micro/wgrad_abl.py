@@ -1,5 +1,6 @@
 """3x3 split-bf16 weight-gradient kernel (wgrad_split_kernel) in isolation: HIP-event time per launch for the step's shapes,
-rotating over 4 buffer pairs.  ARCO_WGRAD_ABL bits (igemm.hip): 1 no MFMA phase, 2 no staging, 4 no global loads."""
+rotating over 4 buffer pairs.  ARCO_WGRAD_ABL bits: 1 no MFMA phase, 2 no staging, 4 no global loads - only in a library built with
+`make -C arco_amd/csrc -B EXTRA=-DARCO_WGRAD_ABLATION` (the branches are compiled out of the product library)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
