@@ -212,8 +212,16 @@ def contrast_sample(pl, memobank, queue_size, func='asmc', num_queries=256, num_
     return contrast_draw(pl, func, _trace)
 
 
+SAMPLER_PREGEN = int(__import__('os').environ.get('ARCO_SAMPLER_PREGEN', '1'))    # A/B switch (0: no pregenerated generator blocks)
+
+
 @torch.no_grad()
 def contrast_counts(pl, memobank, queue_size, num_queries=256, num_negatives=512):
+    if SAMPLER_PREGEN:
+        # While this thread waits for the counters: the CPU generator's next state blocks for the draws the samplers are
+        # about to make (anchor calls: <= one draw per candidate pixel; negative calls: ~2.03 draws per index), computed
+        # by a native worker thread - the replay in contrast_draw then finds them ready (samplers.pregen).
+        samplers.pregen(min(pl.n_pix + pl.C * (int(2.1 * num_queries * num_negatives) + 8192) + 65536, 8 << 20))
     pl.ready.synchronize()                                  # the one device->host dependency of the loss
     C = pl.C
     tot = pl.totals_host.tolist()

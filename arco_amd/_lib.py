@@ -114,6 +114,7 @@ _QUERIES = {   # plain host helpers returning sizes
     # host-side native sampler replay (no GPU work)
     "arco_grid_sample": ([_P, _L, _L, _L, _I, _I, _P], _L),
     "arco_randint": ([_P, _L, _L, _L, _P], _L),
+    "arco_mt_pregen": ([_P, _L, _L, _I], _L),
     "arco_grid_sample_many": ([_P, _L, _I, _P, _P, _I, _I, _P, _I], _L),
 }
 EXPORTS = sorted(list(_SIGS) + list(_QUERIES))

@@ -17,6 +17,13 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <chrono>
+#include <stdio.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <unistd.h>
 
 namespace {
 constexpr int MT_N = 624, MT_M = 397;
@@ -29,6 +36,12 @@ static_assert(sizeof(TorchCpuState) == 5056, "torch CPU generator state layout")
 
 struct MT {
   uint32_t st[MT_N]; int left; uint32_t next;
+  // STREAM mode (arco_mt_pregen): the generator's future state blocks were computed ahead of time - while the host was
+  // waiting for the GPU's counters anyway - and sit in `stream` (block b = the state after the b-th regeneration from the
+  // base state).  Moving to the next block is then a pointer step instead of 624 twists, so skipping ahead is O(1) and
+  // copies of the generator positioned anywhere in the stream can run in parallel.  blk = -1: still in the base block
+  // (st).  Past the last pregenerated block the generator carries on by itself (st <- last block, plain mode).
+  const uint32_t* stream = nullptr; long blk = -1, nblk = 0;
   static inline uint32_t twist(uint32_t u, uint32_t v) {
     return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu);   // branch-free
   }
@@ -39,20 +52,41 @@ struct MT {
     for (int i = MT_N - MT_M; i < MT_N - 1; ++i) st[i] = st[i + MT_M - MT_N] ^ twist(st[i], st[i + 1]);
     st[MT_N - 1] = st[MT_M - 1] ^ twist(st[MT_N - 1], st[0]);
   }
-  // advance by n draws without producing them (a draw = `if (--left == 0) next_state(); st[next++]`)
+  inline const uint32_t* cur() const { return (stream && blk >= 0) ? stream + blk * MT_N : st; }
+  inline void advance() {                      // what next_state() is in plain mode
+    if (stream && blk + 1 < nblk) { ++blk; left = MT_N; next = 0; return; }
+    if (stream) { if (blk >= 0) memcpy(st, stream + blk * MT_N, sizeof(st)); stream = nullptr; blk = -1; }
+    next_state();
+  }
+  // advance by n draws without producing them (a draw = `if (--left == 0) advance(); cur()[next++]`)
   inline void skip(uint64_t n) {
     while (n) {
       const uint64_t avail = (uint64_t)(left - 1);
       if (n <= avail) { left -= (int)n; next += (uint32_t)n; return; }
       n -= avail;
-      next_state(); next = 1; n -= 1;          // the draw that regenerates consumes st[0]; left stays MT_N
+      if (stream && blk + 1 < nblk) {          // whole pregenerated blocks at once
+        const uint64_t whole = (n - 1) / MT_N;  // the draw that enters a block consumes its word 0; left stays MT_N
+        const uint64_t room = (uint64_t)(nblk - 1 - blk) - 1;
+        const uint64_t hop = whole < room ? whole : room;
+        blk += (long)hop; n -= hop * MT_N;
+      }
+      advance(); next = 1; n -= 1;
     }
   }
+  // draws that can still be served without leaving the pregenerated blocks (0 in plain mode)
+  inline uint64_t stream_room() const {
+    if (!stream) return 0;
+    return (uint64_t)(left - 1) + (uint64_t)(nblk - 1 - blk) * MT_N;
+  }
   inline uint32_t operator()() {
-    if (--left == 0) next_state();
-    uint32_t y = st[next++];
+    if (--left == 0) advance();
+    uint32_t y = cur()[next++];
     y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
     return y;
+  }
+  inline void materialize() {                  // leave stream mode keeping the position (before the state is stored)
+    if (stream && blk >= 0) memcpy(st, stream + blk * MT_N, sizeof(st));
+    stream = nullptr; blk = -1;
   }
 };
 inline void randperm(MT& g, int64_t n, int64_t* r) {
@@ -63,6 +97,41 @@ inline void randperm(MT& g, int64_t n, int64_t* r) {
 
 
 namespace {
+// Persistent worker threads for the sampler replay (creating ~20 std::threads per step cost 0.05-0.1 ms EACH under
+// contention, more than the work they were given).  Tasks may submit tasks; a thread that waits for a group runs queued
+// tasks meanwhile.  The pool is leaked on purpose (no join at exit) and rebuilt in a forked child.
+class Pool {
+  std::vector<std::thread> th; std::deque<std::function<void()>> q; std::mutex m; std::condition_variable cv;
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !q.empty(); }); f = std::move(q.front()); q.pop_front(); }
+      f();
+    }
+  }
+ public:
+  explicit Pool(int n) { for (int i = 0; i < n; ++i) { th.emplace_back([this] { loop(); }); th.back().detach(); } }
+  void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(f)); } cv.notify_one(); }
+  bool try_run_one() {
+    std::function<void()> f;
+    { std::lock_guard<std::mutex> lk(m); if (q.empty()) return false; f = std::move(q.front()); q.pop_front(); }
+    f();
+    return true;
+  }
+};
+inline Pool& pool() {
+  static Pool* p = nullptr; static pid_t owner = 0; static std::mutex pm;
+  std::lock_guard<std::mutex> lk(pm);
+  if (!p || owner != getpid()) { p = new Pool(16); owner = getpid(); }
+  return *p;
+}
+struct Group {
+  std::atomic<int> pending{0};
+  void run(std::function<void()> f) { pending.fetch_add(1); pool().submit([this, f]() { f(); pending.fetch_sub(1); }); }
+  void wait() { Pool& p = pool(); while (pending.load() > 0) { if (!p.try_run_one()) std::this_thread::yield(); } }
+  ~Group() { wait(); }
+};
+
 struct GridGeom { long edge, side, per_block, take, last, nblk, per_row; };
 inline bool grid_geom(long high, long shape, int cut, int mirror, GridGeom& q) {
   q.edge = lround(sqrt((double)high));            // python round(): sqrt(int) is never exactly x.5, so they agree
@@ -93,42 +162,91 @@ inline bool grid_draws(long high, long shape, int cut, int mirror, uint64_t* dra
   return true;
 }
 // one sampler call on generator g (loss_helper_3d.py:120-184 / :187-268); returns shape, or 0 for the fallback
-inline size_t grid_scratch_len(const GridGeom& q) { return (size_t)(2 * (q.nblk * q.per_row + 1) + q.last * q.last + 1); }
+inline size_t grid_scratch_len(const GridGeom& q) { return (size_t)(2 * (q.nblk * q.per_row + 1) + q.nblk * (q.last * q.last + 1)); }
 // scratch: grid_scratch_len() int64s (no allocation in here: worker threads would serialise on the mm lock)
-long grid_sample_mt(MT& g, long high, long shape, int cut, int mirror, int64_t* out, int64_t* scratch) {
+// one grid block (bi, bj) of a call: randperm(h * w), then `take` picks; consumes exactly h * w - 1 + take draws
+inline void grid_block(MT& g, const GridGeom& q, int cut, int mirror, int bi, int bj, int64_t* perm, int64_t* row) {
+  const long h = bi == cut - 1 ? q.last : q.side, w = bj == cut - 1 ? q.last : q.side, n = h * w;
+  randperm(g, n, perm);
+  const long org = (bi * q.side) * q.edge + bj * q.side;
+  const long fin = org + (bi * q.side + h - 1) * q.edge + bj * q.side + w - 1;   // first + last == int64(2*mean(block))
+  // x % n, loc / w, loc % w with the block's invariant divisors as multiplications (Lemire's exact 32-bit fastmod /
+  // fastdiv; n, w >= 2): the negative calls make 8192 picks per block, three hardware divisions each
+  const uint64_t Mn = ~0ull / (uint64_t)n + 1, Mw = ~0ull / (uint64_t)w + 1;
+  for (long t = 0; t < q.take; ++t) {
+    const uint32_t x = g();
+    const uint32_t idx = (uint32_t)(((__uint128_t)(Mn * x) * (uint64_t)n) >> 64);      // == x % n
+    const int64_t loc = perm[idx];
+    const int64_t qd = (int64_t)(((__uint128_t)Mw * (uint64_t)loc) >> 64);             // == loc / w
+    const int64_t v = org + qd * q.edge + (loc - qd * w);
+    row[t] = v;
+    if (mirror) row[q.take + t] = fin - v;
+  }
+}
+// par_threads > 1 and the generator in stream mode with every block's draws pregenerated: the blocks (whose draw counts
+// are fixed by the geometry) run on copies of the generator positioned at their offsets, par_threads at a time - the
+// anchor call of a class with ~600 000 candidates is 16 permutations of ~36 000 elements, 1.4 ms in one thread
+// fixed_kept (the caller checked grid_draws(): no candidate can be dropped, kept == nblk * per_row): the final
+// randperm(kept) - a third of a negative call's time, inherently serial - starts at a known stream offset too and runs in
+// its own thread beside the blocks.
+long grid_sample_mt(MT& g, long high, long shape, int cut, int mirror, int64_t* out, int64_t* scratch, int par_threads = 1,
+                    bool fixed_kept = false) {
   GridGeom q;
   if (!grid_geom(high, shape, cut, mirror, q)) return 0;
-  const long edge = q.edge, side = q.side, take = q.take, last = q.last, nblk = q.nblk, per_row = q.per_row;
+  const long nblk = q.nblk, per_row = q.per_row;
   int64_t* vals = scratch;
   int64_t* shuf = scratch + (nblk * per_row + 1);
-  int64_t* perm = shuf + (nblk * per_row + 1);
-  long b = 0;
-  for (int bi = 0; bi < cut; ++bi) {
-    const long h = bi == cut - 1 ? last : side;
-    for (int bj = 0; bj < cut; ++bj, ++b) {
-      const long w = bj == cut - 1 ? last : side;
-      const long n = h * w;
-      randperm(g, n, perm);
-      const long org = (bi * side) * edge + bj * side;
-      const long fin = org + (bi * side + h - 1) * edge + bj * side + w - 1;   // first + last == int64(2*mean(block))
-      int64_t* row = vals + b * per_row;
-      for (long t = 0; t < take; ++t) {
-        const int64_t loc = perm[g() % (uint32_t)n];
-        const int64_t v = org + (loc / w) * edge + loc % w;
-        row[t] = v;
-        if (mirror) row[take + t] = fin - v;
-      }
-    }
+  int64_t* perm0 = shuf + (nblk * per_row + 1);
+  const long perm_len = q.last * q.last + 1;
+  uint64_t block_draws = 0;
+  for (int bi = 0; bi < cut; ++bi)
+    for (int bj = 0; bj < cut; ++bj)
+      block_draws += (uint64_t)((bi == cut - 1 ? q.last : q.side) * (bj == cut - 1 ? q.last : q.side) - 1 + q.take);
+  static const bool trace = getenv("ARCO_SAMPLER_TRACE") != nullptr;
+  auto T0 = std::chrono::steady_clock::now();
+  auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count(); };
+  Group shuffle_group;
+  bool shuffled = false;
+  const long kept_fixed = nblk * per_row;
+  if (fixed_kept && par_threads > 1 && kept_fixed >= 32768 && g.stream_room() >= block_draws + (uint64_t)kept_fixed) {
+    MT g2 = g; g2.skip(block_draws);
+    shuffle_group.run([g2, kept_fixed, shuf]() mutable { randperm(g2, kept_fixed, shuf); });
+    shuffled = true;
   }
+  if (par_threads > 1 && block_draws >= 65536 && g.stream_room() >= block_draws) {
+    std::vector<MT> gs((size_t)nblk);
+    uint64_t off = 0;
+    for (long b = 0; b < nblk; ++b) {
+      const int bi = (int)(b / cut), bj = (int)(b % cut);
+      gs[b] = g; gs[b].skip(off);
+      off += (uint64_t)((bi == cut - 1 ? q.last : q.side) * (bj == cut - 1 ? q.last : q.side) - 1 + q.take);
+    }
+    const int nt = par_threads < (int)nblk ? par_threads : (int)nblk;
+    Group blocks;
+    for (int t = 1; t < nt; ++t)
+      blocks.run([&, t]() { for (long b = t; b < nblk; b += nt) grid_block(gs[b], q, cut, mirror, (int)(b / cut), (int)(b % cut), perm0 + b * perm_len, vals + b * per_row); });
+    for (long b = 0; b < nblk; b += nt) grid_block(gs[b], q, cut, mirror, (int)(b / cut), (int)(b % cut), perm0 + b * perm_len, vals + b * per_row);
+    blocks.wait();
+    g.skip(block_draws);
+  } else {
+    long b = 0;
+    for (int bi = 0; bi < cut; ++bi)
+      for (int bj = 0; bj < cut; ++bj, ++b) grid_block(g, q, cut, mirror, bi, bj, perm0, vals + b * per_row);
+  }
+  const double t_blocks = ms();
   // float32 round trip (torch.Tensor(...).long(), :163 / :245-246), keep < high
   long kept = 0;
   for (long i = 0; i < nblk * per_row; ++i) {
     const int64_t v = (int64_t)(float)vals[i];
     if (v < high) vals[kept++] = v;
   }
-  randperm(g, kept, shuf);
+  const double t_filter = ms();
+  if (shuffled) { shuffle_group.wait(); g.skip(kept > 1 ? (uint64_t)(kept - 1) : 0); }   // (kept == kept_fixed here)
+  else randperm(g, kept, shuf);
+  const double t_shuffle = ms();
   long m = kept < shape ? kept : shape;
   for (long i = 0; i < m; ++i) out[i] = vals[shuf[i]];
+  if (trace && shape >= 32768) fprintf(stderr, "[sampler]   call high %ld: blocks %.3f filter %.3f shuffle(join) %.3f gather %.3f ms\n", high, t_blocks, t_filter - t_blocks, t_shuffle - t_filter, ms() - t_shuffle);
   for (long i = kept; i < shape; ++i) out[i] = (int64_t)(g() % (uint32_t)high);   // one draw per padded element
   return shape;
 }
@@ -143,10 +261,26 @@ inline bool load_state(const uint8_t* state, long state_bytes, MT& g) {
   g.left = ts->legacy.left; g.next = (uint32_t)ts->legacy.next;
   return true;
 }
-inline void store_state(uint8_t* state, const MT& g) {
+inline void store_state(uint8_t* state, const MT& g_in) {
+  MT g = g_in; g.materialize();
   TorchCpuState* ts = reinterpret_cast<TorchCpuState*>(state);
   for (int i = 0; i < MT_N; ++i) ts->legacy.state[i] = g.st[i];
   ts->legacy.left = g.left; ts->legacy.next = g.next;
+}
+// ---- pregenerated state blocks (arco_mt_pregen): valid for the generator state they were made from
+static std::vector<uint32_t> g_stream;
+static MT g_stream_base;
+static long g_stream_blocks = 0;
+static Group g_stream_group;
+static std::mutex g_stream_mutex;
+inline void stream_join() { g_stream_group.wait(); }
+// switch g to stream mode when it is exactly the state the blocks were generated from
+inline void stream_attach(MT& g) {
+  std::lock_guard<std::mutex> lk(g_stream_mutex);
+  stream_join();
+  if (g_stream_blocks <= 0 || g.left != g_stream_base.left || g.next != g_stream_base.next ||
+      memcmp(g.st, g_stream_base.st, sizeof(g.st)) != 0) return;
+  g.stream = g_stream.data(); g.blk = -1; g.nblk = g_stream_blocks;
 }
 }  // namespace
 
@@ -180,6 +314,11 @@ long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const l
   if (n_jobs < 0 || cut <= 0) return -1;
   MT g;
   if (!load_state(state, state_bytes, g)) return state_bytes != (long)sizeof(TorchCpuState) ? -1 : -2;
+  static const bool trace = getenv("ARCO_SAMPLER_TRACE") != nullptr;
+  auto T0 = std::chrono::steady_clock::now();
+  auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count(); };
+  stream_attach(g);                    // pregenerated blocks of exactly this state, if any (arco_mt_pregen)
+  if (trace) fprintf(stderr, "[sampler] attach %.3f ms (stream %d)\n", ms(), g.stream != nullptr);
   std::lock_guard<std::mutex> lock(g_arena_mutex);
   std::vector<size_t> off(n_jobs + 1, 0);
   for (int j = 0; j < n_jobs; ++j) {
@@ -188,7 +327,7 @@ long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const l
     off[j + 1] = off[j] + (ok ? grid_scratch_len(q) : 0);
   }
   if (g_arena.size() < off[n_jobs]) g_arena.resize(off[n_jobs]);
-  std::vector<std::thread> workers;
+  Group workers; int n_workers = 0;
   std::vector<MT> copies((size_t)n_jobs);
   long done = n_jobs;
   for (int j = 0; j < n_jobs; ++j) {
@@ -196,19 +335,44 @@ long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const l
     if (high <= 0 || shape <= 0 || high >= (1l << 31)) { done = -1; break; }
     int64_t* scratch = g_arena.data() + off[j];
     uint64_t draws = 0;
-    if (shape >= 8192 && (int)workers.size() < max_threads && grid_draws(high, shape, cut, mirror, &draws)) {
+    if (shape >= 8192 && n_workers < max_threads && grid_draws(high, shape, cut, mirror, &draws)) {
       copies[j] = g;
       MT* copy = &copies[j];
       int64_t* out = outs[j];
-      workers.emplace_back([copy, high, shape, cut, mirror, out, scratch]() { grid_sample_mt(*copy, high, shape, cut, mirror, out, scratch); });
+      workers.run([copy, high, shape, cut, mirror, out, scratch]() { grid_sample_mt(*copy, high, shape, cut, mirror, out, scratch, 4, true); });
+      ++n_workers;
       g.skip(draws);
+      if (trace) fprintf(stderr, "[sampler] job %d (worker, %ld) launched at %.3f ms\n", j, shape, ms());
       continue;
     }
-    if (grid_sample_mt(g, high, shape, cut, mirror, outs[j], scratch) == 0) { done = j; break; }
+    if (grid_sample_mt(g, high, shape, cut, mirror, outs[j], scratch, max_threads) == 0) { done = j; break; }
+    if (trace) fprintf(stderr, "[sampler] job %d (inline, high %ld) done at %.3f ms\n", j, high, ms());
   }
-  for (auto& t : workers) t.join();
+  workers.wait();
+  if (trace) fprintf(stderr, "[sampler] joined at %.3f ms\n", ms());
   if (done >= 0) store_state(state, g);
   return done;
+}
+
+// Pregenerate the generator's next state blocks for >= n_draws draws from `state` (not modified) - called right before
+// the host blocks on the GPU's counters, so the ~1 ns per draw of mt19937 state regeneration (1.6 M draws per step at
+// config 2) is paid while the host would be idle; background != 0: in a worker thread.  The next arco_grid_sample_many
+// call that starts from exactly this state uses the blocks (any other state: they are ignored).  Returns the block count.
+long arco_mt_pregen(const uint8_t* state, long state_bytes, long n_draws, int background) {
+  MT base;
+  if (n_draws <= 0 || !load_state(state, state_bytes, base)) return -1;
+  std::lock_guard<std::mutex> lk(g_stream_mutex);
+  stream_join();
+  const long blocks = n_draws / MT_N + 2;
+  if ((long)g_stream.size() < blocks * MT_N) g_stream.resize((size_t)blocks * MT_N);
+  g_stream_base = base; g_stream_base.stream = nullptr; g_stream_base.blk = -1;
+  g_stream_blocks = blocks;
+  uint32_t* dst = g_stream.data();
+  auto work = [base, blocks, dst]() mutable {
+    for (long b = 0; b < blocks; ++b) { base.next_state(); memcpy(dst + b * MT_N, base.st, sizeof(base.st)); }
+  };
+  if (background) g_stream_group.run(work); else work();
+  return blocks;
 }
 
 // plain torch.randint(high, (n,)) replay (func not in {'asmc','smc'}, and the high < 16 fallbacks)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 __all__ = ["grid_monte_carlo_sample", "grid_as_monte_carlo_sample", "monte_carlo_sample",
-           "as_monte_carlo_sample", "grid_sample_many"]
+           "as_monte_carlo_sample", "grid_sample_many", "pregen"]
 
 
 def _one_dim(high, shape, patch, mirror):
@@ -125,6 +125,20 @@ def grid_as_monte_carlo_sample(high=5233, shape=256, cut_count=4):
 
 
 @torch.no_grad()
+def pregen(n_draws=3 << 20, background=True):
+    """Compute the torch CPU generator's next state blocks for >= n_draws draws ahead of time (native worker thread; the
+    generator itself is not touched).  The trainers call this right before they block on the GPU's per-class counters:
+    the next grid_sample_many call from the unchanged generator state then reads the blocks instead of regenerating -
+    skip-ahead becomes O(1), the grid blocks of the anchor calls and the negative calls run in parallel.  Pure
+    acceleration: same draws, same final generator state; from any other generator state the blocks are ignored."""
+    from . import _lib
+    st = torch.get_rng_state()
+    rc = _lib.load().arco_mt_pregen(st.data_ptr(), st.numel(), int(n_draws), 1 if background else 0)
+    if rc < 0:
+        raise RuntimeError(f"arco_mt_pregen failed ({rc})")
+    return int(rc)
+
+
 def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=8):
     """[(high, shape), ...] -> list of index tensors, the SAME draws as calling grid_(as_)monte_carlo_sample
     for each job in order, through ONE native call: jobs whose generator consumption does not depend on the drawn

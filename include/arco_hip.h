@@ -290,6 +290,12 @@ long arco_grid_sample(uint8_t* state, long state_bytes, long high, long shape, i
 long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const long* highs, const long* shapes, int cut,
                            int mirror, int64_t* const* outs, int max_threads);
 long arco_randint(uint8_t* state, long state_bytes, long high, long n, int64_t* out);
+/* the generator's next state blocks for >= n_draws draws, computed ahead of time from `state` (not modified; in a worker
+   thread when background != 0) while the host waits for the GPU's per-class counters (loss_helper_3d.py:413-434 needs them
+   before the first sampler call :435-476).  The next arco_grid_sample_many call that starts from exactly this state reads
+   the blocks instead of regenerating (skip-ahead O(1): the big calls run in parallel, the 16 grid blocks of an anchor call
+   too); from any other state they are ignored.  Same draws, same final generator state.                              */
+long arco_mt_pregen(const uint8_t* state, long state_bytes, long n_draws, int background);
 
 #ifdef __cplusplus
 }

@@ -86,3 +86,53 @@ def test_grid_sample_many_equals_sequential_calls(mirror):
         assert torch.equal(torch.get_rng_state(), st_ref), threads
         for r, g_ in zip(ref, got):
             assert torch.equal(r, g_), threads
+
+
+def _many_jobs():
+    jobs = []
+    for na in (572607, 86, 217, 5000):
+        jobs += [(na, 256), (4096, 256 * 512)]
+    return jobs
+
+
+@pytest.mark.parametrize("pre", [3 << 20, 700000, 10000])
+@pytest.mark.parametrize("threads", [8, 1])
+@pytest.mark.parametrize("mirror", [False, True])
+def test_pregenerated_generator_blocks_change_nothing(pre, threads, mirror):
+    """samplers.pregen (the generator's next state blocks computed ahead of time, while the trainer waits for the GPU's
+    counters) is pure acceleration: the sampler sequence of a step draws the same indices and leaves the generator in the
+    same state - with enough blocks, with blocks that run out inside a negative call (700 000 draws) and inside the first
+    anchor call (10 000), with and without the parallel paths."""
+    from arco_amd import samplers
+    jobs = _many_jobs()
+    tot = sum(s for _, s in jobs)
+
+    def run(n_pre):
+        torch.manual_seed(11)
+        torch.rand(7)                       # somewhere inside a state block
+        if n_pre:
+            samplers.pregen(n_pre)
+        buf = torch.empty(tot, dtype=torch.int64)
+        samplers.grid_sample_many(jobs, mirror, out=buf, max_threads=threads)
+        return buf, torch.get_rng_state().clone(), torch.rand(3)
+
+    ref, st_ref, nxt_ref = run(0)
+    got, st, nxt = run(pre)
+    assert torch.equal(ref, got) and torch.equal(st_ref, st) and torch.equal(nxt_ref, nxt)
+
+
+def test_pregenerated_blocks_of_another_state_are_ignored():
+    """Blocks are only used from exactly the generator state they were computed for: any draw in between makes them stale."""
+    from arco_amd import samplers
+    jobs = _many_jobs()
+    tot = sum(s for _, s in jobs)
+    out = []
+    for stale in (True, False):
+        torch.manual_seed(5)
+        if stale:
+            samplers.pregen(3 << 20)
+        torch.rand(1)
+        buf = torch.empty(tot, dtype=torch.int64)
+        samplers.grid_sample_many(jobs, False, out=buf)
+        out.append((buf, torch.get_rng_state().clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
