@@ -237,7 +237,10 @@ def contrast_counts(pl, memobank, queue_size, num_queries=256, num_negatives=512
 
 
 @torch.no_grad()
-def contrast_draw(pl, func='asmc', _trace=None):
+def contrast_draw(pl, func='asmc', _trace=None, defer=False):
+    """defer=True (the trainers): the native replay returns once the CPU generator holds its final state; the negative
+    draws finish in worker threads and the index upload happens in contrast_draw_finish (called by contrast_anchor_pix /
+    contrast_infonce) - the caller draws the equivariance warp and queues that pass in between."""
     if func == 'asmc':                                                  # :327-338
         draw, q_arg, n_arg = samplers.grid_as_monte_carlo_sample, pl.Q, pl.Q * pl.Nn
     elif func == 'smc':
@@ -245,6 +248,7 @@ def contrast_draw(pl, func='asmc', _trace=None):
     else:
         draw, q_arg, n_arg = torch.randint, (pl.Q,), (pl.Q * pl.Nn,)
     pl.entries = []
+    pl._pending_upload = None
     pl.idx_all, pl.idx_stride = None, 0       # packed [anchors(Q) | negatives(Q*Nn)] per entry, when drawn in one native call
     if pl.valid_seg > 1:
         ks = [k for k in range(pl.valid_seg)                               # :435-476, k = LOOP COUNTER
@@ -258,10 +262,13 @@ def contrast_draw(pl, func='asmc', _trace=None):
                 jobs += [(int(pl.n_anchor[k]), pl.Q), (int(pl.bank_len[pl.valid_classes[k]]), pl.Q * pl.Nn)]
             total = sum(sh for _, sh in jobs)
             host = _pinned_i64(total)
-            views = samplers.grid_sample_many(jobs, func == 'asmc', out=host)
+            defer = bool(defer) and _trace is None
+            views = samplers.grid_sample_many(jobs, func == 'asmc', out=host, defer=defer)
             dev_all = torch.empty(total, dtype=torch.int64, device=pl.dev)
-            dev_all.copy_(host[:total], non_blocking=True)
             pl._host_idx = host                                           # keep the staging buffer alive until used
+            pl._pending_upload = (dev_all, total)
+            if not defer:
+                contrast_draw_finish(pl)
             pl.idx_all, pl.idx_stride = dev_all, pl.Q + pl.Q * pl.Nn
             off = 0
             for i, k in enumerate(ks):
@@ -282,6 +289,16 @@ def contrast_draw(pl, func='asmc', _trace=None):
                     _trace.setdefault("anchor_idx", []).append(a_idx)
                     _trace.setdefault("neg_idx", []).append(n_idx)
     return pl
+
+
+def contrast_draw_finish(pl):
+    """Collect a deferred contrast_draw: wait for the worker calls, upload the indices (one copy).  Idempotent."""
+    pend = getattr(pl, "_pending_upload", None)
+    if pend is not None:
+        samplers.finish_many()
+        dev_all, total = pend
+        dev_all.copy_(pl._host_idx[:total], non_blocking=True)
+        pl._pending_upload = None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -361,6 +378,7 @@ def _pack_indices(pl):
 
 @torch.no_grad()
 def contrast_anchor_pix(pl):
+    contrast_draw_finish(pl)
     """global pixel id of every sampled anchor, entries concatenated"""
     if pl.entries:
         _pack_indices(pl)
@@ -426,6 +444,7 @@ def contrast_infonce(pl, A_all, memobank, temp=0.5, momentum_prototype=None, i_i
     """A_all [len(entries)*Q, D]: the sampled anchor rows (student), entries in plan order.
     Returns (loss, prototype-or-None).  The gradient w.r.t. A_all is computed here (it only needs
     forward quantities) and attached through _CompactGrad."""
+    contrast_draw_finish(pl)
     dev, D, Q, Nn, C = pl.dev, pl.D, pl.Q, pl.Nn, pl.C
     Dp = _ceil(D, 16)
     valid_seg = pl.valid_seg

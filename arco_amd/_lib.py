@@ -116,6 +116,8 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_randint": ([_P, _L, _L, _L, _P], _L),
     "arco_mt_pregen": ([_P, _L, _L, _I], _L),
     "arco_grid_sample_many": ([_P, _L, _I, _P, _P, _I, _I, _P, _I], _L),
+    "arco_grid_sample_many_async": ([_P, _L, _I, _P, _P, _I, _I, _P, _I], _L),
+    "arco_grid_sample_many_finish": ([], None),
 }
 EXPORTS = sorted(list(_SIGS) + list(_QUERIES))
 

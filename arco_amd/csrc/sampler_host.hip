@@ -253,6 +253,11 @@ long grid_sample_mt(MT& g, long high, long shape, int cut, int mirror, int64_t* 
 // process-lifetime scratch arena (pages stay resident from call to call); one sampler sequence at a time
 static std::vector<int64_t> g_arena;
 static std::mutex g_arena_mutex;
+// a deferred sampler sequence (arco_grid_sample_many_async) whose worker calls may still be running; owns the arena
+static Group g_many_workers;
+static std::vector<MT> g_many_copies;
+static bool g_many_active = false;
+static void many_finish() { if (g_many_active) { g_many_workers.wait(); g_many_active = false; } }
 inline bool load_state(const uint8_t* state, long state_bytes, MT& g) {
   if (state_bytes != (long)sizeof(TorchCpuState)) return false;
   const TorchCpuState* ts = reinterpret_cast<const TorchCpuState*>(state);
@@ -296,6 +301,7 @@ long arco_grid_sample(uint8_t* state, long state_bytes, long high, long shape, i
   GridGeom q;
   if (!grid_geom(high, shape, cut, mirror, q)) return 0;
   std::lock_guard<std::mutex> lock(g_arena_mutex);
+  many_finish();
   if (g_arena.size() < grid_scratch_len(q)) g_arena.resize(grid_scratch_len(q));
   const long rc = grid_sample_mt(g, high, shape, cut, mirror, out, g_arena.data());
   if (rc > 0) store_state(state, g);
@@ -309,8 +315,24 @@ long arco_grid_sample(uint8_t* state, long state_bytes, long high, long shape, i
 // and goes on with the next call.  Stops at the first call that needs the reference's 1-D fallback (which uses
 // python's `random`): returns its index (n_jobs when all ran); jobs before it are complete and `state` is the
 // generator state right before it.  <0 on error.
+// deferred form: the calls that run in worker threads (the negative draws: their number of draws is known before they
+// run) need not have FINISHED for the generator's final state to be known - arco_grid_sample_many_async returns as soon as
+// the inline calls are done and the last worker is launched (state stored), the trainer draws its next random numbers
+// (the equivariance warp) and queues ~5 ms of GPU work, and collects the indices with arco_grid_sample_many_finish()
+// before it uploads them.  Same outputs, same generator state as arco_grid_sample_many.
+static long sample_many_impl(uint8_t* state, long state_bytes, int n_jobs, const long* highs, const long* shapes, int cut,
+                             int mirror, int64_t* const* outs, int max_threads, bool deferred);
+void arco_grid_sample_many_finish() { std::lock_guard<std::mutex> lock(g_arena_mutex); many_finish(); }
+long arco_grid_sample_many_async(uint8_t* state, long state_bytes, int n_jobs, const long* highs, const long* shapes, int cut,
+                                 int mirror, int64_t* const* outs, int max_threads) {
+  return sample_many_impl(state, state_bytes, n_jobs, highs, shapes, cut, mirror, outs, max_threads, true);
+}
 long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const long* highs, const long* shapes, int cut,
                            int mirror, int64_t* const* outs, int max_threads) {
+  return sample_many_impl(state, state_bytes, n_jobs, highs, shapes, cut, mirror, outs, max_threads, false);
+}
+static long sample_many_impl(uint8_t* state, long state_bytes, int n_jobs, const long* highs, const long* shapes, int cut,
+                             int mirror, int64_t* const* outs, int max_threads, bool deferred) {
   if (n_jobs < 0 || cut <= 0) return -1;
   MT g;
   if (!load_state(state, state_bytes, g)) return state_bytes != (long)sizeof(TorchCpuState) ? -1 : -2;
@@ -320,6 +342,7 @@ long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const l
   stream_attach(g);                    // pregenerated blocks of exactly this state, if any (arco_mt_pregen)
   if (trace) fprintf(stderr, "[sampler] attach %.3f ms (stream %d)\n", ms(), g.stream != nullptr);
   std::lock_guard<std::mutex> lock(g_arena_mutex);
+  many_finish();                       // (a deferred sequence still in flight owns the arena)
   std::vector<size_t> off(n_jobs + 1, 0);
   for (int j = 0; j < n_jobs; ++j) {
     GridGeom q;
@@ -327,8 +350,10 @@ long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const l
     off[j + 1] = off[j] + (ok ? grid_scratch_len(q) : 0);
   }
   if (g_arena.size() < off[n_jobs]) g_arena.resize(off[n_jobs]);
-  Group workers; int n_workers = 0;
-  std::vector<MT> copies((size_t)n_jobs);
+  Group& workers = g_many_workers; int n_workers = 0;
+  std::vector<MT>& copies = g_many_copies;
+  copies.assign((size_t)n_jobs, MT());
+  g_many_active = true;
   long done = n_jobs;
   for (int j = 0; j < n_jobs; ++j) {
     const long high = highs[j], shape = shapes[j];
@@ -348,8 +373,7 @@ long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const l
     if (grid_sample_mt(g, high, shape, cut, mirror, outs[j], scratch, max_threads) == 0) { done = j; break; }
     if (trace) fprintf(stderr, "[sampler] job %d (inline, high %ld) done at %.3f ms\n", j, high, ms());
   }
-  workers.wait();
-  if (trace) fprintf(stderr, "[sampler] joined at %.3f ms\n", ms());
+  if (!deferred || done != n_jobs) { many_finish(); if (trace) fprintf(stderr, "[sampler] joined at %.3f ms\n", ms()); }
   if (done >= 0) store_state(state, g);
   return done;
 }
@@ -361,6 +385,7 @@ long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const l
 long arco_mt_pregen(const uint8_t* state, long state_bytes, long n_draws, int background) {
   MT base;
   if (n_draws <= 0 || !load_state(state, state_bytes, base)) return -1;
+  { std::lock_guard<std::mutex> lock(g_arena_mutex); many_finish(); }     // (deferred workers may still read the old blocks)
   std::lock_guard<std::mutex> lk(g_stream_mutex);
   stream_join();
   const long blocks = n_draws / MT_N + 2;

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 __all__ = ["grid_monte_carlo_sample", "grid_as_monte_carlo_sample", "monte_carlo_sample",
-           "as_monte_carlo_sample", "grid_sample_many", "pregen"]
+           "as_monte_carlo_sample", "grid_sample_many", "finish_many", "pregen"]
 
 
 def _one_dim(high, shape, patch, mirror):
@@ -139,12 +139,20 @@ def pregen(n_draws=3 << 20, background=True):
     return int(rc)
 
 
-def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=8):
+def finish_many():
+    """Wait for the worker calls of a grid_sample_many(..., defer=True) sequence: its output buffer is complete afterwards."""
+    from . import _lib
+    _lib.load().arco_grid_sample_many_finish()
+
+
+def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=8, defer=False):
     """[(high, shape), ...] -> list of index tensors, the SAME draws as calling grid_(as_)monte_carlo_sample
     for each job in order, through ONE native call: jobs whose generator consumption does not depend on the drawn
     values (the negative draws: high = bank length = a perfect square) run in worker threads on copies of the
     generator state while the generator is skipped ahead (csrc/sampler_host.hip).  `out`: optional int64 CPU
-    tensor of sum(shape) elements (e.g. pinned) that receives the jobs back to back."""
+    tensor of sum(shape) elements (e.g. pinned) that receives the jobs back to back.
+    defer=True: return as soon as the generator holds its final state (the worker calls' draw counts are known before
+    they run) - the outputs are complete only after finish_many(); the caller may consume the generator meanwhile."""
     import ctypes
     from . import _lib
     lib = _lib.load()
@@ -168,13 +176,14 @@ def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=8):
         shapes = (ctypes.c_long * m)(*[int(sh) for _, sh in jobs[first:]])
         outs = (ctypes.c_void_p * m)(*[v.data_ptr() for v in views[first:]])
         st = torch.get_rng_state()
-        rc = lib.arco_grid_sample_many(st.data_ptr(), st.numel(), m, highs, shapes, int(cut_count), int(bool(mirror)),
-                                       outs, int(max_threads))
+        fn = lib.arco_grid_sample_many_async if defer else lib.arco_grid_sample_many
+        rc = fn(st.data_ptr(), st.numel(), m, highs, shapes, int(cut_count), int(bool(mirror)), outs, int(max_threads))
         if rc < 0:
             raise RuntimeError(f"arco_grid_sample_many failed ({rc})")
         torch.set_rng_state(st)
         first += int(rc)
         if first < n:                     # this job takes the reference's 1-D fallback (python `random` + torch)
+            lib.arco_grid_sample_many_finish()
             h, sh = jobs[first]
             views[first].copy_(single(int(h), int(sh), cut_count))
             first += 1

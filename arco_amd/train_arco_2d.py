@@ -349,7 +349,7 @@ class ArcoStep2D:
         # --revisit 1.
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)
         unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
-        C_.contrast_draw(plan, a.func)
+        C_.contrast_draw(plan, a.func, defer=True)     # indices collected by contrast_anchor_pix below
         loss_eqv = None
         if a.k2 != 0:
             # equivariance term (:404-423).  The warp is drawn AFTER the samplers, as in the reference: both consume

@@ -174,7 +174,7 @@ class ArcoStep3D:
                             defer_anchor_pix=True)
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
         unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
-        C_.contrast_draw(plan, a.func)
+        C_.contrast_draw(plan, a.func, defer=True)     # indices collected by contrast_anchor_pix below
         loss_eqv = None
         if getattr(a, "eqv_pass", 1):
             # :368-388.  The warp is drawn after the samplers (same torch-generator order as the reference).

@@ -289,6 +289,12 @@ long arco_grid_sample(uint8_t* state, long state_bytes, long high, long shape, i
  * (n_jobs when all ran; `state` = generator state right before that call), <0 on error.                       */
 long arco_grid_sample_many(uint8_t* state, long state_bytes, int n_jobs, const long* highs, const long* shapes, int cut,
                            int mirror, int64_t* const* outs, int max_threads);
+/* deferred form: returns once the generator's final state is known (inline calls done, worker calls launched - their
+   draw counts are fixed); arco_grid_sample_many_finish() waits for the worker calls' outputs.  The trainer draws the
+   equivariance warp (train_arco_2d.py:412, the next consumer of the CPU generator) and queues that pass in between.  */
+long arco_grid_sample_many_async(uint8_t* state, long state_bytes, int n_jobs, const long* highs, const long* shapes, int cut,
+                                 int mirror, int64_t* const* outs, int max_threads);
+void arco_grid_sample_many_finish(void);
 long arco_randint(uint8_t* state, long state_bytes, long high, long n, int64_t* out);
 /* the generator's next state blocks for >= n_draws draws, computed ahead of time from `state` (not modified; in a worker
    thread when background != 0) while the host waits for the GPU's per-class counters (loss_helper_3d.py:413-434 needs them

@@ -136,3 +136,29 @@ def test_pregenerated_blocks_of_another_state_are_ignored():
         samplers.grid_sample_many(jobs, False, out=buf)
         out.append((buf, torch.get_rng_state().clone()))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("pre", [3 << 20, 0])
+def test_deferred_sampler_sequence(pre):
+    """grid_sample_many(defer=True) returns once the generator holds its final state (the worker calls' draw counts are
+    fixed); the caller may consume the generator before finish_many() - same indices, same generator draws afterwards; a
+    following sampler call waits for the pending one by itself."""
+    from arco_amd import samplers
+    jobs = _many_jobs()
+    tot = sum(s for _, s in jobs)
+
+    def run(defer):
+        torch.manual_seed(23)
+        if pre:
+            samplers.pregen(pre)
+        buf = torch.empty(tot, dtype=torch.int64)
+        samplers.grid_sample_many(jobs, True, out=buf, defer=defer)
+        nxt = torch.rand(5)                                   # the next consumer (the equivariance warp in the trainers)
+        extra = samplers.grid_as_monte_carlo_sample(5233, 256)     # a sampler call while workers may still run
+        if defer:
+            samplers.finish_many()
+        return buf, nxt, extra, torch.get_rng_state().clone()
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

@@ -22,7 +22,7 @@ def run(n):
         st.step(l, ll, u, 0, 100)
 run(150)
 for rep in range(3):
-    for d in (0.0, 0.001, -1):
+    for d in (0.0, 0.0005, 0.001, -1):
         delay[0] = max(d, 0.0)
         if d < 0:
             C_.contrast_draw = orig
