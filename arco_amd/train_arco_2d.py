@@ -333,6 +333,22 @@ class ArcoStep2D:
             x1p, f2, f3, f4 = self.q_feature_extractor.forward_lowres1(fm_all)
         else:
             x2p, f3, f4 = self.q_feature_extractor.forward_lowres2(fm_all)
+        # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340): they need neither the
+        # counters nor the samples - queued before the host blocks.  The equivariance term follows the sampler draw below.
+        # k4*loss_q (revisiting loss; no gradient path to any parameter) only with --revisit 1.
+        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)
+        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
+        eqv_in = None
+        if a.k2 != 0:
+            # inputs of the equivariance term that depend neither on the counters nor on the warp: queued BEFORE the host
+            # blocks on the counters (the stretch between the counters' arrival and the warped student pass is the part
+            # of the step where the GPU can run dry: tools/draw_critical.py)
+            with torch.no_grad():
+                labels_all = torch.cat((l_label, u_aug_label))
+                # images_cj1_logits_l (:287-288) is the constant 255 pushed through ToTensor = 1.0 everywhere
+                logits_all = torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits))
+                eqv_in = (glue.eqv_mask(labels_all, logits_all, a.weak_threshold), torch.cat((cj2_l, cj2_u)),
+                          torch.cat((pred_l.detach(), pred_u.detach())))
         # ---- host: wait for the counters; everything that needs the COUNTS but not the sampled INDICES is queued
         #      first (row lists, prototypes, key rows, bank append, the supervised / unsupervised loss forwards), so the
         #      GPU has work while the host replays the samplers (bit-exact torch-CPU-generator sequence, ~2 ms)
@@ -344,11 +360,6 @@ class ArcoStep2D:
                             lazy_teacher=lazy_t, defer_anchor_pix=True)
         if prof:
             ev2[1].record()
-        # supervised CE + Dice and confidence-weighted unsupervised CE (:336-340); the equivariance
-        # term follows the sampler draw below.  k4*loss_q (revisiting loss; no gradient path to any parameter) only with
-        # --revisit 1.
-        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)
-        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
         C_.contrast_draw(plan, a.func, defer=True)     # indices collected by contrast_anchor_pix below
         loss_eqv = None
         if a.k2 != 0:
@@ -360,14 +371,11 @@ class ArcoStep2D:
                                    border_padding=False, random_mirror=True, random_scale=(0.8, 1.2), mode='affine',
                                    device=l_data.device)                 # :255-261 (draws one warp, like the reference)
             with torch.no_grad():
-                labels_all = torch.cat((l_label, u_aug_label))
-                # images_cj1_logits_l (:287-288) is the constant 255 pushed through ToTensor = 1.0 everywhere
-                logits_all = torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits))
-                eq_mask = glue.eqv_mask(labels_all, logits_all, a.weak_threshold)
+                eq_mask, images_cj2, pred_all_d = eqv_in
                 self.tps.reset_control_points()                          # :412
-                images_tps = self.tps(torch.cat((cj2_l, cj2_u)))         # :411-413 images_cj2
+                images_tps = self.tps(images_cj2)                        # :411-413 images_cj2
                 mask_tps = self.tps(eq_mask, padding_mode='zeros')
-                pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
+                pred_tps_org = self.tps(pred_all_d, padding_mode='zeros')
             pred_tps = self.s_train_tps(images_tps)[0]                   # :415 one more student pass (one BN batch)
             loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)   # :419-423
         if prof:
