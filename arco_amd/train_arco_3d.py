@@ -167,13 +167,14 @@ class ArcoStep3D:
             rep_all = self.q_rep(qfe(fm_s))                              # :289-296,301
         else:
             x2p, f3, f4 = qfe.forward_lowres2(fm_s)
+        # the loss forwards need neither counters nor samples: queued before the host blocks (see train_arco_2d.py)
+        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
+        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
         # counters -> [sample-independent GPU work] -> sampler replay on the host -> anchors (see train_arco_2d.py)
         C_.contrast_counts(plan, self.memobank, self.queue_size,
                            adist.anchors_for_rank(a.num_queries, getattr(a, "anchors_per_rank", "split")), a.num_negatives)
         C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size, lazy_teacher=lazy_t,
                             defer_anchor_pix=True)
-        loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
-        unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)
         C_.contrast_draw(plan, a.func, defer=True)     # indices collected by contrast_anchor_pix below
         loss_eqv = None
         if getattr(a, "eqv_pass", 1):
