@@ -108,6 +108,9 @@ class ArcoStep3D:
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
+        # the warped student pass carries no gradient after iteration 0 (:390-393): replayed as one graph - its ~300 eager
+        # launches sat right behind the sampler stage, the stretch of the step where the GPU waits for the host
+        self.s_fwd_tps = graphs.GraphedForward(self.model, enabled=use_graphs)
 
     def q_rep(self, x):
         x = ops.conv(x, self.q_representation[0].weight)
@@ -192,7 +195,7 @@ class ArcoStep3D:
                 mask_tps = self.tps(eq_mask, padding_mode='zeros')
                 pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
             with torch.set_grad_enabled(self.iter_num == 0):             # only iteration 0 back-propagates it (:390-393)
-                pred_tps = self.model(images_tps)[0]                     # :380
+                pred_tps = (self.model if self.iter_num == 0 else self.s_fwd_tps)(images_tps)[0]                     # :380
                 loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
         C_.contrast_anchor_pix(plan)
         if plan.valid_seg <= 1 or not plan.entries:
