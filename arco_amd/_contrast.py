@@ -305,17 +305,13 @@ def contrast_draw_finish(pl):
 # stage 3 (GPU): row lists, prototypes, key enqueue                 loss_helper_3d.py:376-411
 # ----------------------------------------------------------------------------------------------
 @torch.no_grad()
-def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace=None, lazy_teacher=None,
-                     defer_anchor_pix=False):
-    """Row lists, prototypes and key enqueue.  Teacher rows come either from the dense `rep_teacher`
-    [B,D,*spatial] (public API) or lazily from a `lazy_teacher` object (arco_amd.head): the FeatureExtractor
-    is linear, so prototype_c = W_fea4 . mean_c(fea4 input) with the class mask pushed through the
-    bi/trilinear adjoint to the low-res level, and only the <= queue_size key rows per class are evaluated.
-    Same values up to fp32 re-association of the mean."""
+def contrast_lists_protos(pl, rep_teacher=None, lazy_teacher=None):
+    """The part of stage 3 that needs neither the counters on the host nor the samples: per-class row lists
+    (arco_compact_rows: offsets are on the device) and the class prototypes (class masks and totals are on the device).  The
+    trainers queue it BEFORE they block on the counters; contrast_enqueue runs it itself when nobody has."""
     C, n_pix, dev = pl.C, pl.n_pix, pl.dev
     pl.lists = torch.empty((2 * C, n_pix), dtype=torch.int32, device=dev)
     L.call("arco_compact_rows", L.ptr(pl.codes), n_pix, C, L.ptr(pl.offsets), L.ptr(pl.lists))
-    takes = [min(int(pl.n_neg[c]), int(queue_size[c])) for c in range(C)]   # only these can survive the truncation
     if lazy_teacher is None:
         L.require_gpu(rep_teacher)
         T, ldt = rows_view(rep_teacher.detach())
@@ -326,6 +322,29 @@ def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace
         ws = torch.empty(L.query("arco_proto_ws_floats", n_pix, C, D), dtype=torch.float32, device=dev)
         L.call("arco_masked_proto", L.ptr(T), ldt, L.ptr(pl.codes), n_pix, C, D, L.ptr(pl.totals), L.ptr(ws),
                L.ptr(pl.proto))
+    else:
+        pl.proto = lazy_teacher.prototypes(pl)
+    if proto_reduce_hook is not None:        # class means over the GLOBAL batch (one [C, D+1] all-reduce, SURVEY §8e item 3)
+        pl.proto = proto_reduce_hook(pl.proto, pl.totals[:C])
+    pl.D = int(pl.proto.shape[1])
+    pl._lists_protos_done = True
+
+
+@torch.no_grad()
+def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace=None, lazy_teacher=None,
+                     defer_anchor_pix=False):
+    """Row lists, prototypes and key enqueue.  Teacher rows come either from the dense `rep_teacher`
+    [B,D,*spatial] (public API) or lazily from a `lazy_teacher` object (arco_amd.head): the FeatureExtractor
+    is linear, so prototype_c = W_fea4 . mean_c(fea4 input) with the class mask pushed through the
+    bi/trilinear adjoint to the low-res level, and only the <= queue_size key rows per class are evaluated.
+    Same values up to fp32 re-association of the mean."""
+    C, n_pix, dev = pl.C, pl.n_pix, pl.dev
+    if not getattr(pl, "_lists_protos_done", False):
+        contrast_lists_protos(pl, rep_teacher, lazy_teacher)
+    D = pl.D
+    takes = [min(int(pl.n_neg[c]), int(queue_size[c])) for c in range(C)]   # only these can survive the truncation
+    if lazy_teacher is None:
+        T, ldt = rows_view(rep_teacher.detach())
         key_rows = []
         for c in range(C):
             n, take = int(pl.n_neg[c]), takes[c]
@@ -334,19 +353,13 @@ def contrast_enqueue(pl, rep_teacher, memobank, queue_prtlis, queue_size, _trace
                    L.ptr(keys), D)
             key_rows.append(keys)
     else:
-        # lazy teacher (arco_amd.head.LazyTeacher2D / LazyTeacher3D): class means through the linear head,
-        # and only the key rows that can survive the truncation
-        pl.proto = lazy_teacher.prototypes(pl)
-        D = int(pl.proto.shape[1])
+        # lazy teacher (arco_amd.head.LazyTeacher2D / LazyTeacher3D): only the key rows that can survive the truncation
         pix = torch.cat([pl.lists[C + c][int(pl.n_neg[c]) - takes[c]:int(pl.n_neg[c])] for c in range(C)]).to(torch.int64)
         allk = lazy_teacher.rows(pix) if int(pix.shape[0]) > 0 else torch.empty((0, D), dtype=torch.float32, device=dev)
         key_rows, off = [], 0
         for c in range(C):
             key_rows.append(allk[off:off + takes[c]])
             off += takes[c]
-    if proto_reduce_hook is not None:        # class means over the GLOBAL batch (one [C, D+1] all-reduce, SURVEY §8e item 3)
-        pl.proto = proto_reduce_hook(pl.proto, pl.totals[:C])
-    pl.D = D
     pl.new_keys = []
     if tail_gather_all_hook is not None:     # data parallel: every class's surviving rows in one broadcast per contributing rank
         key_rows = tail_gather_all_hook([k.contiguous() for k in key_rows], [int(q) for q in queue_size])

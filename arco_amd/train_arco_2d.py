@@ -349,6 +349,14 @@ class ArcoStep2D:
                 logits_all = torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits))
                 eqv_in = (glue.eqv_mask(labels_all, logits_all, a.weak_threshold), torch.cat((cj2_l, cj2_u)),
                           torch.cat((pred_l.detach(), pred_u.detach())))
+        # per-class row lists and prototypes need the class codes / totals on the DEVICE only: queued before the host blocks
+        evp = None
+        if prof:
+            evp = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            evp[0].record()
+        C_.contrast_lists_protos(plan, rep_all_teacher, lazy_t)
+        if prof:
+            evp[1].record()
         # ---- host: wait for the counters; everything that needs the COUNTS but not the sampled INDICES is queued
         #      first (row lists, prototypes, key rows, bank append, the supervised / unsupervised loss forwards), so the
         #      GPU has work while the host replays the samplers (bit-exact torch-CPU-generator sequence, ~2 ms)
@@ -403,7 +411,7 @@ class ArcoStep2D:
                 self.debug = dict(plan=plan, A_all=A_all.detach(), banks=[m[0] for m in self.memobank])
         if prof:
             ev3[1].record()
-            self.loss_events.append((ev, ev2, ev3))  # masks | lists, prototypes, keys, banks | anchors, head, InfoNCE
+            self.loss_events.append((ev, ev2, ev3, evp))  # masks | keys, banks | anchors, head, InfoNCE | lists, prototypes
         loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
         if loss_eqv is not None:
             loss = loss + a.k2 * loss_eqv

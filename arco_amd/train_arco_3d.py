@@ -170,6 +170,7 @@ class ArcoStep3D:
             rep_all = self.q_rep(qfe(fm_s))                              # :289-296,301
         else:
             x2p, f3, f4 = qfe.forward_lowres2(fm_s)
+        C_.contrast_lists_protos(plan, rep_all_teacher, lazy_t)         # row lists, prototypes: device-side inputs only
         # the loss forwards need neither counters nor samples: queued before the host blocks (see train_arco_2d.py)
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
         unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)

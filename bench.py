@@ -424,6 +424,8 @@ def main():
     torch.cuda.synchronize()
     evs = stepper.loss_events[2:]
     loss_seg = [round(sum(e[i][0].elapsed_time(e[i][1]) for e in evs) / max(1, len(evs)), 3) for i in range(3)]
+    if evs and len(evs[0]) > 3 and evs[0][3] is not None:       # row lists + prototypes: queued ahead of the host sync since round 2
+        loss_seg[1] = round(loss_seg[1] + sum(e[3][0].elapsed_time(e[3][1]) for e in evs) / len(evs), 3)
     loss_ms = sum(loss_seg)
     stepper.profile_loss = False
     stepper.loss_events = []
