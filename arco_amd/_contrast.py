@@ -391,8 +391,8 @@ def _pack_indices(pl):
 
 @torch.no_grad()
 def contrast_anchor_pix(pl):
-    contrast_draw_finish(pl)
     """global pixel id of every sampled anchor, entries concatenated"""
+    contrast_draw_finish(pl)
     if pl.entries:
         _pack_indices(pl)
         E = len(pl.entries)

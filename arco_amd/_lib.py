@@ -88,6 +88,8 @@ _SIGS = {
     "arco_entropy_masks_phase": [_I, _I, _P, _P, _P, _L, _L, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P],
     "arco_sup_loss_fwd": [_P, _L, _L, _I, _P, _P, _P, _P],
     "arco_sup_loss_bwd": [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _P],
+    "arco_dice_probs_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _P],
+    "arco_dice_probs_bwd": [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _P],
     "arco_unsup_loss_fwd": [_P, _L, _I, _L, _I, _P, _P, _F, _P, _P, _P],
     "arco_unsup_loss_bwd": [_P, _L, _I, _L, _I, _P, _P, _P, _P, _L, _P],
     "arco_sgd_nesterov": [_P, _P, _P, _L, _F, _F, _F, _I, _P],

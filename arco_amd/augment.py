@@ -200,7 +200,9 @@ def batch_transform(data, label, logits, crop_size, scale_size, apply_augmentati
         raise NotImplementedError("arco_amd.batch_transform: only the trainers' configuration (same-size crop, scale 1.0)")
     params, morph = draw_batch_transform_params(B, apply_augmentation, scale_size)
     data_t = jitter_blur(data, params)
-    lg = logits.to(torch.float32).contiguous()
+    # a byte image (the reference passes `torch.ones_like(uint8 label) * 255` for the labeled stream, train_arco_2d.py:288)
+    # becomes k/255 through ToTensor; float confidences are quantised to the 8-bit grid by the PIL round trip
+    lg = (logits.to(torch.float32) / 255.0 if not logits.is_floating_point() else logits.to(torch.float32)).contiguous()
     logits_t = torch.empty_like(lg)
     L.call("arco_quantize8", L.ptr(lg), lg.numel(), L.ptr(logits_t))
     if morph:                                                          # :271-279
@@ -210,3 +212,21 @@ def batch_transform(data, label, logits, crop_size, scale_size, apply_augmentati
         aug.init_parameters()
         data_t = aug.forward(data_t).contiguous()
     return data_t, label, logits_t
+
+
+def randomGeneratorWithLogits(image, label, logit, output_size=[256, 256]):
+    """augment.py:339-369 (train_arco_2d.py:292-293): per-image scipy `zoom(order=0)` of image / pseudo-label / confidence to
+    `output_size`, the labels through a uint8 cast (values wrap modulo 256, like the reference's astype(np.uint8)).
+    At the trainers' configuration the zoom factor is 1.0 - nearest-neighbour resampling at the same size is the
+    identity - and everything stays on the GPU; other sizes take the reference's host round trip through scipy."""
+    B, _, x, y = image.shape
+    if (int(output_size[0]), int(output_size[1])) == (int(x), int(y)):
+        img = image[:, :1].to(torch.float32)
+        return img, (label.to(torch.int64) & 255), logit
+    from scipy.ndimage import zoom
+    fac = (output_size[0] / x, output_size[1] / y)
+    dev = image.device
+    img = np.stack([zoom(image[i, 0].detach().cpu().numpy(), fac, order=0) for i in range(B)]).astype(np.float32)
+    lab = np.stack([zoom(label[i].detach().cpu().numpy(), fac, order=0) for i in range(B)]).astype(np.uint8)
+    lg = np.stack([zoom(logit[i].detach().cpu().numpy(), fac, order=0) for i in range(B)])
+    return torch.from_numpy(img).unsqueeze(1).to(dev), torch.from_numpy(lab).long().to(dev), torch.from_numpy(lg).to(dev)

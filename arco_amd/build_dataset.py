@@ -69,3 +69,28 @@ class Synapse_datasetWithIndex(Dataset):
             sample = self.transform(sample)
         sample['case_name'] = name
         return sample
+
+
+class Synapse_dataset(Dataset):
+    """code/build_dataset.py:127-157 (imported by train_arco_2d.py:21): the un-indexed npz slice dataset - `<split>_40.txt`
+    training slices `<base_dir>/<name>.npz`, `<split>_vol_40.txt` validation volumes `<base_dir>/<name>.npy.{h5,npz}`."""
+
+    def __init__(self, base_dir, list_dir, split, transform=None):
+        self.transform, self.split, self.data_dir = transform, split, base_dir
+        self.sample_list = read_list(os.path.join(list_dir, split + ('_vol_40.txt' if split in ('test', 'val') else '_40.txt')))
+
+    def __len__(self):
+        return len(self.sample_list)
+
+    def __getitem__(self, idx):
+        name = self.sample_list[idx]
+        if self.split == "train":
+            with np.load(os.path.join(self.data_dir, name + '.npz')) as data:
+                image, label = data['image'], data['label']
+        else:
+            image, label = read_case(self.data_dir + "/{}.npy".format(name))
+        sample = {'image': image, 'label': label}
+        if self.transform:
+            sample = self.transform(sample)
+        sample['case_name'] = name
+        return sample

@@ -503,6 +503,69 @@ __global__ __launch_bounds__(256) void eqv_loss_bwd_kernel(const float* __restri
 
 static inline int gl_grid(long work) { long g = (work + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
 
+// ---- utils/losses.py:173-209 DiceLoss on PROBABILITIES (the class the reference trainers instantiate: train_arco_2d.py:269,338):
+// rows [M, C] of scores (any values, softmax already applied by the caller), integer labels; per class
+//   dice_c = 1 - (2 I_c + 1e-5) / (Z_c + Y_c + 1e-5),  I = sum p t, Z = sum p^2, Y = sum t^2;  loss = sum_c w_c dice_c / C
+// partial layout per block: [I_c (C), Z_c (C), Y_c (C)]; fp64 fixed-order finalize; backward = one elementwise pass.
+template <int CM>
+__global__ __launch_bounds__(256) void dice_probs_partial_kernel(const float* __restrict__ Pm, long ld, long M, int C,
+                                                                const int64_t* __restrict__ lab, double* __restrict__ part) {
+  double acc[3 * CM];
+#pragma unroll
+  for (int i = 0; i < 3 * CM; ++i) acc[i] = 0.0;
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+    const float* x = Pm + r * ld;
+    const int64_t l = lab[r];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) if (c < C) {
+      const float p = x[c], t = (l == c) ? 1.f : 0.f;
+      acc[c] += (double)(p * t); acc[CM + c] += (double)(p * p); acc[2 * CM + c] += (double)t;
+    }
+  }
+  __shared__ double sh[4][3 * CM];
+#pragma unroll
+  for (int i = 0; i < 3 * CM; ++i) {
+    const double w = wave_sum_d(acc[i]);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][i] = w;
+  }
+  __syncthreads();
+  const int np = 3 * C;
+  if (threadIdx.x < np) {
+    const int t = threadIdx.x, src = (t / C) * CM + t % C;
+    part[(long)blockIdx.x * np + t] = (sh[0][src] + sh[1][src]) + (sh[2][src] + sh[3][src]);
+  }
+}
+__global__ void dice_probs_final_kernel(const double* __restrict__ part, int nblk, int C, const float* __restrict__ wgt,
+                                        double* __restrict__ sums, float* __restrict__ out) {
+  const int np = 3 * C;
+  __shared__ double s[3 * GL_MAXC];
+  for (int i = threadIdx.x >> 6; i < np; i += 4) {
+    double a = 0.0;
+    for (int b = threadIdx.x & 63; b < nblk; b += 64) a += part[(long)b * np + i];
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) { s[i] = a; sums[i] = a; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double d = 0.0;
+    for (int c = 0; c < C; ++c)
+      d += (double)(wgt ? wgt[c] : 1.f) * (1.0 - (2.0 * s[c] + 1e-5) / (s[C + c] + s[2 * C + c] + 1e-5));
+    out[0] = (float)(d / C);
+  }
+}
+__global__ __launch_bounds__(256) void dice_probs_bwd_kernel(const float* __restrict__ Pm, long ld, long M, int C,
+                                                            const int64_t* __restrict__ lab, const double* __restrict__ sums,
+                                                            const float* __restrict__ wgt, const float* __restrict__ g,
+                                                            float* __restrict__ dP, long ldo) {
+  const float gd = g[0] / (float)C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M * C; i += (long)gridDim.x * 256) {
+    const long r = i / C; const int c = (int)(i - r * C);
+    const double t = (lab[r] == c) ? 1.0 : 0.0, p = (double)Pm[r * ld + c];
+    const double den = sums[C + c] + sums[2 * C + c] + 1e-5, num = 2.0 * sums[c] + 1e-5;
+    dP[r * ldo + c] = -gd * (wgt ? wgt[c] : 1.f) * (float)((2.0 * t * den - num * 2.0 * p) / (den * den));
+  }
+}
+
 extern "C" {
 
 int arco_softmax_rows(const float* X, long ld, long M, int C, long P, float* prob_planes, float* maxp, int64_t* amax,
@@ -704,6 +767,26 @@ int arco_sup_loss_bwd(const float* X, long ld, long M, int C, const int64_t* lab
   if (C <= 4) hipLaunchKernelGGL(sup_loss_bwd_kernel<4>, dim3(gl_grid(M)), dim3(256), 0, as_stream(stream), X, ld, M, C, lab, sums, g_ce, g_dice, dX, ldo);
   else if (C <= 8) hipLaunchKernelGGL(sup_loss_bwd_kernel<8>, dim3(gl_grid(M)), dim3(256), 0, as_stream(stream), X, ld, M, C, lab, sums, g_ce, g_dice, dX, ldo);
   else hipLaunchKernelGGL(sup_loss_bwd_kernel<GL_MAXC>, dim3(gl_grid(M)), dim3(256), 0, as_stream(stream), X, ld, M, C, lab, sums, g_ce, g_dice, dX, ldo);
+  return arco_launch_status();
+}
+// DiceLoss on probability rows (utils/losses.py:173-209): ws >= 1024*3*C + 3*C doubles (arco_seg_ws_doubles covers it);
+// wgt = per-class weights or null; out[0] = loss
+int arco_dice_probs_fwd(const float* Pm, long ld, long M, int C, const int64_t* lab, const float* wgt, double* ws, float* out,
+                        void* stream) {
+  ARCO_CHECK_ARG(Pm && lab && ws && out && C >= 1 && C <= GL_MAXC && M > 0 && ld >= C);
+  int nblk = gl_grid(M); if (nblk > 1024) nblk = 1024;
+  double* sums = ws + 1024l * 3 * C;
+  if (C <= 4) hipLaunchKernelGGL(dice_probs_partial_kernel<4>, dim3(nblk), dim3(256), 0, as_stream(stream), Pm, ld, M, C, lab, ws);
+  else if (C <= 8) hipLaunchKernelGGL(dice_probs_partial_kernel<8>, dim3(nblk), dim3(256), 0, as_stream(stream), Pm, ld, M, C, lab, ws);
+  else hipLaunchKernelGGL(dice_probs_partial_kernel<GL_MAXC>, dim3(nblk), dim3(256), 0, as_stream(stream), Pm, ld, M, C, lab, ws);
+  hipLaunchKernelGGL(dice_probs_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), ws, nblk, C, wgt, sums, out);
+  return arco_launch_status();
+}
+int arco_dice_probs_bwd(const float* Pm, long ld, long M, int C, const int64_t* lab, const float* wgt, const double* ws,
+                        const float* g, float* dP, long ldo, void* stream) {
+  ARCO_CHECK_ARG(Pm && lab && ws && g && dP && C >= 1 && C <= GL_MAXC && M > 0);
+  hipLaunchKernelGGL(dice_probs_bwd_kernel, dim3(gl_grid(M * C)), dim3(256), 0, as_stream(stream), Pm, ld, M, C, lab,
+                     ws + 1024l * 3 * C, wgt, g, dP, ldo);
   return arco_launch_status();
 }
 // unsupervised weighted CE: B images of P pixels; ws >= 64*4*B + B + 1 doubles; out[0] = loss

@@ -15,6 +15,7 @@
 #include <string.h>
 #include <math.h>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 #include <chrono>
@@ -122,11 +123,18 @@ class Pool {
     return true;
   }
 };
+// fork(): the child inherits counters of tasks whose threads do not exist there (a deferred sampler sequence or a
+// pregeneration in flight would make its first Group::wait spin forever) and possibly locked mutexes - the atfork child
+// handler (after_fork_child, below the globals it resets) clears them; the pool itself is rebuilt on first use.
+static void after_fork_child();
+static std::mutex g_pool_mutex;
+static Pool* g_pool = nullptr;
 inline Pool& pool() {
-  static Pool* p = nullptr; static pid_t owner = 0; static std::mutex pm;
-  std::lock_guard<std::mutex> lk(pm);
-  if (!p || owner != getpid()) { p = new Pool(16); owner = getpid(); }
-  return *p;
+  static pid_t owner = 0; static bool hooked = false;
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  if (!hooked) { pthread_atfork(nullptr, nullptr, after_fork_child); hooked = true; }
+  if (!g_pool || owner != getpid()) { g_pool = new Pool(16); owner = getpid(); }
+  return *g_pool;
 }
 struct Group {
   std::atomic<int> pending{0};
@@ -289,6 +297,14 @@ inline void stream_attach(MT& g) {
   if (g_stream_blocks <= 0 || g.left != g_stream_base.left || g.next != g_stream_base.next ||
       memcmp(g.st, g_stream_base.st, sizeof(g.st)) != 0) return;
   g.stream = g_stream.data(); g.blk = -1; g.nblk = g_stream_blocks;
+}
+// child side of fork(): no worker thread survived - forget every in-flight task and pregenerated block, re-create the
+// mutexes (one may have been held by a thread that no longer exists), let pool() build a fresh pool on first use
+static void after_fork_child() {
+  new (&g_pool_mutex) std::mutex(); new (&g_arena_mutex) std::mutex(); new (&g_stream_mutex) std::mutex();
+  g_pool = nullptr;
+  g_many_workers.pending.store(0); g_many_active = false; g_many_copies.clear();
+  g_stream_group.pending.store(0); g_stream_blocks = 0;
 }
 }  // namespace
 

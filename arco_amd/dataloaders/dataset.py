@@ -10,7 +10,10 @@ import numpy as np
 import torch
 from scipy import ndimage
 from scipy.ndimage import zoom
+from torch.utils.data import Dataset
 from torch.utils.data.sampler import Sampler
+
+from ._io import read_case, read_list
 
 
 def random_rot_flip(image, label):
@@ -92,3 +95,33 @@ class TwoStreamBatchSampler(Sampler):
 
     def __len__(self):
         return len(self.primary_indices) // self.primary_batch_size
+
+
+class BaseDataSets(Dataset):
+    """code/dataloaders/dataset.py:97-144 (train_arco_2d.py:20, pretrain_2D.py:24): the un-indexed ACDC / MM slice
+    dataset - every slice of `train_slices.list` (`train_slices.txt` for MM) under `<base_dir>/data/slices/`, validation
+    volumes of `val.list` (`test_vol.txt`) under `<base_dir>/data/`; `num` keeps the first `num` training slices."""
+
+    def __init__(self, base_dir=None, split='train', num=None, transform=None):
+        self._base_dir, self.split, self.transform = base_dir, split, transform
+        self.sample_list = []
+        acdc = 'ACDC' in base_dir
+        if split == 'train' and (acdc or 'MM' in base_dir):
+            self.sample_list = read_list(base_dir + ('/train_slices.list' if acdc else '/train_slices.txt'), strip='' if acdc else '.h5')
+        elif split == 'val' and (acdc or 'MM' in base_dir):
+            self.sample_list = read_list(base_dir + ('/val.list' if acdc else '/test_vol.txt'))
+        if num is not None and split == "train":
+            self.sample_list = self.sample_list[:num]
+        print("total {} samples".format(len(self.sample_list)))
+
+    def __len__(self):
+        return len(self.sample_list)
+
+    def __getitem__(self, idx):
+        case = self.sample_list[idx]
+        image, label = read_case(self._base_dir + ("/data/slices/" if self.split == "train" else "/data/") + case)
+        sample = {'image': image, 'label': label}
+        if self.split == "train" and self.transform is not None:
+            sample = self.transform(sample)
+        sample["idx"] = idx
+        return sample

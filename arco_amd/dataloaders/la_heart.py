@@ -30,6 +30,16 @@ class LAHeartWithIndex(Dataset):
         return sample
 
 
+class LAHeart(LAHeartWithIndex):
+    """code/dataloaders/la_heart.py:14-43 (pretrain_3D.py:28): every case of the list, no labeled / unlabeled split."""
+
+    def __init__(self, base_dir=None, split='train', num=None, transform=None):
+        self._base_dir, self.transform = base_dir, transform
+        cases = read_list(f"{base_dir}/../{'train' if split == 'train' else 'test'}.list")
+        self.image_list = cases[:num] if num is not None else cases
+        print("total {} samples".format(len(self.image_list)))
+
+
 class RandomCrop(object):
     """Random `output_size` crop of a volume; axes not larger than the target are first zero-padded by
     (missing // 2 + 3) per side (all three, as soon as one is too small)."""

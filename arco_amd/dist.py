@@ -65,7 +65,19 @@ def anchors_for_rank(num_queries, mode="split"):
     if not is_dist() or mode == "full":
         return int(num_queries)
     world, rank = td.get_world_size(), td.get_rank()
+    if int(num_queries) < world:
+        raise ValueError(f"--anchors_per_rank split needs num_queries >= world size ({num_queries} < {world}): a rank with no "
+                         "anchors has no InfoNCE term (use --anchors_per_rank full, or more queries)")
     return int(num_queries) // world + (1 if rank < int(num_queries) % world else 0)
+
+
+def anchor_weight(num_queries, mode="split"):
+    """Factor on this rank's contrastive loss so that the MEAN over ranks (what the gradient all-reduce forms) is the
+    single-process estimator: a rank's InfoNCE term is a mean over its Q_r anchors, the reference's a mean over all
+    Q = sum_r Q_r of them, so rank r carries Q_r * world / Q - exactly 1.0 whenever world divides num_queries."""
+    if not is_dist() or mode == "full":
+        return 1.0
+    return anchors_for_rank(num_queries, mode) * td.get_world_size() / float(num_queries)
 
 
 def seed_data_pipeline(seed, rank=None):

@@ -9,8 +9,10 @@ stage-1 pre-training only (ISD.forward, arco_amd/pretrain_2D.py): a few 4- and 2
 on pooled maps, run as plain tensor ops around the two HIP U-Nets; _momentum_update_key_encoder
 (model_2D.py:176-182) EMA-updates them every step in both stages.
 """
+import numpy as np  # noqa: F401  (np / F / nn reach the reference trainers through `from model_xD import *`)
 import torch
 import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401
 
 from . import ops, optim, stage1
 from .networks.net_factory_args import net_factory

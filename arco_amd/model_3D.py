@@ -1,8 +1,10 @@
 """Drop-in for the reference's code/model_3D.py on MI355X: FeatureExtractor_3d (:20-63),
 create_model_3d (:113-120), ISD_3d (:219-292); FeatureExtractor / create_model are re-exported from
 model_2D like the reference file defines both.  Same names, arguments, attributes, state_dict keys."""
+import numpy as np  # noqa: F401  (np / F / nn reach the reference trainers through `from model_xD import *`)
 import torch
 import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401
 
 from . import ops, optim
 from .model_2D import FeatureExtractor, create_model  # noqa: F401

@@ -231,6 +231,16 @@ class PackPlan:
         self.valid = True
 
 
+def conv_sp_set(on):
+    """Switch the pipelined split-bf16 3x3 kernels on / off (A/B runs, tests) and return the previous setting.  The
+    per-shape answers cached from the library (`arco_conv_split_ok`, tile configurations) depend on the switch for the
+    few-channel and 16->16 shapes, so the cache is dropped with it - a stale "split ok" would hand split-packed weights
+    to a kernel that no longer takes them (ARCO_ERR_UNSUPPORTED instead of the fp32 fallback)."""
+    prev = L.query("arco_conv_sp_set", int(on))
+    _cfg_cache.clear()
+    return prev
+
+
 def _split_ok(taps, nbd, h, w, k, n, ld):
     key = ("split", taps, nbd, h, w, k, n, ld)
     r = _cfg_cache.get(key)

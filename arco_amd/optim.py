@@ -80,6 +80,18 @@ class EmaPair:
         if s is None:
             s = torch.cat([p.data.reshape(-1) for p in self.sp])
         t = self._flat_of(self.tp)          # (an optimiser built after this pair may have re-homed the teacher)
+        if t is None and any(hasattr(p, "_arco_grad_view") for p in self.tp):
+            # an optimiser owns part of the teacher module (stage 1 with a frozen encoder / decoder): re-homing would pull
+            # those parameters out of its flat buffer - it would keep stepping storage the module no longer reads.  EMA on
+            # a gathered copy and write the rows back instead (one cat + one split per step, no ownership change).
+            t = torch.cat([p.data.reshape(-1) for p in self.tp])
+            L.call("arco_ema", L.ptr(t), L.ptr(s), t.numel(), float(m))
+            off = 0
+            for p in self.tp:
+                p.data.copy_(t[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            self._weights_changed()
+            return
         if t is None:
             t = flatten_params(self.tp)
         self.flat_t = t
@@ -138,6 +150,12 @@ class SGDNesterov:
     @torch.no_grad()
     def step(self):
         g = self.param_groups[0]
+        # the parameters must still be views of flat_p (someone re-homing them - flatten_params on a module this optimiser
+        # owns part of - would leave this step updating storage nobody reads): first and last are checked every step
+        for i in (0, len(self.params) - 1):
+            if self.params[i].data_ptr() != self.flat_p.data_ptr() + 4 * self.offsets[i][0]:
+                raise RuntimeError("SGDNesterov: a parameter no longer lives in this optimiser's flat buffer "
+                                   "(it was re-homed after the optimiser was built)")
         # fold back gradients autograd may have re-homed
         for i, ((off, k), p) in enumerate(zip(self.offsets, self.params)):
             if p.grad is not None and p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:

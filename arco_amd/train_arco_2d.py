@@ -106,12 +106,13 @@ def build_parser():
                    help='1 (reference behaviour): batch_transform of train_arco_2d.py:287-304 - 8-bit PIL round trip of the '
                         'images / confidences, ColorJitter + GaussianBlur + AdvMorph on the unlabeled stream - on the GPU; '
                         '0: the identity (no generator draws)')
-    p.add_argument('--conv_mma', type=str, default='f32x3', choices=['f32x3', 'f32', 'f16', 'bf16'],
+    p.add_argument('--conv_mma', type=str, default='f32x3', choices=['f32x3', 'f32'],
                    help='matrix-core mode of the convolutions / GEMMs (forward and data gradient).  f32x3 (default): fp32-accurate '
                         'products on the bf16 matrix cores - each fp32 operand is split exactly into three bf16 terms, six bf16 '
                         'MFMAs per 32 k instead of eight fp32 MFMAs per 16 k (2.7x fewer matrix-core cycles, error per product '
-                        '<= 2^-23); f32: the native fp32 MFMA (bitwise an fma chain); f16 / bf16 (3-D trainer): operands of the '
-                        '3x3x3 convolutions rounded to f16 / bf16, fp32 accumulate (BASELINE configs[4], tolerance 1e-2)')
+                        '<= 2^-23); f32: the native fp32 MFMA (bitwise an fma chain).  The 3-D trainer '
+                        'adds f16 / bf16: operands of the 3x3x3 convolutions rounded to f16 / bf16, fp32 accumulate (BASELINE '
+                        'configs[4], tolerance 1e-2) - the 2-D kernels have no such mode and this parser rejects it')
     p.add_argument('--anchors_per_rank', type=str, default='split', choices=['split', 'full'],
                    help='data parallel only (SURVEY 8e). split: every rank samples num_queries/world anchors per class, so the '
                         'world draws the same total number of queries as the single-process reference; full: num_queries per rank')
@@ -148,7 +149,10 @@ class ArcoStep2D:
         self.args = args
         self.dev = torch.device(device)
         C = args.num_classes
-        ops.CONV_MMA = {"f32": 0, "f16": 0, "bf16": 0, "f32x3": 3}[getattr(args, "conv_mma", "f32x3")]   # (f16 / bf16: 3-D only)
+        mma = getattr(args, "conv_mma", "f32x3")
+        if mma not in ("f32", "f32x3"):      # no silent fp32 run under a reduced-precision label (the modes exist in 3-D only)
+            raise ValueError(f"--conv_mma {mma}: the 2-D step computes in f32x3 or f32; f16 / bf16 operands are a 3-D trainer mode")
+        ops.CONV_MMA = {"f32": 0, "f32x3": 3}[mma]
         self.random_pool = None
         if getattr(args, "revisit", 0):
             # random_pool (:156-159) is drawn before the models are created, like the reference (same CPU-generator order)
@@ -412,7 +416,7 @@ class ArcoStep2D:
         if prof:
             ev3[1].record()
             self.loss_events.append((ev, ev2, ev3, evp))  # masks | keys, banks | anchors, head, InfoNCE | lists, prototypes
-        loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
+        loss = (a.k1 * adist.anchor_weight(a.num_queries, getattr(a, "anchors_per_rank", "split"))) * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
         if loss_eqv is not None:
             loss = loss + a.k2 * loss_eqv
         loss_q = None
@@ -502,6 +506,8 @@ def train(args, snapshot_path):
     loaders = None
     if args.synthetic:
         iters_per_epoch = 100
+        if world > 1:         # every rank draws its own cutmix boxes / sampler indices / warps (seed + rank), after the broadcast
+            adist.seed_data_pipeline(args.seed)
     else:
         # data parallel: every rank draws its own samples / augmentations (seed + rank), after the weight broadcast above
         loaders = build_loaders(args, generator=adist.seed_data_pipeline(args.seed) if world > 1 else None)

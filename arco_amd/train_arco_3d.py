@@ -32,6 +32,7 @@ def build_parser():
     p = _build_parser_2d()
     p.set_defaults(patch_size=[112, 112, 80], func='asmc', k5=0.1, exp='LA/example_training', model='vnet', max_iterations=6000,
                    root_path='/home/weicheng/selfLearning/DTC/data/2018LA_Seg_Training Set')       # train_arco_3d.py:27-36
+    next(a for a in p._actions if a.dest == 'conv_mma').choices = ['f32x3', 'f32', 'f16', 'bf16']   # the volume kernels' extra modes
     p.add_argument('--eqv_pass', type=int, default=1,
                    help='1: run the equivariance block of train_arco_3d.py:368-388 (warp + one more student forward); '
                         'its loss only enters the objective at iteration 0 there (:390-393), afterwards it is a logged '
@@ -213,7 +214,7 @@ class ArcoStep3D:
         if self.iter_num == 0 and loss_eqv is not None:
             loss = unsup_loss + (loss_dice + loss_ce) + loss_eqv         # :393 (iter_num / max_iterations == 0)
         else:
-            loss = a.k1 * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q only with --revisit 1)
+            loss = (a.k1 * adist.anchor_weight(a.num_queries, getattr(a, "anchors_per_rank", "split"))) * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q only with --revisit 1)
         loss_q = None
         if self.random_pool is not None:      # :304 (before the pool update) and :365; constant w.r.t. every parameter
             nb_l = int(l_data.shape[0])
@@ -281,6 +282,8 @@ def train(args, snapshot_path):
     loaders = None
     if args.synthetic:
         iters_per_epoch = 100
+        if world > 1:         # every rank draws its own cutmix boxes / sampler indices / warps (seed + rank), after the broadcast
+            adist.seed_data_pipeline(args.seed)
     else:
         # data parallel: every rank draws its own samples / augmentations (seed + rank), after the weight broadcast above
         loaders = build_loaders(args, generator=adist.seed_data_pipeline(args.seed) if world > 1 else None)

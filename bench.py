@@ -375,6 +375,8 @@ def main():
         flags += ["--head_levels", str(a.head_levels)]
     args = T.build_parser().parse_args(flags)
     stepper = T.ArcoStep2D(args, dev)
+    if world > 1:             # per-rank generator streams (cutmix boxes, sampler indices, TPS warps), after the weight broadcast
+        adist.seed_data_pipeline(1337)
     b = a.batch_size
     batches = []
     for i in range(4):        # a few resident synthetic batches, cycled

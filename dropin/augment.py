@@ -1,0 +1,4 @@
+"""Drop-in for the reference's code/augment.py: put `dropin/` ahead of `code/` on PYTHONPATH and the reference's own import
+statement (`from augment import *`) binds the MI355X implementation - every name is re-exported from `arco_amd.augment`."""
+import _arco_root  # noqa: F401
+from arco_amd.augment import *  # noqa: F401,F403

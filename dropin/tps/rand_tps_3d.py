@@ -1,0 +1,4 @@
+"""Drop-in for the reference's code/tps/rand_tps_3d.py: put `dropin/` ahead of `code/` on PYTHONPATH and the reference's own import
+statement (`from tps.rand_tps_3d import RandTPS`) binds the MI355X implementation - every name is re-exported from `arco_amd.tps.rand_tps_3d`."""
+import _arco_root  # noqa: F401
+from arco_amd.tps.rand_tps_3d import *  # noqa: F401,F403

@@ -265,6 +265,12 @@ long arco_seg_ws_doubles(long M, int C, int B);
 int arco_sup_loss_fwd(const float* X, long ld, long M, int C, const int64_t* lab, double* ws, float* out, void* stream);
 int arco_sup_loss_bwd(const float* X, long ld, long M, int C, const int64_t* lab, const double* ws, const float* g_ce,
                       const float* g_dice, float* dX, long ldo, void* stream);
+/* utils/losses.py:173-209 DiceLoss.forward on probability rows [M, C] (what train_arco_2d.py:269,338 /
+ * train_arco_3d.py:245,308 instantiate and call): per-class weights or NULL; ws as for arco_sup_loss_fwd                  */
+int arco_dice_probs_fwd(const float* P, long ld, long M, int C, const int64_t* lab, const float* wgt, double* ws, float* out,
+                        void* stream);
+int arco_dice_probs_bwd(const float* P, long ld, long M, int C, const int64_t* lab, const float* wgt, const double* ws,
+                        const float* g, float* dP, long ldo, void* stream);
 int arco_unsup_loss_fwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const float* conf, float thr,
                         double* ws, float* out, void* stream);
 int arco_unsup_loss_bwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const double* ws, const float* g,

@@ -124,9 +124,108 @@ def _sparse_vs_dense(make, batch, steps=1):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# configs[1] - THE HEADLINE (what bench.py times): ACDC-shaped 16 x 256^2, D = 496, 4096-key queues, smc, every flag at the
+# trainer default: graph_train 1, head_levels 3, lazy teacher, batch_transform 1, k2 1, conv_mma f32x3
+# ------------------------------------------------------------------------------------------------------------------
+def _make_acdc(extra, b=8, patch=(256, 256)):
+    from arco_amd import train_arco_2d as T
+    args = T.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1", "--k1", "1.0"] + list(extra))
+    args.patch_size = list(patch)
+    seed_all(11)
+    return T.ArcoStep2D(args, "cuda:0")
+
+
+def _acdc_batch(it, b=8, patch=(256, 256)):
+    from arco_amd import train_arco_2d as T
+    l, ll = T.synthetic_batch(b, patch, 4, 900 + 2 * it, "cuda:0")
+    u, _ = T.synthetic_batch(b, patch, 4, 901 + 2 * it, "cuda:0")
+    return l, ll, u
+
+
+def test_cfg2_acdc_step_at_full_size():
+    """The benchmarked configuration at its own size, in the mode it ships: 6 steps (the student passes replay as HIP graphs
+    from step 3 on), then index replay / torch InfoNCE restatement (1e-3) / FIFO banks on the last, graph-replayed step."""
+    from arco_amd import ops
+    st = _make_acdc([])
+    a = st.args
+    assert (a.graphs, a.graph_train, a.head_levels, a.dense_teacher, a.dense_head, a.batch_transform, a.k2, a.conv_mma,
+            a.apply_aug, a.func, a.num_queries, a.num_negatives) == (1, 1, 3, 0, 0, 1, 1.0, "f32x3", "cutmix", "smc", 256, 512)
+    assert ops.CONV_MMA == 3
+    st.keep_debug = True
+    for it in range(6):
+        seed_all(700 + it)
+        loss, reco = st.step(*_acdc_batch(it))
+        assert bool(torch.isfinite(loss)) and bool(torch.isfinite(reco))
+    assert st.s_train_lu.captured and st.s_train_tps.captured           # the timed steps of bench.py are graph replays
+    _check_step_invariants(st, "smc", 4096, 496, 705)
+    pl = st.debug["plan"]
+    assert pl.n_img == 16 and tuple(pl.spatial) == (256, 256) and pl.Q == 256 and pl.Nn == 512
+    assert pl.valid_seg == 4 and "eqv" in st.last_terms
+    assert all(m[0].shape[1] == 496 for m in st.memobank) and max(m[0].shape[0] for m in st.memobank) == 4096   # banks filled up
+    del st
+    torch.cuda.empty_cache()
+
+
+def test_cfg2_sparse_head_equals_dense_dataflow_at_full_size():
+    """Three-level row-sparse head + lazy teacher == the dense reference dataflow, 16 x 256^2 x 496, from equal state,
+    reference-default loss terms (k2 = 1, batch_transform, cutmix)."""
+    _sparse_vs_dense(lambda extra: _make_acdc(extra), _acdc_batch(50))
+
+
+def _sync_full(dst, src):
+    """dst <- src: weights, momentum, BN buffers, teacher, k-FeatureExtractor, banks, pointers, iteration."""
+    from arco_amd import ops
+    with torch.no_grad():
+        dst.optimizer.flat_p.copy_(src.optimizer.flat_p)
+        dst.optimizer.flat_buf.copy_(src.optimizer.flat_buf)
+        dst.optimizer._started = list(src.optimizer._started)
+        for g_d, g_s in zip(dst.optimizer.param_groups, src.optimizer.param_groups):
+            g_d['lr'] = g_s['lr']
+        for md, ms in ((dst.model, src.model), (dst.ema_model, src.ema_model), (dst.k_feature_extractor, src.k_feature_extractor)):
+            for (kd, vd), (ks, vs) in zip(md.state_dict().items(), ms.state_dict().items()):
+                assert kd == ks
+                vd.copy_(vs)
+        for c in range(len(src.memobank)):
+            dst.memobank[c] = [t.clone() for t in src.memobank[c]]
+            dst.queue_ptrlis[c] = src.queue_ptrlis[c].clone() if torch.is_tensor(src.queue_ptrlis[c]) else src.queue_ptrlis[c]
+    dst.iter_num = src.iter_num
+    ops.bump_weight_epoch()
+
+
+def test_cfg2_graph_replay_equals_eager_at_full_size():
+    """From equal state, the default step (student passes replayed as HIP graphs from step 3 on) gives the loss terms,
+    updated weights, BN buffers and banks of the eager step (--graphs 0) at 16 x 256^2."""
+    st_e, st_g = _make_acdc(["--graphs", "0", "--graph_train", "0"]), _make_acdc([])
+    _drop_off(st_e); _drop_off(st_g)
+    for it in range(6):
+        batch = _acdc_batch(20 + it)
+        _sync_full(st_g, st_e)
+        terms = []
+        for st in (st_e, st_g):
+            seed_all(800 + it)
+            st.step(*batch)
+            terms.append({k: float(v) for k, v in st.last_terms.items()})
+        for k in terms[0]:
+            np.testing.assert_allclose(terms[1][k], terms[0][k], rtol=5e-5, atol=1e-6, err_msg=f"step {it} {k}")
+        pe, pg = st_e.optimizer.flat_p, st_g.optimizer.flat_p
+        assert float((pe - pg).abs().max()) <= 2e-5 * float(pe.abs().max()), it
+        for (k, ve), (_, vg) in zip(st_e.model.state_dict().items(), st_g.model.state_dict().items()):
+            if ve.is_floating_point():
+                np.testing.assert_allclose(vg.cpu().numpy(), ve.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=f"{it} {k}")
+            else:
+                assert int(ve) == int(vg), k
+        for be, bg in zip(st_e.memobank, st_g.memobank):
+            assert be[0].shape == bg[0].shape
+            np.testing.assert_allclose(bg[0].cpu().numpy(), be[0].cpu().numpy(), rtol=2e-4, atol=2e-6)
+    assert st_g.s_train_lu.captured and st_g.s_train_tps.captured and not st_e.s_train_lu.captured
+    del st_e, st_g
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # configs[2]: LA V-Net 112x112x80, --batch_size 2 (4 volumes per step), C = 2, D = 16, asmc
 # ------------------------------------------------------------------------------------------------------------------
-def _make3d(extra, patch=(112, 112, 80), b=2, mma="f32"):
+def _make3d(extra, patch=(112, 112, 80), b=2, mma="f32x3"):
     from arco_amd import train_arco_3d as T3
     args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1", "--num_classes", "2",
                                          "--conv_mma", mma, "--k1", "1.0"] + list(extra))
@@ -135,9 +234,11 @@ def _make3d(extra, patch=(112, 112, 80), b=2, mma="f32"):
     return T3.ArcoStep3D(args, "cuda:0")
 
 
-def test_cfg3_la_vnet_step_at_full_size():
-    from arco_amd import train_arco_3d as T3
-    st = _make3d([])
+@pytest.mark.parametrize("mma", ["f32x3", "f32"])         # f32x3 = the trainer default and the bench sub-record's mode
+def test_cfg3_la_vnet_step_at_full_size(mma):
+    from arco_amd import ops, train_arco_3d as T3
+    st = _make3d([], mma=mma)
+    assert ops.CONV_MMA == {"f32x3": 3, "f32": 0}[mma] and st.args.conv_mma == mma
     st.keep_debug = True
     for it in range(4):                     # step 0 is the reference's "equivariance only" objective; graphs replay from step 3
         l, ll = T3.synthetic_volume_batch(2, (112, 112, 80), 2, 10 + it, "cuda:0")

@@ -17,21 +17,6 @@ def close(a, b, rtol, atol):
     np.testing.assert_allclose(a.detach().cpu().numpy(), b, rtol=rtol, atol=atol)
 
 
-def close_grad(a, b, rtol, atol):
-    """Gradients through a stack of 18 BatchNorm + LeakyReLU layers: the derivative jumps by 100x where a pre-activation
-    crosses zero, and among ~3e5 activations a few lie within fp32 rounding (1e-6) of zero - whether one of them takes
-    the other branch depends on the summation order of the kernels (observed: ONE element of one layer flips between
-    two exact forward kernels for the first layer, every forward output still agrees to 1e-5, and every gradient
-    upstream of it moves by 1-4 % of its maximum).  Strict comparison first; a mismatch is accepted only if it is of
-    that size in the L2 sense - wiring or kernel errors are O(1) and are caught by the strict per-op tests."""
-    got = a.detach().cpu().numpy()
-    try:
-        np.testing.assert_allclose(got, b, rtol=rtol, atol=atol)
-    except AssertionError:
-        rel = float(np.linalg.norm((got - b).ravel()) / max(1e-12, np.linalg.norm(np.asarray(b).ravel())))
-        assert rel < 3e-2, rel
-
-
 def test_unet_vs_reference_golden(golden):
     from arco_amd.networks.unetWithArgs import UNet
     g = golden["g3_nets"]
@@ -48,29 +33,60 @@ def test_unet_vs_reference_golden(golden):
     close(latent, g["unet_latent"], 1e-3, 1e-4)
     for i, f in enumerate(fmap):
         close(f, g[f"unet_fmap{i}"], 1e-3, 1e-4)
-    loss = (logits * probe_like(logits, 1)).sum()
-    for i, f in enumerate(fmap):
-        loss = loss + (f * probe_like(f, 10 + i)).sum()
-    loss.backward()
-    close_grad(x.grad, g["unet_dx"], 5e-3, 1e-3)
-    params = dict(net.named_parameters())
-    for n in g.files:
-        if n.startswith("unet_grad::"):
-            ref = g[n]
-            close_grad(params[n.split("::")[1]].grad, ref, 5e-3, 2e-3 * max(1e-3, float(np.abs(ref).max())))
-    names = [str(s) for s in g["unet_grad_names"]]
-    for n, ref_abs in zip(names, g["unet_grad_abs"]):
-        got = params[n].grad.double().abs().sum().item()
-        if n.endswith("conv_conv.0.bias") or n.endswith("conv_conv.4.bias"):
-            # a conv bias feeding train-mode BN has an analytically ZERO gradient; both sides hold
-            # only fp32 rounding noise, so compare against the noise scale, not relatively
-            assert got < 1.0 and ref_abs < 1.0, n
-            continue
-        assert abs(got - ref_abs) <= 3e-2 * max(ref_abs, 1e-2), n       # L1 norms: same kink allowance as close_grad
     st = net.state_dict()
     for n in g.files:
         if n.startswith("unet_buf::"):
             close(st[n.split("::")[1]].float(), g[n].astype(np.float32), 1e-3, 1e-5)
+
+
+def test_unet_gradients_strict_on_kinkfree_input():
+    """Whole-U-Net gradients against the reference, element by element, no escape clause.  The LeakyReLU derivative jumps
+    100x at zero, so the comparison is only well-posed when no pre-activation lies within forward rounding error of zero:
+    oracle/gen_golden.py g15 searched 6000 fixture inputs for the one whose smallest |BN output| over all 18 BN layers of
+    the REFERENCE forward is largest (4.5e-5, ~40 fp32 ulps of the O(1) pre-activations) and stored the reference's
+    gradients for it.  Every parameter's gradient: L1 and L2 norms to 1e-3; the stored tensors (input gradient + 19
+    parameters from every level of encoder and decoder) to 1e-3 of their largest element (north_star's fp32 tolerance)."""
+    import os
+    from arco_amd.networks.unetWithArgs import UNet
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g15_unet_kinkfree.npz"), allow_pickle=False)
+    assert float(g["margin"]) > 3e-5
+    net = UNet(1, 4).cuda()
+    net.load_state_dict(fx.unet_state(21), strict=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net.train()
+    x = fx.image_batch(int(g["seed"]), 2, 1, (32, 32)).cuda().requires_grad_(True)
+    logits, latent, fmap = net(x)
+    close(logits, g["logits"], 1e-3, 1e-4)
+    loss = (logits * probe_like(logits, 1)).sum()
+    for i, f in enumerate(fmap):
+        loss = loss + (f * probe_like(f, 10 + i)).sum()
+    loss.backward()
+
+    def strict(got, ref, name):
+        err = float(np.abs(got.detach().cpu().numpy() - ref).max())
+        assert err <= 1e-3 * float(np.abs(ref).max()), (name, err, float(np.abs(ref).max()))
+
+    strict(x.grad, g["dx"], "dx")
+    params = dict(net.named_parameters())
+    n_checked = 0
+    for n in g.files:
+        if n.startswith("grad::"):
+            name = n.split("::")[1]
+            if name.endswith("conv_conv.0.bias") or name.endswith("conv_conv.4.bias"):
+                continue
+            strict(params[name].grad, g[n], name)
+            n_checked += 1
+    assert n_checked >= 18
+    for n, ref_abs, ref_l2 in zip([str(s) for s in g["grad_names"]], g["grad_abs"], g["grad_l2"]):
+        got = params[n].grad.double()
+        if n.endswith("conv_conv.0.bias") or n.endswith("conv_conv.4.bias"):
+            # a conv bias feeding train-mode BN has an analytically ZERO gradient: both sides hold fp32 rounding noise
+            assert float(got.abs().sum()) < 1.0 and ref_abs < 1.0, n
+            continue
+        assert abs(float(got.abs().sum()) - ref_abs) <= 1e-3 * ref_abs, (n, float(got.abs().sum()), ref_abs)
+        assert abs(float(got.pow(2).sum().sqrt()) - ref_l2) <= 1e-3 * ref_l2, (n, float(got.pow(2).sum().sqrt()), ref_l2)
 
 
 @pytest.mark.parametrize("tag,dims,od", [("fe_small", (32, 16, 8, 8, 8), 24), ("fe_full", (256, 128, 64, 32, 16), 496)])
@@ -113,11 +129,11 @@ def test_bn_groups_equal_separate_passes(nb, H, W, grads, sp):
     so the gradients are compared in the L2 norm over all parameters (2e-2) instead of element by element."""
     import torch
     from arco_amd import ops, _lib as L_
-    prev_sp = L_.load().arco_conv_sp_set(sp)
+    prev_sp = ops.conv_sp_set(sp)
     try:
         _bn_groups_case(nb, H, W, grads, 2e-3 if sp == 0 else None)
     finally:
-        L_.load().arco_conv_sp_set(prev_sp)
+        ops.conv_sp_set(prev_sp)
 
 
 def _bn_groups_case(nb, H, W, grads, gtol):

@@ -123,6 +123,25 @@ def test_unet_forward_backward(golden):
     assert int(g["unet_n_state_keys"]) == len(sd)
 
 
+def test_unet_oracle_gradients_on_kinkfree_input():
+    """The oracle's U-Net against the reference on the kink-free fixture (g15): every stored gradient tensor."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g15_unet_kinkfree.npz"), allow_pickle=False)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in fx.unet_state(21).items()}
+    x = fx.image_batch(int(g["seed"]), 2, 1, (32, 32)).requires_grad_(True)
+    logits, latent, fmap = orc.unet_forward(x, sd)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-4, atol=1e-5)
+    loss = (logits * probe_like(logits, 1)).sum()
+    for i, f in enumerate(fmap):
+        loss = loss + (f * probe_like(f, 10 + i)).sum()
+    loss.backward()
+    for n in ["dx"] + [n for n in g.files if n.startswith("grad::")]:
+        got = x.grad.numpy() if n == "dx" else sd[n.split("::")[1]].grad.numpy()
+        if n.endswith("conv_conv.0.bias") or n.endswith("conv_conv.4.bias"):
+            continue
+        assert float(np.abs(got - g[n]).max()) <= 1e-3 * float(np.abs(g[n]).max()), n
+
+
 def test_feature_extractor(golden):
     g = golden["g3_nets"]
     dims, od, sp = (32, 16, 8, 8, 8), 24, 32

@@ -162,3 +162,28 @@ def test_deferred_sampler_sequence(pre):
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_forked_child_with_a_sequence_in_flight_does_not_hang():
+    """a process forked while a deferred sampler sequence / a pregeneration is in flight (DataLoader workers)
+    inherits `pending` counters whose threads do not exist in the child; the library's atfork child handler clears them,
+    so the child's first sampler call returns (and gives the plain sequential answer)."""
+    import os
+    import signal
+    from arco_amd import samplers
+    torch.manual_seed(5)
+    samplers.pregen(1 << 20)                                        # worker thread computing state blocks
+    pid = os.fork()
+    if pid == 0:                                                    # child: would spin forever in Group::wait without the handler
+        signal.alarm(20)
+        try:
+            torch.manual_seed(9)
+            out = samplers.grid_monte_carlo_sample(30000, 131072)
+            os._exit(0 if int(out.numel()) == 131072 else 3)
+        except BaseException:
+            os._exit(4)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    torch.manual_seed(9)
+    a = samplers.grid_monte_carlo_sample(30000, 131072)            # the parent is unaffected
+    assert int(a.numel()) == 131072

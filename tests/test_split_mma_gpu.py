@@ -113,17 +113,17 @@ def test_pipelined_3x3_kernel_equals_igemm_kernel(shape):
     wp = ops.pack_weight(wt, 9, 0)
     xr, ldx = ops.rows_view(x)
     res = {}
-    prev = L.load().arco_conv_sp_set(1)
+    prev = ops.conv_sp_set(1)
     try:
         for on in (0, 1):
-            L.load().arco_conv_sp_set(on)
+            ops.conv_sp_set(on)
             cfg = L.query("arco_conv_config_mma", 9, nb, s, s, ci, co, ldx, 3)
             assert (9300000 <= cfg < 9400000) == bool(on), cfg
             out, (ssum, ssq, nmb) = ops.conv_raw(xr, ldx, ci, wp, co, nb, s, s, 9, bias=bias, stats=True)
             assert ssum.shape == (co, nmb)
             res[on] = (out.clone(), ssum.double().sum(1), ssq.double().sum(1))
     finally:
-        L.load().arco_conv_sp_set(prev)
+        ops.conv_sp_set(prev)
     assert torch.equal(res[0][0], res[1][0])
     ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
     assert float((res[1][0].double() - ref).abs().max() / ref.abs().max()) < 3e-6
@@ -149,10 +149,10 @@ def test_narrow_planes_run_on_the_resident_weights_kernel(shape):
     xr, ldx = ops.rows_view(x)
     ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
     res = {}
-    prev = L.load().arco_conv_sp_set(1)
+    prev = ops.conv_sp_set(1)
     try:
         for on in (0, 1):
-            L.load().arco_conv_sp_set(on)
+            ops.conv_sp_set(on)
             ops._cfg_cache.clear()
             split = ops._split_ok(9, nb, s, s, ci, co, ldx)
             assert split == bool(on)
@@ -163,7 +163,7 @@ def test_narrow_planes_run_on_the_resident_weights_kernel(shape):
             res[on] = (out.clone(), ssum.double().sum(1), ssq.double().sum(1))
             assert float((res[on][0].double() - ref).abs().max() / ref.abs().max()) < 3e-6
     finally:
-        L.load().arco_conv_sp_set(prev)
+        ops.conv_sp_set(prev)
         ops._cfg_cache.clear()
     for k in (1, 2):
         assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-5 * nb * s * s / 1024)

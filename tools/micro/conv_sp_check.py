@@ -33,14 +33,14 @@ for nb, ci, co, s in shapes:
     xr, ldx = ops.rows_view(x)
     res = {}
     for on in (0, 1):
-        L.load().arco_conv_sp_set(on)
+        ops.conv_sp_set(on)
         ops._cfg_cache.clear()
         cfg = L.query("arco_conv_config_mma", 9, nb, s, s, ci, co, ldx, 3)
         out, (ssum, ssq, nmb) = ops.conv_raw(xr, ldx, ci, wp, co, nb, s, s, 9, bias=bias, stats=True)
         torch.cuda.synchronize()
         t = timeit(lambda: ops.conv_raw(xr, ldx, ci, wp, co, nb, s, s, 9, bias=bias, stats=True))
         res[on] = (out.clone(), ssum.sum(1).clone(), ssq.sum(1).clone(), t, cfg)
-    L.load().arco_conv_sp_set(1)
+    ops.conv_sp_set(1)
     ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1)
     o0, o1 = res[0][0], res[1][0]
     scale = float(ref.abs().max())
