@@ -16,12 +16,17 @@ from .samplers import (as_monte_carlo_sample, grid_as_monte_carlo_sample, grid_m
 
 
 def label_onehot(inputs, num_segments):
-    """loss_helper_3d.py:892-901 / loss_helper.py:1065-1074: float one-hot [B, C, *spatial] with label 255 = ignore (an
-    all-zero column).  (The trainers define their own variant below their imports - train_arco_2d.py:492-498, negatives
-    clamped to class 0 - which is `arco_amd.glue.label_onehot`.)"""
+    """loss_helper_3d.py:892-901 / loss_helper.py:1065-1074, quirk included: the reference scatters along dim 0 of a
+    [C, B, H, W] buffer with a [B, 1, H, W] index, which writes only into sample 0 - whose "one-hot" is the UNION over the
+    batch of the samples' labels - and leaves the other samples zero; label 255 = ignore (that sample's column zeroed).
+    Returns float [B, C, H, W].  Pinned to the reference function (tests/golden/g16_boundary.npz).  The trainers never
+    reach it: they define their own `label_onehot` below their imports (train_arco_2d.py:492-498, negatives clamped to
+    class 0), which is `arco_amd.glue.label_onehot`."""
     from . import glue
     ignore = inputs == 255
-    out = glue.label_onehot(inputs.masked_fill(ignore, 0), num_segments).to(torch.float32)
+    hot = glue.label_onehot(inputs.masked_fill(ignore, 0), num_segments)
+    out = torch.zeros(hot.shape, dtype=torch.float32, device=hot.device)
+    out[0] = hot.amax(dim=0).to(torch.float32)
     return out.masked_fill(ignore.unsqueeze(1), 0.0)
 
 

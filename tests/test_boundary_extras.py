@@ -81,7 +81,7 @@ def test_dice_loss_class_matches_reference(tag, C, mode):
         inp = x if mode == "sm" else torch.softmax(x, dim=1)
         loss = DiceLoss(C)(inp, lab, **kw)
         loss.backward()
-        np.testing.assert_allclose(float(loss), float(G[f"dice_{tag}_{mode}"]), rtol=1e-5)
+        np.testing.assert_allclose(float(loss.detach()), float(G[f"dice_{tag}_{mode}"]), rtol=1e-5)
         ref = G[f"dice_{tag}_{mode}_grad"]
         np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * float(np.abs(ref).max()))
 
