@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarco_hip.so")
+LIB_PATH = os.environ.get("ARCO_LIB") or os.path.join(_HERE, "lib", "libarco_hip.so")     # ARCO_LIB: an A/B build (tools/build_variant.sh)
 _lib = None
 
 _P, _I, _L, _F, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
@@ -79,6 +79,11 @@ _SIGS = {
     "arco_conv3d_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P],
     "arco_gather_upcat_rows3d": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "arco_scatter_upcat_rows3d": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P],
+    "arco_zero_rows": [_P, _L, _I, _P, _L, _P],
+    "arco_fold_residual": [_P, _I, _I, _P, _P, _P],
+    "arco_unfold_residual": [_P, _P, _I, _I, _P, _P],
+    "arco_combine_terms": [_P, _P, _I, _P, _P],
+    "arco_combine_terms_bwd": [_P, _I, _P, _P, _P],
     "arco_copy_rows": [_P, _L, _L, _I, _P, _L, _I, _P],
     "arco_nchw_to_nhwc": [_P, _I, _I, _L, _P, _L, _P],
     "arco_nhwc_to_nchw": [_P, _L, _I, _I, _L, _P, _P],
@@ -116,6 +121,7 @@ _QUERIES = {   # plain host helpers returning sizes
     # host-side native sampler replay (no GPU work)
     "arco_grid_sample": ([_P, _L, _L, _L, _I, _I, _P], _L),
     "arco_randint": ([_P, _L, _L, _L, _P], _L),
+    "arco_mt_skip": ([_P, _L, _U64], _L),
     "arco_mt_pregen": ([_P, _L, _L, _I], _L),
     "arco_grid_sample_many": ([_P, _L, _I, _P, _P, _I, _I, _P, _I], _L),
     "arco_grid_sample_many_async": ([_P, _L, _I, _P, _P, _I, _I, _P, _I], _L),

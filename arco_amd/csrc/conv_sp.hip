@@ -59,7 +59,11 @@ __device__ __forceinline__ float row16_sum(float v) {    // sum over the 16 lane
 // runs out, and shuttles every accumulator through a scratch AGPR quad around each MFMA chain (4 v_accvgpr_write + hazard
 // nops per chain).  The s_nop covers an operand a VALU instruction has just written (hipcc pads nothing inside asm).
 __device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& x, const bf16x8& y) {
+#ifdef ARCO_EXP_NONOP
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(x), "v"(y));
+#else
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(x), "v"(y));
+#endif
 }
 
 __device__ __forceinline__ void mfma_first(f32x4& c, const bf16x8& x, const bf16x8& y) {     // c = x . y (a tile's first product)
@@ -235,6 +239,9 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
   }
 
   // ================================================================== consumer waves
+#ifdef ARCO_EXP_PRIO
+  __builtin_amdgcn_s_setprio(ARCO_EXP_PRIO);
+#endif
   // fragment addressing: lanes g = 0,1 take tap 2s, g = 2,3 tap 2s+1 (step 4: tap 8 and the zero tap)
   const int tl = g >> 1;
   int aoff[5];
@@ -512,6 +519,9 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
   }
 
   // ================================================================== consumer waves
+#ifdef ARCO_EXP_PRIO
+  __builtin_amdgcn_s_setprio(ARCO_EXP_PRIO);
+#endif
   const int tl = g >> 1;
   int aoff[5];
 #pragma unroll

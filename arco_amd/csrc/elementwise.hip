@@ -872,6 +872,42 @@ static inline int ew_grid(long work) {
   return (int)g;
 }
 
+// ---- small glue kernels that replace chains of ATen launches in the step (profiles/r02_h: ~0.6 ms of fills / copies / adds)
+// rows idx[0..n) of a [rows, ld] tensor set to zero over C channels: re-arms a persistent, zero-by-invariant gradient
+// buffer after a sparse scatter (the row-sparse head's feature-map gradients) instead of a dense fill per step
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ dst, long ld, int C, const int64_t* __restrict__ idx, long n) {
+  const int q4 = C >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * q4; i += (long)gridDim.x * 256) {
+    const long r = i / q4; const int c = (int)(i - r * q4) * 4;
+    *reinterpret_cast<f32x4*>(dst + idx[r] * ld + c) = f32x4{0, 0, 0, 0};
+  }
+}
+// W' = W + I of a square [n, n] 1x1-conv weight, written as its two column blocks lo [n, c] and hi [n, n - c] (the
+// FeatureExtractor's residual folded into the weights, model_2D.py forward_lowres1/2): one launch for eye + add + 2 slices
+__global__ __launch_bounds__(256) void fold_residual_kernel(const float* __restrict__ W, int n, int c, float* __restrict__ lo, float* __restrict__ hi) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)n * n; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / n), k = (int)(i - (long)r * n);
+    const float v = W[i] + (r == k ? 1.f : 0.f);
+    if (k < c) lo[(long)r * c + k] = v; else hi[(long)r * (n - c) + (k - c)] = v;
+  }
+}
+// the reverse for the gradient: dW[r][k] = k < c ? dlo[r][k] : dhi[r][k - c]
+__global__ __launch_bounds__(256) void unfold_residual_kernel(const float* __restrict__ dlo, const float* __restrict__ dhi, int n, int c, float* __restrict__ dW) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)n * n; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / n), k = (int)(i - (long)r * n);
+    dW[i] = k < c ? (dlo ? dlo[(long)r * c + k] : 0.f) : (dhi ? dhi[(long)r * (n - c) + (k - c)] : 0.f);
+  }
+}
+// out[0] = sum_i w_i * (*term_i)  /  grads[i] = w_i * g[0]: the step's loss combination (train_arco_2d.py:426) and its
+// backward as one launch each instead of a chain of 0-d multiplies and adds
+struct TermTable { const float* p[8]; float w[8]; int n; };
+__global__ void combine_terms_kernel(TermTable t, float* __restrict__ out) {
+  if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < t.n; ++i) s += t.w[i] * t.p[i][0]; out[0] = s; }
+}
+__global__ void combine_terms_bwd_kernel(TermTable t, const float* __restrict__ g, float* __restrict__ grads) {
+  if ((int)threadIdx.x < t.n) grads[threadIdx.x] = t.w[threadIdx.x] * g[0];
+}
+
 extern "C" {
 
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
@@ -1070,6 +1106,38 @@ int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, lon
   if (n == 0) return ARCO_OK;
   hipLaunchKernelGGL(scatter_upcat_rows3d_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), dX, ldx, pix, n, dlo,
                      ldlo, Clo, Di, Hi, Wi, dhi, ldhi, Chi, Do, Ho, Wo);
+  return arco_launch_status();
+}
+
+int arco_zero_rows(float* dst, long ld, int C, const int64_t* idx, long n, void* stream) {
+  ARCO_CHECK_ARG(dst && idx && (C & 3) == 0 && (ld & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(ew_grid(n * (C / 4))), dim3(256), 0, as_stream(stream), dst, ld, C, idx, n);
+  return arco_launch_status();
+}
+int arco_fold_residual(const float* W, int n, int c, float* lo, float* hi, void* stream) {
+  ARCO_CHECK_ARG(W && lo && hi && n > 0 && c > 0 && c < n);
+  hipLaunchKernelGGL(fold_residual_kernel, dim3(ew_grid((long)n * n)), dim3(256), 0, as_stream(stream), W, n, c, lo, hi);
+  return arco_launch_status();
+}
+int arco_unfold_residual(const float* dlo, const float* dhi, int n, int c, float* dW, void* stream) {
+  ARCO_CHECK_ARG(dW && n > 0 && c > 0 && c < n);
+  hipLaunchKernelGGL(unfold_residual_kernel, dim3(ew_grid((long)n * n)), dim3(256), 0, as_stream(stream), dlo, dhi, n, c, dW);
+  return arco_launch_status();
+}
+// terms: host array of n (<= 8) device pointers to 0-d floats, weights: host array of n floats
+int arco_combine_terms(const float* const* terms, const float* weights, int n, float* out, void* stream) {
+  ARCO_CHECK_ARG(terms && weights && out && n >= 1 && n <= 8);
+  TermTable t{}; t.n = n;
+  for (int i = 0; i < n; ++i) { t.p[i] = terms[i]; t.w[i] = weights[i]; }
+  hipLaunchKernelGGL(combine_terms_kernel, dim3(1), dim3(64), 0, as_stream(stream), t, out);
+  return arco_launch_status();
+}
+int arco_combine_terms_bwd(const float* weights, int n, const float* g, float* grads, void* stream) {
+  ARCO_CHECK_ARG(weights && g && grads && n >= 1 && n <= 8);
+  TermTable t{}; t.n = n;
+  for (int i = 0; i < n; ++i) t.w[i] = weights[i];
+  hipLaunchKernelGGL(combine_terms_bwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), t, g, grads);
   return arco_launch_status();
 }
 

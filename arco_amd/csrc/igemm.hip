@@ -1907,7 +1907,8 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
     // 32x32 blocks run persistent (2 workgroups per CU, several tiles each); the others one slab per ~tile
     // (16 x 32 blocks of the split kernel: 60.7 KB of LDS, two per CU as well - 768 left a third round at half occupancy)
-    const long target = (hci == 32 && (hco == 32 || a.mma == 3)) ? 512 : 768;
+    static const long target_env = getenv("ARCO_WGRAD_TARGET") ? atol(getenv("ARCO_WGRAD_TARGET")) : 0;     // A/B knob (<= the defaults: the slab reservation)
+    const long target = target_env > 0 ? target_env : ((hci == 32 && (hco == 32 || a.mma == 3)) ? 512 : 768);
     long chunks = target / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
     dim3 hgrid((unsigned)chunks, ydim, zdim);
 #define WH(COB, CIB)                                                                              \

@@ -432,4 +432,16 @@ long arco_randint(uint8_t* state, long state_bytes, long high, long n, int64_t* 
   return n;
 }
 
+// Advance the serialized torch CPU generator by n 32-bit draws without producing them (state regeneration only, ~0.5 us per
+// 624 draws): the generator consumption of a tensor-library call whose VALUES this build does not need - the reference's
+// `random_pool = torch.randn(K, 496, H, W)` (train_arco_2d.py:156) when the revisiting term is off - so that every later
+// draw (weight initialisation, samplers, warps) sits where the reference's sits.
+long arco_mt_skip(uint8_t* state, long state_bytes, uint64_t n) {
+  MT g;
+  if (!load_state(state, state_bytes, g)) return -1;
+  g.skip(n);
+  store_state(state, g);
+  return 0;
+}
+
 }  // extern "C"

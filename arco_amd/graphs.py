@@ -69,8 +69,15 @@ class _GraphedTrainFn(torch.autograd.Function):
             else:
                 if g.data_ptr() != sg.data_ptr():
                     sg.copy_(g)
-                gt.grad_live[i] = True
+                    gt.grad_live[i] = True
+                # (same storage: a consumer wrote its gradient straight into the sink, ops.grad_sink - it re-zeroes what
+                #  it touched through gt.cleanup below, so the buffer is clean again for a step without that gradient)
         gt.bwd_g.replay()
+        for fn in gt.cleanup:
+            fn()
+        gt.cleanup.clear()
+        for k in range(len(gt.sink_busy)):
+            gt.sink_busy[k] = False
         for mark in gt.markers:
             mark()
         return (None, gt.static_dx) + tuple(gt.static_pgrads)
@@ -126,6 +133,12 @@ class GraphedTrain:
             self.diff_idx = [i for i, o in enumerate(self.flat_outs) if o.requires_grad]
             self.static_grads = [torch.zeros_like(self.flat_outs[i]) for i in self.diff_idx]
             self.grad_live = [False] * len(self.diff_idx)
+            # gradient sinks (ops.grad_sink): a consumer with a sparse gradient scatters straight into static_grads[k]
+            self.sink_busy = [False] * len(self.diff_idx)
+            self.cleanup = []
+            self.sink_uses = 0
+            for k, i in enumerate(self.diff_idx):
+                ops.GRAD_SINKS[self.flat_outs[i].data_ptr()] = (self, k)
             inputs = ([self.static_in] if self.static_in.requires_grad else []) + [alias[n] for n, _ in named]
             torch.cuda.synchronize()
             self.bwd_g = torch.cuda.CUDAGraph()

@@ -197,6 +197,24 @@ def _rows3lvl_forward(x1p, f2, f3, f4, w2, w3, w4, pix):
     return X2, X3, X4, nb4, nb16, lylx3, lylx4, _gemm(X4, w4)
 
 
+def _row_grad_buffer(ptr, shape, dev):
+    """Zero channels-last buffer [nb, *spatial, c] for a sparse row-scatter gradient of the feature map [nb, c, *spatial] at
+    `ptr`, and a finaliser fin(idx, n).  When the map is an output of a graph-replayed pass the buffer IS that pass's
+    gradient-input buffer (ops.grad_sink: zero by invariant) - no dense fill, no copy into the graph - and fin registers
+    the re-zeroing of the n touched rows idx after the backward graph has replayed; otherwise a fresh zeros tensor and
+    a no-op."""
+    nb, c, spatial = int(shape[0]), int(shape[1]), tuple(int(v) for v in shape[2:])
+    gt, k = ops.grad_sink(ptr, (nb, c) + spatial)
+    if gt is not None:
+        buf = gt.static_grads[k].movedim(1, -1)
+        if buf.is_contiguous() and c % 4 == 0:
+            def fin(idx, n):
+                gt.cleanup.append(lambda: L.call("arco_zero_rows", L.ptr(buf), c, c, L.ptr(idx), n))
+            return buf, fin
+        gt.sink_busy[k] = False
+    return torch.zeros((nb,) + spatial + (c,), dtype=torch.float32, device=dev), (lambda idx, n: None)
+
+
 class LazyHead3Fn(torch.autograd.Function):
     """Three-level row-sparse head: fea2 (the 64 x 64 level), fea3 and fea4 are all evaluated only where the anchors need
     them - the 4 neighbours at 128 x 128 of every anchor and the 4 neighbours at 64 x 64 of each of those (16 n rows of
@@ -212,6 +230,7 @@ class LazyHead3Fn(torch.autograd.Function):
         hh = _gemm(h0, w1)
         a = _gemm(hh, wq2)
         ctx.save_for_backward(X2, X3, X4, h0, hh, w2, w3, w4, w1, wq2, pix, nb4, nb16, lylx3, lylx4)
+        ctx.fptrs = (f2.data_ptr(), f3.data_ptr(), f4.data_ptr())
         ctx.geom = (int(x1p.shape[0]), int(x1p.shape[1]), int(x1p.shape[2]), int(x1p.shape[3]),
                     int(f2.shape[1]), int(f2.shape[2]), int(f2.shape[3]), int(f3.shape[1]), int(f3.shape[2]), int(f3.shape[3]),
                     int(f4.shape[1]), int(f4.shape[2]), int(f4.shape[3]))
@@ -232,21 +251,24 @@ class LazyHead3Fn(torch.autograd.Function):
         dw4 = _wgrad(dh0, X4, w4)
         dX4 = _gemm_t(dh0, w4)
         dX3p = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
-        df4 = torch.zeros((nb, h4, w4_, c4), dtype=torch.float32, device=dev)
+        df4, fin4 = _row_grad_buffer(ctx.fptrs[2], (nb, c4, h4, w4_), dev)
         L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX4), k3 + c4, k3, L.ptr(lylx4), L.ptr(pix), n, L.ptr(dX3p), k3,
                L.ptr(df4), c4, c4)
+        fin4(pix, n)
         dw3 = _wgrad(dX3p, X3, w3)
         dX3 = _fea_rows(dX3p, w3, 1)
         dX2p = torch.empty((16 * n, k2), dtype=torch.float32, device=dev)
-        df3 = torch.zeros((nb, h3, w3_, c3), dtype=torch.float32, device=dev)
+        df3, fin3 = _row_grad_buffer(ctx.fptrs[1], (nb, c3, h3, w3_), dev)
         L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX3), k3, k2, L.ptr(lylx3), L.ptr(nb4), 4 * n, L.ptr(dX2p), k2,
                L.ptr(df3), c3, c3)
+        fin3(nb4, 4 * n)
         dw2 = _wgrad(dX2p, X2, w2)
         dX2 = _fea_rows(dX2p, w2, 1)
         dx1p = torch.zeros((nb, h1, w1_, c1), dtype=torch.float32, device=dev)
-        df2 = torch.zeros((nb, h2, w2_, c2), dtype=torch.float32, device=dev)
+        df2, fin2 = _row_grad_buffer(ctx.fptrs[0], (nb, c2, h2, w2_), dev)
         L.call("arco_scatter_upcat_rows", L.ptr(dX2), k2, L.ptr(nb16), 16 * n, L.ptr(dx1p), c1, c1, h1, w1_, L.ptr(df2), c2,
                c2, h2, w2_)
+        fin2(nb16, 16 * n)
         return (dx1p.permute(0, 3, 1, 2), df2.permute(0, 3, 1, 2), df3.permute(0, 3, 1, 2), df4.permute(0, 3, 1, 2),
                 dw2, dw3, dw4, dw1, dwq2, None)
 
@@ -336,6 +358,7 @@ class LazyHead3dFn(torch.autograd.Function):
         a = _gemm(h1, w2)
         ctx.save_for_backward(X3, X4, h0, h1, w3, w4, w1, w2, pix)
         ctx.shapes = (tuple(x2p.shape), tuple(f3.shape), tuple(f4.shape))
+        ctx.fptrs = (f3.data_ptr(), f4.data_ptr())
         return a
 
     @staticmethod
@@ -353,16 +376,18 @@ class LazyHead3dFn(torch.autograd.Function):
         dw4 = _wgrad(dh0, X4, w4)
         dX4 = _gemm_t(dh0, w4)
         dX3p = dX4[:, :k3].contiguous()
-        df4 = torch.zeros((s4[0], *s4[2:], c4), dtype=torch.float32, device=dev)
+        df4, fin4 = _row_grad_buffer(ctx.fptrs[1], s4, dev)
         L.call("arco_scatter_add_rows", L.ptr(dX4[:, k3:]), k3 + c4, c4, None, L.ptr(pix), n, None, 1.0, L.ptr(df4), c4)
+        fin4(pix, n)
         dw3 = _wgrad(dX3p, X3, w3)
         y, _ = ops.conv_raw(dX3p, k3, k3, ops.pack_weight(w3, 1, 1), k3, 1, 1, n, 1, residual=dX3p, ld_res=k3)
         dX3 = y.permute(0, 2, 3, 1).reshape(n, k3)
         c2, c3 = int(s2[1]), int(s3[1])
         dx2p = torch.zeros((s2[0], *s2[2:], c2), dtype=torch.float32, device=dev)
-        df3 = torch.zeros((s3[0], *s3[2:], c3), dtype=torch.float32, device=dev)
+        df3, fin3 = _row_grad_buffer(ctx.fptrs[0], s3, dev)
         L.call("arco_scatter_upcat_rows3d", L.ptr(dX3), k3, L.ptr(pix), n, L.ptr(dx2p), c2, c2, s2[2], s2[3], s2[4],
                L.ptr(df3), c3, c3, s3[2], s3[3], s3[4])
+        fin3(pix, n)
         return (dx2p.movedim(-1, 1), df3.movedim(-1, 1), df4.movedim(-1, 1), dw3, dw4, dw1, dw2, None)
 
 

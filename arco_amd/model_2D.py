@@ -51,9 +51,9 @@ class FeatureExtractor(nn.Module):
         x = ops.conv(f[0], self.fea0.weight, None, residual=True)
         c = int(x.shape[1])
         n = c + int(f[1].shape[1])
-        w = self.fea1.weight.view(n, n) + torch.eye(n, dtype=torch.float32, device=x.device)
-        lo = ops.conv(x, w[:, :c].contiguous().view(n, c, 1, 1))
-        x = ops.conv(f[1], w[:, c:].contiguous().view(n, n - c, 1, 1), None, residual=ops.bilinear(lo, f[1].shape[-2:]))
+        w_lo, w_hi = ops.fold_residual(self.fea1.weight, c)          # (W + I)[:, :c], (W + I)[:, c:] in one launch
+        lo = ops.conv(x, w_lo)
+        x = ops.conv(f[1], w_hi, None, residual=ops.bilinear(lo, f[1].shape[-2:]))
         return x, f[2], f[3], f[4]
 
     def forward_lowres2(self, fea_list):
@@ -71,10 +71,9 @@ class FeatureExtractor(nn.Module):
         for i, fea in enumerate((self.fea1, self.fea2), start=1):
             c = int(x.shape[1])
             n = c + int(f[i].shape[1])
-            w = fea.weight.view(n, n) + torch.eye(n, dtype=torch.float32, device=x.device)
-            lo = ops.conv(x, w[:, :c].contiguous().view(n, c, 1, 1))                 # at the low resolution
-            x = ops.conv(f[i], w[:, c:].contiguous().view(n, n - c, 1, 1), None,
-                         residual=ops.bilinear(lo, f[i].shape[-2:]))
+            w_lo, w_hi = ops.fold_residual(fea.weight, c)                            # (W + I)[:, :c], (W + I)[:, c:]
+            lo = ops.conv(x, w_lo)                                                   # at the low resolution
+            x = ops.conv(f[i], w_hi, None, residual=ops.bilinear(lo, f[i].shape[-2:]))
         return x, f[3], f[4]
 
     def forward(self, fea_list):

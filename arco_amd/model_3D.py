@@ -36,10 +36,9 @@ class FeatureExtractor_3d(nn.Module):
         for i, fea in enumerate((self.fea1, self.fea2), start=1):
             c = int(x.shape[1])
             n = c + int(f[i].shape[1])
-            w = fea.weight.view(n, n) + torch.eye(n, dtype=torch.float32, device=x.device)
-            lo = ops.conv(x, w[:, :c].contiguous().view(n, c, 1, 1, 1))
-            x = ops.conv(f[i], w[:, c:].contiguous().view(n, n - c, 1, 1, 1), None,
-                         residual=ops.trilinear(lo, f[i].shape[-3:]))
+            w_lo, w_hi = ops.fold_residual(fea.weight, c)                    # (W + I)[:, :c], (W + I)[:, c:] in one launch
+            lo = ops.conv(x, w_lo)
+            x = ops.conv(f[i], w_hi, None, residual=ops.trilinear(lo, f[i].shape[-3:]))
         return x, f[3], f[4]
 
     def forward(self, fea_list):

@@ -855,3 +855,119 @@ def to_channels_last(x):
     if x.dim() == 4:
         return x.contiguous(memory_format=torch.channels_last)
     return x.contiguous(memory_format=torch.channels_last_3d)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Glue that replaces chains of tensor-library launches of the step (profiles/r02_h: ~0.6 ms of fills / copies / adds)
+# ---------------------------------------------------------------------------------------------------------------------
+GRAD_SINKS = {}      # data_ptr of a graph-replayed pass's output -> (GraphedTrain, index into its static_grads)
+
+
+def grad_sink(ptr, shape):
+    """The persistent gradient-input buffer of the graph-replayed pass that produced the tensor at `ptr` (graphs.GraphedTrain
+    keeps one per differentiable output, zero by invariant between steps), or None.  A consumer whose gradient is SPARSE
+    (the row-sparse head) scatters straight into it and returns it - no dense zeros tensor, no copy into the graph's input -
+    and registers a cleanup that re-zeroes the rows it touched after the backward graph has replayed."""
+    hit = GRAD_SINKS.get(ptr)
+    if hit is None:
+        return None, None
+    gt, k = hit
+    buf = gt.static_grads[k]
+    if not gt.captured or tuple(buf.shape) != tuple(shape) or gt.sink_busy[k]:
+        return None, None
+    if gt.grad_live[k]:                  # a dense gradient was copied in by an earlier step: restore the zero invariant
+        buf.zero_()
+        gt.grad_live[k] = False
+    gt.sink_busy[k] = True
+    gt.sink_uses += 1
+    return gt, k
+
+
+class _SplitBatchFn(torch.autograd.Function):
+    """x -> (x[:n], x[n:]) as views; the backward writes both halves' gradients into ONE buffer (the producing graph's
+    gradient sink when there is one) instead of two zero-padded full-size tensors and an add."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.ptr, ctx.shape = n, x.data_ptr(), tuple(x.shape)
+        ctx.like = x
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n = ctx.n
+        gt, k = grad_sink(ctx.ptr, ctx.shape)
+        if gt is not None:
+            buf = gt.static_grads[k]        # fully overwritten below; dense from now on (grad_live: re-zeroed before a sparse use)
+            gt.grad_live[k] = True
+        else:
+            buf = torch.empty_like(ctx.like)
+        for half, g in ((buf[:n], ga), (buf[n:], gb)):
+            if g is None:
+                half.zero_()
+            else:
+                half.copy_(g)
+        ctx.like = None
+        return buf, None
+
+
+def split_batch(x, n):
+    return _SplitBatchFn.apply(x, int(n))
+
+
+class _FoldResidualFn(torch.autograd.Function):
+    """W [n, n, 1, 1(, 1)] -> (W + I)[:, :c] as [n, c, 1, 1(, 1)], (W + I)[:, c:] as [n, n - c, 1, 1(, 1)] in one launch
+    (model_2D.FeatureExtractor.forward_lowres1/2: the residual folded into the 1x1 weights); backward: one launch."""
+
+    @staticmethod
+    def forward(ctx, w, c):
+        n = int(w.shape[0])
+        wc = w.detach().contiguous()
+        ones = (1,) * (w.dim() - 2)                      # [n, n, 1, 1] (2-D) or [n, n, 1, 1, 1] (3-D) 1x1 conv weights
+        lo = torch.empty((n, c) + ones, dtype=torch.float32, device=w.device)
+        hi = torch.empty((n, n - c) + ones, dtype=torch.float32, device=w.device)
+        L.call("arco_fold_residual", L.ptr(wc), n, c, L.ptr(lo), L.ptr(hi))
+        ctx.geom = (n, c, tuple(w.shape))
+        return lo, hi
+
+    @staticmethod
+    def backward(ctx, dlo, dhi):
+        n, c, shape = ctx.geom
+        dlo = dlo.contiguous() if dlo is not None else None
+        dhi = dhi.contiguous() if dhi is not None else None
+        ref = dlo if dlo is not None else dhi
+        dw = torch.empty(shape, dtype=torch.float32, device=ref.device)
+        L.call("arco_unfold_residual", L.ptr(dlo), L.ptr(dhi), n, c, L.ptr(dw))
+        return dw, None
+
+
+def fold_residual(weight, c):
+    return _FoldResidualFn.apply(weight, int(c))
+
+
+class _CombineTermsFn(torch.autograd.Function):
+    """sum_i w_i * term_i over device scalars in one launch (the step's loss combination); backward one launch."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        import ctypes
+        n = len(terms)
+        ts = [t.detach().reshape(()).float() for t in terms]
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ws = (ctypes.c_float * n)(*[float(w) for w in weights])
+        out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        L.call("arco_combine_terms", ptrs, ws, n, L.ptr(out))
+        ctx.ws, ctx.n = ws, n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = torch.empty(ctx.n, dtype=torch.float32, device=g.device)
+        L.call("arco_combine_terms_bwd", ctx.ws, ctx.n, L.ptr(g.contiguous().float()), L.ptr(grads))
+        return (None,) + tuple(grads[i] for i in range(ctx.n))
+
+
+def combine_terms(weights, terms):
+    """sum_i weights[i] * terms[i] (0-d device tensors, python-float weights), differentiable w.r.t. the terms."""
+    assert 1 <= len(terms) <= 8 and len(weights) == len(terms)
+    return _CombineTermsFn.apply(tuple(weights), *terms)

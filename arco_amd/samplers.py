@@ -188,3 +188,20 @@ def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=8, defer=F
             views[first].copy_(single(int(h), int(sh), cut_count))
             first += 1
     return views
+
+
+def skip_randn(numel):
+    """Advance torch's CPU default generator exactly as `torch.randn(numel)` (float32, contiguous, numel >= 16) would,
+    without producing the values: ATen's normal_fill draws one 32-bit word per element (uniform_real_distribution<float>)
+    and, when numel is not a multiple of 16, 16 more for the recomputed tail - aten/src/ATen/native/cpu/
+    DistributionTemplates.h.  Used for the reference's 4.7 GB `random_pool` draw (train_arco_2d.py:156) when the
+    revisiting term is off, so a seeded run keeps the reference's generator sequence (weight initialisation, samplers,
+    warps) without the pool.  Pinned against torch.randn itself in tests/test_samplers_host.py."""
+    from . import _lib
+    numel = int(numel)
+    assert numel >= 16, "the serial path of small tensors draws differently (normal_distribution<double>)"
+    st = torch.get_rng_state()
+    rc = _lib.load().arco_mt_skip(st.data_ptr(), st.numel(), numel + (16 if numel % 16 else 0))
+    if rc != 0:
+        raise RuntimeError(f"arco_mt_skip failed ({rc})")
+    torch.set_rng_state(st)

@@ -159,6 +159,12 @@ class ArcoStep2D:
             args.dense_head = args.dense_teacher = 1
             assert args.K % args.batch_size == 0, "--K must be a multiple of --batch_size (train_arco_2d.py:113)"
             self.random_pool = glue.RevisitPool(args.K, 256 + 128 + 64 + 32 + 16, args.patch_size, self.dev)
+        else:
+            # --revisit 0 (default): the pool's 4.7 GB of normals are not needed, but their place in the CPU-generator
+            # sequence is - the weight initialisation below, the samplers and the warps then draw what the reference draws
+            # for the same seed (samplers.skip_randn: 0.4 s of state regeneration for K = 36 at 256 x 256)
+            from . import samplers
+            samplers.skip_randn(args.K * REP_DIM * int(args.patch_size[0]) * int(args.patch_size[1]))
         # memory banks (train_arco_2d.py:147-154); device resident from the first enqueue on
         self.memobank, self.queue_ptrlis, self.queue_size = [], [], []
         for i in range(C):
@@ -275,7 +281,7 @@ class ArcoStep2D:
             with ops.bn_groups(2), ops.bn_defer(1):
                 pred_all, _, fm_all = self.s_train_lu(lu)
             nb_l = int(l_data.shape[0])
-            pred_l, pred_u = pred_all[:nb_l], pred_all[nb_l:]
+            pred_l, pred_u = ops.split_batch(pred_all, nb_l)    # (views; one gradient buffer for both halves in the backward)
         else:
             with ops.bn_defer(0):                                        # running statistics: applied after l and cj2_l
                 pred_u, _, u_fm = self.s_train_u(u_aug)                  # :312 (needed first: entropy masks)
@@ -352,7 +358,7 @@ class ArcoStep2D:
                 # images_cj1_logits_l (:287-288) is the constant 255 pushed through ToTensor = 1.0 everywhere
                 logits_all = torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits))
                 eqv_in = (glue.eqv_mask(labels_all, logits_all, a.weak_threshold), torch.cat((cj2_l, cj2_u)),
-                          torch.cat((pred_l.detach(), pred_u.detach())))
+                          pred_all.detach() if batched else torch.cat((pred_l.detach(), pred_u.detach())))
         # per-class row lists and prototypes need the class codes / totals on the DEVICE only: queued before the host blocks
         evp = None
         if prof:
@@ -416,16 +422,19 @@ class ArcoStep2D:
         if prof:
             ev3[1].record()
             self.loss_events.append((ev, ev2, ev3, evp))  # masks | keys, banks | anchors, head, InfoNCE | lists, prototypes
-        loss = (a.k1 * adist.anchor_weight(a.num_queries, getattr(a, "anchors_per_rank", "split"))) * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :426
+        # :426 - one launch for the weighted sum (and one for its backward) instead of a chain of 0-d multiplies and adds
+        ws = [a.k1 * adist.anchor_weight(a.num_queries, getattr(a, "anchors_per_rank", "split")), a.k3, 1.0, 1.0]
+        terms = [reco_loss, unsup_loss, loss_dice, loss_ce]
         if loss_eqv is not None:
-            loss = loss + a.k2 * loss_eqv
+            ws.append(a.k2); terms.append(loss_eqv)
         loss_q = None
         if self.random_pool is not None:
             # :334 (computed before the pool is updated) and :398-400; a constant w.r.t. every parameter
             nb_l = int(l_data.shape[0])
             loss_q = glue.get_revisiting_loss(self.random_pool, rep_all[nb_l:], rep_all_teacher[nb_l:], topk=a.topk)
             glue.revisit_enqueue(rep_all_teacher[nb_l:], self.random_pool)
-            loss = loss + a.k4 * loss_q
+            ws.append(a.k4); terms.append(loss_q)
+        loss = ops.combine_terms(ws, terms)
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()
         adist.allreduce_grads(self.optimizer)

@@ -60,6 +60,9 @@ class ArcoStep3D:
             args.dense_head = 1
             assert args.K % args.batch_size == 0, "--K must be a multiple of --batch_size (train_arco_3d.py:110)"
             self.random_pool = glue.RevisitPool(args.K, REP_DIM_3D, args.patch_size, self.dev)
+        else:      # the pool's normals are not needed, its place in the CPU-generator sequence is (weight init, samplers, warps)
+            from . import samplers
+            samplers.skip_randn(args.K * REP_DIM_3D * int(np.prod(args.patch_size)))
         self.isd = ISD_3d(K=args.K, m=0.99, Ts=0.01, Tt=0.1, num_classes=C,
                           latent_pooling_size=args.latent_pooling_size, latent_feature_size=args.latent_feature_size,
                           output_pooling_size=args.output_pooling_size, train_encoder=True, train_decoder=True).to(self.dev)
@@ -135,7 +138,7 @@ class ArcoStep3D:
             nb_l = int(l_data.shape[0])
             with ops.bn_groups(2):
                 pred_all, _, fm_s = self.s_train_lu(lu)                  # :283-284
-            pred_l, pred_u = pred_all[:nb_l], pred_all[nb_l:]
+            pred_l, pred_u = ops.split_batch(pred_all, nb_l)
         else:
             with ops.bn_defer(0):                                        # running statistics: l first (:283), then u
                 pred_u, _, u_fm = self.s_train_u(u_aug)                  # :284
@@ -211,17 +214,20 @@ class ArcoStep3D:
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
         if self.keep_debug and plan.valid_seg > 1 and plan.entries:
             self.debug = dict(plan=plan, A_all=A_all.detach(), banks=[m[0] for m in self.memobank])
-        if self.iter_num == 0 and loss_eqv is not None:
-            loss = unsup_loss + (loss_dice + loss_ce) + loss_eqv         # :393 (iter_num / max_iterations == 0)
-        else:
-            loss = (a.k1 * adist.anchor_weight(a.num_queries, getattr(a, "anchors_per_rank", "split"))) * reco_loss + a.k3 * unsup_loss + (loss_dice + loss_ce)      # :391 (k4*loss_q only with --revisit 1)
+        first = self.iter_num == 0 and loss_eqv is not None
+        if first:
+            ws, terms = [1.0, 1.0, 1.0, 1.0], [unsup_loss, loss_dice, loss_ce, loss_eqv]      # :393 (iter_num / max_iterations == 0)
+        else:                                                                               # :391 (k4*loss_q only with --revisit 1)
+            ws = [a.k1 * adist.anchor_weight(a.num_queries, getattr(a, "anchors_per_rank", "split")), a.k3, 1.0, 1.0]
+            terms = [reco_loss, unsup_loss, loss_dice, loss_ce]
         loss_q = None
         if self.random_pool is not None:      # :304 (before the pool update) and :365; constant w.r.t. every parameter
             nb_l = int(l_data.shape[0])
             loss_q = glue.get_revisiting_loss(self.random_pool, rep_all[nb_l:], rep_all_teacher[nb_l:], topk=a.topk)
             glue.revisit_enqueue(rep_all_teacher[nb_l:], self.random_pool)
-            if not (self.iter_num == 0 and loss_eqv is not None):
-                loss = loss + a.k4 * loss_q
+            if not first:
+                ws.append(a.k4); terms.append(loss_q)
+        loss = ops.combine_terms(ws, terms)           # one launch (and one for its backward) instead of a chain of 0-d ops
         self.optimizer.zero_grad()
         loss.backward()
         adist.allreduce_grads(self.optimizer)

@@ -203,6 +203,16 @@ int arco_gather_upcat_rows3d(const float* lo, long ldlo, int Clo, int Di, int Hi
                              int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
 int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo, int Di,
                               int Hi, int Wi, float* dhi, long ldhi, int Chi, int Do, int Ho, int Wo, void* stream);
+/* glue kernels replacing chains of tensor-library launches in the step (no reference counterpart: the reference's
+ * autograd does these as separate zeros / add / copy / mul kernels, train_arco_2d.py:426-431, model_2D.py:43-50):
+ * arco_zero_rows: rows idx[] of a [rows, ld] buffer zeroed over C channels (re-arms a persistent gradient buffer);
+ * arco_fold_residual / arco_unfold_residual: W' = W + I split into its column blocks [n, c] | [n, n - c], and the gradient back;
+ * arco_combine_terms(_bwd): out = sum_i w_i * term_i over <= 8 device scalars (host arrays of pointers / weights), grads_i = w_i * g */
+int arco_zero_rows(float* dst, long ld, int C, const int64_t* idx, long n, void* stream);
+int arco_fold_residual(const float* W, int n, int c, float* lo, float* hi, void* stream);
+int arco_unfold_residual(const float* dlo, const float* dhi, int n, int c, float* dW, void* stream);
+int arco_combine_terms(const float* const* terms, const float* weights, int n, float* out, void* stream);
+int arco_combine_terms_bwd(const float* weights, int n, const float* g, float* grads, void* stream);
 int arco_copy_rows(const float* X, long ldx, long M, int C, float* Y, long ldy, int accumulate, void* stream);
 int arco_nchw_to_nhwc(const float* X, int NB, int C, long P, float* Y, long ldy, void* stream);
 int arco_nhwc_to_nchw(const float* X, long ldx, int NB, int C, long P, float* Y, void* stream);
@@ -302,6 +312,9 @@ long arco_grid_sample_many_async(uint8_t* state, long state_bytes, int n_jobs, c
                                  int mirror, int64_t* const* outs, int max_threads);
 void arco_grid_sample_many_finish(void);
 long arco_randint(uint8_t* state, long state_bytes, long high, long n, int64_t* out);
+/* generator consumption of a draw whose values are not needed: advance the serialized torch CPU generator by n 32-bit
+ * draws (train_arco_2d.py:156 `torch.randn(K, 496, H, W)` when the revisiting term is off)                              */
+long arco_mt_skip(uint8_t* state, long state_bytes, uint64_t n);
 /* the generator's next state blocks for >= n_draws draws, computed ahead of time from `state` (not modified; in a worker
    thread when background != 0) while the host waits for the GPU's per-class counters (loss_helper_3d.py:413-434 needs them
    before the first sampler call :435-476).  The next arco_grid_sample_many call that starts from exactly this state reads

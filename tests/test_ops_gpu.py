@@ -134,3 +134,49 @@ def test_sgd_and_ema_vs_golden(golden):
     k = [torch.nn.Parameter(torch.from_numpy(g["ema_k"]).cuda())]
     optim.EmaPair(q, k).update(0.99)
     np.testing.assert_allclose(k[0].detach().cpu().numpy(), g["ema_out"], rtol=1e-6, atol=1e-7)
+
+
+def test_glue_functions_match_torch_expressions():
+    """ops.split_batch / fold_residual / combine_terms (one launch each way) against the tensor expressions they replace:
+    values and gradients."""
+    from arco_amd import ops
+    g = torch.Generator().manual_seed(11)
+    # split_batch: views + one-buffer backward; a missing half's gradient is zero
+    x = torch.randn(6, 4, 8, 8, generator=g).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    a, b = ops.split_batch(x, 2)
+    assert a.data_ptr() == x.data_ptr() and tuple(a.shape) == (2, 4, 8, 8) and tuple(b.shape) == (4, 4, 8, 8)
+    wa, wb = torch.randn(2, 4, 8, 8, generator=g).cuda(), torch.randn(4, 4, 8, 8, generator=g).cuda()
+    ((a * wa).sum() + (b * wb).sum()).backward()
+    assert torch.equal(x.grad, torch.cat((wa, wb)))
+    x.grad = None
+    a, b = ops.split_batch(x, 2)
+    (b * wb).sum().backward()
+    assert torch.equal(x.grad, torch.cat((torch.zeros_like(wa), wb)))
+    # fold_residual: (W + I) split by columns, 2-D and 3-D 1x1 weights
+    for ones in ((1, 1), (1, 1, 1)):
+        n, c = 48, 32
+        w = torch.randn(n, n, *ones, generator=g).cuda().requires_grad_(True)
+        lo, hi = ops.fold_residual(w, c)
+        ref = w.detach().view(n, n) + torch.eye(n, device="cuda")
+        assert tuple(lo.shape) == (n, c) + ones and torch.equal(lo.view(n, c), ref[:, :c]) and torch.equal(hi.view(n, n - c), ref[:, c:])
+        glo, ghi = torch.randn_like(lo), torch.randn_like(hi)
+        ((lo * glo).sum() + (hi * ghi).sum()).backward()
+        assert torch.equal(w.grad.view(n, n), torch.cat((glo.view(n, c), ghi.view(n, n - c)), dim=1))
+    # combine_terms
+    ts = [torch.randn((), generator=g).cuda().requires_grad_(True) for _ in range(5)]
+    ws = [0.01, 1.0, 1.0, 1.0, 0.5]
+    out = ops.combine_terms(ws, ts)
+    ref = sum(w * t.detach().double() for w, t in zip(ws, ts))
+    np.testing.assert_allclose(float(out.detach()), float(ref), rtol=1e-6)
+    (out * 3.0).backward()
+    for w, t in zip(ws, ts):
+        np.testing.assert_allclose(float(t.grad), 3.0 * w, rtol=1e-6)
+
+
+def test_zero_rows():
+    from arco_amd import _lib as L
+    buf = torch.ones(100, 16, device="cuda")
+    idx = torch.tensor([3, 7, 7, 99], dtype=torch.int64, device="cuda")
+    L.call("arco_zero_rows", L.ptr(buf), 16, 16, L.ptr(idx), 4)
+    ref = torch.ones(100, 16); ref[[3, 7, 99]] = 0
+    assert torch.equal(buf.cpu(), ref)

@@ -187,3 +187,33 @@ def test_forked_child_with_a_sequence_in_flight_does_not_hang():
     torch.manual_seed(9)
     a = samplers.grid_monte_carlo_sample(30000, 131072)            # the parent is unaffected
     assert int(a.numel()) == 131072
+
+
+@pytest.mark.parametrize("numel", [16, 17, 1000, 1003, 624 * 5, 624 * 5 + 1, 1 << 20, (1 << 22) + 5])
+def test_skip_randn_matches_torch_randn_consumption(numel):
+    """samplers.skip_randn(n) leaves the CPU generator exactly where torch.randn(n) leaves it (the reference's random_pool
+    draw, train_arco_2d.py:156, skipped without producing 4.7 GB of normals): same next draws of every kind."""
+    from arco_amd import samplers
+    for seed in (0, 1337):
+        torch.manual_seed(seed)
+        torch.randint(100, (7,))                                    # not at a block boundary
+        st0 = torch.get_rng_state()
+        torch.randn(numel)
+        ref_state = torch.get_rng_state()
+        ref_next = (torch.randint(1 << 30, (5,)), torch.rand(3), torch.randperm(11))
+        torch.set_rng_state(st0)
+        samplers.skip_randn(numel)
+        assert torch.equal(torch.get_rng_state(), ref_state)
+        got = (torch.randint(1 << 30, (5,)), torch.rand(3), torch.randperm(11))
+        assert all(torch.equal(a, b) for a, b in zip(ref_next, got))
+
+
+def test_skip_randn_shape_of_the_reference_pool():
+    """K x 496 x H x W as the trainer calls it (small H, W here), drawn as a 4-D tensor like the reference."""
+    from arco_amd import samplers
+    torch.manual_seed(1337)
+    torch.randn(6, 496, 8, 8)
+    ref = torch.randint(1 << 30, (4,))
+    torch.manual_seed(1337)
+    samplers.skip_randn(6 * 496 * 8 * 8)
+    assert torch.equal(torch.randint(1 << 30, (4,)), ref)

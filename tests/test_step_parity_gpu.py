@@ -211,6 +211,8 @@ def test_graphed_student_passes_match_eager():
         for be, bg in zip(st_e.memobank, st_g.memobank):
             np.testing.assert_allclose(bg[0].cpu().numpy(), be[0].cpu().numpy(), rtol=1e-4, atol=1e-6)
     assert st_g.s_train_lu.captured        # the labelled + unlabelled halves run as one grouped pass
+    # the replayed steps took the gradient-sink path (prediction halves + the head's three feature-map scatters per step)
+    assert st_g.s_train_lu.sink_uses >= 4 * 3 and st_g.s_train_lu.cleanup == [] and not any(st_g.s_train_lu.sink_busy)
 
 
 def test_graphed_unet_pass_is_bit_exact_even_with_a_live_eager_graph():
@@ -332,3 +334,30 @@ def test_batched_passes_match_separate_passes_and_ragged_batches_run():
     lab = torch.from_numpy(fx.blob_labels(rs, 2, patch, C)).cuda()
     loss, reco = st_r.step(l, lab, u)
     assert bool(torch.isfinite(loss)) and bool(torch.isfinite(reco))
+
+
+@pytest.mark.parametrize("three_d", [False, True])
+def test_default_trainer_keeps_the_reference_generator_sequence_without_the_pool(three_d):
+    """with --revisit 0 (default) the reference's `torch.randn(K, D, *patch)` pool draw (train_arco_2d.py:156,
+    train_arco_3d.py:153) is not materialised, but its generator consumption is reproduced (samplers.skip_randn): the
+    trainer built with and without the pool initialises identical weights and leaves the CPU generator in the same
+    state, i.e. a seeded default run draws the reference's sequence from step 0."""
+    from arco_amd import train_arco_2d as T, train_arco_3d as T3
+    mod, Step = (T3, T3.ArcoStep3D) if three_d else (T, T.ArcoStep2D)
+    out = []
+    for revisit in (1, 0):
+        argv = ["--batch_size", "2", "--queue_size", "64", "--synthetic", "1", "--K", "4", "--revisit", str(revisit), "--graphs", "0"]
+        if three_d:
+            argv += ["--num_classes", "2"]
+        args = mod.build_parser().parse_args(argv)
+        args.patch_size = [16, 16, 16] if three_d else [32, 32]
+        random.seed(5); np.random.seed(5); torch.manual_seed(5)
+        st = Step(args, "cuda:0")
+        out.append((torch.get_rng_state().clone(), {k: v.detach().cpu().clone() for k, v in st.model.state_dict().items()},
+                    [p.detach().cpu().clone() for p in st.q_representation.parameters()]))
+        del st
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    for a, b in zip(out[0][2], out[1][2]):
+        assert torch.equal(a, b)
