@@ -305,7 +305,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
     const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed_, long P,
     const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, float inv_count,
-    float* __restrict__ dZ, long ldo, const uint64_t* __restrict__ seed_dev) {
+    float* __restrict__ dZ, long ldo, const uint64_t* __restrict__ seed_dev, int gn) {
+  // gn != 0 (GroupNorm / InstanceNorm: statistics per sample over a SET of channels): sum_dy / sum_dyx hold the set's sums
+  // of gamma*dy and gamma*dy*xhat, and dz = istd * (gamma*dy - sum_dy/n - xhat*sum_dyx/n); gamma varies inside a set
   const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
   const long row0 = (long)blockIdx.y * M;                 // blockIdx.y = BN group
   dA += row0 * ldd; Z += row0 * ldz; dZ += row0 * ldo;
@@ -337,7 +339,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
             const float xh = (z[u][e] - mu[e]) * is[e];
             const float y = xh * ga[e] + be[e];
             const float dy = bn_dy(d[u][e], y, slope, drop_mode, p, keep_scale, seed, ei);
-            o[e] = ga[e] * is[e] * (dy - sd[e] * inv_count - xh * sx[e] * inv_count);
+            o[e] = gn ? is[e] * (ga[e] * dy - sd[e] * inv_count - xh * sx[e] * inv_count)
+                      : ga[e] * is[e] * (dy - sd[e] * inv_count - xh * sx[e] * inv_count);
           }
           *reinterpret_cast<f32x4*>(dZ + r * ldo + c) = o;
         }
@@ -357,7 +360,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         const float xh = (z[e] - mean[c + e]) * istd[c + e];
         const float y = xh * gamma[c + e] + beta[c + e];
         const float dy = bn_dy(d[e], y, slope, drop_mode, p, keep_scale, seed, ei);
-        o[e] = gamma[c + e] * istd[c + e] * (dy - sum_dy[c + e] * inv_count - xh * sum_dyx[c + e] * inv_count);
+        o[e] = gn ? istd[c + e] * (gamma[c + e] * dy - sum_dy[c + e] * inv_count - xh * sum_dyx[c + e] * inv_count)
+                  : gamma[c + e] * istd[c + e] * (dy - sum_dy[c + e] * inv_count - xh * sum_dyx[c + e] * inv_count);
       } else {
         o[e] = bn_dy(d[e], z[e], slope, drop_mode, p, keep_scale, seed, ei);
       }
@@ -908,6 +912,44 @@ __global__ void combine_terms_bwd_kernel(TermTable t, const float* __restrict__ 
   if ((int)threadIdx.x < t.n) grads[threadIdx.x] = t.w[threadIdx.x] * g[0];
 }
 
+// ---- GroupNorm / InstanceNorm statistics (vnetWithArgs.py:19-22 `normalization='groupnorm' | 'instancenorm'`): one
+// normalisation set = (sample n, cpg consecutive channels, all voxels).  The per-(sample, channel) slab sums are the BN
+// machinery's with groups = samples; this finalize sums a set's channels: mean / istd rows [N][C], the set's value in
+// each of its channels, so that bn_act_fwd_kernel applies them unchanged.  grid (C / cpg, N), fp64, fixed order.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nblk, int C,
+                                                         int cpg, double count, float eps, float* __restrict__ mean,
+                                                         float* __restrict__ istd) {
+  __shared__ double sh[2][4];
+  const int set = blockIdx.x, n = blockIdx.y, N = gridDim.y, npg = nblk / N, w = threadIdx.x >> 6;
+  double s = 0.0, q = 0.0;
+  for (int j = 0; j < cpg; ++j) {
+    const int c = set * cpg + j;
+    slab_sums2<256>(ssum + (long)c * nblk + n * npg, ssq + (long)c * nblk + n * npg, npg, s, q);
+  }
+  s = wave_sum_d(s); q = wave_sum_d(q);
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = q; }
+  __syncthreads();
+  if (threadIdx.x < cpg) {
+    s = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]); q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[(long)n * C + set * cpg + threadIdx.x] = (float)m;
+    istd[(long)n * C + set * cpg + threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+// backward: sums [N][2][C] (per sample and channel: sum dy, sum dy*xhat) -> per set the sums of gamma*dy, gamma*dy*xhat,
+// written back into every channel of the set (what bn_act_bwd_apply_kernel(gn = 1) reads).  One thread per (n, set).
+__global__ void gn_merge_bwd_kernel(float* __restrict__ sums, const float* __restrict__ gamma, int N, int C, int cpg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, sets = C / cpg;
+  if (i >= N * sets) return;
+  const int n = i / sets, set = i - n * sets;
+  float* s1 = sums + (2l * n) * C + set * cpg; float* s2 = sums + (2l * n + 1) * C + set * cpg;
+  double a = 0.0, b = 0.0;
+  for (int j = 0; j < cpg; ++j) { const double g = gamma ? (double)gamma[set * cpg + j] : 1.0; a += g * (double)s1[j]; b += g * (double)s2[j]; }
+  for (int j = 0; j < cpg; ++j) { s1[j] = (float)a; s2[j] = (float)b; }
+}
+
 extern "C" {
 
 int arco_bn_finalize(const float* ssum, const float* ssq, int nblk, int C, long count, float eps, float momentum,
@@ -962,12 +1004,16 @@ int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, 
 }
 
 // ws: groups * (2*C*nblk + 2*C) floats;  nblk = arco_chan_stats_blocks(M / groups)
-int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
-                    const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
-                    uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
-                    const uint64_t* seed_dev, int groups, void* stream) {
+// cpg = 0: BatchNorm (groups = BN groups).  cpg >= 1: GroupNorm with cpg channels per set / InstanceNorm (cpg = 1),
+// groups = samples; gamma / beta may be null there (no affine: gamma = 1, beta = 0 are expected as real tensors by the kernels,
+// so the host passes ones / zeros).
+static int bn_act_bwd_impl(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
+                           const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
+                           uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
+                           const uint64_t* seed_dev, int groups, int cpg, void* stream) {
   if (groups < 1) groups = 1;
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldz & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0 && M % groups == 0);
+  ARCO_CHECK_ARG(cpg == 0 || (mean && cpg >= 1 && C % cpg == 0));
   const int dm = p > 0.f ? drop_mode : 0;
   hipStream_t st = as_stream(stream);
   const long Mg = M / groups;
@@ -978,13 +1024,42 @@ int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
                        C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk, seed_dev);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, s_dy, s_dyx, nblk, C, sums, dgamma,
                        dbeta, accumulate, groups);
+    if (cpg) {
+      const int nset = groups * (C / cpg);
+      hipLaunchKernelGGL(gn_merge_bwd_kernel, dim3((nset + 255) / 256), dim3(256), 0, st, sums, gamma, groups, C, cpg);
+    }
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, st, dA, ldd, Z, ldz, Mg, C,
-                       mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / (float)Mg, dZ, ldo, seed_dev);
+                       mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / ((float)Mg * (float)(cpg ? cpg : 1)), dZ, ldo,
+                       seed_dev, cpg ? 1 : 0);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
-                       nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo, seed_dev);
+                       nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo, seed_dev, 0);
   }
   return arco_launch_status();
+}
+int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
+                    const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
+                    uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
+                    const uint64_t* seed_dev, int groups, void* stream) {
+  return bn_act_bwd_impl(dA, ldd, Z, ldz, M, C, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, ws, dgamma, dbeta,
+                         accumulate, dZ, ldo, seed_dev, groups, 0, stream);
+}
+// GroupNorm / InstanceNorm + activation (vnetWithArgs.py:19-22): statistics of N samples x (C / cpg) channel sets from the
+// per-(sample, channel) slabs of arco_chan_stats(groups = N) / the conv epilogue; apply = arco_bn_act_fwd(groups = N)
+int arco_gn_finalize(const float* ssum, const float* ssq, int nblk, int C, int cpg, int N, long count_per_sample_channel,
+                     float eps, float* mean, float* istd, void* stream) {
+  ARCO_CHECK_ARG(ssum && ssq && mean && istd && C > 0 && cpg >= 1 && cpg <= 256 && C % cpg == 0 && N >= 1 && nblk % N == 0 &&
+                 count_per_sample_channel > 0);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(C / cpg, N), dim3(256), 0, as_stream(stream), ssum, ssq, nblk, C, cpg,
+                     (double)count_per_sample_channel * (double)cpg, eps, mean, istd);
+  return arco_launch_status();
+}
+int arco_gn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
+                    const float* istd, const float* gamma, const float* beta, float slope, float* ws, float* dgamma,
+                    float* dbeta, int accumulate, float* dZ, long ldo, int N, int cpg, void* stream) {
+  ARCO_CHECK_ARG(mean && istd && gamma && beta && cpg >= 1);
+  return bn_act_bwd_impl(dA, ldd, Z, ldz, M, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1, ws, dgamma, dbeta, accumulate,
+                         dZ, ldo, nullptr, N, cpg, stream);
 }
 
 int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, float* Y, long ldy, void* stream) {

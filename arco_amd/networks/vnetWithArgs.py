@@ -1,7 +1,8 @@
 """3-D V-Net of the ARCO hot path on MI355X - drop-in for the reference's
 code/networks/vnetWithArgs.py (ConvBlock :5-31, DownsamplingConvBlock :67-91,
-UpsamplingDeconvBlock :94-118, VNet :145-252), batch-norm variant (the one
-net_factory_3d builds, net_factory_3dArgs.py:16-18).
+UpsamplingDeconvBlock :94-118, VNet :145-252): every `normalization` the reference's blocks accept - 'batchnorm' (the one
+net_factory_3d builds, net_factory_3dArgs.py:16-18: statistics fused into the conv epilogue), 'groupnorm'
+(nn.GroupNorm(16, C)), 'instancenorm', 'none' (ops.GnActFn: one statistics pass + the apply pass).
 
 Same class names, constructor arguments, return values and state_dict keys (the nn.Conv3d /
 nn.BatchNorm3d children are parameter containers).  Forward on channels-last-3d activations:
@@ -16,10 +17,31 @@ from torch import nn
 from .. import ops
 
 
-def _need_bn(normalization):
-    if normalization != 'batchnorm':
-        raise NotImplementedError("only normalization='batchnorm' is on the ARCO hot path "
-                                  "(net_factory_3dArgs.py:17-18)")
+NORMS = ('batchnorm', 'groupnorm', 'instancenorm', 'none')
+
+
+def _norm_layer(normalization, c):
+    """The parameter container the reference appends after a conv (vnetWithArgs.py:17-24): same class -> same state_dict keys."""
+    if normalization == 'batchnorm':
+        return nn.BatchNorm3d(c)
+    if normalization == 'groupnorm':
+        return nn.GroupNorm(num_groups=16, num_channels=c)
+    if normalization == 'instancenorm':
+        return nn.InstanceNorm3d(c)
+    assert normalization == 'none', normalization
+    return None
+
+
+def _norm_act(z, norm, training):
+    """ReLU(norm(z)) for a pre-activation z that did not get its statistics from the conv epilogue: GroupNorm(16, C) /
+    InstanceNorm3d / nothing (vnetWithArgs.py:19-24).  Batch-independent statistics: the same in train and eval mode."""
+    if norm is None:
+        return ops.act(z, 0.0)
+    if isinstance(norm, nn.GroupNorm):
+        return ops.gn_act(z, norm.weight, norm.bias, norm.num_groups, 0.0, norm.eps)
+    if isinstance(norm, nn.InstanceNorm3d):
+        return ops.in_act(z, 0.0, norm.eps)
+    raise AssertionError(type(norm))
 
 
 def _bn_stage(x, conv, bn, training):
@@ -32,37 +54,55 @@ def _bn_stage(x, conv, bn, training):
                                 slope=0.0, eps=bn.eps)
 
 
+def _stage(x, conv, norm, training):
+    """conv -> norm -> ReLU.  BatchNorm (the variant net_factory_3d builds): statistics fused into the conv epilogue;
+    the other variants: conv, then one statistics pass + the apply pass."""
+    if isinstance(norm, nn.BatchNorm3d):
+        return _bn_stage(x, conv, norm, training)
+    return _norm_act(ops.conv(x, conv.weight, conv.bias), norm, training)
+
+
 class ConvBlock(nn.Module):
     def __init__(self, n_stages, n_filters_in, n_filters_out, normalization='none'):
         super(ConvBlock, self).__init__()
-        _need_bn(normalization)
+        assert normalization in NORMS
         ops_ = []
         for i in range(n_stages):
             ops_.append(nn.Conv3d(n_filters_in if i == 0 else n_filters_out, n_filters_out, 3, padding=1))
-            ops_.append(nn.BatchNorm3d(n_filters_out))
+            norm = _norm_layer(normalization, n_filters_out)
+            if norm is not None:
+                ops_.append(norm)
             ops_.append(nn.ReLU(inplace=True))
         self.conv = nn.Sequential(*ops_)
         self.n_stages = n_stages
+        self.per = 2 if normalization == 'none' else 3
 
     def forward(self, x):
         for i in range(self.n_stages):
-            x = _bn_stage(x, self.conv[3 * i], self.conv[3 * i + 1], self.training)
+            conv = self.conv[self.per * i]
+            x = _stage(x, conv, self.conv[self.per * i + 1] if self.per == 3 else None, self.training)
         return x
 
 
 class DownsamplingConvBlock(nn.Module):
     def __init__(self, n_filters_in, n_filters_out, stride=2, normalization='none'):
         super(DownsamplingConvBlock, self).__init__()
-        _need_bn(normalization)
-        assert stride == 2
-        self.conv = nn.Sequential(nn.Conv3d(n_filters_in, n_filters_out, stride, padding=0, stride=stride),
-                                  nn.BatchNorm3d(n_filters_out), nn.ReLU(inplace=True))
+        assert normalization in NORMS and stride == 2
+        layers = [nn.Conv3d(n_filters_in, n_filters_out, stride, padding=0, stride=stride)]
+        norm = _norm_layer(normalization, n_filters_out)
+        if norm is not None:
+            layers.append(norm)
+        layers.append(nn.ReLU(inplace=True))
+        self.conv = nn.Sequential(*layers)
+        self.has_norm = norm is not None
 
     def forward(self, x):
-        conv, bn = self.conv[0], self.conv[1]
+        conv, bn = self.conv[0], (self.conv[1] if self.has_norm else None)
         co, ci = conv.weight.shape[0], conv.weight.shape[1]
         w2 = conv.weight.permute(0, 2, 3, 4, 1).reshape(co, 8 * ci, 1, 1, 1)      # [co][(dx,dy,dz), ci]
         xs = ops.space_to_depth3(x)
+        if not isinstance(bn, nn.BatchNorm3d):
+            return _norm_act(ops.conv(xs, w2, conv.bias), bn, self.training)
         if self.training:
             return ops.conv_bn_act(xs, w2, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
                                    p=0.0, momentum=bn.momentum, eps=bn.eps, num_batches_tracked=bn.num_batches_tracked)
@@ -73,18 +113,28 @@ class DownsamplingConvBlock(nn.Module):
 class UpsamplingDeconvBlock(nn.Module):
     def __init__(self, n_filters_in, n_filters_out, stride=2, normalization='none'):
         super(UpsamplingDeconvBlock, self).__init__()
-        _need_bn(normalization)
-        assert stride == 2
-        self.conv = nn.Sequential(nn.ConvTranspose3d(n_filters_in, n_filters_out, stride, padding=0, stride=stride),
-                                  nn.BatchNorm3d(n_filters_out), nn.ReLU(inplace=True))
+        assert normalization in NORMS and stride == 2
+        layers = [nn.ConvTranspose3d(n_filters_in, n_filters_out, stride, padding=0, stride=stride)]
+        norm = _norm_layer(normalization, n_filters_out)
+        if norm is not None:
+            layers.append(norm)
+        layers.append(nn.ReLU(inplace=True))
+        self.conv = nn.Sequential(*layers)
+        self.has_norm = norm is not None
 
     def forward(self, x):
-        conv, bn = self.conv[0], self.conv[1]
+        conv, bn = self.conv[0], (self.conv[1] if self.has_norm else None)
         ci, co = conv.weight.shape[0], conv.weight.shape[1]
         w2 = conv.weight.permute(2, 3, 4, 1, 0).reshape(8 * co, ci, 1, 1, 1)      # [(dx,dy,dz), co][ci]
-        # training: the bias only shifts the input of the train-mode BN below -> analytically zero gradient
-        y = ops.conv(x, w2, conv.bias.repeat(8), bias_grad_zero=self.training)
+        is_bn = isinstance(bn, nn.BatchNorm3d)
+        # train-mode BatchNorm: the bias only shifts its input -> analytically zero gradient.  GroupNorm's sets span several
+        # channels (a per-channel shift survives), 'none' has no normalisation: the bias gradient is a real column sum there;
+        # InstanceNorm removes it like BatchNorm does.
+        zero_bias_grad = (self.training and is_bn) or isinstance(bn, nn.InstanceNorm3d)
+        y = ops.conv(x, w2, conv.bias.repeat(8), bias_grad_zero=zero_bias_grad)
         z = ops.depth_to_space3(y)
+        if not is_bn:
+            return _norm_act(z, bn, self.training)
         if self.training:
             return ops.bn_act(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, momentum=bn.momentum,
                               eps=bn.eps, num_batches_tracked=bn.num_batches_tracked)

@@ -857,6 +857,75 @@ def to_channels_last(x):
     return x.contiguous(memory_format=torch.channels_last_3d)
 
 
+class GnActFn(torch.autograd.Function):
+    """a = lrelu(GroupNorm(z)) / lrelu(InstanceNorm(z)): statistics per sample over sets of `cpg` consecutive channels
+    (nn.GroupNorm(16, C): cpg = C // 16; nn.InstanceNorm3d(C): cpg = 1, no affine) - the `normalization='groupnorm' |
+    'instancenorm'` variants of the V-Net blocks (vnetWithArgs.py:19-22,48-51,76-79).  Per-(sample, channel) slab sums with
+    the BatchNorm machinery (groups = samples), a set-wise finalize, the BatchNorm apply pass unchanged; backward: the
+    BatchNorm reduce + finalize, the set-wise merge of the gamma-weighted sums, the apply pass in its GroupNorm form."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, cpg, slope, eps):
+        L.require_gpu(z)
+        zr, ldz = rows_view(z)
+        nb, co = int(z.shape[0]), int(z.shape[1])
+        m = zr.shape[0]
+        sp = tuple(int(v) for v in z.shape[2:])
+        if gamma is None:                               # InstanceNorm3d default: affine=False
+            gamma = torch.ones(co, dtype=torch.float32, device=z.device)
+            beta = torch.zeros(co, dtype=torch.float32, device=z.device)
+            ctx.affine = False
+        else:
+            ctx.affine = True
+        nblk = L.query("arco_chan_stats_blocks", m // nb)
+        ssum = torch.empty((co, nb * nblk), dtype=torch.float32, device=z.device)
+        ssq = torch.empty((co, nb * nblk), dtype=torch.float32, device=z.device)
+        L.call("arco_chan_stats", L.ptr(zr), ldz, m, co, L.ptr(ssum), L.ptr(ssq), nb)
+        mean = torch.empty(nb * co, dtype=torch.float32, device=z.device)      # [N][co]
+        istd = torch.empty(nb * co, dtype=torch.float32, device=z.device)
+        L.call("arco_gn_finalize", L.ptr(ssum), L.ptr(ssq), nb * nblk, co, int(cpg), nb, m // nb, float(eps), L.ptr(mean), L.ptr(istd))
+        a = new_act_nd(nb, co, sp, z.device)
+        _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, 0, 0.0, 0, 1, a, None, nb)
+        ctx.save_for_backward(z, mean, istd, gamma, beta)
+        ctx.cfg = (int(cpg), float(slope))
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        z, mean, istd, gamma, beta = ctx.saved_tensors
+        cpg, slope = ctx.cfg
+        dar, ldd = rows_view(da)
+        zr, ldz = rows_view(z)
+        nb, co = int(z.shape[0]), int(z.shape[1])
+        m = zr.shape[0]
+        nblk = L.query("arco_chan_stats_blocks", m // nb)
+        ws = torch.empty(nb * (2 * co * nblk + 2 * co), dtype=torch.float32, device=da.device)
+        dz = new_act_nd(nb, co, tuple(int(v) for v in z.shape[2:]), da.device)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        L.call("arco_gn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
+               slope, L.ptr(ws), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dz), co, nb, cpg)
+        if not ctx.affine:
+            dgamma = dbeta = None
+        return dz, dgamma, dbeta, None, None, None
+
+
+def gn_act(z, gamma, beta, num_groups=16, slope=0.0, eps=1e-5):
+    """relu(nn.GroupNorm(num_groups, C)(z)) - vnetWithArgs.py:19-20."""
+    c = int(z.shape[1])
+    assert c % num_groups == 0, (c, num_groups)
+    return GnActFn.apply(z, gamma, beta, c // num_groups, slope, eps)
+
+
+def in_act(z, slope=0.0, eps=1e-5):
+    """relu(nn.InstanceNorm3d(C)(z)) (no affine, batch statistics always) - vnetWithArgs.py:21-22."""
+    return GnActFn.apply(z, None, None, 1, slope, eps)
+
+
+def act(z, slope=0.0):
+    """relu / leaky relu alone (`normalization='none'`)."""
+    return BnActFn.apply(z, None, None, None, None, slope, 0.0, 0, 0.1, 1e-5)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Glue that replaces chains of tensor-library launches of the step (profiles/r02_h: ~0.6 ms of fills / copies / adds)
 # ---------------------------------------------------------------------------------------------------------------------

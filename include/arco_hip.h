@@ -161,6 +161,15 @@ int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
                     const uint64_t* seed_dev /* same device salt as the forward (graph replays), or NULL */, int groups, void* stream);
 /* ---- N2/N3  nn.MaxPool2d(2) (unetWithArgs.py:55-58); nn.Upsample(bilinear, align_corners=True)
  *      (unetWithArgs.py:74-75, model_2D.py:43-52)                                                          */
+/* GroupNorm / InstanceNorm + ReLU of the V-Net blocks (vnetWithArgs.py:19-22,48-51,76-79 `normalization='groupnorm'` =
+ * nn.GroupNorm(16, C), `'instancenorm'` = nn.InstanceNorm3d(C)): statistics per sample over a set of cpg channels.
+ * Forward: arco_chan_stats(groups = N) -> arco_gn_finalize -> arco_bn_act_fwd(groups = N) (mean / istd rows [N][C]);
+ * backward: arco_gn_act_bwd (ws as for arco_bn_act_bwd with groups = N)                                                */
+int arco_gn_finalize(const float* ssum, const float* ssq, int nblk, int C, int cpg, int N, long count_per_sample_channel,
+                     float eps, float* mean, float* istd, void* stream);
+int arco_gn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
+                    const float* istd, const float* gamma, const float* beta, float slope, float* ws, float* dgamma,
+                    float* dbeta, int accumulate, float* dZ, long ldo, int N, int cpg, void* stream);
 int arco_maxpool2_fwd(const float* X, long ldx, int NB, int H, int W, int C, float* Y, long ldy, void* stream);
 /* A = lrelu(BN(Z)) (mean / istd rows [groups][C] as arco_bn_act_fwd, no dropout) and P = maxpool2(A) in one pass: the last
    stage of a ConvBlock whose output feeds the next DownBlock's nn.MaxPool2d and the decoder's skip (unetWithArgs.py:36-44,

@@ -990,9 +990,58 @@ def gen_boundary(mods):
     print("g16_boundary", len(out))
 
 
+# ---------------------------------------------------------------- G17 V-Net blocks with the other normalisations
+VNET_NORMS = ("groupnorm", "instancenorm", "none")
+
+
+def gen_vnet_norms(mods):
+    """`normalization='groupnorm' | 'instancenorm' | 'none'` of the reference's V-Net blocks (vnetWithArgs.py:5-118,145-252) -
+    not built by net_factory_3d, but what the blocks accept: ConvBlock / DownsamplingConvBlock / UpsamplingDeconvBlock with
+    outputs, input and parameter gradients; the whole V-Net at 32^3 (sub-sampled outputs / feature maps, their norms, gradient norms)."""
+    V = mods["networks.vnetWithArgs"]
+    out = {}
+    for norm in VNET_NORMS:
+        cases = (("cb", V.ConvBlock(2, 16, 32, normalization=norm), (2, 16, 8, 8, 8)),
+                 ("dw", V.DownsamplingConvBlock(16, 32, normalization=norm), (2, 16, 8, 8, 8)),
+                 ("up", V.UpsamplingDeconvBlock(32, 16, normalization=norm), (2, 32, 4, 4, 4)))
+        for tag, mod, shape in cases:
+            mod.train()
+            fx.fill_state(mod, 170 + len(tag) + len(norm))
+            x = fx.image_batch(171, shape[0], shape[1], shape[2:]).sub(0.5).mul(2.0).requires_grad_(True)
+            y = mod(x)
+            (y * probe_like(y, 6)).sum().backward()
+            t = f"{norm}_{tag}_"
+            out[t + "y"] = y.detach().numpy(); out[t + "dx"] = x.grad.numpy()
+            for n, p in mod.named_parameters():
+                out[t + "g::" + n] = p.grad.numpy()
+        net = V.VNet(n_channels=1, n_classes=2, normalization=norm, has_dropout=True)
+        net.train()
+        fx.fill_state(net, 175)
+        xv = fx.image_batch(8, 2, 1, (32, 32, 32)).requires_grad_(True)     # (InstanceNorm needs > 1 voxel at the bottleneck)
+        vo, v0, vf = net(xv, turnoff_drop=True)
+        lossv = (vo * probe_like(vo, 4)).sum()
+        for i, f in enumerate(vf):
+            lossv = lossv + (f * probe_like(f, 20 + i)).sum()
+        lossv.backward()
+        t = f"{norm}_vnet_"
+        out[t + "out_sub"] = vo.detach()[..., ::2, ::2, ::2].numpy()
+        out[t + "out_l2"] = np.array(float(vo.detach().double().pow(2).sum().sqrt()))
+        for i, f in enumerate(vf):
+            out[t + f"fmap{i}_sub"] = f.detach()[:, ::3, ::3, ::3, ::3].numpy()
+            out[t + f"fmap{i}_l2"] = np.array(float(f.detach().double().pow(2).sum().sqrt()))
+        out[t + "dx_l2"] = np.array(float(xv.grad.double().pow(2).sum().sqrt()))
+        names, gl2 = [], []
+        for n, p in net.named_parameters():
+            names.append(n); gl2.append(float(p.grad.double().pow(2).sum().sqrt()))
+        out[t + "grad_names"] = np.array(names); out[t + "grad_l2"] = np.array(gl2)
+        out[t + "n_state_keys"] = np.array(len(net.state_dict()))
+    np.savez_compressed(os.path.join(OUT, "g17_vnet_norms.npz"), **out)
+    print("g17_vnet_norms", len(out))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
@@ -1009,3 +1058,4 @@ if __name__ == "__main__":
     if "g14" in which: gen_pretrain(mods, three_d=True)
     if "g15" in which: gen_unet_kinkfree(mods)
     if "g16" in which: gen_boundary(mods)
+    if "g17" in which: gen_vnet_norms(mods)

@@ -417,3 +417,28 @@ def stage1_batch_3d(seed, it, cfg=STAGE1_CFG_3D):
     im_k = (im_q + torch.from_numpy((0.05 * rs.standard_normal((b, 1, *size))).astype(np.float32))).clamp(0, 1)
     lab = torch.from_numpy(blob_labels(rs, b, size, cfg["num_classes"]))
     return im_q, im_k, lab
+
+
+def fill_state(module, seed):
+    """Deterministic parameters for ANY module, by state_dict order and shape (both the reference module and this package's
+    twin have the same keys): conv / linear weights ~ N(0, 1/fan_in), norm weights 1 + 0.1 N, biases 0.1 N, running_var in
+    [0.5, 1.5], counters untouched.  Returns the state dict it loaded."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for k, v in module.state_dict().items():
+        shape = tuple(v.shape)
+        if not v.is_floating_point():
+            sd[k] = v.clone()
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(rs.uniform(0.5, 1.5, size=shape).astype(np.float32))
+        elif v.dim() >= 2:
+            fan = 1
+            for d in shape[1:]:
+                fan *= d
+            sd[k] = torch.from_numpy((rs.standard_normal(shape) / np.sqrt(fan)).astype(np.float32))
+        elif k.endswith("weight"):
+            sd[k] = torch.from_numpy((1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32))
+        else:
+            sd[k] = torch.from_numpy((0.1 * rs.standard_normal(shape)).astype(np.float32))
+    module.load_state_dict(sd, strict=True)
+    return sd
