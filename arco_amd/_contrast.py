@@ -40,6 +40,8 @@ count_gather_hook = None
 # callable(keys[n,D], cls, queue_size) -> only the rows that survive the FIFO truncation (rank order)
 tail_gather_hook = None
 tail_gather_all_hook = None  # the same for all classes at once: (list of key rows per class, queue sizes) -> list (one broadcast per rank)
+totals_gather_hook = None    # data parallel: device [3C] counters -> device [world, 3C] (dist.gather_totals_device), queued before the host sync
+count_table_hook = None      # data parallel: host table [world][C] of new-key counts -> sums over ranks (dist.set_rank_counts)
 proto_reduce_hook = None     # data parallel: (proto [C, D], counts [C]) -> count-weighted mean over ranks (dist.reduce_prototypes)
 
 
@@ -177,6 +179,11 @@ def contrast_masks(label_l, label_u, prob_l, prob_u, low_mask, high_mask, delta_
            L.ptr(pl.offsets), L.ptr(pl.totals))
     pl.totals_host = torch.empty(3 * C, dtype=torch.int64).pin_memory()
     pl.totals_host.copy_(pl.totals, non_blocking=True)
+    pl.all_totals_host = None
+    if totals_gather_hook is not None:        # every rank's counters, gathered on the device and copied with the local ones
+        allt = totals_gather_hook(pl.totals)
+        pl.all_totals_host = torch.empty(tuple(allt.shape), dtype=torch.int64).pin_memory()
+        pl.all_totals_host.copy_(allt, non_blocking=True)
     pl.ready = torch.cuda.Event()
     pl.ready.record()
     pl.C, pl.P, pl.n_pix, pl.dev = C, P, n_pix, dev
@@ -226,7 +233,10 @@ def contrast_counts(pl, memobank, queue_size, num_queries=256, num_negatives=512
     C = pl.C
     tot = pl.totals_host.tolist()
     pl.n_lv, pl.n_anchor, pl.n_neg = tot[:C], tot[C:2 * C], tot[2 * C:]
-    n_neg_all = pl.n_neg if count_gather_hook is None else count_gather_hook(pl.n_neg)
+    if getattr(pl, "all_totals_host", None) is not None and count_table_hook is not None:
+        n_neg_all = count_table_hook([row[2 * C:] for row in pl.all_totals_host.tolist()])      # no collective here
+    else:
+        n_neg_all = pl.n_neg if count_gather_hook is None else count_gather_hook(pl.n_neg)
     pl.n_neg_all = n_neg_all
     # bank lengths after this step's enqueue (loss_helper_3d.py:23-26)
     pl.bank_len = [min(int(memobank[c][0].shape[0]) + int(n_neg_all[c]), int(queue_size[c])) for c in range(C)]

@@ -52,6 +52,8 @@ def init(backend=None):
         _contrast.tail_gather_hook = gather_tail_keys
         _contrast.tail_gather_all_hook = gather_tail_keys_all
         _contrast.proto_reduce_hook = reduce_prototypes
+        _contrast.totals_gather_hook = gather_totals_device
+        _contrast.count_table_hook = set_rank_counts
         from . import glue
         glue.state_reduce_hook = allreduce_sum
         return td.get_rank(), td.get_world_size()
@@ -110,12 +112,54 @@ def broadcast_module_states(modules, src=0):
             td.broadcast(t.data, src)
 
 
+_pending_buckets = []     # [(Work, start element)] of gradient buckets whose all-reduce is already in flight
+
+
+def allreduce_bucket_async(optimizer, start):
+    """Start the all-reduce of the flat gradient buffer's tail [start:] (the q_representation / FeatureExtractor
+    parameters: their gradients are final once the head's backward is queued, before the U-Net's backward has run) -
+    it overlaps the U-Net backward; allreduce_grads then reduces the rest and waits for this one."""
+    if not is_dist():
+        return
+    _pending_buckets.append((td.all_reduce(optimizer.flat_g[start:], op=td.ReduceOp.SUM, async_op=True), int(start)))
+
+
+class _GradsReadyFn(torch.autograd.Function):
+    """Identity on the feature maps that enter the heads; its backward runs when every gradient that flows back through
+    the heads has been produced - the moment the heads' parameter gradients are complete."""
+
+    @staticmethod
+    def forward(ctx, opt_start, *maps):
+        ctx.opt_start = opt_start
+        return maps
+
+    @staticmethod
+    def backward(ctx, *grads):
+        opt, start = ctx.opt_start
+        allreduce_bucket_async(opt, start)
+        return (None,) + grads
+
+
+def mark_heads_done(maps, optimizer, start):
+    """Data parallel: wrap the feature maps the heads consume; the heads' gradient bucket (flat_g[start:]) is all-reduced
+    asynchronously as soon as their backward is done (two buckets, decoder-side first: SURVEY 8e item 1).  Identity
+    when not distributed."""
+    if not is_dist() or start <= 0 or start >= optimizer.flat_g.numel():
+        return maps
+    return list(_GradsReadyFn.apply((optimizer, int(start)), *maps))
+
+
 def allreduce_grads(optimizer):
-    """Mean of the flat gradient buffer over ranks - one RCCL all-reduce."""
+    """Mean of the flat gradient buffer over ranks: one RCCL all-reduce, or two when the heads' bucket is already in
+    flight (allreduce_bucket_async) - the rest is reduced here and both are awaited (stream-ordered, no host wait)."""
     if not is_dist():
         return
     g = optimizer.flat_g
-    td.all_reduce(g, op=td.ReduceOp.SUM)
+    split = min((st for _, st in _pending_buckets), default=g.numel())
+    td.all_reduce(g[:split], op=td.ReduceOp.SUM)
+    for work, _ in _pending_buckets:
+        work.wait()
+    _pending_buckets.clear()
     g.mul_(1.0 / td.get_world_size())
     optimizer._touched.update(range(len(optimizer.params)))
 
@@ -158,7 +202,33 @@ def gather_keys(keys):
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
-_rank_counts = None      # [world][C] local key counts of the current step (set by gather_counts)
+_rank_counts = None      # [world][C] local key counts of the current step (set by gather_counts / set_rank_counts)
+
+
+@torch.no_grad()
+def gather_totals_device(totals):
+    """All-gather of the step's per-class counter vector ON THE DEVICE, queued right behind the kernel that produced it
+    (_contrast.contrast_masks): [3C] int64 -> [world, 3C].  The gathered table then rides on the SAME asynchronous
+    device->host copy / event the local counters already use, so the host learns every rank's counts at its one sync
+    point - no second rendezvous + `.tolist()` after it (gather_counts, the host-side form, stays for callers that
+    hold their counts on the host)."""
+    world = td.get_world_size()
+    out = torch.empty((world, totals.numel()), dtype=totals.dtype, device=totals.device)
+    if totals.is_cuda and td.get_backend() != "nccl":            # single-GPU rehearsal over gloo: through the host
+        t = totals.cpu()
+        o = torch.empty((world, t.numel()), dtype=t.dtype)
+        td.all_gather_into_tensor(o.view(-1), t.contiguous())
+        out.copy_(o)
+        return out
+    td.all_gather_into_tensor(out.view(-1), totals.contiguous())
+    return out
+
+
+def set_rank_counts(table):
+    """table[r][c] = rank r's new-key count of class c (from the device-gathered counters); returns the sums over ranks."""
+    global _rank_counts
+    _rank_counts = [[int(v) for v in row] for row in table]
+    return [sum(r[c] for r in _rank_counts) for c in range(len(_rank_counts[0]))]
 
 
 def gather_counts(counts):

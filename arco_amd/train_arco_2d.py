@@ -188,6 +188,7 @@ class ArcoStep2D:
         params = [p for p in self.model.parameters() if p.requires_grad]
         params_rep = [p for p in self.q_representation.parameters() if p.requires_grad]
         params_fea = [p for p in self.q_feature_extractor.parameters() if p.requires_grad]
+        self.heads_start = sum(p.numel() for p in params)     # flat_g[heads_start:] = the heads' gradient bucket (dist.mark_heads_done)
         self.optimizer = optim.SGDNesterov(params + params_rep + params_fea, lr=args.base_lr, weight_decay=0.0001,
                                            momentum=0.9, nesterov=True)
         with torch.no_grad():                                            # :250-253
@@ -335,6 +336,8 @@ class ArcoStep2D:
                 lazy_t = head.LazyTeacher2DL2(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
         if not batched:
             fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]     # :317-318
+        # data parallel: the heads' gradient bucket is all-reduced as soon as the heads' backward is done, under the U-Net's
+        fm_all = adist.mark_heads_done(fm_all, self.optimizer, self.heads_start)
         if dense:
             rep_all = self.q_rep(self.q_feature_extractor(fm_all))       # :324-325,330
         elif getattr(a, "head_levels", 3) == 1:

@@ -76,6 +76,7 @@ class ArcoStep3D:
         params = [p for p in self.model.parameters() if p.requires_grad]
         params_rep = [p for p in self.q_representation.parameters() if p.requires_grad]
         params_fea = [p for p in self.q_feature_extractor.parameters() if p.requires_grad]
+        self.heads_start = sum(p.numel() for p in params)     # flat_g[heads_start:] = the heads' gradient bucket (dist.mark_heads_done)
         self.optimizer = optim.SGDNesterov(params + params_rep + params_fea, lr=args.base_lr, weight_decay=0.0001,
                                            momentum=0.9, nesterov=True)
         with torch.no_grad():
@@ -170,6 +171,7 @@ class ArcoStep3D:
                 rep_all_teacher, lazy_t = kfe(fm_t), None
             else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys per class
                 rep_all_teacher, lazy_t = None, head.LazyTeacher3D(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
+        fm_s = adist.mark_heads_done(fm_s, self.optimizer, self.heads_start)     # data parallel: heads' gradient bucket reduced early
         if dense:
             rep_all = self.q_rep(qfe(fm_s))                              # :289-296,301
         else:

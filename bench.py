@@ -177,7 +177,18 @@ def roofline_from_profile(prof, n_steps, step_ms):
         head = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
     head.update({"flop_per_algorithmic_byte": round(intensity, 1), "machine_balance_flop_per_byte": round(balance, 1),
                  "avg_algorithmic_bytes_per_launch": avg_bytes})
-    roof = {**head, "traffic": PMC_TRAFFIC_BYTES.get((taps, m, n, k)) if k_mma == 0 else PMC_TRAFFIC_SPLIT.get((taps, m, n, k)),
+    # HBM bytes per launch from the PMC passes (profiles/*_traffic.md), averaged over the SAME timed launches as `achieved`
+    # (a launch class without a PMC row counts with the mean measured ratio of the classes that have one)
+    table = PMC_TRAFFIC_BYTES if k_mma == 0 else PMC_TRAFFIC_SPLIT
+    known = [(table[shp], conv_algorithmic_bytes(*shp, k_mma)) for _, _, _, shp in launches if shp in table]
+    traffic = ratio = by_shape = None
+    if known:
+        mean_ratio = sum(t for t, _ in known) / sum(a_ for _, a_ in known)
+        traffic = sum(table.get(shp, conv_algorithmic_bytes(*shp, k_mma) * mean_ratio) for _, _, _, shp in launches) / len(launches)
+        ratio = round(traffic / avg_bytes, 4)
+        by_shape = {f"{shp[0]}x{shp[1]}x{shp[2]}x{shp[3]}": round(table[shp] / conv_algorithmic_bytes(*shp, k_mma), 4)
+                    for shp in sorted({l_[3] for l_ in launches}) if shp in table}
+    roof = {**head, "traffic": traffic, "traffic_over_algorithmic": ratio, "traffic_over_algorithmic_by_shape": by_shape,
             "peak_note": {0: "fp32 MFMA peak", 3: "dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32-accurate product); the native fp32 MFMA peak is 157.3"}.get(k_mma, "dense f16/bf16 MFMA peak"),
             "kernel": _kernel_name(cfg), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(rec["n"] / n_steps, 1),
             "launches_timed": len(launches), "avg_flop_per_launch": avg_flop,
@@ -479,6 +490,8 @@ def main():
             out["whole_step"] = whole
         if sustained is not None:
             out["sustained"] = sustained
+            out["sustained_ms_per_step"] = sustained["ms_per_step"]        # flat copies beside value / ms_per_step: the rate the
+            out["sustained_steps_per_s"] = sustained["steps_per_s"]        # chip holds after >= 3 s of load (clock-settled)
         if k2_0 is not None:
             out["north_star_path_only_k2_0"] = k2_0
         if world == 1 and not a.no_subs:

@@ -92,8 +92,97 @@ def _worker(rank, world, port, q):
         batched = adist.gather_tail_keys_all(mine, [qs] * len(table))
         assert all(torch.equal(a, b) for a, b in zip(per_class, batched)), (rank, qs, table)
     assert _contrast.tail_gather_all_hook is adist.gather_tail_keys_all
+    # 8. counters gathered as a device table (no host-side collective): [3C] -> [world, 3C]; the per-rank key-count table
+    #    set from it gives the same sums / tail exchange as the host-side gather_counts
+    C3 = torch.tensor([rank, 5 * rank + 1, 0, 11, 7 * rank, 2, 3 + rank, 0, 9 * rank], dtype=torch.int64)      # C = 3: [n_lv | n_anchor | n_neg]
+    tab = adist.gather_totals_device(C3)
+    assert tuple(tab.shape) == (world, 9) and all(torch.equal(tab[rr], torch.tensor([rr, 5 * rr + 1, 0, 11, 7 * rr, 2, 3 + rr, 0, 9 * rr])) for rr in range(world))
+    sums = adist.set_rank_counts([row[6:] for row in tab.tolist()])
+    assert sums == [sum(3 + rr for rr in range(world)), 0, sum(9 * rr for rr in range(world))]
+    assert sums == adist.gather_counts([3 + rank, 0, 9 * rank])
+    assert _contrast.totals_gather_hook is adist.gather_totals_device and _contrast.count_table_hook is adist.set_rank_counts
+    # 9. two gradient buckets: the heads' tail is all-reduced from inside the backward (mark_heads_done), the rest in
+    #    allreduce_grads; the result is the plain mean
+    class Opt2:
+        pass
+    o2 = Opt2()
+    o2.flat_g = torch.zeros(20)
+    o2.params = [0, 1]
+    o2._touched = set()
+    x = torch.ones(3, requires_grad=True)
+    (m0,) = adist.mark_heads_done([x * 2.0], o2, 12)
+    o2.flat_g[:12] = float(rank + 1); o2.flat_g[12:] = float(10 * (rank + 1))       # "gradients" present before the backward reaches the marker
+    m0.sum().backward()
+    assert len(adist._pending_buckets) == 1 and torch.equal(x.grad, torch.full((3,), 2.0))
+    adist.allreduce_grads(o2)
+    mean = sum(rr + 1 for rr in range(world)) / world
+    assert torch.allclose(o2.flat_g[:12], torch.full((12,), mean)) and torch.allclose(o2.flat_g[12:], torch.full((8,), 10 * mean))
+    assert adist._pending_buckets == []
+    # 10. anchors per rank: the split covers num_queries exactly, the loss weights average to one
+    for Q in (256, 50, 7):
+        if Q >= world:
+            q_r = adist.anchors_for_rank(Q, "split")
+            t = torch.tensor([float(q_r), adist.anchor_weight(Q, "split")], dtype=torch.float64)
+            td.all_reduce(t)
+            assert int(t[0]) == Q and abs(float(t[1]) / world - 1.0) < 1e-12
+    if world > 2:
+        try:
+            adist.anchors_for_rank(world - 1, "split")
+            raise AssertionError("expected a ValueError")
+        except ValueError:
+            pass
     td.barrier()
     q.put((rank, "ok"))
+
+
+def _worker4(rank, world, port, q):
+    """world 4, ragged / empty ranks: key all-gather-v, the all-classes tail exchange through the FIFO truncation, the
+    device counter table, Q = 50 anchors split 13 / 13 / 12 / 12."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as td
+    from arco_amd import dist as adist
+    adist.init(backend="gloo")
+    D = 4
+    for qs, table in ((8, [[20, 0, 3, 1], [0, 0, 0, 5], [2, 3, 0, 0], [0, 0, 0, 0]]), (5, [[5, 5, 5, 5], [0, 9, 0, 1], [1, 0, 0, 0], [3, 3, 3, 3]]),
+                      (16, [[1, 2, 3, 4], [0, 0, 7, 0], [16, 0, 0, 1], [40, 1, 0, 0]])):
+        counts = [t[rank] for t in table]
+        tab = adist.gather_totals_device(torch.tensor([0] * 8 + counts, dtype=torch.int64))        # C = 4: n_neg is the last third
+        assert adist.set_rank_counts([row[8:] for row in tab.tolist()]) == [sum(t) for t in table]
+        mine = [(torch.arange(n * D, dtype=torch.float32).view(n, D) + 1000 * rank + 100 * c)[max(0, n - qs):] for c, n in enumerate(counts)]
+        batched = adist.gather_tail_keys_all(mine, [qs] * len(table))
+        for c, got in enumerate(batched):
+            ref = adist.gather_keys(mine[c])                                                       # all-gather-v, rank order
+            old_bank = torch.full((3, D), -1.0)
+            assert torch.equal(torch.cat((old_bank, got))[-qs:], torch.cat((old_bank, ref))[-qs:]), (rank, qs, c)
+    assert adist.anchors_for_rank(50, "split") == (13 if rank < 2 else 12)
+    w = torch.tensor([adist.anchor_weight(50, "split")], dtype=torch.float64)
+    td.all_reduce(w)
+    assert abs(float(w) / world - 1.0) < 1e-12
+    try:
+        adist.anchors_for_rank(3, "split")
+        raise AssertionError("expected a ValueError")
+    except ValueError:
+        pass
+    td.barrier()
+    q.put((rank, "ok"))
+
+
+def _run(world, target):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(r, "ok") for r in range(world)]
+
+
+def test_world4_gloo_ragged_ranks():
+    _run(4, _worker4)
 
 
 def test_world2_gloo():
