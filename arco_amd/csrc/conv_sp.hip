@@ -59,11 +59,7 @@ __device__ __forceinline__ float row16_sum(float v) {    // sum over the 16 lane
 // runs out, and shuttles every accumulator through a scratch AGPR quad around each MFMA chain (4 v_accvgpr_write + hazard
 // nops per chain).  The s_nop covers an operand a VALU instruction has just written (hipcc pads nothing inside asm).
 __device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& x, const bf16x8& y) {
-#ifdef ARCO_EXP_NONOP
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(x), "v"(y));
-#else
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(x), "v"(y));
-#endif
 }
 
 __device__ __forceinline__ void mfma_first(f32x4& c, const bf16x8& x, const bf16x8& y) {     // c = x . y (a tile's first product)
@@ -121,14 +117,22 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     Desc d2 = d1; advance(d2);
     Desc d3 = d2; advance(d3);
     const int qA = tid & 3;
-    int hyA[NA], hxA[NA], ldsA[NA], toff[NA];
+    // per-thread geometry of the NA activation pieces, fixed for the launch (see conv3x3_rw_kernel): LDS offset, byte offset
+    // from the halo origin, masks of the pieces on the tile's top / bottom halo row and left / right halo column
+    int ldsA[NA]; unsigned voff[NA];
+    unsigned m_valid = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int row = (tid + it * 256) >> 2;
-      hyA[it] = row / 18; hxA[it] = row - hyA[it] * 18;
-      ldsA[it] = row < G::AROWS ? row * 24 + qA * 2 : -1;
-      toff[it] = (hyA[it] * a.W + hxA[it]) * (int)a.lda + qA * 4;
+      const int hy = row / 18, hx = row - hy * 18;
+      const bool valid = row < G::AROWS;
+      ldsA[it] = valid ? row * 24 + qA * 2 : -1;
+      voff[it] = valid ? (unsigned)(((hy * a.W + hx) * (int)a.lda + qA * 4) * 4) : 0u;
+      m_valid |= valid ? (1u << it) : 0u;
+      m_top |= (valid && hy == 0) ? (1u << it) : 0u; m_bot |= (valid && hy == TH + 1) ? (1u << it) : 0u;
+      m_left |= (valid && hx == 0) ? (1u << it) : 0u; m_right |= (valid && hx == 17) ? (1u << it) : 0u;
     }
+    const unsigned safe_off = (unsigned)(((a.W + 1) * (int)a.lda + qA * 4) * 4);      // the tile's first pixel: always inside the tensor
     int woff[NB], wq[NB], wtap[NB];               // weight piece of LDS-DMA instruction i: dword offset, piece of the row, local tap (2 = padding)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -149,19 +153,26 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     // a chunk lasts ~2 us, less than an HBM miss under load.
     f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
     auto load_A = [&](const Desc& d, bool real, int set) {
-      const long base = (((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16;
-      const float* pa[NA];
-      unsigned okm = 0;
-#pragma unroll
-      for (int it = 0; it < NA; ++it) {
-        const int y = d.y0 + hyA[it] - 1, x = d.x0 + hxA[it] - 1;
-        const bool ok = real && ldsA[it] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-        pa[it] = ok ? a.A + base + toff[it] : a.A;
-        okm |= ok ? (1u << it) : 0u;
-      }
+      // scalar base of the halo origin + the per-piece byte offsets: a tile costs a few scalar instructions and one mask
+      // expression, not ~20 VALU instructions per piece; out-of-image pieces load the tile's first pixel and are zeroed at
+      // the split; a descriptor past the last chunk (real == false: dummy loads that keep the vmcnt counts exact) may name
+      // a tile outside the tensor and loads the tensor's first pixels
+      const float* gbase = real ? a.A + ((((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16) : a.A;
+      unsigned bad = (d.y0 == 0 ? m_top : 0u) | (d.y0 + TH == a.H ? m_bot : 0u) | (d.x0 == 0 ? m_left : 0u) | (d.x0 + 16 == a.W ? m_right : 0u);
+      if (!real) bad = ~0u;
+      const unsigned okm = m_valid & ~bad;
       okm2[set] = okm;
+      const bool border = !real || d.y0 == 0 || d.y0 + TH == a.H || d.x0 == 0 || d.x0 + 16 == a.W;     // wave-uniform: NA loads per wave either way
+      if (!border) {
 #pragma unroll
-      for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set][it]) : "v"(pa[it]) : "memory");
+        for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(voff[it]), "s"(gbase) : "memory");
+      } else {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+          const unsigned o = ((okm >> it) & 1u) ? voff[it] : safe_off;
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(o), "s"(gbase) : "memory");
+        }
+      }
     };
     auto ra_fence = [&](int set) {
 #pragma unroll
@@ -239,9 +250,6 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
   }
 
   // ================================================================== consumer waves
-#ifdef ARCO_EXP_PRIO
-  __builtin_amdgcn_s_setprio(ARCO_EXP_PRIO);
-#endif
   // fragment addressing: lanes g = 0,1 take tap 2s, g = 2,3 tap 2s+1 (step 4: tap 8 and the zero tap)
   const int tl = g >> 1;
   int aoff[5];
@@ -447,36 +455,55 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
     Desc d2 = d1; advance(d2);
     Desc d3 = d2; advance(d3);
     const int qA = tid & 3;
-    int hyA[NA], hxA[NA], ldsA[NA], toff[NA];
+    // Per-thread geometry of the NA activation pieces, fixed for the whole launch: LDS offset, byte offset from the halo
+    // origin (pixel (y0 - 1, x0 - 1), channel 16 c + 4 qA), and bit masks over the pieces that fall on the tile's top /
+    // bottom halo row and left / right halo column.  A tile then costs a handful of scalar instructions (base address, which
+    // image borders it touches) and ONE mask expression - no per-piece coordinate arithmetic (round 2: ~20 VALU instructions
+    // per piece, 2300 cycles per tile next to the MFMA waves of the same SIMDs).
+    int ldsA[NA]; unsigned voff[NA];
+    unsigned m_valid = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int row = (tid + it * 256) >> 2;
-      hyA[it] = row / 18; hxA[it] = row - hyA[it] * 18;
-      ldsA[it] = row < G::AROWS ? row * 24 + qA * 2 : -1;
-      toff[it] = (hyA[it] * a.W + hxA[it]) * (int)a.lda + qA * 4;
+      const int hy = row / 18, hx = row - hy * 18;
+      const bool valid = row < G::AROWS;
+      ldsA[it] = valid ? row * 24 + qA * 2 : -1;
+      voff[it] = valid ? (unsigned)(((hy * a.W + hx) * (int)a.lda + qA * 4) * 4) : 0u;
+      m_valid |= valid ? (1u << it) : 0u;
+      m_top |= (valid && hy == 0) ? (1u << it) : 0u; m_bot |= (valid && hy == TH + 1) ? (1u << it) : 0u;
+      m_left |= (valid && hx == 0) ? (1u << it) : 0u; m_right |= (valid && hx == 17) ? (1u << it) : 0u;
     }
+    const unsigned safe_off = (unsigned)(((a.W + 1) * (int)a.lda + qA * 4) * 4);      // the tile's first pixel: always inside the tensor
     f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
     auto load_A = [&](const Desc& d, bool real, int set) {
-      const long base = (((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16;
-      const float* pa[NA];
-      unsigned okm = 0;
+      // (scalar) base of the halo origin; out-of-image pieces load the tile's first pixel instead and are zeroed at the split
+      // (a descriptor past the workgroup's last chunk - real == false, the loads are dummies that keep the vmcnt counts
+      //  exact - may name a tile outside the tensor: those load the tensor's first pixels)
+      const float* gbase = real ? a.A + ((((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16) : a.A;
+      unsigned bad = (d.y0 == 0 ? m_top : 0u) | (d.y0 + TH == a.H ? m_bot : 0u) | (d.x0 == 0 ? m_left : 0u) | (d.x0 + 16 == a.W ? m_right : 0u);
+      if (!real || d.c * 16 + qA * 4 >= a.K) bad = ~0u;
+      okm2[set] = m_valid & ~bad;
+      // WAVE-UNIFORM choice (every wave must issue exactly NA load instructions: the vmcnt waits count them)
+      const bool border = !real || d.y0 == 0 || d.y0 + TH == a.H || d.x0 == 0 || d.x0 + 16 == a.W || d.c * 16 + 16 > a.K;
+      if (!border) {
 #pragma unroll
-      for (int it = 0; it < NA; ++it) {
-        const int y = d.y0 + hyA[it] - 1, x = d.x0 + hxA[it] - 1;
-        const bool ok = real && ldsA[it] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W && d.c * 16 + qA * 4 < a.K;
-        pa[it] = ok ? a.A + base + toff[it] : a.A;
-        okm |= ok ? (1u << it) : 0u;
+        for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(voff[it]), "s"(gbase) : "memory");
+      } else {
+        const unsigned okm = okm2[set];
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+          const unsigned o = ((okm >> it) & 1u) ? voff[it] : safe_off;
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(o), "s"(gbase) : "memory");
+        }
       }
-      okm2[set] = okm;
-#pragma unroll
-      for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[set][it]) : "v"(pa[it]) : "memory");
     };
     auto store_all = [&](unsigned* buf, int set) {
 #pragma unroll
       for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[set][it])::"memory");
+      const unsigned okm = okm2[set];
 #pragma unroll
       for (int it = 0; it < NA; ++it) {
-        const f32x4 v = ((okm2[set] >> it) & 1u) ? ra[set][it] : f32x4{0, 0, 0, 0};
+        const f32x4 v = ((okm >> it) & 1u) ? ra[set][it] : f32x4{0, 0, 0, 0};
         u32x2 p0, p1, p2;
         split3_bf16x4(v, p0, p1, p2);
         if (ldsA[it] >= 0) {
@@ -485,16 +512,19 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
         }
       }
     };
-    // chunk 0 -> buffer 0, chunk 1 -> buffer 1 (both before the first barrier), chunks 2 and 3 in flight
+    // Prologue: chunks 0 and 1 are requested together, but the consumers are released as soon as chunk 0 is staged
+    // (round 2 staged both first: two splits and a second burst of loads in front of the first MFMA, ~4 us of a 40 us launch);
+    // chunk 1 is split into buffer 1 while the consumers run steps 0-3 of chunk 0 - exactly what every later chunk does.
     load_A(d0, true, 0);
     load_A(d1, total_gc > 1, 1);
-    wait_vm<0>();                      // (the weight DMA too)
+    wait_vm<NA>();                     // chunk 0 and, older in the queue, the weight DMA (only chunk 1's loads are younger)
     store_all(As, 0);
-    store_all(As + G::A_DW, 1);
     load_A(d2, total_gc > 2, 0);
-    load_A(d3, total_gc > 3, 1);
     wait_lgkm0();
-    __builtin_amdgcn_s_barrier();      // B0: weights, bias, buffers 0 and 1
+    __builtin_amdgcn_s_barrier();      // B0: weights, bias, buffer 0
+    wait_vm<NA>();                     // chunk 1 (only chunk 2's loads are younger)
+    store_all(As + G::A_DW, 1);
+    load_A(d3, total_gc > 3, 1);
     // barrier k (k = 0 .. total_gc - 1; the consumer passes it at the head of step 4 of chunk k): buffer k & 1 is free,
     // buffer (k + 1) & 1 is complete.  Behind it: chunk k + 2 -> buffer k & 1, then the loads of chunk k + 4.
     Desc dn = d3; advance(dn);         // chunk k + 4
@@ -519,9 +549,6 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
   }
 
   // ================================================================== consumer waves
-#ifdef ARCO_EXP_PRIO
-  __builtin_amdgcn_s_setprio(ARCO_EXP_PRIO);
-#endif
   const int tl = g >> 1;
   int aoff[5];
 #pragma unroll

@@ -911,7 +911,15 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
       if (tiles64 < 192 && a.stat_groups <= 1) return launch_igemm<1, 32, 64, 2, 2, 32, true>(a, st, nmb);
       return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
     }
-    if ((a.Npad + 223) / 224 * 224 < (a.Npad + 127) / 128 * 128) return launch_igemm<1, 64, 224, 2, 2, 32, false>(a, st, nmb);
+    if ((a.Npad + 223) / 224 * 224 < (a.Npad + 127) / 128 * 128) {
+      // N = 448 / 192 / 224 ...: 224-wide tiles pad N least, but the 64 x 224 split tile is single-buffered (50 KB of B
+      // planes per chunk); A/B knob ARCO_GEMM224: 0 = 64 x 224 (round 2), 1 = 64 x 64, 2 = 128 x 64, 3 = 128 x 128
+      static const int g224 = getenv("ARCO_GEMM224") ? atoi(getenv("ARCO_GEMM224")) : 0;
+      if (g224 == 1 && (a.Npad & 63) == 0) return launch_igemm<1, 64, 64, 2, 2, 32, true>(a, st, nmb);
+      if (g224 == 2 && (a.Npad & 63) == 0) return launch_igemm<1, 128, 64, 2, 2, 32, true>(a, st, nmb);
+      if (g224 == 3) return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
+      return launch_igemm<1, 64, 224, 2, 2, 32, false>(a, st, nmb);
+    }
     return launch_igemm<1, 128, 128, 2, 2, 32, true>(a, st, nmb);
   }
   if (taps == 1) {
