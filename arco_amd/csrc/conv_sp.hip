@@ -40,6 +40,13 @@ struct SpGeom {
   static constexpr size_t LDS_BYTES = (size_t)(2 * A_DW + 5 * SLOT_DW + BIAS_DW) * 4;
 };
 
+// a wave-uniform pointer moved into SGPRs (v_readfirstlane): the scalar-base operand of a global load must not sit in VGPRs,
+// where the register allocator may leave a value it knows to be uniform (seen under register pressure: "invalid operand")
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // lgkmcnt(0) through the builtin: hipcc models the instruction, so it knows the fragment registers read in the previous
 // step have landed (after an asm wait it re-waits lgkmcnt(0) in front of the first MFMA, behind 24 fresh reads)
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
       // expression, not ~20 VALU instructions per piece; out-of-image pieces load the tile's first pixel and are zeroed at
       // the split; a descriptor past the last chunk (real == false: dummy loads that keep the vmcnt counts exact) may name
       // a tile outside the tensor and loads the tensor's first pixels
-      const float* gbase = real ? a.A + ((((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16) : a.A;
+      const float* gbase = uniform_ptr(real ? a.A + ((((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16) : a.A);
       unsigned bad = (d.y0 == 0 ? m_top : 0u) | (d.y0 + TH == a.H ? m_bot : 0u) | (d.x0 == 0 ? m_left : 0u) | (d.x0 + 16 == a.W ? m_right : 0u);
       if (!real) bad = ~0u;
       const unsigned okm = m_valid & ~bad;
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
       // (scalar) base of the halo origin; out-of-image pieces load the tile's first pixel instead and are zeroed at the split
       // (a descriptor past the workgroup's last chunk - real == false, the loads are dummies that keep the vmcnt counts
       //  exact - may name a tile outside the tensor: those load the tensor's first pixels)
-      const float* gbase = real ? a.A + ((((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16) : a.A;
+      const float* gbase = uniform_ptr(real ? a.A + ((((long)d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.lda + d.c * 16) : a.A);
       unsigned bad = (d.y0 == 0 ? m_top : 0u) | (d.y0 + TH == a.H ? m_bot : 0u) | (d.x0 == 0 ? m_left : 0u) | (d.x0 + 16 == a.W ? m_right : 0u);
       if (!real || d.c * 16 + qA * 4 >= a.K) bad = ~0u;
       okm2[set] = m_valid & ~bad;
