@@ -1910,7 +1910,13 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   if (taps >= 9) {       // spatial kernels: all taps of a plane per block, operands staged once (halo in LDS)
     const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
     a.CoutPad = (Cout + hco - 1) / hco * hco; a.CinPad = (Cin + hci - 1) / hci * hci;
-    const bool flat = (W & 15) != 0 && W + 2 <= IGEMM_FLAT_WPMAX;     // narrow planes: flat-position tiles
+    // narrow planes (W not a multiple of 16): flat-position tiles for the fp32 / reduced-precision kernels.  In split-bf16 mode
+    // the rectangular 8 x 16 tiles of wgrad_split_kernel are taken instead, ragged last column of tiles and all (W = 40: 17 %
+    // of the MFMA rows idle, W = 20 / 10: 37 %) - six bf16 MFMAs per 32 pixels still beat eight fp32 MFMAs per 16 by more than
+    // that (A/B knob ARCO_WGRAD_FLAT_SPLIT=0: round 2's choice, the fp32 flat-tile kernel)
+    static const int flat_split = getenv("ARCO_WGRAD_FLAT_SPLIT") ? atoi(getenv("ARCO_WGRAD_FLAT_SPLIT")) : 1;
+    const bool split_ok = a.mma == 3 && (Cout & 3) == 0 && (Cin & 3) == 0 && (ld_dz & 3) == 0 && (ld_in & 3) == 0;
+    const bool flat = (W & 15) != 0 && W + 2 <= IGEMM_FLAT_WPMAX && !(split_ok && flat_split && W >= 10);
     if (flat) a.n_tiles = NB * ((H * (W + 2) + 127) / 128);
     const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
     // 32x32 blocks run persistent (2 workgroups per CU, several tiles each); the others one slab per ~tile

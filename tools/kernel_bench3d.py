@@ -20,6 +20,7 @@ def run(nv, ci, co, sp):
     fl = 2.0 * nv * sp[0] * sp[1] * sp[2] * ci * co * 27
     with torch.no_grad():
         ms = timeit(lambda: ops.conv(x, wt, None))
+    ops.CONV_MMA = int(os.environ.get("MMA", ops.CONV_MMA))
     y = ops.conv(xg, wt, None)
     gy = torch.randn_like(y)
     def bwd():
