@@ -63,8 +63,10 @@ l_dp = loss_r.detach().clone()
 td.all_reduce(l_dp); l_dp /= world
 every = [None] * world
 td.all_gather_object(every, dict(inp={k: v.cpu() for k, v in inp.items()}, traces=traces))
-hooks = (C_.key_gather_hook, C_.count_gather_hook, C_.tail_gather_hook, C_.proto_reduce_hook, C_.tail_gather_all_hook)
+hooks = (C_.key_gather_hook, C_.count_gather_hook, C_.tail_gather_hook, C_.proto_reduce_hook, C_.tail_gather_all_hook,
+         C_.totals_gather_hook, C_.count_table_hook)
 C_.key_gather_hook = C_.count_gather_hook = C_.tail_gather_hook = C_.proto_reduce_hook = C_.tail_gather_all_hook = None     # single-process semantics
+C_.totals_gather_hook = C_.count_table_hook = None
 try:
     halves = lambda key: torch.cat([e["inp"][key][:Bn_] for e in every] + [e["inp"][key][Bn_:] for e in every]).to(dev)
     cat = lambda key: torch.cat([e["inp"][key] for e in every]).to(dev)
@@ -86,7 +88,8 @@ try:
         C_.contrast_anchor_pix(pl1)
         l_single, _ = C_.contrast_infonce(pl1, C_.GatherRowsFn.apply(rep_all, pl1.anchor_pix), bank1)
 finally:
-    C_.key_gather_hook, C_.count_gather_hook, C_.tail_gather_hook, C_.proto_reduce_hook, C_.tail_gather_all_hook = hooks
+    (C_.key_gather_hook, C_.count_gather_hook, C_.tail_gather_hook, C_.proto_reduce_hook, C_.tail_gather_all_hook,
+     C_.totals_gather_hook, C_.count_table_hook) = hooks
 assert abs(float(l_single) - float(l_dp)) < 1e-5 * max(1.0, abs(float(l_single))), (float(l_single), float(l_dp))
 for c in range(Cn):
     assert torch.equal(bank[c][0], bank1[c][0]) and int(ptr[c]) == int(ptr1[c]), c
