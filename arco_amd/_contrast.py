@@ -60,8 +60,9 @@ def rows_view(x):
         r = y.view(-1, D)
     except RuntimeError:
         r = y.contiguous().view(-1, D)
-    if r.stride(1) != 1 or r.stride(0) % 4 != 0 or r.data_ptr() % 16 != 0 or r.dtype != torch.float32:
-        r = r.to(torch.float32).contiguous()
+    keep = r.dtype in (torch.float32, torch.float16)       # f16: the V-Net body's activation storage (ops.ACT_HALF)
+    if r.stride(1) != 1 or r.stride(0) % 4 != 0 or r.data_ptr() % 16 != 0 or not keep:
+        r = (r if keep else r.to(torch.float32)).contiguous()
     return r, r.stride(0)
 
 

@@ -23,6 +23,12 @@ static inline int arco_launch_status() {
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+// four consecutive channels of an activation row as fp32, from fp32 or f16 storage (the *_h entry points: f16 activation storage)
+__device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4f(const _Float16* p) { return __builtin_convertvector(*reinterpret_cast<const f16x4_t*>(p), f32x4); }
+__device__ __forceinline__ void st4f(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4f(_Float16* p, f32x4 v) { *reinterpret_cast<f16x4_t*>(p) = __builtin_convertvector(v, f16x4_t); }
 
 // bit layout of the per-pixel class code (C <= 21)
 #define ARCO_MAXC 21

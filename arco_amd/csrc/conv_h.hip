@@ -1,0 +1,592 @@
+// f16 ACTIVATION STORAGE for the volume path (BASELINE.json configs[4], "fp16 MFMA conv": the V-Net body of
+// vnetWithArgs.py:5-31,67-118,145-252 with every activation and activation gradient held as f16 in HBM and LDS; weights,
+// BatchNorm statistics, loss and optimizer stay fp32).  Three kernels:
+//
+//   hconv_kernel     3x3x3 (planes of H x W, depth tap = outer loop) and 1x1x1 convolutions, forward and - with flipped +
+//                    transposed packed weights - data gradient.  f16 tiles go from HBM to LDS untouched (16-byte pieces,
+//                    rows of 16 or 32 channels padded to 48 / 80 bytes: conflict-free ds_read_b128 fragments), one
+//                    v_mfma_f32_16x16x32_f16 per 16 pixels x 16 channels x 32 k (3x3: the 16 channels of TWO taps),
+//                    fp32 accumulate, D = W . X^T so that a lane ends with 4 consecutive channels of one pixel (8-byte
+//                    stores); BatchNorm partial statistics of the ROUNDED outputs in the epilogue.  Double-buffered LDS:
+//                    chunk c+1 is loaded to registers and written to the other buffer around the MFMAs of chunk c.
+//   hwgrad_kernel    weight gradient dW[tap][co][ci] = sum_pix dZ[pix][co] X[pix + tap][ci] (K = pixels).  Both operands
+//                    sit in LDS exactly as they sit in HBM ([pixel][channel] rows) and are read through
+//                    ds_read_b64_tr_b16 - the transposing LDS read of gfx950 hands every lane 4 consecutive PIXELS of one
+//                    channel, which is what the MFMA wants as k - so staging is a plain 16-byte copy (the split-bf16 kernel
+//                    transposes and splits on the VALU).  Row strides are 8 x odd dwords: the eight rows a 32-lane half
+//                    reads land on eight distinct 8-bank groups.  The four waves of a workgroup take one 32-pixel K step of
+//                    a 128-pixel tile each and own ALL taps x sub-tiles (a tap's input fragment feeds CO_T MFMAs); partners
+//                    are summed once per launch.  Slabs [chunk][tap][CoutPad][CinPad] as in igemm.hip -> wgrad_reduce.
+//   cast kernels     the fp32 <-> f16 boundary of the V-Net (outputs up, gradients down with the loss scale).
+#include "igemm_args.h"
+#include <stdlib.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+
+constexpr int HFLAT_WPMAX = 64;          // flat-position tiles: padded row stride W + 2 <= 64 (as igemm.hip)
+
+__device__ __forceinline__ h8 lds_h8(const unsigned* p) { return __builtin_bit_cast(h8, u32x4(*reinterpret_cast<const u32x4_ma*>(p))); }
+
+template <int TAPS, int BM, int BN, int WM, int WN, int DEPTH, bool FLAT>
+struct HGeom {
+  static constexpr int KC = TAPS == 9 ? 16 : 32;
+  static constexpr int LDK = KC / 2 + 4;                    // dwords per LDS row (48 / 80 bytes)
+  static constexpr int TH = BM / 16;
+  static constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * HFLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
+  static constexpr int BROWS = TAPS * BN;
+  static constexpr int PA = KC / 8;                         // 16-byte pieces per row
+  static constexpr int NA = (AROWS * PA + 255) / 256, NBI = (BROWS * PA + 255) / 256;
+  static constexpr int BUF = (AROWS + BROWS + 1) * LDK;     // dwords per buffer (+ the zero weight row)
+};
+
+template <int TAPS, int BM, int BN, int WM, int WN, int DEPTH, bool FLAT>
+__global__ __launch_bounds__(256) void hconv_kernel(IgemmArgs a) {
+  using G = HGeom<TAPS, BM, BN, WM, WN, DEPTH, FLAT>;
+  constexpr int KC = G::KC, LDK = G::LDK, AROWS = G::AROWS, BROWS = G::BROWS, PA = G::PA, NA = G::NA, NBI = G::NBI, BUF = G::BUF;
+  constexpr int TH = G::TH, A_T = BM / 16 / WM, C_T = BN / 16 / WN;
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+  const _Float16* const Ag = reinterpret_cast<const _Float16*>(a.A);
+  const _Float16* const Wg = reinterpret_cast<const _Float16*>(a.Wp);
+  _Float16* const Cg = reinterpret_cast<_Float16*>(a.C);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN, li = lane & 15, g = lane >> 4;
+  int mblk, nblk;
+  {   // XCD-aware tile order: the N-tiles of one M-tile (shared input rows) on consecutive slots of one XCD
+    const int T = a.n_mblocks * a.n_nblocks, L = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = L & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    mblk = v / a.n_nblocks; nblk = v - mblk * a.n_nblocks;
+  }
+  const int n0 = nblk * BN;
+  long m0 = 0; int img = 0, y0 = 0, x0 = 0, f0 = 0;
+  const int Wp = a.W + 2;
+  if (TAPS == 9 && FLAT) {
+    const int per_plane = (a.H * Wp + BM - 1) / BM;
+    img = mblk / per_plane; f0 = (mblk - img * per_plane) * BM;
+  } else if (TAPS == 9) {
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + TH - 1) / TH;
+    int t = mblk;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; img = t / tiles_y;
+    y0 = ty * TH; x0 = tx * 16;
+  } else {
+    m0 = (long)mblk * BM;
+  }
+  long m_lim = a.M;
+  if (TAPS == 1 && a.stat_groups > 1) {       // GEMM form with grouped BN statistics: M-blocks laid out per group
+    const int mpg = a.n_mblocks / a.stat_groups, g_ = mblk / mpg;
+    const long Mg = a.M / a.stat_groups;
+    m0 = g_ * Mg + (long)(mblk - g_ * mpg) * BM;
+    m_lim = (g_ + 1) * Mg;
+  }
+
+  f32x4 acc[A_T][C_T];
+#pragma unroll
+  for (int i = 0; i < A_T; ++i)
+#pragma unroll
+    for (int j = 0; j < C_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  const _Float16* srcA[NA]; int ldsA[NA], kA[NA];
+#pragma unroll
+  for (int it = 0; it < NA; ++it) {
+    const int idx = tid + it * 256;
+    srcA[it] = nullptr; ldsA[it] = -1; kA[it] = 0;
+    if (idx < AROWS * PA) {
+      const int row = idx / PA, q = idx - row * PA;
+      long pix = -1;
+      if (TAPS == 9 && FLAT) {
+        const int pidx = f0 + row - 1;
+        if (pidx >= 0 && row < BM + 2 * Wp + 2) {
+          const int py = pidx / Wp, px = pidx - py * Wp;
+          const int y = py - 1, x = px - 1;
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
+        }
+      } else if (TAPS == 9) {
+        const int hy = row / 18, hx = row - hy * 18;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        if (y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
+      } else {
+        const long m = m0 + row;
+        if (m < m_lim) pix = m;
+      }
+      ldsA[it] = row * LDK + q * 4; kA[it] = 8 * q;
+      if (pix >= 0) srcA[it] = Ag + pix * a.lda + 8 * q;
+    }
+  }
+  const _Float16* srcB[NBI]; int ldsB[NBI];
+#pragma unroll
+  for (int it = 0; it < NBI; ++it) {
+    const int idx = tid + it * 256;
+    srcB[it] = nullptr; ldsB[it] = -1;
+    if (idx < BROWS * PA) {
+      const int row = idx / PA, q = idx - row * PA;
+      const int tap = row / BN, n = row - tap * BN;
+      ldsB[it] = (AROWS + row) * LDK + q * 4;
+      if (n0 + n < a.Npad) srcB[it] = Wg + ((long)tap * a.Npad + n0 + n) * a.Kpad + 8 * q;
+    }
+  }
+
+  const int nchunks = (a.K + KC - 1) / KC;
+  const bool vecA = (a.K & 7) == 0 && (a.lda & 7) == 0;
+  const int plane = DEPTH == 3 ? img % a.D3 : 0;
+  const long plane_elems = (long)a.H * a.W * a.lda;
+  const long wslice = (long)9 * a.Npad * a.Kpad;
+  u32x4 ra[NA], rb[NBI];
+  auto load_chunk = [&](int itc) {
+    const int dd = DEPTH == 3 ? itc / nchunks : 0;
+    const int kc0 = (DEPTH == 3 ? itc - dd * nchunks : itc) * KC;
+    const bool plane_ok = DEPTH == 3 ? (plane + dd - 1 >= 0 && plane + dd - 1 < a.D3) : true;
+    const long aoff = DEPTH == 3 ? (long)(dd - 1) * plane_elems + kc0 : kc0;
+    const long boff = DEPTH == 3 ? (long)dd * wslice + kc0 : kc0;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (TAPS == 1 && !vecA) {        // rows that are not whole 16-byte pieces (the 2-class logits' gradient: K = 2)
+        if (srcA[it]) {
+          h8 e8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (kc0 + kA[it] + e < a.K) e8[e] = srcA[it][aoff + e];
+          v = __builtin_bit_cast(u32x4, e8);
+        }
+      } else if (srcA[it] && plane_ok && kc0 + kA[it] < a.K) v = *reinterpret_cast<const u32x4*>(srcA[it] + aoff);
+      ra[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NBI; ++it) {
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (srcB[it]) v = *reinterpret_cast<const u32x4*>(srcB[it] + boff);
+      rb[it] = v;
+    }
+  };
+  auto store_chunk = [&](unsigned* buf) {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) if (ldsA[it] >= 0) *reinterpret_cast<u32x4_ma*>(buf + ldsA[it]) = ra[it];
+#pragma unroll
+    for (int it = 0; it < NBI; ++it) if (ldsB[it] >= 0) *reinterpret_cast<u32x4_ma*>(buf + ldsB[it]) = rb[it];
+  };
+  auto compute = [&](const unsigned* buf) {
+    const unsigned* As = buf; const unsigned* Bs = buf + AROWS * LDK;
+    constexpr int NSTEP = TAPS == 9 ? 5 : 1;
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      const int tapL = TAPS == 9 ? 2 * st + (g >> 1) : 0;          // lanes g = 0,1: tap 2s, g = 2,3: tap 2s+1
+      const bool zt = tapL > 8;                                    // the 10th half-step: zero weight row
+      const int tapA = zt ? 8 : tapL;
+      const int dy = TAPS == 9 ? tapA / 3 : 0, dx = TAPS == 9 ? tapA % 3 : 0;
+      const int koff = TAPS == 9 ? (g & 1) * 4 : g * 4;
+      h8 fa[A_T];
+#pragma unroll
+      for (int at = 0; at < A_T; ++at) {
+        const int s = wm * A_T + at;
+        const int row = TAPS == 9 ? (FLAT ? s * 16 + li + dy * Wp + dx : (s + dy) * 18 + li + dx) : s * 16 + li;
+        fa[at] = lds_h8(As + row * LDK + koff);
+      }
+#pragma unroll
+      for (int ct = 0; ct < C_T; ++ct) {
+        const int row = zt ? BROWS : tapA * BN + (wn * C_T + ct) * 16 + li;
+        const h8 fb = lds_h8(Bs + row * LDK + koff);
+#pragma unroll
+        for (int at = 0; at < A_T; ++at)
+          acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, fa[at], acc[at][ct], 0, 0, 0);
+      }
+    }
+  };
+
+  const int niter = DEPTH * nchunks;
+  for (int i = tid; i < 2 * LDK; i += 256) smem_u[(i / LDK) * BUF + (AROWS + BROWS) * LDK + i % LDK] = 0u;
+  load_chunk(0);
+  store_chunk(smem_u);
+  __syncthreads();
+  for (int c = 0; c < niter; ++c) {
+    unsigned* cur = smem_u + (c & 1) * BUF;
+    unsigned* nxt = smem_u + ((c + 1) & 1) * BUF;
+    const bool more = c + 1 < niter;
+    if (more) load_chunk(c + 1);
+    compute(cur);
+    if (more) store_chunk(nxt);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, round to f16, 8-byte stores, BN partial statistics of the rounded values
+  float t1[C_T][4], t2[C_T][4];
+  const bool v4 = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 7) == 0);
+#pragma unroll
+  for (int ct = 0; ct < C_T; ++ct) {
+    const int nb = n0 + (wn * C_T + ct) * 16 + 4 * g;
+    f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bv[r] = (a.bias && nb + r < a.N) ? a.bias[nb + r] : 0.f; t1[ct][r] = 0.f; t2[ct][r] = 0.f; }
+#pragma unroll
+    for (int at = 0; at < A_T; ++at) {
+      const int s = wm * A_T + at;
+      long pix = -1;
+      if (TAPS == 9 && FLAT) {
+        const int f = f0 + s * 16 + li, y = f / Wp, xq = f - y * Wp;
+        if (y < a.H && xq >= 1 && xq <= a.W) pix = ((long)img * a.H + y) * a.W + xq - 1;
+      } else if (TAPS == 9) {
+        const int y = y0 + s, x = x0 + li;
+        if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x;
+      } else {
+        const long m = m0 + s * 16 + li;
+        if (m < m_lim) pix = m;
+      }
+      if (pix < 0) continue;
+      const f32x4 v = acc[at][ct] + bv;
+      const h4 hv = __builtin_convertvector(v, h4);
+      if (v4 && nb + 3 < a.N) {
+        *reinterpret_cast<h4*>(Cg + pix * a.ldc + nb) = hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float x = (float)hv[r]; t1[ct][r] += x; t2[ct][r] += x * x; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb + r < a.N) {
+            Cg[pix * a.ldc + nb + r] = hv[r];
+            const float x = (float)hv[r]; t1[ct][r] += x; t2[ct][r] += x * x;
+          }
+      }
+    }
+  }
+  if (a.stat_sum) {
+    float* red = reinterpret_cast<float*>(smem_u);   // [2][WM][BN]
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v1 = t1[ct][r], v2 = t2[ct][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+        if (li == 0) {
+          const int nl = (wn * C_T + ct) * 16 + 4 * g + r;
+          red[(0 * WM + wm) * BN + nl] = v1;
+          red[(1 * WM + wm) * BN + nl] = v2;
+        }
+      }
+    __syncthreads();
+    for (int nl = tid; nl < BN; nl += 256) {
+      const int n = n0 + nl;
+      if (n < a.N) {
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { v1 += red[(0 * WM + w) * BN + nl]; v2 += red[(1 * WM + w) * BN + nl]; }
+        a.stat_sum[(long)n * a.n_mblocks + mblk] = v1;
+        a.stat_sq[(long)n * a.n_mblocks + mblk] = v2;
+      }
+    }
+  }
+}
+
+template <int TAPS, int BM, int BN, int WM, int WN, int DEPTH, bool FLAT>
+static int launch_hconv(const IgemmArgs& a, hipStream_t st, int* q) {
+  using G = HGeom<TAPS, BM, BN, WM, WN, DEPTH, FLAT>;
+  int mblocks;
+  if (TAPS == 9 && FLAT) mblocks = a.NB * ((a.H * (a.W + 2) + BM - 1) / BM);
+  else if (TAPS == 9) mblocks = a.NB * ((a.H + G::TH - 1) / G::TH) * ((a.W + 15) / 16);
+  else if (a.stat_groups > 1) mblocks = a.stat_groups * (int)((a.M / a.stat_groups + BM - 1) / BM);
+  else mblocks = (int)((a.M + BM - 1) / BM);
+  if (q) {
+    q[0] = mblocks;
+    q[1] = TAPS * 1000000 + BM * 1000 + BN + (FLAT ? 500000 : 0);
+    q[2] = G::KC * 100 + DEPTH * 10 + 1;
+    return ARCO_OK;
+  }
+  size_t sh = (size_t)2 * G::BUF * 4;
+  const size_t red = (size_t)2 * WM * BN * sizeof(float);
+  if (sh < red) sh = red;
+  auto kern = hconv_kernel<TAPS, BM, BN, WM, WN, DEPTH, FLAT>;
+  static bool attr_set = false;
+  if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
+  IgemmArgs b = a;
+  b.n_mblocks = mblocks;
+  b.n_nblocks = (a.Npad + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks * b.n_nblocks)), dim3(256), sh, st, b);
+  return arco_launch_status();
+}
+
+static long h_rect_blocks(const IgemmArgs& a, int bm, int bn) {
+  return (long)a.NB * ((a.H + bm / 16 - 1) / (bm / 16)) * ((a.W + 15) / 16) * ((a.Npad + bn - 1) / bn);
+}
+static long h_flat_blocks(const IgemmArgs& a, int bm, int bn) {
+  return (long)a.NB * ((a.H * (a.W + 2) + bm - 1) / bm) * ((a.Npad + bn - 1) / bn);
+}
+template <bool FLAT>
+static int hconv_dispatch3(const IgemmArgs& a, hipStream_t st, int* q) {
+  static const long want = getenv("ARCO_HCONV_WANT") ? atol(getenv("ARCO_HCONV_WANT")) : 512;
+  auto blocks = [&](int bm, int bn) { return FLAT ? h_flat_blocks(a, bm, bn) : h_rect_blocks(a, bm, bn); };
+  if (a.Npad <= 16) return launch_hconv<9, 128, 16, 4, 1, 3, FLAT>(a, st, q);
+  if (a.Npad <= 32) {
+    if (blocks(128, 32) >= want) return launch_hconv<9, 128, 32, 4, 1, 3, FLAT>(a, st, q);
+    return launch_hconv<9, 64, 32, 2, 2, 3, FLAT>(a, st, q);
+  }
+  if (blocks(128, 64) >= want) return launch_hconv<9, 128, 64, 4, 1, 3, FLAT>(a, st, q);
+  if (blocks(64, 64) >= want) return launch_hconv<9, 64, 64, 2, 2, 3, FLAT>(a, st, q);
+  if (blocks(64, 32) >= want) return launch_hconv<9, 64, 32, 2, 2, 3, FLAT>(a, st, q);
+  return launch_hconv<9, 32, 32, 2, 2, 3, FLAT>(a, st, q);
+}
+
+// entry of the f16-storage convolutions (called from arco_conv3d_fwd with mma == 4).  a.Kpad = ceil32(K) (the f16 pack)
+int hconv_dispatch(const IgemmArgs& a, int taps, hipStream_t st, int* q) {
+  if ((taps != 1 && ((a.K & 7) != 0 || (a.lda & 7) != 0)) || a.R != nullptr) return ARCO_ERR_UNSUPPORTED;
+  if (!q && (((reinterpret_cast<uintptr_t>(a.A) & 15) != 0 && (a.K & 7) == 0) || (reinterpret_cast<uintptr_t>(a.Wp) & 15) != 0)) return ARCO_ERR_ARG;
+  if (taps == 27) {
+    if ((a.W & 15) != 0 && a.W + 2 <= HFLAT_WPMAX) return hconv_dispatch3<true>(a, st, q);
+    return hconv_dispatch3<false>(a, st, q);
+  }
+  if (taps == 1) {
+    if (a.Npad <= 16) return launch_hconv<1, 256, 16, 4, 1, 1, false>(a, st, q);
+    if (a.Npad <= 32) return launch_hconv<1, 128, 32, 4, 1, 1, false>(a, st, q);
+    if (a.M * (long)a.Npad <= 4096l * 1024) {
+      const long tiles64 = ((a.M + 63) / 64) * ((a.Npad + 63) / 64);
+      if (tiles64 < 192 && a.stat_groups <= 1) return launch_hconv<1, 32, 64, 2, 2, 1, false>(a, st, q);
+      return launch_hconv<1, 64, 64, 2, 2, 1, false>(a, st, q);
+    }
+    return launch_hconv<1, 128, 128, 2, 2, 1, false>(a, st, q);
+  }
+  return ARCO_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------------
+struct HWgradArgs {
+  const _Float16* dZ; long ldz; int Cout;
+  const _Float16* X; long ldx; int Cin;
+  int taps, NB, H, W, D3; long M;
+  float* partial;      // [chunks][taps][CoutPad][CinPad]
+  int CoutPad, CinPad, n_tiles;
+};
+
+constexpr int h_row_dw(int chans) { return chans == 16 ? 8 : (chans == 32 ? 24 : 40); }   // 8 x odd dwords
+
+// two transposing reads -> the 8 k (= pixel) values of one channel per lane: elements 0-3 from the block at `p`, 4-7 from `p + off2`
+__device__ __forceinline__ h8 tr_pair(const unsigned* p, int off2_dw) {
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(p));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(p + off2_dw));
+  return __builtin_bit_cast(h8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+
+// NT = 9: the nine taps of one plane pair (3-D: depth tap = blockIdx.z, input plane x + dd - 1), tiles of 8 x 16 pixels (ragged
+// at the plane's edges); NT = 1: GEMM form, tiles of 128 consecutive rows.
+template <int CO_T, int CI_T, int NT>
+__global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a) {
+  constexpr int CO_B = 16 * CO_T, CI_B = 16 * CI_T;
+  constexpr int RSZ = h_row_dw(CO_B), RSX = h_row_dw(CI_B);
+  constexpr int XR = NT == 9 ? 180 : 128;
+  constexpr int PZ = CO_B / 8, PX = CI_B / 8;                     // 16-byte pieces per row
+  constexpr int NZ = (128 * PZ + 255) / 256, NX = (XR * PX + 255) / 256;
+  constexpr int NSUB = CO_T * CI_T;
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_w[];
+  unsigned* const Zs = smem_w;                   // [128][RSZ]
+  unsigned* const Xs = smem_w + 128 * RSZ;       // [XR][RSX]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int dd = NT == 9 ? blockIdx.z : 0;
+  const int dpl = (NT == 9 && a.taps == 27) ? dd - 1 : 0;
+  const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 7) / 8;
+  const int ci_tiles = a.CinPad / CI_B;
+  const int co0 = (blockIdx.y / ci_tiles) * CO_B, ci0 = (blockIdx.y % ci_tiles) * CI_B;
+  const bool vz = (a.Cout & 7) == 0 && (a.ldz & 7) == 0, vx = (a.Cin & 7) == 0 && (a.ldx & 7) == 0;
+
+  f32x4 acc[NT][CO_T][CI_T];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < CO_T; ++i)
+#pragma unroll
+      for (int j = 0; j < CI_T; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
+
+  u32x4 pz[NZ], px_[NX];
+  auto load8 = [&](const _Float16* src, int c, int C, bool vec) -> u32x4 {
+    if (vec) return c < C ? *reinterpret_cast<const u32x4*>(src) : u32x4{0, 0, 0, 0};
+    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (c + e < C) v[e] = src[e];
+    return __builtin_bit_cast(u32x4, v);
+  };
+  auto fetch = [&](int t) {
+    int img = 0, y0 = 0, x0 = 0; long m0 = 0; bool plane_ok = true;
+    if (NT == 9) {
+      int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; img = tt / tiles_y;
+      y0 = ty * 8; x0 = tx * 16;
+      const int pl = a.taps == 27 ? img % a.D3 + dpl : 0;
+      plane_ok = pl >= 0 && pl < a.D3;
+    } else {
+      m0 = (long)t * 128;
+    }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      const int idx = tid + i * 256, p = idx / PZ, q = idx - p * PZ, c = co0 + 8 * q;
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (idx < 128 * PZ && plane_ok) {
+        long pix = -1;
+        if (NT == 9) { const int y = y0 + (p >> 4), x = x0 + (p & 15); if (y < a.H && x < a.W) pix = ((long)img * a.H + y) * a.W + x; }
+        else if (m0 + p < a.M) pix = m0 + p;
+        if (pix >= 0) v = load8(a.dZ + pix * a.ldz + c, c, a.Cout, vz);
+      }
+      pz[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = tid + i * 256, r = idx / PX, q = idx - r * PX, c = ci0 + 8 * q;
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (idx < XR * PX && plane_ok) {
+        long pix = -1;
+        if (NT == 9) {
+          const int y = y0 + r / 18 - 1, x = x0 + r % 18 - 1;
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W) pix = ((long)(img + dpl) * a.H + y) * a.W + x;
+        } else if (m0 + r < a.M) pix = m0 + r;
+        if (pix >= 0) v = load8(a.X + pix * a.ldx + c, c, a.Cin, vx);
+      }
+      px_[i] = v;
+    }
+  };
+
+  // lane geometry of the transposing reads: lane 4q+p of a 16-lane group supplies row q, column quad p of its 4 x 16 block.
+  // K step = wave: pixel (h, G = g, q) of the step = tile row 2 wid + h, column 4 g + q  (GEMM form: row 32 wid + 16 h + 4 g + q)
+  const int tq = li >> 2, tp = li & 3;
+  const int zrow = NT == 9 ? (2 * wid) * 16 + 4 * g + tq : 32 * wid + 4 * g + tq;
+  const int xrow = NT == 9 ? (2 * wid) * 18 + 4 * g + tq : zrow;
+  const unsigned* const zb = Zs + zrow * RSZ + 2 * tp;
+  const unsigned* const xb = Xs + xrow * RSX + 2 * tp;
+
+  int t = blockIdx.x;
+  if (t < a.n_tiles) fetch(t);
+  while (t < a.n_tiles) {
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) { const int idx = tid + i * 256; if (idx < 128 * PZ) *reinterpret_cast<u32x4_ma*>(Zs + (idx / PZ) * RSZ + 4 * (idx % PZ)) = pz[i]; }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { const int idx = tid + i * 256; if (idx < XR * PX) *reinterpret_cast<u32x4_ma*>(Xs + (idx / PX) * RSX + 4 * (idx % PX)) = px_[i]; }
+    __syncthreads();
+    const int next = t + gridDim.x;
+    if (next < a.n_tiles) fetch(next);
+    h8 zf[CO_T];
+#pragma unroll
+    for (int i = 0; i < CO_T; ++i) zf[i] = tr_pair(zb + 8 * i, 16 * RSZ);
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+      const int toff = NT == 9 ? ((tap / 3) * 18 + tap % 3) * RSX : 0;
+#pragma unroll
+      for (int j = 0; j < CI_T; ++j) {
+        const h8 xf = tr_pair(xb + toff + 8 * j, (NT == 9 ? 18 : 16) * RSX);
+#pragma unroll
+        for (int i = 0; i < CO_T; ++i)
+          acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zf[i], xf, acc[tap][i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    t = next;
+  }
+
+  // sum the four K-step waves (once per launch, tap by tap through LDS), then one slab per workgroup
+  float* const red = reinterpret_cast<float*>(smem_w);     // [4 waves][NSUB][4][64]
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CO_T; ++i)
+#pragma unroll
+      for (int j = 0; j < CI_T; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wid * NSUB + i * CI_T + j) * 4 + r) * 64 + lane] = acc[tap][i][j][r];
+    __syncthreads();
+    float* out = a.partial + (((long)blockIdx.x * a.taps + dd * NT + tap) * a.CoutPad) * a.CinPad;
+    const int r = wid;                                        // this thread sums element (r, lane) of every sub-tile
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      const float v = (red[((0 * NSUB + s) * 4 + r) * 64 + lane] + red[((1 * NSUB + s) * 4 + r) * 64 + lane]) +
+                      (red[((2 * NSUB + s) * 4 + r) * 64 + lane] + red[((3 * NSUB + s) * 4 + r) * 64 + lane]);
+      out[(long)(co0 + (s / CI_T) * 16 + 4 * g + r) * a.CinPad + ci0 + (s % CI_T) * 16 + li] = v;
+    }
+  }
+}
+
+template <int CO_T, int CI_T, int NT>
+static void launch_hwgrad(const HWgradArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int RSZ = h_row_dw(16 * CO_T), RSX = h_row_dw(16 * CI_T), XR = NT == 9 ? 180 : 128;
+  size_t sh = (size_t)(128 * RSZ + XR * RSX) * 4;
+  const size_t rd = (size_t)4 * CO_T * CI_T * 4 * 64 * 4;
+  if (sh < rd) sh = rd;
+  auto kern = hwgrad_kernel<CO_T, CI_T, NT>;
+  static bool attr_set = false;
+  if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
+  hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, a);
+}
+
+// dW (+)= weight gradient from f16 dZ / X; ws sized by arco_wgrad_ws_floats (same slab reservation as the fp32 kernels)
+int hwgrad_dispatch(const void* dZ, long ld_dz, int Cout, const void* in, long ld_in, int Cin, int taps, int NB, int D3, int H, int W,
+                    float* ws, float* dW, int accumulate, hipStream_t st) {
+  HWgradArgs a{};
+  a.dZ = reinterpret_cast<const _Float16*>(dZ); a.ldz = ld_dz; a.Cout = Cout;
+  a.X = reinterpret_cast<const _Float16*>(in); a.ldx = ld_in; a.Cin = Cin;
+  a.taps = taps; a.NB = NB; a.H = H; a.W = W; a.D3 = D3; a.M = (long)NB * H * W; a.partial = ws;
+  if ((Cin & 7) != 0 || (ld_in & 7) != 0 || (ld_dz & 1) != 0) return ARCO_ERR_UNSUPPORTED;
+  long chunks;
+  if (taps >= 9) {
+    const int hco = Cout > 16 ? 32 : 16, hci = Cin > 16 ? 32 : 16;
+    a.CoutPad = (Cout + hco - 1) / hco * hco; a.CinPad = (Cin + hci - 1) / hci * hci;
+    a.n_tiles = NB * ((H + 7) / 8) * ((W + 15) / 16);
+    const int zdim = taps / 9, ydim = (a.CoutPad / hco) * (a.CinPad / hci);
+    static const long target = getenv("ARCO_HWGRAD_TARGET") ? atol(getenv("ARCO_HWGRAD_TARGET")) : 512;
+    chunks = target / ((long)zdim * ydim); if (chunks > a.n_tiles) chunks = a.n_tiles; if (chunks < 1) chunks = 1;
+    const dim3 grid((unsigned)chunks, ydim, zdim);
+    if (hco == 32 && hci == 32) launch_hwgrad<2, 2, 9>(a, grid, st);
+    else if (hco == 32) launch_hwgrad<2, 1, 9>(a, grid, st);
+    else if (hci == 32) launch_hwgrad<1, 2, 9>(a, grid, st);
+    else launch_hwgrad<1, 1, 9>(a, grid, st);
+  } else {
+    const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
+    a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
+    a.n_tiles = (int)((a.M + 127) / 128);
+    const long ydim = (long)(a.CoutPad / co_b) * (a.CinPad / ci_b);
+    static const long target1 = getenv("ARCO_HWGRAD1_TARGET") ? atol(getenv("ARCO_HWGRAD1_TARGET")) : 512;
+    chunks = target1 / ydim; if (chunks < 1) chunks = 1; if (chunks > a.n_tiles) chunks = a.n_tiles;
+    const dim3 grid((unsigned)chunks, (unsigned)ydim, 1);
+#define HW1(CO, CI) if (co_b == 16 * CO && ci_b == 16 * CI) launch_hwgrad<CO, CI, 1>(a, grid, st)
+    HW1(4, 4); else HW1(4, 2); else HW1(4, 1); else HW1(2, 4); else HW1(2, 2); else HW1(2, 1); else HW1(1, 4); else HW1(1, 2); else HW1(1, 1);
+#undef HW1
+  }
+  launch_wgrad_reduce(st, ws, (int)chunks, taps, a.CoutPad, a.CinPad, Cout, Cin, dW, accumulate);
+  return arco_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the fp32 <-> f16 boundary
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_h2f_kernel(const _Float16* __restrict__ x, long n4, long n, float* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const h4 v = *reinterpret_cast<const h4*>(x + 4 * i);
+    *reinterpret_cast<f32x4*>(y + 4 * i) = __builtin_convertvector(v, f32x4);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[4 * n4 + threadIdx.x] = (float)x[4 * n4 + threadIdx.x];
+}
+__global__ __launch_bounds__(256) void cast_f2h_kernel(const float* __restrict__ x, long n4, long n, float scale, _Float16* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i) * scale;
+    *reinterpret_cast<h4*>(y + 4 * i) = __builtin_convertvector(v, h4);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[4 * n4 + threadIdx.x] = (_Float16)(x[4 * n4 + threadIdx.x] * scale);
+}
+
+extern "C" {
+
+// y[i] = (float) x[i]: a dense f16 activation -> fp32 (the V-Net's outputs leave the f16 region)
+int arco_cast_h2f(const void* x, long n, float* y, void* stream) {
+  ARCO_CHECK_ARG(x && y && n > 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  long gb = (n / 4 + 255) / 256; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
+  hipLaunchKernelGGL(cast_h2f_kernel, dim3((unsigned)gb), dim3(256), 0, as_stream(stream), reinterpret_cast<const _Float16*>(x), n / 4, n, y);
+  return arco_launch_status();
+}
+// y[i] = (f16)(scale * x[i]): an fp32 gradient enters the f16 region multiplied by the loss scale
+int arco_cast_f2h(const float* x, long n, float scale, void* y, void* stream) {
+  ARCO_CHECK_ARG(x && y && n > 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  long gb = (n / 4 + 255) / 256; if (gb > 4096) gb = 4096; if (gb < 1) gb = 1;
+  hipLaunchKernelGGL(cast_f2h_kernel, dim3((unsigned)gb), dim3(256), 0, as_stream(stream), x, n / 4, n, scale, reinterpret_cast<_Float16*>(y));
+  return arco_launch_status();
+}
+
+}  // extern "C"

@@ -135,7 +135,8 @@ __device__ __forceinline__ void block_channel_totals(f32x4 s, f32x4 q, int C, fl
   }
 }
 
-__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ X, long ldx, long M, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ X, long ldx, long M, int C,
                                                         float* __restrict__ ssum, float* __restrict__ ssq, int nblk) {
   const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
   // blockIdx.y = BN group: rows [g*M, (g+1)*M), slabs [g*nblk, (g+1)*nblk) of the gridDim.y*nblk slabs per channel
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
   f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
   if (tr < rstep)
     for (long r = r0 + tr; r < r1; r += rstep) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ldx + 4 * tq);
+      const f32x4 v = ld4f(X + r * ldx + 4 * tq);
       s += v; q += v * v;
     }
   extern __shared__ __attribute__((aligned(16))) float red[];   // [2][256][4]
@@ -154,11 +155,12 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
 
 // ---- BN apply + LeakyReLU(slope) + dropout:  a = drop(lrelu((z-mean)*istd*gamma+beta))
 //      drop_mode 0: none, 1: per element (nn.Dropout), 2: per (image, channel) (nn.Dropout3d)
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Z, long ldz, long M, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Z, long ldz, long M, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ istd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float slope, int drop_mode, float p, uint64_t seed_, long P,
-                                                        float* __restrict__ Aout, long lda,
+                                                        T* __restrict__ Aout, long lda,
                                                         const uint64_t* __restrict__ seed_dev) {
   const int q4 = C / 4;
   // blockIdx.y = BN group: rows [g*M, (g+1)*M) of the tensor with parameter row g (M = rows per group)
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     for (long rb = gt / q4; rb < M; rb += 4 * rstride) {
       f32x4 z[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const long r = rb + u * rstride; if (r < M) z[u] = *reinterpret_cast<const f32x4*>(Z + r * ldz + c); }
+      for (int u = 0; u < 4; ++u) { const long r = rb + u * rstride; if (r < M) z[u] = ld4f(Z + r * ldz + c); }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long r = rb + u * rstride;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
             else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)(((r + row0) / P) * C + c + e), p) ? y * keep_scale : 0.f;
             o[e] = y;
           }
-          *reinterpret_cast<f32x4*>(Aout + r * lda + c) = o;
+          st4f(Aout + r * lda + c, o);
         }
       }
     }
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
     const long r = i / q4; const int c = (int)(i - r * q4) * 4;
-    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
+    const f32x4 z = ld4f(Z + r * ldz + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
       else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)(((r + row0) / P) * C + c + e), p) ? y * keep_scale : 0.f;
       o[e] = y;
     }
-    *reinterpret_cast<f32x4*>(Aout + r * lda + c) = o;
+    st4f(Aout + r * lda + c, o);
   }
 }
 
@@ -224,8 +226,9 @@ __device__ __forceinline__ float bn_dy(float dA, float y, float slope, int drop_
 }
 
 // ---- BN backward pass 1: per-channel partial sums of dy and dy*xhat
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
-    const float* __restrict__ dA, long ldd, const float* __restrict__ Z, long ldz, long M, int C,
+    const T* __restrict__ dA, long ldd, const T* __restrict__ Z, long ldz, long M, int C,
     const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
     const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed_, long P,
     float* __restrict__ s_dy, float* __restrict__ s_dyx, int nblk, const uint64_t* __restrict__ seed_dev) {
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
       for (int u = 0; u < 4; ++u) {
         const long r = rb + (long)u * rstep;
         if (r < r1) {
-          z[u] = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
-          d[u] = *reinterpret_cast<const f32x4*>(dA + r * ldd + c);
+          z[u] = ld4f(Z + r * ldz + c);
+          d[u] = ld4f(dA + r * ldd + c);
         }
       }
 #pragma unroll
@@ -300,12 +303,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 // ---- BN backward pass 2: dz = gamma*istd*(dy - sum_dy/n - xhat*sum_dyx/n)
 //      sums are read from `sums` = [dbeta_this_call | dgamma_this_call] (not the accumulated grads)
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
-    const float* __restrict__ dA, long ldd, const float* __restrict__ Z, long ldz, long M, int C,
+    const T* __restrict__ dA, long ldd, const T* __restrict__ Z, long ldz, long M, int C,
     const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
     const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed_, long P,
     const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, float inv_count,
-    float* __restrict__ dZ, long ldo, const uint64_t* __restrict__ seed_dev, int gn) {
+    T* __restrict__ dZ, long ldo, const uint64_t* __restrict__ seed_dev, int gn) {
   // gn != 0 (GroupNorm / InstanceNorm: statistics per sample over a SET of channels): sum_dy / sum_dyx hold the set's sums
   // of gamma*dy and gamma*dy*xhat, and dz = istd * (gamma*dy - sum_dy/n - xhat*sum_dyx/n); gamma varies inside a set
   const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const long r = rb + u * rstride;
-        if (r < M) { z[u] = *reinterpret_cast<const f32x4*>(Z + r * ldz + c); d[u] = *reinterpret_cast<const f32x4*>(dA + r * ldd + c); }
+        if (r < M) { z[u] = ld4f(Z + r * ldz + c); d[u] = ld4f(dA + r * ldd + c); }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
             o[e] = gn ? is[e] * (ga[e] * dy - sd[e] * inv_count - xh * sx[e] * inv_count)
                       : ga[e] * is[e] * (dy - sd[e] * inv_count - xh * sx[e] * inv_count);
           }
-          *reinterpret_cast<f32x4*>(dZ + r * ldo + c) = o;
+          st4f(dZ + r * ldo + c, o);
         }
       }
     }
@@ -350,8 +354,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
     const long r = i / q4; const int c = (int)(i - r * q4) * 4;
-    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ldz + c);
-    const f32x4 d = *reinterpret_cast<const f32x4*>(dA + r * ldd + c);
+    const f32x4 z = ld4f(Z + r * ldz + c);
+    const f32x4 d = ld4f(dA + r * ldd + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         o[e] = bn_dy(d[e], z[e], slope, drop_mode, p, keep_scale, seed, ei);
       }
     }
-    *reinterpret_cast<f32x4*>(dZ + r * ldo + c) = o;
+    st4f(dZ + r * ldo + c, o);
   }
 }
 
@@ -983,33 +987,60 @@ int arco_chan_stats_blocks(long M) {
   return (int)b;
 }
 
-int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, int groups, void* stream) {
+extern "C++" {
+template <typename T>
+static int chan_stats_impl(const T* X, long ldx, long M, int C, float* ssum, float* ssq, int groups, void* stream) {
   if (groups < 1) groups = 1;
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldx & 3) == 0 && M % groups == 0);
   const int nblk = arco_chan_stats_blocks(M / groups);            // slabs per group; ssum/ssq: [C][groups*nblk]
-  hipLaunchKernelGGL(chan_stats_kernel, dim3(nblk, groups), dim3(256), 2048 * sizeof(float), as_stream(stream), X, ldx,
+  hipLaunchKernelGGL(chan_stats_kernel<T>, dim3(nblk, groups), dim3(256), 2048 * sizeof(float), as_stream(stream), X, ldx,
                      M / groups, C, ssum, ssq, nblk);
   return arco_launch_status();
 }
+}  // extern "C++"
+int arco_chan_stats(const float* X, long ldx, long M, int C, float* ssum, float* ssq, int groups, void* stream) {
+  return chan_stats_impl<float>(X, ldx, M, C, ssum, ssq, groups, stream);
+}
+// ... of an f16 tensor (f16 activation storage; statistics stay fp32)
+int arco_chan_stats_h(const void* X, long ldx, long M, int C, float* ssum, float* ssq, int groups, void* stream) {
+  return chan_stats_impl<_Float16>(reinterpret_cast<const _Float16*>(X), ldx, M, C, ssum, ssq, groups, stream);
+}
 
-int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
-                    const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
-                    const uint64_t* seed_dev, int groups, void* stream) {
+extern "C++" {
+template <typename T>
+static int bn_act_fwd_impl(const T* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                           const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, T* A, long lda,
+                           const uint64_t* seed_dev, int groups, void* stream) {
   if (groups < 1) groups = 1;
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && p < 1.0f && M % groups == 0);
   const long Mg = M / groups;                 // mean / istd: [groups][C]; rows [g*Mg, (g+1)*Mg) use row g
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, as_stream(stream), Z, ldz, Mg, C, mean,
+  hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, as_stream(stream), Z, ldz, Mg, C, mean,
                      istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda, seed_dev);
   return arco_launch_status();
+}
+}  // extern "C++"
+int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                    const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
+                    const uint64_t* seed_dev, int groups, void* stream) {
+  return bn_act_fwd_impl<float>(Z, ldz, M, C, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, A, lda, seed_dev, groups, stream);
+}
+// f16 activation storage: Z and A are f16 tensors (parameters and statistics fp32, arithmetic fp32)
+int arco_bn_act_fwd_h(const void* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                      const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, void* A, long lda,
+                      const uint64_t* seed_dev, int groups, void* stream) {
+  return bn_act_fwd_impl<_Float16>(reinterpret_cast<const _Float16*>(Z), ldz, M, C, mean, istd, gamma, beta, slope, drop_mode, p, seed, P,
+                                   reinterpret_cast<_Float16*>(A), lda, seed_dev, groups, stream);
 }
 
 // ws: groups * (2*C*nblk + 2*C) floats;  nblk = arco_chan_stats_blocks(M / groups)
 // cpg = 0: BatchNorm (groups = BN groups).  cpg >= 1: GroupNorm with cpg channels per set / InstanceNorm (cpg = 1),
 // groups = samples; gamma / beta may be null there (no affine: gamma = 1, beta = 0 are expected as real tensors by the kernels,
 // so the host passes ones / zeros).
-static int bn_act_bwd_impl(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
+extern "C++" {
+template <typename T>
+static int bn_act_bwd_impl(const T* dA, long ldd, const T* Z, long ldz, long M, int C, const float* mean,
                            const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
-                           uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
+                           uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, T* dZ, long ldo,
                            const uint64_t* seed_dev, int groups, int cpg, void* stream) {
   if (groups < 1) groups = 1;
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldz & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0 && M % groups == 0);
@@ -1020,7 +1051,7 @@ static int bn_act_bwd_impl(const float* dA, long ldd, const float* Z, long ldz, 
   if (mean) {
     const int nblk = arco_chan_stats_blocks(Mg);
     float* s_dy = ws; float* s_dyx = ws + (long)groups * C * nblk; float* sums = ws + 2l * groups * C * nblk;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nblk, groups), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, Mg,
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(nblk, groups), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, Mg,
                        C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk, seed_dev);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, s_dy, s_dyx, nblk, C, sums, dgamma,
                        dbeta, accumulate, groups);
@@ -1028,21 +1059,31 @@ static int bn_act_bwd_impl(const float* dA, long ldd, const float* Z, long ldz, 
       const int nset = groups * (C / cpg);
       hipLaunchKernelGGL(gn_merge_bwd_kernel, dim3((nset + 255) / 256), dim3(256), 0, st, sums, gamma, groups, C, cpg);
     }
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, st, dA, ldd, Z, ldz, Mg, C,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, st, dA, ldd, Z, ldz, Mg, C,
                        mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / ((float)Mg * (float)(cpg ? cpg : 1)), dZ, ldo,
                        seed_dev, cpg ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
                        nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo, seed_dev, 0);
   }
   return arco_launch_status();
 }
+}  // extern "C++"
 int arco_bn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M, int C, const float* mean,
                     const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
                     uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, float* dZ, long ldo,
                     const uint64_t* seed_dev, int groups, void* stream) {
-  return bn_act_bwd_impl(dA, ldd, Z, ldz, M, C, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, ws, dgamma, dbeta,
-                         accumulate, dZ, ldo, seed_dev, groups, 0, stream);
+  return bn_act_bwd_impl<float>(dA, ldd, Z, ldz, M, C, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, ws, dgamma, dbeta,
+                                accumulate, dZ, ldo, seed_dev, groups, 0, stream);
+}
+// f16 activation storage: dA, Z, dZ are f16 tensors; the channel sums (ws) and dgamma / dbeta fp32
+int arco_bn_act_bwd_h(const void* dA, long ldd, const void* Z, long ldz, long M, int C, const float* mean,
+                      const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
+                      uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, void* dZ, long ldo,
+                      const uint64_t* seed_dev, int groups, void* stream) {
+  return bn_act_bwd_impl<_Float16>(reinterpret_cast<const _Float16*>(dA), ldd, reinterpret_cast<const _Float16*>(Z), ldz, M, C, mean, istd,
+                                   gamma, beta, slope, drop_mode, p, seed, P, ws, dgamma, dbeta, accumulate,
+                                   reinterpret_cast<_Float16*>(dZ), ldo, seed_dev, groups, 0, stream);
 }
 // GroupNorm / InstanceNorm + activation (vnetWithArgs.py:19-22): statistics of N samples x (C / cpg) channel sets from the
 // per-(sample, channel) slabs of arco_chan_stats(groups = N) / the conv epilogue; apply = arco_bn_act_fwd(groups = N)
@@ -1058,7 +1099,7 @@ int arco_gn_act_bwd(const float* dA, long ldd, const float* Z, long ldz, long M,
                     const float* istd, const float* gamma, const float* beta, float slope, float* ws, float* dgamma,
                     float* dbeta, int accumulate, float* dZ, long ldo, int N, int cpg, void* stream) {
   ARCO_CHECK_ARG(mean && istd && gamma && beta && cpg >= 1);
-  return bn_act_bwd_impl(dA, ldd, Z, ldz, M, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1, ws, dgamma, dbeta, accumulate,
+  return bn_act_bwd_impl<float>(dA, ldd, Z, ldz, M, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1, ws, dgamma, dbeta, accumulate,
                          dZ, ldo, nullptr, N, cpg, stream);
 }
 

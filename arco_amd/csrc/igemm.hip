@@ -852,7 +852,13 @@ __global__ __launch_bounds__(256) void conv3d_image_kernel(IgemmArgs a) {
       const int gy = ty * TH + py, gx = tx * TW + li;
       if (gy < a.H && gx < a.W && 4 * g < a.N) {
         const long pix = ((long)pl * a.H + gy) * a.W + gx;
-        *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + 4 * g) = acc;
+        if (a.mma == 4) {      // f16 activation storage: round, store 8 bytes, statistics of the rounded values
+          const f16x4 hv = to_f16x4(acc);
+          *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.C) + pix * a.ldc + 4 * g) = hv;
+          acc = __builtin_convertvector(hv, f32x4);
+        } else {
+          *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + 4 * g) = acc;
+        }
         s1 += acc; s2 += acc * acc;
       }
     }
@@ -973,7 +979,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int Ci
   float v = 0.f;
   if ((mode & 1) == 0) { if (n < Cout && k < Cin) v = W[((long)n * Cin + k) * taps + tap]; }
   else { if (n < Cin && k < Cout) v = W[((long)k * Cin + n) * taps + (taps - 1 - tap)]; }
-  if (mode & 2) store_split3(v, reinterpret_cast<unsigned short*>(Wp), r, k, Kpad);
+  if (mode & 4) reinterpret_cast<_Float16*>(Wp)[i] = (_Float16)v;           // f16 pack (conv_h.hip): [tap][Npad][Kpad = ceil32(K)]
+  else if (mode & 2) store_split3(v, reinterpret_cast<unsigned short*>(Wp), r, k, Kpad);
   else Wp[i] = v;
 }
 
@@ -998,7 +1005,8 @@ __global__ void pack_many_kernel(const PackDesc* __restrict__ desc, int n_desc, 
     float v = 0.f;
     if ((d.mode & 1) == 0) { if (n < d.Cout && k < d.Cin) v = d.src[((long)n * d.Cin + k) * d.taps + tap]; }
     else { if (n < d.Cin && k < d.Cout) v = d.src[((long)k * d.Cin + n) * d.taps + (d.taps - 1 - tap)]; }
-    if (d.mode & 2) store_split3(v, reinterpret_cast<unsigned short*>(d.dst), r, k, d.Kpad);
+    if (d.mode & 4) reinterpret_cast<_Float16*>(d.dst)[j] = (_Float16)v;
+    else if (d.mode & 2) store_split3(v, reinterpret_cast<unsigned short*>(d.dst), r, k, d.Kpad);
     else d.dst[j] = v;
   }
 }
@@ -1522,7 +1530,11 @@ __global__ __launch_bounds__(256) void wgrad_image3d_kernel(WgradArgs a) {
       const int u = tid + 256 * i, p = u >> 2, q = u & 3;
       const int gy = ty * TH + (p >> 4), gx = tx * TW + (p & 15);
       f32x4 v = {0, 0, 0, 0};
-      if (gy < a.H && gx < a.W && 4 * q < a.Cout) v = *reinterpret_cast<const f32x4*>(a.dZ + (((long)pl * a.H + gy) * a.W + gx) * a.ldz + 4 * q);
+      if (gy < a.H && gx < a.W && 4 * q < a.Cout) {
+        const long zo = (((long)pl * a.H + gy) * a.W + gx) * a.ldz + 4 * q;
+        if (a.mma == 4) v = __builtin_convertvector(*reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(a.dZ) + zo), f32x4);
+        else v = *reinterpret_cast<const f32x4*>(a.dZ + zo);
+      }
       *reinterpret_cast<f32x4*>(&Zs[p * 16 + 4 * q]) = v;
     }
     __syncthreads();
@@ -1612,7 +1624,7 @@ __global__ __launch_bounds__(512) void wgrad_reduce4_kernel(const float* __restr
     }
   }
 }
-static void launch_wgrad_reduce(hipStream_t st, const float* ws, int chunks, int taps, int CoutPad, int CinPad, int Cout, int Cin,
+void launch_wgrad_reduce(hipStream_t st, const float* ws, int chunks, int taps, int CoutPad, int CinPad, int Cout, int Cin,
                                 float* dW, int accumulate) {
   const long tot = (long)Cout * Cin * taps;
   static const bool v4 = !(getenv("ARCO_WGRAD_REDUCE4") && atoi(getenv("ARCO_WGRAD_REDUCE4")) == 0);
@@ -1626,7 +1638,8 @@ static void launch_wgrad_reduce(hipStream_t st, const float* ws, int chunks, int
 
 // column sums (bias gradient): out[c] = sum_pix X[pix][c].  float4 lanes along channels,
 // rows strided over the block, per-block slabs + fp64 fixed-order finalize.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, long M, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, long ldx, long M, int C,
                                                             float* __restrict__ partial) {
   const long rpb = (M + gridDim.x - 1) / gridDim.x;
   const long r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
@@ -1635,7 +1648,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const int q4 = C / 4, tq = threadIdx.x % q4, tr = threadIdx.x / q4, rstep = 256 / q4;
     f32x4 s = {0, 0, 0, 0};
     if (tr < rstep)
-      for (long r = r0 + tr; r < r1; r += rstep) s += *reinterpret_cast<const f32x4*>(X + r * ldx + 4 * tq);
+      for (long r = r0 + tr; r < r1; r += rstep) s += ld4f(X + r * ldx + 4 * tq);
     *reinterpret_cast<f32x4*>(&red[threadIdx.x * 4]) = s;
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -1649,7 +1662,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const int rstep = 256 / C, c = threadIdx.x % C, tr = threadIdx.x / C;
     float s = 0.f;
     if (tr < rstep)
-      for (long r = r0 + tr; r < r1; r += rstep) s += X[r * ldx + c];
+      for (long r = r0 + tr; r < r1; r += rstep) s += (float)X[r * ldx + c];
     red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < C) {
@@ -1660,7 +1673,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   } else {
     for (int c = threadIdx.x; c < C; c += 256) {
       float s = 0.f;
-      for (long r = r0; r < r1; ++r) s += X[r * ldx + c];
+      for (long r = r0; r < r1; ++r) s += (float)X[r * ldx + c];
       partial[(long)blockIdx.x * C + c] = s;
     }
   }
@@ -1707,6 +1720,10 @@ int arco_conv_mblocks_mma(int taps, int NB, int H, int W, int Cin, int Cout, lon
   a.stat_groups = stat_groups > 1 ? stat_groups : 1;
   a.mma = mma;
   int q[3] = {0, 0, 0};
+  if (mma == 4 && !(taps == 27 && image_conv3d_eligible(a))) {
+    a.Kpad = (Cin + 31) / 32 * 32;
+    return hconv_dispatch(a, taps, nullptr, q) == ARCO_OK ? q[0] : ARCO_ERR_UNSUPPORTED;
+  }
   if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
   return q[0];
 }
@@ -1727,6 +1744,10 @@ int arco_conv_config_mma(int taps, int NB, int H, int W, int Cin, int Cout, long
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
   a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in; a.mma = mma;
   int q[3] = {0, 0, 0};
+  if (mma == 4 && !(taps == 27 && image_conv3d_eligible(a))) {
+    a.Kpad = (Cin + 31) / 32 * 32;
+    return hconv_dispatch(a, taps, nullptr, q) == ARCO_OK ? q[1] : ARCO_ERR_UNSUPPORTED;
+  }
   if (dispatch_igemm(a, taps, nullptr, q) != ARCO_OK) return ARCO_ERR_UNSUPPORTED;
   return q[1];
 }
@@ -1759,9 +1780,9 @@ int arco_conv_split_ok(int taps, int NB, int H, int W, int Cin, int Cout, long l
 }
 
 int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream) {
-  ARCO_CHECK_ARG(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9 || taps == 27) && mode >= 0 && mode <= 3);
+  ARCO_CHECK_ARG(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9 || taps == 27) && mode >= 0 && mode <= 5 && (mode & 6) != 6);
   const int N = (mode & 1) == 0 ? Cout : Cin, K = (mode & 1) == 0 ? Cin : Cout;
-  const int Npad = (N + 15) / 16 * 16, Kpad = (mode & 2) ? (K + 31) / 32 * 32 : (K + 15) / 16 * 16;   // split: Wp holds 3 bf16 per element
+  const int Npad = (N + 15) / 16 * 16, Kpad = (mode & 6) ? (K + 31) / 32 * 32 : (K + 15) / 16 * 16;   // split: Wp holds 3 bf16 per element; mode | 4: one f16
   const long tot = (long)taps * Npad * Kpad;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), W, Cout, Cin, taps,
                      mode, Npad, Kpad, Wp);
@@ -1844,7 +1865,7 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                     int NV, int D3, int H, int W, int stat_groups, int mma, void* stream) {
   const int NB = NV * D3;
-  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0 && mma >= 0 && mma <= 3);
+  ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0 && mma >= 0 && mma <= 4);
   IgemmArgs a{};
   a.A = in; a.lda = ld_in; a.Wp = Wp; a.N = N; a.K = K;
   a.Npad = (N + 15) / 16 * 16; a.Kpad = (K + 15) / 16 * 16;
@@ -1858,6 +1879,11 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
     a.Kpad = taps == 1 ? a.Kg * 16 : (K + 15) / 16 * 16;
   }
   ARCO_CHECK_ARG(NV % a.stat_groups == 0);
+  if (mma == 4) {       // f16 activation storage: `out` (and `in`, unless this is the one-channel fp32 volume of the first layer) are f16
+    if (taps == 27 && image_conv3d_eligible(a)) return launch_image_conv3d<3>(a, as_stream(stream), nullptr);
+    a.Kpad = (K + 31) / 32 * 32;
+    return hconv_dispatch(a, taps, as_stream(stream), nullptr);
+  }
   return dispatch_igemm(a, taps, as_stream(stream), nullptr);
 }
 
@@ -1886,9 +1912,11 @@ int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long
 int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
                       int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, void* stream) {
   const int NB = NV * D3;
-  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9 || taps == 27) && mma >= 0 && mma <= 3);
+  ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9 || taps == 27) && mma >= 0 && mma <= 4);
+  if (mma == 4 && !(taps >= 9 && Cin == 1))      // f16 activation storage (dZ and in are f16; the first layer's input volume is fp32)
+    return hwgrad_dispatch(dZ, ld_dz, Cout, in, ld_in, Cin, taps, NB, D3, H, W, ws, dW, accumulate, as_stream(stream));
   WgradArgs a{};
-  a.D3 = D3; a.mma = mma == 3 ? 3 : ((taps == 27 && mma) ? 2 : 0);   // 1 / 2: bf16 operands (gradients: range); 3: split-bf16 (fp32-accurate)
+  a.D3 = D3; a.mma = mma >= 3 ? mma : ((taps == 27 && mma) ? 2 : 0);   // 1 / 2: bf16 operands (gradients: range); 3: split-bf16 (fp32-accurate)
   a.dZ = dZ; a.ldz = ld_dz; a.Cout = Cout; a.Ain = in; a.lda = ld_in; a.Cin = Cin; a.taps = taps;
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.partial = ws;
   static const int abl = getenv("ARCO_WGRAD_ABL") ? atoi(getenv("ARCO_WGRAD_ABL")) : 0;
@@ -1997,7 +2025,16 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
 int arco_colsum(const float* X, long ldx, long M, int C, float* ws, float* out, int accumulate, void* stream) {
   ARCO_CHECK_ARG(X && ws && out && M > 0 && C > 0);
   int nblk = (int)((M + 511) / 512); if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 1024 * sizeof(float), as_stream(stream), X, ldx, M, C, ws);
+  hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nblk), dim3(256), 1024 * sizeof(float), as_stream(stream), X, ldx, M, C, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, as_stream(stream), ws, nblk, C, out, accumulate);
+  return arco_launch_status();
+}
+// the same over an f16 tensor (f16 activation storage: bias gradients of the V-Net's convolutions)
+int arco_colsum_h(const void* X, long ldx, long M, int C, float* ws, float* out, int accumulate, void* stream) {
+  ARCO_CHECK_ARG(X && ws && out && M > 0 && C > 0);
+  int nblk = (int)((M + 511) / 512); if (nblk > 1024) nblk = 1024; if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(colsum_partial_kernel<_Float16>, dim3(nblk), dim3(256), 1024 * sizeof(float), as_stream(stream),
+                     reinterpret_cast<const _Float16*>(X), ldx, M, C, ws);
   hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, as_stream(stream), ws, nblk, C, out, accumulate);
   return arco_launch_status();
 }

@@ -16,7 +16,8 @@ struct IgemmArgs {
   long M;                            // total pixels
   int ksplit; long slab_stride;      // split-K (TAPS==1): blockIdx.y = K slab, output slab y at C + y*slab_stride
   int stat_groups;                   // BN groups: images [g*NB/G, (g+1)*NB/G) feed the stat slabs [g*n_mblocks/G, ...)
-  int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3, 1x1x1)
+  int mma;                           // 0: fp32 MFMA (default); 1 / 2: operands rounded to f16 / bf16 in registers, fp32 accumulate (3x3x3, 1x1x1);
+                                     // 3: split-bf16; 4: f16 activation STORAGE (A / C are f16 tensors, conv_h.hip)
   int Kg;                            // mma == 3: 16-k groups per packed weight row (= ceil32(K) / 16)
   int batch; long batchA, batchW, batchC;   // TAPS==1 batched GEMM: blockIdx.z = problem, operands at + z * stride (floats)
 };
@@ -60,3 +61,13 @@ __device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
 // then falls through to igemm_kernel), otherwise the launch status; q != nullptr: query only (q[0] = M-tiles = BN stat
 // slabs per channel, q[1] = instantiation id, q[2] = KC*100 + DEPTH*10).
 int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
+
+// conv_h.hip: f16 activation storage (mma == 4).  hconv_dispatch: forward / data gradient of the 3x3x3 and 1x1x1 convolutions on
+// f16 tensors (a.A, a.C point at f16 rows, a.Wp at the f16 pack [tap][Npad][ceil32(K)], a.Kpad = ceil32(K)); q as above.
+// hwgrad_dispatch: their weight gradient from f16 dZ / X (fp32 slabs in ws, fp32 dW).
+int hconv_dispatch(const IgemmArgs& a, int taps, hipStream_t st, int* q);
+int hwgrad_dispatch(const void* dZ, long ld_dz, int Cout, const void* in, long ld_in, int Cin, int taps, int NB, int D3, int H, int W,
+                    float* ws, float* dW, int accumulate, hipStream_t st);
+// igemm.hip: fixed-order sum of the weight-gradient slabs [chunk][tap][CoutPad][CinPad] into dW (torch layout)
+void launch_wgrad_reduce(hipStream_t st, const float* ws, int chunks, int taps, int CoutPad, int CinPad, int Cout, int Cin,
+                         float* dW, int accumulate);

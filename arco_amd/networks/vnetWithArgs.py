@@ -10,6 +10,9 @@ nn.BatchNorm3d children are parameter containers).  Forward on channels-last-3d 
                 BN partial statistics fused in the epilogue, then one BN+ReLU apply pass;
   k2 s2 conv  = space-to-depth (8*C channels) + 1x1x1 GEMM (+fused BN statistics);
   k2 s2 convT = 1x1x1 GEMM to 8*C channels + depth-to-space, then BN+ReLU.
+With ops.ACT_HALF (train_arco_3d --act_dtype f16; BASELINE.json configs[4]) the first layer writes f16 and the whole body runs
+on f16 activations and activation gradients (csrc/conv_h.hip, the *_h entry points; 'batchnorm' only); the logits and the
+feature maps are handed out as fp32.
 """
 import torch
 from torch import nn
@@ -33,6 +36,12 @@ def _norm_layer(normalization, c):
 
 
 def _norm_act(z, norm, training):
+    if z.dtype == torch.float16:
+        raise RuntimeError("arco_amd: f16 activation storage is built for normalization='batchnorm' (the V-Net net_factory_3d makes)")
+    return _norm_act32(z, norm, training)
+
+
+def _norm_act32(z, norm, training):
     """ReLU(norm(z)) for a pre-activation z that did not get its statistics from the conv epilogue: GroupNorm(16, C) /
     InstanceNorm3d / nothing (vnetWithArgs.py:19-24).  Batch-independent statistics: the same in train and eval mode."""
     if norm is None:
@@ -138,10 +147,7 @@ class UpsamplingDeconvBlock(nn.Module):
         if self.training:
             return ops.bn_act(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, momentum=bn.momentum,
                               eps=bn.eps, num_batches_tracked=bn.num_batches_tracked)
-        with torch.no_grad():
-            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-            shift = bn.bias - bn.running_mean * scale
-            return torch.relu(z * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
+        return ops.bn_act_eval(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, eps=bn.eps)
 
 
 class VNet(nn.Module):
@@ -197,7 +203,9 @@ class VNet(nn.Module):
         feature_map.append(x9)
         x9 = self._drop(x9)
         out = ops.conv(x9, self.out_conv.weight, self.out_conv.bias)
-        return out, feature_map
+        # f16 activation storage (ops.ACT_HALF): the logits and the feature maps leave the f16 region as fp32 - heads, losses
+        # and samplers are fp32; gradients come back through the same boundary with the loss scale
+        return ops.from_half(out), [ops.from_half(f) for f in feature_map]
 
     def forward(self, input, turnoff_drop=False):
         if turnoff_drop:

@@ -23,6 +23,15 @@ CONV_MMA = int(__import__('os').environ.get('ARCO_CONV_MMA', '3'))          # MF
                       # 0 ("f32"): the native fp32 MFMA (bitwise an fma chain);
                       # 1 / 2 ("f16" / "bf16"): the 3x3x3 convolutions round their operands to f16 / bf16 (BASELINE configs[4])
 PROFILE_EVERY = 1    # time every n-th conv launch of an instantiation (bench.py: 7, prime vs the per-step launch counts)
+ACT_HALF = False     # f16 ACTIVATION STORAGE of the volume path (--act_dtype f16 of train_arco_3d, BASELINE configs[4]): the V-Net's
+                     # first layer writes f16 and every operator below follows its input's dtype (csrc/conv_h.hip, the *_h entry points);
+                     # weights, BatchNorm statistics, parameter gradients, loss and optimizer stay fp32
+LOSS_SCALE = 16384.0  # gradients enter the f16 region multiplied by this (from_half's backward); the trainer divides the
+                      # region's parameter gradients by it before the optimiser step
+
+
+def _is_half(t):
+    return t is not None and t.dtype == torch.float16
 
 
 class bn_groups:
@@ -126,9 +135,9 @@ def new_act(nb, c, h, w, dev):
     return torch.empty((nb, h, w, c), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
 
 
-def new_act_nd(n, c, spatial, dev):
+def new_act_nd(n, c, spatial, dev, dtype=torch.float32):
     """Fresh channels-last activation, logical [n, c, *spatial] (2-D or 3-D)."""
-    t = torch.empty((n, *spatial, c), dtype=torch.float32, device=dev)
+    t = torch.empty((n, *spatial, c), dtype=dtype, device=dev)
     return t.movedim(-1, 1)
 
 
@@ -193,7 +202,12 @@ class PackPlan:
             for mode in ((0, 1) if with_dgrad and w.requires_grad else (0,)):
                 n, k = (co, ci) if mode == 0 else (ci, co)
                 npad, kpad = _ceil16(n), _ceil16(k)
-                buf = sbuf = None
+                buf = sbuf = hbuf = None
+                if ACT_HALF and isinstance(m, torch.nn.Conv3d) and k % 8 == 0 and taps in (1, 27):   # f16 pack (csrc/conv_h.hip)
+                    kp32 = (k + 31) // 32 * 32
+                    hbuf = torch.empty((taps, npad, kp32), dtype=torch.float16, device=dev)
+                    recs.append((w, hbuf, co, ci, taps, mode | 4, npad, kp32, total))
+                    total += taps * npad * kp32
                 if not (mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0):   # else served zero-copy by pack_weight
                     buf = torch.empty((taps, npad, kpad), dtype=torch.float32, device=dev)
                     recs.append((w, buf, co, ci, taps, mode, npad, kpad, total))
@@ -203,7 +217,7 @@ class PackPlan:
                     sbuf = torch.empty((taps, npad, kp32 * 3 // 2), dtype=torch.float32, device=dev)
                     recs.append((w, sbuf, co, ci, taps, mode | 2, npad, kp32, total))
                     total += taps * npad * kp32
-                self.entries.append((w, mode, buf, sbuf))
+                self.entries.append((w, mode, buf, sbuf, hbuf))
         self.total, self.n = total, len(recs)
         self.valid = False
         _plans.append(self)
@@ -213,12 +227,12 @@ class PackPlan:
             assert len(raw) == self.n * L.query("arco_pack_desc_bytes")
             self.desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
             self.ptrs = [(w.data_ptr(), w) for (w, *_r) in recs]
-            for w, mode, buf, sbuf in self.entries:
+            for w, mode, buf, sbuf, hbuf in self.entries:
                 d = getattr(w, "_arco_plan", None)
                 if d is None:
                     d = {}
                     w._arco_plan = d
-                d[mode] = (self, buf, sbuf)
+                d[mode] = (self, buf, sbuf, hbuf)
 
     def refresh(self):
         """Re-pack every weight of the plan (one launch).  Called by whoever changed the weights."""
@@ -249,8 +263,12 @@ def _split_ok(taps, nbd, h, w, k, n, ld):
     return r
 
 
-def _pack_now(w, co, ci, taps, mode, split):
+def _pack_now(w, co, ci, taps, mode, split, half=False):
     n, k = (co, ci) if mode == 0 else (ci, co)
+    if half:
+        wp = torch.empty((taps, _ceil16(n), (k + 31) // 32 * 32), dtype=torch.float16, device=w.device)
+        L.call("arco_pack_conv_weight", L.ptr(w), co, ci, taps, mode | 4, L.ptr(wp))
+        return wp
     if split:
         wp = torch.empty((taps, _ceil16(n), (k + 31) // 32 * 32 * 3 // 2), dtype=torch.float32, device=w.device)
     else:
@@ -259,17 +277,45 @@ def _pack_now(w, co, ci, taps, mode, split):
     return wp
 
 
-def pack_weight(weight, taps, mode):
+def _pack_half(weight, taps, mode):
+    """The f16 pack [taps][Npad][ceil32(K)] of a conv weight (f16 activation storage): from the PackPlan, else per weight-epoch."""
+    plan = getattr(weight, "_arco_plan", None)
+    if plan is not None and mode in plan and plan[mode][0].valid and plan[mode][3] is not None:
+        return plan[mode][3]
+    capturing = torch.cuda.is_current_stream_capturing()
+    cache = getattr(weight, "_arco_pack_h", None)
+    key = (mode, weight._version)
+    if cache is not None and not capturing:
+        hit = cache.get(key)
+        if hit is not None and hit[0] == WEIGHT_EPOCH:
+            return hit[1]
+    co, ci = int(weight.shape[0]), int(weight.shape[1])
+    wp = _pack_now(weight.detach().contiguous(), co, ci, taps, mode, False, half=True)
+    if not capturing:
+        try:
+            if cache is None:
+                cache = weight._arco_pack_h = {}
+            cache.clear() if len(cache) > 4 else None
+            cache[key] = (WEIGHT_EPOCH, wp)
+        except AttributeError:
+            pass
+    return wp
+
+
+def pack_weight(weight, taps, mode, half=False):
     """torch [Cout, Cin, kh, kw] -> Wp[taps][Npad][Kpad]; mode 0 forward, 1 dgrad (flipped+transposed).
     Served from the module's PackPlan when one is valid, else cached per weight-epoch.  With CONV_MMA == 3 the returned
-    tensor carries `_arco_split`: the same weights in the split-bf16 operand format (conv_raw picks the one the kernel takes)."""
+    tensor carries `_arco_split`: the same weights in the split-bf16 operand format (conv_raw picks the one the kernel takes).
+    half=True: the f16 pack of the f16-storage kernels."""
+    if half:
+        return _pack_half(weight, taps, mode)
     co, ci = int(weight.shape[0]), int(weight.shape[1])
     w = weight.detach()
     want_split = CONV_MMA == 3 and (ci if mode == 0 else co) % 4 == 0
     zero_copy = mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0 and w.is_contiguous()
     plan = getattr(weight, "_arco_plan", None)
     if plan is not None and mode in plan and plan[mode][0].valid:
-        _, buf, sbuf = plan[mode]
+        _, buf, sbuf, _h = plan[mode]
         if (buf is not None or zero_copy) and (sbuf is not None or not want_split):
             wp = buf if buf is not None else w.view(co, ci)
             wp._arco_split = sbuf if want_split else None
@@ -296,18 +342,30 @@ def pack_weight(weight, taps, mode):
     return wp
 
 
+def use_half(x, taps, ci):
+    """Does a convolution of x run on the f16-storage kernels?  Yes when x is f16, or when x is the fp32 one-channel volume
+    entering the V-Net's first 3x3x3 layer in f16 mode (that layer's output opens the f16 region)."""
+    return _is_half(x) or (ACT_HALF and taps == 27 and ci == 1 and x.dim() == 5)
+
+
 def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1, sp=None,
-             stat_groups=1, grad=False):
+             stat_groups=1, grad=False, half=False):
     """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out channels-last, stat slabs or None).
-    2-D: nb images of h x w -> out [nb,n,h,w].  3-D (d3 > 1): nb volumes of d3 planes -> out [nb,n,d3,h,w]."""
+    2-D: nb images of h x w -> out [nb,n,h,w].  3-D (d3 > 1): nb volumes of d3 planes -> out [nb,n,d3,h,w].
+    half: f16 activation storage - out (and xr, unless k == 1) are f16, wp is the f16 pack (k == 1: the fp32 pack)."""
+    odt = torch.float16 if half else torch.float32
     if sp is not None:
-        out = new_act_nd(nb, n, sp, xr.device)         # keeps the caller's rank (a 3-D volume may have depth 1)
+        out = new_act_nd(nb, n, sp, xr.device, odt)    # keeps the caller's rank (a 3-D volume may have depth 1)
     elif d3 > 1:
-        out = new_act_nd(nb, n, (d3, h, w), xr.device)
+        out = new_act_nd(nb, n, (d3, h, w), xr.device, odt)
     else:
         out = new_act(nb, n, h, w, xr.device)
     mma = 0
-    if CONV_MMA == 3:
+    if half:
+        if residual is not None or (d3 <= 1 and sp is None):
+            raise RuntimeError("arco_amd: f16 activation storage covers the volume path's convolutions without a residual operand")
+        mma = 4
+    elif CONV_MMA == 3:
         sp_ = getattr(wp, "_arco_split", None)
         if sp_ is not None and _split_ok(taps, nb * d3, h, w, k, n, ld):
             wp, mma = sp_, 3
@@ -355,8 +413,12 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
             if rec["n"] % PROFILE_EVERY == 1 % PROFILE_EVERY:
                 prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 prof[0].record()
+        if _is_half(dzr):     # f16 activation storage (xr is f16 too, or the first layer's fp32 one-channel volume)
+            mma = 4
+        else:
+            mma = 3 if (CONV_MMA == 3 and taps in (9, 27)) else (2 if (CONV_MMA in (1, 2) and taps == 27) else 0)
         L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
-               accumulate, 3 if (CONV_MMA == 3 and taps in (9, 27)) else (2 if (CONV_MMA in (1, 2) and taps == 27) else 0))
+               accumulate, mma)
         if prof is not None:
             prof[1].record()
             rec["timed"].append((prof[0], prof[1], flop, (taps, nb * d3 * h * w, co, ci)))
@@ -394,7 +456,7 @@ def _grad_into(param, compute):
 def colsum(xr, ld, m, c):
     ws = torch.empty(1024 * c, dtype=torch.float32, device=xr.device)
     out = torch.empty(c, dtype=torch.float32, device=xr.device)
-    L.call("arco_colsum", L.ptr(xr), ld, m, c, L.ptr(ws), L.ptr(out), 0)
+    L.call("arco_colsum_h" if _is_half(xr) else "arco_colsum", L.ptr(xr), ld, m, c, L.ptr(ws), L.ptr(out), 0)
     return out
 
 
@@ -410,14 +472,15 @@ class ConvFn(torch.autograd.Function):
         taps = _taps(weight)
         xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
-        wp = pack_weight(weight, taps, 0)
+        half = use_half(x, taps, ci)
+        wp = pack_weight(weight, taps, 0, half=half and ci != 1)
         if isinstance(residual, torch.Tensor):              # y = conv(x) + R  (R: any tensor of y's shape)
             rr, ldr = rows_view(residual)
             res_self = False
         else:                                               # True: y = conv(x) + x
             rr, ldr = (xr, ld) if residual else (None, 0)
             res_self = bool(residual)
-        y, _ = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, residual=rr, ld_res=ldr, d3=d3, sp=sp)
+        y, _ = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, residual=rr, ld_res=ldr, d3=d3, sp=sp, half=half)
         ctx.save_for_backward(x, weight)
         ctx.residual, ctx.has_bias, ctx.taps = res_self, bias is not None, taps
         ctx.res_tensor = isinstance(residual, torch.Tensor)
@@ -432,9 +495,10 @@ class ConvFn(torch.autograd.Function):
         ci = int(x.shape[1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wd = pack_weight(weight, taps, 1)
+            half = _is_half(dy)
+            wd = pack_weight(weight, taps, 1, half=half)
             dx, _ = conv_raw(dyr, ldy, co, wd, ci, nv, h, w, taps, grad=True, residual=dyr if ctx.residual else None,
-                             ld_res=ldy if ctx.residual else 0, d3=d3, sp=sp)
+                             ld_res=ldy if ctx.residual else 0, d3=d3, sp=sp, half=half)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -446,8 +510,8 @@ class ConvFn(torch.autograd.Function):
 
 def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out, ld_out=None, groups=1):
     seed_dev = SEED_DEV if (p > 0 and torch.cuda.is_current_stream_capturing()) else None
-    L.call("arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
-           float(slope), int(drop_mode), float(p), seed, P, L.ptr(out), co if ld_out is None else ld_out,
+    L.call("arco_bn_act_fwd_h" if _is_half(zr) else "arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd),
+           L.ptr(gamma), L.ptr(beta), float(slope), int(drop_mode), float(p), seed, P, L.ptr(out), co if ld_out is None else ld_out,
            L.ptr(seed_dev), groups)
     return seed_dev
 
@@ -460,7 +524,11 @@ def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, s
     m = zr.shape[0]
     nblk = L.query("arco_chan_stats_blocks", m // groups)
     ws = torch.empty(groups * (2 * co * nblk + 2 * co), dtype=torch.float32, device=da.device)
-    dz = new_act_nd(int(z.shape[0]), co, tuple(int(v) for v in z.shape[2:]), da.device)
+    half = _is_half(zr)
+    if half != _is_half(dar):          # a gradient that reached an f16 activation in fp32 (or the reverse): follow the activation
+        dar = dar.to(zr.dtype)
+        ldd = dar.stride(0)
+    dz = new_act_nd(int(z.shape[0]), co, tuple(int(v) for v in z.shape[2:]), da.device, zr.dtype)
     dgamma = dbeta = None
     acc = 0
     if gamma is not None:
@@ -474,9 +542,9 @@ def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, s
             db_t = dbeta = torch.empty_like(beta)
     else:
         dg_t = db_t = None
-    L.call("arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma),
-           L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dz), co, L.ptr(seed_dev),
-           groups)
+    L.call("arco_bn_act_bwd_h" if half else "arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd),
+           L.ptr(gamma), L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dz), co,
+           L.ptr(seed_dev), groups)
     return dz, dgamma, dbeta
 
 
@@ -494,12 +562,13 @@ class ConvBnActFn(torch.autograd.Function):
         xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
         m = nv * d3 * h * w
-        wp = pack_weight(weight, taps, 0)
+        half = use_half(x, taps, ci)
+        wp = pack_weight(weight, taps, 0, half=half and ci != 1)
         G = BN_GROUPS
         if G > 1 and nv % G != 0:
             raise RuntimeError(f"arco_amd: bn_groups({G}) needs a batch that is a multiple of {G}, got {nv}")
         z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, stats=True, d3=d3, sp=sp,
-                                       stat_groups=G)
+                                       stat_groups=G, half=half)
         mean = torch.empty(G * co, dtype=torch.float32, device=x.device)      # [G][co]
         istd = torch.empty(G * co, dtype=torch.float32, device=x.device)
         d0, dbuf = _defer_args(running_mean, running_var, co, G, momentum)
@@ -511,7 +580,7 @@ class ConvBnActFn(torch.autograd.Function):
             a, ld_a = buf[:, :co], co + int(cat_room)
             _LAST_CAT_BUF = buf
         else:
-            a, ld_a = new_act_nd(nv, co, sp, x.device), co
+            a, ld_a = new_act_nd(nv, co, sp, x.device, z.dtype), co
         zr, ldz = rows_view(z)
         ctx.pool = bool(pool)
         ctx.groups = G
@@ -556,8 +625,9 @@ class ConvBnActFn(torch.autograd.Function):
         dzr, ldzz = rows_view(dz)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wd = pack_weight(weight, taps, 1)
-            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3, sp=sp, grad=True)
+            half = _is_half(dz)
+            wd = pack_weight(weight, taps, 1, half=half)
+            dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3, sp=sp, grad=True, half=half)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if has_bias and ctx.needs_input_grad[2]:
@@ -595,14 +665,14 @@ class BnActFn(torch.autograd.Function):
             nblk = L.query("arco_chan_stats_blocks", m // G)
             ssum = torch.empty((co, G * nblk), dtype=torch.float32, device=z.device)
             ssq = torch.empty((co, G * nblk), dtype=torch.float32, device=z.device)
-            L.call("arco_chan_stats", L.ptr(zr), ldz, m, co, L.ptr(ssum), L.ptr(ssq), G)
+            L.call("arco_chan_stats_h" if _is_half(zr) else "arco_chan_stats", L.ptr(zr), ldz, m, co, L.ptr(ssum), L.ptr(ssq), G)
             mean = torch.empty(G * co, dtype=torch.float32, device=z.device)
             istd = torch.empty(G * co, dtype=torch.float32, device=z.device)
             d0, dbuf = _defer_args(running_mean, running_var, co, G, momentum)
             L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), G * nblk, co, m, float(eps), float(momentum), L.ptr(mean),
                    L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G, d0, L.ptr(dbuf))
         seed = _next_seed() if p > 0 else 0
-        a = new_act_nd(int(z.shape[0]), co, sp, z.device)
+        a = new_act_nd(int(z.shape[0]), co, sp, z.device, zr.dtype)
         ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a, None, G)
         ctx.groups = G
         ctx.save_for_backward(z, mean, istd, gamma, beta)
@@ -636,14 +706,15 @@ def _s2d3(x, inverse):
     n, c = int(x.shape[0]), int(x.shape[1])
     sp = [int(v) for v in x.shape[2:]]
     xr, ld = rows_view(x)
+    e = 2 if _is_half(xr) else 1          # the kernel permutes 4-byte words: an f16 row of C channels is a row of C / 2 words
     if not inverse:
         x2, y2, z2 = sp[0] // 2, sp[1] // 2, sp[2] // 2
-        out = new_act_nd(n, 8 * c, (x2, y2, z2), x.device)
-        L.call("arco_s2d3", L.ptr(xr), ld, n, x2, y2, z2, c, L.ptr(out), 8 * c, 0)
+        out = new_act_nd(n, 8 * c, (x2, y2, z2), x.device, xr.dtype)
+        L.call("arco_s2d3", L.ptr(xr), ld // e, n, x2, y2, z2, c // e, L.ptr(out), 8 * c // e, 0)
     else:
         cv = c // 8
-        out = new_act_nd(n, cv, (2 * sp[0], 2 * sp[1], 2 * sp[2]), x.device)
-        L.call("arco_s2d3", L.ptr(out), cv, n, sp[0], sp[1], sp[2], cv, L.ptr(xr), ld, 1)
+        out = new_act_nd(n, cv, (2 * sp[0], 2 * sp[1], 2 * sp[2]), x.device, xr.dtype)
+        L.call("arco_s2d3", L.ptr(out), cv // e, n, sp[0], sp[1], sp[2], cv // e, L.ptr(xr), ld // e, 1)
     return out
 
 
@@ -798,12 +869,25 @@ def conv_bn_act_eval(x, weight, bias, gamma, beta, running_mean, running_var, sl
         taps = _taps(weight)
         xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
         co = int(weight.shape[0])
-        z, _ = conv_raw(xr, ld, ci, pack_weight(weight, taps, 0), co, nv, h, w, taps, bias=bias, d3=d3, sp=sp)
-        istd = torch.rsqrt(running_var + eps)
-        a = new_act_nd(nv, co, sp, x.device)
+        half = use_half(x, taps, ci)
+        z, _ = conv_raw(xr, ld, ci, pack_weight(weight, taps, 0, half=half and ci != 1), co, nv, h, w, taps, bias=bias, d3=d3, sp=sp,
+                        half=half)
+        return bn_act_eval(z, gamma, beta, running_mean, running_var, slope, eps)
+
+
+def bn_act_eval(z, gamma, beta, running_mean, running_var, slope=0.0, eps=1e-5):
+    """lrelu(BN_eval(z)) with the running statistics (inference; no autograd); follows z's storage type."""
+    with torch.no_grad():
         zr, ldz = rows_view(z)
-        L.call("arco_bn_act_fwd", L.ptr(zr), ldz, nv * d3 * h * w, co, L.ptr(running_mean), L.ptr(istd), L.ptr(gamma),
-               L.ptr(beta), float(slope), 0, 0.0, 0, d3 * h * w, L.ptr(a), co, None, 1)
+        co = int(z.shape[1])
+        sp = tuple(int(v) for v in z.shape[2:])
+        P = 1
+        for v in sp:
+            P *= v
+        istd = torch.rsqrt(running_var + eps)
+        a = new_act_nd(int(z.shape[0]), co, sp, z.device, zr.dtype)
+        L.call("arco_bn_act_fwd_h" if _is_half(zr) else "arco_bn_act_fwd", L.ptr(zr), ldz, zr.shape[0], co, L.ptr(running_mean),
+               L.ptr(istd), L.ptr(gamma), L.ptr(beta), float(slope), 0, 0.0, 0, P, L.ptr(a), co, None, 1)
         return a
 
 
@@ -816,6 +900,36 @@ def bn_act(z, gamma, beta, running_mean, running_var, slope=0.0, p=0.0, drop_mod
 def dropout3d(x, p):
     """nn.Dropout3d(p) in training mode: whole (sample, channel) volumes are dropped (vnetWithArgs.py:195,238)."""
     return BnActFn.apply(x, None, None, None, None, 1.0, p, 2, 0.1, 1e-5)
+
+
+class _FromHalfFn(torch.autograd.Function):
+    """The boundary of the f16 region: an f16 activation leaves it as fp32; the fp32 gradient enters it multiplied by
+    LOSS_SCALE (gradients of 1e-7 would flush in f16) - every parameter gradient produced inside the region carries the
+    factor, and the trainer divides it out of the flat gradient buffer before the optimiser step."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xr, ld = rows_view(x)
+        c = int(x.shape[1])
+        assert ld == c, "from_half: dense channels-last activation expected"
+        y = new_act_nd(int(x.shape[0]), c, tuple(int(v) for v in x.shape[2:]), x.device)
+        L.call("arco_cast_h2f", L.ptr(xr), xr.numel(), L.ptr(y))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dyr, ld = rows_view(dy)
+        c = int(dy.shape[1])
+        if ld != c:
+            dyr = dyr.contiguous()
+        dx = new_act_nd(int(dy.shape[0]), c, tuple(int(v) for v in dy.shape[2:]), dy.device, torch.float16)
+        L.call("arco_cast_f2h", L.ptr(dyr), dyr.numel(), float(LOSS_SCALE), L.ptr(dx))
+        return dx
+
+
+def from_half(x):
+    """fp32 view of an activation for the consumers outside the f16 region (identity for fp32 tensors)."""
+    return _FromHalfFn.apply(x) if _is_half(x) else x
 
 
 def space_to_depth3(x):

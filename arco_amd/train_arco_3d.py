@@ -33,6 +33,12 @@ def build_parser():
     p.set_defaults(patch_size=[112, 112, 80], func='asmc', k5=0.1, exp='LA/example_training', model='vnet', max_iterations=6000,
                    root_path='/home/weicheng/selfLearning/DTC/data/2018LA_Seg_Training Set')       # train_arco_3d.py:27-36
     next(a for a in p._actions if a.dest == 'conv_mma').choices = ['f32x3', 'f32', 'f16', 'bf16']   # the volume kernels' extra modes
+    p.add_argument('--act_dtype', type=str, default='f32', choices=['f32', 'f16'],
+                   help="f16: the V-Net's activations and activation gradients are stored as f16 (BASELINE configs[4], 'fp16 MFMA "
+                        "conv'): f16 matrix cores with fp32 accumulation, fp32 weights / BatchNorm statistics / loss / optimizer; "
+                        "heads and losses stay fp32 (--conv_mma applies to them)")
+    p.add_argument('--loss_scale', type=float, default=16384.0,
+                   help='--act_dtype f16: gradients enter the f16 region multiplied by this power of two')
     p.add_argument('--eqv_pass', type=int, default=1,
                    help='1: run the equivariance block of train_arco_3d.py:368-388 (warp + one more student forward); '
                         'its loss only enters the objective at iteration 0 there (:390-393), afterwards it is a logged '
@@ -48,6 +54,8 @@ class ArcoStep3D:
         self.dev = torch.device(device)
         C = args.num_classes
         ops.CONV_MMA = {"f32": 0, "f16": 1, "bf16": 2, "f32x3": 3}[getattr(args, "conv_mma", "f32x3")]
+        ops.ACT_HALF = getattr(args, "act_dtype", "f32") == "f16"          # before the PackPlans: they carry the f16 packs
+        ops.LOSS_SCALE = float(getattr(args, "loss_scale", 16384.0))
         self.memobank, self.queue_ptrlis, self.queue_size = [], [], []
         for i in range(C):                                                # :144-151
             self.memobank.append([torch.randn(1, REP_DIM_3D)])
@@ -232,6 +240,8 @@ class ArcoStep3D:
         loss = ops.combine_terms(ws, terms)           # one launch (and one for its backward) instead of a chain of 0-d ops
         self.optimizer.zero_grad()
         loss.backward()
+        if ops.ACT_HALF:       # the V-Net's parameter gradients carry the loss scale of the f16 region
+            self.optimizer.flat_g[:self.heads_start].mul_(1.0 / ops.LOSS_SCALE)
         adist.allreduce_grads(self.optimizer)
         self.optimizer.step()
         self.isd._momentum_update_key_encoder()

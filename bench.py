@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
 PEAK_F16_MFMA_TFLOPS = 2500.0       # dense f16/bf16 MFMA (MI355X_MICROARCH.md); --conv_mma f16 launches are priced against it
 PEAK_SPLIT_TFLOPS = 2500.0 / 6.0     # split-bf16 mode: 6 bf16 MFMAs per fp32-accurate product -> 416.7 TFLOP/s of ALGORITHMIC fp32 work
-PEAK_BY_MMA = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_F16_MFMA_TFLOPS, 2: PEAK_F16_MFMA_TFLOPS, 3: PEAK_SPLIT_TFLOPS}
+PEAK_BY_MMA = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_F16_MFMA_TFLOPS, 2: PEAK_F16_MFMA_TFLOPS, 3: PEAK_SPLIT_TFLOPS, 4: PEAK_F16_MFMA_TFLOPS}
 PEAK_HBM_TBS = 8.0
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes):
 # profiles/r01_pmc_conv_traffic.md (3x3 backbone kernel) and profiles/r01_pmc_gemm_traffic.md; key (taps, M, N, K)
@@ -62,8 +62,10 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 
 
 def conv_algorithmic_bytes(taps, m, n, k, mma):
-    """Bytes a conv / GEMM launch must move: the input read once, the output written once (fp32), the packed weights
-    (split-bf16: 6 B per weight, else 4 B)."""
+    """Bytes a conv / GEMM launch must move: the input read once, the output written once (fp32; f16 storage, mma 4: 2 B), the
+    packed weights (split-bf16: 6 B per weight, f16 storage: 2 B, else 4 B)."""
+    if mma == 4:
+        return 2.0 * m * (k + n) + 2.0 * taps * n * k
     return 4.0 * m * (k + n) + (6.0 if mma == 3 else 4.0) * taps * n * k
 
 
@@ -119,13 +121,19 @@ def spawn_ranks(a, argv):
 
 
 MMA_NAMES = {0: "fp32 MFMA 16x16x4", 1: "f16-operand MFMA 16x16x16, fp32 accumulate", 2: "bf16-operand MFMA 16x16x16, fp32 accumulate",
-             3: "split-bf16 (3 x bf16 = exact fp32 operands) MFMA 16x16x32, fp32 accumulate"}
+             3: "split-bf16 (3 x bf16 = exact fp32 operands) MFMA 16x16x32, fp32 accumulate",
+             4: "f16 storage, f16 MFMA 16x16x32, fp32 accumulate"}
 
 
 def _kernel_name(key):
     if isinstance(key, tuple):
         return f"wgrad<taps={key[1]},co={key[2]},ci={key[3]}> (weight gradient, fp32 MFMA 16x16x4)"
     mma, key = key // 100000000, key % 100000000
+    if mma == 4 and not (9700000 <= key < 9900000):
+        flat = 9500000 <= key < 9700000
+        base = key - (9500000 if flat else (key // 1000000) * 1000000)
+        return (f"hconv_kernel<{key // 1000000},{base // 1000},{base % 1000},...{',FLAT' if flat else ''}> (f16 activation storage, "
+                "v_mfma_f32_16x16x32_f16, fp32 accumulate; 3x3x3 depth taps looped)")
     if 9700000 <= key < 9900000:
         return f"conv3x3_image_kernel<Cin={key % 100000 // 1000}> (few-channel input: the taps are the reduction dimension; {MMA_NAMES[mma]})"
     if 9500000 <= key < 9700000:        # flat-position tiles of the 3x3x3 kernels (narrow planes)
@@ -269,8 +277,9 @@ SUBS = {   # every entry: kind, batch_size, patch, classes, mma (+ in_chns for 2
     "cityscapes_19c_512x1024": dict(kind="2d", batch_size=1, patch=[512, 1024], classes=19, in_chns=3, mma="f32x3",
                                     workload="Cityscapes-shaped 19-class 3x512x1024, 2 images/GPU (--batch_size 1), D=496, "
                                              "4096-key/class queue (the per-GPU shard of BASELINE.json configs[3])"),
-    "lits_160x160x96_f16": dict(kind="3d", batch_size=1, patch=[160, 160, 96], classes=2, mma="f16",
-                                workload="LiTS-shaped 3D 2-class 160x160x96, 1+1 volumes/GPU, --conv_mma f16 "
+    "lits_160x160x96_f16": dict(kind="3d", batch_size=1, patch=[160, 160, 96], classes=2, mma="f32x3", act="f16",
+                                workload="LiTS-shaped 3D 2-class 160x160x96, 1+1 volumes/GPU, --act_dtype f16: f16 activation "
+                                         "storage + f16 matrix cores in the V-Net, fp32 heads / losses / statistics / optimizer "
                                          "(the per-GPU shard of BASELINE.json configs[4])"),
 }
 
@@ -287,7 +296,8 @@ def run_sub(name, steps):
     if cfg["kind"] == "3d":
         from arco_amd import train_arco_3d as T3
         args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1",
-                                             "--num_classes", str(cfg["classes"]), "--conv_mma", cfg["mma"]])
+                                             "--num_classes", str(cfg["classes"]), "--conv_mma", cfg["mma"],
+                                             "--act_dtype", cfg.get("act", "f32")])
         args.patch_size = cfg["patch"]
         st = T3.ArcoStep3D(args, dev)
         l, ll = T3.synthetic_volume_batch(b, args.patch_size, cfg["classes"], 1, dev)
@@ -315,7 +325,8 @@ def run_sub(name, steps):
     roof, whole = roofline_from_profile(prof, 2, ms)
     terms = {k: round(float(v), 5) for k, v in st.last_terms.items()}
     print(json.dumps({"sub": name, "workload": cfg["workload"], "ms_per_step": round(ms, 3), "steps_per_s": round(1e3 / ms, 3),
-                      "steps": steps, "dtype": {"f32": "f32", "f32x3": "f32 (split-bf16 matrix-core mode, fp32-accurate)"}.get(cfg["mma"], "f32 storage, f16/bf16 MFMA operands"),
+                      "steps": steps, "dtype": ("f16 activation storage + f16 MFMA (fp32 accumulate) in the V-Net; fp32 elsewhere" if cfg.get("act") == "f16" else
+                                                {"f32": "f32", "f32x3": "f32 (split-bf16 matrix-core mode, fp32-accurate)"}.get(cfg["mma"], "f32 storage, f16/bf16 MFMA operands")),
                       "flags": "trainer defaults" + ("" if cfg["kind"] == "2d" else " (--eqv_pass 1)"),
                       "peak_mem_gb": round(mem, 2), "loss_terms": terms, "roofline": roof, "whole_step": whole}))
 

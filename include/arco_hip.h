@@ -331,6 +331,31 @@ long arco_mt_skip(uint8_t* state, long state_bytes, uint64_t n);
    too); from any other state they are ignored.  Same draws, same final generator state.                              */
 long arco_mt_pregen(const uint8_t* state, long state_bytes, long n_draws, int background);
 
+/* ---- f16 ACTIVATION STORAGE of the volume path (BASELINE.json configs[4] "fp16 MFMA conv"; csrc/conv_h.hip) --------------
+ * The V-Net body (vnetWithArgs.py:5-31 ConvBlock, :67-91 DownsamplingConvBlock, :94-118 UpsamplingDeconvBlock, :145-252 VNet)
+ * with every activation and activation gradient held as f16 in HBM; weights, BatchNorm statistics, parameter gradients,
+ * loss and optimizer fp32.  Entry points that take f16 tensors:
+ *   arco_conv3d_fwd(..., mma = 4):   `in` and `out` are f16 rows (taps 27 with K = 1: `in` is the fp32 one-channel volume, `out`
+ *                                    f16), Wp is the f16 pack of arco_pack_conv_weight(mode | 4) = [taps][ceil16(N)][ceil32(K)]
+ *                                    halves (the K = 1 layer: the fp32 pack); v_mfma_f32_16x16x32_f16, fp32 accumulate, BN partials
+ *                                    of the rounded outputs; no residual operand.
+ *   arco_conv3d_wgrad(..., mma = 4): dZ and `in` f16 (Cin = 1: `in` fp32), dW fp32; operands transposed by ds_read_b64_tr_b16.
+ *   arco_chan_stats_h / arco_bn_act_fwd_h / arco_bn_act_bwd_h / arco_colsum_h: the fp32 entry points of the same name on f16
+ *                                    tensors (fp32 arithmetic, statistics and parameter gradients).
+ *   arco_cast_h2f / arco_cast_f2h:   the region's boundary: outputs to fp32; fp32 gradients in, multiplied by the loss scale.
+ * Space-to-depth (arco_s2d3) is a permutation of 4-byte words: f16 tensors pass with C / 2 and ld / 2.                       */
+int arco_chan_stats_h(const void* X, long ldx, long M, int C, float* ssum, float* ssq, int groups, void* stream);
+int arco_bn_act_fwd_h(const void* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                      const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, void* A, long lda,
+                      const uint64_t* seed_dev, int groups, void* stream);
+int arco_bn_act_bwd_h(const void* dA, long ldd, const void* Z, long ldz, long M, int C, const float* mean,
+                      const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
+                      uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, void* dZ, long ldo,
+                      const uint64_t* seed_dev, int groups, void* stream);
+int arco_colsum_h(const void* X, long ldx, long M, int C, float* ws, float* out, int accumulate, void* stream);
+int arco_cast_h2f(const void* x, long n, float* y, void* stream);
+int arco_cast_f2h(const float* x, long n, float scale, void* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

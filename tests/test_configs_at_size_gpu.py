@@ -346,13 +346,17 @@ def test_cfg4_cityscapes_shape_vs_cpu_oracle():
 # configs[4]: LiTS-shaped 160 x 160 x 96, 1 + 1 volumes per GPU, f16 MFMA operands (tolerance 1e-2)
 # ------------------------------------------------------------------------------------------------------------------
 def test_cfg5_lits_f16_step_at_full_size_tracks_fp32():
+    """Both reduced-precision modes of the volume path against the fp32 step (f32 = native fp32 MFMA) from the same weights and
+    batches: "f16" = f16 MFMA operands on fp32 tensors (--conv_mma f16), "f16s" = f16 ACTIVATION STORAGE (--act_dtype f16: every
+    V-Net activation and activation gradient f16 in HBM, csrc/conv_h.hip).  Budget of BASELINE.json configs[4]: 1e-2."""
     from arco_amd import ops, train_arco_3d as T3
     sp = (160, 160, 96)
     out = {}
     try:
-        for mode in ("f32", "f16"):
-            st = _make3d(["--eqv_pass", "0"], patch=sp, b=1, mma=mode)
-            assert ops.CONV_MMA == {"f32": 0, "f16": 1}[mode]
+        for mode in ("f32", "f16", "f16s"):
+            extra = ["--eqv_pass", "0"] + (["--act_dtype", "f16"] if mode == "f16s" else [])
+            st = _make3d(extra, patch=sp, b=1, mma={"f32": "f32", "f16": "f16", "f16s": "f32x3"}[mode])
+            assert ops.CONV_MMA == {"f32": 0, "f16": 1, "f16s": 3}[mode] and ops.ACT_HALF == (mode == "f16s")
             _drop_off(st)
             st.keep_debug = True
             terms = []
@@ -362,14 +366,16 @@ def test_cfg5_lits_f16_step_at_full_size_tracks_fp32():
                 seed_all(600 + it)
                 st.step(l, ll, u)
                 terms.append([float(st.last_terms[k]) for k in ("ce", "dice", "unsup", "reco")])
-            if mode == "f16":
+            if mode != "f32":
                 _check_step_invariants(st, "asmc", 4096, 16, 602)
             out[mode] = np.array(terms)
             del st
             torch.cuda.empty_cache()
     finally:
         ops.CONV_MMA = 3
-    assert np.all(np.isfinite(out["f16"]))
-    np.testing.assert_allclose(out["f16"][0, :2], out["f32"][0, :2], rtol=1e-2)      # first step, same weights: CE / Dice at 1e-2
-    np.testing.assert_allclose(out["f16"][:, :2], out["f32"][:, :2], rtol=5e-2)      # trajectories stay together
-    assert not np.array_equal(out["f16"], out["f32"])                                # the reduced-precision kernels really ran
+        ops.ACT_HALF = False
+    for mode in ("f16", "f16s"):
+        assert np.all(np.isfinite(out[mode]))
+        np.testing.assert_allclose(out[mode][0, :2], out["f32"][0, :2], rtol=1e-2)      # first step, same weights: CE / Dice at 1e-2
+        np.testing.assert_allclose(out[mode][:, :2], out["f32"][:, :2], rtol=5e-2)      # trajectories stay together
+        assert not np.array_equal(out[mode], out["f32"])                                # the reduced-precision kernels really ran

@@ -1,0 +1,233 @@
+"""f16 ACTIVATION STORAGE of the volume path (BASELINE.json configs[4], "fp16 MFMA conv"; csrc/conv_h.hip, the *_h entry points)
+against the fp32 kernels of the same operators on the SAME f16-representable inputs: what differs is only the rounding of the
+stored outputs (2^-11 relative) - products are exact in both (f16 x f16 fits fp32), accumulation is fp32 in both.  Tolerances are
+written per test.  Reference operators: nn.Conv3d / BatchNorm3d / ReLU / ConvTranspose3d of vnetWithArgs.py:5-31,67-118."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last_3d)
+
+
+def _rand_act(rs, shape, dev, scale=1.0):
+    x = torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32)).to(dev)
+    return _cl(x.half())            # f16-representable values, channels-last
+
+
+def _maxrel(a, b):
+    return float((a.float() - b.float()).abs().max()) / max(1e-12, float(b.float().abs().max()))
+
+
+def _l2rel(a, b):
+    return float((a.float() - b.float()).norm()) / max(1e-20, float(b.float().norm()))
+
+
+# (ci, co, D, H, W): rectangular tiles (W % 16 == 0), flat tiles (narrow planes), ragged planes, several N-tile shapes
+CONV3_SHAPES = [(16, 16, 6, 16, 32), (32, 32, 5, 24, 48), (16, 32, 4, 20, 12), (64, 64, 6, 12, 6), (128, 128, 5, 10, 6),
+                (32, 64, 3, 9, 7), (256, 256, 3, 5, 3)]
+
+
+@pytest.mark.parametrize("ci,co,D,H,W", CONV3_SHAPES)
+def test_conv3x3x3_f16_storage_forward_backward(ci, co, D, H, W):
+    from arco_amd import ops
+    dev = "cuda:0"
+    rs = np.random.RandomState(ci + co + W)
+    x16 = _rand_act(rs, (2, ci, D, H, W), dev)
+    w = torch.from_numpy((rs.standard_normal((co, ci, 3, 3, 3)) / np.sqrt(27 * ci)).astype(np.float32)).to(dev)
+    w = w.half().float().requires_grad_(True)              # f16-representable weights: the f16 pack is then exact
+    b = torch.from_numpy(rs.standard_normal(co).astype(np.float32)).to(dev).requires_grad_(True)
+    dy16 = _rand_act(rs, (2, co, D, H, W), dev)
+    outs = {}
+    for mode in ("h", "f"):
+        x = (x16 if mode == "h" else x16.float()).clone().requires_grad_(True)
+        w.grad = b.grad = None
+        y = ops.conv(x, w, b)
+        assert y.dtype == (torch.float16 if mode == "h" else torch.float32)
+        y.backward(dy16 if mode == "h" else dy16.float())
+        outs[mode] = (y.detach().float(), x.grad.float(), w.grad.clone(), b.grad.clone())
+    yh, dxh, dwh, dbh = outs["h"]
+    yf, dxf, dwf, dbf = outs["f"]
+    assert _maxrel(yh, yf) < 1e-3                # one f16 rounding of the output
+    assert _maxrel(dxh, dxf) < 1e-3
+    assert _maxrel(dwh, dwf) < 2e-5              # exact products, fp32 accumulation in another order
+    assert _maxrel(dbh, dbf) < 2e-5
+
+
+@pytest.mark.parametrize("ci,co,M", [(128, 32, (6, 10, 12)), (256, 64, (5, 6, 6)), (32, 128, (8, 12, 16)), (16, 2, (8, 16, 16)),
+                                     (1024, 256, (3, 5, 3)), (256, 1024, (3, 5, 3))])
+def test_conv1x1x1_f16_storage_forward_backward(ci, co, M):
+    from arco_amd import ops
+    dev = "cuda:0"
+    rs = np.random.RandomState(ci + co)
+    x16 = _rand_act(rs, (2, ci, *M), dev)
+    w = torch.from_numpy((rs.standard_normal((co, ci, 1, 1, 1)) / np.sqrt(ci)).astype(np.float32)).to(dev).half().float().requires_grad_(True)
+    b = torch.from_numpy(rs.standard_normal(co).astype(np.float32)).to(dev).requires_grad_(True)
+    dy16 = _rand_act(rs, (2, co, *M), dev)
+    outs = {}
+    for mode in ("h", "f"):
+        x = (x16 if mode == "h" else x16.float()).clone().requires_grad_(True)
+        w.grad = b.grad = None
+        y = ops.conv(x, w, b)
+        y.backward(dy16 if mode == "h" else dy16.float())
+        outs[mode] = (y.detach().float(), x.grad.float(), w.grad.clone(), b.grad.clone())
+    for k, tol in enumerate((1e-3, 1e-3, 2e-5, 2e-5)):
+        assert _maxrel(outs["h"][k], outs["f"][k]) < tol, k
+
+
+def test_first_layer_f16_output_and_weight_gradient():
+    """The one-channel fp32 volume enters the f16 region through the first 3x3x3 layer (vnetWithArgs.py:182 block_one)."""
+    from arco_amd import ops
+    dev = "cuda:0"
+    rs = np.random.RandomState(5)
+    x = _cl(torch.from_numpy(rs.uniform(size=(2, 1, 6, 20, 24)).astype(np.float32)).to(dev))
+    w = torch.from_numpy((rs.standard_normal((16, 1, 3, 3, 3)) / 5).astype(np.float32)).to(dev).requires_grad_(True)
+    b = torch.from_numpy(rs.standard_normal(16).astype(np.float32)).to(dev).requires_grad_(True)
+    dy16 = _rand_act(rs, (2, 16, 6, 20, 24), dev)
+    outs = {}
+    try:
+        for half in (True, False):
+            ops.ACT_HALF = half
+            w.grad = b.grad = None
+            y = ops.conv(x, w, b)
+            assert y.dtype == (torch.float16 if half else torch.float32)
+            y.backward(dy16 if half else dy16.float())
+            outs[half] = (y.detach().float(), w.grad.clone(), b.grad.clone())
+    finally:
+        ops.ACT_HALF = False
+    assert _maxrel(outs[True][0], outs[False][0]) < 1e-3
+    assert _maxrel(outs[True][1], outs[False][1]) < 2e-5
+    assert _maxrel(outs[True][2], outs[False][2]) < 2e-5
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_conv_bn_relu_stage_f16_storage(groups):
+    """conv -> train-mode BatchNorm (statistics from the conv epilogue, of the ROUNDED outputs) -> ReLU, forward and backward;
+    running statistics updated alike."""
+    from arco_amd import ops
+    dev = "cuda:0"
+    rs = np.random.RandomState(11)
+    ci, co = 32, 32
+    x16 = _rand_act(rs, (2, ci, 6, 16, 16), dev)
+    w = torch.from_numpy((rs.standard_normal((co, ci, 3, 3, 3)) / np.sqrt(27 * ci)).astype(np.float32)).to(dev).half().float().requires_grad_(True)
+    b = torch.zeros(co, device=dev, requires_grad=True)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, co).astype(np.float32)).to(dev).requires_grad_(True)
+    beta = torch.from_numpy(rs.standard_normal(co).astype(np.float32) * 0.2).to(dev).requires_grad_(True)
+    da16 = _rand_act(rs, (2, co, 6, 16, 16), dev)
+    outs = {}
+    for mode in ("h", "f"):
+        rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
+        nbt = torch.zeros((), dtype=torch.long, device=dev)
+        x = (x16 if mode == "h" else x16.float()).clone().requires_grad_(True)
+        for t in (w, b, gamma, beta):
+            t.grad = None
+        with ops.bn_groups(groups):
+            a = ops.conv_bn_act(x, w, b, gamma, beta, rm, rv, slope=0.0, p=0.0, num_batches_tracked=nbt)
+        assert a.dtype == (torch.float16 if mode == "h" else torch.float32)
+        a.backward(da16 if mode == "h" else da16.float())
+        outs[mode] = (a.detach().float(), x.grad.float(), w.grad.clone(), gamma.grad.clone(), beta.grad.clone(), rm.clone(), rv.clone())
+    # the f16 path normalises z rounded to f16 (2^-11 of |z| ~ 1) against statistics of the same rounded values.  A rounding can
+    # move a pre-activation across the ReLU kink: the handful of elements it flips carry their whole gradient, so the gradients
+    # are compared in the L2 norm (the flips are a 1e-3 fraction of the elements), the activation element-wise
+    assert _maxrel(outs["h"][0], outs["f"][0]) < 3e-3
+    for k in range(1, 5):
+        assert _l2rel(outs["h"][k], outs["f"][k]) < 1e-2, k
+    for k in (5, 6):
+        assert _maxrel(outs["h"][k], outs["f"][k]) < 1e-3, k
+
+
+def test_bn_act_and_dropout3d_on_f16_tensors():
+    from arco_amd import ops
+    dev = "cuda:0"
+    rs = np.random.RandomState(3)
+    z16 = _rand_act(rs, (2, 16, 4, 8, 8), dev)
+    da16 = _rand_act(rs, (2, 16, 4, 8, 8), dev)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, 16).astype(np.float32)).to(dev).requires_grad_(True)
+    beta = torch.zeros(16, device=dev, requires_grad=True)
+    outs = {}
+    for mode in ("h", "f"):
+        z = (z16 if mode == "h" else z16.float()).clone().requires_grad_(True)
+        gamma.grad = beta.grad = None
+        a = ops.bn_act(z, gamma, beta, torch.zeros(16, device=dev), torch.ones(16, device=dev), slope=0.0)
+        a.backward(da16 if mode == "h" else da16.float())
+        outs[mode] = (a.detach().float(), z.grad.float(), gamma.grad.clone(), beta.grad.clone())
+    assert _maxrel(outs["h"][0], outs["f"][0]) < 2e-3       # same stored z in both: the kink sits at the same elements
+    assert _maxrel(outs["h"][1], outs["f"][1]) < 3e-3
+    assert _maxrel(outs["h"][2], outs["f"][2]) < 1e-4 and _maxrel(outs["h"][3], outs["f"][3]) < 1e-4
+    # Dropout3d: whole (sample, channel) volumes dropped, survivors scaled by 1 / (1 - p); same mask for both storage types
+    ops.reseed_dropout(7)
+    dh = ops.dropout3d(z16, 0.5)
+    ops.reseed_dropout(7)
+    df = ops.dropout3d(z16.float(), 0.5)
+    assert dh.dtype == torch.float16 and _maxrel(dh, df) < 1e-3
+    kept = (dh.float().abs().sum(dim=(2, 3, 4)) > 0)
+    assert 0 < int(kept.sum()) < kept.numel()
+
+
+def test_space_to_depth_and_boundary_casts_on_f16_tensors():
+    from arco_amd import ops
+    dev = "cuda:0"
+    rs = np.random.RandomState(9)
+    x16 = _rand_act(rs, (2, 16, 4, 6, 8), dev)
+    s = ops.space_to_depth3(x16)
+    assert s.dtype == torch.float16 and tuple(s.shape) == (2, 128, 2, 3, 4)
+    assert torch.equal(s.float(), ops.space_to_depth3(x16.float()))
+    assert torch.equal(ops.depth_to_space3(s), x16)
+    x = x16.clone().requires_grad_(True)
+    y = ops.from_half(x)
+    assert y.dtype == torch.float32 and torch.equal(y, x16.float())
+    g = torch.from_numpy((rs.standard_normal(tuple(y.shape)) * 1e-7).astype(np.float32)).to(dev)
+    y.backward(_cl(g))
+    ref = (g * ops.LOSS_SCALE).half()
+    assert x.grad.dtype == torch.float16 and torch.equal(x.grad, _cl(ref))
+    assert float(x.grad.float().abs().max()) > 1e-4          # 1e-7 survives thanks to the loss scale
+
+
+def test_vnet_f16_storage_tracks_fp32_forward_and_gradients():
+    """The whole V-Net (batchnorm, dropout off), 2 volumes of 32 x 32 x 16: logits and every parameter gradient of the f16-storage
+    body against the fp32 body (split-bf16 kernels) from the same weights - the budget of BASELINE.json configs[4] is 1e-2."""
+    from arco_amd import ops
+    from arco_amd.networks.vnetWithArgs import VNet
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    net = VNet(n_channels=1, n_classes=2, normalization='batchnorm', has_dropout=False).to(dev).train()
+    rs = np.random.RandomState(1)
+    x = torch.from_numpy(rs.uniform(size=(2, 1, 32, 32, 16)).astype(np.float32)).to(dev)
+    tgt = torch.from_numpy(rs.standard_normal((2, 2, 32, 32, 16)).astype(np.float32)).to(dev)
+    res = {}
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    try:
+        for half in (False, True):
+            ops.ACT_HALF = half
+            ops.bump_weight_epoch()
+            net.load_state_dict(sd)
+            net.zero_grad()
+            out, f0, fm = net(x)
+            assert out.dtype == torch.float32 and all(f.dtype == torch.float32 for f in fm)
+            loss = ((out - tgt) ** 2).mean() + sum((f ** 2).mean() for f in fm) * 0.1
+            loss.backward()
+            scale = ops.LOSS_SCALE if half else 1.0
+            res[half] = (out.detach().clone(), [f.detach().clone() for f in fm],
+                         {n: p.grad.detach().clone() / scale for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        ops.ACT_HALF = False
+        ops.bump_weight_epoch()
+    # (the deepest level of this small volume normalises over 8 voxels: a BatchNorm over so few samples amplifies the rounding;
+    #  at LiTS size the same comparison is test_cfg5_... in test_configs_at_size_gpu.py)
+    assert _l2rel(res[True][0], res[False][0]) < 5e-3 and _maxrel(res[True][0], res[False][0]) < 3e-2
+    for a, b in zip(res[True][1], res[False][1]):
+        assert _l2rel(a, b) < 5e-3 and _maxrel(a, b) < 3e-2
+    assert set(res[True][2]) == set(res[False][2])
+    worst = 0.0
+    for n, g in res[False][2].items():
+        gh = res[True][2][n]
+        if float(g.abs().max()) < 1e-9:           # conv biases under train-mode BN: exact zeros in both
+            assert float(gh.abs().max()) < 1e-6
+            continue
+        e = float((gh - g).norm()) / float(g.norm())
+        worst = max(worst, e)
+        assert e < 2e-2, (n, e)
+    print("worst relative L2 gradient error", worst)

@@ -9,7 +9,8 @@ random.seed(1337); np.random.seed(1337); torch.manual_seed(1337)
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 eqv = int(os.environ.get("EQV_PASS", "0"))     # 1: with the reference's equivariance block (one more student forward per step)
 args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1", "--num_classes", "2",
-                                     "--eqv_pass", str(eqv), "--conv_mma", os.environ.get("CONV_MMA", "f32"), "--graph_train", os.environ.get("GRAPH_TRAIN", "0")])
+                                     "--eqv_pass", str(eqv), "--conv_mma", os.environ.get("CONV_MMA", "f32"), "--graph_train", os.environ.get("GRAPH_TRAIN", "0"),
+                                     "--act_dtype", os.environ.get("ACT_DTYPE", "f32")])
 if len(sys.argv) > 4:
     args.patch_size = [int(v) for v in sys.argv[2:5]]
 st = T3.ArcoStep3D(args, "cuda:0")
@@ -20,4 +21,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 8
 for _ in range(n): loss, reco = st.step(l, ll, u)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"3D step b={b} patch={args.patch_size} eqv_pass={eqv} conv_mma={args.conv_mma}: {dt*1e3:.1f} ms/step  {1/dt:.2f} steps/s  loss {float(reco):.4f}  mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB")
+print(f"3D step b={b} patch={args.patch_size} eqv_pass={eqv} conv_mma={args.conv_mma} act_dtype={args.act_dtype}: {dt*1e3:.1f} ms/step  {1/dt:.2f} steps/s  loss {float(reco):.4f}  mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB")
