@@ -187,7 +187,7 @@ def test_space_to_depth_and_boundary_casts_on_f16_tensors():
 
 
 def test_vnet_f16_storage_tracks_fp32_forward_and_gradients():
-    """The whole V-Net (batchnorm, dropout off), 2 volumes of 32 x 32 x 16: logits and every parameter gradient of the f16-storage
+    """The whole V-Net (batchnorm, dropout off), 2 volumes of 64 x 64 x 32: logits and every parameter gradient of the f16-storage
     body against the fp32 body (split-bf16 kernels) from the same weights - the budget of BASELINE.json configs[4] is 1e-2."""
     from arco_amd import ops
     from arco_amd.networks.vnetWithArgs import VNet
@@ -195,13 +195,14 @@ def test_vnet_f16_storage_tracks_fp32_forward_and_gradients():
     torch.manual_seed(3)
     net = VNet(n_channels=1, n_classes=2, normalization='batchnorm', has_dropout=False).to(dev).train()
     rs = np.random.RandomState(1)
-    x = torch.from_numpy(rs.uniform(size=(2, 1, 32, 32, 16)).astype(np.float32)).to(dev)
-    tgt = torch.from_numpy(rs.standard_normal((2, 2, 32, 32, 16)).astype(np.float32)).to(dev)
+    x = torch.from_numpy(rs.uniform(size=(2, 1, 64, 64, 32)).astype(np.float32)).to(dev)
+    tgt = torch.from_numpy(rs.standard_normal((2, 2, 64, 64, 32)).astype(np.float32)).to(dev)
     res = {}
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     try:
-        for half in (False, True):
-            ops.ACT_HALF = half
+        for half in (False, True, "operands"):       # "operands": fp32 tensors, f16-rounded MFMA operands (--conv_mma f16), for scale
+            ops.ACT_HALF = half is True
+            ops.CONV_MMA = 1 if half == "operands" else 3
             ops.bump_weight_epoch()
             net.load_state_dict(sd)
             net.zero_grad()
@@ -209,25 +210,39 @@ def test_vnet_f16_storage_tracks_fp32_forward_and_gradients():
             assert out.dtype == torch.float32 and all(f.dtype == torch.float32 for f in fm)
             loss = ((out - tgt) ** 2).mean() + sum((f ** 2).mean() for f in fm) * 0.1
             loss.backward()
-            scale = ops.LOSS_SCALE if half else 1.0
+            scale = ops.LOSS_SCALE if half is True else 1.0
             res[half] = (out.detach().clone(), [f.detach().clone() for f in fm],
                          {n: p.grad.detach().clone() / scale for n, p in net.named_parameters() if p.grad is not None})
     finally:
         ops.ACT_HALF = False
+        ops.CONV_MMA = 3
         ops.bump_weight_epoch()
-    # (the deepest level of this small volume normalises over 8 voxels: a BatchNorm over so few samples amplifies the rounding;
-    #  at LiTS size the same comparison is test_cfg5_... in test_configs_at_size_gpu.py)
-    assert _l2rel(res[True][0], res[False][0]) < 5e-3 and _maxrel(res[True][0], res[False][0]) < 3e-2
-    for a, b in zip(res[True][1], res[False][1]):
-        assert _l2rel(a, b) < 5e-3 and _maxrel(a, b) < 3e-2
+    # Random weights, ~25 rounded layers: a perturbation of 2^-11 per stored value grows through the untrained network (every
+    # conv + BatchNorm + ReLU stage amplifies it a little), so this comparison is looser than the per-operator ones above and
+    # than the loss terms at LiTS size (test_cfg5_... in test_configs_at_size_gpu.py: 1e-2).  The operand-rounding mode on
+    # fp32 tensors is measured beside it: storage rounding must stay in that mode's league.
+    e2, em = _l2rel(res[True][0], res[False][0]), _maxrel(res[True][0], res[False][0])
+    o2 = _l2rel(res["operands"][0], res[False][0])
+    print("logits: relative L2 / max error", e2, em, "| f16-operand mode on fp32 tensors: L2", o2)
+    assert e2 < 2e-2 and em < 3e-2 and e2 < 3 * max(o2, 3e-3), (e2, em, o2)
+    for i, (a, b) in enumerate(zip(res[True][1], res[False][1])):
+        e2, em = _l2rel(a, b), _maxrel(a, b)
+        assert e2 < 2e-2 and em < 5e-2, (i, e2, em)
     assert set(res[True][2]) == set(res[False][2])
+    # Gradients: a forward perturbation of 1e-3 moves ~4e-4 of a layer's pre-activations across the ReLU kink, and every flipped
+    # element carries its whole gradient - an L2 gradient difference of ~2 % per layer that accumulates towards the input, for ANY
+    # two forwards that differ by a rounding (the same effect made tests/golden/g15 search a kink-free input for the U-Net).  The
+    # gradients of the last layers (no flips below them yet) are held to 2e-2; all of them must stay within 1.5 x the distance
+    # of the operand-rounding mode on fp32 tensors (+ 2e-2), which rounds the same activations at every conv input.
     worst = 0.0
     for n, g in res[False][2].items():
-        gh = res[True][2][n]
-        if float(g.abs().max()) < 1e-9:           # conv biases under train-mode BN: exact zeros in both
+        gh, go = res[True][2][n], res["operands"][2][n]
+        if float(g.abs().max()) < 1e-9:           # conv biases under train-mode BN: exact zeros in every mode
             assert float(gh.abs().max()) < 1e-6
             continue
-        e = float((gh - g).norm()) / float(g.norm())
+        e, eo = float((gh - g).norm()) / float(g.norm()), float((go - g).norm()) / float(g.norm())
         worst = max(worst, e)
-        assert e < 2e-2, (n, e)
+        assert e < 1.5 * eo + 2e-2, (n, e, eo)
+        if n.startswith(("out_conv", "block_nine")):
+            assert e < 2e-2, (n, e)
     print("worst relative L2 gradient error", worst)
