@@ -184,13 +184,19 @@ class PackPlan:
     one pack launch per layer per forward.  The owner calls refresh() whenever the weights changed (optimiser
     step / EMA update); pack_weight() then serves the plan's buffers."""
 
-    def __init__(self, modules, with_dgrad):
+    def __init__(self, modules, with_dgrad, half=None):
+        """half: one flag per top-level module - True: the module runs on f16 activations (ops.ACT_HALF: the V-Net body), its
+        Conv3d weights get the f16 pack ONLY (the one-channel first layer keeps the fp32 pack its kernel reads); False / None:
+        fp32 activations (heads), the fp32 / split-bf16 packs."""
         import struct
         recs, self.entries = [], []
         dev = None
         total = 0
-        mods = [m for top in (modules if isinstance(modules, (list, tuple)) else [modules]) for m in top.modules()]
-        for m in mods:
+        tops = modules if isinstance(modules, (list, tuple)) else [modules]
+        flags = list(half) if half is not None else [False] * len(tops)
+        assert len(flags) == len(tops)
+        mods = [(m, bool(f)) for top, f in zip(tops, flags) for m in top.modules()]
+        for m, m_half in mods:
             w = getattr(m, "weight", None)
             if not isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d)) or w is None:
                 continue
@@ -203,11 +209,13 @@ class PackPlan:
                 n, k = (co, ci) if mode == 0 else (ci, co)
                 npad, kpad = _ceil16(n), _ceil16(k)
                 buf = sbuf = hbuf = None
-                if ACT_HALF and isinstance(m, torch.nn.Conv3d) and k % 8 == 0 and taps in (1, 27):   # f16 pack (csrc/conv_h.hip)
+                if m_half and isinstance(m, torch.nn.Conv3d) and k % 8 == 0 and taps in (1, 27):   # f16 pack (csrc/conv_h.hip)
                     kp32 = (k + 31) // 32 * 32
                     hbuf = torch.empty((taps, npad, kp32), dtype=torch.float16, device=dev)
                     recs.append((w, hbuf, co, ci, taps, mode | 4, npad, kp32, total))
                     total += taps * npad * kp32
+                    self.entries.append((w, mode, None, None, hbuf))
+                    continue
                 if not (mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0):   # else served zero-copy by pack_weight
                     buf = torch.empty((taps, npad, kpad), dtype=torch.float32, device=dev)
                     recs.append((w, buf, co, ci, taps, mode, npad, kpad, total))

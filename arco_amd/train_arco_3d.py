@@ -96,10 +96,10 @@ class ArcoStep3D:
                   self.q_feature_extractor):
             m.train()
         # packed conv weights: one launch per weight owner per step (ops.PackPlan), refreshed by the owner
-        plan_s = ops.PackPlan([self.model, self.q_representation, self.q_feature_extractor], True)
+        plan_s = ops.PackPlan([self.model, self.q_representation, self.q_feature_extractor], True, half=[ops.ACT_HALF, False, False])
         self.optimizer.plans = [plan_s]
         pairs = self.isd._ensure_ema_pairs()
-        pairs[0].plans = [ops.PackPlan([self.ema_model], False)]
+        pairs[0].plans = [ops.PackPlan([self.ema_model], False, half=[ops.ACT_HALF])]
         for pr in pairs[1:]:
             pr.plans = [ops.PackPlan([], False)]
         self.k_fe_ema.plans = [ops.PackPlan([self.k_feature_extractor], False)]
