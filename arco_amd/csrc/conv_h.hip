@@ -4,7 +4,7 @@
 //
 //   hconv_kernel     3x3x3 (planes of H x W, depth tap = outer loop) and 1x1x1 convolutions, forward and - with flipped +
 //                    transposed packed weights - data gradient.  f16 tiles go from HBM to LDS untouched (16-byte pieces,
-//                    rows of 16 or 32 channels padded to 48 / 80 bytes: conflict-free ds_read_b128 fragments), one
+//                    rows of 16 channels unpadded / of 32 channels padded to 96 bytes: conflict-free ds_read_b128 fragments), one
 //                    v_mfma_f32_16x16x32_f16 per 16 pixels x 16 channels x 32 k (3x3: the 16 channels of TWO taps),
 //                    fp32 accumulate, D = W . X^T so that a lane ends with 4 consecutive channels of one pixel (8-byte
 //                    stores); BatchNorm partial statistics of the ROUNDED outputs in the epilogue.  Double-buffered LDS:
@@ -34,7 +34,11 @@ __device__ __forceinline__ h8 lds_h8(const unsigned* p) { return __builtin_bit_c
 template <int TAPS, int BM, int BN, int WM, int WN, int DEPTH, bool FLAT>
 struct HGeom {
   static constexpr int KC = TAPS == 9 ? 16 : 32;
-  static constexpr int LDK = KC / 2 + 4;                    // dwords per LDS row (48 / 80 bytes)
+  // dwords per LDS row: 8 (3x3: 16 channels, no padding) / 24 (1x1: 32 channels + 8).  A ds_read_b128 is served in the lane groups
+  // {0-3, 12-15, 20-27}, ...: eight rows r of one k-half and eight rows of the next half (+4 dwords) - conflict-free iff the row
+  // stride is an EVEN number s of 4-dword slots (slots s*r are even, s*r + 1 odd, each set distinct mod 16); s = 3 (a 48-byte row)
+  // made 5 of every 16 lanes collide
+  static constexpr int LDK = KC == 16 ? 8 : 24;
   static constexpr int TH = BM / 16;
   static constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * HFLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
   static constexpr int BROWS = TAPS * BN;

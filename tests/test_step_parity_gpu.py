@@ -78,7 +78,7 @@ def test_two_steps_vs_cpu_oracle(variant):
             np.testing.assert_allclose(st_g.random_pool.channels_first().cpu().numpy(), pool_o["rows"].numpy(), rtol=2e-3, atol=2e-6)
             assert int(st_g.random_pool.ptr) == int(pool_o["ptr"]) == (b * (it + 1)) % 4
         for k in ("ce", "dice", "unsup", "reco") + (("eqv",) if variant["k2"] else ()):
-            np.testing.assert_allclose(float(tg[k]), to[k], rtol=2e-3, atol=1e-5, err_msg=f"step {it} {k}")
+            np.testing.assert_allclose(float(tg[k]), to[k], rtol=1e-3, atol=1e-5, err_msg=f"step {it} {k}")      # north_star: loss within 1e-3
         for bo, bg in zip(bank_o, st_g.memobank):
             if bt and bo[0].shape != bg[0].shape:
                 # AdvMorph'ed images agree to ~1e-4 (fp32 association of eight grid compositions): a pixel sitting on a
@@ -86,7 +86,7 @@ def test_two_steps_vs_cpu_oracle(variant):
                 assert abs(int(bo[0].shape[0]) - int(bg[0].shape[0])) <= 2
                 continue
             assert bo[0].shape == bg[0].shape
-            np.testing.assert_allclose(bg[0].cpu().numpy(), bo[0].numpy(), rtol=2e-3, atol=2e-4)
+            np.testing.assert_allclose(bg[0].cpu().numpy(), bo[0].numpy(), rtol=1e-3, atol=2e-4)      # rows of magnitude ~2: 1e-4 of the row
         if not bt:
             assert [int(p) for p in ptr_o] == [int(p) for p in st_g.queue_ptrlis]
     AdvMorph.init_velocity = real_velocity
@@ -99,19 +99,19 @@ def test_two_steps_vs_cpu_oracle(variant):
         ref = v.detach()
         err = float((sd_g[k].cpu() - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
         worst = max(worst, err)
-    assert worst < 2e-3, worst
+    assert worst < 1e-3, worst
     for k, v in st_o["q_fe"].items():
         ref = v.detach()
         got = st_g.q_feature_extractor.state_dict()[k].cpu()
-        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 2e-3, k
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-3, k
     for i in range(2):
         ref = st_o["q_rep"][i].detach()
         got = st_g.q_representation[i].weight.detach().cpu()
-        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 2e-3
+        assert float((got - ref).abs().max()) / float(ref.abs().max()) < 1e-3
     sd_t = st_g.ema_model.state_dict()
     for k, v in st_o["teacher"].items():
         if v.is_floating_point() and "running" not in k:
-            assert float((sd_t[k].cpu() - v).abs().max()) / max(1e-6, float(v.abs().max())) < 2e-3, k
+            assert float((sd_t[k].cpu() - v).abs().max()) / max(1e-6, float(v.abs().max())) < 1e-3, k
     # BatchNorm running statistics: the momentum updates of the train-mode forwards must land in the reference's order
     # (student: l, cj2_l, u [, tps]; teacher: u, l, u_aug) although the trainer runs the forwards in another order
     for name, sd_ref, sd_got in (("student", st_o["student"], sd_g), ("teacher", st_o["teacher"], sd_t)):
