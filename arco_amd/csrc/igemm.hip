@@ -1335,12 +1335,18 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
 // v_alignbit_b32, dx = 2: the next dwords) - 18 LDS reads feed the 54 MFMAs of a K step.  Persistent over tiles with the
 // next tile's global loads in flight during the MFMAs; partial layout / reduction identical to wgrad_halo2_kernel.
 // ---------------------------------------------------------------------------
+#ifndef ARCO_WG_CSZ
+#define ARCO_WG_CSZ 68
+#endif
+#ifndef ARCO_WG_CSX
+#define ARCO_WG_CSX 124
+#endif
 template <int CO_B, int CI_B>
 __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
   constexpr int QZ = CO_B / 4, QA = CI_B / 4;
   constexpr int ZU = 32 * QZ, XU = 50 * QA;                 // staging units (4 pixels x 4 channels)
   constexpr int NZU = (ZU + 255) / 256, NXU = (XU + 255) / 256;
-  constexpr int CSZ = 68, CSX = 124;                        // dwords per (plane, channel) row: 128 px / 10 x 24 halo px (+ pad)
+  constexpr int CSZ = ARCO_WG_CSZ, CSX = ARCO_WG_CSX;      // dwords per (plane, channel) row: 128 px / 10 x 24 halo px (+ pad)
   constexpr int CI_T = CI_B / 16, NSUB = (CO_B / 16) * CI_T, WPS = 4 / NSUB, KS = 4 / WPS;
   extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
   unsigned int* Zs = smem_u;                                // [3][CO_B][CSZ]
@@ -1972,7 +1978,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
     const bool split = a.mma == 3 && !flat && (Cout & 3) == 0 && (Cin & 3) == 0 && (ld_dz & 3) == 0 && (ld_in & 3) == 0;
 #define WS(COB, CIB)                                                                              \
     do {                                                                                          \
-      size_t sh = (size_t)(3 * COB * 68 + 3 * CIB * 124) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4; \
+      size_t sh = (size_t)(3 * COB * ARCO_WG_CSZ + 3 * CIB * ARCO_WG_CSX) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4; \
       if (sh < rd && (COB / 16) * (CIB / 16) < 4) sh = rd;                                        \
       static bool attr_s = false;                                                                 \
       if (sh > 64 * 1024 && !attr_s) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<COB, CIB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_s = true; } \

@@ -205,7 +205,7 @@ class VNet(nn.Module):
         out = ops.conv(x9, self.out_conv.weight, self.out_conv.bias)
         # f16 activation storage (ops.ACT_HALF): the logits and the feature maps leave the f16 region as fp32 - heads, losses
         # and samplers are fp32; gradients come back through the same boundary with the loss scale
-        return ops.from_half(out), [ops.from_half(f) for f in feature_map]
+        return ops.from_half(out), ([ops.from_half(f) for f in feature_map] if ops.FM_CAST else feature_map)
 
     def forward(self, input, turnoff_drop=False):
         if turnoff_drop:

@@ -940,6 +940,22 @@ def from_half(x):
     return _FromHalfFn.apply(x) if _is_half(x) else x
 
 
+FM_CAST = True        # see logits_only()
+
+
+class logits_only:
+    """`with ops.logits_only():` - a V-Net forward inside hands its feature maps out as they are (f16 in f16 mode) instead of
+    casting them to fp32: for the passes of the step that only read the logits (the pseudo-label pass, the warped pass)."""
+
+    def __enter__(self):
+        global FM_CAST
+        self.prev, FM_CAST = FM_CAST, False
+
+    def __exit__(self, *exc):
+        global FM_CAST
+        FM_CAST = self.prev
+
+
 def space_to_depth3(x):
     return S2D3Fn.apply(x, False)
 

@@ -135,7 +135,7 @@ class ArcoStep3D:
         for pl in self.plans:                                            # stale only if someone else touched weights
             if not pl.valid:
                 pl.refresh()
-        with torch.no_grad():                                            # :260-262
+        with torch.no_grad(), ops.logits_only():                         # :260-262
             pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         # :268-278: the mixing strategy of --apply_aug on the GPU (train_arco_3d.py:270-271); the PIL transforms are identity
@@ -209,7 +209,7 @@ class ArcoStep3D:
                 images_tps = self.tps(torch.cat((l_data, u_aug)))
                 mask_tps = self.tps(eq_mask, padding_mode='zeros')
                 pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
-            with torch.set_grad_enabled(self.iter_num == 0):             # only iteration 0 back-propagates it (:390-393)
+            with torch.set_grad_enabled(self.iter_num == 0), ops.logits_only():   # only iteration 0 back-propagates it (:390-393)
                 pred_tps = (self.model if self.iter_num == 0 else self.s_fwd_tps)(images_tps)[0]                     # :380
                 loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
         C_.contrast_anchor_pix(plan)

@@ -129,6 +129,8 @@ def _kernel_name(key):
     if isinstance(key, tuple):
         return f"wgrad<taps={key[1]},co={key[2]},ci={key[3]}> (weight gradient, fp32 MFMA 16x16x4)"
     mma, key = key // 100000000, key % 100000000
+    if mma == 4 and key // 1000000 == 27:
+        return "conv3d_image_kernel<3> (one-channel fp32 volume -> 16 channels, f16 output; the 27 taps are the reduction dimension)"
     if mma == 4 and not (9700000 <= key < 9900000):
         flat = 9500000 <= key < 9700000
         base = key - (9500000 if flat else (key // 1000000) * 1000000)
