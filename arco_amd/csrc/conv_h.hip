@@ -334,11 +334,225 @@ static int hconv_dispatch3(const IgemmArgs& a, hipStream_t st, int* q) {
   return launch_hconv<9, 32, 32, 2, 2, 3, FLAT>(a, st, q);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident-weights form for the shallow levels (3x3x3, K = N = 16 on 8 x 16 tiles / 256 threads, K = N = 32 on 16 x 16 tiles / 512
+// threads; planes with H % TH == 0 and W % 16 == 0: the V-Net's 160x160x96 / 80x80x48 levels).  hconv_kernel re-stages a tile's weights (27 taps: as many bytes as the activations at these
+// widths) and reads every input plane three times; here a persistent workgroup
+//   * copies ALL 27 taps' weights to LDS once per launch,
+//   * owns units of (volume, TH x 16 tile, S consecutive planes) and walks the depth axis with a RING of three input plane
+//     tiles in LDS: producing output plane p needs only plane p + 1 as new input (loaded to registers during plane p - 1's
+//     MFMAs) - every input plane tile is read once per unit instead of three times, and never again for the weights,
+//   * pairs the 27 taps freely across the three resident planes: 14 MFMA steps per 16 channels instead of 15,
+// with the same MFMA / fragment layout as hconv_kernel (rows of 16 channels = 32 bytes, no padding: conflict-free).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NC, int C_T, int TH>
+struct HRwGeom {
+  static constexpr int HR = (TH + 2) * 18;                // halo rows of a TH x 16 tile
+  static constexpr int NT = 32 * TH, NW = TH / 2;         // threads / waves: a wave owns two tile rows
+  static constexpr int WROWS = 27 * C_T * 16 + 1;         // weight rows per 16-k chunk (+ the zero row)
+  static constexpr int W_DW = NC * WROWS * 8, A_DW = NC * HR * 8;
+  static constexpr int NP = (HR * NC * 2 + NT - 1) / NT;  // 16-byte activation pieces per thread and plane
+  static constexpr size_t LDS_BYTES = (size_t)(W_DW + 3 * A_DW + 2 * NW * C_T * 16) * 4;
+};
+
+template <int NC, int C_T, int TH>
+__global__ __launch_bounds__(32 * TH) void hconv_rw_kernel(IgemmArgs a, int S, int nseg) {
+  using G = HRwGeom<NC, C_T, TH>;
+  constexpr int HR = G::HR, WROWS = G::WROWS, NP = G::NP, NT = G::NT, NW = G::NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_r[];
+  unsigned* const Ws = smem_r;                        // [NC][WROWS][8]
+  unsigned* const As = smem_r + G::W_DW;              // [3][NC][HR][8]
+  float* const red = reinterpret_cast<float*>(smem_r + G::W_DW + 3 * G::A_DW);     // [2][NW][C_T * 16]
+  const _Float16* const Ag = reinterpret_cast<const _Float16*>(a.A);
+  const _Float16* const Wg = reinterpret_cast<const _Float16*>(a.Wp);
+  _Float16* const Cg = reinterpret_cast<_Float16*>(a.C);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4, h = g >> 1;
+  const int tiles_x = a.W >> 4, tiles_y = a.H / TH;
+  const int units = (a.NB / a.D3) * tiles_y * tiles_x * nseg;
+
+  // weights: global pack [tap][Npad][Kpad = 32] halves -> LDS [chunk][tap * N + n][16 halves]
+  for (int i = tid; i < NC * (WROWS - 1) * 2; i += NT) {
+    const int half = i & 1, r = (i >> 1) % (WROWS - 1), c = (i >> 1) / (WROWS - 1);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(Wg + (long)r * a.Kpad + c * 16 + half * 8);      // r = tap * Npad + n, Npad == N
+    *reinterpret_cast<u32x4_ma*>(Ws + (c * WROWS + r) * 8 + half * 4) = v;
+  }
+  for (int i = tid; i < NC * 8; i += NT) Ws[((i >> 3) * WROWS + WROWS - 1) * 8 + (i & 7)] = 0u;
+
+  // piece geometry (plane-invariant): halo row, chunk, half
+  int prow[NP], pc[NP], ph[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int idx = tid + i * NT;
+    const int qq = idx % (2 * NC);
+    prow[i] = idx < HR * NC * 2 ? idx / (2 * NC) : -1; pc[i] = qq >> 1; ph[i] = qq & 1;
+  }
+  f32x4 bv[C_T];
+#pragma unroll
+  for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[ct][r] = a.bias ? a.bias[ct * 16 + 4 * g + r] : 0.f;
+
+  u32x4 R[NP];
+  for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+    const int seg = unit % nseg; int col = unit / nseg;
+    const int tx = col % tiles_x; col /= tiles_x;
+    const int ty = col % tiles_y; const int v = col / tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16, p0 = seg * S, p1 = min(a.D3, p0 + S);
+    auto load_plane = [&](int p) {
+      const bool pok = p >= 0 && p < a.D3;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        u32x4 val = u32x4{0, 0, 0, 0};
+        if (prow[i] >= 0 && pok) {
+          const int hy = prow[i] / 18, hx = prow[i] - hy * 18;
+          const int y = y0 + hy - 1, x = x0 + hx - 1;
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+            val = *reinterpret_cast<const u32x4*>(Ag + ((((long)v * a.D3 + p) * a.H + y) * a.W + x) * a.lda + pc[i] * 16 + ph[i] * 8);
+        }
+        R[i] = val;
+      }
+    };
+    auto store_plane = [&](int slot) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if (prow[i] >= 0) *reinterpret_cast<u32x4_ma*>(As + slot * G::A_DW + (pc[i] * HR + prow[i]) * 8 + ph[i] * 4) = R[i];
+    };
+    float t1[C_T][4], t2[C_T][4];
+#pragma unroll
+    for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { t1[ct][r] = 0.f; t2[ct][r] = 0.f; }
+
+    int sA = 0, sB = 1, sC = 2;                 // ring slots of planes p - 1, p, p + 1
+    load_plane(p0 - 1); store_plane(sA);
+    load_plane(p0); store_plane(sB);
+    load_plane(p0 + 1);
+    for (int p = p0; p < p1; ++p) {
+      store_plane(sC);
+      __syncthreads();
+      if (p + 1 < p1) load_plane(p + 2);        // in flight during this plane's MFMAs
+      f32x4 acc[2][C_T];
+#pragma unroll
+      for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int ct = 0; ct < C_T; ++ct) acc[at][ct] = f32x4{0, 0, 0, 0};
+      const int sb0 = sA * G::A_DW, sb1 = sB * G::A_DW, sb2 = sC * G::A_DW;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+          // lanes g = 0,1 take tap 2s, g = 2,3 tap 2s + 1 (tap 27: the zero weight row on tap 26's activations)
+          constexpr int dummy = 0; (void)dummy;
+          const int tp0 = 2 * s, tp1 = 2 * s + 1 > 26 ? 26 : 2 * s + 1;
+          const int dz0 = tp0 / 9, dz1 = tp1 / 9;
+          const int o0 = ((tp0 % 9) / 3) * 18 + tp0 % 3, o1 = ((tp1 % 9) / 3) * 18 + tp1 % 3;
+          const int base0 = (dz0 == 0 ? sb0 : (dz0 == 1 ? sb1 : sb2)) + o0 * 8;
+          const int base1 = (dz1 == 0 ? sb0 : (dz1 == 1 ? sb1 : sb2)) + o1 * 8;
+          const int abase = (h ? base1 : base0) + c * HR * 8 + (g & 1) * 4;
+          const int wrow = h ? (2 * s + 1 > 26 ? WROWS - 1 : tp1 * C_T * 16 + li) : tp0 * C_T * 16 + li;
+          const int wstep = (h && 2 * s + 1 > 26) ? 0 : 16;         // the zero row serves every channel group
+          h8 fa[2];
+#pragma unroll
+          for (int at = 0; at < 2; ++at) fa[at] = lds_h8(As + abase + ((2 * wid + at) * 18 + li) * 8);
+#pragma unroll
+          for (int ct = 0; ct < C_T; ++ct) {
+            const h8 fb = lds_h8(Ws + (c * WROWS + wrow + ct * wstep) * 8 + (g & 1) * 4);
+#pragma unroll
+            for (int at = 0; at < 2; ++at)
+              acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, fa[at], acc[at][ct], 0, 0, 0);
+          }
+        }
+      }
+      // epilogue of the plane: bias, f16, 8-byte stores, statistics of the rounded values
+#pragma unroll
+      for (int at = 0; at < 2; ++at) {
+        const long pix = ((((long)v * a.D3 + p) * a.H + y0 + 2 * wid + at) * a.W + x0 + li);
+#pragma unroll
+        for (int ct = 0; ct < C_T; ++ct) {
+          const h4 hv = __builtin_convertvector(acc[at][ct] + bv[ct], h4);
+          *reinterpret_cast<h4*>(Cg + pix * a.ldc + ct * 16 + 4 * g) = hv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float x = (float)hv[r]; t1[ct][r] += x; t2[ct][r] += x * x; }
+        }
+      }
+      __syncthreads();                          // slot sA (plane p - 1) is free from here on
+      const int t = sA; sA = sB; sB = sC; sC = t;
+    }
+    if (a.stat_sum) {       // the unit's sums go to the slab of its first plane tile, zeros to the slabs of its other planes
+#pragma unroll
+      for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v1 = t1[ct][r], v2 = t2[ct][r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+          if (li == 0) { red[(0 * NW + wid) * C_T * 16 + ct * 16 + 4 * g + r] = v1; red[(1 * NW + wid) * C_T * 16 + ct * 16 + 4 * g + r] = v2; }
+        }
+      __syncthreads();
+      if (tid < C_T * 16) {
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { v1 += red[(0 * NW + w) * C_T * 16 + tid]; v2 += red[(1 * NW + w) * C_T * 16 + tid]; }
+        for (int p = p0; p < p1; ++p) {
+          const long slab = (((long)v * a.D3 + p) * tiles_y + ty) * tiles_x + tx;
+          a.stat_sum[(long)tid * a.n_mblocks + slab] = p == p0 ? v1 : 0.f;
+          a.stat_sq[(long)tid * a.n_mblocks + slab] = p == p0 ? v2 : 0.f;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+static int hconv_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+static bool hconv_rw_eligible(const IgemmArgs& a) {
+  static const int mode = getenv("ARCO_HCONV_RW") ? atoi(getenv("ARCO_HCONV_RW")) : 1;      // A/B switch: bit 0: 16 channels (default), bit 1: 32 (16 x 16 tiles, 512 threads: measured level with hconv_kernel, 502 vs 521 TFLOP/s in the step - off)
+  const bool on = a.K == 16 ? (mode & 1) : (mode & 2);
+  const int th = a.K == 16 ? 8 : 16;
+  return on && a.K == a.N && (a.K == 16 || a.K == 32) && a.Npad == a.N && a.H % th == 0 && (a.W & 15) == 0 && (a.lda & 7) == 0 &&
+         (a.ldc & 3) == 0 && a.R == nullptr && a.Kpad == 32;
+}
+// BN slabs: one per plane tile, NB * (H / TH) * (W / 16) (a function of the plane count alone, like the other kernels' counts)
+template <int NC, int C_T, int TH>
+static int launch_hconv_rw(const IgemmArgs& a, hipStream_t st, int* q) {
+  using G = HRwGeom<NC, C_T, TH>;
+  const long tiles = (long)(a.H / TH) * (a.W >> 4);
+  if (q) { q[0] = (int)(a.NB * tiles); q[1] = 9 * 1000000 + 400000 + TH * 1000 + C_T * 16; q[2] = 16 * 100 + 30 + 1; return ARCO_OK; }
+  if (a.D3 < 1 || a.NB % a.D3 != 0) return ARCO_ERR_ARG;
+  const long cols = (long)(a.NB / a.D3) * tiles;
+  int per_cu = (int)(160 * 1024 / G::LDS_BYTES); if (per_cu > 4) per_cu = 4; if (per_cu < 1) per_cu = 1;
+  const long slots = (long)hconv_cus() * per_cu;
+  // planes per unit: long units amortise the two halo planes; short ones fill the chip when there are few tile columns
+  int S = 8;
+  while (S > 2 && cols * ((a.D3 + S - 1) / S) < 3 * slots) S >>= 1;
+  if (S > a.D3) S = a.D3;
+  const int nseg = (a.D3 + S - 1) / S;
+  const long units = cols * nseg;
+  auto kern = hconv_rw_kernel<NC, C_T, TH>;
+  static bool attr_set = false;
+  if (G::LDS_BYTES > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
+  IgemmArgs b = a;
+  b.n_mblocks = (int)(a.NB * tiles);
+  const long grid = slots < units ? slots : units;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, st, b, S, nseg);
+  return arco_launch_status();
+}
+
 // entry of the f16-storage convolutions (called from arco_conv3d_fwd with mma == 4).  a.Kpad = ceil32(K) (the f16 pack)
 int hconv_dispatch(const IgemmArgs& a, int taps, hipStream_t st, int* q) {
   if ((taps != 1 && ((a.K & 7) != 0 || (a.lda & 7) != 0)) || a.R != nullptr) return ARCO_ERR_UNSUPPORTED;
   if (!q && (((reinterpret_cast<uintptr_t>(a.A) & 15) != 0 && (a.K & 7) == 0) || (reinterpret_cast<uintptr_t>(a.Wp) & 15) != 0)) return ARCO_ERR_ARG;
   if (taps == 27) {
+    if (hconv_rw_eligible(a)) return a.K == 16 ? launch_hconv_rw<1, 1, 8>(a, st, q) : launch_hconv_rw<2, 2, 16>(a, st, q);
     if ((a.W & 15) != 0 && a.W + 2 <= HFLAT_WPMAX) return hconv_dispatch3<true>(a, st, q);
     return hconv_dispatch3<false>(a, st, q);
   }

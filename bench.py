@@ -131,6 +131,9 @@ def _kernel_name(key):
     mma, key = key // 100000000, key % 100000000
     if mma == 4 and key // 1000000 == 27:
         return "conv3d_image_kernel<3> (one-channel fp32 volume -> 16 channels, f16 output; the 27 taps are the reduction dimension)"
+    if mma == 4 and 9400000 <= key < 9500000:
+        return (f"hconv_rw_kernel<TH={(key - 9400000) // 1000},N={key % 1000}> (f16 activation storage; persistent workgroups, all 27 taps' weights "
+                "resident in LDS, ring of three input planes walked along the depth axis)")
     if mma == 4 and not (9700000 <= key < 9900000):
         flat = 9500000 <= key < 9700000
         base = key - (9500000 if flat else (key // 1000000) * 1000000)

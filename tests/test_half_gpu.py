@@ -27,8 +27,11 @@ def _l2rel(a, b):
 
 
 # (ci, co, D, H, W): rectangular tiles (W % 16 == 0), flat tiles (narrow planes), ragged planes, several N-tile shapes
+# (16, 16, ...) with H % 8 == 0 and (32, 32, ...) with H % 16 == 0, W % 16 == 0: the resident-weights kernel (units of several
+# planes, ragged last unit, a single plane); the others: hconv_kernel
 CONV3_SHAPES = [(16, 16, 6, 16, 32), (32, 32, 5, 24, 48), (16, 32, 4, 20, 12), (64, 64, 6, 12, 6), (128, 128, 5, 10, 6),
-                (32, 64, 3, 9, 7), (256, 256, 3, 5, 3)]
+                (32, 64, 3, 9, 7), (256, 256, 3, 5, 3), (32, 32, 6, 32, 32), (16, 16, 11, 24, 16), (16, 16, 1, 8, 16),
+                (32, 32, 9, 16, 48)]
 
 
 @pytest.mark.parametrize("ci,co,D,H,W", CONV3_SHAPES)
