@@ -65,6 +65,8 @@ _SIGS = {
     "arco_bn_act_fwd_h": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _L, _P, _I, _P],
     "arco_bn_act_bwd_h": [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _I, _F, _U64, _L, _P, _P, _P, _I, _P, _L, _P, _I, _P],
     "arco_colsum_h": [_P, _L, _L, _I, _P, _P, _I, _P],
+    "arco_bn_act_add_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _P, _L, _P, _L, _I, _P],
+    "arco_bn_act_add_fwd_h": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _P, _L, _P, _L, _I, _P],
     "arco_cast_h2f": [_P, _L, _P, _P],
     "arco_cast_f2h": [_P, _L, _F, _P, _P],
     "arco_gn_finalize": [_P, _P, _I, _I, _I, _I, _L, _F, _P, _P, _P],

@@ -161,11 +161,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Z
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float slope, int drop_mode, float p, uint64_t seed_, long P,
                                                         T* __restrict__ Aout, long lda,
-                                                        const uint64_t* __restrict__ seed_dev) {
+                                                        const uint64_t* __restrict__ seed_dev,
+                                                        const T* __restrict__ R = nullptr, long ldr = 0) {
+  // R != nullptr: a = drop(lrelu(BN(z))) + R  (the skip addition of the V-Net decoder, vnetWithArgs.py:224-236, in the apply pass)
   const int q4 = C / 4;
   // blockIdx.y = BN group: rows [g*M, (g+1)*M) of the tensor with parameter row g (M = rows per group)
   const long row0 = (long)blockIdx.y * M;
   Z += row0 * ldz; Aout += row0 * lda;
+  if (R) R += row0 * ldr;
   if (mean) { mean += (long)blockIdx.y * C; istd += (long)blockIdx.y * C; }
   const long tot = M * q4;
   const float keep_scale = drop_mode ? 1.0f / (1.0f - p) : 1.0f;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Z
             else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)(((r + row0) / P) * C + c + e), p) ? y * keep_scale : 0.f;
             o[e] = y;
           }
+          if (R) o += ld4f(R + r * ldr + c);
           st4f(Aout + r * lda + c, o);
         }
       }
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Z
       else if (drop_mode == 2) y = drop_keep(seed, (uint64_t)(((r + row0) / P) * C + c + e), p) ? y * keep_scale : 0.f;
       o[e] = y;
     }
+    if (R) o += ld4f(R + r * ldr + c);
     st4f(Aout + r * lda + c, o);
   }
 }
@@ -1010,12 +1015,12 @@ extern "C++" {
 template <typename T>
 static int bn_act_fwd_impl(const T* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                            const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, T* A, long lda,
-                           const uint64_t* seed_dev, int groups, void* stream) {
+                           const uint64_t* seed_dev, int groups, void* stream, const T* R = nullptr, long ldr = 0) {
   if (groups < 1) groups = 1;
-  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && p < 1.0f && M % groups == 0);
+  ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && p < 1.0f && M % groups == 0 && (!R || (ldr & 3) == 0));
   const long Mg = M / groups;                 // mean / istd: [groups][C]; rows [g*Mg, (g+1)*Mg) use row g
   hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, as_stream(stream), Z, ldz, Mg, C, mean,
-                     istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda, seed_dev);
+                     istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda, seed_dev, R, ldr);
   return arco_launch_status();
 }
 }  // extern "C++"
@@ -1023,6 +1028,18 @@ int arco_bn_act_fwd(const float* Z, long ldz, long M, int C, const float* mean, 
                     const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, float* A, long lda,
                     const uint64_t* seed_dev, int groups, void* stream) {
   return bn_act_fwd_impl<float>(Z, ldz, M, C, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, A, lda, seed_dev, groups, stream);
+}
+// A = drop(lrelu(BN(Z))) + R: the apply pass with the decoder's skip addition (vnetWithArgs.py:224-236 `block_x_up(x) + skip`)
+int arco_bn_act_add_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                        const float* beta, float slope, const float* R, long ldr, float* A, long lda, int groups, void* stream) {
+  ARCO_CHECK_ARG(R != nullptr);
+  return bn_act_fwd_impl<float>(Z, ldz, M, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1, A, lda, nullptr, groups, stream, R, ldr);
+}
+int arco_bn_act_add_fwd_h(const void* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                          const float* beta, float slope, const void* R, long ldr, void* A, long lda, int groups, void* stream) {
+  ARCO_CHECK_ARG(R != nullptr);
+  return bn_act_fwd_impl<_Float16>(reinterpret_cast<const _Float16*>(Z), ldz, M, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1,
+                                   reinterpret_cast<_Float16*>(A), lda, nullptr, groups, stream, reinterpret_cast<const _Float16*>(R), ldr);
 }
 // f16 activation storage: Z and A are f16 tensors (parameters and statistics fp32, arithmetic fp32)
 int arco_bn_act_fwd_h(const void* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,

@@ -131,7 +131,14 @@ class UpsamplingDeconvBlock(nn.Module):
         self.conv = nn.Sequential(*layers)
         self.has_norm = norm is not None
 
-    def forward(self, x):
+    def forward(self, x, skip=None):
+        """skip: the decoder's `block_x_up(x) + skip` (vnetWithArgs.py:224-236) with the addition folded into the BatchNorm apply
+        pass (train-mode batchnorm); the other variants add afterwards."""
+        y = self._forward(x, skip)
+        return y if (skip is None or self._fused) else y + skip
+
+    def _forward(self, x, skip):
+        self._fused = False
         conv, bn = self.conv[0], (self.conv[1] if self.has_norm else None)
         ci, co = conv.weight.shape[0], conv.weight.shape[1]
         w2 = conv.weight.permute(2, 3, 4, 1, 0).reshape(8 * co, ci, 1, 1, 1)      # [(dx,dy,dz), co][ci]
@@ -145,8 +152,9 @@ class UpsamplingDeconvBlock(nn.Module):
         if not is_bn:
             return _norm_act(z, bn, self.training)
         if self.training:
+            self._fused = skip is not None and skip.dtype == z.dtype
             return ops.bn_act(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, momentum=bn.momentum,
-                              eps=bn.eps, num_batches_tracked=bn.num_batches_tracked)
+                              eps=bn.eps, num_batches_tracked=bn.num_batches_tracked, residual=skip if self._fused else None)
         return ops.bn_act_eval(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, eps=bn.eps)
 
 
@@ -191,13 +199,13 @@ class VNet(nn.Module):
 
     def decoder(self, features):
         x1, x2, x3, x4, x5 = features
-        x5_up = self.block_five_up(x5) + x4
+        x5_up = self.block_five_up(x5, x4)
         feature_map = [x5_up]
-        x6_up = self.block_six_up(self.block_six(x5_up)) + x3
+        x6_up = self.block_six_up(self.block_six(x5_up), x3)
         feature_map.append(x6_up)
-        x7_up = self.block_seven_up(self.block_seven(x6_up)) + x2
+        x7_up = self.block_seven_up(self.block_seven(x6_up), x2)
         feature_map.append(x7_up)
-        x8_up = self.block_eight_up(self.block_eight(x7_up)) + x1
+        x8_up = self.block_eight_up(self.block_eight(x7_up), x1)
         feature_map.append(x8_up)
         x9 = self.block_nine(x8_up)
         feature_map.append(x9)

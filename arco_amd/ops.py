@@ -656,7 +656,7 @@ class BnActFn(torch.autograd.Function):
     transposed conv of UpsamplingDeconvBlock, vnetWithArgs.py:94-118).  gamma=None: plain dropout/activation."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps, nbt=None):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps, nbt=None, residual=None):
         zr, ldz = rows_view(z)
         co = int(z.shape[1])
         m = zr.shape[0]
@@ -681,7 +681,16 @@ class BnActFn(torch.autograd.Function):
                    L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G, d0, L.ptr(dbuf))
         seed = _next_seed() if p > 0 else 0
         a = new_act_nd(int(z.shape[0]), co, sp, z.device, zr.dtype)
-        ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a, None, G)
+        ctx.has_res = residual is not None
+        if residual is not None:        # a = lrelu(BN(z)) + residual in the apply pass (the V-Net decoder's skip additions)
+            if gamma is None or p > 0 or residual.dtype != z.dtype or tuple(residual.shape) != tuple(z.shape):
+                raise RuntimeError("arco_amd: bn_act(residual=...) is the dropout-free BatchNorm apply with a same-shape, same-dtype addend")
+            rr, ldr = rows_view(residual)
+            L.call("arco_bn_act_add_fwd_h" if _is_half(zr) else "arco_bn_act_add_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd),
+                   L.ptr(gamma), L.ptr(beta), float(slope), L.ptr(rr), ldr, L.ptr(a), co, G)
+            ctx.seed_dev = None
+        else:
+            ctx.seed_dev = _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, a, None, G)
         ctx.groups = G
         ctx.save_for_backward(z, mean, istd, gamma, beta)
         ctx.cfg = (float(slope), float(p), int(drop_mode), seed, P)
@@ -693,7 +702,8 @@ class BnActFn(torch.autograd.Function):
         slope, p, drop_mode, seed, P = ctx.cfg
         dz, dgamma, dbeta = _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, ctx.seed_dev,
                                          ctx.groups)
-        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None
+        # (the activation is recomputed from z in the backward kernels, so the added residual never enters them; its gradient is da)
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, (da if ctx.has_res else None)
 
 
 class S2D3Fn(torch.autograd.Function):
@@ -900,9 +910,10 @@ def bn_act_eval(z, gamma, beta, running_mean, running_var, slope=0.0, eps=1e-5):
 
 
 def bn_act(z, gamma, beta, running_mean, running_var, slope=0.0, p=0.0, drop_mode=0, momentum=0.1, eps=1e-5,
-           num_batches_tracked=None):
+           num_batches_tracked=None, residual=None):
+    """residual: a tensor of z's shape added AFTER the activation in the same pass (vnetWithArgs.py:224-236, the decoder's skips)."""
     return BnActFn.apply(z, gamma, beta, running_mean, running_var, slope, p, drop_mode, momentum, eps,
-                         num_batches_tracked)
+                         num_batches_tracked, residual)
 
 
 def dropout3d(x, p):

@@ -353,6 +353,12 @@ int arco_bn_act_bwd_h(const void* dA, long ldd, const void* Z, long ldz, long M,
                       uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, void* dZ, long ldo,
                       const uint64_t* seed_dev, int groups, void* stream);
 int arco_colsum_h(const void* X, long ldx, long M, int C, float* ws, float* out, int accumulate, void* stream);
+/* A = lrelu(BN(Z)) + R: the apply pass of UpsamplingDeconvBlock's BatchNorm with the decoder's skip addition folded in
+ * (vnetWithArgs.py:224-236 `x5_up = self.block_five_up(x5) + x4` ...); mean / istd rows [groups][C] as for arco_bn_act_fwd      */
+int arco_bn_act_add_fwd(const float* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                        const float* beta, float slope, const float* R, long ldr, float* A, long lda, int groups, void* stream);
+int arco_bn_act_add_fwd_h(const void* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
+                          const float* beta, float slope, const void* R, long ldr, void* A, long lda, int groups, void* stream);
 int arco_cast_h2f(const void* x, long n, float* y, void* stream);
 int arco_cast_f2h(const float* x, long n, float scale, void* y, void* stream);
 
