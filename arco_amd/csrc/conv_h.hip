@@ -31,6 +31,12 @@ constexpr int HFLAT_WPMAX = 64;          // flat-position tiles: padded row stri
 
 __device__ __forceinline__ h8 lds_h8(const unsigned* p) { return __builtin_bit_cast(h8, u32x4(*reinterpret_cast<const u32x4_ma*>(p))); }
 
+// thread -> piece map of the staging stores.  With 4 pieces per row (32 channels, 24-dword rows) a ds_write_b128 lane octet would hold
+// rows r, r + 1, which overlap in 8 of the 32 banks; rows r, r + 2 do not: swap the two low bits of the row index
+template <int PIECES> __device__ __forceinline__ int hrow_perm(int r) {
+  return PIECES == 4 ? ((r & ~3) | ((r & 1) << 1) | ((r >> 1) & 1)) : r;
+}
+
 template <int TAPS, int BM, int BN, int WM, int WN, int DEPTH, bool FLAT>
 struct HGeom {
   static constexpr int KC = TAPS == 9 ? 16 : 32;
@@ -38,7 +44,11 @@ struct HGeom {
   // {0-3, 12-15, 20-27}, ...: eight rows r of one k-half and eight rows of the next half (+4 dwords) - conflict-free iff the row
   // stride is an EVEN number s of 4-dword slots (slots s*r are even, s*r + 1 odd, each set distinct mod 16); s = 3 (a 48-byte row)
   // made 5 of every 16 lanes collide
+#ifdef ARCO_HCONV_ROWS_48_80      // A/B build: the padded rows measured first (5 of 16 lanes per ds_read_b128 group on a busy bank)
+  static constexpr int LDK = KC / 2 + 4;
+#else
   static constexpr int LDK = KC == 16 ? 8 : 24;
+#endif
   static constexpr int TH = BM / 16;
   static constexpr int AROWS = TAPS == 9 ? (FLAT ? BM + 2 * HFLAT_WPMAX + 2 : (TH + 2) * 18) : BM;
   static constexpr int BROWS = TAPS * BN;
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(IgemmArgs a) {
     const int idx = tid + it * 256;
     srcA[it] = nullptr; ldsA[it] = -1; kA[it] = 0;
     if (idx < AROWS * PA) {
-      const int row = idx / PA, q = idx - row * PA;
+      const int q = idx % PA, row = hrow_perm<PA>(idx / PA);
       long pix = -1;
       if (TAPS == 9 && FLAT) {
         const int pidx = f0 + row - 1;
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(IgemmArgs a) {
     const int idx = tid + it * 256;
     srcB[it] = nullptr; ldsB[it] = -1;
     if (idx < BROWS * PA) {
-      const int row = idx / PA, q = idx - row * PA;
+      const int q = idx % PA, row = hrow_perm<PA>(idx / PA);
       const int tap = row / BN, n = row - tap * BN;
       ldsB[it] = (AROWS + row) * LDK + q * 4;
       if (n0 + n < a.Npad) srcB[it] = Wg + ((long)tap * a.Npad + n0 + n) * a.Kpad + 8 * q;
@@ -394,7 +404,12 @@ __global__ __launch_bounds__(32 * TH) void hconv_rw_kernel(IgemmArgs a, int S, i
     for (int r = 0; r < 4; ++r) bv[ct][r] = a.bias ? a.bias[ct * 16 + 4 * g + r] : 0.f;
 
   u32x4 R[NP];
-  for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+  // XCD-aware unit order: workgroups are dealt round-robin over the 8 XCDs (private L2s); XCD x takes the x-th CONTIGUOUS eighth of
+  // the units, so the units that share halo rows / planes (neighbouring tiles and depth segments) meet in one L2
+  const bool xmap = (gridDim.x & 7) == 0;
+  const int G8 = xmap ? (int)gridDim.x >> 3 : (int)gridDim.x, U8 = xmap ? (units + 7) >> 3 : units;
+  const int u_lo = xmap ? ((int)blockIdx.x & 7) * U8 : 0, u_hi = xmap ? min(units, u_lo + U8) : units;
+  for (int unit = u_lo + (xmap ? (int)blockIdx.x >> 3 : (int)blockIdx.x); unit < u_hi; unit += G8) {
     const int seg = unit % nseg; int col = unit / nseg;
     const int tx = col % tiles_x; col /= tiles_x;
     const int ty = col % tiles_y; const int v = col / tiles_y;
@@ -517,7 +532,7 @@ static int hconv_cus() {
 static bool hconv_rw_eligible(const IgemmArgs& a) {
   static const int mode = getenv("ARCO_HCONV_RW") ? atoi(getenv("ARCO_HCONV_RW")) : 1;      // A/B switch: bit 0: 16 channels (default), bit 1: 32 (16 x 16 tiles, 512 threads: measured level with hconv_kernel, 502 vs 521 TFLOP/s in the step - off)
   const bool on = a.K == 16 ? (mode & 1) : (mode & 2);
-  const int th = a.K == 16 ? 8 : 16;
+  const int th = a.K == 16 ? ((mode & 4) && a.H % 16 == 0 ? 16 : 8) : 16;
   return on && a.K == a.N && (a.K == 16 || a.K == 32) && a.Npad == a.N && a.H % th == 0 && (a.W & 15) == 0 && (a.lda & 7) == 0 &&
          (a.ldc & 3) == 0 && a.R == nullptr && a.Kpad == 32;
 }
@@ -552,7 +567,11 @@ int hconv_dispatch(const IgemmArgs& a, int taps, hipStream_t st, int* q) {
   if ((taps != 1 && ((a.K & 7) != 0 || (a.lda & 7) != 0)) || a.R != nullptr) return ARCO_ERR_UNSUPPORTED;
   if (!q && (((reinterpret_cast<uintptr_t>(a.A) & 15) != 0 && (a.K & 7) == 0) || (reinterpret_cast<uintptr_t>(a.Wp) & 15) != 0)) return ARCO_ERR_ARG;
   if (taps == 27) {
-    if (hconv_rw_eligible(a)) return a.K == 16 ? launch_hconv_rw<1, 1, 8>(a, st, q) : launch_hconv_rw<2, 2, 16>(a, st, q);
+    if (hconv_rw_eligible(a)) {
+      static const int mode = getenv("ARCO_HCONV_RW") ? atoi(getenv("ARCO_HCONV_RW")) : 1;
+      if (a.K == 16) return ((mode & 4) && a.H % 16 == 0) ? launch_hconv_rw<1, 1, 16>(a, st, q) : launch_hconv_rw<1, 1, 8>(a, st, q);
+      return launch_hconv_rw<2, 2, 16>(a, st, q);
+    }
     if ((a.W & 15) != 0 && a.W + 2 <= HFLAT_WPMAX) return hconv_dispatch3<true>(a, st, q);
     return hconv_dispatch3<false>(a, st, q);
   }
@@ -618,6 +637,9 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a) {
 #pragma unroll
       for (int j = 0; j < CI_T; ++j) acc[t][i][j] = f32x4{0, 0, 0, 0};
 
+  // 32-channel rows (4 pieces, 24-dword stride): a ds_write_b128 is served 8 lanes at a time over 32 banks - rows r and r + 1 of a
+  // lane octet overlap in 8 banks, rows r and r + 2 do not: the two low bits of the row index are swapped in the thread -> piece map
+  auto rperm = [](int p, int pieces) { return pieces == 4 ? ((p & ~3) | ((p & 1) << 1) | ((p >> 1) & 1)) : p; };
   u32x4 pz[NZ], px_[NX];
   auto load8 = [&](const _Float16* src, int c, int C, bool vec) -> u32x4 {
     if (vec) return c < C ? *reinterpret_cast<const u32x4*>(src) : u32x4{0, 0, 0, 0};
@@ -638,7 +660,7 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
-      const int idx = tid + i * 256, p = idx / PZ, q = idx - p * PZ, c = co0 + 8 * q;
+      const int idx = tid + i * 256, p = rperm(idx / PZ, PZ), q = idx % PZ, c = co0 + 8 * q;
       u32x4 v = u32x4{0, 0, 0, 0};
       if (idx < 128 * PZ && plane_ok) {
         long pix = -1;
@@ -650,7 +672,7 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int idx = tid + i * 256, r = idx / PX, q = idx - r * PX, c = ci0 + 8 * q;
+      const int idx = tid + i * 256, r = rperm(idx / PX, PX), q = idx % PX, c = ci0 + 8 * q;
       u32x4 v = u32x4{0, 0, 0, 0};
       if (idx < XR * PX && plane_ok) {
         long pix = -1;
@@ -676,9 +698,9 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a) {
   if (t < a.n_tiles) fetch(t);
   while (t < a.n_tiles) {
 #pragma unroll
-    for (int i = 0; i < NZ; ++i) { const int idx = tid + i * 256; if (idx < 128 * PZ) *reinterpret_cast<u32x4_ma*>(Zs + (idx / PZ) * RSZ + 4 * (idx % PZ)) = pz[i]; }
+    for (int i = 0; i < NZ; ++i) { const int idx = tid + i * 256; if (idx < 128 * PZ) *reinterpret_cast<u32x4_ma*>(Zs + rperm(idx / PZ, PZ) * RSZ + 4 * (idx % PZ)) = pz[i]; }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { const int idx = tid + i * 256; if (idx < XR * PX) *reinterpret_cast<u32x4_ma*>(Xs + (idx / PX) * RSX + 4 * (idx % PX)) = px_[i]; }
+    for (int i = 0; i < NX; ++i) { const int idx = tid + i * 256; if (idx < XR * PX) *reinterpret_cast<u32x4_ma*>(Xs + rperm(idx / PX, PX) * RSX + 4 * (idx % PX)) = px_[i]; }
     __syncthreads();
     const int next = t + gridDim.x;
     if (next < a.n_tiles) fetch(next);
