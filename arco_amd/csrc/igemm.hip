@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     const int idx = tid + it * 256;
     srcA[it] = nullptr; ldsA[it] = -1; kA[it] = 0;
     if (idx < AROWS * Q4) {
-      const int row = idx / Q4, q = idx - row * Q4;
+      // split-bf16 GEMM tiles (Q4 = 8 pieces per row, 56-dword rows): the 16 lanes of a ds_write_b64 group would hold rows r, r + 1,
+      // which overlap in 8 of the 32 banks (PMC: 19-37 % of these kernels' LDS cycles were conflicts); rows r, r + 2 do not
+      const int q = idx % Q4, r_ = idx / Q4;
+      const int row = (X3 && TAPS == 1 && (AROWS & 3) == 0) ? ((r_ & ~3) | ((r_ & 1) << 1) | ((r_ >> 1) & 1)) : r_;
       long pix = -1;
       if (TAPS == 9 && FLAT) {
         const int pidx = f0 + row - 1;               // position in the plane padded by one halo row / column
@@ -1335,11 +1338,20 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
 // v_alignbit_b32, dx = 2: the next dwords) - 18 LDS reads feed the 54 MFMAs of a K step.  Persistent over tiles with the
 // next tile's global loads in flight during the MFMAs; partial layout / reduction identical to wgrad_halo2_kernel.
 // ---------------------------------------------------------------------------
+// LDS channel rows of wgrad_split_kernel.  PMC (tools/pmc_lds_step.sh): with plain rows of 68 / 124 dwords TWO THIRDS of the kernel's
+// LDS cycles were bank conflicts - the staging stores (8 lanes = 8 channel quads of one pixel group, channel stride 4 rows = 16 mod 32
+// banks: 4-way) and the fragment reads (2-way).  The dword offset inside a channel's row is XOR-ed with 4 * (channel / 4): the eight
+// quads of a store group land in eight different 4-dword blocks, and with rows of 72 / 136 dwords the ds_read_b128 groups are
+// conflict-free as well (model: tools/micro/lds_bank_model.py - stores 4 -> 1.0 / 1.2, b128 reads 2 -> 1.0 / 1.5 cycles per group).
+// ARCO_WG_SWZ=0 + ARCO_WG_CSZ=68 + ARCO_WG_CSX=124 rebuilds round 2's layout.
+#ifndef ARCO_WG_SWZ
+#define ARCO_WG_SWZ 1
+#endif
 #ifndef ARCO_WG_CSZ
-#define ARCO_WG_CSZ 68
+#define ARCO_WG_CSZ (ARCO_WG_SWZ ? 72 : 68)
 #endif
 #ifndef ARCO_WG_CSX
-#define ARCO_WG_CSX 124
+#define ARCO_WG_CSX (ARCO_WG_SWZ ? 136 : 124)
 #endif
 template <int CO_B, int CI_B>
 __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
@@ -1400,13 +1412,14 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
     for (int e = 0; e < 4; ++e) {
       u32x2 p0, p1, p2;
       split3_bf16x4(f32x4{v[0][e], v[1][e], v[2][e], v[3][e]}, p0, p1, p2);
-      unsigned int* d = base + (long)(chan0 + e) * cs + off;
+      unsigned int* d = base + (long)(chan0 + e) * cs + (ARCO_WG_SWZ ? (off ^ (((chan0 >> 2) & 7) << 2)) : off);
       *reinterpret_cast<u32x2_ma*>(d) = p0;
       *reinterpret_cast<u32x2_ma*>(d + (long)nchan * cs) = p1;
       *reinterpret_cast<u32x2_ma*>(d + 2l * nchan * cs) = p2;
     }
   };
 
+  const int swz_z = ARCO_WG_SWZ ? (((wi * 16 + li) >> 2) & 7) << 2 : 0, swz_x = ARCO_WG_SWZ ? (((wj * 16 + li) >> 2) & 7) << 2 : 0;
   int t = blockIdx.x;
   if (t < a.n_tiles && !(WGRAD_ABL(a) & 4)) fetch(t);
   while (t < a.n_tiles) {
@@ -1431,15 +1444,16 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
       const int s = part * KS + ks, rr = 2 * s + (g >> 1), h = g & 1;
       bf16x8 za[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) za[p] = lds_bf16x8(&Zs[(p * CO_B + wi * 16 + li) * CSZ + rr * 8 + h * 4]);
+      for (int p = 0; p < 3; ++p) za[p] = lds_bf16x8(&Zs[(p * CO_B + wi * 16 + li) * CSZ + ((rr * 8 + h * 4) ^ swz_z)]);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         unsigned int w[3][6];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          const unsigned int* src = &Xs[(p * CI_B + wj * 16 + li) * CSX + (rr + dy) * 12 + h * 4];
-          const u32x4 lo = *reinterpret_cast<const u32x4_ma*>(src);
-          const u32x2 hi = *reinterpret_cast<const u32x2_ma*>(src + 4);
+          const unsigned int* row = &Xs[(p * CI_B + wj * 16 + li) * CSX];
+          const int o = (rr + dy) * 12 + h * 4;
+          const u32x4 lo = *reinterpret_cast<const u32x4_ma*>(row + (o ^ swz_x));
+          const u32x2 hi = *reinterpret_cast<const u32x2_ma*>(row + ((o + 4) ^ swz_x));
           w[p][0] = lo[0]; w[p][1] = lo[1]; w[p][2] = lo[2]; w[p][3] = lo[3];
           w[p][4] = hi[0]; w[p][5] = hi[1];
         }
