@@ -453,31 +453,36 @@ __global__ __launch_bounds__(32 * TH) void hconv_rw_kernel(IgemmArgs a, int S, i
 #pragma unroll
         for (int ct = 0; ct < C_T; ++ct) acc[at][ct] = f32x4{0, 0, 0, 0};
       const int sb0 = sA * G::A_DW, sb1 = sB * G::A_DW, sb2 = sC * G::A_DW;
+      // fragment reads of step st + 1 are issued in front of step st's MFMAs (two register sets; left to itself the compiler reads a
+      // step's fragments, waits for them and only then issues its MFMAs - an LDS round trip per step on the critical path)
+      h8 fa[2][2], fb[2][C_T];
+      auto read_step = [&](int st, int set) {
+        const int c = st / 14, sp_ = st % 14;
+        // lanes g = 0,1 take tap 2s, g = 2,3 tap 2s + 1 (tap 27: the zero weight row on tap 26's activations)
+        const int tp0 = 2 * sp_, tp1 = 2 * sp_ + 1 > 26 ? 26 : 2 * sp_ + 1;
+        const int dz0 = tp0 / 9, dz1 = tp1 / 9;
+        const int o0 = ((tp0 % 9) / 3) * 18 + tp0 % 3, o1 = ((tp1 % 9) / 3) * 18 + tp1 % 3;
+        const int base0 = (dz0 == 0 ? sb0 : (dz0 == 1 ? sb1 : sb2)) + o0 * 8;
+        const int base1 = (dz1 == 0 ? sb0 : (dz1 == 1 ? sb1 : sb2)) + o1 * 8;
+        const int abase = (h ? base1 : base0) + c * HR * 8 + (g & 1) * 4;
+        const int wrow = h ? (2 * sp_ + 1 > 26 ? WROWS - 1 : tp1 * C_T * 16 + li) : tp0 * C_T * 16 + li;
+        const int wstep = (h && 2 * sp_ + 1 > 26) ? 0 : 16;         // the zero row serves every channel group
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
+        for (int at = 0; at < 2; ++at) fa[set][at] = lds_h8(As + abase + ((2 * wid + at) * 18 + li) * 8);
 #pragma unroll
-        for (int s = 0; s < 14; ++s) {
-          // lanes g = 0,1 take tap 2s, g = 2,3 tap 2s + 1 (tap 27: the zero weight row on tap 26's activations)
-          constexpr int dummy = 0; (void)dummy;
-          const int tp0 = 2 * s, tp1 = 2 * s + 1 > 26 ? 26 : 2 * s + 1;
-          const int dz0 = tp0 / 9, dz1 = tp1 / 9;
-          const int o0 = ((tp0 % 9) / 3) * 18 + tp0 % 3, o1 = ((tp1 % 9) / 3) * 18 + tp1 % 3;
-          const int base0 = (dz0 == 0 ? sb0 : (dz0 == 1 ? sb1 : sb2)) + o0 * 8;
-          const int base1 = (dz1 == 0 ? sb0 : (dz1 == 1 ? sb1 : sb2)) + o1 * 8;
-          const int abase = (h ? base1 : base0) + c * HR * 8 + (g & 1) * 4;
-          const int wrow = h ? (2 * s + 1 > 26 ? WROWS - 1 : tp1 * C_T * 16 + li) : tp0 * C_T * 16 + li;
-          const int wstep = (h && 2 * s + 1 > 26) ? 0 : 16;         // the zero row serves every channel group
-          h8 fa[2];
+        for (int ct = 0; ct < C_T; ++ct) fb[set][ct] = lds_h8(Ws + (c * WROWS + wrow + ct * wstep) * 8 + (g & 1) * 4);
+      };
+      read_step(0, 0);
 #pragma unroll
-          for (int at = 0; at < 2; ++at) fa[at] = lds_h8(As + abase + ((2 * wid + at) * 18 + li) * 8);
+      for (int st = 0; st < NC * 14; ++st) {
+        if (st + 1 < NC * 14) read_step(st + 1, (st + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ct = 0; ct < C_T; ++ct) {
-            const h8 fb = lds_h8(Ws + (c * WROWS + wrow + ct * wstep) * 8 + (g & 1) * 4);
+        for (int ct = 0; ct < C_T; ++ct)
 #pragma unroll
-            for (int at = 0; at < 2; ++at)
-              acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, fa[at], acc[at][ct], 0, 0, 0);
-          }
-        }
+          for (int at = 0; at < 2; ++at)
+            acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[st & 1][ct], fa[st & 1][at], acc[at][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // epilogue of the plane: bias, f16, 8-byte stores, statistics of the rounded values
 #pragma unroll

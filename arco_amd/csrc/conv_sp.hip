@@ -705,6 +705,189 @@ static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
   return arco_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3-D counterpart for the full-resolution level of the V-Net (3x3x3, 16 -> 16, planes with H % 16 == 0 and W % 16 == 0: block_nine and
+// its data gradient, vnetWithArgs.py:222-238).  igemm_kernel<9,128,16,..,DEPTH=3> re-stages the 27 taps' weights for every tile
+// (as many bytes as the activations at this width) and reads every input plane three times.  Here a persistent workgroup of 8 waves
+//   * keeps ALL 27 taps' pre-split weights in LDS for the launch (41 KB),
+//   * owns units of (volume, 16 x 16 tile, S consecutive planes) and walks the depth axis with a RING of three split input plane
+//     tiles: output plane p needs only plane p + 1 as new input (loaded during plane p - 1's MFMAs, split on the way into LDS),
+//   * pairs the 27 taps freely across the three resident planes: 14 MFMA steps per plane instead of 15.
+// Same arithmetic as the other split-bf16 kernels (six v_mfma_f32_16x16x32_bf16 per fp32-accurate product, small terms first,
+// D = W . X^T, 16-byte stores, BN partial statistics: one slab per plane tile).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Rw3Geom {
+  static constexpr int TH = 16, HR = (TH + 2) * 18, NT = 512, NW = 8;
+  static constexpr int WROWS = 27 * 16 + 1;                 // + the zero row
+  static constexpr int W_DW = WROWS * 24, A_DW = HR * 24;
+  static constexpr int NP = (HR * 4 + NT - 1) / NT;         // 16-byte activation pieces (4 channels) per thread and plane
+  static constexpr size_t LDS_BYTES = (size_t)(W_DW + 3 * A_DW + 2 * NW * 16) * 4;
+};
+
+__global__ __launch_bounds__(512) void conv3d_rw16_kernel(IgemmArgs a, int S, int nseg) {
+  using G = Rw3Geom;
+  constexpr int HR = G::HR, WROWS = G::WROWS, NP = G::NP, NT = G::NT, NW = G::NW, TH = G::TH;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned* const Ws = reinterpret_cast<unsigned*>(smem);            // [WROWS][24]
+  unsigned* const As = Ws + G::W_DW;                                 // [3][HR][24]
+  float* const red = reinterpret_cast<float*>(As + 3 * G::A_DW);     // [2][NW][16]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4, h = g >> 1;
+  const int tiles_x = a.W >> 4, tiles_y = a.H / TH;
+  const int units = (a.NB / a.D3) * tiles_y * tiles_x * nseg;
+
+  // weights: the split pack [tap][Npad = 16][Kg = 2][3][16] bf16 -> LDS rows [tap * 16 + n] of the first 16-k group (24 dwords)
+  for (int i = tid; i < (WROWS - 1) * 6; i += NT) {
+    const int r = i / 6, q6 = i - r * 6;
+    *reinterpret_cast<u32x4_ma*>(Ws + r * 24 + q6 * 4) = *reinterpret_cast<const u32x4*>(a.Wp + ((long)r * a.Kg) * 24 + q6 * 4);
+  }
+  for (int i = tid; i < 24; i += NT) Ws[(WROWS - 1) * 24 + i] = 0u;
+
+  int prow[NP], pq[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int idx = tid + i * NT;
+    prow[i] = idx < HR * 4 ? idx >> 2 : -1; pq[i] = idx & 3;
+  }
+  f32x4 bv;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = a.bias ? a.bias[4 * g + r] : 0.f;
+
+  f32x4 R[NP];
+  const bool xmap = (gridDim.x & 7) == 0;         // XCD-aware unit order: a contiguous eighth of the units per XCD (shared halos meet in one L2)
+  const int G8 = xmap ? (int)gridDim.x >> 3 : (int)gridDim.x, U8 = xmap ? (units + 7) >> 3 : units;
+  const int u_lo = xmap ? ((int)blockIdx.x & 7) * U8 : 0, u_hi = xmap ? min(units, u_lo + U8) : units;
+  for (int unit = u_lo + (xmap ? (int)blockIdx.x >> 3 : (int)blockIdx.x); unit < u_hi; unit += G8) {
+    const int seg = unit % nseg; int col = unit / nseg;
+    const int tx = col % tiles_x; col /= tiles_x;
+    const int ty = col % tiles_y; const int v = col / tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16, p0 = seg * S, p1 = min(a.D3, p0 + S);
+    auto load_plane = [&](int p) {
+      const bool pok = p >= 0 && p < a.D3;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        f32x4 val = f32x4{0, 0, 0, 0};
+        if (prow[i] >= 0 && pok) {
+          const int hy = prow[i] / 18, hx = prow[i] - hy * 18;
+          const int y = y0 + hy - 1, x = x0 + hx - 1;
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+            val = *reinterpret_cast<const f32x4*>(a.A + ((((long)v * a.D3 + p) * a.H + y) * a.W + x) * a.lda + pq[i] * 4);
+        }
+        R[i] = val;
+      }
+    };
+    auto store_plane = [&](int slot) {           // split into the three bf16 planes of the row's 16-k group
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if (prow[i] >= 0) {
+          u32x2 p0_, p1_, p2_;
+          split3_bf16x4(R[i], p0_, p1_, p2_);
+          unsigned* d = As + slot * G::A_DW + prow[i] * 24 + pq[i] * 2;
+          *reinterpret_cast<u32x2_ma*>(d) = p0_; *reinterpret_cast<u32x2_ma*>(d + 8) = p1_; *reinterpret_cast<u32x2_ma*>(d + 16) = p2_;
+        }
+    };
+    f32x4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+    int sA = 0, sB = 1, sC = 2;                  // ring slots of planes p - 1, p, p + 1
+    load_plane(p0 - 1); store_plane(sA);
+    load_plane(p0); store_plane(sB);
+    load_plane(p0 + 1);
+    for (int p = p0; p < p1; ++p) {
+      store_plane(sC);
+      __syncthreads();
+      if (p + 1 < p1) load_plane(p + 2);         // in flight during this plane's MFMAs
+      f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+      const int sb0 = sA * G::A_DW, sb1 = sB * G::A_DW, sb2 = sC * G::A_DW;
+      // the fragments of step s + 1 are read in front of step s's MFMAs (two register sets): no LDS round trip between steps
+      bf16x8 fb[2][3], fa[2][2][3];
+      auto read_step = [&](int sp_, int set) {
+        // lanes g = 0,1 take tap 2s, g = 2,3 tap 2s + 1 (tap 27: the zero weight row on tap 26's activations)
+        const int tp0 = 2 * sp_, tp1 = 2 * sp_ + 1 > 26 ? 26 : 2 * sp_ + 1;
+        const int dz0 = tp0 / 9, dz1 = tp1 / 9;
+        const int o0 = ((tp0 % 9) / 3) * 18 + tp0 % 3, o1 = ((tp1 % 9) / 3) * 18 + tp1 % 3;
+        const int base0 = (dz0 == 0 ? sb0 : (dz0 == 1 ? sb1 : sb2)) + o0 * 24;
+        const int base1 = (dz1 == 0 ? sb0 : (dz1 == 1 ? sb1 : sb2)) + o1 * 24;
+        const int abase = (h ? base1 : base0) + (g & 1) * 4;
+        const int wrow = h ? (2 * sp_ + 1 > 26 ? WROWS - 1 : tp1 * 16 + li) : tp0 * 16 + li;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fb[set][pl] = lds_bf16x8(Ws + wrow * 24 + (g & 1) * 4 + 8 * pl);
+#pragma unroll
+        for (int at = 0; at < 2; ++at)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fa[set][at][pl] = lds_bf16x8(As + abase + ((2 * wid + at) * 18 + li) * 24 + 8 * pl);
+      };
+      read_step(0, 0);
+#pragma unroll
+      for (int s = 0; s < 14; ++s) {
+        if (s + 1 < 14) read_step(s + 1, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int at = 0; at < 2; ++at) {         // D = W . X^T; small terms first
+          f32x4 c = acc[at];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s & 1][0], fa[s & 1][at][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s & 1][2], fa[s & 1][at][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s & 1][1], fa[s & 1][at][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s & 1][0], fa[s & 1][at][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s & 1][1], fa[s & 1][at][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s & 1][0], fa[s & 1][at][0], c, 0, 0, 0);
+          acc[at] = c;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int at = 0; at < 2; ++at) {
+        const long pix = ((((long)v * a.D3 + p) * a.H + y0 + 2 * wid + at) * a.W + x0 + li);
+        const f32x4 o = acc[at] + bv;
+        *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + 4 * g) = o;
+        t1 += o; t2 += o * o;
+      }
+      __syncthreads();                           // slot sA (plane p - 1) is free from here on
+      const int t = sA; sA = sB; sB = sC; sC = t;
+    }
+    if (a.stat_sum) {       // the unit's sums go to the slab of its first plane tile, zeros to the slabs of its other planes
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v1 = row16_sum(t1[r]), v2 = row16_sum(t2[r]);
+        if (li == 0) { red[(0 * NW + wid) * 16 + 4 * g + r] = v1; red[(1 * NW + wid) * 16 + 4 * g + r] = v2; }
+      }
+      __syncthreads();
+      if (tid < 16) {
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { v1 += red[(0 * NW + w) * 16 + tid]; v2 += red[(1 * NW + w) * 16 + tid]; }
+        for (int p = p0; p < p1; ++p) {
+          const long slab = (((long)v * a.D3 + p) * tiles_y + ty) * tiles_x + tx;
+          a.stat_sum[(long)tid * a.n_mblocks + slab] = p == p0 ? v1 : 0.f;
+          a.stat_sq[(long)tid * a.n_mblocks + slab] = p == p0 ? v2 : 0.f;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// returns -1 when the shape is not taken (the caller falls through to igemm_kernel)
+int conv3d_rw_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
+  static const bool off = getenv("ARCO_CONV3D_RW") && atoi(getenv("ARCO_CONV3D_RW")) == 0;      // A/B switch
+  if (off || a.mma != 3 || a.K != 16 || a.N != 16 || a.Npad != 16 || a.Kg != 2 || (a.H & 15) != 0 || (a.W & 15) != 0 ||
+      (a.lda & 3) != 0 || (a.ldc & 3) != 0 || a.R != nullptr) return -1;
+  using G = Rw3Geom;
+  const long tiles = (long)(a.H / G::TH) * (a.W >> 4);
+  if (q) { q[0] = (int)(a.NB * tiles); q[1] = 9 * 1000000 + 450000 + 16; q[2] = 16 * 100 + 30 + 1; return ARCO_OK; }
+  if (a.D3 < 1 || a.NB % a.D3 != 0) return ARCO_ERR_ARG;
+  const long cols = (long)(a.NB / a.D3) * tiles, slots = conv_sp_cus();
+  int S = 8;
+  while (S > 2 && cols * ((a.D3 + S - 1) / S) < 3 * slots) S >>= 1;
+  if (S > a.D3) S = a.D3;
+  const int nseg = (a.D3 + S - 1) / S;
+  const long units = cols * nseg;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_rw16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
+  IgemmArgs b = a;
+  b.n_mblocks = (int)(a.NB * tiles);
+  hipLaunchKernelGGL(conv3d_rw16_kernel, dim3((unsigned)(slots < units ? slots : units)), dim3(G::NT), G::LDS_BYTES, st, b, S, nseg);
+  return arco_launch_status();
+}
+
 // A/B knob: ARCO_CONV_SP=0 / arco_conv_sp_set(0) keeps every shape on igemm_kernel
 static int& conv_sp_flag() { static int on = !(getenv("ARCO_CONV_SP") && atoi(getenv("ARCO_CONV_SP")) == 0); return on; }
 static bool conv_sp_on() { return conv_sp_flag() != 0; }

@@ -947,6 +947,10 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
   }
   if (taps == 27 && image_conv3d_eligible(a)) return launch_image_conv3d<3>(a, st, nmb);   // one-channel volume (first layer)
   if (taps == 9 && image_conv3d_eligible(a)) return launch_image_conv3d<1>(a, st, nmb);     // one-channel image
+  if (taps == 27 && a.mma == 3) {     // the 16 -> 16 full-resolution level: resident weights, ring of three input planes (conv_sp.hip)
+    const int r = conv3d_rw_dispatch(a, st, nmb);
+    if (r != -1) return r;
+  }
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
   if (taps == 9 && a.mma == 3) {     // 2-D levels with enough tiles: the software-pipelined kernels of conv_sp.hip
     const int r = conv_sp_dispatch(a, st, nmb);
@@ -1739,6 +1743,7 @@ int arco_conv_mblocks_mma(int taps, int NB, int H, int W, int Cin, int Cout, lon
   a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in;
   a.stat_groups = stat_groups > 1 ? stat_groups : 1;
   a.mma = mma;
+  if (mma == 3) a.Kg = (Cin + 31) / 32 * 2;
   int q[3] = {0, 0, 0};
   if (mma == 4 && !(taps == 27 && image_conv3d_eligible(a))) {
     a.Kpad = (Cin + 31) / 32 * 32;
@@ -1763,6 +1768,7 @@ int arco_conv_config_mma(int taps, int NB, int H, int W, int Cin, int Cout, long
   IgemmArgs a{};
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
   a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in; a.mma = mma;
+  if (mma == 3) a.Kg = (Cin + 31) / 32 * 2;
   int q[3] = {0, 0, 0};
   if (mma == 4 && !(taps == 27 && image_conv3d_eligible(a))) {
     a.Kpad = (Cin + 31) / 32 * 32;

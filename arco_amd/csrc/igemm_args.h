@@ -61,6 +61,8 @@ __device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
 // then falls through to igemm_kernel), otherwise the launch status; q != nullptr: query only (q[0] = M-tiles = BN stat
 // slabs per channel, q[1] = instantiation id, q[2] = KC*100 + DEPTH*10).
 int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
+// conv_sp.hip: the resident-weights 3x3x3 kernel of the 16 -> 16 full-resolution level (split-bf16); -1 when the shape is not taken
+int conv3d_rw_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
 
 // conv_h.hip: f16 activation storage (mma == 4).  hconv_dispatch: forward / data gradient of the 3x3x3 and 1x1x1 convolutions on
 // f16 tensors (a.A, a.C point at f16 rows, a.Wp at the f16 pack [tap][Npad][ceil32(K)], a.Kpad = ceil32(K)); q as above.

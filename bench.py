@@ -143,6 +143,8 @@ def _kernel_name(key):
         return f"conv3x3_image_kernel<Cin={key % 100000 // 1000}> (few-channel input: the taps are the reduction dimension; {MMA_NAMES[mma]})"
     if 9500000 <= key < 9700000:        # flat-position tiles of the 3x3x3 kernels (narrow planes)
         return f"igemm_kernel<9,{(key - 9500000) // 1000},{key % 1000},...,FLAT,MMA={mma}> ({MMA_NAMES[mma]} implicit GEMM, 3x3x3 depth taps looped)"
+    if 9450000 <= key < 9500000:
+        return f"conv3d_rw16_kernel ({MMA_NAMES[mma]}; 3x3x3 16 -> 16: persistent workgroups, 27 taps' weights resident in LDS, ring of three input planes along the depth axis)"
     if 9350000 <= key < 9400000:
         return f"conv3x3_rw_kernel<A_T={(key - 9350000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, weights resident in LDS)"
     if 9300000 <= key < 9350000:

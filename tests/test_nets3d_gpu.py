@@ -29,7 +29,9 @@ def close(a, b, rtol=3e-4, atol=3e-5):
                                                 (2, 64, 64, 5, 14, 14, 3), (1, 32, 32, 3, 28, 28, 3), (2, 128, 256, 5, 7, 7, 3),
                                                 (1, 16, 16, 2, 9, 56, 3), (1, 64, 32, 4, 13, 30, 3),
                                                 # one-channel volumes (the V-Net's first layer): taps-as-K kernels, ragged tiles
-                                                (2, 1, 16, 5, 20, 19, 3), (1, 1, 16, 3, 33, 48, 3), (2, 1, 8, 4, 16, 16, 3)])
+                                                (2, 1, 16, 5, 20, 19, 3), (1, 1, 16, 3, 33, 48, 3), (2, 1, 8, 4, 16, 16, 3),
+                                                # 16 -> 16 on planes of whole 16 x 16 tiles: conv3d_rw16_kernel (units of several planes, ragged last unit, one plane)
+                                                (2, 16, 16, 6, 16, 32, 3), (1, 16, 16, 11, 32, 16, 3), (2, 16, 16, 1, 16, 16, 3)])
 def test_conv3d_fwd_bwd(nb, ci, co, d, h, w, k):
     from arco_amd import ops
     rs = np.random.RandomState(ci + co + d)
