@@ -126,3 +126,25 @@ for name in ("none", "q", "qx", "m1s2"):
             print(name, csz, csx, analyse(16, csz, csx, fams2[name]))
         except Exception as e:
             print(name, csz, csx, "err", e)
+
+print("---- X second read as b128 / alternatives")
+def xreads(csx, f, second):
+    tot = 0; n = 0
+    for s in range(4):
+        for dy in range(3):
+            def a(l, s=s, dy=dy):
+                li, g = l & 15, l >> 4; rr, h = 2*s + (g >> 1), g & 1
+                return li*csx + (((rr+dy)*12 + h*4) ^ f(li))
+            def a2(l, s=s, dy=dy):
+                li, g = l & 15, l >> 4; rr, h = 2*s + (g >> 1), g & 1
+                return li*csx + (((rr+dy)*12 + h*4 + 4) ^ f(li))
+            tot += read_b128(a) + (read_b128(a2) if second == "b128" else 2 * read_b64(a2)); n += 1
+    return tot / n      # LDS cycles per (s, dy): b128 = 4 groups, b64 = 2 halves
+res = []
+for csx in (128, 132, 136):
+    for name, f in fams2.items():
+        for second in ("b64", "b128"):
+            w = analyse(32, 72, csx, f)[2]
+            res.append((xreads(csx, f, second), w, name, csx, second))
+res.sort()
+for r in res[:12]: print(r)
