@@ -67,6 +67,10 @@ _SIGS = {
     "arco_colsum_h": [_P, _L, _L, _I, _P, _P, _I, _P],
     "arco_bn_act_add_fwd": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _P, _L, _P, _L, _I, _P],
     "arco_bn_act_add_fwd_h": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _P, _L, _P, _L, _I, _P],
+    "arco_bn_act_d2s_fwd": [_P, _L, _I, _P, _P, _P, _P, _F, _P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "arco_bn_act_d2s_fwd_h": [_P, _L, _I, _P, _P, _P, _P, _F, _P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "arco_bn_act_d2s_bwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "arco_bn_act_d2s_bwd_h": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "arco_cast_h2f": [_P, _L, _P, _P],
     "arco_cast_f2h": [_P, _L, _F, _P, _P],
     "arco_gn_finalize": [_P, _P, _I, _I, _I, _I, _L, _F, _P, _P, _P],

@@ -153,6 +153,25 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ X
   block_channel_totals(s, q, C, red, ssum + (long)blockIdx.y * nblk, ssq + (long)blockIdx.y * nblk, nblk * gridDim.y);
 }
 
+// depth-to-space folded into the BatchNorm passes of UpsamplingDeconvBlock (vnetWithArgs.py:94-118): the GEMM form of the k2 s2 transposed
+// conv leaves Y[(n, x, y, z)][tap * C + c]; read as rows (voxel, tap) of C channels it IS the pre-activation, only in another row order -
+// statistics do not care, and the apply pass writes row (voxel, tap) to voxel (n, 2x+dx, 2y+dy, 2z+dz) of the activation (the backward
+// reads dA from there): no separate depth-to-space / space-to-depth pass in either direction.  tap = dx*4 + dy*2 + dz as in s2d3_kernel.
+struct D2S { int X2, Y2, Z2; };
+__device__ __forceinline__ long d2s_row(long r, const D2S& d) {
+  const long q = r >> 3; const int tap = (int)(r & 7);
+  const int z = (int)(q % d.Z2); long t = q / d.Z2; const int y = (int)(t % d.Y2); t /= d.Y2; const int x = (int)(t % d.X2); const long n = t / d.X2;
+  return ((n * (2 * d.X2) + 2 * x + (tap >> 2)) * (2 * d.Y2) + 2 * y + ((tap >> 1) & 1)) * (long)(2 * d.Z2) + 2 * z + (tap & 1);
+}
+// the inverse: activation voxel row -> (voxel, tap) row of Y.  The forward apply walks the OUTPUT rows (contiguous stores, gathered loads:
+// scattered 8- / 16-byte stores measured slower than the depth-to-space pass they replace on f16 rows)
+__device__ __forceinline__ long d2s_src_row(long ro, const D2S& d) {
+  const int zf = (int)(ro % (2 * d.Z2)); long t = ro / (2 * d.Z2); const int yf = (int)(t % (2 * d.Y2)); t /= 2 * d.Y2;
+  const int xf = (int)(t % (2 * d.X2)); const long n = t / (2 * d.X2);
+  const int tap = (xf & 1) * 4 + (yf & 1) * 2 + (zf & 1);
+  return ((((n * d.X2 + (xf >> 1)) * d.Y2 + (yf >> 1)) * (long)d.Z2 + (zf >> 1)) << 3) + tap;
+}
+
 // ---- BN apply + LeakyReLU(slope) + dropout:  a = drop(lrelu((z-mean)*istd*gamma+beta))
 //      drop_mode 0: none, 1: per element (nn.Dropout), 2: per (image, channel) (nn.Dropout3d)
 template <typename T>
@@ -162,11 +181,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Z
                                                         float slope, int drop_mode, float p, uint64_t seed_, long P,
                                                         T* __restrict__ Aout, long lda,
                                                         const uint64_t* __restrict__ seed_dev,
-                                                        const T* __restrict__ R = nullptr, long ldr = 0) {
+                                                        const T* __restrict__ R = nullptr, long ldr = 0, D2S ds = D2S{0, 0, 0}) {
   // R != nullptr: a = drop(lrelu(BN(z))) + R  (the skip addition of the V-Net decoder, vnetWithArgs.py:224-236, in the apply pass)
+  // ds.X2 != 0: the loop runs over the rows (voxels) of A / R, the depth-to-space'd tensor; Z is gathered from the (voxel, tap) rows of the
+  // GEMM-form transposed conv (d2s_src_row)
   const int q4 = C / 4;
   // blockIdx.y = BN group: rows [g*M, (g+1)*M) of the tensor with parameter row g (M = rows per group)
   const long row0 = (long)blockIdx.y * M;
+  const T* const Z0 = Z;
   Z += row0 * ldz; Aout += row0 * lda;
   if (R) R += row0 * ldr;
   if (mean) { mean += (long)blockIdx.y * C; istd += (long)blockIdx.y * C; }
@@ -184,7 +206,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Z
     for (long rb = gt / q4; rb < M; rb += 4 * rstride) {
       f32x4 z[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const long r = rb + u * rstride; if (r < M) z[u] = ld4f(Z + r * ldz + c); }
+      for (int u = 0; u < 4; ++u) {
+        const long r = rb + u * rstride;
+        if (r < M) z[u] = ld4f(ds.X2 ? Z0 + d2s_src_row(r + row0, ds) * ldz + c : Z + r * ldz + c);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long r = rb + u * rstride;
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Z
   }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
     const long r = i / q4; const int c = (int)(i - r * q4) * 4;
-    const f32x4 z = ld4f(Z + r * ldz + c);
+    const f32x4 z = ld4f(ds.X2 ? Z0 + d2s_src_row(r + row0, ds) * ldz + c : Z + r * ldz + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -236,10 +261,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const T* __restrict__ dA, long ldd, const T* __restrict__ Z, long ldz, long M, int C,
     const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
     const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed_, long P,
-    float* __restrict__ s_dy, float* __restrict__ s_dyx, int nblk, const uint64_t* __restrict__ seed_dev) {
+    float* __restrict__ s_dy, float* __restrict__ s_dyx, int nblk, const uint64_t* __restrict__ seed_dev, D2S ds = D2S{0, 0, 0}) {
   const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
   // blockIdx.y = BN group (rows [g*M, (g+1)*M), parameter row g, slab block [g][C][nblk])
   const long row0 = (long)blockIdx.y * M;
+  const T* const dA0 = dA;          // ds.X2 != 0: dA rows are voxels of the depth-to-space'd tensor (see D2S)
   dA += row0 * ldd; Z += row0 * ldz;
   mean += (long)blockIdx.y * C; istd += (long)blockIdx.y * C;
   s_dy += (long)blockIdx.y * C * nblk; s_dyx += (long)blockIdx.y * C * nblk;
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
         const long r = rb + (long)u * rstep;
         if (r < r1) {
           z[u] = ld4f(Z + r * ldz + c);
-          d[u] = ld4f(dA + r * ldd + c);
+          d[u] = ld4f(ds.X2 ? dA0 + d2s_row(r + row0, ds) * ldd + c : dA + r * ldd + c);
         }
       }
 #pragma unroll
@@ -314,11 +340,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ gamma,
     const float* __restrict__ beta, float slope, int drop_mode, float p, uint64_t seed_, long P,
     const float* __restrict__ sum_dy, const float* __restrict__ sum_dyx, float inv_count,
-    T* __restrict__ dZ, long ldo, const uint64_t* __restrict__ seed_dev, int gn) {
+    T* __restrict__ dZ, long ldo, const uint64_t* __restrict__ seed_dev, int gn, D2S ds = D2S{0, 0, 0}) {
   // gn != 0 (GroupNorm / InstanceNorm: statistics per sample over a SET of channels): sum_dy / sum_dyx hold the set's sums
   // of gamma*dy and gamma*dy*xhat, and dz = istd * (gamma*dy - sum_dy/n - xhat*sum_dyx/n); gamma varies inside a set
   const uint64_t seed = seed_dev ? seed_ ^ (seed_dev[0] * 0x9E3779B97F4A7C15ull) : seed_;
   const long row0 = (long)blockIdx.y * M;                 // blockIdx.y = BN group
+  const T* const dA0 = dA;          // ds.X2 != 0: dA rows are voxels of the depth-to-space'd tensor (see D2S)
   dA += row0 * ldd; Z += row0 * ldz; dZ += row0 * ldo;
   if (mean) { mean += (long)blockIdx.y * C; istd += (long)blockIdx.y * C; sum_dy += 2l * blockIdx.y * C; sum_dyx += 2l * blockIdx.y * C; }
   const int q4 = C / 4;
@@ -335,7 +362,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const long r = rb + u * rstride;
-        if (r < M) { z[u] = ld4f(Z + r * ldz + c); d[u] = ld4f(dA + r * ldd + c); }
+        if (r < M) { z[u] = ld4f(Z + r * ldz + c); d[u] = ld4f(ds.X2 ? dA0 + d2s_row(r + row0, ds) * ldd + c : dA + r * ldd + c); }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -360,7 +387,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
     const long r = i / q4; const int c = (int)(i - r * q4) * 4;
     const f32x4 z = ld4f(Z + r * ldz + c);
-    const f32x4 d = ld4f(dA + r * ldd + c);
+    const f32x4 d = ld4f(ds.X2 ? dA0 + d2s_row(r + row0, ds) * ldd + c : dA + r * ldd + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1015,12 +1042,12 @@ extern "C++" {
 template <typename T>
 static int bn_act_fwd_impl(const T* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                            const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, T* A, long lda,
-                           const uint64_t* seed_dev, int groups, void* stream, const T* R = nullptr, long ldr = 0) {
+                           const uint64_t* seed_dev, int groups, void* stream, const T* R = nullptr, long ldr = 0, D2S ds = D2S{0, 0, 0}) {
   if (groups < 1) groups = 1;
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (lda & 3) == 0 && p < 1.0f && M % groups == 0 && (!R || (ldr & 3) == 0));
   const long Mg = M / groups;                 // mean / istd: [groups][C]; rows [g*Mg, (g+1)*Mg) use row g
   hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, as_stream(stream), Z, ldz, Mg, C, mean,
-                     istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda, seed_dev, R, ldr);
+                     istd, gamma, beta, slope, p > 0.f ? drop_mode : 0, p, seed, P, A, lda, seed_dev, R, ldr, ds);
   return arco_launch_status();
 }
 }  // extern "C++"
@@ -1041,6 +1068,20 @@ int arco_bn_act_add_fwd_h(const void* Z, long ldz, long M, int C, const float* m
   return bn_act_fwd_impl<_Float16>(reinterpret_cast<const _Float16*>(Z), ldz, M, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1,
                                    reinterpret_cast<_Float16*>(A), lda, nullptr, groups, stream, reinterpret_cast<const _Float16*>(R), ldr);
 }
+// UpsamplingDeconvBlock's BatchNorm + ReLU straight from the GEMM-form transposed conv (see D2S): Y rows = (voxel of the NV x X2 x Y2 x Z2
+// grid, tap) of C channels (Y = [voxels][8 C] dense), A / R = the [NV, 2 X2, 2 Y2, 2 Z2] activation / skip tensor; M8 = 8 * voxels
+int arco_bn_act_d2s_fwd(const float* Y, long M8, int C, const float* mean, const float* istd, const float* gamma, const float* beta,
+                        float slope, const float* R, long ldr, float* A, long lda, int X2, int Y2, int Z2, int groups, void* stream) {
+  ARCO_CHECK_ARG(X2 > 0 && Y2 > 0 && Z2 > 0 && M8 % (8l * X2 * Y2 * Z2) == 0);
+  return bn_act_fwd_impl<float>(Y, C, M8, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1, A, lda, nullptr, groups, stream, R, ldr, D2S{X2, Y2, Z2});
+}
+int arco_bn_act_d2s_fwd_h(const void* Y, long M8, int C, const float* mean, const float* istd, const float* gamma, const float* beta,
+                          float slope, const void* R, long ldr, void* A, long lda, int X2, int Y2, int Z2, int groups, void* stream) {
+  ARCO_CHECK_ARG(X2 > 0 && Y2 > 0 && Z2 > 0 && M8 % (8l * X2 * Y2 * Z2) == 0);
+  return bn_act_fwd_impl<_Float16>(reinterpret_cast<const _Float16*>(Y), C, M8, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1,
+                                   reinterpret_cast<_Float16*>(A), lda, nullptr, groups, stream, reinterpret_cast<const _Float16*>(R), ldr,
+                                   D2S{X2, Y2, Z2});
+}
 // f16 activation storage: Z and A are f16 tensors (parameters and statistics fp32, arithmetic fp32)
 int arco_bn_act_fwd_h(const void* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                       const float* beta, float slope, int drop_mode, float p, uint64_t seed, long P, void* A, long lda,
@@ -1058,7 +1099,7 @@ template <typename T>
 static int bn_act_bwd_impl(const T* dA, long ldd, const T* Z, long ldz, long M, int C, const float* mean,
                            const float* istd, const float* gamma, const float* beta, float slope, int drop_mode, float p,
                            uint64_t seed, long P, float* ws, float* dgamma, float* dbeta, int accumulate, T* dZ, long ldo,
-                           const uint64_t* seed_dev, int groups, int cpg, void* stream) {
+                           const uint64_t* seed_dev, int groups, int cpg, void* stream, D2S ds = D2S{0, 0, 0}) {
   if (groups < 1) groups = 1;
   ARCO_CHECK_ARG(C > 0 && (C & 3) == 0 && C <= 1024 && (ldz & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0 && M % groups == 0);
   ARCO_CHECK_ARG(cpg == 0 || (mean && cpg >= 1 && C % cpg == 0));
@@ -1069,7 +1110,7 @@ static int bn_act_bwd_impl(const T* dA, long ldd, const T* Z, long ldz, long M, 
     const int nblk = arco_chan_stats_blocks(Mg);
     float* s_dy = ws; float* s_dyx = ws + (long)groups * C * nblk; float* sums = ws + 2l * groups * C * nblk;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(nblk, groups), dim3(256), 2048 * sizeof(float), st, dA, ldd, Z, ldz, Mg,
-                       C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk, seed_dev);
+                       C, mean, istd, gamma, beta, slope, dm, p, seed, P, s_dy, s_dyx, nblk, seed_dev, ds);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, s_dy, s_dyx, nblk, C, sums, dgamma,
                        dbeta, accumulate, groups);
     if (cpg) {
@@ -1078,7 +1119,7 @@ static int bn_act_bwd_impl(const T* dA, long ldd, const T* Z, long ldz, long M, 
     }
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(ew_grid(Mg * (C / 4)), groups), dim3(256), 0, st, dA, ldd, Z, ldz, Mg, C,
                        mean, istd, gamma, beta, slope, dm, p, seed, P, sums, sums + C, 1.0f / ((float)Mg * (float)(cpg ? cpg : 1)), dZ, ldo,
-                       seed_dev, cpg ? 1 : 0);
+                       seed_dev, cpg ? 1 : 0, ds);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, dA, ldd, Z, ldz, M, C,
                        nullptr, nullptr, nullptr, nullptr, slope, dm, p, seed, P, nullptr, nullptr, 0.f, dZ, ldo, seed_dev, 0);
@@ -1101,6 +1142,22 @@ int arco_bn_act_bwd_h(const void* dA, long ldd, const void* Z, long ldz, long M,
   return bn_act_bwd_impl<_Float16>(reinterpret_cast<const _Float16*>(dA), ldd, reinterpret_cast<const _Float16*>(Z), ldz, M, C, mean, istd,
                                    gamma, beta, slope, drop_mode, p, seed, P, ws, dgamma, dbeta, accumulate,
                                    reinterpret_cast<_Float16*>(dZ), ldo, seed_dev, groups, 0, stream);
+}
+// backward of arco_bn_act_d2s_fwd: dA in the activation's voxel order, dY in Y's (voxel, tap) row order (what the GEMM's gradients read)
+int arco_bn_act_d2s_bwd(const float* dA, long ldd, const float* Y, long M8, int C, const float* mean, const float* istd,
+                        const float* gamma, const float* beta, float slope, float* ws, float* dgamma, float* dbeta, int accumulate,
+                        float* dY, int X2, int Y2, int Z2, int groups, void* stream) {
+  ARCO_CHECK_ARG(X2 > 0 && Y2 > 0 && Z2 > 0 && M8 % (8l * X2 * Y2 * Z2) == 0 && mean);
+  return bn_act_bwd_impl<float>(dA, ldd, Y, C, M8, C, mean, istd, gamma, beta, slope, 0, 0.f, 0, 1, ws, dgamma, dbeta, accumulate, dY, C,
+                                nullptr, groups, 0, stream, D2S{X2, Y2, Z2});
+}
+int arco_bn_act_d2s_bwd_h(const void* dA, long ldd, const void* Y, long M8, int C, const float* mean, const float* istd,
+                          const float* gamma, const float* beta, float slope, float* ws, float* dgamma, float* dbeta, int accumulate,
+                          void* dY, int X2, int Y2, int Z2, int groups, void* stream) {
+  ARCO_CHECK_ARG(X2 > 0 && Y2 > 0 && Z2 > 0 && M8 % (8l * X2 * Y2 * Z2) == 0 && mean);
+  return bn_act_bwd_impl<_Float16>(reinterpret_cast<const _Float16*>(dA), ldd, reinterpret_cast<const _Float16*>(Y), C, M8, C, mean, istd,
+                                   gamma, beta, slope, 0, 0.f, 0, 1, ws, dgamma, dbeta, accumulate, reinterpret_cast<_Float16*>(dY), C,
+                                   nullptr, groups, 0, stream, D2S{X2, Y2, Z2});
 }
 // GroupNorm / InstanceNorm + activation (vnetWithArgs.py:19-22): statistics of N samples x (C / cpg) channel sets from the
 // per-(sample, channel) slabs of arco_chan_stats(groups = N) / the conv epilogue; apply = arco_bn_act_fwd(groups = N)

@@ -148,6 +148,11 @@ class UpsamplingDeconvBlock(nn.Module):
         # InstanceNorm removes it like BatchNorm does.
         zero_bias_grad = (self.training and is_bn) or isinstance(bn, nn.InstanceNorm3d)
         y = ops.conv(x, w2, conv.bias.repeat(8), bias_grad_zero=zero_bias_grad)
+        if is_bn and self.training and ops.D2S_FUSE and co % 4 == 0:
+            # depth-to-space folded into the BatchNorm passes (and the skip addition with it): ops.BnActD2sFn
+            self._fused = skip is not None and skip.dtype == y.dtype
+            return ops.bn_act_d2s(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0, momentum=bn.momentum, eps=bn.eps,
+                                  num_batches_tracked=bn.num_batches_tracked, residual=skip if self._fused else None)
         z = ops.depth_to_space3(y)
         if not is_bn:
             return _norm_act(z, bn, self.training)

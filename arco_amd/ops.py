@@ -706,6 +706,83 @@ class BnActFn(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, (da if ctx.has_res else None)
 
 
+class BnActD2sFn(torch.autograd.Function):
+    """a = lrelu(BN_train(depth_to_space(y))) (+ residual) WITHOUT the depth-to-space pass: y = [N, 8C, X, Y, Z] is the GEMM form of
+    the k2 s2 transposed conv of UpsamplingDeconvBlock (vnetWithArgs.py:94-118, tap-major channels); read as (voxel, tap) rows of C
+    channels it is the pre-activation in another row order.  Statistics over those rows; the apply pass writes each row to its
+    voxel of a = [N, C, 2X, 2Y, 2Z]; the backward reads da from there and returns dy in y's layout (csrc/elementwise.hip, D2S)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, slope, momentum, eps, nbt, residual):
+        yr, ldy = rows_view(y)
+        n, c8 = int(y.shape[0]), int(y.shape[1])
+        x2, y2, z2 = (int(v) for v in y.shape[2:])
+        c = c8 // 8
+        if ldy != c8 or c8 % 8 or c % 4:
+            raise RuntimeError("arco_amd: bn_act_d2s needs a dense [N, 8C, X, Y, Z] channels-last tensor with C % 4 == 0")
+        half = _is_half(yr)
+        m8 = yr.shape[0] * 8
+        G = BN_GROUPS
+        if G > 1 and n % G != 0:
+            raise RuntimeError(f"arco_amd: bn_groups({G}) needs a batch that is a multiple of {G}")
+        nblk = L.query("arco_chan_stats_blocks", m8 // G)
+        ssum = torch.empty((c, G * nblk), dtype=torch.float32, device=y.device)
+        ssq = torch.empty((c, G * nblk), dtype=torch.float32, device=y.device)
+        L.call("arco_chan_stats_h" if half else "arco_chan_stats", L.ptr(yr), c, m8, c, L.ptr(ssum), L.ptr(ssq), G)
+        mean = torch.empty(G * c, dtype=torch.float32, device=y.device)
+        istd = torch.empty(G * c, dtype=torch.float32, device=y.device)
+        d0, dbuf = _defer_args(running_mean, running_var, c, G, momentum)
+        L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), G * nblk, c, m8, float(eps), float(momentum), L.ptr(mean),
+               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G, d0, L.ptr(dbuf))
+        a = new_act_nd(n, c, (2 * x2, 2 * y2, 2 * z2), y.device, yr.dtype)
+        rr, ldr = (None, 0)
+        if residual is not None:
+            if residual.dtype != y.dtype or tuple(residual.shape) != tuple(a.shape):
+                raise RuntimeError("arco_amd: bn_act_d2s(residual=...) needs an addend of the activation's shape and dtype")
+            rr, ldr = rows_view(residual)
+        L.call("arco_bn_act_d2s_fwd_h" if half else "arco_bn_act_d2s_fwd", L.ptr(yr), m8, c, L.ptr(mean), L.ptr(istd), L.ptr(gamma),
+               L.ptr(beta), float(slope), L.ptr(rr), ldr, L.ptr(a), c, x2, y2, z2, G)
+        ctx.save_for_backward(y, mean, istd, gamma, beta)
+        ctx.cfg = (float(slope), G, nblk, residual is not None)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        y, mean, istd, gamma, beta = ctx.saved_tensors
+        slope, G, nblk, has_res = ctx.cfg
+        yr, _ = rows_view(y)
+        n, c8 = int(y.shape[0]), int(y.shape[1])
+        x2, y2, z2 = (int(v) for v in y.shape[2:])
+        c = c8 // 8
+        half = _is_half(yr)
+        dar, ldd = rows_view(da)
+        if _is_half(dar) != half:
+            dar = dar.to(yr.dtype)
+            ldd = dar.stride(0)
+        dy = new_act_nd(n, c8, (x2, y2, z2), y.device, yr.dtype)
+        ws = torch.empty(G * (2 * c * nblk + 2 * c), dtype=torch.float32, device=y.device)
+        dgamma = dbeta = None
+        acc = 0
+        gv, bv = getattr(gamma, "_arco_grad_view", None), getattr(beta, "_arco_grad_view", None)
+        if (gv is not None and bv is not None and gamma.grad is not None and beta.grad is not None
+                and gamma.grad.data_ptr() == gv.data_ptr() and beta.grad.data_ptr() == bv.data_ptr()):
+            dg_t, db_t, acc = gv, bv, 1               # straight into the optimiser's flat gradient buffer
+            gamma._arco_mark(); beta._arco_mark()
+        else:
+            dg_t = dgamma = torch.empty_like(gamma)
+            db_t = dbeta = torch.empty_like(beta)
+        L.call("arco_bn_act_d2s_bwd_h" if half else "arco_bn_act_d2s_bwd", L.ptr(dar), ldd, L.ptr(yr), yr.shape[0] * 8, c, L.ptr(mean),
+               L.ptr(istd), L.ptr(gamma), L.ptr(beta), slope, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dy), x2, y2, z2, G)
+        return dy, dgamma, dbeta, None, None, None, None, None, None, (da if has_res else None)
+
+
+def bn_act_d2s(y, gamma, beta, running_mean, running_var, slope=0.0, momentum=0.1, eps=1e-5, num_batches_tracked=None, residual=None):
+    return BnActD2sFn.apply(y, gamma, beta, running_mean, running_var, slope, momentum, eps, num_batches_tracked, residual)
+
+
+D2S_FUSE = int(__import__('os').environ.get('ARCO_D2S_FUSE', '1'))      # A/B switch: 0 = separate depth-to-space pass in UpsamplingDeconvBlock
+
+
 class S2D3Fn(torch.autograd.Function):
     """[N,C,2X,2Y,2Z] -> [N,8C,X,Y,Z] (tap-major channels) and back (inverse=True): pure data movement that
     turns the k=2,s=2 (transposed) Conv3d of the V-Net into a 1x1x1 GEMM."""

@@ -359,6 +359,21 @@ int arco_bn_act_add_fwd(const float* Z, long ldz, long M, int C, const float* me
                         const float* beta, float slope, const float* R, long ldr, float* A, long lda, int groups, void* stream);
 int arco_bn_act_add_fwd_h(const void* Z, long ldz, long M, int C, const float* mean, const float* istd, const float* gamma,
                           const float* beta, float slope, const void* R, long ldr, void* A, long lda, int groups, void* stream);
+/* UpsamplingDeconvBlock's BatchNorm + ReLU (+ skip) straight from the GEMM form of the k2 s2 transposed conv (vnetWithArgs.py:94-118):
+ * Y = [voxels of the NV x X2 x Y2 x Z2 grid][8 C] (tap-major channels, tap = dx*4 + dy*2 + dz) is read as M8 = 8 * voxels rows of C
+ * channels - the pre-activation in (voxel, tap) row order; statistics: arco_chan_stats(Y, ld = C, M8, C); the apply pass writes row
+ * (voxel, tap) to voxel (n, 2x+dx, 2y+dy, 2z+dz) of A (and adds R there), the backward reads dA from there and leaves dY in Y's
+ * order - no depth-to-space / space-to-depth pass in either direction.                                                            */
+int arco_bn_act_d2s_fwd(const float* Y, long M8, int C, const float* mean, const float* istd, const float* gamma, const float* beta,
+                        float slope, const float* R, long ldr, float* A, long lda, int X2, int Y2, int Z2, int groups, void* stream);
+int arco_bn_act_d2s_fwd_h(const void* Y, long M8, int C, const float* mean, const float* istd, const float* gamma, const float* beta,
+                          float slope, const void* R, long ldr, void* A, long lda, int X2, int Y2, int Z2, int groups, void* stream);
+int arco_bn_act_d2s_bwd(const float* dA, long ldd, const float* Y, long M8, int C, const float* mean, const float* istd,
+                        const float* gamma, const float* beta, float slope, float* ws, float* dgamma, float* dbeta, int accumulate,
+                        float* dY, int X2, int Y2, int Z2, int groups, void* stream);
+int arco_bn_act_d2s_bwd_h(const void* dA, long ldd, const void* Y, long M8, int C, const float* mean, const float* istd,
+                          const float* gamma, const float* beta, float slope, float* ws, float* dgamma, float* dbeta, int accumulate,
+                          void* dY, int X2, int Y2, int Z2, int groups, void* stream);
 int arco_cast_h2f(const void* x, long n, float* y, void* stream);
 int arco_cast_f2h(const float* x, long n, float scale, void* y, void* stream);
 
