@@ -71,6 +71,8 @@ _SIGS = {
     "arco_bn_act_d2s_fwd_h": [_P, _L, _I, _P, _P, _P, _P, _F, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "arco_bn_act_d2s_bwd": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "arco_bn_act_d2s_bwd_h": [_P, _L, _P, _L, _I, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "arco_d2s3_add": [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    "arco_d2s3_add_h": [_P, _L, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "arco_cast_h2f": [_P, _L, _P, _P],
     "arco_cast_f2h": [_P, _L, _F, _P, _P],
     "arco_gn_finalize": [_P, _P, _I, _I, _I, _I, _L, _F, _P, _P, _P],

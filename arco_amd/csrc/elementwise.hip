@@ -703,6 +703,22 @@ __global__ __launch_bounds__(256) void s2d3_kernel(float* __restrict__ V, long l
   }
 }
 
+// V = depth_to_space(P) + ADD in one pass: the gradient of an activation that feeds BOTH a DownsamplingConvBlock (through space-to-depth)
+// and the decoder's skip connection (vnetWithArgs.py:186-201,224-236) - instead of the inverse permutation followed by an add
+template <typename T>
+__global__ __launch_bounds__(256) void d2s3_add_kernel(const T* __restrict__ P, long ldp, int NV, int X2, int Y2, int Z2, int C,
+                                                      const T* __restrict__ ADD, long lda, T* __restrict__ V, long ldv) {
+  const int q4 = C / 4;
+  const long tot = (long)NV * X2 * Y2 * Z2 * 8 * q4;
+  const D2S ds{X2, Y2, Z2};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {      // over OUTPUT voxels: contiguous stores
+    const int c = (int)(i % q4) * 4; const long ro = i / q4;
+    const long r = d2s_src_row(ro, ds);                        // (voxel, tap) row of P: P[q][tap * C + c] at q = r >> 3, tap = r & 7
+    const f32x4 v = ld4f(P + (r >> 3) * ldp + (r & 7) * C + c) + ld4f(ADD + ro * lda + c);
+    st4f(V + ro * ldv + c, v);
+  }
+}
+
 // ---- trilinear resize, align_corners=True (nn.Upsample(mode='trilinear'), model_3D.py:46-58)
 __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ X, long ldx, int NV, int Di, int Hi, int Wi,
                                                            int C, int Do, int Ho, int Wo, float* __restrict__ Y, long ldy) {
@@ -1266,6 +1282,20 @@ int arco_s2d3(float* V, long ldv, int NV, int X2, int Y2, int Z2, int C, float* 
   ARCO_CHECK_ARG((C & 3) == 0 && (ldv & 3) == 0 && (ldp & 3) == 0);
   hipLaunchKernelGGL(s2d3_kernel, dim3(ew_grid((long)NV * X2 * Y2 * Z2 * 8 * (C / 4))), dim3(256), 0, as_stream(stream), V, ldv,
                      NV, X2, Y2, Z2, C, P, ldp, dir);
+  return arco_launch_status();
+}
+// V[(n, 2x+dx, 2y+dy, 2z+dz)][c] = P[(n, x, y, z)][tap * C + c] + ADD[(same voxel)][c]   (tap = dx*4 + dy*2 + dz)
+int arco_d2s3_add(const float* P, long ldp, int NV, int X2, int Y2, int Z2, int C, const float* ADD, long lda, float* V, long ldv, void* stream) {
+  ARCO_CHECK_ARG(P && ADD && V && (C & 3) == 0 && (ldp & 3) == 0 && (lda & 3) == 0 && (ldv & 3) == 0);
+  hipLaunchKernelGGL(d2s3_add_kernel<float>, dim3(ew_grid((long)NV * X2 * Y2 * Z2 * 8 * (C / 4))), dim3(256), 0, as_stream(stream), P, ldp,
+                     NV, X2, Y2, Z2, C, ADD, lda, V, ldv);
+  return arco_launch_status();
+}
+int arco_d2s3_add_h(const void* P, long ldp, int NV, int X2, int Y2, int Z2, int C, const void* ADD, long lda, void* V, long ldv, void* stream) {
+  ARCO_CHECK_ARG(P && ADD && V && (C & 3) == 0 && (ldp & 3) == 0 && (lda & 3) == 0 && (ldv & 3) == 0);
+  hipLaunchKernelGGL(d2s3_add_kernel<_Float16>, dim3(ew_grid((long)NV * X2 * Y2 * Z2 * 8 * (C / 4))), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const _Float16*>(P), ldp, NV, X2, Y2, Z2, C, reinterpret_cast<const _Float16*>(ADD), lda,
+                     reinterpret_cast<_Float16*>(V), ldv);
   return arco_launch_status();
 }
 int arco_trilinear_fwd(const float* X, long ldx, int NV, int Di, int Hi, int Wi, int C, int Do, int Ho, int Wo, float* Y,

@@ -105,11 +105,13 @@ class DownsamplingConvBlock(nn.Module):
         self.conv = nn.Sequential(*layers)
         self.has_norm = norm is not None
 
-    def forward(self, x):
+    def forward(self, x, xs=None):
+        """xs: space_to_depth3(x) when the caller already made it (VNet.encoder: ops.s2d_skip pairs it with the skip alias of x)."""
         conv, bn = self.conv[0], (self.conv[1] if self.has_norm else None)
         co, ci = conv.weight.shape[0], conv.weight.shape[1]
         w2 = conv.weight.permute(0, 2, 3, 4, 1).reshape(co, 8 * ci, 1, 1, 1)      # [co][(dx,dy,dz), ci]
-        xs = ops.space_to_depth3(x)
+        if xs is None:
+            xs = ops.space_to_depth3(x)
         if not isinstance(bn, nn.BatchNorm3d):
             return _norm_act(ops.conv(xs, w2, conv.bias), bn, self.training)
         if self.training:
@@ -195,11 +197,13 @@ class VNet(nn.Module):
 
     def encoder(self, input):
         x = ops.to_channels_last(input.to(torch.float32))
-        x1 = self.block_one(x)
-        x2 = self.block_two(self.block_one_dw(x1))
-        x3 = self.block_three(self.block_two_dw(x2))
-        x4 = self.block_four(self.block_three_dw(x3))
-        x5 = self._drop(self.block_five(self.block_four_dw(x4)))
+        # every level's activation feeds the next DownsamplingConvBlock (through space-to-depth) AND the decoder's skip connection: the
+        # two gradients meet inside one kernel (ops.S2dSkipFn); the returned features are the skip aliases
+        x1s, x1 = ops.s2d_skip(self.block_one(x))
+        x2s, x2 = ops.s2d_skip(self.block_two(self.block_one_dw(x1, x1s)))
+        x3s, x3 = ops.s2d_skip(self.block_three(self.block_two_dw(x2, x2s)))
+        x4s, x4 = ops.s2d_skip(self.block_four(self.block_three_dw(x3, x3s)))
+        x5 = self._drop(self.block_five(self.block_four_dw(x4, x4s)))
         return [x1, x2, x3, x4, x5]
 
     def decoder(self, features):

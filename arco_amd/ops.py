@@ -797,6 +797,42 @@ class S2D3Fn(torch.autograd.Function):
         return _s2d3(dy, not ctx.inverse), None
 
 
+class S2dSkipFn(torch.autograd.Function):
+    """(space_to_depth(x), x-as-skip) for an encoder activation that feeds BOTH the next DownsamplingConvBlock and the decoder's skip
+    connection (vnetWithArgs.py:186-201,224-236): the backward forms depth_to_space(d xs) + d skip in one pass (arco_d2s3_add) instead
+    of the inverse permutation followed by a full-tensor add (the 3-D sibling of MaxPoolSkipFn)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return _s2d3(x, False), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dxs, dskip):
+        if dxs is None:
+            return dskip
+        if dskip is None or dskip.dtype != dxs.dtype:
+            d = _s2d3(dxs, True)
+            return d if dskip is None else d + dskip
+        n, c = ctx.shape[0], ctx.shape[1]
+        x2, y2, z2 = (int(v) for v in dxs.shape[2:])
+        pr, ldp = rows_view(dxs)
+        ar, lda = rows_view(dskip)
+        out = new_act_nd(n, c, ctx.shape[2:], dxs.device, pr.dtype)
+        L.call("arco_d2s3_add_h" if _is_half(pr) else "arco_d2s3_add", L.ptr(pr), ldp, n, x2, y2, z2, c, L.ptr(ar), lda, L.ptr(out), c)
+        return out
+
+
+S2D_SKIP = int(__import__('os').environ.get('ARCO_S2D_SKIP', '1'))      # A/B switch: 0 = inverse permutation + tensor-library add
+
+
+def s2d_skip(x):
+    """(space_to_depth3(x), alias of x to use as the skip connection) - see S2dSkipFn."""
+    if not S2D_SKIP:
+        return S2D3Fn.apply(x, False), x
+    return S2dSkipFn.apply(x)
+
+
 def _s2d3(x, inverse):
     n, c = int(x.shape[0]), int(x.shape[1])
     sp = [int(v) for v in x.shape[2:]]

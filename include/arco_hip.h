@@ -374,6 +374,10 @@ int arco_bn_act_d2s_bwd(const float* dA, long ldd, const float* Y, long M8, int 
 int arco_bn_act_d2s_bwd_h(const void* dA, long ldd, const void* Y, long M8, int C, const float* mean, const float* istd,
                           const float* gamma, const float* beta, float slope, float* ws, float* dgamma, float* dbeta, int accumulate,
                           void* dY, int X2, int Y2, int Z2, int groups, void* stream);
+/* V = depth_to_space(P) + ADD: the gradient of an encoder activation that feeds both the next DownsamplingConvBlock (through
+ * space-to-depth) and the decoder's skip connection (vnetWithArgs.py:186-201,224-236), one pass instead of arco_s2d3 + an add    */
+int arco_d2s3_add(const float* P, long ldp, int NV, int X2, int Y2, int Z2, int C, const float* ADD, long lda, float* V, long ldv, void* stream);
+int arco_d2s3_add_h(const void* P, long ldp, int NV, int X2, int Y2, int Z2, int C, const void* ADD, long lda, void* V, long ldv, void* stream);
 int arco_cast_h2f(const void* x, long n, float* y, void* stream);
 int arco_cast_f2h(const float* x, long n, float scale, void* y, void* stream);
 
