@@ -1,6 +1,6 @@
 // f16 ACTIVATION STORAGE for the volume path (BASELINE.json configs[4], "fp16 MFMA conv": the V-Net body of
 // vnetWithArgs.py:5-31,67-118,145-252 with every activation and activation gradient held as f16 in HBM and LDS; weights,
-// BatchNorm statistics, loss and optimizer stay fp32).  Three kernels:
+// BatchNorm statistics, loss and optimizer stay fp32).  Kernels:
 //
 //   hconv_kernel     3x3x3 (planes of H x W, depth tap = outer loop) and 1x1x1 convolutions, forward and - with flipped +
 //                    transposed packed weights - data gradient.  f16 tiles go from HBM to LDS untouched (16-byte pieces,
@@ -17,6 +17,7 @@
 //                    reads land on eight distinct 8-bank groups.  The four waves of a workgroup take one 32-pixel K step of
 //                    a 128-pixel tile each and own ALL taps x sub-tiles (a tap's input fragment feeds CO_T MFMAs); partners
 //                    are summed once per launch.  Slabs [chunk][tap][CoutPad][CinPad] as in igemm.hip -> wgrad_reduce.
+//   hconv_rw_kernel  the resident-weights form of hconv_kernel for the 16-channel full-resolution level (further down).
 //   cast kernels     the fp32 <-> f16 boundary of the V-Net (outputs up, gradients down with the loss scale).
 #include "igemm_args.h"
 #include <stdlib.h>
