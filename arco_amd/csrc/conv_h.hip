@@ -332,10 +332,12 @@ static long h_flat_blocks(const IgemmArgs& a, int bm, int bn) {
 }
 template <bool FLAT>
 static int hconv_dispatch3(const IgemmArgs& a, hipStream_t st, int* q) {
-  static const long want = getenv("ARCO_HCONV_WANT") ? atol(getenv("ARCO_HCONV_WANT")) : 512;
+  static const long want = getenv("ARCO_HCONV_WANT") ? atol(getenv("ARCO_HCONV_WANT")) : 256;      // (the deep levels run better on the larger tiles even with one workgroup per CU: 128 ch 39.8 -> 37.6 us)
   auto blocks = [&](int bm, int bn) { return FLAT ? h_flat_blocks(a, bm, bn) : h_rect_blocks(a, bm, bn); };
   if (a.Npad <= 16) return launch_hconv<9, 128, 16, 4, 1, 3, FLAT>(a, st, q);
   if (a.Npad <= 32) {
+    static const int big = getenv("ARCO_HCONV_256") ? atoi(getenv("ARCO_HCONV_256")) : 1;      // 256-pixel tiles (4 x 2 MFMA tiles per wave: 6 fragment reads per 8 MFMAs instead of 4 per 4): 32 -> 32 @80x80x48 x2 63 -> 54 us; 0 = off
+    if (big && !FLAT && blocks(256, 32) >= want) return launch_hconv<9, 256, 32, 4, 1, 3, false>(a, st, q);
     if (blocks(128, 32) >= want) return launch_hconv<9, 128, 32, 4, 1, 3, FLAT>(a, st, q);
     return launch_hconv<9, 64, 32, 2, 2, 3, FLAT>(a, st, q);
   }

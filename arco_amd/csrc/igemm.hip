@@ -527,6 +527,8 @@ static int dispatch_flat3(const IgemmArgs& a, hipStream_t st, int* nmb) {
   const long want = want_blocks(a);
   if (a.Npad <= 16) return launch_igemm<9, 128, 16, 4, 1, 16, false, 3, true>(a, st, nmb);
   if (a.Npad <= 32) {
+    static const int big = getenv("ARCO_IGEMM_256") ? atoi(getenv("ARCO_IGEMM_256")) : 0;      // A/B: 256-position tiles (4 x 2 MFMA tiles per wave)
+    if (big && a.mma == 3 && flat_blocks(a, 256, 32) >= want) return launch_igemm<9, 256, 32, 4, 1, 16, false, 3, true>(a, st, nmb);
     if (flat_blocks(a, 128, 32) >= want) return launch_igemm<9, 128, 32, 4, 1, 16, false, 3, true>(a, st, nmb);
     return launch_igemm<9, 64, 32, 2, 2, 16, false, 3, true>(a, st, nmb);
   }
