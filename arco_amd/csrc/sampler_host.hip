@@ -155,21 +155,28 @@ inline bool grid_geom(long high, long shape, int cut, int mirror, GridGeom& q) {
   q.per_row = mirror ? 2 * q.take : q.take;
   return true;
 }
-// number of generator draws of one call when it does not depend on the drawn values: no candidate can be
-// dropped by the `< high` filter (edge^2 <= high, exact float32 round trip) -> kept = nblk * per_row
-inline bool grid_draws(long high, long shape, int cut, int mirror, uint64_t* draws) {
+// number of generator draws of one call when it does not depend on the drawn values.  Two cases:
+//  (a) no candidate can be dropped by the `< high` filter (edge^2 <= high, exact float32 round trip): kept = nblk * per_row;
+//  (b) candidates may be dropped (edge^2 > high: the anchor calls - high = the class's candidate count is rarely a square), but at most
+//      `shape` are drawn (nblk * per_row <= shape): the final randperm(kept') takes kept' - 1 draws and the padding shape - kept' draws -
+//      shape - 1 together WHATEVER kept' is (kept' >= 1: block (0, 0) holds values < high only, and its mirror images stay inside the block).
+// *kept_fixed: case (a) (the caller may start the final shuffle at a known stream offset).
+inline bool grid_draws(long high, long shape, int cut, int mirror, uint64_t* draws, bool* kept_fixed = nullptr) {
   GridGeom q;
   if (!grid_geom(high, shape, cut, mirror, q)) return false;
-  if (q.edge * q.edge > high || high > (1l << 24)) return false;
+  if (q.edge * q.edge > (1l << 24) || high > (1l << 24)) return false;          // (float32 round trip of the picked values must be exact)
+  const long kept = q.nblk * q.per_row;
+  const bool fixed = q.edge * q.edge <= high;
+  if (!fixed && !(kept <= shape && q.take >= 1 && kept >= 1)) return false;
   uint64_t d = 0;
   for (int bi = 0; bi < cut; ++bi) {
     const long h = bi == cut - 1 ? q.last : q.side;
     for (int bj = 0; bj < cut; ++bj) { const long w = bj == cut - 1 ? q.last : q.side; d += (uint64_t)(h * w - 1 + q.take); }
   }
-  const long kept = q.nblk * q.per_row;
   if (kept > 0) d += (uint64_t)(kept - 1);
   if (kept < shape) d += (uint64_t)(shape - kept);
   *draws = d;
+  if (kept_fixed) *kept_fixed = fixed;
   return true;
 }
 // one sampler call on generator g (loss_helper_3d.py:120-184 / :187-268); returns shape, or 0 for the fallback
@@ -378,12 +385,36 @@ static long sample_many_impl(uint8_t* state, long state_bytes, int n_jobs, const
     const long high = highs[j], shape = shapes[j];
     if (high <= 0 || shape <= 0 || high >= (1l << 31)) { done = -1; break; }
     int64_t* scratch = g_arena.data() + off[j];
-    uint64_t draws = 0;
-    if (shape >= 8192 && n_workers < max_threads && grid_draws(high, shape, cut, mirror, &draws)) {
+    {   // the 1-D fallback's first branch (loss_helper.py:207-208 / :255-256: `high // patch > shape or high < patch` ->
+        // torch.randint(high, size=(shape,)), one 32-bit draw per element) natively: with C = 2 the banks of a volume step keep their
+        // single initial row, so every negative call is randint(1, (Q * Nn,)) - handled in Python it cut the sequence (and joined
+        // the deferred anchor calls in front of it) at every class
+      GridGeom qq;
+      if (!grid_geom(high, shape, cut, mirror, qq) && (high / 16 > shape || high < 16)) {
+        int64_t* out = outs[j];
+        if (shape >= 8192 && n_workers < max_threads) {
+          copies[j] = g;
+          MT* copy = &copies[j];
+          workers.run([copy, high, shape, out]() { for (long i = 0; i < shape; ++i) out[i] = (int64_t)((*copy)() % (uint32_t)high); });
+          ++n_workers;
+          g.skip((uint64_t)shape);
+        } else {
+          for (long i = 0; i < shape; ++i) out[i] = (int64_t)(g() % (uint32_t)high);
+        }
+        continue;
+      }
+    }
+    uint64_t draws = 0; bool kfix = false;
+    // worker calls: the negative draws (large shape) and - new in round 3 - the anchor calls of classes with many candidates (the
+    // background class of a volume: 2.2 M candidates = 16 block shuffles of 138 000 elements, 2 ms that used to run inline with the GPU
+    // idle; their generator consumption is value-independent too, case (b) of grid_draws)
+    static const bool anchors_async = !(getenv("ARCO_SAMPLER_ANCHORS_ASYNC") && atoi(getenv("ARCO_SAMPLER_ANCHORS_ASYNC")) == 0);
+    if ((shape >= 8192 || (anchors_async && high >= 65536)) && n_workers < max_threads && grid_draws(high, shape, cut, mirror, &draws, &kfix)) {
       copies[j] = g;
       MT* copy = &copies[j];
       int64_t* out = outs[j];
-      workers.run([copy, high, shape, cut, mirror, out, scratch]() { grid_sample_mt(*copy, high, shape, cut, mirror, out, scratch, 4, true); });
+      const int par = shape >= 8192 ? 4 : 16;
+      workers.run([copy, high, shape, cut, mirror, out, scratch, par, kfix]() { grid_sample_mt(*copy, high, shape, cut, mirror, out, scratch, par, kfix); });
       ++n_workers;
       g.skip(draws);
       if (trace) fprintf(stderr, "[sampler] job %d (worker, %ld) launched at %.3f ms\n", j, shape, ms());

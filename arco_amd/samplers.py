@@ -145,7 +145,10 @@ def finish_many():
     _lib.load().arco_grid_sample_many_finish()
 
 
-def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=8, defer=False):
+_MAX_THREADS = int(__import__('os').environ.get('ARCO_SAMPLER_THREADS', '8'))
+
+
+def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=None, defer=False):
     """[(high, shape), ...] -> list of index tensors, the SAME draws as calling grid_(as_)monte_carlo_sample
     for each job in order, through ONE native call: jobs whose generator consumption does not depend on the drawn
     values (the negative draws: high = bank length = a perfect square) run in worker threads on copies of the
@@ -177,7 +180,7 @@ def grid_sample_many(jobs, mirror, cut_count=4, out=None, max_threads=8, defer=F
         outs = (ctypes.c_void_p * m)(*[v.data_ptr() for v in views[first:]])
         st = torch.get_rng_state()
         fn = lib.arco_grid_sample_many_async if defer else lib.arco_grid_sample_many
-        rc = fn(st.data_ptr(), st.numel(), m, highs, shapes, int(cut_count), int(bool(mirror)), outs, int(max_threads))
+        rc = fn(st.data_ptr(), st.numel(), m, highs, shapes, int(cut_count), int(bool(mirror)), outs, int(max_threads or _MAX_THREADS))
         if rc < 0:
             raise RuntimeError(f"arco_grid_sample_many failed ({rc})")
         torch.set_rng_state(st)

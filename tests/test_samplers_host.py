@@ -138,6 +138,35 @@ def test_pregenerated_blocks_of_another_state_are_ignored():
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_anchor_calls_with_droppable_candidates_run_deferred(seed):
+    """Anchor calls of classes with many candidates run in worker threads too (round 3): high is rarely a square, so picked values
+    >= high can be dropped - but at most `shape` values are drawn, and then the final shuffle + padding consume shape - 1 draws
+    whatever is dropped (loss_helper.py:419-431).  high = 70 000: 225 of 70 225 grid values are droppable, ~0.8 drops per call - the
+    seeds cover calls with and without drops; 2 204 346 = the background class of the LA step.  Same indices, same generator state
+    and same following draws as the calls made one by one."""
+    import random
+    from arco_amd import samplers
+    # (1, 131072), (9, 300): the 1-D fallback's torch.randint branch (a volume step's banks keep one row) - native, does not cut the sequence
+    jobs = [(70000, 256), (4096, 256 * 512), (2204346, 256), (1, 256 * 512), (191444, 256), (1, 256 * 512), (70000, 256), (9, 300), (66000, 256)]
+    torch.manual_seed(seed); random.seed(seed)
+    ref = [samplers.grid_as_monte_carlo_sample(h, sh) for h, sh in jobs]
+    nxt_ref = torch.rand(4)
+    st_ref = torch.get_rng_state().clone()
+    assert any(int((r >= 0).sum()) == 256 for r in ref)
+    for pre in (0, 4 << 20):
+        torch.manual_seed(seed); random.seed(seed)
+        if pre:
+            samplers.pregen(pre)
+        buf = torch.empty(sum(sh for _, sh in jobs), dtype=torch.int64)
+        got = samplers.grid_sample_many(jobs, True, out=buf, defer=True)
+        nxt = torch.rand(4)                                   # drawn while the worker calls may still run
+        samplers.finish_many()
+        assert torch.equal(nxt, nxt_ref) and torch.equal(torch.get_rng_state(), st_ref), pre
+        for r, g_ in zip(ref, got):
+            assert torch.equal(r, g_), pre
+
+
 @pytest.mark.parametrize("pre", [3 << 20, 0])
 def test_deferred_sampler_sequence(pre):
     """grid_sample_many(defer=True) returns once the generator holds its final state (the worker calls' draw counts are
