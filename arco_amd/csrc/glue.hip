@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void sup_loss_partial_kernel(const float* __re
     for (int c = 0; c < CM; ++c) if (c < C) {
       const float p = expf(v[c] - lse);
       const float t = (l == c) ? 1.f : 0.f;
-      if (l == c) acc[0] += (double)(lse - v[c]);
+      if (l == c) acc[0] += (double)(logf(s) - (v[c] - mx));
       acc[2 + c] += (double)(p * t); acc[2 + CM + c] += (double)(p * p); acc[2 + 2 * CM + c] += (double)t;
     }
     acc[1] += 1.0;
@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256) void unsup_loss_partial_kernel(const float* __
       for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[c]);
       float s = 0.f;
       for (int c = 0; c < C; ++c) s += expf(x[c] - mx);
-      const float ce = mx + logf(s) - x[l];
+      // torch's log_softmax association, (x - max) - log(sum): with saturated logits `max + log(sum)` rounds log(sum) away
+      // and CE > 0 - which selects the elements of the mean (train_arco_2d.py:488) - would drop rows torch keeps
+      const float ce = logf(s) - (x[l] - mx);
       if (ce > 0.f) { a2 += (double)ce; a3 += 1.0; }
     }
   }
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void unsup_loss_bwd_kernel(const float* __rest
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf(x[c] - mx);
     const float lse = mx + logf(s);
-    const bool sel = l >= 0 && (lse - x[l >= 0 ? l : 0]) > 0.f;
+    const bool sel = l >= 0 && (logf(s) - (x[l >= 0 ? l : 0] - mx)) > 0.f;
     const float w = sel ? gs * (float)stats[r / P] : 0.f;
     for (int c = 0; c < C; ++c) dX[r * ldo + c] = sel ? w * (expf(x[c] - lse) - (l == c ? 1.f : 0.f)) : 0.f;
   }

@@ -138,6 +138,8 @@ class ArcoStep3D:
         with torch.no_grad(), ops.logits_only():                         # :260-262
             pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
+        if self.keep_debug:      # tests: the teacher's decisions before the mixing (cutout writes -1 into the labels in place)
+            dbg_pseudo = (pseudo_labels.clone(), pseudo_logits.clone())
         # :268-278: the mixing strategy of --apply_aug on the GPU (train_arco_3d.py:270-271); the PIL transforms are identity
         u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data_3d(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
         self.k_fe_ema.update(0.99)                                      # :279-281
@@ -167,6 +169,9 @@ class ArcoStep3D:
             low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
         plan = C_.contrast_masks(label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all,
                                  delta_n=a.strong_threshold_u2pl)
+        if self.keep_debug:      # tests: the step's gradient-free decision inputs (tests/test_step3d_parity_gpu.py)
+            self.decisions = dict(pseudo_labels=dbg_pseudo[0], pseudo_logits=dbg_pseudo[1], low=low_mask_all, high=high_mask_all,
+                                  prob_l_t=prob_l_t, prob_u_t=prob_u_t)
         dense = getattr(a, "dense_head", 0)
         if not batched:
             pred_l, _, l_fm = self.s_train_l(l_data)                     # :283

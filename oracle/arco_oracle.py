@@ -323,43 +323,51 @@ def feature_extractor_forward(fmap, sd, mode='bilinear'):
 # --------------------------------------------------------------------------
 
 
-def _vnet_bn(x, sd, key, train):
+def _vnet_bn(x, sd, key, train, track=False):
+    """track=True: train mode that also makes the momentum update of sd's running statistics in place (nn.BatchNorm3d)."""
     if train:
-        return bn_train(x, sd[f"{key}.weight"], sd[f"{key}.bias"])
+        rm = sd[f"{key}.running_mean"] if track else None
+        rv = sd[f"{key}.running_var"] if track else None
+        return bn_train(x, sd[f"{key}.weight"], sd[f"{key}.bias"], rm, rv)
     return F.batch_norm(x, sd[f"{key}.running_mean"], sd[f"{key}.running_var"], sd[f"{key}.weight"], sd[f"{key}.bias"],
                         False, 0.1, 1e-5)
 
 
-def _vnet_stage(x, sd, pre, n, train=True):
+def _vnet_stage(x, sd, pre, n, train=True, track=False, tap=None):
     for s in range(n):
-        x = F.conv3d(x, sd[f"{pre}.conv.{3 * s}.weight"], sd[f"{pre}.conv.{3 * s}.bias"], padding=1)
-        x = F.relu(_vnet_bn(x, sd, f"{pre}.conv.{3 * s + 1}", train))
+        z = F.conv3d(x, sd[f"{pre}.conv.{3 * s}.weight"], sd[f"{pre}.conv.{3 * s}.bias"], padding=1)
+        a = F.relu(_vnet_bn(z, sd, f"{pre}.conv.{3 * s + 1}", train, track))
+        if tap is not None:      # tests: (conv key, input, pre-BN output, activation) of every 3x3x3 stage, in forward order
+            z.retain_grad(); a.retain_grad()
+            tap.append((f"{pre}.conv.{3 * s}", x, z, a))
+        x = a
     return x
 
 
-def _vnet_down(x, sd, pre, train=True):
+def _vnet_down(x, sd, pre, train=True, track=False):
     x = F.conv3d(x, sd[f"{pre}.conv.0.weight"], sd[f"{pre}.conv.0.bias"], stride=2)
-    return F.relu(_vnet_bn(x, sd, f"{pre}.conv.1", train))
+    return F.relu(_vnet_bn(x, sd, f"{pre}.conv.1", train, track))
 
 
-def _vnet_up(x, sd, pre, train=True):
+def _vnet_up(x, sd, pre, train=True, track=False):
     x = F.conv_transpose3d(x, sd[f"{pre}.conv.0.weight"], sd[f"{pre}.conv.0.bias"], stride=2)
-    return F.relu(_vnet_bn(x, sd, f"{pre}.conv.1", train))
+    return F.relu(_vnet_bn(x, sd, f"{pre}.conv.1", train, track))
 
 
-def vnet_forward(x, sd, train=True):
-    """train=False: net.eval() (BatchNorm on the running statistics), as the evaluation uses it."""
-    t = train
-    x1 = _vnet_stage(x, sd, "block_one", 1, t)
-    x2 = _vnet_stage(_vnet_down(x1, sd, "block_one_dw", t), sd, "block_two", 2, t)
-    x3 = _vnet_stage(_vnet_down(x2, sd, "block_two_dw", t), sd, "block_three", 3, t)
-    x4 = _vnet_stage(_vnet_down(x3, sd, "block_three_dw", t), sd, "block_four", 3, t)
-    x5 = _vnet_stage(_vnet_down(x4, sd, "block_four_dw", t), sd, "block_five", 3, t)
-    u5 = _vnet_up(x5, sd, "block_five_up", t) + x4
-    u6 = _vnet_up(_vnet_stage(u5, sd, "block_six", 3, t), sd, "block_six_up", t) + x3
-    u7 = _vnet_up(_vnet_stage(u6, sd, "block_seven", 3, t), sd, "block_seven_up", t) + x2
-    u8 = _vnet_up(_vnet_stage(u7, sd, "block_eight", 2, t), sd, "block_eight_up", t) + x1
-    x9 = _vnet_stage(u8, sd, "block_nine", 1, t)
+def vnet_forward(x, sd, train=True, track=False, tap=None):
+    """train=False: net.eval() (BatchNorm on the running statistics), as the evaluation uses it; track=True: train mode
+    with the running-statistics momentum updates of the BatchNorm3d layers made in place, in forward order."""
+    t, k = train, track
+    x1 = _vnet_stage(x, sd, "block_one", 1, t, k, tap)
+    x2 = _vnet_stage(_vnet_down(x1, sd, "block_one_dw", t, k), sd, "block_two", 2, t, k, tap)
+    x3 = _vnet_stage(_vnet_down(x2, sd, "block_two_dw", t, k), sd, "block_three", 3, t, k, tap)
+    x4 = _vnet_stage(_vnet_down(x3, sd, "block_three_dw", t, k), sd, "block_four", 3, t, k, tap)
+    x5 = _vnet_stage(_vnet_down(x4, sd, "block_four_dw", t, k), sd, "block_five", 3, t, k, tap)
+    u5 = _vnet_up(x5, sd, "block_five_up", t, k) + x4
+    u6 = _vnet_up(_vnet_stage(u5, sd, "block_six", 3, t, k, tap), sd, "block_six_up", t, k) + x3
+    u7 = _vnet_up(_vnet_stage(u6, sd, "block_seven", 3, t, k, tap), sd, "block_seven_up", t, k) + x2
+    u8 = _vnet_up(_vnet_stage(u7, sd, "block_eight", 2, t, k, tap), sd, "block_eight_up", t, k) + x1
+    x9 = _vnet_stage(u8, sd, "block_nine", 1, t, k, tap)
     out = F.conv3d(x9, sd["out_conv.weight"], sd["out_conv.bias"])
     fmap = [u5, u6, u7, u8, x9]
     return out, fmap[0], fmap

@@ -1039,9 +1039,86 @@ def gen_vnet_norms(mods):
     print("g17_vnet_norms", len(out))
 
 
+# ---------------------------------------------------------------- G18 whole V-Net, strict gradients (float64 run of the reference module)
+VNET_STRICT = dict(shape=(48, 48, 32), b=2, seeds=range(2000, 2800), state_seed=52, deep_elems=512, stride=53)
+
+
+def gen_vnet_strict(mods):
+    """Strict gradient target for the whole V-Net (vnetWithArgs.py:145-252).  Two things make the fp32 reference itself a
+    poor target here (measured in this script, stored as `ref32_dev::*`): (i) torch's CPU BatchNorm3d backward sums 10^5
+    random-sign terms per channel sequentially in fp32, and the weight gradients of the layer below multiply that coherent
+    error by sum(activation) - the fp32 run of the REFERENCE sits 0.3-7 % from its own float64 run on every input tried;
+    (ii) ReLU decisions at the deep levels (36-288 values per channel, each a visible share of its channel) flip under forward rounding.  So the target is the
+    reference module evaluated in float64 (`net.double()`: the reference's code, exact to 1e-12), on the input whose smallest
+    |BatchNorm output| over the deep layers (<= 512 values per channel: the 6x6x4 and 3x3x2 levels) is largest among 800 fixture seeds; planes
+    48x48x32 ... 3x3x2 are not multiples of 16, so the ragged-tile paths of the 27-tap kernels are on the path."""
+    V = mods["networks.vnetWithArgs"]
+    cfg = VNET_STRICT
+    net = V.VNet(n_channels=1, n_classes=2, normalization='batchnorm', has_dropout=True)
+    sd = fx.vnet_state(cfg["state_seed"])
+    net.load_state_dict(sd, strict=True)
+    net.train()
+
+    def deep_margin(x):
+        worst = [float("inf")]
+
+        def hook(mod, i, o):
+            if o.numel() // o.shape[1] <= cfg["deep_elems"]:
+                worst[0] = min(worst[0], float(o.detach().abs().min()))
+        hooks = [m.register_forward_hook(hook) for m in net.modules() if isinstance(m, nn.BatchNorm3d)]
+        with torch.no_grad():
+            net(x, turnoff_drop=True)
+        for h in hooks:
+            h.remove()
+        return worst[0]
+
+    best = (-1.0, None)
+    for s in cfg["seeds"]:
+        net.load_state_dict(sd)
+        m = deep_margin(fx.image_batch(s, cfg["b"], 1, cfg["shape"]))
+        if m > best[0]:
+            best = (m, s)
+    margin, seed = best
+
+    def run(dt):
+        net.load_state_dict(sd)
+        net.to(dt)
+        for p_ in net.parameters():
+            p_.grad = None
+        x = fx.image_batch(seed, cfg["b"], 1, cfg["shape"]).to(dt).requires_grad_(True)
+        o, _, fm = net(x, turnoff_drop=True)
+        loss = (o * probe_like(o, 4).to(dt)).sum()
+        for i, f in enumerate(fm):
+            loss = loss + (f * probe_like(f, 20 + i).to(dt)).sum()
+        loss.backward()
+        return o.detach(), [f.detach() for f in fm], x.grad.detach(), {n: p_.grad.detach().clone() for n, p_ in net.named_parameters()}
+
+    o32, f32_, dx32, g32 = run(torch.float32)
+    o64, f64_, dx64, g64 = run(torch.float64)
+    net.to(torch.float32)
+    out = dict(seed=np.array(seed), margin=np.array(margin), stride=np.array(cfg["stride"]),
+               out_sub=o64[..., ::2, ::2, ::2].float().numpy(), dx=dx64.float().numpy(),
+               out_l2=np.array(float(o64.pow(2).sum().sqrt())))
+    for i, f in enumerate(f64_):
+        out[f"fmap{i}_l2"] = np.array(float(f.pow(2).sum().sqrt()))
+    names, gabs, gl2, dev = [], [], [], []
+    for n, g in g64.items():
+        names.append(n); gabs.append(float(g.abs().sum())); gl2.append(float(g.pow(2).sum().sqrt()))
+        dev.append(float((g32[n].double() - g).abs().max() / max(1e-30, float(g.abs().max()))))
+        flat = g.reshape(-1)
+        out["grad::" + n] = (flat if flat.numel() <= 120000 else flat[::cfg["stride"]]).float().numpy()
+    out["grad_names"] = np.array(names); out["grad_abs"] = np.array(gabs); out["grad_l2"] = np.array(gl2)
+    out["ref32_dev"] = np.array(dev)                 # the fp32 reference's own distance to this target, per parameter
+    out["ref32_dev_dx"] = np.array(float((dx32.double() - dx64).abs().max() / dx64.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "g18_vnet_strict.npz"), **out)
+    skip = lambda n: n.endswith(".bias") and ".conv." in n and int(n.split(".")[-2]) % 3 == 0
+    print("g18_vnet_strict seed", seed, "deep margin", margin, "fp32 reference vs its float64 run: worst",
+          max(d for n, d in zip(names, dev) if not skip(n)), "dx", float(out["ref32_dev_dx"]))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
@@ -1059,3 +1136,4 @@ if __name__ == "__main__":
     if "g15" in which: gen_unet_kinkfree(mods)
     if "g16" in which: gen_boundary(mods)
     if "g17" in which: gen_vnet_norms(mods)
+    if "g18" in which: gen_vnet_strict(mods)

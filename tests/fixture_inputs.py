@@ -31,7 +31,7 @@ def onehot(lab, n_cls):
 
 
 def loss_inputs(seed, b=2, n_cls=4, feat=16, spatial=(16, 16), absent=(), low_p=0.35, high_p=0.5,
-                single_class=False, tie_probs=False):
+                single_class=False, tie_probs=False, label_bonus=0.8):
     """Inputs of compute_contra_memobank_loss for one step (b labeled + b unlabeled)."""
     rs = np.random.RandomState(seed)
     B = 2 * b
@@ -45,7 +45,7 @@ def loss_inputs(seed, b=2, n_cls=4, feat=16, spatial=(16, 16), absent=(), low_p=
         lab_u = blob_labels(rs, b, spatial, n_cls, absent)
     lab = np.concatenate([lab_l, lab_u])
     logit = rs.standard_normal((B, n_cls, *spatial)).astype(np.float32)
-    logit += 0.8 * np.moveaxis(np.eye(n_cls, dtype=np.float32)[lab], -1, 1)
+    logit += label_bonus * np.moveaxis(np.eye(n_cls, dtype=np.float32)[lab], -1, 1)
     if tie_probs:
         logit = np.round(logit)          # many exact ties between classes
     prob = torch.softmax(torch.from_numpy(logit), 1)
@@ -97,6 +97,16 @@ LOSS_CASES = {
                             dict(func='smc', num_queries=32, num_negatives=16, delta_n=1.0), 20, 'zeros'),
     "proto_momentum": (dict(b=2, n_cls=4, feat=16, spatial=(16, 16)),
                        dict(func='smc', num_queries=32, num_negatives=16, delta_n=0.97), 96, 'zeros'),
+    # 5-D cases whose banks FILL (loss_helper.py:442-686 with C >= 4, the 3-D trainer's default --num_classes 4,
+    # train_arco_3d.py:44,144-151): with C = 2 or 3 the rank window [3, 20) is empty and no key is ever enqueued.
+    # Step 0 meets the one-row randn bank (1-D fallback sampler), step 1 the grid negative sampler on a grown bank,
+    # step 2 the FIFO truncation.
+    "c4_3d": (dict(b=1, n_cls=4, feat=16, spatial=(12, 12, 8), label_bonus=0.2),
+              dict(func='asmc', num_queries=32, num_negatives=16, delta_n=0.97), [100, 40, 40, 40], 'randn'),
+    "c4_3d_absent": (dict(b=2, n_cls=4, feat=16, spatial=(10, 12, 8), absent=(2,)),
+                     dict(func='smc', num_queries=32, num_negatives=16, delta_n=0.97), [200, 300, 300, 300], 'randn'),
+    "c5_3d_default_q": (dict(b=1, n_cls=5, feat=16, spatial=(12, 10, 12), label_bonus=0.0),
+                        dict(func='asmc', delta_n=0.97), [260, 30000, 150, 30000, 30000], 'randn'),
 }
 LOSS_STEPS = 3
 

@@ -225,10 +225,10 @@ def test_cfg2_graph_replay_equals_eager_at_full_size():
 # ------------------------------------------------------------------------------------------------------------------
 # configs[2]: LA V-Net 112x112x80, --batch_size 2 (4 volumes per step), C = 2, D = 16, asmc
 # ------------------------------------------------------------------------------------------------------------------
-def _make3d(extra, patch=(112, 112, 80), b=2, mma="f32x3"):
+def _make3d(extra, patch=(112, 112, 80), b=2, mma="f32x3", n_cls=2, qsize=4096):
     from arco_amd import train_arco_3d as T3
-    args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", "4096", "--synthetic", "1", "--num_classes", "2",
-                                         "--conv_mma", mma, "--k1", "1.0"] + list(extra))
+    args = T3.build_parser().parse_args(["--batch_size", str(b), "--queue_size", str(qsize), "--synthetic", "1",
+                                         "--num_classes", str(n_cls), "--conv_mma", mma, "--k1", "1.0"] + list(extra))
     args.patch_size = list(patch)
     seed_all(7)
     return T3.ArcoStep3D(args, "cuda:0")
@@ -251,6 +251,40 @@ def test_cfg3_la_vnet_step_at_full_size(mma):
     # the unlabeled negative mask is always empty and the banks keep their single initial randn row (train_arco_3d.py:148)
     assert all(m[0].shape == (1, 16) for m in st.memobank) and st.debug["plan"].new_keys == [0, 0]
     assert "eqv" in st.last_terms                                     # --eqv_pass 1 (reference default) ran at size
+    del st
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_la_vnet_step_at_full_size_four_classes_banks_fill():
+    """The reference trainer's own default is --num_classes 4 (train_arco_3d.py:44): with C = 4 the rank window [3, 20) of
+    loss_helper.py:489,559-561 is not empty, so the 5-D enqueue (`rep_teacher[negative_mask]` on [B, H, W, D, 16] tensors), bank
+    growth past the initial randn row, the grid negative sampler on a grown bank and the FIFO truncation at queue_size all run
+    at the LA size - what the C = 2 steps above can never reach."""
+    from arco_amd import train_arco_3d as T3
+    qsize = 512
+    st = _make3d([], n_cls=4, qsize=qsize)
+    st.keep_debug = True
+    grew, total_keys, lens = False, 0, []
+    for it in range(5):
+        l, ll = T3.synthetic_volume_batch(2, (112, 112, 80), 4, 10 + it, "cuda:0")
+        u, _ = T3.synthetic_volume_batch(2, (112, 112, 80), 4, 20 + it, "cuda:0")
+        before = [m[0].clone() for m in st.memobank]
+        seed_all(300 + it)
+        loss, reco = st.step(l, ll, u)
+        assert bool(torch.isfinite(loss))
+        pl = st.debug["plan"]
+        total_keys += sum(pl.new_keys)
+        lens.append([int(m[0].shape[0]) for m in st.memobank])
+        for c in range(4):                              # FIFO by truncation: the old rows that survive keep their order at the head
+            nb, na, k = before[c].shape[0], st.memobank[c][0].shape[0], int(pl.new_keys[c])
+            assert na == min(qsize, nb + k), (c, nb, k, na)
+            keep = na - min(k, na)
+            if keep:
+                assert torch.equal(st.memobank[c][0][:keep], before[c][nb - keep:])
+        grew = grew or any(x > 16 for x in lens[-1])
+    _check_step_invariants(st, "asmc", qsize, 16, 304)
+    assert total_keys > 0 and grew, (total_keys, lens)
+    assert any(x == qsize for x in lens[-1]), lens                      # at least one bank met the truncation
     del st
     torch.cuda.empty_cache()
 

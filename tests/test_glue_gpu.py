@@ -99,3 +99,35 @@ def test_supervised_and_unsup_losses_vs_reference(golden):
         np.testing.assert_allclose(pu_.grad.cpu().numpy(), g["unsup_grad"], rtol=1e-4, atol=1e-9)
         np.testing.assert_allclose(glue.compute_unsupervised_loss(pu_, lab_u.cuda(), logits_u.cuda(), 0.5).item(),
                                    float(g["unsup_loss_t05"]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_unsup_loss_on_saturated_logits_selects_what_torch_selects(nd):
+    """compute_unsupervised_loss averages over `loss > 0` (train_arco_2d.py:488, train_arco_3d.py:458): with confident logits a
+    large share of the per-voxel CE values is EXACTLY zero in fp32, and which ones are depends on the association of the
+    log-softmax - torch computes (x - max) - log(sum).  Round 4 found the kernel's `max + log(sum) - x` dropping 3 % more rows
+    (the 3-D step parity test); the oracle function is the reference's own arithmetic (F.cross_entropy)."""
+    import arco_oracle as orc
+    from arco_amd import glue
+    rs = np.random.RandomState(5)
+    sp = (24, 20) if nd == 2 else (12, 10, 8)
+    C, b = 4, 2
+    for scale in (1.0, 12.0, 40.0):
+        pred = torch.from_numpy((scale * rs.standard_normal((b, C, *sp))).astype(np.float32))
+        lab = pred.argmax(1)                                            # pseudo-labels: the arg-max, as in the trainers
+        flip = torch.from_numpy(rs.uniform(size=(b, *sp)) < 0.1)
+        lab = torch.where(flip, torch.from_numpy(rs.randint(0, C, size=(b, *sp))), lab)
+        lab[0].view(-1)[:7] = -1
+        conf = torch.from_numpy(rs.uniform(0.3, 1.0, size=(b, *sp)).astype(np.float32))
+        po = pred.clone().requires_grad_(True)
+        lo = orc.compute_unsupervised_loss(po, lab, conf, 0.5)
+        lo.backward()
+        n_zero = int((torch.nn.functional.cross_entropy(pred, lab, reduction='none', ignore_index=-1) == 0).sum())
+        if scale >= 12.0:
+            assert n_zero > 0.05 * lab.numel()                          # the case is what it claims to be
+        pg = pred.cuda().requires_grad_(True)
+        lg = glue.compute_unsupervised_loss(pg, lab.cuda(), conf.cuda(), 0.5)
+        lg.backward()
+        np.testing.assert_allclose(lg.item(), lo.item(), rtol=1e-5, err_msg=f"scale {scale}")
+        # (rows with CE ~ 1e-8: exp(log_softmax) - 1 rounds to 0 or to half an ulp of 1, times a weight of ~1e-3)
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), po.grad.numpy(), rtol=1e-4, atol=2e-8)

@@ -24,9 +24,12 @@ def to_dev(inp):
 
 @pytest.mark.parametrize("case", list(fx.LOSS_CASES))
 def test_loss_chain_vs_golden(golden, case):
-    from arco_amd.loss_helper_3d import compute_contra_memobank_loss
     g = golden["g2_loss"]
     ikw, lkw, qsize, binit = fx.LOSS_CASES[case]
+    if len(ikw["spatial"]) == 3:      # 5-D tensors go through the module the 3-D trainer imports (train_arco_3d.py:22)
+        from arco_amd.loss_helper import compute_contra_memobank_loss
+    else:
+        from arco_amd.loss_helper_3d import compute_contra_memobank_loss
     bank, ptr, qs = fx.fresh_bank(ikw["n_cls"], ikw["feat"], qsize, binit)
     mom = torch.zeros(ikw["n_cls"], lkw["num_queries"], 1, ikw["feat"]).cuda() if case == "proto_momentum" else None
     seed_all(1337)

@@ -93,9 +93,16 @@ def test_loss_chain(golden, case):
 def test_loss_cases_exercise_real_work(golden):
     """At least the mainstream cases must have a non-trivial loss and gradient."""
     g = golden["g2_loss"]
-    for case in ("d16_smc", "d16_asmc", "d64_smc_default_q", "binary_3d"):
+    for case in ("d16_smc", "d16_asmc", "d64_smc_default_q", "binary_3d", "c4_3d", "c4_3d_absent", "c5_3d_default_q"):
         assert any(abs(float(g[f"{case}_s{s}_loss"])) > 1e-3 for s in range(fx.LOSS_STEPS)), case
         assert any(np.abs(g[f"{case}_s{s}_grad"]).sum() > 0 for s in range(fx.LOSS_STEPS)), case
+    # the 5-D cases with C >= 4 must reach what binary_3d cannot (SURVEY 8a V3): keys enqueued on 5-D tensors, a bank that
+    # grows past one row (grid negative sampler) and one that is truncated at queue_size (loss_helper.py:12-32)
+    for case in ("c4_3d", "c4_3d_absent", "c5_3d_default_q"):
+        qs = fx.LOSS_CASES[case][2]
+        assert int(g[f"{case}_s0_new_keys"].sum()) > 0 and int(g[f"{case}_s1_bank_len"].max()) > 16, case
+        assert any(int(g[f"{case}_s{s}_bank_len"][0]) == qs[0] == int(g[f"{case}_s{s}_ptr"][0]) for s in range(fx.LOSS_STEPS)), case
+    assert int(g["binary_3d_s2_bank_len"].max()) == 1
 
 
 def probe_like(t, seed):
@@ -424,3 +431,33 @@ def test_color_jitter_blur_oracle_vs_pillow(tag):
     if sigma is not None:
         a = orc.gaussian_blur_u8(a, sigma)
     np.testing.assert_array_equal(a, g12[tag])
+
+
+def test_vnet_oracle_float64_matches_reference_g18():
+    """The oracle V-Net, run in float64, against the REFERENCE module's float64 run (g18): outputs, input gradient and every
+    parameter gradient to 1e-9 - the oracle's V-Net backward is pinned to the reference, and tests/test_nets3d_gpu.py may use
+    its in-network tensors as ground truth."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g18_vnet_strict.npz"), allow_pickle=False)
+    sd = {k: (v.double() if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in fx.vnet_state(52).items()}
+    x = fx.image_batch(int(g["seed"]), 2, 1, (48, 48, 32)).double().requires_grad_(True)
+    tap = []
+    out, _, fmap = orc.vnet_forward(x, sd, tap=tap)
+    assert len(tap) == 21
+    loss = (out * probe_like(out, 4).double()).sum()
+    for i, f in enumerate(fmap):
+        loss = loss + (f * probe_like(f, 20 + i).double()).sum()
+    loss.backward()
+    np.testing.assert_allclose(out.detach()[..., ::2, ::2, ::2].numpy(), g["out_sub"], rtol=1e-5, atol=1e-6)     # stored as fp32
+    np.testing.assert_allclose(float(out.detach().pow(2).sum().sqrt()), float(g["out_l2"]), rtol=1e-10)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=1e-5, atol=1e-6 * float(np.abs(g["dx"]).max()))
+    stride = int(g["stride"])
+    for n, ref_abs, ref_l2 in zip([str(s_) for s_ in g["grad_names"]], g["grad_abs"], g["grad_l2"]):
+        got = sd[n].grad
+        if n.endswith(".bias") and ".conv." in n and int(n.split(".")[-2]) % 3 == 0:
+            continue
+        np.testing.assert_allclose(float(got.abs().sum()), ref_abs, rtol=1e-8, err_msg=n)
+        np.testing.assert_allclose(float(got.pow(2).sum().sqrt()), ref_l2, rtol=1e-8, err_msg=n)
+        flat = got.reshape(-1)
+        np.testing.assert_allclose((flat if flat.numel() <= 120000 else flat[::stride]).numpy(), g["grad::" + n], rtol=1e-5,
+                                   atol=1e-6 * float(np.abs(g["grad::" + n]).max()), err_msg=n)
