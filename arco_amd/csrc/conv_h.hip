@@ -814,10 +814,18 @@ __global__ __launch_bounds__(256) void cast_h2f_kernel(const _Float16* __restric
 }
 __global__ __launch_bounds__(256) void cast_f2h_kernel(const float* __restrict__ x, long n4, long n, float scale, _Float16* __restrict__ y) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i) * scale;
+    // saturate at the largest finite f16: a scaled gradient above 65504 becomes +-65504 (a clipped value) instead of an inf that
+    // the f16 backward would spread through every gradient below it; NaNs pass (fminf / fmaxf would hide them: selects keep them)
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i) * scale;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 65504.f ? 65504.f : (v[j] < -65504.f ? -65504.f : v[j]);
     *reinterpret_cast<h4*>(y + 4 * i) = __builtin_convertvector(v, h4);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[4 * n4 + threadIdx.x] = (_Float16)(x[4 * n4 + threadIdx.x] * scale);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    float t = x[4 * n4 + threadIdx.x] * scale;
+    t = t > 65504.f ? 65504.f : (t < -65504.f ? -65504.f : t);
+    y[4 * n4 + threadIdx.x] = (_Float16)t;
+  }
 }
 
 extern "C" {

@@ -112,14 +112,28 @@ def broadcast_module_states(modules, src=0):
             td.broadcast(t.data, src)
 
 
-_pending_buckets = []     # [(Work, start element)] of gradient buckets whose all-reduce is already in flight
+_pending_buckets = []     # [(Work, start element)] of gradient buckets whose all-reduce is already in flight (at most one)
+
+
+def begin_step(optimizer=None):
+    """Start of a step's backward bookkeeping: handles a previous step left behind (an exception between the hook and
+    allreduce_grads, a second backward) are dropped - after waiting for them, so that no collective is abandoned mid-flight."""
+    for work, _ in _pending_buckets:
+        try:
+            work.wait()
+        except Exception:
+            pass
+    _pending_buckets.clear()
+    if optimizer is not None:
+        optimizer._bucket_start = None
 
 
 def allreduce_bucket_async(optimizer, start):
     """Start the all-reduce of the flat gradient buffer's tail [start:] (the q_representation / FeatureExtractor
     parameters: their gradients are final once the head's backward is queued, before the U-Net's backward has run) -
-    it overlaps the U-Net backward; allreduce_grads then reduces the rest and waits for this one."""
-    if not is_dist():
+    it overlaps the U-Net backward; allreduce_grads then reduces the rest and waits for this one.  A second call within one
+    step (a second backward through the marker, retain_graph) is ignored: the bucket is already in flight."""
+    if not is_dist() or _pending_buckets:
         return
     _pending_buckets.append((td.all_reduce(optimizer.flat_g[start:], op=td.ReduceOp.SUM, async_op=True), int(start)))
 
@@ -136,6 +150,8 @@ class _GradsReadyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         opt, start = ctx.opt_start
+        from . import ops
+        ops.join_side()            # the heads' weight gradients may still be on the side stream (ops._wgrad)
         allreduce_bucket_async(opt, start)
         return (None,) + grads
 
@@ -143,23 +159,41 @@ class _GradsReadyFn(torch.autograd.Function):
 def mark_heads_done(maps, optimizer, start):
     """Data parallel: wrap the feature maps the heads consume; the heads' gradient bucket (flat_g[start:]) is all-reduced
     asynchronously as soon as their backward is done (two buckets, decoder-side first: SURVEY 8e item 1).  Identity
-    when not distributed."""
+    when not distributed.
+
+    Every rank calls this every step with the same `start`, whatever its data: that - not whether the marker's backward
+    fires, which depends on the rank's own batch (a background-only crop takes the loss's zero path and never reaches the
+    heads) - decides that the step's gradient exchange is the two collectives [start:], [:start] in this order
+    (allreduce_grads issues the first itself on a rank whose marker did not fire).  ADVICE r3 (high)."""
     if not is_dist() or start <= 0 or start >= optimizer.flat_g.numel():
         return maps
+    begin_step(optimizer)
+    optimizer._bucket_start = int(start)
     return list(_GradsReadyFn.apply((optimizer, int(start)), *maps))
 
 
 def allreduce_grads(optimizer):
-    """Mean of the flat gradient buffer over ranks: one RCCL all-reduce, or two when the heads' bucket is already in
-    flight (allreduce_bucket_async) - the rest is reduced here and both are awaited (stream-ordered, no host wait)."""
+    """Mean of the flat gradient buffer over ranks.  One RCCL all-reduce - or, in a step that went through mark_heads_done,
+    exactly two on EVERY rank: the heads' bucket [start:] (already in flight where the marker's backward fired, issued here
+    where it did not) and then the rest [:start]; both are awaited (stream-ordered, no host wait)."""
     if not is_dist():
         return
     g = optimizer.flat_g
-    split = min((st for _, st in _pending_buckets), default=g.numel())
-    td.all_reduce(g[:split], op=td.ReduceOp.SUM)
-    for work, _ in _pending_buckets:
-        work.wait()
-    _pending_buckets.clear()
+    start = getattr(optimizer, "_bucket_start", None)
+    if start is None:
+        if _pending_buckets:                      # cannot happen through mark_heads_done; never reduce with a stale split
+            begin_step()
+        td.all_reduce(g, op=td.ReduceOp.SUM)
+    else:
+        if _pending_buckets and _pending_buckets[0][1] != start:
+            begin_step()
+        if not _pending_buckets:                  # this rank's backward never reached the heads: same collective, issued now
+            _pending_buckets.append((td.all_reduce(g[start:], op=td.ReduceOp.SUM, async_op=True), start))
+        td.all_reduce(g[:start], op=td.ReduceOp.SUM)
+        for work, _ in _pending_buckets:
+            work.wait()
+        _pending_buckets.clear()
+        optimizer._bucket_start = None
     g.mul_(1.0 / td.get_world_size())
     optimizer._touched.update(range(len(optimizer.params)))
 

@@ -70,8 +70,12 @@ class _GraphedTrainFn(torch.autograd.Function):
                 if g.data_ptr() != sg.data_ptr():
                     sg.copy_(g)
                     gt.grad_live[i] = True
-                # (same storage: a consumer wrote its gradient straight into the sink, ops.grad_sink - it re-zeroes what
-                #  it touched through gt.cleanup below, so the buffer is clean again for a step without that gradient)
+                elif sg._version != gt.sink_version[i]:
+                    # same storage (a consumer scattered its gradient straight into the sink, ops.grad_sink, and re-zeroes the
+                    # rows it touched through gt.cleanup below) - but autograd ALSO accumulated into the buffer in place (the
+                    # map has a second consumer with a dense gradient): the rows the cleanup does not know are dirty, so the
+                    # next sparse use pays a dense zero (raw-pointer kernels do not bump the version counter, tensor ops do)
+                    gt.grad_live[i] = True
         gt.bwd_g.replay()
         for fn in gt.cleanup:
             fn()
@@ -135,6 +139,7 @@ class GraphedTrain:
             self.grad_live = [False] * len(self.diff_idx)
             # gradient sinks (ops.grad_sink): a consumer with a sparse gradient scatters straight into static_grads[k]
             self.sink_busy = [False] * len(self.diff_idx)
+            self.sink_version = [0] * len(self.diff_idx)       # static_grads[k]._version when the sink was handed out
             self.cleanup = []
             self.sink_uses = 0
             for k, i in enumerate(self.diff_idx):
@@ -146,6 +151,7 @@ class GraphedTrain:
             with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(self.bwd_g, pool=pool):
                 grads = torch.autograd.grad([self.flat_outs[i] for i in self.diff_idx], inputs, self.static_grads,
                                             allow_unused=True)
+                ops.join_side()          # the weight-gradient branch (ops._wgrad) joins the capture stream: a graph edge
             grads = list(grads)
             self.static_dx = grads.pop(0) if self.static_in.requires_grad else None
             self.static_pgrads = grads         # None where the kernels wrote into the flat gradient buffer

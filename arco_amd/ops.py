@@ -433,6 +433,48 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
     return _grad_into(like, compute)
 
 
+# ---- weight gradients on a second stream (round 4) --------------------------------------------------------------------------
+# In a layer's backward the weight gradient depends only on dZ and the saved input; the critical chain is
+# BN-backward -> data gradient -> the next layer's BN-backward.  The weight-gradient launches (wgrad + slab reduction: 2.4 ms of
+# the 2-D step, 108 launches that each fill the chip for 10-50 us with start-up / tail phases) are queued on a side stream,
+# forked behind the kernel that produced dZ and joined once at the end of the backward pass (join_side: GraphedTrain's
+# capture, the trainers after loss.backward(), the data-parallel bucket hook) - inside a HIP-graph capture the fork / join
+# become graph edges.  Only gradients that go straight into the optimiser's flat buffer take the side stream (nobody reads
+# them before the join); accumulation into one parameter from two passes stays ordered (one side stream, launch order).
+# Tensors the side stream reads are held until the join, so the caching allocator cannot hand their memory to a kernel on
+# the main stream while the side stream still reads it.  A/B: ARCO_WGRAD_SIDE=0.
+WGRAD_SIDE = int(__import__('os').environ.get('ARCO_WGRAD_SIDE', '1'))
+_side = {"stream": None, "keep": [], "dirty": False}
+
+
+def _wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1, keep=()):
+    view = getattr(like, "_arco_grad_view", None)
+    if not (WGRAD_SIDE and view is not None and like.grad is not None and like.grad.data_ptr() == view.data_ptr()):
+        return conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=d3)
+    cur = torch.cuda.current_stream()
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream()
+    sd = _side["stream"]
+    sd.wait_stream(cur)                                  # fork: behind everything queued so far (dZ is complete)
+    with torch.cuda.stream(sd):
+        out = conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=d3)
+    _side["keep"].append((dzr, xr) + tuple(keep))
+    if not _side["dirty"]:
+        # joined at the end of THIS backward pass whoever runs it (loss.backward(), autograd.grad inside a graph capture, a
+        # test): the engine calls back on the calling thread once every node has run
+        torch.autograd.Variable._execution_engine.queue_callback(join_side)
+    _side["dirty"] = True
+    return out
+
+
+def join_side():
+    """The current stream waits for the side stream's weight gradients (no-op when none were queued)."""
+    if _side["dirty"]:
+        torch.cuda.current_stream().wait_stream(_side["stream"])
+        _side["keep"].clear()
+        _side["dirty"] = False
+
+
 _zero_cache = {}
 
 
@@ -502,13 +544,13 @@ class ConvFn(torch.autograd.Function):
         xr, ldx = rows_view(x)
         ci = int(x.shape[1])
         dx = dw = db = None
+        if ctx.needs_input_grad[1]:      # first: it forks to the side stream and runs beside the data gradient
+            dw = _wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3, keep=(dy, x))
         if ctx.needs_input_grad[0]:
             half = _is_half(dy)
             wd = pack_weight(weight, taps, 1, half=half)
             dx, _ = conv_raw(dyr, ldy, co, wd, ci, nv, h, w, taps, grad=True, residual=dyr if ctx.residual else None,
                              ld_res=ldy if ctx.residual else 0, d3=d3, sp=sp, half=half)
-        if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # bias_grad_zero: the output feeds a train-mode BatchNorm, whose backward makes the column sums of dy
             # exactly zero in exact arithmetic (see ConvBnActFn.backward) - no pass over dy for rounding noise
@@ -632,12 +674,12 @@ class ConvBnActFn(torch.autograd.Function):
                                          ctx.seed_dev, ctx.groups)
         dzr, ldzz = rows_view(dz)
         dx = dw = db = None
+        if ctx.needs_input_grad[1]:      # first: it forks to the side stream and runs beside the data gradient / the next BN passes
+            dw = _wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3, keep=(dz, x))
         if ctx.needs_input_grad[0]:
             half = _is_half(dz)
             wd = pack_weight(weight, taps, 1, half=half)
             dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3, sp=sp, grad=True, half=half)
-        if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3)
         if has_bias and ctx.needs_input_grad[2]:
             # a conv bias under train-mode BN has an analytically ZERO gradient (BN removes the channel mean):
             # sum(dz) = -gamma*istd*mean(dy*xhat)*sum(xhat) and sum(xhat) == 0.  The reference's autograd
@@ -1210,6 +1252,7 @@ def grad_sink(ptr, shape):
         buf.zero_()
         gt.grad_live[k] = False
     gt.sink_busy[k] = True
+    gt.sink_version[k] = buf._version
     gt.sink_uses += 1
     return gt, k
 
@@ -1301,4 +1344,11 @@ class _CombineTermsFn(torch.autograd.Function):
 def combine_terms(weights, terms):
     """sum_i weights[i] * terms[i] (0-d device tensors, python-float weights), differentiable w.r.t. the terms."""
     assert 1 <= len(terms) <= 8 and len(weights) == len(terms)
+    dev = next((t.device for t in terms if torch.is_tensor(t) and t.is_cuda), None)
+    if dev is None:
+        raise RuntimeError("arco_amd.combine_terms: no term lives on the GPU")
+    # a drop-in caller may hand in a python float or a CPU 0-d tensor (a constant-zero fallback): the kernel dereferences
+    # device pointers, so every term is brought to the device first (constants carry no gradient; tensors keep theirs)
+    terms = [t if (torch.is_tensor(t) and t.device == dev) else torch.as_tensor(t, dtype=torch.float32).to(dev) for t in terms]
+    L.require_gpu(*terms)
     return _CombineTermsFn.apply(tuple(weights), *terms)

@@ -140,6 +140,15 @@ class SGDNesterov:
             self._touched.add(i)
         return mark
 
+    def touch_from(self, start_elem):
+        """Mark every parameter at flat offset >= start_elem as having received a (zero) gradient this step.  The reference's
+        degenerate-batch loss is `0.0 * rep.sum()` (loss_helper_3d.py:417-424): attached to the graph, it hands every head
+        parameter a ZERO gradient - and torch.optim.SGD then still applies weight decay and momentum to them, whereas a
+        parameter without a gradient is skipped.  The trainers' zero path calls this after backward."""
+        for i, (off, _k) in enumerate(self.offsets):
+            if off >= start_elem:
+                self._touched.add(i)
+
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
         self._touched.clear()

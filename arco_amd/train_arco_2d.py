@@ -402,7 +402,8 @@ class ArcoStep2D:
         if prof:
             ev3[0].record()
         C_.contrast_anchor_pix(plan)
-        if plan.valid_seg <= 1 or not plan.entries:
+        zero_path = plan.valid_seg <= 1 or not plan.entries
+        if zero_path:
             reco_loss = self.q_representation[1].weight.sum() * 0.0      # :417-424 zero attached to the graph
         else:
             if dense:
@@ -440,6 +441,9 @@ class ArcoStep2D:
         loss = ops.combine_terms(ws, terms)
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()
+        ops.join_side()                     # weight gradients queued on the side stream (ops._wgrad)
+        if zero_path:     # `0 * rep.sum()` gives EVERY head parameter a zero gradient: SGD still decays / applies momentum to them
+            self.optimizer.touch_from(self.heads_start)
         adist.allreduce_grads(self.optimizer)
         self.optimizer.step()
         self.isd._momentum_update_key_encoder()                          # :432

@@ -105,6 +105,7 @@ class ArcoStep3D:
         self.k_fe_ema.plans = [ops.PackPlan([self.k_feature_extractor], False)]
         self.plans = [plan_s] + [pl for pr in pairs for pl in pr.plans] + self.k_fe_ema.plans
         self.iter_num = 0
+        self._ovf_host, self._ovf_event, self.overflow_steps, self._clean_steps = None, None, 0, 0     # f16 overflow guard
         self.keep_debug = False          # tests: keep the last step's plan and anchor rows (self.debug)
         use_graphs = bool(getattr(args, "graphs", 1))
         g_train = use_graphs and bool(getattr(args, "graph_train", 0))
@@ -125,6 +126,53 @@ class ArcoStep3D:
         # launches sat right behind the sampler stage, the stretch of the step where the GPU waits for the host
         self.s_fwd_tps = graphs.GraphedForward(self.model, enabled=use_graphs)
 
+    def _unscale_and_guard(self):
+        """--act_dtype f16: divide the loss scale out of the V-Net's stretch of the flat gradient and guard the step against an
+        overflow of the f16 backward (an inf / NaN in flat_g would go straight into SGD, the EMA teacher and,
+        a step later, the memory banks - silently and for good).  All on the device, no host synchronisation in the step:
+        `ok` = every V-Net gradient finite; non-finite values are replaced by zeros and the WHOLE gradient is multiplied by ok, so
+        an overflowed step degenerates to a zero-gradient step (weight decay and momentum only) instead of poisoning the run.
+        The flag is copied to pinned memory and read at the START of the next step (long complete by then): an overflow halves
+        the loss scale (floor 1), 500 clean steps double it again up to --loss_scale (dynamic loss scaling)."""
+        gv = self.optimizer.flat_g[:self.heads_start]
+        gv.mul_(1.0 / ops.LOSS_SCALE)
+        ok = torch.isfinite(gv).all()
+        torch.nan_to_num_(gv, nan=0.0, posinf=0.0, neginf=0.0)
+        self.optimizer.flat_g.mul_(ok.to(torch.float32))
+        if self._ovf_host is None:
+            self._ovf_host = torch.ones(1, dtype=torch.bool).pin_memory()
+        self._ovf_host.copy_(ok.view(1), non_blocking=True)
+        self._ovf_event = torch.cuda.Event()
+        self._ovf_event.record()
+
+    def _loss_scale_update(self):
+        """Host side of the guard: consume last step's flag (see _unscale_and_guard)."""
+        ev = self._ovf_event
+        if ev is None:
+            return
+        ev.synchronize()              # recorded a whole step ago: returns at once
+        self._ovf_event = None
+        if not bool(self._ovf_host[0]):
+            self.overflow_steps += 1
+            self._clean_steps = 0
+            ops.LOSS_SCALE = max(1.0, ops.LOSS_SCALE / 2.0)
+            self._recapture_train_graphs()
+            logging.warning("f16 backward overflowed at iteration %d: step reduced to a zero-gradient step, loss scale -> %g",
+                            self.iter_num - 1, ops.LOSS_SCALE)
+        else:
+            self._clean_steps += 1
+            if self._clean_steps >= 500 and ops.LOSS_SCALE < float(getattr(self.args, "loss_scale", 16384.0)):
+                ops.LOSS_SCALE *= 2.0
+                self._clean_steps = 0
+                self._recapture_train_graphs()
+
+    def _recapture_train_graphs(self):
+        """The loss scale is a kernel argument of the boundary cast inside the captured backward graphs: a new scale needs a
+        new capture (the next call of each GraphedTrain re-captures; rare)."""
+        for v in vars(self).values():
+            if isinstance(v, graphs.GraphedTrain):
+                v.captured = False
+
     def q_rep(self, x):
         x = ops.conv(x, self.q_representation[0].weight)
         return ops.conv(x, self.q_representation[1].weight)
@@ -132,6 +180,8 @@ class ArcoStep3D:
     def step(self, l_data, l_label, u_data, epoch_num=0, max_epoch=1):
         a = self.args
         C = a.num_classes
+        if ops.ACT_HALF:
+            self._loss_scale_update()
         for pl in self.plans:                                            # stale only if someone else touched weights
             if not pl.valid:
                 pl.refresh()
@@ -218,7 +268,8 @@ class ArcoStep3D:
                 pred_tps = (self.model if self.iter_num == 0 else self.s_fwd_tps)(images_tps)[0]                     # :380
                 loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
         C_.contrast_anchor_pix(plan)
-        if plan.valid_seg <= 1 or not plan.entries:
+        zero_path = plan.valid_seg <= 1 or not plan.entries
+        if zero_path:
             reco_loss = self.q_representation[1].weight.sum() * 0.0
         elif dense:
             A_all = C_.GatherRowsFn.apply(rep_all, plan.anchor_pix)
@@ -245,8 +296,11 @@ class ArcoStep3D:
         loss = ops.combine_terms(ws, terms)           # one launch (and one for its backward) instead of a chain of 0-d ops
         self.optimizer.zero_grad()
         loss.backward()
+        ops.join_side()                     # weight gradients queued on the side stream (ops._wgrad)
+        if zero_path and not first:      # `0 * rep.sum()` (loss_helper.py:588-595): zero gradients for every head parameter
+            self.optimizer.touch_from(self.heads_start)
         if ops.ACT_HALF:       # the V-Net's parameter gradients carry the loss scale of the f16 region
-            self.optimizer.flat_g[:self.heads_start].mul_(1.0 / ops.LOSS_SCALE)
+            self._unscale_and_guard()
         adist.allreduce_grads(self.optimizer)
         self.optimizer.step()
         self.isd._momentum_update_key_encoder()

@@ -364,16 +364,16 @@ def test_cfg4_cityscapes_shape_vs_cpu_oracle():
         st_g.step(l.cuda(), lab.cuda(), u.cuda())
         to, tg = st_o["last_terms"], st_g.last_terms
         for k in ("ce", "dice", "unsup", "reco", "eqv"):
-            np.testing.assert_allclose(float(tg[k]), to[k], rtol=2e-3, atol=1e-5, err_msg=f"step {it} {k}")
+            np.testing.assert_allclose(float(tg[k]), to[k], rtol=1e-3, atol=1e-5, err_msg=f"step {it} {k}")      # north_star: 1e-3
         for bo, bg in zip(bank_o, st_g.memobank):
             assert bo[0].shape == bg[0].shape
-            np.testing.assert_allclose(bg[0].cpu().numpy(), bo[0].numpy(), rtol=2e-3, atol=2e-4)
+            np.testing.assert_allclose(bg[0].cpu().numpy(), bo[0].numpy(), rtol=1e-3, atol=2e-4)
         assert [int(p) for p in ptr_o] == [int(p) for p in st_g.queue_ptrlis]
     sd_g = st_g.model.state_dict()
     for k, v in st_o["student"].items():
         if v.requires_grad:
             ref = v.detach()
-            assert float((sd_g[k].cpu() - ref).abs().max()) <= 2e-3 * max(1e-6, float(ref.abs().max())), k
+            assert float((sd_g[k].cpu() - ref).abs().max()) <= 1e-3 * max(1e-6, float(ref.abs().max())), k
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -388,7 +388,9 @@ def test_cfg5_lits_f16_step_at_full_size_tracks_fp32():
     out = {}
     try:
         for mode in ("f32", "f16", "f16s"):
-            extra = ["--eqv_pass", "0"] + (["--act_dtype", "f16"] if mode == "f16s" else [])
+            # --strong_threshold 0.55: with two classes and untrained weights no pseudo-label is 0.97 confident, and the
+            # unsupervised term would be an exact zero in every mode
+            extra = ["--eqv_pass", "0", "--strong_threshold", "0.55"] + (["--act_dtype", "f16"] if mode == "f16s" else [])
             st = _make3d(extra, patch=sp, b=1, mma={"f32": "f32", "f16": "f16", "f16s": "f32x3"}[mode])
             assert ops.CONV_MMA == {"f32": 0, "f16": 1, "f16s": 3}[mode] and ops.ACT_HALF == (mode == "f16s")
             _drop_off(st)
@@ -412,4 +414,14 @@ def test_cfg5_lits_f16_step_at_full_size_tracks_fp32():
         assert np.all(np.isfinite(out[mode]))
         np.testing.assert_allclose(out[mode][0, :2], out["f32"][0, :2], rtol=1e-2)      # first step, same weights: CE / Dice at 1e-2
         np.testing.assert_allclose(out[mode][:, :2], out["f32"][:, :2], rtol=5e-2)      # trajectories stay together
+        # unsupervised CE: the same per-voxel CE (1e-2) times the share of voxels whose confidence passes the threshold - a
+        # count over 2.5 M voxels that a 1e-3 perturbation of the probabilities moves by ~1e-3.  Measured 1e-4 ... 9e-4: held to 5e-3.
+        assert out["f32"][0, 2] > 1e-3
+        np.testing.assert_allclose(out[mode][:, 2], out["f32"][:, 2], rtol=5e-3)
+        # contrastive term: a Monte-Carlo estimate over 256 anchors x 512 negatives per class; a perturbed forward moves the
+        # candidate sets (entropy percentiles, thresholds), so the SAMPLED anchors differ between the modes: the two estimates
+        # of the same quantity agree to their sampling noise (measured 0.7e-3 ... 2e-3), held to 1e-2 = configs[4]'s budget; the
+        # deterministic part of the loss is held to 1e-3 on fixed samples by _check_step_invariants above and by tests/test_loss_gpu.py
+        np.testing.assert_allclose(out[mode][:, 3], out["f32"][:, 3], rtol=1e-2)
+        print(mode, "relative distance to fp32 (ce, dice, unsup, reco) per step:", np.abs(out[mode] / out["f32"] - 1).round(5).tolist())
         assert not np.array_equal(out[mode], out["f32"])                                # the reduced-precision kernels really ran

@@ -118,6 +118,42 @@ def _worker(rank, world, port, q):
     mean = sum(rr + 1 for rr in range(world)) / world
     assert torch.allclose(o2.flat_g[:12], torch.full((12,), mean)) and torch.allclose(o2.flat_g[12:], torch.full((8,), 10 * mean))
     assert adist._pending_buckets == []
+    # 9b. ADVICE r3 (high): the marker's backward fires only on ranks whose loss reaches the heads - a background-only batch
+    #     takes the loss's zero path (train_arco_2d.py: `weight.sum() * 0`) and never touches the marker.  Every rank must still
+    #     issue the SAME two collectives, [start:] then [:start]: here rank 0 fires, the other ranks do not; then the reverse;
+    #     then nobody fires; a stale handle left by an aborted step and a double backward must not change the sequence either.
+    for firing in ([0], [r_ for r_ in range(world) if r_ != 0], [], list(range(world))):
+        x = torch.ones(3, requires_grad=True)
+        (m0,) = adist.mark_heads_done([x * 2.0], o2, 12)
+        assert o2._bucket_start == 12
+        o2.flat_g[:12] = float(rank + 1); o2.flat_g[12:] = float(10 * (rank + 1))
+        if rank in firing:
+            m0.sum().backward(retain_graph=True)
+            m0.sum().backward()                                 # a second backward through the marker: ignored
+            assert len(adist._pending_buckets) == 1
+        else:
+            (x * 0.0).sum().backward()                          # the zero path: attached to the graph, not to the marker
+            assert adist._pending_buckets == []
+        adist.allreduce_grads(o2)
+        assert torch.allclose(o2.flat_g[:12], torch.full((12,), mean)) and torch.allclose(o2.flat_g[12:], torch.full((8,), 10 * mean)), firing
+        assert adist._pending_buckets == [] and o2._bucket_start is None
+    # an aborted step (the hook fired, allreduce_grads never ran - every rank, as an exception in the shared step code would):
+    # the next step's mark_heads_done drops the stale handle and the exchange is the usual pair
+    x = torch.ones(3, requires_grad=True)
+    (m0,) = adist.mark_heads_done([x * 2.0], o2, 12)
+    m0.sum().backward()
+    assert len(adist._pending_buckets) == 1
+    x = torch.ones(3, requires_grad=True)
+    (m0,) = adist.mark_heads_done([x * 2.0], o2, 12)
+    assert adist._pending_buckets == []
+    o2.flat_g[:12] = float(rank + 1); o2.flat_g[12:] = float(10 * (rank + 1))
+    m0.sum().backward()
+    adist.allreduce_grads(o2)
+    assert torch.allclose(o2.flat_g[:12], torch.full((12,), mean)) and torch.allclose(o2.flat_g[12:], torch.full((8,), 10 * mean))
+    # without a marker in the step: one collective over the whole buffer
+    o2.flat_g[:] = float(rank + 1)
+    adist.allreduce_grads(o2)
+    assert torch.allclose(o2.flat_g, torch.full((20,), mean))
     # 10. anchors per rank: the split covers num_queries exactly, the loss weights average to one
     for Q in (256, 50, 7):
         if Q >= world:

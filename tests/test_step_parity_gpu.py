@@ -25,11 +25,20 @@ def _drop_off(m):
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=0.0, apply_aug="classmix"),
                                      dict(revisit=1, K=4, topk=2, k2=0.0, apply_aug="cutmix"),
                                      dict(dense_head=0, head_levels=2, dense_teacher=0, k2=1.0, apply_aug="cutmix", batch_transform=1),
-                                     dict(dense_head=0, head_levels=3, dense_teacher=0, k2=1.0, apply_aug="cutmix")])
+                                     dict(dense_head=0, head_levels=3, dense_teacher=0, k2=1.0, apply_aug="cutmix"),
+                                     # the loss's degenerate-batch path (loss_helper_3d.py:417-424: <= 1 valid class -> `0.0 * rep.sum()`):
+                                     # every head parameter gets a ZERO gradient, and SGD still applies weight decay / momentum to it
+                                     dict(dense_head=0, head_levels=3, dense_teacher=0, k2=0.0, apply_aug="none", zero_path=1),
+                                     dict(dense_head=1, k2=0.0, apply_aug="none", zero_path=1)])
 def test_two_steps_vs_cpu_oracle(variant):
     from arco_amd import train_arco_2d as T
     b, patch, C, Q, Nn, qs = 2, (64, 64), 4, 64, 32, 300
     unet_sd, fe_sd = fx.unet_state(21, 1, C), fx.fe_state(31)
+    variant = dict(variant)
+    zero_path = bool(variant.pop("zero_path", 0))
+    if zero_path:       # both nets predict class 0 everywhere and the labels are all background: one valid class
+        unet_sd["decoder.out_conv.weight"] = unet_sd["decoder.out_conv.weight"] * 0.0
+        unet_sd["decoder.out_conv.bias"] = torch.tensor([6.0, 0.0, 0.0, 0.0])
     qrep_w = [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]]
     argv = ["--batch_size", str(b), "--queue_size", str(qs), "--synthetic", "1", "--num_queries", str(Q),
             "--num_negatives", str(Nn), "--k1", "1.0", "--base_lr", "0.01", "--graphs", "0"]
@@ -67,6 +76,8 @@ def test_two_steps_vs_cpu_oracle(variant):
         l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
         u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
         lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
+        if zero_path:
+            lab = torch.zeros_like(lab)
         random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
         cpu_step.step(st_o, l, lab, u, bank_o, ptr_o, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn, k2=variant["k2"],
                       apply_aug=variant["apply_aug"], pool=pool_o, topk=variant.get("topk", 5), bt=bool(bt), morph_velocity=vel)
@@ -90,6 +101,16 @@ def test_two_steps_vs_cpu_oracle(variant):
         if not bt:
             assert [int(p) for p in ptr_o] == [int(p) for p in st_g.queue_ptrlis]
     AdvMorph.init_velocity = real_velocity
+    if zero_path:
+        assert to["reco"] == 0.0 and float(tg["reco"]) == 0.0
+        # the heads moved by weight decay + momentum alone - and they did move (a skipped parameter would sit at its seed value)
+        for k, v in st_o["q_fe"].items():
+            got = st_g.q_feature_extractor.state_dict()[k].cpu()
+            assert float((got - fe_sd[k]).abs().max()) > 0
+            np.testing.assert_allclose(got.numpy(), v.detach().numpy(), rtol=1e-6, atol=1e-9)
+        for i in range(2):
+            np.testing.assert_allclose(st_g.q_representation[i].weight.detach().cpu().numpy(), st_o["q_rep"][i].detach().numpy(),
+                                       rtol=1e-6, atol=1e-9)
     # updated weights: student U-Net (by name), heads, teacher
     sd_g = st_g.model.state_dict()
     worst = 0.0
