@@ -442,8 +442,13 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
 # become graph edges.  Only gradients that go straight into the optimiser's flat buffer take the side stream (nobody reads
 # them before the join); accumulation into one parameter from two passes stays ordered (one side stream, launch order).
 # Tensors the side stream reads are held until the join, so the caching allocator cannot hand their memory to a kernel on
-# the main stream while the side stream still reads it.  A/B: ARCO_WGRAD_SIDE=0.
-WGRAD_SIDE = int(__import__('os').environ.get('ARCO_WGRAD_SIDE', '1'))
+# the main stream while the side stream still reads it.  A/B: ARCO_WGRAD_SIDE=0..3.
+# Measured (round 4, one box, alternating runs; profiles/r04_notes.md): the graph-replayed 2-D step gets SLOWER with it (13.4 ->
+# 14.2 ms forked before the data gradient, 13.6-13.9 forked behind it: the persistent one-workgroup-per-CU kernels lose more
+# to a co-resident weight-gradient workgroup than the tails give back), the eager 3-D LA step 3 % faster (30.1 -> 29.2 ms).
+# Hence: off by default, the 3-D trainer switches it on (mode 1) unless ARCO_WGRAD_SIDE says otherwise.
+_WGRAD_SIDE_ENV = __import__('os').environ.get('ARCO_WGRAD_SIDE')
+WGRAD_SIDE = int(_WGRAD_SIDE_ENV) if _WGRAD_SIDE_ENV is not None else 0
 _side = {"stream": None, "keep": [], "dirty": False}
 
 
@@ -674,12 +679,18 @@ class ConvBnActFn(torch.autograd.Function):
                                          ctx.seed_dev, ctx.groups)
         dzr, ldzz = rows_view(dz)
         dx = dw = db = None
-        if ctx.needs_input_grad[1]:      # first: it forks to the side stream and runs beside the data gradient / the next BN passes
+        # WGRAD_SIDE 1: the weight gradient forks first and runs beside this layer's data gradient; 2: it forks behind the data
+        # gradient (beside the next layer's BatchNorm backward passes); 3: as 2, and the next data gradient waits for it
+        if ctx.needs_input_grad[1] and WGRAD_SIDE < 2:
             dw = _wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3, keep=(dz, x))
         if ctx.needs_input_grad[0]:
             half = _is_half(dz)
             wd = pack_weight(weight, taps, 1, half=half)
+            if WGRAD_SIDE == 3 and _side["dirty"]:
+                torch.cuda.current_stream().wait_stream(_side["stream"])
             dx, _ = conv_raw(dzr, ldzz, co, wd, ci, nv, h, w, taps, d3=d3, sp=sp, grad=True, half=half)
+        if ctx.needs_input_grad[1] and WGRAD_SIDE >= 2:
+            dw = _wgrad(dzr, ldzz, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3, keep=(dz, x))
         if has_bias and ctx.needs_input_grad[2]:
             # a conv bias under train-mode BN has an analytically ZERO gradient (BN removes the channel mean):
             # sum(dz) = -gamma*istd*mean(dy*xhat)*sum(xhat) and sum(xhat) == 0.  The reference's autograd

@@ -104,11 +104,37 @@ args = T.build_parser().parse_args(["--batch_size", "2", "--queue_size", "200", 
                                     "--num_negatives", "32", "--k1", "1.0", "--base_lr", "0.05"])
 args.patch_size = [64, 64]
 st = T.ArcoStep2D(args, dev)
-for i in range(4):
+assert args.graph_train == 1                 # trainer default: the student passes replay as HIP graphs from their third call
+fired = []
+real_async = adist.allreduce_bucket_async
+def counting_async(opt, start):
+    fired.append(len(adist._pending_buckets) == 0)
+    return real_async(opt, start)
+adist.allreduce_bucket_async = counting_async
+real_draw = C_.contrast_draw
+N_STEPS, ZERO_STEP = 8, 5
+for i in range(N_STEPS):
     l_img, l_lab = T.synthetic_batch(2, args.patch_size, 4, 100 + 10 * i + rank, dev)      # different data per rank
     u_img, _ = T.synthetic_batch(2, args.patch_size, 4, 200 + 10 * i + rank, dev)
+    if i == ZERO_STEP and rank == 1:
+        # ADVICE r3 (high), on the real step: THIS rank's loss takes the degenerate-batch path (no entries -> `weight.sum() * 0`,
+        # the heads' marker never fires) while rank 0's does not - the gradient exchange must still be the same two collectives
+        def no_entries(pl, *a_, **k_):
+            r = real_draw(pl, *a_, **k_)
+            C_.contrast_draw_finish(pl)
+            pl.entries = []
+            return r
+        C_.contrast_draw = no_entries
+    n_before = len(fired)
     loss, reco = st.step(l_img, l_lab, u_img)
+    C_.contrast_draw = real_draw
+    if i == ZERO_STEP and rank == 1:
+        assert len(fired) == n_before and float(reco) == 0.0, "the zero path must not reach the heads' marker"
+    else:
+        assert len(fired) == n_before + 1 and fired[-1], f"step {i}: the heads' bucket did not start from inside the backward"
+    assert adist._pending_buckets == [] and st.optimizer._bucket_start is None
 torch.cuda.synchronize()
+assert st.s_train_lu.captured and st.s_train_lu.calls >= N_STEPS       # the async bucket met graph-replayed backward passes (steps 3..)
 
 
 def digest(ts):
@@ -125,4 +151,5 @@ td.all_gather_object(both, mine)
 assert both[0] == both[1], (both[0], both[1])
 assert sum(int(b[0].shape[0]) for b in st.memobank) > 4, "banks never grew"
 if rank == 0:
+    print(f"DDP_OK {N_STEPS} steps, graph-replayed student passes from step 3, heads' bucket fired {len(fired)} times on rank 0, rank 1 took the zero path at step {ZERO_STEP};")
     print("DDP_OK global entropy thresholds; rank-averaged loss == single-process loss on the concatenated batch (%.6f);" % float(l_dp), " banks/ptr/params/teacher identical on 2 ranks; bank lens", mine[4], "loss", float(reco))
