@@ -445,8 +445,9 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
 # the main stream while the side stream still reads it.  A/B: ARCO_WGRAD_SIDE=0..3.
 # Measured (round 4, one box, alternating runs; profiles/r04_notes.md): the graph-replayed 2-D step gets SLOWER with it (13.4 ->
 # 14.2 ms forked before the data gradient, 13.6-13.9 forked behind it: the persistent one-workgroup-per-CU kernels lose more
-# to a co-resident weight-gradient workgroup than the tails give back), the eager 3-D LA step 3 % faster (30.1 -> 29.2 ms).
-# Hence: off by default, the 3-D trainer switches it on (mode 1) unless ARCO_WGRAD_SIDE says otherwise.
+# to a co-resident weight-gradient workgroup than the tails give back); the 3-D LA step gains 3 % only with EAGER student passes
+# (30.1 -> 29.2 ms: two queues hide host launch time), nothing under the default graph replay (30.1-30.6 both ways; LiTS f16
+# 20.5 vs 20.7).  Hence: off by default, kept as a knob (ARCO_WGRAD_SIDE=1..3).
 _WGRAD_SIDE_ENV = __import__('os').environ.get('ARCO_WGRAD_SIDE')
 WGRAD_SIDE = int(_WGRAD_SIDE_ENV) if _WGRAD_SIDE_ENV is not None else 0
 _side = {"stream": None, "keep": [], "dirty": False}

@@ -56,8 +56,6 @@ class ArcoStep3D:
         ops.CONV_MMA = {"f32": 0, "f16": 1, "bf16": 2, "f32x3": 3}[getattr(args, "conv_mma", "f32x3")]
         ops.ACT_HALF = getattr(args, "act_dtype", "f32") == "f16"          # before the PackPlans: they carry the f16 packs
         ops.LOSS_SCALE = float(getattr(args, "loss_scale", 16384.0))
-        if ops._WGRAD_SIDE_ENV is None:        # weight gradients beside the data gradients: a gain for the volume step only (ops._wgrad)
-            ops.WGRAD_SIDE = 1
         self.memobank, self.queue_ptrlis, self.queue_size = [], [], []
         for i in range(C):                                                # :144-151
             self.memobank.append([torch.randn(1, REP_DIM_3D)])
