@@ -1012,7 +1012,25 @@ __global__ void pack_many_kernel(const PackDesc* __restrict__ desc, int n_desc, 
     const long j = i - d.first;
     const int k = j % d.Kpad; const long r = j / d.Kpad; const int n = r % d.Npad; const int tap = r / d.Npad;
     float v = 0.f;
-    if ((d.mode & 1) == 0) { if (n < d.Cout && k < d.Cin) v = d.src[((long)n * d.Cin + k) * d.taps + tap]; }
+    const int gm = d.mode >> 3;
+    if (gm) {
+      // GEMM form of a k2 s2 (transposed) convolution, gathered straight from the torch layout (round 4: the V-Net's
+      // DownsamplingConvBlock / UpsamplingDeconvBlock rebuilt and re-packed their [N][K] weights at every forward: ~130
+      // launches per volume step).  Logical matrix W2[a][b] (a < Cout, b < Cin; one "tap"); d.taps carries the inner dim g:
+      //   gm 1 (Conv3d [co][ci][8]):           W2[co][t * ci + c] = W[co][c][t],  g = ci
+      //   gm 2 (ConvTranspose3d [ci][co][8]):  W2[t * co + o][ci] = W[ci][o][t],  g = co
+      //   gm 4 (bias repeated over the 8 taps): W2[0][t * co + o] = bias[o],       g = co
+      int a_, b_; bool ok;
+      if ((d.mode & 1) == 0) { a_ = n; b_ = k; ok = n < d.Cout && k < d.Cin; }
+      else { a_ = k; b_ = n; ok = n < d.Cin && k < d.Cout; }
+      if (ok) {
+        const int g = d.taps;
+        if (gm == 1) v = d.src[((long)a_ * g + b_ % g) * 8 + b_ / g];
+        else if (gm == 2) v = d.src[((long)b_ * g + a_ % g) * 8 + a_ / g];
+        else v = d.src[b_ % g];
+      }
+    }
+    else if ((d.mode & 1) == 0) { if (n < d.Cout && k < d.Cin) v = d.src[((long)n * d.Cin + k) * d.taps + tap]; }
     else { if (n < d.Cin && k < d.Cout) v = d.src[((long)k * d.Cin + n) * d.taps + (d.taps - 1 - tap)]; }
     if (d.mode & 4) reinterpret_cast<_Float16*>(d.dst)[j] = (_Float16)v;
     else if (d.mode & 2) store_split3(v, reinterpret_cast<unsigned short*>(d.dst), r, k, d.Kpad);

@@ -108,16 +108,15 @@ class DownsamplingConvBlock(nn.Module):
     def forward(self, x, xs=None):
         """xs: space_to_depth3(x) when the caller already made it (VNet.encoder: ops.s2d_skip pairs it with the skip alias of x)."""
         conv, bn = self.conv[0], (self.conv[1] if self.has_norm else None)
-        co, ci = conv.weight.shape[0], conv.weight.shape[1]
-        w2 = conv.weight.permute(0, 2, 3, 4, 1).reshape(co, 8 * ci, 1, 1, 1)      # [co][(dx,dy,dz), ci]
+        w2, bias = ops.gemm_weight(conv)                                          # [co][(dx,dy,dz), ci]
         if xs is None:
             xs = ops.space_to_depth3(x)
         if not isinstance(bn, nn.BatchNorm3d):
-            return _norm_act(ops.conv(xs, w2, conv.bias), bn, self.training)
+            return _norm_act(ops.conv(xs, w2, bias), bn, self.training)
         if self.training:
-            return ops.conv_bn_act(xs, w2, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
+            return ops.conv_bn_act(xs, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
                                    p=0.0, momentum=bn.momentum, eps=bn.eps, num_batches_tracked=bn.num_batches_tracked)
-        return ops.conv_bn_act_eval(xs, w2, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
+        return ops.conv_bn_act_eval(xs, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, slope=0.0,
                                     eps=bn.eps)
 
 
@@ -143,13 +142,13 @@ class UpsamplingDeconvBlock(nn.Module):
         self._fused = False
         conv, bn = self.conv[0], (self.conv[1] if self.has_norm else None)
         ci, co = conv.weight.shape[0], conv.weight.shape[1]
-        w2 = conv.weight.permute(2, 3, 4, 1, 0).reshape(8 * co, ci, 1, 1, 1)      # [(dx,dy,dz), co][ci]
+        w2, bias8 = ops.gemm_weight(conv)                                         # [(dx,dy,dz), co][ci]
         is_bn = isinstance(bn, nn.BatchNorm3d)
         # train-mode BatchNorm: the bias only shifts its input -> analytically zero gradient.  GroupNorm's sets span several
         # channels (a per-channel shift survives), 'none' has no normalisation: the bias gradient is a real column sum there;
         # InstanceNorm removes it like BatchNorm does.
         zero_bias_grad = (self.training and is_bn) or isinstance(bn, nn.InstanceNorm3d)
-        y = ops.conv(x, w2, conv.bias.repeat(8), bias_grad_zero=zero_bias_grad)
+        y = ops.conv(x, w2, bias8, bias_grad_zero=zero_bias_grad)
         if is_bn and self.training and ops.D2S_FUSE and co % 4 == 0:
             # depth-to-space folded into the BatchNorm passes (and the skip addition with it): ops.BnActD2sFn
             self._fused = skip is not None and skip.dtype == y.dtype

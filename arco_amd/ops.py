@@ -169,6 +169,8 @@ WEIGHT_EPOCH = 0
 
 
 _plans = []
+_PLAN_BY_PTR = {}       # data_ptr of a plan-owned GEMM-form weight W2 -> {mode: (plan, buf, sbuf, hbuf)} (the tensor object that
+                        # reaches pack_weight is an autograd output sharing W2's storage: attributes do not travel, addresses do)
 
 
 def bump_weight_epoch():
@@ -196,8 +198,51 @@ class PackPlan:
         flags = list(half) if half is not None else [False] * len(tops)
         assert len(flags) == len(tops)
         mods = [(m, bool(f)) for top, f in zip(tops, flags) for m in top.modules()]
+        self.gemm_entries = []
         for m, m_half in mods:
             w = getattr(m, "weight", None)
+            if isinstance(m, (torch.nn.Conv3d, torch.nn.ConvTranspose3d)) and w is not None and tuple(w.shape[2:]) == (2, 2, 2) \
+                    and tuple(m.stride) == (2, 2, 2):
+                # k2 s2 (transposed) convolution = space-to-depth / depth-to-space + a GEMM over W2 [N2][K2] (vnetWithArgs.py
+                # DownsamplingConvBlock / UpsamplingDeconvBlock): W2, its packs (and the 8x repeated bias of the transposed
+                # form) are persistent buffers of the plan, gathered from the torch layout by the plan's one launch
+                up = isinstance(m, torch.nn.ConvTranspose3d)
+                dev = w.device
+                if up:
+                    ci_, co_ = int(w.shape[0]), int(w.shape[1])
+                    n2, k2, gm, g = 8 * co_, ci_, 2, co_
+                else:
+                    co_, ci_ = int(w.shape[0]), int(w.shape[1])
+                    n2, k2, gm, g = co_, 8 * ci_, 1, ci_
+                if n2 % 16 or k2 % 16:
+                    continue                                  # (W2 doubles as the zero-copy [N][K] operand: whole 16-blocks only)
+                w2 = torch.empty((n2, k2, 1, 1, 1), dtype=torch.float32, device=dev)
+                recs.append((w, w2, n2, k2, g, gm << 3, n2, k2, total)); total += n2 * k2
+                ent = {}
+                for mode in ((0, 1) if with_dgrad and w.requires_grad else (0,)):
+                    n, k = (n2, k2) if mode == 0 else (k2, n2)
+                    buf = sbuf = hbuf = None
+                    if m_half:
+                        kp32 = (k + 31) // 32 * 32
+                        hbuf = torch.empty((1, n, kp32), dtype=torch.float16, device=dev)
+                        recs.append((w, hbuf, n2, k2, g, (gm << 3) | mode | 4, n, kp32, total)); total += n * kp32
+                    else:
+                        if mode == 1:
+                            buf = torch.empty((1, n, k), dtype=torch.float32, device=dev)
+                            recs.append((w, buf, n2, k2, g, (gm << 3) | mode, n, k, total)); total += n * k
+                        if CONV_MMA == 3:
+                            kp32 = (k + 31) // 32 * 32
+                            sbuf = torch.empty((1, n, kp32 * 3 // 2), dtype=torch.float32, device=dev)
+                            recs.append((w, sbuf, n2, k2, g, (gm << 3) | mode | 2, n, kp32, total)); total += n * kp32
+                    ent[mode] = (self, buf, sbuf, hbuf)
+                bias8 = None
+                if up and m.bias is not None:
+                    bias8 = torch.empty(8 * co_, dtype=torch.float32, device=dev)
+                    recs.append((m.bias, bias8, 1, 8 * co_, co_, 4 << 3, 1, 8 * co_, total)); total += 8 * co_
+                _PLAN_BY_PTR[w2.data_ptr()] = ent
+                self.gemm_entries.append((w, w2, bias8))
+                w._arco_gemm = (self, w2, bias8)
+                continue
             if not isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d)) or w is None:
                 continue
             dev = w.device
@@ -287,7 +332,7 @@ def _pack_now(w, co, ci, taps, mode, split, half=False):
 
 def _pack_half(weight, taps, mode):
     """The f16 pack [taps][Npad][ceil32(K)] of a conv weight (f16 activation storage): from the PackPlan, else per weight-epoch."""
-    plan = getattr(weight, "_arco_plan", None)
+    plan = getattr(weight, "_arco_plan", None) or _PLAN_BY_PTR.get(weight.data_ptr())
     if plan is not None and mode in plan and plan[mode][0].valid and plan[mode][3] is not None:
         return plan[mode][3]
     capturing = torch.cuda.is_current_stream_capturing()
@@ -321,7 +366,7 @@ def pack_weight(weight, taps, mode, half=False):
     w = weight.detach()
     want_split = CONV_MMA == 3 and (ci if mode == 0 else co) % 4 == 0
     zero_copy = mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0 and w.is_contiguous()
-    plan = getattr(weight, "_arco_plan", None)
+    plan = getattr(weight, "_arco_plan", None) or _PLAN_BY_PTR.get(weight.data_ptr())
     if plan is not None and mode in plan and plan[mode][0].valid:
         _, buf, sbuf, _h = plan[mode]
         if (buf is not None or zero_copy) and (sbuf is not None or not want_split):
@@ -992,6 +1037,56 @@ class BilinearFn(torch.autograd.Function):
         dx = new_act(nb, c, h, w, dy.device)
         L.call("arco_bilinear_bwd", L.ptr(dyr), ldy, nb, h, w, c, ho, wo, L.ptr(dx), c, 0)
         return dx, None, None
+
+
+class _GemmWeightFn(torch.autograd.Function):
+    """W2 = the GEMM form of a k2 s2 (transposed) conv weight, served from the PackPlan's persistent buffer (refreshed with the
+    plan: no permute / copy / pack launches per forward); the backward un-permutes dW2 into the torch layout (views)."""
+
+    @staticmethod
+    def forward(ctx, w, w2buf, up):
+        ctx.up, ctx.wshape = bool(up), tuple(w.shape)
+        return w2buf.detach()
+
+    @staticmethod
+    def backward(ctx, dw2):
+        a, b = ctx.wshape[0], ctx.wshape[1]
+        if ctx.up:          # W2 [(t, co)][ci] <- W [ci][co][t]
+            dw = dw2.reshape(2, 2, 2, b, a).permute(4, 3, 0, 1, 2)
+        else:               # W2 [co][(t, ci)] <- W [co][ci][t]
+            dw = dw2.reshape(a, 2, 2, 2, b).permute(0, 4, 1, 2, 3)
+        return dw, None, None
+
+
+class _Bias8Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b, b8buf):
+        return b8buf.detach()
+
+    @staticmethod
+    def backward(ctx, db8):
+        return db8.view(8, -1).sum(0), None
+
+
+def gemm_weight(conv):
+    """(W2, bias') of a k2 s2 Conv3d / ConvTranspose3d in GEMM form: W2 [co][8 ci] resp. [8 co][ci] (tap-major), bias' = the
+    bias (Conv3d) resp. the bias repeated over the 8 taps (ConvTranspose3d).  From the module's PackPlan when it is valid,
+    otherwise built here (permute + reshape, as round 3 did at every forward)."""
+    w, b = conv.weight, conv.bias
+    up = isinstance(conv, torch.nn.ConvTranspose3d)
+    ent = getattr(w, "_arco_gemm", None)
+    if ent is not None and ent[0].valid:
+        _, w2buf, b8buf = ent
+        grad = torch.is_grad_enabled()
+        w2 = _GemmWeightFn.apply(w, w2buf, up) if (grad and w.requires_grad) else w2buf
+        if up and b is not None:
+            b = _Bias8Fn.apply(b, b8buf) if (grad and b.requires_grad) else b8buf
+        return w2, b
+    if up:
+        ci, co = w.shape[0], w.shape[1]
+        return w.permute(2, 3, 4, 1, 0).reshape(8 * co, ci, 1, 1, 1), (b.repeat(8) if b is not None else None)
+    co, ci = w.shape[0], w.shape[1]
+    return w.permute(0, 2, 3, 4, 1).reshape(co, 8 * ci, 1, 1, 1), b
 
 
 def conv(x, weight, bias=None, residual=False, bias_grad_zero=False):

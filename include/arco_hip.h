@@ -98,7 +98,11 @@ int arco_conv_split_ok(int taps, int NB, int H, int W, int Cin, int Cout, long l
  *      model_2D.py:25-33; train_arco_2d.py:231-234).  Wp = packed weights [taps][ceil16(N)][ceil16(K)].    */
 int arco_pack_conv_weight(const float* W, int Cout, int Cin, int taps, int mode, float* Wp, void* stream);
 /* all conv weights of a model in ONE launch: `desc` = device array of records {const float* src; float* dst;
- * int Cout, Cin, taps, mode, Npad, Kpad; long first;} (arco_pack_desc_bytes() bytes each)                */
+ * int Cout, Cin, taps, mode, Npad, Kpad; long first;} (arco_pack_desc_bytes() bytes each).
+ * mode bits: 1 data-gradient form (flipped + transposed), 2 split-bf16, 4 f16; mode >> 3 != 0 gathers the GEMM form of a
+ * k2 s2 (transposed) convolution straight from the torch layout - nn.Conv3d(k2, s2) / nn.ConvTranspose3d(k2, s2) of
+ * vnetWithArgs.py:67-118: 1 = W2[co][t*ci + c] = W[co][c][t], 2 = W2[t*co + o][ci] = W[ci][o][t], 4 = the bias repeated over
+ * the 8 taps; `taps` then carries the inner dimension (ci resp. co), Cout / Cin are W2's logical [N][K]                */
 long arco_pack_desc_bytes();
 int arco_pack_many(const void* desc, int n_desc, long total, void* stream);
 /* small-M x N, long-K GEMM (InfoNCE anchor gradient, loss_helper_3d.py:503-509 backward): K split into `splits`
