@@ -29,6 +29,16 @@ __device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ f32x4 ld4f(const _Float16* p) { return __builtin_convertvector(*reinterpret_cast<const f16x4_t*>(p), f32x4); }
 __device__ __forceinline__ void st4f(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void st4f(_Float16* p, f32x4 v) { *reinterpret_cast<f16x4_t*>(p) = __builtin_convertvector(v, f16x4_t); }
+// eight consecutive channels of an f16 row in one 16-byte access (the BN apply passes on f16 activation storage)
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x8 ld8f(const _Float16* p) { return __builtin_convertvector(*reinterpret_cast<const f16x8_t*>(p), f32x8); }
+__device__ __forceinline__ void st8f(_Float16* p, f32x8 v) { *reinterpret_cast<f16x8_t*>(p) = __builtin_convertvector(v, f16x8_t); }
+__device__ __forceinline__ f32x8 ld8p(const float* p) {      // eight per-channel parameters
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // bit layout of the per-pixel class code (C <= 21)
 #define ARCO_MAXC 21
