@@ -134,7 +134,11 @@ def cpu_baseline_child():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_step
     physical, logical, model = _host_cpu()
-    torch.set_num_threads(max(1, min(physical, 128)))
+    # the thread count at which the oracle step is FASTEST on this pool's hosts (2 x 64-core EPYC 9575F), measured in round 4:
+    # 16 / 32 / 64 / 128 threads -> 4.6 / 4.3 / 6.6 / 10.7 s per step, loss alone 806 / 769 / 931 / 1461 ms (torch's intra-op
+    # pool loses to cross-socket traffic beyond one CCD group); `cores` reports the threads used, physical_cores the host's.
+    # ARCO_CPU_THREADS overrides.
+    torch.set_num_threads(int(os.environ.get("ARCO_CPU_THREADS", max(1, min(physical, 32)))))
     cpu_step.timed_sample(b=1, patch=(64, 64), k2=1.0, bt=True)          # warm the thread pool / allocator
     secs, threads = cpu_step.timed_sample(b=2, steps=3, k2=1.0, bt=True)
     loss_ms = cpu_loss_only(threads)
@@ -159,7 +163,7 @@ def cpu_baseline():
                               "queues, 256 x 512 samples per class); the GPU twin is contrastive_loss_ms_per_step at 16 images",
             "sample": f"{r.get('steps', 1)} chained full oracle steps at --batch_size 2 (4 images, 256x256, C=4, D=496, cutmix, "
                       f"k2 = 1 equivariance term and batch_transform on, like the GPU headline), {secs:.1f} s per step on {threads} threads "
-                      f"(= physical cores); scaled x4 to the 16-image step"}
+                      f"({r.get('physical_cores')} physical cores on the host); scaled x4 to the 16-image step"}
 
 
 def spawn_ranks(a, argv):
