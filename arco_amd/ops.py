@@ -239,6 +239,7 @@ class PackPlan:
                 if up and m.bias is not None:
                     bias8 = torch.empty(8 * co_, dtype=torch.float32, device=dev)
                     recs.append((m.bias, bias8, 1, 8 * co_, co_, 4 << 3, 1, 8 * co_, total)); total += 8 * co_
+                ent["shape"] = (n2, k2)      # (the lookup checks it: an address match alone must not hand out another weight's packs)
                 _PLAN_BY_PTR[w2.data_ptr()] = ent
                 self.gemm_entries.append((w, w2, bias8))
                 w._arco_gemm = (self, w2, bias8)
@@ -316,6 +317,14 @@ def _split_ok(taps, nbd, h, w, k, n, ld):
     return r
 
 
+def _plan_by_ptr(weight):
+    """The plan entry of a plan-owned GEMM-form weight W2 (ops.gemm_weight hands out autograd outputs that share W2's storage)."""
+    ent = _PLAN_BY_PTR.get(weight.data_ptr())
+    if ent is not None and ent.get("shape") == (int(weight.shape[0]), int(weight.shape[1])) and weight.dim() == 5:
+        return ent
+    return None
+
+
 def _pack_now(w, co, ci, taps, mode, split, half=False):
     n, k = (co, ci) if mode == 0 else (ci, co)
     if half:
@@ -332,7 +341,7 @@ def _pack_now(w, co, ci, taps, mode, split, half=False):
 
 def _pack_half(weight, taps, mode):
     """The f16 pack [taps][Npad][ceil32(K)] of a conv weight (f16 activation storage): from the PackPlan, else per weight-epoch."""
-    plan = getattr(weight, "_arco_plan", None) or _PLAN_BY_PTR.get(weight.data_ptr())
+    plan = getattr(weight, "_arco_plan", None) or _plan_by_ptr(weight)
     if plan is not None and mode in plan and plan[mode][0].valid and plan[mode][3] is not None:
         return plan[mode][3]
     capturing = torch.cuda.is_current_stream_capturing()
@@ -366,7 +375,7 @@ def pack_weight(weight, taps, mode, half=False):
     w = weight.detach()
     want_split = CONV_MMA == 3 and (ci if mode == 0 else co) % 4 == 0
     zero_copy = mode == 0 and taps == 1 and co % 16 == 0 and ci % 16 == 0 and w.is_contiguous()
-    plan = getattr(weight, "_arco_plan", None) or _PLAN_BY_PTR.get(weight.data_ptr())
+    plan = getattr(weight, "_arco_plan", None) or _plan_by_ptr(weight)
     if plan is not None and mode in plan and plan[mode][0].valid:
         _, buf, sbuf, _h = plan[mode]
         if (buf is not None or zero_copy) and (sbuf is not None or not want_split):
