@@ -14,7 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401
 
-from . import ops, optim, stage1
+from . import ops, stage1
+from . import optim as _optim      # NOT `optim`: the reference trainers do `import torch.optim as optim` and then `from model_2D import *`
 from .networks.net_factory_args import net_factory
 
 
@@ -152,7 +153,7 @@ class ISD(nn.Module):
 
     def _ensure_ema_pairs(self):
         if self._ema_pairs is None:
-            self._ema_pairs = [optim.EmaPair(q, k) for q, k in (
+            self._ema_pairs = [_optim.EmaPair(q, k) for q, k in (
                 (self._unwrap(self.model), self._unwrap(self.ema_model)),
                 (self._unwrap(self.q_outputs_head), self._unwrap(self.k_outputs_head)),
                 (self._unwrap(self.q_latent_head), self._unwrap(self.k_latent_head)))]

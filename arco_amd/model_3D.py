@@ -6,7 +6,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401
 
-from . import ops, optim
+from . import ops
+from . import optim as _optim      # NOT `optim`: a star import of this module must not shadow the trainer's `import torch.optim as optim`
 from .model_2D import FeatureExtractor, create_model  # noqa: F401
 from .networks.net_factory_3dArgs import net_factory_3d
 
@@ -115,7 +116,7 @@ class ISD_3d(nn.Module):
 
     def _ensure_ema_pairs(self):
         if self._ema_pairs is None:
-            self._ema_pairs = [optim.EmaPair(q, k) for q, k in (
+            self._ema_pairs = [_optim.EmaPair(q, k) for q, k in (
                 (self.model, self.ema_model), (self.q_outputs_head, self.k_outputs_head),
                 (self.q_latent_head, self.k_latent_head))]
         return self._ema_pairs

@@ -133,3 +133,36 @@ print("FROM_REF", from_ref)
     # hot-path modules must come from dropin/, not from the reference tree (dataloaders.utils, which the stage-1 trainers
     # import and never use, is allowed to fall through to the reference's own file: namespace packages merge)
     assert out["FROM_REF"] == "[]", out
+
+
+_SHADOW_CHILD = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+# what the reference trainers bind BEFORE their star imports (train_arco_2d.py:1-19, train_arco_3d.py:1-19)
+import torch, logging, os, pickle, argparse, shutil, random
+import torch.optim as optim
+from torch.nn.modules.loss import CrossEntropyLoss
+import torch.utils.data.sampler as sampler
+from utils import losses, metrics, ramps
+before = dict(torch=torch, logging=logging, sys=sys, os=os, pickle=pickle, optim=optim, argparse=argparse, shutil=shutil,
+              random=random, CrossEntropyLoss=CrossEntropyLoss, sampler=sampler, losses=losses, metrics=metrics, ramps=ramps)
+ns = dict(before)
+for stmt in sys.argv[2:]:
+    exec(stmt, ns)
+bad = [k for k, v in before.items() if ns.get(k) is not v]
+print("SHADOWED " + ",".join(bad))
+'''
+
+
+@pytest.mark.parametrize("stmts", [["from augment import *", "from loss_helper_3d import *", "from model_2D import *"],
+                                   ["from augment_3d import *", "from loss_helper import *", "from model_3D import *"]])
+def test_star_imports_do_not_rebind_what_the_trainer_imported_before(stmts):
+    """Round 4, found by tests/test_dropin_loop_gpu.py: `arco_amd.model_2D` bound its optimiser module as `optim`, and the
+    reference trainers do `import torch.optim as optim` (train_arco_2d.py:8) BEFORE `from model_2D import *` (:24) - the star
+    import replaced torch.optim and `optim.SGD(...)` (:248) raised.  No name the trainers bind ahead of their star imports may be
+    rebound by them."""
+    out = subprocess.run([sys.executable, "-c", _SHADOW_CHILD, os.path.join(ROOT, "dropin")] + stmts, capture_output=True, text=True,
+                         timeout=300, env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("SHADOWED")][-1]
+    assert line.strip() == "SHADOWED", line
