@@ -54,3 +54,35 @@ def test_reference_style_loop_over_the_dropin_modules_matches_the_cpu_oracle(k2,
                rm=st["student"]["encoder.in_conv.conv_conv.1.running_mean"])
     for k, v in ref.items():
         np.testing.assert_allclose(t[k], float(v.detach().double().abs().sum()), rtol=2e-4, err_msg=k)
+
+
+def test_reference_style_3d_loop_over_the_dropin_modules_runs_and_matches_the_oracle_where_it_can():
+    """tools/dropin_loop3d.py: the loop body of train_arco_3d.py:255-400 over `dropin/` (torch `nn.Conv3d` q_representation,
+    torch.optim.SGD, C = 4 so that the 5-D banks fill).  Step 0's supervised terms do not depend on any sampled index or threshold
+    decision: they are compared with the CPU oracle of the 3-D step at 1e-3; the rest of the run (three steps, iteration 0 with the
+    equivariance objective) must stay finite, fill the banks and move the weights - the strict whole-step comparison of the 3-D step,
+    with forced decisions, is tests/test_step3d_parity_gpu.py."""
+    import cpu_step3d
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_loop3d.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    got = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("DROPIN_LOOP3D ")][-1][len("DROPIN_LOOP3D "):])
+    assert got["tail"]["model_file"].startswith(os.path.join(ROOT, "dropin"))
+    for s_ in got["steps"]:
+        assert all(np.isfinite(s_[k]) for k in ("ce", "dice", "unsup", "reco", "eqv", "loss")) and s_["banks_on_gpu"]
+    assert got["tail"]["finite"] and got["tail"]["qrep_finite"] and got["tail"]["moved"] > 0
+    assert max(got["steps"][-1]["bank_len"]) > 16                       # C = 4: the 5-D enqueue ran
+    C, b, patch = 4, 2, (32, 32, 32)
+    torch.manual_seed(3)
+    st = cpu_step3d.make_state(fx.vnet_state(52, 1, C), fx.fe_state(61, (128, 64, 32, 16, 16), 16, nd=3),
+                               [torch.randn(16, 16, 1, 1, 1) / 4, torch.randn(16, 16, 1, 1, 1) / 4])
+    bank, ptr, qsz = fx.fresh_bank(C, 16, 200, 'randn')
+    rs = np.random.RandomState(13)
+    l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+    u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+    lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
+    l = l + 0.5 * (lab > 0).unsqueeze(1).float()
+    random.seed(10); np.random.seed(10); torch.manual_seed(10)
+    cpu_step3d.step(st, l, lab, u, bank, ptr, qsz, n_cls=C, k1=1.0, nq=48, nn_=16, strong_threshold=0.3)
+    for k in ("ce", "dice"):
+        np.testing.assert_allclose(got["steps"][0][k], st["last_terms"][k], rtol=1e-3, err_msg=k)
