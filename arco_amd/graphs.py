@@ -98,10 +98,19 @@ class GraphedTrain:
     The capture is taken w.r.t. leaf aliases of the parameters (see _capture), so live autograd graphs over
     the real parameters (optimizer hooks, the other pass of the same step) do not leak into it."""
 
-    def __init__(self, module, warmup=2, enabled=True):
+    def __init__(self, module, warmup=2, enabled=True, grad_views=None):
+        """grad_views: {id(parameter): tensor} - the captured backward accumulates the parameter gradients THERE instead of in
+        the parameters' own .grad views (optim.SGDNesterov.second_grad_views: a pass replayed on a side stream beside another
+        backward pass over the same parameters)."""
         self.module, self.warmup, self.enabled = module, warmup, enabled
+        self.grad_views = grad_views
         self.calls = 0
         self.captured = False
+
+    def will_replay(self, x):
+        """Will the next call with input x capture-or-replay the graphs (rather than run the module eagerly)?"""
+        return (self.enabled and self.calls >= self.warmup and torch.is_grad_enabled()
+                and (not self.captured or tuple(x.shape) == self.shape))
 
     def _capture(self, x):
         from torch.utils import _pytree as pytree
@@ -128,7 +137,11 @@ class GraphedTrain:
                     for k, v in p.__dict__.items():
                         if k.startswith("_arco"):
                             setattr(a, k, v)
-                    if p.grad is not None:
+                    gv = self.grad_views.get(id(p)) if self.grad_views is not None else None
+                    if gv is not None:
+                        a._arco_grad_view = gv
+                        a.grad = gv
+                    elif p.grad is not None:
                         a.grad = p.grad
                     alias[n] = a
                 self.alias = alias
@@ -152,8 +165,18 @@ class GraphedTrain:
                 grads = torch.autograd.grad([self.flat_outs[i] for i in self.diff_idx], inputs, self.static_grads,
                                             allow_unused=True)
                 ops.join_side()          # the weight-gradient branch (ops._wgrad) joins the capture stream: a graph edge
-            grads = list(grads)
-            self.static_dx = grads.pop(0) if self.static_in.requires_grad else None
+                grads = list(grads)
+                self.static_dx = grads.pop(0) if self.static_in.requires_grad else None
+                if self.grad_views is not None:
+                    # gradients autograd returned as tensors (biases without a BatchNorm behind them): accumulated into the second
+                    # buffer inside the captured graph - handing them to autograd would let AccumulateGrad `+=` the parameters'
+                    # own .grad on this pass's stream while the other pass does the same on its stream
+                    for i, (n, p) in enumerate(named):
+                        if grads[i] is not None and self.grad_views.get(id(p)) is not None:
+                            self.grad_views[id(p)].add_(grads[i])
+                            grads[i] = None
+                            if hasattr(p, "_arco_mark") and p._arco_mark not in self.markers:
+                                self.markers.append(p._arco_mark)
             self.static_pgrads = grads         # None where the kernels wrote into the flat gradient buffer
         finally:
             ops.SEED_DEV = prev_salt

@@ -140,6 +140,25 @@ class SGDNesterov:
             self._touched.add(i)
         return mark
 
+    def second_grad_views(self):
+        """A second flat gradient buffer with the layout of the first: {id(param): view}.  A graph-replayed pass that runs
+        CONCURRENTLY with another backward pass over the same parameters (train_arco_2d: the warped student pass on a side
+        stream) accumulates its parameter gradients here - two kernels doing `+=` on one buffer from two streams would race -
+        and merge_second() adds the buffer into the first once both passes are done.  a + b is commutative in fp32: the merged
+        gradient is bit-identical to the sequential accumulation."""
+        if getattr(self, "flat_g2", None) is None:
+            self.flat_g2 = torch.zeros_like(self.flat_g)
+            self._g2_views = {id(p): self.flat_g2[off:off + k].view(p.shape) for (off, k), p in zip(self.offsets, self.params)}
+            self._g2_dirty = False
+        return self._g2_views
+
+    def merge_second(self, n_elems=None):
+        if getattr(self, "flat_g2", None) is not None and self._g2_dirty:
+            n = self.flat_g.numel() if n_elems is None else int(n_elems)
+            self.flat_g[:n].add_(self.flat_g2[:n])
+            self.flat_g2[:n].zero_()
+            self._g2_dirty = False
+
     def touch_from(self, start_elem):
         """Mark every parameter at flat offset >= start_elem as having received a (zero) gradient this step.  The reference's
         degenerate-batch loss is `0.0 * rep.sum()` (loss_helper_3d.py:417-424): attached to the graph, it hands every head

@@ -142,6 +142,19 @@ def patients_to_slices(dataset, patiens_num):
     return ref_dict[str(patiens_num)]
 
 
+# Pass-level concurrency on a second stream (round 4; profiles/r04_notes.md section 7).  The step is a dependent chain of ~870 kernels,
+# most of them 5-40 us: a kernel rarely fills the chip for its whole duration, and one launch floor (~5 us) per link adds up to a
+# third of the step.  Running two INDEPENDENT passes side by side fills those gaps - unlike kernel-level forks inside one pass
+# (ops._wgrad), which made the persistent kernels of the same pass fight for CUs.
+#   1: the teacher's grouped pass beside the student forward                                  13.30 -> 13.16 ms
+#   2: + the statistics-only student pass (cj2_l) beside the masks / heads work               -> 12.87 ms
+#   3: + the warped student pass (equivariance term) on the side stream: its forward beside the heads / InfoNCE, its BACKWARD
+#      beside the main pass's backward, parameter gradients into a second flat buffer          -> 11.37 ms  (default)
+# Results are unchanged: the passes were independent already, only their order in time is free; the two gradient buffers are
+# summed once (a + b, bit-identical to accumulating in sequence).  ARCO_TEACHER_SIDE=0 restores the single-stream step.
+TEACHER_SIDE = int(os.environ.get("ARCO_TEACHER_SIDE", "3"))
+
+
 class ArcoStep2D:
     """State + one training step of the 2-D hot path (train_arco_2d.py:147-154,220-253,284-435)."""
 
@@ -212,6 +225,8 @@ class ArcoStep2D:
         # HIP-event timing of the three contrastive-loss segments: only when a profiler asks for it (bench.py sets
         # profile_loss); a training run records no events (no stream bubbles, nothing accumulates)
         self.profile_loss = False
+        self._t_stream = None
+        self._stats_on_side = False
         self.keep_debug = False          # tests: keep the last step's plan and anchor rows (self.debug)
         self.loss_events = []
         # no-grad forwards replayed as HIP graphs (one graph per call site: outputs are static buffers)
@@ -228,7 +243,11 @@ class ArcoStep2D:
                                mode='affine', device=device)
         self.batched_passes = bool(getattr(args, "batched_passes", 1))
         self.s_train_lu = graphs.GraphedTrain(self.model, enabled=g_train)
-        self.s_train_tps = graphs.GraphedTrain(self.model, enabled=g_train)  # the equivariance term's student pass (:415)
+        # the equivariance term's student pass (:415).  ARCO_TEACHER_SIDE >= 3: replayed on the side stream - its forward beside the
+        # heads / InfoNCE, its backward beside the main pass's backward - with a gradient buffer of its own (optim.second_grad_views)
+        self._tps_side = TEACHER_SIDE >= 3 and g_train
+        self.s_train_tps = graphs.GraphedTrain(self.model, enabled=g_train,
+                                               grad_views=self.optimizer.second_grad_views() if self._tps_side else None)
         self.t_fwd_lu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
@@ -279,8 +298,18 @@ class ArcoStep2D:
             lu = torch.cat((l_data, u_aug))
             # The u half postpones its running-statistics update (ops.bn_defer) until the images_cj2_l pass below has
             # made its own: the momentum updates then land in the reference's order l, cj2_l, u (:310-312).
+            t_side = None
+            if TEACHER_SIDE:      # the teacher's grouped pass (independent of the student's) on a second stream, beside the student forward
+                if self._t_stream is None:
+                    self._t_stream = torch.cuda.Stream()
+                t_side = self._t_stream
+                t_side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(t_side), torch.no_grad(), ops.bn_groups(2):
+                    pred_t, _, fm_t = self.t_fwd_lu(lu)
             with ops.bn_groups(2), ops.bn_defer(1):
                 pred_all, _, fm_all = self.s_train_lu(lu)
+            if t_side is not None:
+                torch.cuda.current_stream().wait_stream(t_side)
             nb_l = int(l_data.shape[0])
             pred_l, pred_u = ops.split_batch(pred_all, nb_l)    # (views; one gradient buffer for both halves in the backward)
         else:
@@ -288,8 +317,9 @@ class ArcoStep2D:
                 pred_u, _, u_fm = self.s_train_u(u_aug)                  # :312 (needed first: entropy masks)
         with torch.no_grad():                                            # teacher params carry no grad (:158-160)
             if batched:
-                with ops.bn_groups(2):
-                    pred_t, _, fm_t = self.t_fwd_lu(lu)                  # :314-315 as one grouped pass
+                if not TEACHER_SIDE:
+                    with ops.bn_groups(2):
+                        pred_t, _, fm_t = self.t_fwd_lu(lu)              # :314-315 as one grouped pass
                 pred_l_t, pred_u_t = pred_t[:nb_l], pred_t[nb_l:]
             else:
                 pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)               # :314
@@ -316,8 +346,17 @@ class ArcoStep2D:
             # images_cj2_l forward (:311): BN running statistics only - its FE/q_rep outputs (l_feature_map_2,
             # :319,326) are never read.  One graph launch (~1 ms of GPU work) queued BEFORE the host sync: work for
             # the GPU while the host replays the samplers (14.8 vs 15.1 ms/step when queued after the sync).
-            self.s_fwd_stats(cj2_l)
-            ops.apply_deferred_bn()                                      # the u pass's running-statistics update (:312)
+            if TEACHER_SIDE >= 2 and batched:      # (mode 2: this statistics-only pass too runs beside the main stream's work)
+                if self._t_stream is None:
+                    self._t_stream = torch.cuda.Stream()
+                self._t_stream.wait_stream(torch.cuda.current_stream())     # behind the student pass: BN buffers in the reference's order
+                with torch.cuda.stream(self._t_stream):
+                    self.s_fwd_stats(cj2_l)
+                    ops.apply_deferred_bn()
+                self._stats_on_side = True
+            else:
+                self.s_fwd_stats(cj2_l)
+                ops.apply_deferred_bn()                                  # the u pass's running-statistics update (:312)
             # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
             if not batched:
                 fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
@@ -382,6 +421,7 @@ class ArcoStep2D:
         if prof:
             ev2[1].record()
         C_.contrast_draw(plan, a.func, defer=True)     # indices collected by contrast_anchor_pix below
+        tps_on_side = False
         loss_eqv = None
         if a.k2 != 0:
             # equivariance term (:404-423).  The warp is drawn AFTER the samplers, as in the reference: both consume
@@ -397,8 +437,24 @@ class ArcoStep2D:
                 images_tps = self.tps(images_cj2)                        # :411-413 images_cj2
                 mask_tps = self.tps(eq_mask, padding_mode='zeros')
                 pred_tps_org = self.tps(pred_all_d, padding_mode='zeros')
-            pred_tps = self.s_train_tps(images_tps)[0]                   # :415 one more student pass (one BN batch)
-            loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)   # :419-423
+            tps_on_side = self._tps_side and self.s_train_tps.will_replay(images_tps)
+            if tps_on_side:        # behind the statistics-only pass on that stream (running statistics: cj2_l, u, then this pass)
+                if self._t_stream is None:
+                    self._t_stream = torch.cuda.Stream()
+                self._t_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._t_stream):
+                    pred_tps = self.s_train_tps(images_tps)[0]
+                self._stats_on_side = False
+                self.optimizer._g2_dirty = True
+            else:
+                if self._stats_on_side:    # the warped pass updates the same running statistics next
+                    torch.cuda.current_stream().wait_stream(self._t_stream)
+                    self._stats_on_side = False
+                pred_tps = self.s_train_tps(images_tps)[0]               # :415 one more student pass (one BN batch)
+                loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)   # :419-423
+        if self._stats_on_side:            # (no equivariance pass: the optimiser must not change the weights under the statistics pass)
+            torch.cuda.current_stream().wait_stream(self._t_stream)
+            self._stats_on_side = False
         if prof:
             ev3[0].record()
         C_.contrast_anchor_pix(plan)
@@ -426,6 +482,9 @@ class ArcoStep2D:
         if prof:
             ev3[1].record()
             self.loss_events.append((ev, ev2, ev3, evp))  # masks | keys, banks | anchors, head, InfoNCE | lists, prototypes
+        if tps_on_side:                    # the heads and the InfoNCE above ran beside the warped pass's forward
+            torch.cuda.current_stream().wait_stream(self._t_stream)
+            loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)   # :419-423
         # :426 - one launch for the weighted sum (and one for its backward) instead of a chain of 0-d multiplies and adds
         ws = [a.k1 * adist.anchor_weight(a.num_queries, getattr(a, "anchors_per_rank", "split")), a.k3, 1.0, 1.0]
         terms = [reco_loss, unsup_loss, loss_dice, loss_ce]
@@ -442,6 +501,7 @@ class ArcoStep2D:
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()
         ops.join_side()                     # weight gradients queued on the side stream (ops._wgrad)
+        self.optimizer.merge_second(self.heads_start)      # the warped pass's parameter gradients (replayed on the side stream)
         if zero_path:     # `0 * rep.sum()` gives EVERY head parameter a zero gradient: SGD still decays / applies momentum to them
             self.optimizer.touch_from(self.heads_start)
         adist.allreduce_grads(self.optimizer)
