@@ -24,6 +24,9 @@ from .tps.rand_tps_3d import RandTPS as RandTPS3D
 from .model_3D import ISD_3d, FeatureExtractor_3d
 from .train_arco_2d import build_parser as _build_parser_2d
 
+# pass-level concurrency on a second stream (see train_arco_2d.TEACHER_SIDE): 1 = the teacher's grouped pass beside the student
+# forward, 2 (default) = + the gradient-free warped student pass beside the heads / InfoNCE / backward.  ARCO_TEACHER_SIDE=0: off.
+PASS_SIDE = min(2, int(os.environ.get("ARCO_TEACHER_SIDE", "3")))
 FEA_DIM_3D = [128, 64, 32, 16, 16]
 REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
 
@@ -105,6 +108,7 @@ class ArcoStep3D:
         self.k_fe_ema.plans = [ops.PackPlan([self.k_feature_extractor], False)]
         self.plans = [plan_s] + [pl for pr in pairs for pl in pr.plans] + self.k_fe_ema.plans
         self.iter_num = 0
+        self._side, self._tps_pending = None, False
         self._ovf_host, self._ovf_event, self.overflow_steps, self._clean_steps = None, None, 0, 0     # f16 overflow guard
         self.keep_debug = False          # tests: keep the last step's plan and anchor rows (self.debug)
         use_graphs = bool(getattr(args, "graphs", 1))
@@ -197,16 +201,27 @@ class ArcoStep3D:
         if batched:     # labelled + unlabelled volumes as one pass with two BatchNorm groups (see train_arco_2d.py)
             lu = torch.cat((l_data, u_aug))
             nb_l = int(l_data.shape[0])
+            t_side = None
+            if PASS_SIDE >= 1:      # the teacher's grouped pass on a second stream, beside the student forward (see train_arco_2d.TEACHER_SIDE)
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                t_side = self._side
+                t_side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(t_side), torch.no_grad(), ops.bn_groups(2):
+                    pred_t, _, fm_t = self.t_fwd_lu(lu)                  # :286-287
             with ops.bn_groups(2):
                 pred_all, _, fm_s = self.s_train_lu(lu)                  # :283-284
+            if t_side is not None:
+                torch.cuda.current_stream().wait_stream(t_side)
             pred_l, pred_u = ops.split_batch(pred_all, nb_l)
         else:
             with ops.bn_defer(0):                                        # running statistics: l first (:283), then u
                 pred_u, _, u_fm = self.s_train_u(u_aug)                  # :284
         with torch.no_grad():
             if batched:
-                with ops.bn_groups(2):
-                    pred_t, _, fm_t = self.t_fwd_lu(lu)                  # :286-287
+                if PASS_SIDE < 1:
+                    with ops.bn_groups(2):
+                        pred_t, _, fm_t = self.t_fwd_lu(lu)              # :286-287
                 pred_l_t, pred_u_t = pred_t[:nb_l], pred_t[nb_l:]
             else:
                 pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)               # :286
@@ -264,9 +279,21 @@ class ArcoStep3D:
                 images_tps = self.tps(torch.cat((l_data, u_aug)))
                 mask_tps = self.tps(eq_mask, padding_mode='zeros')
                 pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
-            with torch.set_grad_enabled(self.iter_num == 0), ops.logits_only():   # only iteration 0 back-propagates it (:390-393)
-                pred_tps = (self.model if self.iter_num == 0 else self.s_fwd_tps)(images_tps)[0]                     # :380
-                loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
+            if PASS_SIDE >= 2 and self.iter_num > 0 and self.s_fwd_tps.enabled:
+                # after iteration 0 the warped pass is a logged value and a running-statistics update (:390-393): nothing of this
+                # step waits for it - it runs on the second stream beside the heads, the InfoNCE and the whole backward pass, and
+                # is joined before the optimiser touches the weights
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side), torch.no_grad(), ops.logits_only():
+                    pred_tps = self.s_fwd_tps(images_tps)[0]
+                    loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
+                self._tps_pending = True
+            else:
+                with torch.set_grad_enabled(self.iter_num == 0), ops.logits_only():   # only iteration 0 back-propagates it (:390-393)
+                    pred_tps = (self.model if self.iter_num == 0 else self.s_fwd_tps)(images_tps)[0]                 # :380
+                    loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
         C_.contrast_anchor_pix(plan)
         zero_path = plan.valid_seg <= 1 or not plan.entries
         if zero_path:
@@ -297,6 +324,9 @@ class ArcoStep3D:
         self.optimizer.zero_grad()
         loss.backward()
         ops.join_side()                     # weight gradients queued on the side stream (ops._wgrad)
+        if self._tps_pending:               # the warped pass on the second stream reads the weights the optimiser is about to change
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._tps_pending = False
         if zero_path and not first:      # `0 * rep.sum()` (loss_helper.py:588-595): zero gradients for every head parameter
             self.optimizer.touch_from(self.heads_start)
         if ops.ACT_HALF:       # the V-Net's parameter gradients carry the loss scale of the f16 region

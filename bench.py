@@ -405,6 +405,10 @@ def run_sub(name, steps):
         torch.cuda.synchronize()
     ms = timed(run_steps, steps)
     mem = torch.cuda.max_memory_allocated() / 1e9
+    if cfg["kind"] == "2d":
+        T.TEACHER_SIDE = 0            # single-stream eager pass for the per-kernel timing (see main())
+    else:
+        T3.PASS_SIDE = 0
     prof = eager_profile(st, run_steps, 2)
     roof, whole = roofline_from_profile(prof, 2, ms)
     terms = {k: round(float(v), 5) for k, v in st.last_terms.items()}
@@ -546,6 +550,9 @@ def main():
     # replay is timestamped unreliably on this stack (the kernel trace of the same step shows the segment's kernels back to
     # back: profiles/README.md), so the graph-replayed passes next to the segments are launched as plain kernels here.
     from arco_amd import graphs as _graphs
+    # (the instrumented passes below run on ONE stream: HIP events on the launch stream cannot price a segment or a kernel while
+    #  another pass runs beside it on the side stream - T.TEACHER_SIDE is the step's pass-concurrency switch)
+    side_mode, T.TEACHER_SIDE = T.TEACHER_SIDE, 0
     prev_flags = _graphs.set_enabled(stepper, {"s_train_tps": False, "s_train_lu": False})
     stepper.profile_loss = True
     stepper.loss_events = []
@@ -559,6 +566,7 @@ def main():
     stepper.profile_loss = False
     stepper.loss_events = []
     _graphs.set_enabled(stepper, prev_flags)
+    T.TEACHER_SIDE = side_mode
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -580,7 +588,9 @@ def main():
             k2_0 = {"ms_per_step": round(ms0, 3), "steps_per_s": round(1e3 / ms0, 3), "steps": a.k2_0_steps,
                     "note": "--k2 0: the north-star path alone (contrastive + supervised + unsupervised terms), no "
                             "equivariance pass; round 1's headline configuration"}
+        T.TEACHER_SIDE = 0            # single-stream eager pass: per-kernel HIP-event timing (see above)
         prof = eager_profile(stepper, run, 3)
+        T.TEACHER_SIDE = side_mode
         roof, whole = roofline_from_profile(prof, 3, step_ms)
 
     if rank == 0:
@@ -601,6 +611,7 @@ def main():
                        "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc", "apply_aug": args.apply_aug,
                        "loss_terms": f"k1*contrastive + k3*unsupervised + CE + Dice + k2*equivariance (k2 = {a.k2:g})",
                        "graph_train": int(bool(getattr(args, "graph_train", 0))), "parallelism": f"dp{world}",
+                       "pass_concurrency": f"ARCO_TEACHER_SIDE={T.TEACHER_SIDE} (teacher / statistics / warped student passes on a second stream)",
                        "contrastive_loss_ms_per_step": round(loss_ms, 3),
                        "sustained_ms_per_step": (sustained or {}).get("ms_per_step"),
                        "whole_step_tflops": (whole or {}).get("tflops_over_whole_step")},
