@@ -214,3 +214,59 @@ def test_three_steps_3d_vs_cpu_oracle(variant):
     if C >= 4:
         assert keys_seen > 0                   # C = 4: the 5-D enqueue ran inside the step on both sides
     print(f"worst parameter-update deviation so far: L2 {_STATS['e2']:.3f} (bound 0.1), element-wise {_STATS['emax']:.3f} (bound 0.3)")
+
+
+def test_pass_concurrency_3d_equals_the_single_stream_step():
+    """The 3-D step with the teacher's grouped pass and the gradient-free warped pass on the second stream (train_arco_3d.PASS_SIDE = 2,
+    the default) against the single-stream step (0), four steps from equal state: loss terms, weights, BatchNorm buffers."""
+    from arco_amd import ops, train_arco_3d as T3
+    prev = T3.PASS_SIDE
+    try:
+        sts = []
+        for mode in (0, 2):
+            T3.PASS_SIDE = mode
+            random.seed(3); np.random.seed(3); torch.manual_seed(3)
+            args = T3.build_parser().parse_args(["--batch_size", "1", "--queue_size", "200", "--synthetic", "1", "--num_classes", "4",
+                                                 "--num_queries", "48", "--num_negatives", "16", "--k1", "1.0"])
+            args.patch_size = [32, 32, 32]
+            st = T3.ArcoStep3D(args, "cuda:0")
+            for m in (st.model, st.ema_model):
+                _drop_off(m)
+            sts.append(st)
+        st_a, st_b = sts
+
+        def sync(dst, src):       # every step starts from EQUAL state (two fp32 trajectories drift apart through the decisions)
+            with torch.no_grad():
+                dst.optimizer.flat_p.copy_(src.optimizer.flat_p)
+                dst.optimizer.flat_buf.copy_(src.optimizer.flat_buf)
+                dst.optimizer._started = list(src.optimizer._started)
+                for g_d, g_s in zip(dst.optimizer.param_groups, src.optimizer.param_groups):
+                    g_d['lr'] = g_s['lr']
+                for md, ms in ((dst.model, src.model), (dst.ema_model, src.ema_model), (dst.k_feature_extractor, src.k_feature_extractor)):
+                    for (kd, vd), (ks, vs) in zip(md.state_dict().items(), ms.state_dict().items()):
+                        vd.copy_(vs)
+                dst.memobank = [[m[0].clone()] for m in src.memobank]
+                dst.queue_ptrlis = [q.clone() if torch.is_tensor(q) else q for q in src.queue_ptrlis]
+            dst.iter_num = src.iter_num
+            ops.bump_weight_epoch()
+
+        for it in range(4):
+            l, ll = T3.synthetic_volume_batch(1, (32, 32, 32), 4, 10 + it, "cuda:0")
+            u, _ = T3.synthetic_volume_batch(1, (32, 32, 32), 4, 20 + it, "cuda:0")
+            sync(st_b, st_a)
+            terms = []
+            for st, mode in ((st_a, 0), (st_b, 2)):
+                T3.PASS_SIDE = mode
+                random.seed(50 + it); np.random.seed(50 + it); torch.manual_seed(50 + it)
+                st.step(l, ll, u)
+                torch.cuda.synchronize()
+                terms.append({k: float(v) for k, v in st.last_terms.items()})
+            for k in terms[0]:
+                np.testing.assert_allclose(terms[1][k], terms[0][k], rtol=1e-4, atol=1e-6, err_msg=f"step {it} {k}")
+            pa, pb = st_a.optimizer.flat_p, st_b.optimizer.flat_p
+            assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max()), it
+        for (k, va), (_, vb) in zip(st_a.model.state_dict().items(), st_b.model.state_dict().items()):
+            if va.is_floating_point() and "running" in k:
+                np.testing.assert_allclose(vb.cpu().numpy(), va.cpu().numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+    finally:
+        T3.PASS_SIDE = prev

@@ -382,3 +382,52 @@ def test_default_trainer_keeps_the_reference_generator_sequence_without_the_pool
         assert torch.equal(out[0][1][k], out[1][1][k]), k
     for a, b in zip(out[0][2], out[1][2]):
         assert torch.equal(a, b)
+
+
+def test_pass_concurrency_equals_the_single_stream_step():
+    """Round 4: the default step runs the teacher's grouped pass, the statistics-only pass and the warped student pass on a second
+    stream (train_arco_2d.TEACHER_SIDE = 3: forward AND backward of the warped pass beside the main pass's, parameter gradients in a
+    second flat buffer merged once).  From equal state, steps 1-6 (graphs captured at the third call, replayed afterwards) must give
+    the losses, weights, BatchNorm buffers and banks of the single-stream step (ARCO_TEACHER_SIDE=0) - the passes were independent
+    already, only their order in time changed."""
+    from arco_amd import train_arco_2d as T
+    b, patch, C = 2, (64, 64), 4
+    seed_state = (fx.unet_state(21, 1, C), fx.fe_state(31), [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]])
+    prev = T.TEACHER_SIDE
+    try:
+        T.TEACHER_SIDE = 0
+        st_a = _trainer(1, seed_state)
+        T.TEACHER_SIDE = 3
+        st_b = _trainer(1, seed_state)
+        assert st_b._tps_side and not st_a._tps_side
+        rs = np.random.RandomState(5)
+        for it in range(6):
+            l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32)).cuda()
+            u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32)).cuda()
+            lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C)).cuda()
+            _sync_state(st_b, st_a)
+            terms = []
+            for st, mode in ((st_a, 0), (st_b, 3)):
+                T.TEACHER_SIDE = mode
+                random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
+                st.step(l, lab, u)
+                torch.cuda.synchronize()
+                terms.append({k: float(v) for k, v in st.last_terms.items()})
+            for k in terms[0]:
+                np.testing.assert_allclose(terms[1][k], terms[0][k], rtol=2e-5, atol=1e-6, err_msg=f"step {it} {k}")
+            pa, pb = st_a.optimizer.flat_p, st_b.optimizer.flat_p
+            assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max()), it
+            for (k, va), (_, vb) in zip(st_a.model.state_dict().items(), st_b.model.state_dict().items()):
+                if va.is_floating_point():
+                    np.testing.assert_allclose(vb.cpu().numpy(), va.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=f"{it} {k}")
+                else:
+                    assert int(va) == int(vb), k
+            for (k, va), (_, vb) in zip(st_a.ema_model.state_dict().items(), st_b.ema_model.state_dict().items()):
+                if va.is_floating_point():
+                    np.testing.assert_allclose(vb.cpu().numpy(), va.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=f"teacher {it} {k}")
+            for ba, bb in zip(st_a.memobank, st_b.memobank):
+                np.testing.assert_allclose(bb[0].cpu().numpy(), ba[0].cpu().numpy(), rtol=1e-4, atol=1e-6)
+        assert st_b.s_train_tps.captured and st_b.s_train_tps.grad_views is not None
+        assert float(st_b.optimizer.flat_g2.abs().max()) == 0.0            # merged and cleared
+    finally:
+        T.TEACHER_SIDE = prev
