@@ -501,6 +501,12 @@ class ArcoStep2D:
         self.optimizer.zero_grad()                                       # :429-431
         loss.backward()
         ops.join_side()                     # weight gradients queued on the side stream (ops._wgrad)
+        if tps_on_side:
+            # the warped pass's backward graph was replayed on the side stream and hands nothing back to autograd (its parameter
+            # gradients go straight into the second buffer), so the engine has no leaf stream to synchronise with at the end of
+            # backward(): wait for it here.  (Found as a 1-in-3 flake of test_cfg2_graph_replay_equals_eager_at_full_size: the LAST
+            # gradient of that backward, the first layer's weight, was merged before it was complete.)
+            torch.cuda.current_stream().wait_stream(self._t_stream)
         self.optimizer.merge_second(self.heads_start)      # the warped pass's parameter gradients (replayed on the side stream)
         if zero_path:     # `0 * rep.sum()` gives EVERY head parameter a zero gradient: SGD still decays / applies momentum to them
             self.optimizer.touch_from(self.heads_start)
