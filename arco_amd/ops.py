@@ -52,25 +52,26 @@ class bn_groups:
         BN_GROUPS = self.prev
 
 
-BN_DEFER = None       # see bn_defer()
-_DEFERRED = {}        # running_mean.data_ptr() -> dict(rm, rv, buf, C, n, momentum), in registration order
-_DEFER_TABLE = None   # (keys, device descriptor table) of the last apply_deferred_bn()
+BN_DEFER = None       # (from_group, slot) inside `with bn_defer(...)`, else None
+_DEFERRED = {}        # slot -> {running_mean.data_ptr() -> dict(rm, rv, buf, C, n, momentum)}, in registration order
+_DEFER_TABLE = {}     # slot -> (keys, device descriptor table) of the last apply_deferred_bn(slot)
 
 
 class bn_defer:
-    """`with ops.bn_defer(g0):` - inside, the groups >= g0 of every train-mode BatchNorm forward compute and use their
-    batch statistics as usual but POSTPONE their running-statistics momentum update; `ops.apply_deferred_bn()` applies
+    """`with ops.bn_defer(g0, slot):` - inside, the groups >= g0 of every train-mode BatchNorm forward compute and use their
+    batch statistics as usual but POSTPONE their running-statistics momentum update; `ops.apply_deferred_bn(slot)` applies
     the postponed updates later (one launch for all layers).  The momentum updates do not commute: the reference
     runs model(l), model(cj2_l), model(u) (train_arco_2d.py:310-312) while the trainer here runs (l, u) as one grouped
-    pass and cj2_l afterwards - with the u group deferred behind the cj2_l pass the running statistics receive the
-    three updates in the reference's order."""
+    pass and cj2_l before or after it - with the u group deferred (slot 0) and, when it runs first, the cj2_l pass deferred
+    as well (slot 1), the running statistics receive the three updates in the reference's order: l inside the grouped
+    pass, then apply_deferred_bn(1), then apply_deferred_bn(0)."""
 
-    def __init__(self, from_group=0):
-        self.g0 = int(from_group)
+    def __init__(self, from_group=0, slot=0):
+        self.v = (int(from_group), int(slot))
 
     def __enter__(self):
         global BN_DEFER
-        self.prev, BN_DEFER = BN_DEFER, self.g0
+        self.prev, BN_DEFER = BN_DEFER, self.v
 
     def __exit__(self, *exc):
         global BN_DEFER
@@ -79,35 +80,36 @@ class bn_defer:
 
 def _defer_args(running_mean, running_var, co, G, momentum):
     """(defer_from, deferred buffer or None) for the arco_bn_finalize call of one BN layer."""
-    global _DEFER_TABLE
-    if BN_DEFER is None or running_mean is None or BN_DEFER >= G:
+    if BN_DEFER is None or running_mean is None or BN_DEFER[0] >= G:
         return 0, None
-    n = G - BN_DEFER
+    g0, slot = BN_DEFER
+    n = G - g0
     key = running_mean.data_ptr()
-    e = _DEFERRED.get(key)
+    tab = _DEFERRED.setdefault(slot, {})
+    e = tab.get(key)
     if e is None or e["n"] != n or e["C"] != co:
         e = dict(rm=running_mean, rv=running_var, C=co, n=n, momentum=float(momentum),
                  buf=torch.zeros(n * 2 * co + 1, dtype=torch.float32, device=running_mean.device))
-        _DEFERRED[key] = e
-        _DEFER_TABLE = None
-    return BN_DEFER, e["buf"]
+        tab[key] = e
+        _DEFER_TABLE.pop(slot, None)
+    return g0, e["buf"]
 
 
-def apply_deferred_bn():
-    """Apply every postponed running-statistics update (see bn_defer); layers with nothing pending are skipped on the
-    device (a flag per layer), so calling it when nothing was deferred is harmless."""
-    global _DEFER_TABLE
-    if not _DEFERRED:
+def apply_deferred_bn(slot=0):
+    """Apply every postponed running-statistics update of a slot (see bn_defer); layers with nothing pending are skipped on
+    the device (a flag per layer), so calling it when nothing was deferred is harmless."""
+    tab = _DEFERRED.get(slot)
+    if not tab:
         return
-    keys = tuple(_DEFERRED)
-    if _DEFER_TABLE is None or _DEFER_TABLE[0] != keys:
+    keys = tuple(tab)
+    if slot not in _DEFER_TABLE or _DEFER_TABLE[slot][0] != keys:
         import struct
         raw = b"".join(struct.pack("<QQQiifi", e["rm"].data_ptr(), e["rv"].data_ptr(), e["buf"].data_ptr(), e["C"], e["n"],
-                                   e["momentum"], 0) for e in _DEFERRED.values())
+                                   e["momentum"], 0) for e in tab.values())
         assert len(raw) == len(keys) * L.query("arco_bn_defer_desc_bytes")
-        dev = next(iter(_DEFERRED.values()))["buf"].device
-        _DEFER_TABLE = (keys, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev))
-    L.call("arco_bn_apply_deferred", L.ptr(_DEFER_TABLE[1]), len(keys))
+        dev = next(iter(tab.values()))["buf"].device
+        _DEFER_TABLE[slot] = (keys, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev))
+    L.call("arco_bn_apply_deferred", L.ptr(_DEFER_TABLE[slot][1]), len(keys))
 
 
 def _next_seed():

@@ -16,6 +16,7 @@ Also built: batch_transform (PIL round trip, ColorJitter, GaussianBlur, AdvMorph
 """
 import argparse
 import logging
+import contextlib
 import os
 import random
 import sys
@@ -149,10 +150,14 @@ def patients_to_slices(dataset, patiens_num):
 #   1: the teacher's grouped pass beside the student forward                                  13.30 -> 13.16 ms
 #   2: + the statistics-only student pass (cj2_l) beside the masks / heads work               -> 12.87 ms
 #   3: + the warped student pass (equivariance term) on the side stream: its forward beside the heads / InfoNCE, its BACKWARD
-#      beside the main pass's backward, parameter gradients into a second flat buffer          -> 11.37 ms  (default)
+#      beside the main pass's backward, parameter gradients into a second flat buffer          -> 11.37 ms
+#   4: + the step's critical path shortened (tools/step_timeline.py): the statistics pass moves to the step's start, beside the
+#      teacher's first pass (its running-statistics updates postponed into slot 1 of ops.bn_defer, so they still land between l
+#      and u); warps + warped pass start on the side stream as soon as the host has drawn the warp, the bank appends are
+#      queued after them                                                  same process, alternating: 11.64 -> 11.27 ms  (default)
 # Results are unchanged: the passes were independent already, only their order in time is free; the two gradient buffers are
 # summed once (a + b, bit-identical to accumulating in sequence).  ARCO_TEACHER_SIDE=0 restores the single-stream step.
-TEACHER_SIDE = int(os.environ.get("ARCO_TEACHER_SIDE", "3"))
+TEACHER_SIDE = int(os.environ.get("ARCO_TEACHER_SIDE", "4"))
 
 
 class ArcoStep2D:
@@ -272,17 +277,30 @@ class ArcoStep2D:
             if not pl.valid:
                 pl.refresh()
         dense = getattr(a, "dense_head", 0)
-        with torch.no_grad():                                            # :284-286
-            pred_u0, _, _ = self.t_fwd_u0(u_data)
-            pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         # randomGeneratorWithLogits (:292-293) is a same-size zoom(order=0) = the identity; then the mixing strategy
         # (:296-297) on the GPU with the reference's host draws; other --apply_aug values leave the batch unchanged
         bt = bool(getattr(a, "batch_transform", 1))
         cj2_l = l_data
         if bt:      # :287-290: two calls without augmentation - images_cj1_logits_l (the constant 255 -> 1.0) and images_cj2_l
+            # (queued in front of the teacher's pass below, which consumes nothing of the torch CPU generator: the host draws keep
+            # the reference's order)
             augment.draw_batch_transform_params(int(l_data.shape[0]), False)         # (only its generator draws matter)
             cj2_l, _, _ = augment.batch_transform(l_data, l_label, torch.ones_like(l_label, dtype=torch.float32), a.patch_size,
                                                   (1.0, 1.0), False)
+        stats_early = TEACHER_SIDE >= 4 and self.batched_passes and l_data.shape == u_data.shape
+        if stats_early:
+            # Mode 4: the statistics-only student pass on images_cj2_l (:311) depends on nothing but the weights - it runs on the
+            # side stream beside the teacher's first pass (two 8-image passes, neither of which fills the chip alone).  Its
+            # running-statistics updates are postponed (slot 1) and land between those of the l and the u half of the grouped
+            # student pass below: the reference's order l, cj2_l, u.
+            if self._t_stream is None:
+                self._t_stream = torch.cuda.Stream()
+            self._t_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._t_stream), torch.no_grad(), ops.bn_defer(0, 1):
+                self.s_fwd_stats(cj2_l)
+        with torch.no_grad():                                            # :284-286
+            pred_u0, _, _ = self.t_fwd_u0(u_data)
+            pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
         u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
         cj2_u = u_aug
         if bt:      # :299-304: two independent strong augmentations of the mixed unlabeled batch
@@ -290,6 +308,8 @@ class ArcoStep2D:
             u_aug, u_aug_label, u_aug_logits = augment.batch_transform(u_aug, u_aug_label, u_aug_logits, a.patch_size, (1.0, 1.0), True)
         self.k_fe_ema.update(0.99)                                      # :306-308
         batched = self.batched_passes and l_data.shape == u_aug.shape
+        if stats_early:           # (the student's BatchNorm buffers - num_batches_tracked - belong to the passes below from here on)
+            torch.cuda.current_stream().wait_stream(self._t_stream)
         if batched:
             # the labelled and the unlabelled student forward (:310,312) as ONE batch-2b pass with two BatchNorm
             # groups (ops.bn_groups: per-half batch statistics, running statistics updated half after half) - same
@@ -346,7 +366,10 @@ class ArcoStep2D:
             # images_cj2_l forward (:311): BN running statistics only - its FE/q_rep outputs (l_feature_map_2,
             # :319,326) are never read.  One graph launch (~1 ms of GPU work) queued BEFORE the host sync: work for
             # the GPU while the host replays the samplers (14.8 vs 15.1 ms/step when queued after the sync).
-            if TEACHER_SIDE >= 2 and batched:      # (mode 2: this statistics-only pass too runs beside the main stream's work)
+            if stats_early:
+                ops.apply_deferred_bn(1)                                 # cj2_l (ran beside the teacher's first pass), then
+                ops.apply_deferred_bn()                                  # the u half / pass
+            elif TEACHER_SIDE >= 2 and batched:    # (mode 2: this statistics-only pass too runs beside the main stream's work)
                 if self._t_stream is None:
                     self._t_stream = torch.cuda.Stream()
                 self._t_stream.wait_stream(torch.cuda.current_stream())     # behind the student pass: BN buffers in the reference's order
@@ -401,6 +424,9 @@ class ArcoStep2D:
                 logits_all = torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits))
                 eqv_in = (glue.eqv_mask(labels_all, logits_all, a.weak_threshold), torch.cat((cj2_l, cj2_u)),
                           pred_all.detach() if batched else torch.cat((pred_l.detach(), pred_u.detach())))
+            if TEACHER_SIDE >= 4:          # mode 4: the warps and the warped pass start from here on the side stream
+                self._eqv_in_ready = torch.cuda.Event()
+                self._eqv_in_ready.record()
         # per-class row lists and prototypes need the class codes / totals on the DEVICE only: queued before the host blocks
         evp = None
         if prof:
@@ -414,14 +440,18 @@ class ArcoStep2D:
         #      GPU has work while the host replays the samplers (bit-exact torch-CPU-generator sequence, ~2 ms)
         C_.contrast_counts(plan, self.memobank, self.queue_size,
                            adist.anchors_for_rank(a.num_queries, getattr(a, "anchors_per_rank", "split")), a.num_negatives)
-        if prof:
-            ev2[0].record()
-        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size,
-                            lazy_teacher=lazy_t, defer_anchor_pix=True)
-        if prof:
-            ev2[1].record()
+        def enqueue():                     # key rows of the teacher -> banks (no generator draws, no use of the sampled indices)
+            if prof:
+                ev2[0].record()
+            C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size,
+                                lazy_teacher=lazy_t, defer_anchor_pix=True)
+            if prof:
+                ev2[1].record()
+        enqueue_late = TEACHER_SIDE >= 4 and a.k2 != 0    # mode 4: the warped pass is on the step's critical path - queue it first
+        if not enqueue_late:
+            enqueue()
         C_.contrast_draw(plan, a.func, defer=True)     # indices collected by contrast_anchor_pix below
-        tps_on_side = False
+        tps_on_side = tps_early = False
         loss_eqv = None
         if a.k2 != 0:
             # equivariance term (:404-423).  The warp is drawn AFTER the samplers, as in the reference: both consume
@@ -431,16 +461,27 @@ class ArcoStep2D:
                 self.tps = RandTPS(a.patch_size[0], a.patch_size[1], batch_size=nb2, sigma=a.tps_sigma,
                                    border_padding=False, random_mirror=True, random_scale=(0.8, 1.2), mode='affine',
                                    device=l_data.device)                 # :255-261 (draws one warp, like the reference)
-            with torch.no_grad():
-                eq_mask, images_cj2, pred_all_d = eqv_in
-                self.tps.reset_control_points()                          # :412
-                images_tps = self.tps(images_cj2)                        # :411-413 images_cj2
-                mask_tps = self.tps(eq_mask, padding_mode='zeros')
-                pred_tps_org = self.tps(pred_all_d, padding_mode='zeros')
-            tps_on_side = self._tps_side and self.s_train_tps.will_replay(images_tps)
-            if tps_on_side:        # behind the statistics-only pass on that stream (running statistics: cj2_l, u, then this pass)
-                if self._t_stream is None:
-                    self._t_stream = torch.cuda.Stream()
+            eq_mask, images_cj2, pred_all_d = eqv_in
+            tps_on_side = self._tps_side and self.s_train_tps.will_replay(images_cj2)
+            tps_early = tps_on_side and TEACHER_SIDE >= 4
+            if tps_on_side and self._t_stream is None:
+                self._t_stream = torch.cuda.Stream()
+            if tps_early:
+                # Mode 4: the warps and the warped pass do not queue behind the main stream's row lists / bank appends / index
+                # uploads: they run on the side stream from the moment the host has drawn the warp, behind `eqv_in` on the main
+                # stream (which is behind the grouped pass and the running-statistics updates above).
+                self._t_stream.wait_event(self._eqv_in_ready)
+            with torch.cuda.stream(self._t_stream) if tps_early else contextlib.nullcontext():
+                with torch.no_grad():
+                    self.tps.reset_control_points()                      # :412
+                    images_tps = self.tps(images_cj2)                    # :411-413 images_cj2
+                    mask_tps = self.tps(eq_mask, padding_mode='zeros')
+                    pred_tps_org = self.tps(pred_all_d, padding_mode='zeros')
+                if tps_early:
+                    pred_tps = self.s_train_tps(images_tps)[0]           # :415
+            if tps_early:
+                self.optimizer._g2_dirty = True
+            elif tps_on_side:      # behind the statistics-only pass on that stream (running statistics: cj2_l, u, then this pass)
                 self._t_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._t_stream):
                     pred_tps = self.s_train_tps(images_tps)[0]
@@ -452,6 +493,8 @@ class ArcoStep2D:
                     self._stats_on_side = False
                 pred_tps = self.s_train_tps(images_tps)[0]               # :415 one more student pass (one BN batch)
                 loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)   # :419-423
+        if enqueue_late:
+            enqueue()
         if self._stats_on_side:            # (no equivariance pass: the optimiser must not change the weights under the statistics pass)
             torch.cuda.current_stream().wait_stream(self._t_stream)
             self._stats_on_side = False

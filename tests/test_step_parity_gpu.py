@@ -384,8 +384,10 @@ def test_default_trainer_keeps_the_reference_generator_sequence_without_the_pool
         assert torch.equal(a, b)
 
 
-def test_pass_concurrency_equals_the_single_stream_step():
-    """Round 4: the default step runs the teacher's grouped pass, the statistics-only pass and the warped student pass on a second
+@pytest.mark.parametrize("side_mode", [3, 4])
+def test_pass_concurrency_equals_the_single_stream_step(side_mode):
+    """(side_mode 4: the warped pass additionally starts before the main stream's row lists / bank appends and runs its OWN backward()
+    on the side stream before the heads and the InfoNCE are done.)  Round 4: the default step runs the teacher's grouped pass, the statistics-only pass and the warped student pass on a second
     stream (train_arco_2d.TEACHER_SIDE = 3: forward AND backward of the warped pass beside the main pass's, parameter gradients in a
     second flat buffer merged once).  From equal state, steps 1-6 (graphs captured at the third call, replayed afterwards) must give
     the losses, weights, BatchNorm buffers and banks of the single-stream step (ARCO_TEACHER_SIDE=0) - the passes were independent
@@ -397,7 +399,7 @@ def test_pass_concurrency_equals_the_single_stream_step():
     try:
         T.TEACHER_SIDE = 0
         st_a = _trainer(1, seed_state)
-        T.TEACHER_SIDE = 3
+        T.TEACHER_SIDE = side_mode
         st_b = _trainer(1, seed_state)
         assert st_b._tps_side and not st_a._tps_side
         rs = np.random.RandomState(5)
@@ -407,7 +409,7 @@ def test_pass_concurrency_equals_the_single_stream_step():
             lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C)).cuda()
             _sync_state(st_b, st_a)
             terms = []
-            for st, mode in ((st_a, 0), (st_b, 3)):
+            for st, mode in ((st_a, 0), (st_b, side_mode)):
                 T.TEACHER_SIDE = mode
                 random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
                 st.step(l, lab, u)

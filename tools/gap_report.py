@@ -25,7 +25,8 @@ for a, b in zip(marks[:-1], marks[1:]):
         if e > cur_end:
             cur_end = e; prev = n
     tot_busy += busy; tot_idle += span - busy
-    print(f"step span {span / 1e6:7.3f} ms  busy {busy / 1e6:7.3f}  idle {(span - busy) / 1e6:6.3f}  kernels {len(seg) - 1}")
+    ksum = sum(e - s for s, e, n in seg[:-1])        # > busy when kernels of two streams ran side by side
+    print(f"step span {span / 1e6:7.3f} ms  busy {busy / 1e6:7.3f}  idle {(span - busy) / 1e6:6.3f}  kernel-time sum {ksum / 1e6:7.3f}  kernels {len(seg) - 1}")
 print(f"mean busy {tot_busy / 1e6 / (len(marks) - 1):.3f} ms  idle {tot_idle / 1e6 / (len(marks) - 1):.3f} ms")
 gaps.sort(reverse=True)
 agg = {}
