@@ -25,8 +25,11 @@ from .model_3D import ISD_3d, FeatureExtractor_3d
 from .train_arco_2d import build_parser as _build_parser_2d
 
 # pass-level concurrency on a second stream (see train_arco_2d.TEACHER_SIDE): 1 = the teacher's grouped pass beside the student
-# forward, 2 (default) = + the gradient-free warped student pass beside the heads / InfoNCE / backward.  ARCO_TEACHER_SIDE=0: off.
-PASS_SIDE = min(2, int(os.environ.get("ARCO_TEACHER_SIDE", "3")))
+# forward, 2 = + the gradient-free warped student pass beside the heads / InfoNCE / backward.  ARCO_TEACHER_SIDE=0: off.
+# 3 (default; tools/step_timeline3d.py) = + the teacher's FeatureExtractor on the side stream behind its pass (beside the masks and the
+# student's FeatureExtractor), and the warped pass no longer queued behind the main stream's heads / row lists / loss forwards: it
+# starts as soon as the host has drawn the warp - beside that low-occupancy stretch instead of beside the backward pass.
+PASS_SIDE = min(3, int(os.environ.get("ARCO_TEACHER_SIDE", "4")))
 FEA_DIM_3D = [128, 64, 32, 16, 16]
 REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
 
@@ -198,6 +201,7 @@ class ArcoStep3D:
         u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data_3d(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
         self.k_fe_ema.update(0.99)                                      # :279-281
         batched = self.batched_passes and l_data.shape == u_aug.shape
+        lazy_t_side = None
         if batched:     # labelled + unlabelled volumes as one pass with two BatchNorm groups (see train_arco_2d.py)
             lu = torch.cat((l_data, u_aug))
             nb_l = int(l_data.shape[0])
@@ -207,13 +211,20 @@ class ArcoStep3D:
                     self._side = torch.cuda.Stream()
                 t_side = self._side
                 t_side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(t_side), torch.no_grad(), ops.bn_groups(2):
-                    pred_t, _, fm_t = self.t_fwd_lu(lu)                  # :286-287
+                with torch.cuda.stream(t_side), torch.no_grad():
+                    with ops.bn_groups(2):
+                        pred_t, _, fm_t = self.t_fwd_lu(lu)              # :286-287
+                    t_done = t_side.record_event()
+                    if PASS_SIDE >= 3 and not getattr(a, "dense_head", 0):   # :292-293 (the teacher's heads: joined before the row lists)
+                        kfe = self.k_feature_extractor
+                        lazy_t_side = head.LazyTeacher3D(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
             with ops.bn_groups(2):
                 pred_all, _, fm_s = self.s_train_lu(lu)                  # :283-284
             if t_side is not None:
-                torch.cuda.current_stream().wait_stream(t_side)
+                torch.cuda.current_stream().wait_event(t_done)
             pred_l, pred_u = ops.split_batch(pred_all, nb_l)
+            if PASS_SIDE >= 3:     # the warped pass's inputs (volumes, mixed labels, the grouped pass's logits) exist from here on
+                self._fwd_ready = torch.cuda.current_stream().record_event()
         else:
             with ops.bn_defer(0):                                        # running statistics: l first (:283), then u
                 pred_u, _, u_fm = self.s_train_u(u_aug)                  # :284
@@ -247,6 +258,8 @@ class ArcoStep3D:
         with torch.no_grad():                                            # :292-293
             if dense:
                 rep_all_teacher, lazy_t = kfe(fm_t), None
+            elif lazy_t_side is not None:
+                rep_all_teacher, lazy_t = None, lazy_t_side
             else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys per class
                 rep_all_teacher, lazy_t = None, head.LazyTeacher3D(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
         fm_s = adist.mark_heads_done(fm_s, self.optimizer, self.heads_start)     # data parallel: heads' gradient bucket reduced early
@@ -254,6 +267,8 @@ class ArcoStep3D:
             rep_all = self.q_rep(qfe(fm_s))                              # :289-296,301
         else:
             x2p, f3, f4 = qfe.forward_lowres2(fm_s)
+        if lazy_t_side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)          # the teacher's FeatureExtractor (side stream)
         C_.contrast_lists_protos(plan, rep_all_teacher, lazy_t)         # row lists, prototypes: device-side inputs only
         # the loss forwards need neither counters nor samples: queued before the host blocks (see train_arco_2d.py)
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
@@ -261,8 +276,13 @@ class ArcoStep3D:
         # counters -> [sample-independent GPU work] -> sampler replay on the host -> anchors (see train_arco_2d.py)
         C_.contrast_counts(plan, self.memobank, self.queue_size,
                            adist.anchors_for_rank(a.num_queries, getattr(a, "anchors_per_rank", "split")), a.num_negatives)
-        C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size, lazy_teacher=lazy_t,
-                            defer_anchor_pix=True)
+        tps_early = (PASS_SIDE >= 3 and batched and getattr(a, "eqv_pass", 1) and self.iter_num > 0 and self.s_fwd_tps.enabled)
+
+        def enqueue():                     # teacher key rows -> banks (no generator draws, no use of the sampled indices)
+            C_.contrast_enqueue(plan, rep_all_teacher, self.memobank, self.queue_ptrlis, self.queue_size, lazy_teacher=lazy_t,
+                                defer_anchor_pix=True)
+        if not tps_early:
+            enqueue()
         C_.contrast_draw(plan, a.func, defer=True)     # indices collected by contrast_anchor_pix below
         loss_eqv = None
         if getattr(a, "eqv_pass", 1):
@@ -272,28 +292,42 @@ class ArcoStep3D:
                 self.tps = RandTPS3D(a.patch_size[0], a.patch_size[1], a.patch_size[2], batch_size=nb2, sigma=a.tps_sigma,
                                      border_padding=False, random_mirror=True, random_scale=(0.8, 1.2), mode='affine',
                                      device=l_data.device)
-            with torch.no_grad():
-                eq_mask = glue.eqv_mask(torch.cat((l_label, u_aug_label)),
-                                        torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits)), a.weak_threshold)
-                self.tps.reset_control_points()                          # :377
-                images_tps = self.tps(torch.cat((l_data, u_aug)))
-                mask_tps = self.tps(eq_mask, padding_mode='zeros')
-                pred_tps_org = self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros')
-            if PASS_SIDE >= 2 and self.iter_num > 0 and self.s_fwd_tps.enabled:
+
+            def warp_inputs():
+                with torch.no_grad():
+                    eq_mask = glue.eqv_mask(torch.cat((l_label, u_aug_label)),
+                                            torch.cat((u_aug_logits.new_ones(l_label.shape), u_aug_logits)), a.weak_threshold)
+                    self.tps.reset_control_points()                      # :377
+                    return (self.tps(torch.cat((l_data, u_aug))), self.tps(eq_mask, padding_mode='zeros'),
+                            self.tps(torch.cat((pred_l.detach(), pred_u.detach())), padding_mode='zeros'))
+            side_ok = PASS_SIDE >= 2 and self.iter_num > 0 and self.s_fwd_tps.enabled
+            if side_ok and self._side is None:
+                self._side = torch.cuda.Stream()
+            if tps_early:
                 # after iteration 0 the warped pass is a logged value and a running-statistics update (:390-393): nothing of this
-                # step waits for it - it runs on the second stream beside the heads, the InfoNCE and the whole backward pass, and
-                # is joined before the optimiser touches the weights
-                if self._side is None:
-                    self._side = torch.cuda.Stream()
-                self._side.wait_stream(torch.cuda.current_stream())
+                # step waits for it.  Warps, pass and loss run on the second stream from the moment the host has drawn the warp -
+                # beside the heads' forwards, row lists and loss forwards of the main stream (a stretch of small launches), the
+                # InfoNCE and the start of the backward pass - behind the grouped pass (running statistics: l, u, then this pass),
+                # and are joined before the optimiser touches the weights.
+                self._side.wait_event(self._fwd_ready)
                 with torch.cuda.stream(self._side), torch.no_grad(), ops.logits_only():
+                    images_tps, mask_tps, pred_tps_org = warp_inputs()
                     pred_tps = self.s_fwd_tps(images_tps)[0]
                     loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
                 self._tps_pending = True
+                enqueue()
             else:
-                with torch.set_grad_enabled(self.iter_num == 0), ops.logits_only():   # only iteration 0 back-propagates it (:390-393)
-                    pred_tps = (self.model if self.iter_num == 0 else self.s_fwd_tps)(images_tps)[0]                 # :380
-                    loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
+                images_tps, mask_tps, pred_tps_org = warp_inputs()
+                if side_ok:    # (PASS_SIDE 2: behind everything queued on the main stream so far, beside InfoNCE and backward)
+                    self._side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._side), torch.no_grad(), ops.logits_only():
+                        pred_tps = self.s_fwd_tps(images_tps)[0]
+                        loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
+                    self._tps_pending = True
+                else:
+                    with torch.set_grad_enabled(self.iter_num == 0), ops.logits_only():   # only iteration 0 back-propagates it (:390-393)
+                        pred_tps = (self.model if self.iter_num == 0 else self.s_fwd_tps)(images_tps)[0]                 # :380
+                        loss_eqv = glue.eqv_loss(pred_tps, pred_tps_org, mask_tps)
         C_.contrast_anchor_pix(plan)
         zero_path = plan.valid_seg <= 1 or not plan.entries
         if zero_path:

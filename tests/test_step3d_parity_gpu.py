@@ -216,14 +216,16 @@ def test_three_steps_3d_vs_cpu_oracle(variant):
     print(f"worst parameter-update deviation so far: L2 {_STATS['e2']:.3f} (bound 0.1), element-wise {_STATS['emax']:.3f} (bound 0.3)")
 
 
-def test_pass_concurrency_3d_equals_the_single_stream_step():
-    """The 3-D step with the teacher's grouped pass and the gradient-free warped pass on the second stream (train_arco_3d.PASS_SIDE = 2,
+@pytest.mark.parametrize("side_mode", [2, 3])
+def test_pass_concurrency_3d_equals_the_single_stream_step(side_mode):
+    """(side_mode 3: the teacher's FeatureExtractor behind its pass on the second stream, the warped pass started as soon as the host
+    has drawn the warp instead of behind the main stream's queue, bank appends queued after it.)  The 3-D step with the teacher's grouped pass and the gradient-free warped pass on the second stream (train_arco_3d.PASS_SIDE = 2,
     the default) against the single-stream step (0), four steps from equal state: loss terms, weights, BatchNorm buffers."""
     from arco_amd import ops, train_arco_3d as T3
     prev = T3.PASS_SIDE
     try:
         sts = []
-        for mode in (0, 2):
+        for mode in (0, side_mode):
             T3.PASS_SIDE = mode
             random.seed(3); np.random.seed(3); torch.manual_seed(3)
             args = T3.build_parser().parse_args(["--batch_size", "1", "--queue_size", "200", "--synthetic", "1", "--num_classes", "4",

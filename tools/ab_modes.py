@@ -6,13 +6,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from arco_amd import train_arco_2d as T
 modes = [int(x) for x in sys.argv[1:] if x.lstrip("-").isdigit()] or [3, 4]
-reps, block = 8, 100
+city = "--city" in sys.argv          # the Cityscapes-shaped shard (BASELINE.json configs[3]): 2 images 3x512x1024, 19 classes
+reps, block = (6, 20) if city else (8, 100)
 sts = {}
 for m in modes:
     T.TEACHER_SIDE = m
-    args = T.build_parser().parse_args(["--batch_size", "8", "--queue_size", "4096", "--func", "smc", "--synthetic", "1"])
+    if city:
+        args = T.build_parser().parse_args(["--batch_size", "1", "--queue_size", "4096", "--synthetic", "1", "--num_classes", "19", "--in_chns", "3"])
+        args.patch_size = [512, 1024]
+    else:
+        args = T.build_parser().parse_args(["--batch_size", "8", "--queue_size", "4096", "--func", "smc", "--synthetic", "1"])
     sts[m] = T.ArcoStep2D(args, "cuda:0")
-bs = [(T.synthetic_batch(8, args.patch_size, 4, 100 + 2 * i, "cuda:0"), T.synthetic_batch(8, args.patch_size, 4, 101 + 2 * i, "cuda:0")[0]) for i in range(4)]
+if city:
+    bs = [(T.synthetic_batch(1, args.patch_size, 19, 1 + 2 * i, "cuda:0", in_chns=3), T.synthetic_batch(1, args.patch_size, 19, 2 + 2 * i, "cuda:0", in_chns=3)[0]) for i in range(4)]
+else:
+    bs = [(T.synthetic_batch(8, args.patch_size, 4, 100 + 2 * i, "cuda:0"), T.synthetic_batch(8, args.patch_size, 4, 101 + 2 * i, "cuda:0")[0]) for i in range(4)]
 def run(m, n):
     T.TEACHER_SIDE = m
     st = sts[m]
@@ -20,7 +28,7 @@ def run(m, n):
         (l, ll), u = bs[i % 4]
         st.step(l, ll, u, 0, 100)
 for m in modes:
-    run(m, 60)
+    run(m, 12 if city else 60)
 res = {m: [] for m in modes}
 for r in range(reps):
     for m in (modes if r % 2 == 0 else modes[::-1]):
