@@ -22,6 +22,8 @@ _SIGS = {
     "arco_lv_weights": [_P, _L, _I, _I, _P, _P],
     "arco_weighted_row_sum": [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _L, _P],
     "arco_gather_rows": [_P, _L, _I, _P, _P, _P, _L, _L, _P, _L, _P],
+    "arco_weighted_row_sum_h": [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _L, _P],
+    "arco_gather_rows_h": [_P, _L, _I, _P, _P, _P, _L, _L, _P, _L, _P],
     "arco_bank_append": [_P, _L, _P, _L, _L, _I, _P, _P],
     "arco_normalize_rows": [_P, _L, _L, _I, _F, _P, _L, _P, _L, _P, _P],
     "arco_neg_multiplicity": [_P, _I, _I, _L, _L, _P, _P],
@@ -96,6 +98,9 @@ _SIGS = {
     "arco_gather_upcat_rows3d": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "arco_scatter_upcat_rows3d": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P],
     "arco_zero_rows": [_P, _L, _I, _P, _L, _P],
+    "arco_gather_upcat_rows3d_h": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    "arco_cast_rows_f2h": [_P, _L, _I, _P, _L, _F, _P, _L, _P],
+    "arco_zero_rows_h": [_P, _L, _I, _P, _L, _P],
     "arco_fold_residual": [_P, _I, _I, _P, _P, _P],
     "arco_unfold_residual": [_P, _P, _I, _I, _P, _P],
     "arco_combine_terms": [_P, _P, _I, _P, _P],

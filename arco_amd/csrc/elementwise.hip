@@ -859,8 +859,9 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restr
 
 // ---- 3-D anchor-row gather of cat(trilinear_up(lo), hi) and its adjoint (row-sparse head of FeatureExtractor_3d,
 // model_3D.py:52-55).  Same fp32 index math / lerp order as trilinear_fwd_kernel -> rows bit-identical to the dense path.
+template <typename TH>
 __global__ __launch_bounds__(256) void gather_upcat_rows3d_kernel(const float* __restrict__ lo, long ldlo, int Clo, int Di, int Hi, int Wi,
-                                                                 const float* __restrict__ hi, long ldhi, int Chi, int Do, int Ho, int Wo,
+                                                                 const TH* __restrict__ hi, long ldhi, int Chi, int Do, int Ho, int Wo,
                                                                  const int64_t* __restrict__ pix, long n, float* __restrict__ X, long ldx) {
   const int lane = threadIdx.x & 63;
   const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -893,8 +894,8 @@ __global__ __launch_bounds__(256) void gather_upcat_rows3d_kernel(const float* _
              lz * (hy * (hx * v100[e] + lx * v101[e]) + ly * (hx * v110[e] + lx * v111[e]));
     *reinterpret_cast<f32x4*>(o + c) = r;
   }
-  const float* h = hi + p * ldhi;
-  for (int c = lane * 4; c < Chi; c += 256) *reinterpret_cast<f32x4*>(o + Clo + c) = *reinterpret_cast<const f32x4*>(h + c);
+  const TH* h = hi + p * ldhi;
+  for (int c = lane * 4; c < Chi; c += 256) *reinterpret_cast<f32x4*>(o + Clo + c) = ld4f(h + c);
 }
 __global__ __launch_bounds__(256) void scatter_upcat_rows3d_kernel(const float* __restrict__ dX, long ldx, const int64_t* __restrict__ pix, long n,
                                                                   float* __restrict__ dlo, long ldlo, int Clo, int Di, int Hi, int Wi,
@@ -1002,11 +1003,26 @@ static inline int ew_grid(long work) {
 // ---- small glue kernels that replace chains of ATen launches in the step (profiles/r02_h: ~0.6 ms of fills / copies / adds)
 // rows idx[0..n) of a [rows, ld] tensor set to zero over C channels: re-arms a persistent, zero-by-invariant gradient
 // buffer after a sparse scatter (the row-sparse head's feature-map gradients) instead of a dense fill per step
-__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ dst, long ld, int C, const int64_t* __restrict__ idx, long n) {
+template <typename T>
+__global__ __launch_bounds__(256) void zero_rows_kernel(T* __restrict__ dst, long ld, int C, const int64_t* __restrict__ idx, long n) {
   const int q4 = C >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * q4; i += (long)gridDim.x * 256) {
     const long r = i / q4; const int c = (int)(i - r * q4) * 4;
-    *reinterpret_cast<f32x4*>(dst + idx[r] * ld + c) = f32x4{0, 0, 0, 0};
+    st4f(dst + idx[r] * ld + c, f32x4{0, 0, 0, 0});
+  }
+}
+// rows idx[0..n) of an fp32 [rows, ld] gradient buffer -> the same rows of an f16 buffer, multiplied by the loss scale and saturated
+// at the largest finite f16 (see cast_f2h_kernel): the row-sparse head's feature-map gradients enter the f16 region without a dense
+// cast of the whole map.  Duplicate indices write the same value twice.
+__global__ __launch_bounds__(256) void cast_rows_f2h_kernel(const float* __restrict__ src, long lds_, int C, const int64_t* __restrict__ idx,
+                                                           long n, float scale, _Float16* __restrict__ dst, long ldd) {
+  const int q4 = C >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * q4; i += (long)gridDim.x * 256) {
+    const long r = i / q4; const int c = (int)(i - r * q4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + idx[r] * lds_ + c) * scale;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 65504.f ? 65504.f : (v[j] < -65504.f ? -65504.f : v[j]);
+    st4f(dst + idx[r] * ldd + c, v);
   }
 }
 // W' = W + I of a square [n, n] 1x1-conv weight, written as its two column blocks lo [n, c] and hi [n, n - c] (the
@@ -1388,8 +1404,17 @@ int arco_gather_upcat_rows3d(const float* lo, long ldlo, int Clo, int Di, int Hi
                              int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream) {
   ARCO_CHECK_ARG((Clo & 3) == 0 && (Chi & 3) == 0 && (ldlo & 3) == 0 && (ldhi & 3) == 0 && (ldx & 3) == 0);
   if (n == 0) return ARCO_OK;
-  hipLaunchKernelGGL(gather_upcat_rows3d_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), lo, ldlo, Clo, Di, Hi, Wi,
+  hipLaunchKernelGGL(gather_upcat_rows3d_kernel<float>, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), lo, ldlo, Clo, Di, Hi, Wi,
                      hi, ldhi, Chi, Do, Ho, Wo, pix, n, X, ldx);
+  return arco_launch_status();
+}
+// ... with the full-resolution map `hi` stored as f16 (f16 activation storage); lo, X fp32
+int arco_gather_upcat_rows3d_h(const float* lo, long ldlo, int Clo, int Di, int Hi, int Wi, const void* hi, long ldhi, int Chi,
+                               int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream) {
+  ARCO_CHECK_ARG((Clo & 3) == 0 && (Chi & 3) == 0 && (ldlo & 3) == 0 && (ldhi & 3) == 0 && (ldx & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(gather_upcat_rows3d_kernel<_Float16>, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), lo, ldlo, Clo, Di, Hi, Wi,
+                     reinterpret_cast<const _Float16*>(hi), ldhi, Chi, Do, Ho, Wo, pix, n, X, ldx);
   return arco_launch_status();
 }
 int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo, int Di,
@@ -1403,7 +1428,20 @@ int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, lon
 int arco_zero_rows(float* dst, long ld, int C, const int64_t* idx, long n, void* stream) {
   ARCO_CHECK_ARG(dst && idx && (C & 3) == 0 && (ld & 3) == 0);
   if (n == 0) return ARCO_OK;
-  hipLaunchKernelGGL(zero_rows_kernel, dim3(ew_grid(n * (C / 4))), dim3(256), 0, as_stream(stream), dst, ld, C, idx, n);
+  hipLaunchKernelGGL(zero_rows_kernel<float>, dim3(ew_grid(n * (C / 4))), dim3(256), 0, as_stream(stream), dst, ld, C, idx, n);
+  return arco_launch_status();
+}
+int arco_zero_rows_h(void* dst, long ld, int C, const int64_t* idx, long n, void* stream) {
+  ARCO_CHECK_ARG(dst && idx && (C & 3) == 0 && (ld & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(zero_rows_kernel<_Float16>, dim3(ew_grid(n * (C / 4))), dim3(256), 0, as_stream(stream), reinterpret_cast<_Float16*>(dst), ld, C, idx, n);
+  return arco_launch_status();
+}
+int arco_cast_rows_f2h(const float* src, long ld_src, int C, const int64_t* idx, long n, float scale, void* dst, long ld_dst, void* stream) {
+  ARCO_CHECK_ARG(src && dst && idx && (C & 3) == 0 && (ld_src & 3) == 0 && (ld_dst & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(cast_rows_f2h_kernel, dim3(ew_grid(n * (C / 4))), dim3(256), 0, as_stream(stream), src, ld_src, C, idx, n, scale,
+                     reinterpret_cast<_Float16*>(dst), ld_dst);
   return arco_launch_status();
 }
 int arco_fold_residual(const float* W, int n, int c, float* lo, float* hi, void* stream) {

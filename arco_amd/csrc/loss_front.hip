@@ -199,8 +199,8 @@ __global__ void lv_weights_kernel(const uint64_t* __restrict__ codes, long n_pix
 }
 
 // weighted row sums: out[c][:] = sum_rows Wt[row][c0+c] * T[row][:]   (same tiling as masked_row_sum)
-template <int NDI>
-__global__ __launch_bounds__(256) void weighted_row_sum_kernel(const float* __restrict__ T, long ldt,
+template <int NDI, typename TS>
+__global__ __launch_bounds__(256) void weighted_row_sum_kernel(const TS* __restrict__ T, long ldt,
                                                               const float* __restrict__ Wt, long ldw, long n_rows, int D,
                                                               int c0, int nc, int lpr, long rows_per_block,
                                                               float* __restrict__ partial /*[grid][nc][D]*/) {
@@ -219,12 +219,12 @@ __global__ __launch_bounds__(256) void weighted_row_sum_kernel(const float* __re
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) { w[cc] = (row < r1 && cc < nc) ? Wt[row * ldw + c0 + cc] : 0.f; any |= (w[cc] != 0.f); }
     if (any) {
-      const float* src = T + row * ldt;
+      const TS* src = T + row * ldt;
 #pragma unroll
       for (int di = 0; di < NDI; ++di) {
         const int d = (di * lpr + dl) * 4;
         if (d < D) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src + d);
+          const f32x4 v = ld4f(src + d);
 #pragma unroll
           for (int cc = 0; cc < 8; ++cc) if (w[cc] != 0.f) acc[cc][di] += v * w[cc];
         }
@@ -296,7 +296,8 @@ __global__ void proto_finalize_kernel(const float* __restrict__ partial, int nbl
 }
 
 // (5) row gather: out[j] = src[list ? list[idx[j]] : idx[j]]   (rows of D floats)
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, long lds_, int D,
+template <typename TS>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const TS* __restrict__ src, long lds_, int D,
                                                          const int32_t* __restrict__ list,
                                                          const int64_t* __restrict__ idx64,
                                                          const int32_t* __restrict__ idx32, long first, long n,
@@ -306,12 +307,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   if (j >= n) return;
   long r = idx64 ? idx64[first + j] : (idx32 ? (long)idx32[first + j] : first + j);
   if (list) r = list[r];
-  const float* s = src + r * lds_;
+  const TS* s = src + r * lds_;
   float* o = out + j * ldo;
   if ((D & 3) == 0) {
-    for (int d = lane * 4; d < D; d += 256) *reinterpret_cast<f32x4*>(o + d) = *reinterpret_cast<const f32x4*>(s + d);
+    for (int d = lane * 4; d < D; d += 256) *reinterpret_cast<f32x4*>(o + d) = ld4f(s + d);
   } else {
-    for (int d = lane; d < D; d += 64) o[d] = s[d];
+    for (int d = lane; d < D; d += 64) o[d] = (float)s[d];
   }
 }
 
@@ -711,8 +712,10 @@ int arco_lv_weights(const uint64_t* codes, long n_pix, int C, int Cp, float* W, 
 
 // out[c][0..D) = sum_rows Wt[row][c] * T[row][0..D)  (divided by totals[c] when totals != NULL);
 // partial: arco_proto_ws_floats(n_rows, C, D) floats
-int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
-                          const int64_t* totals, float* partial, float* out, long ldo, void* stream) {
+extern "C++" {
+template <typename TS>
+static int weighted_row_sum_impl(const TS* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
+                                 const int64_t* totals, float* partial, float* out, long ldo, void* stream) {
   ARCO_CHECK_ARG(D > 0 && (D & 3) == 0 && D <= 512 && (ldt & 3) == 0 && C <= ARCO_MAXC);
   long grid = (n_rows + 63) / 64;                      // HBM-bound row sweep: >= 4 blocks per CU in flight
   if (grid > 1024) grid = 1024;
@@ -725,24 +728,44 @@ int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, l
     const int nc = (C - c0) < 8 ? (C - c0) : 8;
     const size_t sh = (size_t)4 * 8 * D * sizeof(float);
     if (ndi == 1)
-      hipLaunchKernelGGL(weighted_row_sum_kernel<1>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
+      hipLaunchKernelGGL((weighted_row_sum_kernel<1, TS>), dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
     else if (ndi == 2)
-      hipLaunchKernelGGL(weighted_row_sum_kernel<2>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
+      hipLaunchKernelGGL((weighted_row_sum_kernel<2, TS>), dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
     else
-      hipLaunchKernelGGL(weighted_row_sum_kernel<4>, dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
+      hipLaunchKernelGGL((weighted_row_sum_kernel<4, TS>), dim3(grid), dim3(256), sh, as_stream(stream), T, ldt, Wt, ldw, n_rows, D, c0, nc, lpr, rpb, partial);
     hipLaunchKernelGGL(row_sum_finalize_kernel, dim3((nc * D + 63) / 64), dim3(64, 16), 0, as_stream(stream), partial,
                        (int)grid, nc, D, c0, totals, out, ldo);
   }
   return arco_launch_status();
 }
+template <typename TS>
+static int gather_rows_impl(const TS* src, long ld_src, int D, const int32_t* list, const int64_t* idx64,
+                            const int32_t* idx32, long first, long n, float* out, long ld_out, void* stream) {
+  ARCO_CHECK_ARG(D > 0 && n >= 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(gather_rows_kernel<TS>, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), src, ld_src, D, list,
+                     idx64, idx32, first, n, out, ld_out);
+  return arco_launch_status();
+}
+}  // extern "C++"
+int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
+                          const int64_t* totals, float* partial, float* out, long ldo, void* stream) {
+  return weighted_row_sum_impl<float>(T, ldt, Wt, ldw, n_rows, C, D, totals, partial, out, ldo, stream);
+}
+// ... of an f16 row matrix (f16 activation storage: the full-resolution V-Net feature maps stay f16, sums are fp32)
+int arco_weighted_row_sum_h(const void* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
+                            const int64_t* totals, float* partial, float* out, long ldo, void* stream) {
+  return weighted_row_sum_impl<_Float16>(reinterpret_cast<const _Float16*>(T), ldt, Wt, ldw, n_rows, C, D, totals, partial, out, ldo, stream);
+}
 
 int arco_gather_rows(const float* src, long ld_src, int D, const int32_t* list, const int64_t* idx64,
                      const int32_t* idx32, long first, long n, float* out, long ld_out, void* stream) {
-  ARCO_CHECK_ARG(D > 0 && n >= 0);
-  if (n == 0) return ARCO_OK;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), src, ld_src, D, list,
-                     idx64, idx32, first, n, out, ld_out);
-  return arco_launch_status();
+  return gather_rows_impl<float>(src, ld_src, D, list, idx64, idx32, first, n, out, ld_out, stream);
+}
+// ... from an f16 row matrix into fp32 rows
+int arco_gather_rows_h(const void* src, long ld_src, int D, const int32_t* list, const int64_t* idx64,
+                       const int32_t* idx32, long first, long n, float* out, long ld_out, void* stream) {
+  return gather_rows_impl<_Float16>(reinterpret_cast<const _Float16*>(src), ld_src, D, list, idx64, idx32, first, n, out, ld_out, stream);
 }
 
 int arco_bank_append(const float* old, long len_old, const float* keys, long n, long queue_size, int D, float* out,

@@ -215,6 +215,37 @@ def _row_grad_buffer(ptr, shape, dev):
     return torch.zeros((nb,) + spatial + (c,), dtype=torch.float32, device=dev), (lambda idx, n: None)
 
 
+def _row_grad_buffer_h(ptr, shape, dev):
+    """_row_grad_buffer for a feature map stored as f16 (ops.fm_rows_half): (fp32 scatter target [nb, *spatial, c], done(idx, n) ->
+    the f16 gradient [nb, *spatial, c] carrying ops.LOSS_SCALE).  Graph-replayed producer: the scatter target is a persistent fp32
+    scratch (zero by invariant), done() casts the n touched rows into the producer's f16 gradient-input buffer (ops.grad_sink),
+    re-zeroes them in the scratch and registers their re-zeroing in the f16 buffer for after the backward graph - the rows are summed
+    in fp32 and rounded once, exactly as the dense cast of the dense fp32 gradient did.  Otherwise: a fresh fp32 tensor and a dense cast."""
+    nb, c, spatial = int(shape[0]), int(shape[1]), tuple(int(v) for v in shape[2:])
+    gt, k = ops.grad_sink(ptr, (nb, c) + spatial)
+    if gt is not None:
+        buf = gt.static_grads[k].movedim(1, -1)
+        if buf.is_contiguous() and c % 4 == 0 and buf.dtype == torch.float16:
+            scratch = gt.__dict__.setdefault("_row_scratch", {}).get(k)
+            if scratch is None:
+                scratch = gt._row_scratch[k] = torch.zeros(buf.shape, dtype=torch.float32, device=dev)
+
+            def done(idx, n):
+                L.call("arco_cast_rows_f2h", L.ptr(scratch), c, c, L.ptr(idx), n, float(ops.LOSS_SCALE), L.ptr(buf), c)
+                L.call("arco_zero_rows", L.ptr(scratch), c, c, L.ptr(idx), n)
+                gt.cleanup.append(lambda: L.call("arco_zero_rows_h", L.ptr(buf), c, c, L.ptr(idx), n))
+                return buf
+            return scratch, done
+        gt.sink_busy[k] = False
+    dense = torch.zeros((nb,) + spatial + (c,), dtype=torch.float32, device=dev)
+
+    def done_dense(idx, n):
+        out = torch.empty(dense.shape, dtype=torch.float16, device=dev)
+        L.call("arco_cast_f2h", L.ptr(dense), dense.numel(), float(ops.LOSS_SCALE), L.ptr(out))
+        return out
+    return dense, done_dense
+
+
 class LazyHead3Fn(torch.autograd.Function):
     """Three-level row-sparse head: fea2 (the 64 x 64 level), fea3 and fea4 are all evaluated only where the anchors need
     them - the 4 neighbours at 128 x 128 of every anchor and the 4 neighbours at 64 x 64 of each of those (16 n rows of
@@ -287,7 +318,8 @@ def _class_weights(pl):
 
 def _wsum(rows, ld, wt, ldw, n_rows, C, D, totals, out, ldo):
     ws = torch.empty(L.query("arco_proto_ws_floats", n_rows, C, D), dtype=torch.float32, device=rows.device)
-    L.call("arco_weighted_row_sum", L.ptr(rows), ld, L.ptr(wt), ldw, n_rows, C, D, L.ptr(totals), L.ptr(ws), L.ptr(out), ldo)
+    fn = "arco_weighted_row_sum_h" if rows.dtype == torch.float16 else "arco_weighted_row_sum"      # (f16 activation storage)
+    L.call(fn, L.ptr(rows), ld, L.ptr(wt), ldw, n_rows, C, D, L.ptr(totals), L.ptr(ws), L.ptr(out), ldo)
 
 
 class LazyTeacher2D:
@@ -337,12 +369,13 @@ def _rows3d_forward(x2p, f3, f4, w3, w4, pix):
     n = int(pix.shape[0])
     k3 = c2 + c3
     X3 = torch.empty((n, k3), dtype=torch.float32, device=pix.device)
-    L.call("arco_gather_upcat_rows3d", L.ptr(lo), ldlo, c2, d2, h2, w2_, L.ptr(r3), ld3, c3, d3, h3, w3_, L.ptr(pix), n,
-           L.ptr(X3), k3)
+    L.call("arco_gather_upcat_rows3d_h" if r3.dtype == torch.float16 else "arco_gather_upcat_rows3d",
+           L.ptr(lo), ldlo, c2, d2, h2, w2_, L.ptr(r3), ld3, c3, d3, h3, w3_, L.ptr(pix), n, L.ptr(X3), k3)
     y3, _ = ops.conv_raw(X3, k3, k3, ops.pack_weight(w3, 1, 0), k3, 1, 1, n, 1, residual=X3, ld_res=k3)
     X4 = torch.empty((n, k3 + c4), dtype=torch.float32, device=pix.device)
     X4[:, :k3] = y3.permute(0, 2, 3, 1).reshape(n, k3)
-    L.call("arco_gather_rows", L.ptr(r4), ld4, c4, None, L.ptr(pix), None, 0, n, L.ptr(X4[:, k3:]), k3 + c4)
+    L.call("arco_gather_rows_h" if r4.dtype == torch.float16 else "arco_gather_rows",
+           L.ptr(r4), ld4, c4, None, L.ptr(pix), None, 0, n, L.ptr(X4[:, k3:]), k3 + c4)
     return X3, X4, _gemm(X4, w4)
 
 
@@ -359,6 +392,7 @@ class LazyHead3dFn(torch.autograd.Function):
         ctx.save_for_backward(X3, X4, h0, h1, w3, w4, w1, w2, pix)
         ctx.shapes = (tuple(x2p.shape), tuple(f3.shape), tuple(f4.shape))
         ctx.fptrs = (f3.data_ptr(), f4.data_ptr())
+        ctx.fhalf = (f3.dtype == torch.float16, f4.dtype == torch.float16)      # ops.fm_rows_half: maps consumed as stored
         return a
 
     @staticmethod
@@ -376,18 +410,22 @@ class LazyHead3dFn(torch.autograd.Function):
         dw4 = _wgrad(dh0, X4, w4)
         dX4 = _gemm_t(dh0, w4)
         dX3p = dX4[:, :k3].contiguous()
-        df4, fin4 = _row_grad_buffer(ctx.fptrs[1], s4, dev)
+        df4, fin4 = (_row_grad_buffer_h if ctx.fhalf[1] else _row_grad_buffer)(ctx.fptrs[1], s4, dev)
         L.call("arco_scatter_add_rows", L.ptr(dX4[:, k3:]), k3 + c4, c4, None, L.ptr(pix), n, None, 1.0, L.ptr(df4), c4)
-        fin4(pix, n)
+        r = fin4(pix, n)
+        if ctx.fhalf[1]:
+            df4 = r
         dw3 = _wgrad(dX3p, X3, w3)
         y, _ = ops.conv_raw(dX3p, k3, k3, ops.pack_weight(w3, 1, 1), k3, 1, 1, n, 1, residual=dX3p, ld_res=k3)
         dX3 = y.permute(0, 2, 3, 1).reshape(n, k3)
         c2, c3 = int(s2[1]), int(s3[1])
         dx2p = torch.zeros((s2[0], *s2[2:], c2), dtype=torch.float32, device=dev)
-        df3, fin3 = _row_grad_buffer(ctx.fptrs[0], s3, dev)
+        df3, fin3 = (_row_grad_buffer_h if ctx.fhalf[0] else _row_grad_buffer)(ctx.fptrs[0], s3, dev)
         L.call("arco_scatter_upcat_rows3d", L.ptr(dX3), k3, L.ptr(pix), n, L.ptr(dx2p), c2, c2, s2[2], s2[3], s2[4],
                L.ptr(df3), c3, c3, s3[2], s3[3], s3[4])
-        fin3(pix, n)
+        r = fin3(pix, n)
+        if ctx.fhalf[0]:
+            df3 = r
         return (dx2p.movedim(-1, 1), df3.movedim(-1, 1), df4.movedim(-1, 1), dw3, dw4, dw1, dw2, None)
 
 

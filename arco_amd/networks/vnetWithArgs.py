@@ -221,6 +221,8 @@ class VNet(nn.Module):
         out = ops.conv(x9, self.out_conv.weight, self.out_conv.bias)
         # f16 activation storage (ops.ACT_HALF): the logits and the feature maps leave the f16 region as fp32 - heads, losses
         # and samplers are fp32; gradients come back through the same boundary with the loss scale
+        if ops.FM_CAST == 'lowres':      # ops.fm_rows_half: the two full-resolution maps stay f16 for the row-sparse heads
+            return ops.from_half(out), [ops.from_half(f) for f in feature_map[:-2]] + feature_map[-2:]
         return ops.from_half(out), ([ops.from_half(f) for f in feature_map] if ops.FM_CAST else feature_map)
 
     def forward(self, input, turnoff_drop=False):

@@ -1224,7 +1224,7 @@ def from_half(x):
     return _FromHalfFn.apply(x) if _is_half(x) else x
 
 
-FM_CAST = True        # see logits_only()
+FM_CAST = True        # True | False (logits_only) | 'lowres' (fm_rows_half)
 
 
 class logits_only:
@@ -1238,6 +1238,17 @@ class logits_only:
     def __exit__(self, *exc):
         global FM_CAST
         FM_CAST = self.prev
+
+
+class fm_rows_half(logits_only):
+    """`with ops.fm_rows_half():` - a V-Net forward inside (f16 mode) casts its three LOW-resolution feature maps to fp32 and hands
+    the two full-resolution ones out as stored (f16): the row-sparse heads (arco_amd.head.lazy_head3d, LazyTeacher3D) read rows /
+    weighted row sums of those two straight from the f16 maps and return a row-sparse f16 gradient - no dense cast of a
+    full-resolution map in either direction (they were 0.64 ms of the LiTS-shaped step)."""
+
+    def __enter__(self):
+        global FM_CAST
+        self.prev, FM_CAST = FM_CAST, 'lowres'
 
 
 def space_to_depth3(x):

@@ -263,6 +263,19 @@ class ArcoStep2D:
         x = ops.conv(x, self.q_representation[0].weight)
         return ops.conv(x, self.q_representation[1].weight)
 
+    def _teacher_heads(self, fm_t, dense):
+        """(dense teacher representation or None, lazy teacher or None): the teacher's FeatureExtractor (:321-322) in the form the
+        loss front end consumes - rows are only needed as class means (prototypes) and <= queue_size keys per class."""
+        a, kfe = self.args, self.k_feature_extractor
+        if getattr(a, "dense_teacher", 0) or dense:
+            return kfe(fm_t), None
+        if getattr(a, "head_levels", 3) == 1:
+            x3p_t, f4_t = kfe.forward_lowres(fm_t)
+            return None, head.LazyTeacher2D(x3p_t, f4_t, kfe.fea4.weight)
+        if getattr(a, "teacher_levels", 2) == 3:
+            return None, head.LazyTeacher2DL3(*kfe.forward_lowres1(fm_t), kfe.fea2.weight, kfe.fea3.weight, kfe.fea4.weight)
+        return None, head.LazyTeacher2DL2(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
+
     def step(self, l_data, l_label, u_data, epoch_num=0, max_epoch=1):
         """One iteration.  The mixing strategy of --apply_aug (augment.generate_unsup_data) and batch_transform (8-bit PIL
         round trip, ColorJitter, GaussianBlur, AdvMorph: augment.batch_transform) run on the GPU with the reference's host draws.
@@ -383,19 +396,7 @@ class ArcoStep2D:
             # FeatureExtractor is per-image -> run it once on the batch-concatenated maps (:321-322)
             if not batched:
                 fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
-            if getattr(a, "dense_teacher", 0) or dense:
-                rep_all_teacher, lazy_t = self.k_feature_extractor(fm_t), None
-            elif getattr(a, "head_levels", 3) == 1:
-                x3p_t, f4_t = self.k_feature_extractor.forward_lowres(fm_t)
-                rep_all_teacher, lazy_t = None, head.LazyTeacher2D(x3p_t, f4_t, self.k_feature_extractor.fea4.weight)
-            elif getattr(a, "teacher_levels", 2) == 3:
-                kfe = self.k_feature_extractor
-                rep_all_teacher = None
-                lazy_t = head.LazyTeacher2DL3(*kfe.forward_lowres1(fm_t), kfe.fea2.weight, kfe.fea3.weight, kfe.fea4.weight)
-            else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys/class
-                kfe = self.k_feature_extractor
-                rep_all_teacher = None
-                lazy_t = head.LazyTeacher2DL2(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
+            rep_all_teacher, lazy_t = self._teacher_heads(fm_t, dense)
         if not batched:
             fm_all = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]     # :317-318
         # data parallel: the heads' gradient bucket is all-reduced as soon as the heads' backward is done, under the U-Net's

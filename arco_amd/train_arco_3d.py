@@ -8,6 +8,7 @@ mixing strategy of --apply_aug, the equivariance block (--eqv_pass), the opt-in 
 SGD-Nesterov, EMA.  batch_transform is the identity in the reference's 3-D pipeline (augment_3d.py:133-159).
 --synthetic 0 trains from an LA dataset directory (build_loaders); --conv_mma selects reduced-precision MFMA operands.
 """
+import contextlib
 import logging
 import os
 import random
@@ -30,6 +31,8 @@ from .train_arco_2d import build_parser as _build_parser_2d
 # student's FeatureExtractor), and the warped pass no longer queued behind the main stream's heads / row lists / loss forwards: it
 # starts as soon as the host has drawn the warp - beside that low-occupancy stretch instead of beside the backward pass.
 PASS_SIDE = min(3, int(os.environ.get("ARCO_TEACHER_SIDE", "4")))
+LISTS_SIDE = int(os.environ.get("ARCO_LISTS_SIDE", "1"))
+FM_ROWS_HALF = int(os.environ.get("ARCO_FM_ROWS_HALF", "1"))     # --act_dtype f16: heads read the full-resolution maps as f16 (ops.fm_rows_half)
 FEA_DIM_3D = [128, 64, 32, 16, 16]
 REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
 
@@ -192,6 +195,10 @@ class ArcoStep3D:
         for pl in self.plans:                                            # stale only if someone else touched weights
             if not pl.valid:
                 pl.refresh()
+        # f16 activation storage with the row-sparse heads: the two full-resolution feature maps are consumed as stored (f16 rows,
+        # f16 row-sparse gradients) - no dense cast of a full-resolution map in either direction (ops.fm_rows_half)
+        rows_half = ops.ACT_HALF and FM_ROWS_HALF and not getattr(a, "dense_head", 0) and self.random_pool is None
+        fm_ctx = ops.fm_rows_half if rows_half else contextlib.nullcontext
         with torch.no_grad(), ops.logits_only():                         # :260-262
             pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
@@ -212,13 +219,13 @@ class ArcoStep3D:
                 t_side = self._side
                 t_side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(t_side), torch.no_grad():
-                    with ops.bn_groups(2):
+                    with ops.bn_groups(2), fm_ctx():
                         pred_t, _, fm_t = self.t_fwd_lu(lu)              # :286-287
                     t_done = t_side.record_event()
                     if PASS_SIDE >= 3 and not getattr(a, "dense_head", 0):   # :292-293 (the teacher's heads: joined before the row lists)
                         kfe = self.k_feature_extractor
                         lazy_t_side = head.LazyTeacher3D(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
-            with ops.bn_groups(2):
+            with ops.bn_groups(2), fm_ctx():
                 pred_all, _, fm_s = self.s_train_lu(lu)                  # :283-284
             if t_side is not None:
                 torch.cuda.current_stream().wait_event(t_done)
@@ -226,17 +233,18 @@ class ArcoStep3D:
             if PASS_SIDE >= 3:     # the warped pass's inputs (volumes, mixed labels, the grouped pass's logits) exist from here on
                 self._fwd_ready = torch.cuda.current_stream().record_event()
         else:
-            with ops.bn_defer(0):                                        # running statistics: l first (:283), then u
+            with ops.bn_defer(0), fm_ctx():                              # running statistics: l first (:283), then u
                 pred_u, _, u_fm = self.s_train_u(u_aug)                  # :284
         with torch.no_grad():
             if batched:
                 if PASS_SIDE < 1:
-                    with ops.bn_groups(2):
+                    with ops.bn_groups(2), fm_ctx():
                         pred_t, _, fm_t = self.t_fwd_lu(lu)              # :286-287
                 pred_l_t, pred_u_t = pred_t[:nb_l], pred_t[nb_l:]
             else:
-                pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)               # :286
-                pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)                # :287
+                with fm_ctx():
+                    pred_l_t, _, l_fm_t = self.t_fwd_l(l_data)           # :286
+                    pred_u_t, _, u_fm_t = self.t_fwd_u(u_aug)            # :287
             alpha_t = 20 * (1 - epoch_num / max_epoch)
             label_l = glue.label_onehot(l_label, C)
             label_u = glue.label_onehot(u_aug_label, C)
@@ -245,12 +253,21 @@ class ArcoStep3D:
             low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
         plan = C_.contrast_masks(label_l, label_u, prob_l_t, prob_u_t, low_mask_all, high_mask_all,
                                  delta_n=a.strong_threshold_u2pl)
+        lists_done = None
+        if lazy_t_side is not None and LISTS_SIDE:
+            # row lists and prototypes need the masks and the TEACHER's heads only: on the side stream (behind those heads), beside
+            # the student's FeatureExtractor on this one, instead of in line behind it
+            self._side.wait_event(torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(self._side):
+                C_.contrast_lists_protos(plan, None, lazy_t_side)
+                lists_done = self._side.record_event()
         if self.keep_debug:      # tests: the step's gradient-free decision inputs (tests/test_step3d_parity_gpu.py)
             self.decisions = dict(pseudo_labels=dbg_pseudo[0], pseudo_logits=dbg_pseudo[1], low=low_mask_all, high=high_mask_all,
                                   prob_l_t=prob_l_t, prob_u_t=prob_u_t)
         dense = getattr(a, "dense_head", 0)
         if not batched:
-            pred_l, _, l_fm = self.s_train_l(l_data)                     # :283
+            with fm_ctx():
+                pred_l, _, l_fm = self.s_train_l(l_data)                 # :283
             ops.apply_deferred_bn()
             fm_t = [torch.cat((x, y)) for x, y in zip(l_fm_t, u_fm_t)]
             fm_s = [torch.cat((x, y)) for x, y in zip(l_fm, u_fm)]
@@ -267,9 +284,12 @@ class ArcoStep3D:
             rep_all = self.q_rep(qfe(fm_s))                              # :289-296,301
         else:
             x2p, f3, f4 = qfe.forward_lowres2(fm_s)
-        if lazy_t_side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)          # the teacher's FeatureExtractor (side stream)
-        C_.contrast_lists_protos(plan, rep_all_teacher, lazy_t)         # row lists, prototypes: device-side inputs only
+        if lists_done is not None:
+            torch.cuda.current_stream().wait_event(lists_done)
+        else:
+            if lazy_t_side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)      # the teacher's FeatureExtractor (side stream)
+            C_.contrast_lists_protos(plan, rep_all_teacher, lazy_t)     # row lists, prototypes: device-side inputs only
         # the loss forwards need neither counters nor samples: queued before the host blocks (see train_arco_2d.py)
         loss_ce, loss_dice = glue.supervised_loss(pred_l, l_label)       # :306-310
         unsup_loss = glue.compute_unsupervised_loss(pred_u, u_aug_label, u_aug_logits, a.strong_threshold)

@@ -47,6 +47,12 @@ int arco_weighted_row_sum(const float* T, long ldt, const float* Wt, long ldw, l
  * (rep[mask][idx] / rep_teacher[negative_mask], loss_helper_3d.py:403,455-457).                           */
 int arco_gather_rows(const float* src, long ld_src, int D, const int32_t* list, const int64_t* idx64,
                      const int32_t* idx32, long first, long n, float* out, long ld_out, void* stream);
+/* the same two with an f16 row matrix as the source (BASELINE.json configs[4], --act_dtype f16: the V-Net's full-resolution
+ * feature maps are consumed by the heads as stored - FeatureExtractor_3d rows model_3D.py:52-58 - sums and rows are fp32)    */
+int arco_weighted_row_sum_h(const void* T, long ldt, const float* Wt, long ldw, long n_rows, int C, int D,
+                            const int64_t* totals, float* partial, float* out, long ldo, void* stream);
+int arco_gather_rows_h(const void* src, long ld_src, int D, const int32_t* list, const int64_t* idx64,
+                       const int32_t* idx32, long first, long n, float* out, long ld_out, void* stream);
 /* ---- L3  out = cat(old, keys)[-min(len_old+n, queue_size):]  (dequeue_and_enqueue, loss_helper_3d.py:12-32) */
 int arco_bank_append(const float* old, long len_old, const float* keys, long n, long queue_size, int D, float* out,
                      void* stream);
@@ -216,6 +222,13 @@ int arco_gather_upcat_rows3d(const float* lo, long ldlo, int Clo, int Di, int Hi
                              int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
 int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo, int Di,
                               int Hi, int Wi, float* dhi, long ldhi, int Chi, int Do, int Ho, int Wo, void* stream);
+/* ... with `hi` stored as f16; and the way back for its row-sparse gradient: rows idx[] of an fp32 buffer -> the same rows of an
+ * f16 buffer, times the loss scale, saturated at +-65504 (arco_cast_f2h on the touched rows only); arco_zero_rows for f16       */
+int arco_gather_upcat_rows3d_h(const float* lo, long ldlo, int Clo, int Di, int Hi, int Wi, const void* hi, long ldhi, int Chi,
+                               int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
+int arco_cast_rows_f2h(const float* src, long ld_src, int C, const int64_t* idx, long n, float scale, void* dst, long ld_dst,
+                       void* stream);
+int arco_zero_rows_h(void* dst, long ld, int C, const int64_t* idx, long n, void* stream);
 /* glue kernels replacing chains of tensor-library launches in the step (no reference counterpart: the reference's
  * autograd does these as separate zeros / add / copy / mul kernels, train_arco_2d.py:426-431, model_2D.py:43-50):
  * arco_zero_rows: rows idx[] of a [rows, ld] buffer zeroed over C channels (re-arms a persistent gradient buffer);

@@ -367,3 +367,110 @@ def test_f16_backward_overflow_is_contained_and_the_loss_scale_adapts():
         ops.ACT_HALF = False
         ops.LOSS_SCALE = 16384.0
         ops.bump_weight_epoch()
+
+
+def test_row_sparse_heads_on_f16_feature_maps_equal_the_cast_path():
+    """ops.fm_rows_half (round 4): the row-sparse student head (head.lazy_head3d; FeatureExtractor_3d + q_representation rows,
+    model_3D.py:46-58, train_arco_3d.py:289-296) and the lazy teacher (prototypes = class-weighted row sums, key rows) read the two
+    full-resolution feature maps as stored f16 and return a row-sparse f16 gradient carrying the loss scale.  Against the path they
+    replace - dense cast to fp32 (ops.from_half), fp32 heads, dense cast of the fp32 gradient back: identical rows, identical
+    prototypes (same fp32 sums of the same f16-representable values), identical weight / low-resolution gradients, and the f16
+    feature-map gradients bit-equal (rows summed in fp32, rounded once, in both)."""
+    from arco_amd import head, ops, _contrast as C_
+    import fixture_inputs as fx
+    dev = "cuda:0"
+    rs = np.random.RandomState(3)
+    nb, c2, c3, c4, sp, lo_sp = 2, 224, 16, 16, (16, 16, 16), (8, 8, 8)
+    k3 = c2 + c3
+    x2p = _cl(torch.from_numpy(rs.standard_normal((nb, c2) + lo_sp).astype(np.float32)).to(dev))
+    f3h, f4h = _rand_act(rs, (nb, c3) + sp, dev), _rand_act(rs, (nb, c4) + sp, dev)
+    w3 = torch.from_numpy((rs.standard_normal((k3, k3, 1, 1, 1)) / np.sqrt(k3)).astype(np.float32)).to(dev)
+    w4 = torch.from_numpy((rs.standard_normal((16, k3 + c4, 1, 1, 1)) / np.sqrt(k3 + c4)).astype(np.float32)).to(dev)
+    w1 = torch.from_numpy((rs.standard_normal((16, 16, 1, 1, 1)) / 4).astype(np.float32)).to(dev)
+    w2 = torch.from_numpy((rs.standard_normal((16, 16, 1, 1, 1)) / 4).astype(np.float32)).to(dev)
+    n_vox = nb * sp[0] * sp[1] * sp[2]
+    pix = torch.from_numpy(rs.randint(0, n_vox, size=300)).to(dev)
+    pix[7] = pix[3]; pix[100] = pix[3]                      # repeated voxels: their gradient rows add up
+    da = torch.from_numpy(rs.standard_normal((300, 16)).astype(np.float32) * 1e-3).to(dev)
+    prev_scale = ops.LOSS_SCALE
+    try:
+        ops.LOSS_SCALE = 1024.0
+        res = {}
+        for mode in ("half", "cast"):
+            leaves = [t.clone().requires_grad_(True) for t in (x2p, w3, w4, w1, w2)]
+            f3l, f4l = f3h.clone().requires_grad_(True), f4h.clone().requires_grad_(True)
+            f3, f4 = (f3l, f4l) if mode == "half" else (ops.from_half(f3l), ops.from_half(f4l))
+            a = head.lazy_head3d(leaves[0], f3, f4, leaves[1], leaves[2], leaves[3], leaves[4], pix)
+            a.backward(da)
+            res[mode] = [a.detach()] + [t.grad for t in leaves] + [f3l.grad, f4l.grad]
+            assert f3l.grad.dtype == torch.float16 and f4l.grad.dtype == torch.float16
+        for i, (h, c) in enumerate(zip(res["half"], res["cast"])):
+            if i in (1, 6, 7):      # scattered with fp32 atomics (trilinear adjoint / repeated voxels): summation order is free
+                tol = 1e-6 if i == 1 else 2.0 ** -10
+                assert float((h.float() - c.float()).abs().max()) <= tol * float(c.float().abs().max()), i
+                if i > 1:           # every row that was touched once is bit-equal
+                    assert float((h != c).float().mean()) < 1e-4, i
+            else:
+                assert torch.equal(h, c), (i, float((h.float() - c.float()).abs().max()))
+        g3 = res["half"][-2].float()
+        assert float(g3.abs().max()) > 0 and int((g3.movedim(1, -1).reshape(n_vox, c3).abs().sum(1) > 0).sum()) <= 298
+        # teacher: prototypes and key rows
+        inp = {k: v.to(dev) for k, v in fx.loss_inputs(9, b=1, n_cls=3, feat=16, spatial=sp).items()}
+        pl = C_.contrast_masks(inp["label_l"], inp["label_u"], inp["prob_l"], inp["prob_u"], inp["low_mask"], inp["high_mask"], 0.97)
+        t_h = head.LazyTeacher3D(x2p, f3h, f4h, w3, w4)
+        t_c = head.LazyTeacher3D(x2p, ops.from_half(f3h), ops.from_half(f4h), w3, w4)
+        assert torch.equal(t_h.prototypes(pl), t_c.prototypes(pl))
+        assert torch.equal(t_h.rows(pix), t_c.rows(pix))
+    finally:
+        ops.LOSS_SCALE = prev_scale
+
+
+def test_f16_step_with_f16_feature_map_rows_equals_the_dense_cast_step():
+    """Whole 3-D steps in f16 mode with train_arco_3d.FM_ROWS_HALF on (default) and off: the same numbers reach the same kernels
+    (the casts of the touched rows replace the casts of the whole maps), so loss terms and weights agree exactly, eager and replayed."""
+    import random
+    from arco_amd import ops, train_arco_3d as T3
+    prev = T3.FM_ROWS_HALF
+    try:
+        sts = {}
+        for flag in (1, 0):
+            T3.FM_ROWS_HALF = flag
+            sts[flag] = _make3d_small([])
+        for k in ("isd", "q_representation", "q_feature_extractor", "k_feature_extractor"):
+            getattr(sts[0], k).load_state_dict(getattr(sts[1], k).state_dict())
+        ops.bump_weight_epoch()
+        for st in sts.values():
+            for m in (st.model, st.ema_model):
+                m.has_dropout = False
+        def sync(dst, src):       # every step starts from EQUAL state: what is compared is one step, not a trajectory
+            with torch.no_grad():
+                dst.optimizer.flat_p.copy_(src.optimizer.flat_p)
+                dst.optimizer.flat_buf.copy_(src.optimizer.flat_buf)
+                dst.optimizer._started = list(src.optimizer._started)
+                for md, ms in ((dst.model, src.model), (dst.ema_model, src.ema_model), (dst.k_feature_extractor, src.k_feature_extractor)):
+                    for (kd, vd), (ks, vs) in zip(md.state_dict().items(), ms.state_dict().items()):
+                        vd.copy_(vs)
+                dst.memobank = [[m[0].clone()] for m in src.memobank]
+                dst.queue_ptrlis = [q.clone() if torch.is_tensor(q) else q for q in src.queue_ptrlis]
+            ops.bump_weight_epoch()
+
+        for it in range(5):
+            l, ll = T3.synthetic_volume_batch(1, (32, 32, 32), 2, 10 + it, "cuda:0")
+            u, _ = T3.synthetic_volume_batch(1, (32, 32, 32), 2, 20 + it, "cuda:0")
+            sync(sts[0], sts[1])
+            terms = {}
+            for flag, st in sts.items():
+                T3.FM_ROWS_HALF = flag
+                random.seed(100 + it); np.random.seed(100 + it); torch.manual_seed(100 + it)
+                st.step(l, ll, u)
+                terms[flag] = [float(st.last_terms[k]) for k in ("ce", "dice", "unsup", "reco", "eqv")]
+            # the forward sees identical numbers (exact); the gradients differ by the order of fp32 atomic adds in the scatters
+            assert terms[1] == terms[0], (it, terms)
+            pa, pb = sts[1].optimizer.flat_p, sts[0].optimizer.flat_p
+            assert float((pa - pb).abs().max()) <= 1e-6 * float(pa.abs().max()), (it, float((pa - pb).abs().max()))
+        assert sts[1].s_train_lu.captured and sts[1].s_train_lu.flat_outs[-1].dtype == torch.float16      # the last feature map left the graph as f16
+        assert sts[0].s_train_lu.flat_outs[-1].dtype == torch.float32
+    finally:
+        T3.FM_ROWS_HALF = prev
+        ops.ACT_HALF = False
+        ops.bump_weight_epoch()
