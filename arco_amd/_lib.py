@@ -138,6 +138,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_sel_state_offset": ([_I], _L),
     "arco_pack_desc_bytes": ([], _L),
     "arco_bn_defer_desc_bytes": ([], _L),
+    "arco_loss_slabs": ([_I], _L),
     "arco_seg_ws_doubles": ([_L, _I, _I], _L),
     # host-side native sampler replay (no GPU work)
     "arco_grid_sample": ([_P, _L, _L, _L, _I, _I, _P], _L),

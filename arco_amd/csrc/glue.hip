@@ -504,6 +504,9 @@ __global__ __launch_bounds__(256) void eqv_loss_bwd_kernel(const float* __restri
 }
 
 static inline int gl_grid(long work) { long g = (work + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
+// slabs per image of the per-image loss partials (unsupervised CE, equivariance): 64 with >= 8 images, more with fewer (a 1+1-volume 3-D step has ONE image of
+// 2.5 M voxels: 64 blocks left three quarters of the chip idle, 0.26 ms per call)
+static inline int unsup_nblk(int B) { return B >= 8 ? 64 : (B >= 4 ? 128 : (B >= 2 ? 256 : 512)); }
 
 // ---- utils/losses.py:173-209 DiceLoss on PROBABILITIES (the class the reference trainers instantiate: train_arco_2d.py:269,338):
 // rows [M, C] of scores (any values, softmax already applied by the caller), integer labels; per class
@@ -617,19 +620,19 @@ int arco_field_resize(const float* in, int B, int h, int w, int C, int H, int W,
   hipLaunchKernelGGL(field_resize_kernel, dim3(gl_grid((long)B * H * W * C)), dim3(256), 0, as_stream(stream), in, B, h, w, C, H, W, out);
   return arco_launch_status();
 }
-// ws: 64*2*B + B doubles; out[0] = loss_eqv
+// ws: arco_loss_slabs(B) * 2 * B + B doubles; out[0] = loss_eqv
 int arco_eqv_loss_fwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C, double* ws,
                       float* out, void* stream) {
   ARCO_CHECK_ARG(P_ && Q_ && mask && ws && out && B > 0 && P > 0 && C >= 1);
-  const int nblk = 64;
+  const int nblk = unsup_nblk(B);
   hipLaunchKernelGGL(eqv_loss_partial_kernel, dim3(nblk, B), dim3(256), 0, as_stream(stream), P_, ldp, Q_, ldq, mask, P, C, ws);
-  hipLaunchKernelGGL(eqv_loss_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), ws, B, nblk, ws + 64l * 2 * B, out);
+  hipLaunchKernelGGL(eqv_loss_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), ws, B, nblk, ws + (long)nblk * 2 * B, out);
   return arco_launch_status();
 }
 int arco_eqv_loss_bwd(const float* P_, long ldp, const float* Q_, long ldq, const float* mask, int B, long P, int C,
                       const double* ws, const float* g, float* dP, long ldo, void* stream) {
   hipLaunchKernelGGL(eqv_loss_bwd_kernel, dim3(gl_grid((long)B * P)), dim3(256), 0, as_stream(stream), P_, ldp, Q_, ldq, mask, P,
-                     (long)B * P, C, B, ws + 64l * 2 * B, g, dP, ldo);
+                     (long)B * P, C, B, ws + (long)unsup_nblk(B) * 2 * B, g, dP, ldo);
   return arco_launch_status();
 }
 
@@ -791,11 +794,12 @@ int arco_dice_probs_bwd(const float* Pm, long ld, long M, int C, const int64_t* 
                      ws + 1024l * 3 * C, wgt, g, dP, ldo);
   return arco_launch_status();
 }
-// unsupervised weighted CE: B images of P pixels; ws >= 64*4*B + B + 1 doubles; out[0] = loss
+// unsupervised weighted CE: B images of P pixels; ws >= arco_loss_slabs(B) * 4 * B + B + 1 doubles; out[0] = loss
+long arco_loss_slabs(int B) { return unsup_nblk(B); }
 int arco_unsup_loss_fwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const float* conf, float thr,
                         double* ws, float* out, void* stream) {
   ARCO_CHECK_ARG(C >= 1 && C <= GL_MAXC && B > 0 && P > 0);
-  const int nblk = 64;
+  const int nblk = unsup_nblk(B);
   hipLaunchKernelGGL(unsup_loss_partial_kernel, dim3(nblk, B), dim3(256), 0, as_stream(stream), X, ld, P, C, lab, conf, thr, ws);
   hipLaunchKernelGGL(unsup_loss_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), ws, B, nblk, ws + (long)nblk * 4 * B, out);
   return arco_launch_status();
@@ -803,7 +807,7 @@ int arco_unsup_loss_fwd(const float* X, long ld, int B, long P, int C, const int
 int arco_unsup_loss_bwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const double* ws, const float* g,
                         float* dX, long ldo, void* stream) {
   hipLaunchKernelGGL(unsup_loss_bwd_kernel, dim3(gl_grid((long)B * P)), dim3(256), 0, as_stream(stream), X, ld, P, (long)B * P, C,
-                     lab, ws + 64l * 4 * B, B, g, dX, ldo);
+                     lab, ws + (long)unsup_nblk(B) * 4 * B, B, g, dX, ldo);
   return arco_launch_status();
 }
 

@@ -121,7 +121,7 @@ class _UnsupLossFn(torch.autograd.Function):
         r, ld, b, C, P = _geom(pred)
         lab = target.to(torch.int64).contiguous()
         cf = conf.to(torch.float32).contiguous()
-        ws = torch.empty(64 * 4 * b + b + 1, dtype=torch.float64, device=pred.device)
+        ws = torch.empty(L.query("arco_loss_slabs", b) * 4 * b + b + 1, dtype=torch.float64, device=pred.device)
         out = torch.empty(1, dtype=torch.float32, device=pred.device)
         L.call("arco_unsup_loss_fwd", L.ptr(r), ld, b, P, C, L.ptr(lab), L.ptr(cf), float(thr), L.ptr(ws), L.ptr(out))
         ctx.save_for_backward(pred, lab, ws)
@@ -155,7 +155,7 @@ class _EqvLossFn(torch.autograd.Function):
         p, ldp, b, C, P = _geom(pred_tps)
         q, ldq, _, _, _ = _geom(pred_tps_org.detach())
         m = mask_tps.detach().to(torch.float32).contiguous().view(-1)
-        ws = torch.empty(64 * 2 * b + b, dtype=torch.float64, device=pred_tps.device)
+        ws = torch.empty(L.query("arco_loss_slabs", b) * 2 * b + b, dtype=torch.float64, device=pred_tps.device)
         out = torch.empty(1, dtype=torch.float32, device=pred_tps.device)
         L.call("arco_eqv_loss_fwd", L.ptr(p), ldp, L.ptr(q), ldq, L.ptr(m), b, P, C, L.ptr(ws), L.ptr(out))
         ctx.save_for_backward(pred_tps, pred_tps_org, m, ws)

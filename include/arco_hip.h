@@ -307,6 +307,8 @@ int arco_dice_probs_fwd(const float* P, long ld, long M, int C, const int64_t* l
                         void* stream);
 int arco_dice_probs_bwd(const float* P, long ld, long M, int C, const int64_t* lab, const float* wgt, const double* ws,
                         const float* g, float* dP, long ldo, void* stream);
+/* workspaces of the two per-image losses: unsup ws >= arco_loss_slabs(B) * 4 * B + B + 1 doubles, eqv ws >= arco_loss_slabs(B) * 2 * B + B */
+long arco_loss_slabs(int B);
 int arco_unsup_loss_fwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const float* conf, float thr,
                         double* ws, float* out, void* stream);
 int arco_unsup_loss_bwd(const float* X, long ld, int B, long P, int C, const int64_t* lab, const double* ws, const float* g,

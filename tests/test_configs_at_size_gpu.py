@@ -13,6 +13,7 @@ At full size the CPU oracle needs minutes per step, so the whole training step i
 """
 import random
 
+import os
 import numpy as np
 import pytest
 import torch
@@ -208,6 +209,12 @@ def test_cfg2_graph_replay_equals_eager_at_full_size():
         for k in terms[0]:
             np.testing.assert_allclose(terms[1][k], terms[0][k], rtol=5e-5, atol=1e-6, err_msg=f"step {it} {k}")
         pe, pg = st_e.optimizer.flat_p, st_g.optimizer.flat_p
+        if os.environ.get("ARCO_TEST_DIAG"):         # per-parameter deviation of the step's update, largest first
+            dev_ = []
+            for (k, ve), (_, vg) in zip(st_e.model.named_parameters(), st_g.model.named_parameters()):
+                dev_.append((float((ve - vg).abs().max()) / max(1e-12, float(ve.abs().max())), k))
+            print(f"DIAG step {it}: " + "  ".join(f"{k} {d:.1e}" for d, k in sorted(dev_, reverse=True)[:4]), flush=True)
+            print(f"DIAG terms {it}: " + "  ".join(f"{k} {terms[0][k]:.9g}/{terms[1][k]:.9g}" for k in terms[0]), flush=True)
         assert float((pe - pg).abs().max()) <= 2e-5 * float(pe.abs().max()), it
         for (k, ve), (_, vg) in zip(st_e.model.state_dict().items(), st_g.model.state_dict().items()):
             if ve.is_floating_point():

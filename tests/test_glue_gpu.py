@@ -131,3 +131,37 @@ def test_unsup_loss_on_saturated_logits_selects_what_torch_selects(nd):
         np.testing.assert_allclose(lg.item(), lo.item(), rtol=1e-5, err_msg=f"scale {scale}")
         # (rows with CE ~ 1e-8: exp(log_softmax) - 1 rounds to 0 or to half an ulp of 1, times a weight of ~1e-3)
         np.testing.assert_allclose(pg.grad.cpu().numpy(), po.grad.numpy(), rtol=1e-4, atol=2e-8)
+
+
+@pytest.mark.parametrize("b", [1, 2, 3, 5, 6, 7, 8, 11])
+def test_per_image_losses_at_every_batch_count(b):
+    """The unsupervised CE (train_arco_2d.py:482-489) and the equivariance loss (:419-423) keep per-image partial sums in
+    arco_loss_slabs(b) slabs per image - more slabs with fewer images (round 4: a 1+1-volume 3-D step has one image of 2.5 M
+    voxels).  Every image count from 1 to beyond 8, values and gradients against the oracle functions; a guard page of the
+    workspace allocation is not available here, so the check that no partial lands outside its slab is the agreement itself on
+    counts where the slab count changes (1, 2-3, 4-7, >= 8)."""
+    import arco_oracle as orc
+    from arco_amd import glue
+    rs = np.random.RandomState(40 + b)
+    C, sp = 3, (20, 28)
+    pred = torch.from_numpy((3 * rs.standard_normal((b, C, *sp))).astype(np.float32))
+    lab = torch.from_numpy(rs.randint(-1, C, size=(b, *sp)))
+    conf = torch.from_numpy(rs.uniform(0.3, 1.0, size=(b, *sp)).astype(np.float32))
+    po = pred.clone().requires_grad_(True)
+    lo = orc.compute_unsupervised_loss(po, lab, conf, 0.6)
+    lo.backward()
+    pg = pred.cuda().requires_grad_(True)
+    lg = glue.compute_unsupervised_loss(pg, lab.cuda(), conf.cuda(), 0.6)
+    lg.backward()
+    np.testing.assert_allclose(lg.item(), lo.item(), rtol=1e-5)
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), po.grad.numpy(), rtol=1e-4, atol=2e-8)
+    org = torch.from_numpy((2 * rs.standard_normal((b, C, *sp))).astype(np.float32))
+    mask = torch.from_numpy((rs.uniform(size=(b, 1, *sp)) < 0.7).astype(np.float32))
+    po = pred.clone().requires_grad_(True)
+    eo = orc.eqv_loss(po, org, mask)
+    eo.backward()
+    pg = pred.cuda().requires_grad_(True)
+    eg = glue.eqv_loss(pg, org.cuda(), mask.cuda())
+    eg.backward()
+    np.testing.assert_allclose(eg.item(), eo.item(), rtol=1e-5)
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), po.grad.numpy(), rtol=1e-4, atol=1e-8)
