@@ -1,5 +1,5 @@
 """Same-process A/B of train_arco_2d.TEACHER_SIDE modes: one trainer per mode (own graphs), alternating blocks of steps on one box.
-python tools/ab_modes.py 3 4 [--reps 8 --block 100]"""
+python tools/ab_modes.py 3 4 -4 [--city]      (-4: mode 4 without train_arco_2d.SIDE_SYNC)"""
 import os, sys, time
 os.environ.setdefault("OMP_NUM_THREADS", "4")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ city = "--city" in sys.argv          # the Cityscapes-shaped shard (BASELINE.jso
 reps, block = (6, 20) if city else (8, 100)
 sts = {}
 for m in modes:
-    T.TEACHER_SIDE = abs(m) // 10 if abs(m) >= 10 else abs(m)
+    T.TEACHER_SIDE = abs(m)
     if city:
         args = T.build_parser().parse_args(["--batch_size", "1", "--queue_size", "4096", "--synthetic", "1", "--num_classes", "19", "--in_chns", "3"])
         args.patch_size = [512, 1024]
@@ -23,8 +23,8 @@ else:
     bs = [(T.synthetic_batch(8, args.patch_size, 4, 100 + 2 * i, "cuda:0"), T.synthetic_batch(8, args.patch_size, 4, 101 + 2 * i, "cuda:0")[0]) for i in range(4)]
 def run(m, n):
     key = m
-    T.SIDE_SYNC = 0 if m < 0 else (2 if m >= 10 else 1)   # -m: mode m without the host-side wait in front of backward(); 10 m: split backward
-    m = abs(m) // 10 if abs(m) >= 10 else abs(m)
+    T.SIDE_SYNC = 0 if m < 0 else 1           # -m: mode m without the host-side wait in front of backward()
+    m = abs(m)
     T.TEACHER_SIDE = m
     st = sts[key]
     for i in range(n):

@@ -70,6 +70,15 @@ def dbg_backward(ctx, da):
     dw4 = _wgrad(dh0, X4, w4)
     dX4 = _gemm_t(dh0, w4); rec("b3_dX4", dX4)
     dX3p = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
+    if seg_log[0] < 6:
+        seg_log[0] += 1
+        ptr = dX3p.data_ptr()
+        for seg in torch.cuda.memory_snapshot():
+            if seg["address"] <= ptr < seg["address"] + seg["total_size"]:
+                blocks = [(b_["state"], b_["size"]) for b_ in seg["blocks"]]
+                print(f"  SEGMENT of dX3p: pool_id {seg.get('segment_pool_id')} stream {seg.get('stream')} type {seg.get('segment_type')} size {seg['total_size']} "
+                      f"blocks {len(blocks)} active {sum(1 for st_, _ in blocks if st_.startswith('active'))}; current stream {torch.cuda.current_stream().cuda_stream:#x} "
+                      f"default {torch.cuda.default_stream().cuda_stream:#x}", flush=True)
     df4, fin4 = _row_grad_buffer(ctx.fptrs[2], (nb, c4, h4, w4_), dev)
     L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX4), k3 + c4, k3, L.ptr(lylx4), L.ptr(pix), n, L.ptr(dX3p), k3, L.ptr(df4), c4, c4)
     rec("b4_dX3p", dX3p)
@@ -92,6 +101,7 @@ def dbg_backward(ctx, da):
             dw2, dw3, dw4, dw1, dwq2, None)
 H_.LazyHead3Fn.backward = staticmethod(dbg_backward)
 ref_probe = {}
+seg_log = [0]
 dumped = [False]
 def cmp_probe(name):
     out = []
