@@ -36,9 +36,18 @@ def restore(st, s):
         st.queue_ptrlis = [q.clone() if torch.is_tensor(q) else q for q in s["ptr"]]
     st.iter_num = s["it"]
     ops.bump_weight_epoch()
+MAIN = torch.cuda.Stream() if os.environ.get("SC_MAIN_STREAM") else None      # the whole step on an explicit stream instead of the legacy default stream
+import contextlib
+def main_ctx():
+    if MAIN is None:
+        return contextlib.nullcontext()
+    MAIN.wait_stream(torch.cuda.default_stream())
+    return torch.cuda.stream(MAIN)
 for name, st in sts.items():                 # warm: graphs captured at the third call
     for it in range(4):
-        TC.seed_all(800 + it); st.step(*TC._acdc_batch(20 + it))
+        TC.seed_all(800 + it)
+        with main_ctx():
+            st.step(*TC._acdc_batch(20 + it))
     torch.cuda.synchronize()
 snaps = {name: snapshot(st) for name, st in sts.items()}
 # probes: the InfoNCE's precomputed anchor gradient and its inputs (head forward rows), the heads' incoming gradient
@@ -137,7 +146,9 @@ for t in range(n):
     for name, st in sts.items():
         restore(st, snaps[name])
         TC.seed_all(804)
-        st.step(*batch)
+        torch.cuda.synchronize()
+        with main_ctx():
+            st.step(*batch)
         torch.cuda.synchronize()
         g = st.optimizer.flat_g.clone()
         if name not in ref:
