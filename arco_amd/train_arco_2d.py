@@ -158,6 +158,7 @@ def patients_to_slices(dataset, patiens_num):
 # Results are unchanged: the passes were independent already, only their order in time is free; the two gradient buffers are
 # summed once (a + b, bit-identical to accumulating in sequence).  ARCO_TEACHER_SIDE=0 restores the single-stream step.
 TEACHER_SIDE = int(os.environ.get("ARCO_TEACHER_SIDE", "4"))
+# Modes >= 3 need the host-side wait of SIDE_SYNC (see ArcoStep2D.step, in front of loss.backward()) to be reproducible.
 SIDE_SYNC = int(os.environ.get("ARCO_SIDE_SYNC", "1"))
 
 
@@ -551,9 +552,9 @@ class ArcoStep2D:
             # (arco_lerp4_cat_rows_bwd into a freshly allocated buffer: single 128 / 256-byte cache-line runs reading back as the
             # block's previous content), only with the warped pass on the second queue (modes >= 3), also with every graph replay
             # serialised against the default stream by events, never with a device- or stream-synchronize in front of backward()
-            # (0 of 180 amplified trials against 10-14 of 60).  Enqueueing the backward of a pass whose forward graph is still
+            # (0 of 500 amplified trials on five boxes against 10-59 of 60).  Enqueueing the backward of a pass whose forward graph is still
             # running on the other queue is what it takes; the mechanism below the HIP API is not understood (profiles/r04_notes.md
-            # section 8).  Cost: the host gives up ~1 ms of its lead once per step, 0.1-0.2 ms of step time.  ARCO_SIDE_SYNC=0: off.
+            # section 8).  Cost: the host gives up its lead once per step, 0.3-0.4 ms of step time (11.36 -> 11.66 ms).  ARCO_SIDE_SYNC=0: off.
             self._t_stream.synchronize()
         loss.backward()
         ops.join_side()                     # weight gradients queued on the side stream (ops._wgrad)
