@@ -1,0 +1,42 @@
+"""Host-side bookkeeping of the step schedule (no GPU work): the BatchNorm running-statistics deferral slots of ops.bn_defer
+(train_arco_2d mode 4 postpones the statistics pass's updates into slot 1 and the u half's into slot 0, so that they land in the
+reference's order l, cj2_l, u - train_arco_2d.py:310-312) and the workspace sizing of the per-image losses."""
+import torch
+
+from arco_amd import _lib as L, ops
+
+
+def test_bn_defer_slots_are_separate_and_nest():
+    assert ops.BN_DEFER is None
+    rm, rv = torch.zeros(8), torch.ones(8)
+    assert ops._defer_args(rm, rv, 8, 2, 0.1) == (0, None)                 # outside any context: immediate update
+    with ops.bn_defer(1):                                                  # slot 0: groups >= 1 deferred
+        g0, buf0 = ops._defer_args(rm, rv, 8, 2, 0.1)
+        assert g0 == 1 and buf0.numel() == 1 * 2 * 8 + 1
+        assert ops._defer_args(rm, rv, 8, 1, 0.1) == (0, None)             # a one-group pass has no group >= 1
+        with ops.bn_defer(0, 1):                                           # slot 1: every group deferred
+            g1, buf1 = ops._defer_args(rm, rv, 8, 1, 0.1)
+            assert g1 == 0 and buf1.numel() == 1 * 2 * 8 + 1 and buf1.data_ptr() != buf0.data_ptr()
+            assert ops._defer_args(rm, rv, 8, 1, 0.1)[1].data_ptr() == buf1.data_ptr()     # same layer, same slot: same buffer
+        assert ops.BN_DEFER == (1, 0)
+        assert ops._defer_args(rm, rv, 8, 2, 0.1)[1].data_ptr() == buf0.data_ptr()
+    assert ops.BN_DEFER is None
+    key = rm.data_ptr()
+    assert key in ops._DEFERRED[0] and key in ops._DEFERRED[1]
+    assert ops._DEFERRED[0][key]["n"] == 1 and ops._DEFERRED[1][key]["n"] == 1
+    # a different group count for the same layer re-registers the slot's entry (and invalidates its descriptor table)
+    with ops.bn_defer(0):
+        _, buf2 = ops._defer_args(rm, rv, 8, 2, 0.1)
+    assert buf2.numel() == 2 * 2 * 8 + 1 and ops._DEFERRED[0][key]["n"] == 2
+    for slot in (0, 1):
+        ops._DEFERRED[slot].pop(key)
+        ops._DEFER_TABLE.pop(slot, None)
+
+
+def test_loss_slab_counts():
+    """arco_loss_slabs(B): slabs per image of the unsupervised-CE / equivariance partial sums - 64 from 8 images on, more with fewer
+    (one 2.5 M-voxel volume on 64 blocks left the chip idle); the Python callers size their workspaces from it."""
+    got = {b: int(L.query("arco_loss_slabs", b)) for b in (1, 2, 3, 4, 5, 7, 8, 9, 16, 64)}
+    assert got == {1: 512, 2: 256, 3: 256, 4: 128, 5: 128, 7: 128, 8: 64, 9: 64, 16: 64, 64: 64}
+    for b, n in got.items():
+        assert n * b >= 512 or b >= 8
