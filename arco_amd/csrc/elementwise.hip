@@ -744,12 +744,22 @@ __global__ __launch_bounds__(256) void lerp4_cat_rows_bwd_kernel(const float* __
   const float ly = lylx[2 * j], lx = lylx[2 * j + 1], hy = 1.f - ly, hx = 1.f - lx;
   const float* g = dX + j * ldx;
   float* v0 = dV + (4 * j) * ldv;
+  // The two MIXED weights are single v_mul_f32 instructions on purpose.  Left to the compiler they became
+  // `v_pk_mul_f32 v[16:17], v[20:21], v[18:19] op_sel:[0,1] op_sel_hi:[1,0]` - a packed-fp32 instruction whose LOW result takes
+  // the HIGH dword of src1 - and gfx950 computes that low result with src1.hi read as 0 in lanes 48-63 whenever another wave of
+  // the SIMD is executing a K=32 MFMA (v_mfma_f32_16x16x32_bf16 / _f16): the non-reproducible gradient of round 4 (this kernel
+  // beside the warped pass's backward graph on the second queue; torch-free reproducer tools/debug/pkmul_repro.hip, form sweep
+  // tools/debug/pkmul_sweep.hip, profiles/r05_notes.md section 1).  tests/test_isa_lint.py keeps the form out of the library.
+  const float w00 = hy * hx, w11 = ly * lx;
+  float w01, w10;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(w01) : "v"(hy), "v"(lx));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(w10) : "v"(ly), "v"(hx));
   for (int c = lane * 4; c < Clo; c += 256) {
     const f32x4 d = *reinterpret_cast<const f32x4*>(g + c);
-    *reinterpret_cast<f32x4*>(v0 + c) = d * (hy * hx);
-    *reinterpret_cast<f32x4*>(v0 + ldv + c) = d * (hy * lx);
-    *reinterpret_cast<f32x4*>(v0 + 2 * ldv + c) = d * (ly * hx);
-    *reinterpret_cast<f32x4*>(v0 + 3 * ldv + c) = d * (ly * lx);
+    *reinterpret_cast<f32x4*>(v0 + c) = d * w00;
+    *reinterpret_cast<f32x4*>(v0 + ldv + c) = d * w01;
+    *reinterpret_cast<f32x4*>(v0 + 2 * ldv + c) = d * w10;
+    *reinterpret_cast<f32x4*>(v0 + 3 * ldv + c) = d * w11;
   }
   float* h = dhi + pix[j] * ldhi;
   for (int c = lane; c < Chi; c += 64) atomicAdd(h + c, g[Clo + c]);

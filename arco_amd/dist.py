@@ -207,6 +207,14 @@ def allreduce_sum(t):
 
 
 @torch.no_grad()
+def allreduce_min(t):
+    """In-place minimum over ranks (the f16 overflow flag of train_arco_3d._unscale_and_guard: one decision for all replicas)."""
+    if is_dist():
+        td.all_reduce(t, op=td.ReduceOp.MIN)
+    return t
+
+
+@torch.no_grad()
 def reduce_prototypes(proto, counts):
     """Class prototypes over the global batch: sum_r n_r * proto_r / sum_r n_r with n_r the rank's count of valid
     pixels of the class (a class absent on a rank contributes nothing; absent everywhere -> NaN, as the reference's

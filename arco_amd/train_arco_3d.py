@@ -140,15 +140,25 @@ class ArcoStep3D:
         """--act_dtype f16: divide the loss scale out of the V-Net's stretch of the flat gradient and guard the step against an
         overflow of the f16 backward (an inf / NaN in flat_g would go straight into SGD, the EMA teacher and,
         a step later, the memory banks - silently and for good).  All on the device, no host synchronisation in the step:
-        `ok` = every V-Net gradient finite; non-finite values are replaced by zeros and the WHOLE gradient is multiplied by ok, so
-        an overflowed step degenerates to a zero-gradient step (weight decay and momentum only) instead of poisoning the run.
+        `ok` = every V-Net gradient finite (on every rank); non-finite values are replaced by zeros and the V-Net's gradient is multiplied
+        by ok, so an overflowed step leaves the V-Net with weight decay and momentum only instead of poisoning the run (the heads' fp32
+        gradients do not pass through the f16 region and are applied).
         The flag is copied to pinned memory and read at the START of the next step (long complete by then): an overflow halves
         the loss scale (floor 1), 500 clean steps double it again up to --loss_scale (dynamic loss scaling)."""
         gv = self.optimizer.flat_g[:self.heads_start]
         gv.mul_(1.0 / ops.LOSS_SCALE)
         ok = torch.isfinite(gv).all()
         torch.nan_to_num_(gv, nan=0.0, posinf=0.0, neginf=0.0)
-        self.optimizer.flat_g.mul_(ok.to(torch.float32))
+        okf = ok.to(torch.float32).view(1)
+        if adist.is_dist():
+            # every rank must take the same decision (a rank that zeroed alone would leave the replicas' loss scales, graphs and -
+            # through momentum - weights apart): MIN over ranks, issued by every rank every f16 step, in front of the V-Net bucket
+            adist.allreduce_min(okf)
+        # Only the V-Net's stretch is written: the heads' gradients are fp32, produced UPSTREAM of the f16 backward (always
+        # finite), and under data parallelism their bucket flat_g[heads_start:] is already inside an asynchronous all-reduce
+        # started by dist.mark_heads_done's backward hook - nothing may write it before allreduce_grads has waited (ADVICE r4).
+        gv.mul_(okf)
+        ok = okf > 0
         if self._ovf_host is None:
             self._ovf_host = torch.ones(1, dtype=torch.bool).pin_memory()
         self._ovf_host.copy_(ok.view(1), non_blocking=True)

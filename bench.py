@@ -611,7 +611,7 @@ def main():
                        "classes": 4, "rep_dim": 496, "num_queries": 256, "num_negatives": 512, "func": "smc", "apply_aug": args.apply_aug,
                        "loss_terms": f"k1*contrastive + k3*unsupervised + CE + Dice + k2*equivariance (k2 = {a.k2:g})",
                        "graph_train": int(bool(getattr(args, "graph_train", 0))), "parallelism": f"dp{world}",
-                       "pass_concurrency": f"ARCO_TEACHER_SIDE={T.TEACHER_SIDE} (teacher / statistics / warped student passes on a second stream), ARCO_SIDE_SYNC={T.SIDE_SYNC} (host-side wait in front of backward)",
+                       "pass_concurrency": f"ARCO_TEACHER_SIDE={T.TEACHER_SIDE} (teacher / statistics / warped student passes on a second stream), ARCO_SIDE_SYNC={T.SIDE_SYNC} (round 4's host-side wait in front of backward; 0 = off since the round-5 kernel fix)",
                        "contrastive_loss_ms_per_step": round(loss_ms, 3),
                        "sustained_ms_per_step": (sustained or {}).get("ms_per_step"),
                        "whole_step_tflops": (whole or {}).get("tflops_over_whole_step")},

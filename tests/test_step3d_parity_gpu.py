@@ -257,7 +257,7 @@ def test_pass_concurrency_3d_equals_the_single_stream_step(side_mode):
             u, _ = T3.synthetic_volume_batch(1, (32, 32, 32), 4, 20 + it, "cuda:0")
             sync(st_b, st_a)
             terms = []
-            for st, mode in ((st_a, 0), (st_b, 2)):
+            for st, mode in ((st_a, 0), (st_b, side_mode)):       # PASS_SIDE is read at step time: the parametrized mode, not a constant
                 T3.PASS_SIDE = mode
                 random.seed(50 + it); np.random.seed(50 + it); torch.manual_seed(50 + it)
                 st.step(l, ll, u)

@@ -89,14 +89,14 @@ def dbg_backward(ctx, da):
                       f"blocks {len(blocks)} active {sum(1 for st_, _ in blocks if st_.startswith('active'))}; current stream {torch.cuda.current_stream().cuda_stream:#x} "
                       f"default {torch.cuda.default_stream().cuda_stream:#x}", flush=True)
     df4, fin4 = _row_grad_buffer(ctx.fptrs[2], (nb, c4, h4, w4_), dev)
-    L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX4), k3 + c4, k3, L.ptr(lylx4), L.ptr(pix), n, L.ptr(dX3p), k3, L.ptr(df4), c4, c4)
+    lerp4_bwd("dX3p", dX4, k3 + c4, k3, lylx4, pix, n, dX3p, df4, c4)
     rec("b4_dX3p", dX3p)
     fin4(pix, n)
     dw3 = _wgrad(dX3p, X3, w3)
     dX3 = _fea_rows(dX3p, w3, 1); rec("b5_dX3", dX3)
     dX2p = torch.empty((16 * n, k2), dtype=torch.float32, device=dev)
     df3, fin3 = _row_grad_buffer(ctx.fptrs[1], (nb, c3, h3, w3_), dev)
-    L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX3), k3, k2, L.ptr(lylx3), L.ptr(nb4), 4 * n, L.ptr(dX2p), k2, L.ptr(df3), c3, c3)
+    lerp4_bwd("dX2p", dX3, k3, k2, lylx3, nb4, 4 * n, dX2p, df3, c3)
     rec("b6_dX2p", dX2p)
     fin3(nb4, 4 * n)
     dw2 = _wgrad(dX2p, X2, w2)
@@ -109,6 +109,128 @@ def dbg_backward(ctx, da):
     return (dx1p.permute(0, 3, 1, 2), df2.permute(0, 3, 1, 2), df3.permute(0, 3, 1, 2), df4.permute(0, 3, 1, 2),
             dw2, dw3, dw4, dw1, dwq2, None)
 H_.LazyHead3Fn.backward = staticmethod(dbg_backward)
+
+# ---- round 5 probes (profiles/r05_notes.md section 1): canary pre-fill, expected-value check and an instrumented kernel twin
+import ctypes
+SC_CANARY = int(os.environ.get("SC_CANARY", "0"))
+SC_DBG_LERP = int(os.environ.get("SC_DBG_LERP", "-1"))          # -1: the product kernel; 0 / 1 / 2: tools/debug/lerp4_dbg.hip variants
+SC_CHECK = int(os.environ.get("SC_CHECK", "0"))                  # compare each adjoint output with its torch restatement
+_dbglib = None
+SC_ISA = os.environ.get("SC_ISA", "")                             # a hand-edited ISA variant of the product kernel: tools/debug/isa/<name>.co
+if SC_DBG_LERP >= 0 or SC_ISA:
+    _dbglib = ctypes.CDLL(os.path.join(ROOT, "tools", "debug", "liblerp4dbg.so"))
+    _P, _I, _Lg = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+    _dbglib.dbg_lerp4_cat_rows_bwd.argtypes = [_I, _P, _Lg, _I, _P, _P, _Lg, _P, _Lg, _P, _Lg, _I, _P, _P]
+    _dbglib.dbg_lerp4_cat_rows_bwd.restype = _I
+    _dbglib.dbg_lerp4_module_launch.argtypes = [_P, _Lg, _I, _P, _P, _Lg, _P, _Lg, _P, _Lg, _I, _P, _P]
+    _dbglib.dbg_lerp4_module_launch.restype = _I
+    if SC_ISA:
+        torch.cuda.init(); torch.zeros(1, device="cuda")
+        rc = _dbglib.dbg_lerp4_module_load(os.path.join(ROOT, "tools", "debug", "isa", SC_ISA + ".co").encode())
+        assert rc == 0, rc
+CANARY_BITS = 0x7fc0dead
+lerp_events = [0]
+def lerp4_bwd(tag, dXin, ldx, Clo, lylx, pix, n, dV, df, Chi):
+    dbg = None
+    if SC_CANARY:
+        dV.view(torch.int32).fill_(CANARY_BITS)
+    if SC_ISA:
+        if "record" in SC_ISA:
+            dbg = torch.zeros((n * 64, 64), dtype=torch.int32, device=dV.device)
+        rc = _dbglib.dbg_lerp4_module_launch(L.ptr(dXin), ldx, Clo, L.ptr(lylx), L.ptr(pix), n, L.ptr(dV), Clo, L.ptr(df), Chi, Chi, L.ptr(dbg), L.stream())
+        assert rc == 0
+    elif _dbglib is not None:
+        dbg = torch.zeros((n * 64, 16), dtype=torch.int32, device=dV.device)
+        rc = _dbglib.dbg_lerp4_cat_rows_bwd(SC_DBG_LERP, L.ptr(dXin), ldx, Clo, L.ptr(lylx), L.ptr(pix), n, L.ptr(dV), Clo, L.ptr(df), Chi, Chi,
+                                            L.ptr(dbg), L.stream())
+        assert rc == 0
+    else:
+        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dXin), ldx, Clo, L.ptr(lylx), L.ptr(pix), n, L.ptr(dV), Clo, L.ptr(df), Chi, Chi)
+    if not SC_CHECK:
+        return
+    if SC_CHECK == 2:       # no host synchronisation inside backward(): snapshot now (stream-ordered copies), compare after the step
+        pending_checks.append((tag, dXin.clone(), Clo, lylx, n, dV.clone(), dbg))
+        return
+    lerp4_check(tag, dXin, Clo, lylx, n, dV, dbg)
+pending_checks = []
+def lerp4_check(tag, dXin, Clo, lylx, n, dV, dbg):
+    ly, lx = lylx[0:2 * n:2], lylx[1:2 * n:2]
+    wts = torch.stack(((1 - ly) * (1 - lx), (1 - ly) * lx, ly * (1 - lx), ly * lx), 1)
+    exp = (dXin[:n, None, :Clo] * wts[:, :, None]).reshape(4 * n, Clo)
+    bad = ~((dV == exp) | ((dV == 0) & (exp == 0)))
+    nbad = int(bad.sum())
+    if nbad == 0:
+        return
+    lerp_events[0] += 1
+    if lerp_events[0] > 6:
+        return
+    rows, cols = bad.nonzero(as_tuple=True)
+    vb = dV[bad]
+    bits = vb.view(torch.int32)
+    lanes = (cols % 256) // 4
+    passes = cols // 256
+    urows = torch.unique(rows)
+    print(f"  LERP4 {tag}: {nbad} bad elements in {int(urows.numel())} rows of {4 * n}; canary left {int((bits == CANARY_BITS).sum())}, zeros {int((vb == 0).sum())}, "
+          f"other {int(((bits != CANARY_BITS) & (vb != 0)).sum())}; row%4 hist {torch.bincount(urows % 4, minlength=4).tolist()}; "
+          f"lane hist (16-lane groups) {torch.bincount(lanes // 16, minlength=4).tolist()}; pass hist {torch.bincount(passes, minlength=2).tolist()}; "
+          f"per-row counts {torch.unique(torch.bincount(rows)[urows]).tolist()}", flush=True)
+    oth = (bits != CANARY_BITS) & (vb != 0)
+    if int(oth.sum()):
+        print(f"    other values: got {vb[oth][:6].tolist()} expected {exp[bad][oth][:6].tolist()} ratio {(vb[oth][:6] / exp[bad][oth][:6]).tolist()}", flush=True)
+    if dbg is not None and dbg.shape[1] == 64:        # the ISA variant that records its own registers (isa/v5_record.s)
+        d = dbg.view(n, 64, 64)
+        j, t, e, p_ = rows // 4, rows % 4, cols % 4, cols // 256
+        recd = d[j, lanes]                                                         # [nbad, 64]
+        widx = torch.tensor([[2, 3, 10, 11], [4, 5, 12, 13], [6, 7, 14, 15], [0, 1, 8, 9]], device=dV.device)[t, e]      # weight register of (t, e)
+        wrec = recd.gather(1, widx[:, None])[:, 0].contiguous().view(torch.float32)
+        wexp = wts[j, t]
+        didx = 16 + p_ * 16 + t * 4 + e
+        drec = recd.gather(1, didx[:, None])[:, 0].contiguous().view(torch.float32)
+        print(f"    recorded WEIGHT register of the bad element: zero at {int((wrec == 0).sum())} of {nbad}, equal to the expected weight at {int((wrec == wexp).sum())}; "
+              f"recorded PRODUCT register (store data): zero at {int((drec == 0).sum())}, equal to expected at {int((drec == exp[bad]).sum())}", flush=True)
+        # the same registers in the GOOD lanes of the bad waves, and ALL 16 weight registers of the bad lanes
+        bj = torch.unique(j)
+        wall = d[bj][:, :, 0:16].contiguous().view(torch.float32)               # [waves, 64 lanes, 16 regs v12..v27]
+        zero_map = (wall == 0)
+        print(f"    zero weight registers by 16-lane group (waves x regs v12..v27), bad waves {int(bj.numel())}: "
+              f"{[zero_map[:, g * 16:(g + 1) * 16, :].any(1).sum(0).tolist() for g in range(4)]}", flush=True)
+        uniform = (wall == wall[:, :1, :]).all(1)                                # register wave-uniform?
+        print(f"    weight registers wave-uniform (count of bad waves per register): {uniform.sum(0).tolist()}", flush=True)
+        hw = d[bj, 0, 48].to(torch.int64) & 0xffffffff; xcc = d[bj, 0, 49].to(torch.int64) & 0xf
+        hw_all = d[:, 0, 48].to(torch.int64) & 0xffffffff; xcc_all = d[:, 0, 49].to(torch.int64) & 0xf
+        print(f"    bad waves: xcc hist {torch.bincount(xcc, minlength=8).tolist()} (all {torch.bincount(xcc_all, minlength=8).tolist()}); simd {torch.bincount((hw >> 4) & 3, minlength=4).tolist()}; "
+              f"wave slot {torch.bincount(hw & 15, minlength=16).tolist()}; se {torch.bincount((hw >> 13) & 7, minlength=8).tolist()}; cu {torch.bincount((hw >> 8) & 15, minlength=16).tolist()}; "
+              f"queue bad {torch.unique((hw >> 24) & 7).tolist()} all {torch.unique((hw_all >> 24) & 7).tolist()}; pipe bad {torch.unique((hw >> 6) & 3).tolist()} all {torch.unique((hw_all >> 6) & 3).tolist()}; "
+              f"vmid all {torch.unique((hw_all >> 20) & 15).tolist()}; me all {torch.unique((hw_all >> 30) & 3).tolist()}", flush=True)
+        k = int(j[0]); ln = int(lanes[0])
+        print(f"    sample: wave j={k} lane {ln} weights v12..v27 {d[k, ln, 0:16].contiguous().view(torch.float32).tolist()}; lane 0 of the same wave {d[k, 0, 0:16].contiguous().view(torch.float32).tolist()}; "
+              f"expected (w0,w1,w2,w3) {wts[k].tolist()} ly,lx {float(ly[k])},{float(lx[k])}", flush=True)
+    elif dbg is not None:
+        d = dbg.view(n, 64, 16)
+        j, t = rows // 4, rows % 4
+        rec = d[j, lanes]                                   # [nbad, 16]
+        wrec = rec[:, 0:4].contiguous().view(torch.float32)
+        wexp = wts[j]
+        w_wrong = (wrec != wexp).any(1)
+        w_t = wrec.gather(1, t[:, None])[:, 0]
+        print(f"    recorded weights differ from expected at {int(w_wrong.sum())} of {nbad} bad elements; recorded weight of the bad row is 0 at {int((w_t == 0).sum())}; "
+              f"expected weight of the bad row is 0 at {int((wexp.gather(1, t[:, None])[:, 0] == 0).sum())}", flush=True)
+        aexp = ((4 * j + t) * Clo + lanes * 4) * 4
+        arec = rec.gather(1, (4 + t)[:, None])[:, 0].to(torch.int64) & 0xffffffff
+        print(f"    recorded row address differs from expected at {int((arec != (aexp & 0xffffffff)).sum())}; recorded lane id wrong at {int(((rec[:, 13] & 63) != lanes).sum())}; "
+              f"recorded ly/lx wrong at {int((rec[:, 14:16].contiguous().view(torch.float32) != torch.stack((ly[j], lx[j]), 1)).any(1).sum())}", flush=True)
+        allw = d[:, 0, :]
+        hw_all, xcc_all = allw[:, 8].to(torch.int64) & 0xffffffff, allw[:, 9].to(torch.int64) & 0xf
+        bj = torch.unique(j)
+        hb = hw_all[bj]
+        print(f"    bad waves {int(bj.numel())}: xcc hist {torch.bincount(xcc_all[bj], minlength=8).tolist()} (all waves {torch.bincount(xcc_all, minlength=8).tolist()}); "
+              f"simd hist {torch.bincount((hb >> 4) & 3, minlength=4).tolist()}; se hist {torch.bincount((hb >> 13) & 7, minlength=8).tolist()}; cu hist {torch.bincount((hb >> 8) & 15, minlength=16).tolist()}; "
+              f"queue ids bad {torch.unique((hb >> 24) & 7).tolist()} all {torch.unique((hw_all >> 24) & 7).tolist()}; pipe ids bad {torch.unique((hb >> 6) & 3).tolist()} all {torch.unique((hw_all >> 6) & 3).tolist()}; "
+              f"me bad {torch.unique((hb >> 30) & 3).tolist()}; vmid {torch.unique((hw_all >> 20) & 15).tolist()}", flush=True)
+        tt0, tt1 = allw[:, 10].to(torch.int64) & 0xffffffff, allw[:, 11].to(torch.int64) & 0xffffffff
+        dur = (tt1 - tt0) & 0xffffffff
+        print(f"    wave duration (clock ticks): bad median {int(dur[bj].median())} max {int(dur[bj].max())}; all median {int(dur.median())} max {int(dur.max())}; "
+              f"kernel span {int(((tt1.max() - tt0.min()) & 0xffffffff))}; bad waves start offsets (first 8) {((tt0[bj] - tt0.min()) & 0xffffffff)[:8].tolist()}", flush=True)
 ref_probe = {}
 seg_log = [0]
 dumped = [False]
@@ -150,6 +272,9 @@ for t in range(n):
         with main_ctx():
             st.step(*batch)
         torch.cuda.synchronize()
+        for chk in pending_checks:
+            lerp4_check(*chk)
+        pending_checks.clear()
         g = st.optimizer.flat_g.clone()
         if name not in ref:
             ref[name] = g
