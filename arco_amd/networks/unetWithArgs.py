@@ -72,20 +72,34 @@ class DownBlock(nn.Module):
 
 
 class UpBlock(nn.Module):
-    """Upsampling followed by ConvBlock (unetWithArgs.py:64-85).  The reference Decoder never
-    passes `bilinear`, so the default bilinear=True path (1x1 conv + x2 align_corners bilinear) is the
-    one on the hot path; the ConvTranspose2d branch is unreachable from UNet and not provided."""
+    """Upsampling followed by ConvBlock (unetWithArgs.py:64-85).  The reference Decoder never passes `bilinear`, so the default
+    bilinear=True path (1x1 conv + x2 align_corners bilinear) is the one on the hot path.  bilinear=False (:76-77,
+    `nn.ConvTranspose2d(in_channels1, in_channels2, kernel_size=2, stride=2)`) is unreachable from UNet but part of the module's
+    surface: it runs as the GEMM form of a k2 s2 transposed conv (one 1x1-conv launch over [4 co][ci] weights, as the V-Net's
+    UpsamplingDeconvBlock does in 3-D) followed by the pixel shuffle."""
 
     def __init__(self, in_channels1, in_channels2, out_channels, dropout_p, bilinear=True):
         super(UpBlock, self).__init__()
         self.bilinear = bilinear
-        if not bilinear:
-            raise NotImplementedError("UpBlock(bilinear=False) is not on the ARCO hot path")
-        self.conv1x1 = nn.Conv2d(in_channels1, in_channels2, kernel_size=1)
-        self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        if bilinear:
+            self.conv1x1 = nn.Conv2d(in_channels1, in_channels2, kernel_size=1)
+            self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels1, in_channels2, kernel_size=2, stride=2)
         self.conv = ConvBlock(in_channels2 * 2, out_channels, dropout_p)
 
+    def _deconv(self, x1):
+        w, b = self.up.weight, self.up.bias                         # [ci][co][2][2]
+        ci, co = int(w.shape[0]), int(w.shape[1])
+        w2 = w.permute(2, 3, 1, 0).reshape(4 * co, ci, 1, 1)        # rows (dy, dx, co)
+        y = ops.conv(x1, w2, b.repeat(4) if b is not None else None)            # [N, 4 co, H, W], channels-last rows
+        n, _, h, wd = y.shape
+        y = y.permute(0, 2, 3, 1).reshape(n, h, wd, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * wd, co)
+        return y.permute(0, 3, 1, 2)                                # logical NCHW over channels-last memory
+
     def forward(self, x1, x2):
+        if not self.bilinear:
+            return self.conv(torch.cat([x2, self._deconv(x1)], dim=1))
         x1 = ops.conv(x1, self.conv1x1.weight, self.conv1x1.bias)
         if (x1.shape[2] * 2, x1.shape[3] * 2) == tuple(x2.shape[2:]):
             x = ops.upcat(x1, x2)                       # cat([x2, up(x1)]) written in place behind the skip

@@ -419,27 +419,6 @@ def run_sub(name, steps):
                       "peak_mem_gb": round(mem, 2), "loss_terms": terms, "roofline": roof, "whole_step": whole}))
 
 
-def dropin_loop_record(steps=6):
-    """The LITERAL drop-in: tools/dropin_loop.py - the reference trainer's loop body (train_arco_2d.py:284-435) over the names its
-    own import statements bind through dropin/, with torch's nn.Conv2d q_representation and torch.optim.SGD - at the headline
-    workload (batch_transform left out: it is not part of the boundary's arithmetic)."""
-    try:
-        env = dict(os.environ, DROPIN_TIME_STEPS=str(steps))
-        env.pop("PYTHONPATH", None)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_loop.py")], env=env, capture_output=True, text=True, timeout=900)
-        for ln in reversed(out.stdout.splitlines()):
-            if ln.startswith("DROPIN_TIME "):
-                r = json.loads(ln[len("DROPIN_TIME "):])
-                return {"sub": "dropin_reference_loop", "ms_per_step": r["ms_per_step"], "steps_per_s": round(1e3 / r["ms_per_step"], 3),
-                        "steps": r["steps"], "peak_mem_gb": r["peak_mem_gb"], "loss_terms": r["last"],
-                        "workload": "the reference trainer's own loop body (train_arco_2d.py:284-435, dense dataflow, torch nn.Conv2d "
-                                    "q_representation, torch.optim.SGD, the reference's EMA statements, no graphs / plans / flat buffers) "
-                                    "over the modules dropin/ binds; headline workload without batch_transform"}
-        return {"sub": "dropin_reference_loop", "error": (out.stderr or out.stdout)[-400:]}
-    except Exception as e:
-        return {"sub": "dropin_reference_loop", "error": repr(e)}
-
-
 def sub_record(name, steps):
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--sub", name, "--sub_steps", str(steps)],
@@ -631,7 +610,7 @@ def main():
             del stepper
             batches.clear()
             torch.cuda.empty_cache()
-            out["configs"] = [sub_record(n, a.sub_steps) for n in SUBS] + [dropin_loop_record(a.sub_steps)]
+            out["configs"] = [sub_record(n, a.sub_steps) for n in SUBS]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

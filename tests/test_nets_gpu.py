@@ -225,3 +225,33 @@ def test_pooling_fused_into_the_activation_pass_is_bit_identical(groups):
         assert torch.equal(res[0][1][n], res[1][1][n]), n
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+def test_upblock_conv_transpose_branch_matches_torch():
+    """UpBlock(bilinear=False) (unetWithArgs.py:76-77: nn.ConvTranspose2d k2 s2 instead of 1x1 conv + bilinear) - unreachable from
+    UNet, but a drop-in user may construct it.  Same state_dict keys as the reference module; output and every gradient against
+    torch's own conv_transpose2d + the same ConvBlock arithmetic on the CPU (float64)."""
+    import torch.nn.functional as F
+    from arco_amd.networks.unetWithArgs import UpBlock
+    torch.manual_seed(11)
+    blk = UpBlock(32, 16, 16, 0.0, bilinear=False).cuda().train()
+    assert sorted(k for k in blk.state_dict() if k.startswith("up.")) == ["up.bias", "up.weight"]
+    assert tuple(blk.up.weight.shape) == (32, 16, 2, 2)
+    x1 = torch.randn(2, 32, 12, 10, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x2 = torch.randn(2, 16, 24, 20, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = blk(x1, x2)
+    probe = probe_like(y, 5)
+    (y * probe).sum().backward()
+    # float64 restatement on the CPU: torch's transposed conv, then the ConvBlock (conv3x3 + train-mode BN + LeakyReLU, twice)
+    sd = {k: v.detach().double().cpu() for k, v in blk.state_dict().items()}
+    a1 = x1.detach().double().cpu().requires_grad_(True); a2 = x2.detach().double().cpu().requires_grad_(True)
+    w_up = sd["up.weight"].clone().requires_grad_(True)
+    z = torch.cat([a2, F.conv_transpose2d(a1, w_up, sd["up.bias"], stride=2)], dim=1)
+    for i in (0, 4):
+        z = F.conv2d(z, sd[f"conv.conv_conv.{i}.weight"], sd[f"conv.conv_conv.{i}.bias"], padding=1)
+        z = F.batch_norm(z, None, None, sd[f"conv.conv_conv.{i + 1}.weight"], sd[f"conv.conv_conv.{i + 1}.bias"], training=True, eps=1e-5)
+        z = F.leaky_relu(z, 0.01)
+    (z * probe.double().cpu()).sum().backward()
+    close(y, z.detach().numpy(), 2e-4, 2e-5)
+    for got, ref in ((x1.grad, a1.grad), (x2.grad, a2.grad), (blk.up.weight.grad, w_up.grad)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
