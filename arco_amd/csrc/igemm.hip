@@ -915,6 +915,10 @@ static int launch_image_conv(const IgemmArgs& a, hipStream_t st, int* q) {
 }
 static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb) {
   if (taps == 1 && a.mma == 3) {      // split-bf16 GEMMs: K chunks of 32
+    if (!nmb) {                       // the wide many-tile GEMMs: the software-pipelined kernel of gemm_sp.hip (launches only: the
+      const int r = gemm_sp_dispatch(a, st, nullptr);      // tile queries describe igemm_kernel, which every statistics launch uses)
+      if (r != -1) return r;
+    }
     if (a.Npad <= 16) return launch_igemm<1, 256, 16, 4, 1, 32, false>(a, st, nmb);
     if (a.Npad <= 32) return launch_igemm<1, 128, 32, 4, 1, 32, false>(a, st, nmb);
     if (a.M * (long)a.Npad <= 4096l * 1024) {

@@ -64,6 +64,9 @@ int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
 // conv_sp.hip: the resident-weights 3x3x3 kernel of the 16 -> 16 full-resolution level (split-bf16); -1 when the shape is not taken
 int conv3d_rw_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
 
+// gemm_sp.hip: the software-pipelined split-bf16 1x1 GEMM (wide, many-tile launches without BN statistics); -1 when the shape is not taken
+int gemm_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
+
 // conv_h.hip: f16 activation storage (mma == 4).  hconv_dispatch: forward / data gradient of the 3x3x3 and 1x1x1 convolutions on
 // f16 tensors (a.A, a.C point at f16 rows, a.Wp at the f16 pack [tap][Npad][ceil32(K)], a.Kpad = ceil32(K)); q as above.
 // hwgrad_dispatch: their weight gradient from f16 dZ / X (fp32 slabs in ws, fp32 dW).

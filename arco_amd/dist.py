@@ -25,8 +25,16 @@ import torch.distributed as td
 from . import _contrast
 
 
+# ARCO_FORCE_DIST=1: a world of ONE rank is treated as distributed - init() creates a one-rank `nccl` group and every exchange of
+# this module (two gradient buckets, counter all-gather, tail broadcast, prototype all-reduce, percentile histograms, the f16
+# overflow flag) goes through RCCL and torch's ProcessGroupNCCL stream / event machinery inside the default two-stream,
+# graph-replayed step.  A one-GPU box cannot measure scaling; it CAN show that the collectives' stream sits correctly beside the
+# step's two streams (tests/test_dist_gpu.py::test_forced_one_rank_nccl_group_*; bench.py sub-record `forced_dist_world1`).
+FORCE = os.environ.get("ARCO_FORCE_DIST", "0") == "1"
+
+
 def is_dist():
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    return td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or FORCE)
 
 
 def local_rank():
@@ -40,11 +48,17 @@ def local_rank():
 def init(backend=None):
     """Initialise from the torchrun environment (RANK/WORLD_SIZE/MASTER_*).  Returns (rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not td.is_initialized():
+    if (world > 1 or FORCE) and not td.is_initialized():
         if backend is None:
             backend = os.environ.get("ARCO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank())
+        if world == 1 and "MASTER_ADDR" not in os.environ:          # forced one-rank group outside torchrun
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         td.init_process_group(backend=backend)
     if is_dist():
         _contrast.key_gather_hook = gather_keys

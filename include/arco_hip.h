@@ -125,6 +125,11 @@ int arco_conv_config_mma(int taps, int NB, int H, int W, int Cin, int Cout, long
  * or ARCO_CONV_SP=0 in the environment for off) lets the eligible wide 2-D shapes take it, 0 keeps every shape on
  * igemm_kernel.  Returns the previous setting.  Tile counts differ: query arco_conv_mblocks_mma after switching.   */
 int arco_conv_sp_set(int on);
+/* A/B switch of the software-pipelined split-bf16 1x1 GEMM (gemm_sp.hip; the wide many-tile FeatureExtractor / q_representation GEMMs,
+ * model_2D.py:20-55, train_arco_2d.py:231-234): on = 0 (or ARCO_GEMM_SP=0) keeps every GEMM on igemm_kernel; min_tiles > 0 also sets the
+ * smallest 128 x 128 tile count the kernel takes (default 2048, ARCO_GEMM_SP_TILES).  Outputs are bit-identical either way.  Returns the
+ * previous `on`. */
+int arco_gemm_sp_set(int on, long min_tiles);
 /* out = conv(in) (+bias)(+residual); optional per-channel (sum, sumsq) block partials for train-mode BN. */
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,

@@ -525,25 +525,11 @@ def test_cfg2_default_step_is_reproducible_at_full_size():
         st.step(*_acdc_batch(20 + it))
     torch.cuda.synchronize()
     assert st.s_train_lu.captured and st.s_train_tps.captured
-    snap = dict(p=st.optimizer.flat_p.clone(), b=st.optimizer.flat_buf.clone(), started=list(st.optimizer._started),
-                lr=[g['lr'] for g in st.optimizer.param_groups],
-                sd=[{k: v.clone() for k, v in m.state_dict().items()} for m in (st.model, st.ema_model, st.k_feature_extractor)],
-                bank=[[t.clone() for t in m] for m in st.memobank],
-                ptr=[q.clone() if torch.is_tensor(q) else q for q in st.queue_ptrlis], it=st.iter_num)
+    snap = _snapshot(st)
     batch = _acdc_batch(24)
     ref, worst = None, 0.0
     for trial in range(60):
-        with torch.no_grad():
-            st.optimizer.flat_p.copy_(snap["p"]); st.optimizer.flat_buf.copy_(snap["b"]); st.optimizer._started = list(snap["started"])
-            for g, lr in zip(st.optimizer.param_groups, snap["lr"]):
-                g['lr'] = lr
-            for m, sd in zip((st.model, st.ema_model, st.k_feature_extractor), snap["sd"]):
-                for k, v in m.state_dict().items():
-                    v.copy_(sd[k])
-            st.memobank = [[t.clone() for t in m] for m in snap["bank"]]
-            st.queue_ptrlis = [q.clone() if torch.is_tensor(q) else q for q in snap["ptr"]]
-        st.iter_num = snap["it"]
-        ops.bump_weight_epoch()
+        _restore(st, snap)
         seed_all(804)
         st.step(*batch)
         torch.cuda.synchronize()

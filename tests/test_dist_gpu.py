@@ -17,3 +17,31 @@ def test_two_ranks_stay_identical():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "DDP_OK" in out.stdout
+
+
+def test_forced_one_rank_nccl_group_equals_the_plain_step_and_stays_reproducible():
+    """ARCO_FORCE_DIST=1: a one-rank `nccl` group, every exchange of arco_amd/dist.py issued through RCCL /
+    ProcessGroupNCCL inside the default two-stream, graph-replayed step at the headline size.  The run must (i) issue the step's
+    collectives (two gradient buckets + counters + prototypes + percentile sums every step), (ii) give the loss terms and final weights
+    of the plain single-process run (a one-rank sum is the identity; the rank mean divides by 1), (iii) reproduce one step's gradient
+    over 30 executions to 1e-5 with RCCL's stream present."""
+    import json
+    res = {}
+    for force in ("0", "1"):
+        env = dict(os.environ, ARCO_FORCE_DIST=force, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "force_dist_check.py"), "30"], env=env, capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        res[force] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("FORCE_DIST ")][-1][len("FORCE_DIST "):])
+    plain, forced = res["0"], res["1"]
+    assert forced["dist"] and not plain["dist"]
+    c = forced["collectives_per_step"]
+    assert c["all_reduce"] >= 4 and c["all_gather"] >= 1, c              # buckets (2) + prototypes + percentile sums; counter table
+    for a, b in zip(plain["terms"], forced["terms"]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-5 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    assert abs(plain["checksum"] - forced["checksum"]) <= 1e-6 * plain["checksum"]
+    assert forced["worst_repro"] <= 1e-5 and plain["worst_repro"] <= 1e-5, (forced["worst_repro"], plain["worst_repro"])
+    print("ms per step plain / forced one-rank nccl:", plain["ms_per_step"], forced["ms_per_step"], "collectives per step:", c)

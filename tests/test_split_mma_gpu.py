@@ -168,3 +168,35 @@ def test_narrow_planes_run_on_the_resident_weights_kernel(shape):
     for k in (1, 2):
         assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-5 * nb * s * s / 1024)
     assert torch.allclose(res[1][1], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+def test_pipelined_gemm_is_bit_identical_to_the_implicit_gemm_kernel():
+    """gemm_sp_kernel (csrc/gemm_sp.hip: persistent workgroups, loader / MFMA wave roles, 64 x 256 tiles) computes every product of
+    igemm_kernel<1,...,MMA=3> in the same order: outputs equal BIT FOR BIT on interior, ragged (M, N, K edges) and residual / bias
+    shapes; both agree with a float64 GEMM to split-bf16 accuracy.  (model_2D.py:20-55, train_arco_2d.py:231-234 at production widths.)"""
+    from arco_amd import ops, _lib as L
+    prev_mma = ops.CONV_MMA
+    ops.CONV_MMA = 3
+    torch.manual_seed(3)
+    try:
+        for (M, K, N, res, bias) in ((8192, 496, 496, False, False), (4100, 480, 480, True, False), (3001, 100, 252, True, True),
+                                     (16384, 32, 224, True, False), (6000, 240, 16, False, False), (5000, 448, 448, False, True)):
+            x = torch.randn(M, K, device="cuda") * torch.exp(torch.randn(M, 1, device="cuda"))
+            w = torch.randn(N, K, 1, 1, device="cuda") / K ** 0.5
+            r = torch.randn(M, N, device="cuda") if res else None
+            b = torch.randn(N, device="cuda") if bias else None
+            outs = []
+            for on in (0, 1):
+                L.query("arco_gemm_sp_set", on, 1)
+                ops._cfg_cache.clear()
+                wp = ops.pack_weight(w, 1, 0)
+                o, _ = ops.conv_raw(x, K, K, wp, N, 1, 1, M, 1, bias=b, residual=r, ld_res=N if res else 0)
+                outs.append(o.permute(0, 2, 3, 1).reshape(M, N).clone())
+            assert torch.equal(outs[0], outs[1]), (M, K, N)
+            ref = x.double() @ w.view(N, K).double().t() + (r.double() if res else 0) + (b.double() if bias else 0)
+            scale = (x.double().abs() @ w.view(N, K).double().abs().t()).max()
+            assert float((outs[1].double() - ref).abs().max() / scale) < 2e-6, (M, K, N)
+    finally:
+        L.query("arco_gemm_sp_set", 1, 2048)
+        ops._cfg_cache.clear()
+        ops.CONV_MMA = prev_mma
