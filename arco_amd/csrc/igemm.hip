@@ -1203,6 +1203,83 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// 1x1 weight gradient of the WIDE heads (FeatureExtractor fea3 / fea4, q_representation: model_2D.py:46-53, train_arco_2d.py:231-234;
+// dW [496 x 496] = dY^T [496 x M] . X [M x 496] at M = 5 x 10^5): 128 x 128 output blocks, each WAVE owns a 64 x 64 quadrant for
+// all 128 pixels of a tile.  wgrad_kernel<64,64> gives every wave the whole 64 x 64 block for a quarter of the pixels: its
+// 8 x 8 = 64 blocks read each operand eight times (16.6 GB at M = 524 288: 53 TFLOP/s, bound by L2 / HBM traffic); here 4 x 4
+// blocks read each operand four times, no cross-wave reduction, one workgroup per CU (139 KB of LDS), the next tile's 128 KB
+// travelling global -> registers under the current tile's 512 fp32 MFMAs per wave.  Same products and per-block summation
+// order over pixels as wgrad_kernel within a slab; slabs are summed in fixed order by wgrad_reduce_kernel.
+// ---------------------------------------------------------------------------
+template <int TP>       // pixels per staged tile: 128 (139 KB of LDS, one workgroup per CU) or 64 (70 KB, two per CU)
+__global__ __launch_bounds__(256) void wgrad_q_kernel(WgradArgs a) {
+  constexpr int CO_B = 128, CI_B = 128, LDZ = CO_B + WGRAD1_PAD, LDA = CI_B + WGRAD1_PAD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zs = smem;                 // [TP][LDZ]
+  float* Xs = smem + TP * LDZ;      // [TP][LDA]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int co0 = blockIdx.y * CO_B, ci0 = blockIdx.z * CI_B;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  constexpr int NP = TP * (128 / 4) / 256;           // 16-byte pieces per thread, tile and operand (16 / 8)
+  f32x4 rz[NP], rx[NP];
+  auto fetch = [&](int t) {
+    const long m0 = (long)t * TP;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int idx = tid + it * 256, p = idx >> 5, q = idx & 31;
+      const long m = m0 + p;
+      const int cz = co0 + 4 * q, cx = ci0 + 4 * q;
+      // clamped addresses + a select: branch-free loads (a conditional load puts a vmcnt(0) behind every piece)
+      const bool okz = m < a.M && cz < a.Cout, okx = m < a.M && cx < a.Cin;
+      const f32x4 vz = *reinterpret_cast<const f32x4*>(okz ? a.dZ + m * a.ldz + cz : a.dZ);
+      const f32x4 vx = *reinterpret_cast<const f32x4*>(okx ? a.Ain + m * a.lda + cx : a.Ain);
+      rz[it] = okz ? vz : f32x4{0, 0, 0, 0};
+      rx[it] = okx ? vx : f32x4{0, 0, 0, 0};
+    }
+  };
+  int t = blockIdx.x;
+  if (t < a.n_tiles) fetch(t);
+  for (; t < a.n_tiles; t += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int idx = tid + it * 256, p = idx >> 5, q = idx & 31;
+      *reinterpret_cast<f32x4*>(&Zs[p * LDZ + 4 * q]) = rz[it];
+      *reinterpret_cast<f32x4*>(&Xs[p * LDA + 4 * q]) = rx[it];
+    }
+    __syncthreads();
+    if (t + (int)gridDim.x < a.n_tiles) fetch(t + gridDim.x);
+#pragma unroll 4
+    for (int ks = 0; ks < TP / 4; ++ks) {
+      const int p = ks * 4 + g;
+      float zf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) zf[i] = Zs[p * LDZ + (wr * 4 + i) * 16 + li];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = Xs[p * LDA + (wc * 4 + j) * 16 + li];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = a.partial + ((long)blockIdx.x * a.CoutPad) * a.CinPad;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(long)(co0 + (wr * 4 + i) * 16 + 4 * g + r) * a.CinPad + ci0 + (wc * 4 + j) * 16 + li] = acc[i][j][r];
+}
+
+// ---------------------------------------------------------------------------
 // all-taps weight gradient for the shallow layers (Cout, Cin <= 32): one block owns a tile of 8x16 output
 // pixels of one plane, stages the dZ tile and the input HALO patch once in LDS and accumulates all 9 taps of
 // the plane (3-D: the depth tap dd = blockIdx.z, input plane x+dd-1) -> both operands are read from HBM/L2
@@ -2042,6 +2119,34 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
 #undef WH
     launch_wgrad_reduce(st, ws, (int)chunks, taps, a.CoutPad, a.CinPad, Cout, Cin, dW, accumulate);
     return arco_launch_status();
+  }
+  {   // wide 1x1 gradients over many pixels: 128 x 128 blocks, one workgroup per CU (wgrad_q_kernel); A/B knob ARCO_WGRAD_Q=0
+    static const int wq = getenv("ARCO_WGRAD_Q") ? atoi(getenv("ARCO_WGRAD_Q")) : 1;
+    const int cop = (Cout + 127) / 128 * 128, cip = (Cin + 127) / 128 * 128;
+    const long yzq = (long)(cop / 128) * (cip / 128);
+    long chq = 256 / yzq; if (chq < 1) chq = 1; if (chq > a.n_tiles) chq = a.n_tiles;
+    if (wq && taps == 1 && a.mma != 4 && Cout >= 192 && Cin >= 192 && a.M >= 32768 && (Cout & 3) == 0 && (Cin & 3) == 0 &&
+        (ld_dz & 3) == 0 && (ld_in & 3) == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+        chq * cop * cip <= arco_wgrad_ws_floats(Cout, Cin, taps, a.M)) {
+      a.CoutPad = cop; a.CinPad = cip;
+      static const int tp = getenv("ARCO_WGRAD_Q_TP") ? atoi(getenv("ARCO_WGRAD_Q_TP")) : 64;
+      if (tp == 64) {
+        a.n_tiles = (int)((a.M + 63) / 64);
+        long ch2 = 512 / yzq; if (ch2 < 1) ch2 = 1; if (ch2 > a.n_tiles) ch2 = a.n_tiles;
+        if (ch2 * cop * cip <= arco_wgrad_ws_floats(Cout, Cin, taps, a.M)) chq = ch2;
+        constexpr int shq = 64 * (2 * (128 + WGRAD1_PAD)) * 4;
+        static bool attr_q = false;
+        if (!attr_q) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_q_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, shq); attr_q = true; }
+        hipLaunchKernelGGL(wgrad_q_kernel<64>, dim3((unsigned)chq, cop / 128, cip / 128), dim3(256), shq, st, a);
+      } else {
+        constexpr int shq = 128 * (2 * (128 + WGRAD1_PAD)) * 4;
+        static bool attr_q = false;
+        if (!attr_q) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_q_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, shq); attr_q = true; }
+        hipLaunchKernelGGL(wgrad_q_kernel<128>, dim3((unsigned)chq, cop / 128, cip / 128), dim3(256), shq, st, a);
+      }
+      launch_wgrad_reduce(st, ws, (int)chq, taps, a.CoutPad, a.CinPad, Cout, Cin, dW, accumulate);
+      return arco_launch_status();
+    }
   }
   const long yz = (long)(a.CoutPad / co_b) * (a.CinPad / ci_b) * taps;
   static const long target1 = getenv("ARCO_WGRAD1_TARGET") ? atol(getenv("ARCO_WGRAD1_TARGET")) : 512;   // two resident workgroups per CU, 6-13 tiles each (2048: 3 tiles each, a third of them behind an exposed first fetch; 4x the slabs)

@@ -39,9 +39,13 @@ def test_forced_one_rank_nccl_group_equals_the_plain_step_and_stays_reproducible
     assert forced["dist"] and not plain["dist"]
     c = forced["collectives_per_step"]
     assert c["all_reduce"] >= 4 and c["all_gather"] >= 1, c              # buckets (2) + prototypes + percentile sums; counter table
-    for a, b in zip(plain["terms"], forced["terms"]):
+    # The exchanged quantities pass through other arithmetic (count-weighted prototype sums divided by the counts again, the phased
+    # percentile selection): equal to fp32 rounding in the first step, and six chained steps of training amplify a 1e-7 difference
+    # like any other (measured 5e-5 on the contrastive term at step 5) - first step strict, trajectory at north_star's 1e-3
+    for it, (a, b) in enumerate(zip(plain["terms"], forced["terms"])):
         for k in a:
-            assert abs(a[k] - b[k]) <= 2e-5 * max(1.0, abs(a[k])), (k, a[k], b[k])
-    assert abs(plain["checksum"] - forced["checksum"]) <= 1e-6 * plain["checksum"]
+            tol = 2e-6 if it == 0 else 1e-3
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (it, k, a[k], b[k])
+    assert abs(plain["checksum"] - forced["checksum"]) <= 1e-5 * plain["checksum"]
     assert forced["worst_repro"] <= 1e-5 and plain["worst_repro"] <= 1e-5, (forced["worst_repro"], plain["worst_repro"])
     print("ms per step plain / forced one-rank nccl:", plain["ms_per_step"], forced["ms_per_step"], "collectives per step:", c)

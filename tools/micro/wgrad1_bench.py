@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from arco_amd import ops
-for m, co, ci in [(16384, 448, 448), (1024, 496, 496), (4096, 480, 480), (16384, 384, 128), (262144, 16, 32), (4096, 128, 256), (65536, 32, 64), (4096, 256, 256)]:
+for m, co, ci in [(524288, 496, 496), (131072, 480, 480), (65536, 448, 448), (40000, 252, 200), (16384, 448, 448), (1024, 496, 496), (4096, 480, 480), (16384, 384, 128), (262144, 16, 32), (4096, 128, 256), (65536, 32, 64), (4096, 256, 256)]:
     xs = [torch.randn(1, m, 1, ci, device="cuda").permute(0, 3, 1, 2) for _ in range(4)]
     gs = [torch.randn(1, m, 1, co, device="cuda").permute(0, 3, 1, 2) for _ in range(4)]
     wt = torch.zeros(co, ci, 1, 1, device="cuda")
