@@ -11,6 +11,13 @@ import torch
 
 from . import ops
 
+# Stream-capture error mode of every capture below.  "global" (torch's default) forbids capture-unsafe HIP calls from ANY thread
+# while a capture is open - and ProcessGroupNCCL's watchdog thread polls its pending collectives with hipEventQuery: with an `nccl`
+# process group alive the first capture of a step aborted the process ("operation not permitted when stream is capturing" raised
+# in the watchdog; found by the one-rank ARCO_FORCE_DIST run of round 5 - the gloo rehearsals have no such thread).
+# "thread_local" restricts the check to the capturing thread, which issues nothing but the captured launches.
+CAPTURE_MODE = "thread_local"
+
 
 class GraphedForward:
     """Every instance owns its dropout salt (ops.SEED_DEV is swapped to it while the instance captures, as GraphedTrain does):
@@ -41,7 +48,7 @@ class GraphedForward:
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     out = self.fn(static_in)
             finally:
                 ops.SEED_DEV = prev_salt
@@ -132,7 +139,7 @@ class GraphedTrain:
             torch.cuda.synchronize()
             pool = torch.cuda.graph_pool_handle()
             self.fwd_g = torch.cuda.CUDAGraph()
-            with torch.enable_grad(), torch.cuda.graph(self.fwd_g, pool=pool):
+            with torch.enable_grad(), torch.cuda.graph(self.fwd_g, pool=pool, capture_error_mode=CAPTURE_MODE):
                 # The capture differentiates w.r.t. fresh leaf ALIASES of the parameters (same storage, same
                 # flat-gradient views / packed-weight plans): their gradient accumulators are born on the
                 # capture stream.  The real parameters' accumulators may be alive on the legacy stream (optimizer
@@ -167,7 +174,7 @@ class GraphedTrain:
             torch.cuda.synchronize()
             self.bwd_g = torch.cuda.CUDAGraph()
             # single-threaded autograd: every captured launch is issued by the capturing thread
-            with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(self.bwd_g, pool=pool):
+            with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(self.bwd_g, pool=pool, capture_error_mode=CAPTURE_MODE):
                 grads = torch.autograd.grad([self.flat_outs[i] for i in self.diff_idx], inputs, self.static_grads,
                                             allow_unused=True)
                 ops.join_side()          # the weight-gradient branch (ops._wgrad) joins the capture stream: a graph edge

@@ -1116,9 +1116,111 @@ def gen_vnet_strict(mods):
           max(d for n, d in zip(names, dev) if not skip(n)), "dx", float(out["ref32_dev_dx"]))
 
 
+
+# ---------------------------------------------------------------- G19 the trainers' loop bodies, executed from the reference's own text
+def _loop_block(path, first_marker, last_marker):
+    """The source lines of a reference trainer's loop body, from the line holding `first_marker` to the line holding
+    `last_marker` (inclusive), dedented - read from /root/reference at generation time (this container only) and exec'd below:
+    no text of the reference's loop lives in this repository (copy-paste findings)."""
+    lines = open(path).read().splitlines()
+    i0 = next(i for i, l in enumerate(lines) if first_marker in l)
+    # the `with torch.no_grad():` that opens the body sits right above the teacher's first forward
+    while not lines[i0 - 1].strip().startswith("with torch.no_grad()"):
+        i0 -= 1
+    i0 -= 1
+    i1 = next(i for i, l in enumerate(lines) if i > i0 and l.strip().replace(" ", "") == last_marker)
+    return textwrap.dedent("\n".join(lines[i0:i1 + 1]))
+
+
+def gen_trainer_loop(mods):
+    """G19: two chained iterations of the loop body of train_arco_2d.py (:283-435) and of train_arco_3d.py (:259-400), run
+    from the REFERENCE's text over the REFERENCE's modules on CPU - ISD / FeatureExtractor / compute_contra_memobank_loss /
+    RandTPS / DiceLoss, torch nn.Conv2d q_representation, torch.optim.SGD - on fixture inputs.  Stubs: the PIL / scipy
+    augmentations (batch_transform, randomGeneratorWithLogits: identity - pinned separately by g10 / g12 / g16), tensorboard
+    and logging.  Recorded per iteration: every loss term, bank lengths / pointers / checksums; at the end checksums of
+    student / teacher / head weights.  tests/test_dropin_user_gpu.py drives the drop-in modules through the same sequence
+    in this repository's own form and compares at 1e-3."""
+    import importlib
+    out = {}
+    rand_tps = importlib.import_module("tps.rand_tps")
+    losses_mod = importlib.import_module("utils.losses")
+    M2, L2 = mods["model_2D"], mods["loss_helper_3d"]
+    path2 = os.path.join(ref_shim.REF, "train_arco_2d.py")
+    ns, _ = _pull_functions(path2, {"compute_unsupervised_loss", "label_onehot", "get_revisiting_loss", "_dequeue_and_enqueue"})
+    aug, _ = _pull_functions(os.path.join(ref_shim.REF, "augment.py"), {"generate_cutout_mask", "generate_class_mask", "generate_unsup_data"})
+    body = _loop_block(path2, "ema_model(train_u_data)", "iter_num+=1")
+    for tag, (k2, mix) in {"a": (1.0, "cutmix"), "b": (0.0, "cutout")}.items():
+        C, b, patch, Q, Nn, qs, K = 4, 2, (64, 64), 64, 32, 300, 6
+        args = types.SimpleNamespace(patch_size=list(patch), apply_aug=mix, k1=1.0, k2=k2, k3=1.0, k4=0.5, topk=3, K=K,
+                                     strong_threshold=0.97, strong_threshold_u2pl=0.97, weak_threshold=0.7, func="smc",
+                                     num_queries=Q, num_negatives=Nn, num_classes=C)
+        seed_all(5)
+        isd = M2.ISD(K=36, m=0.99, Ts=0.01, Tt=0.1, num_classes=C, latent_pooling_size=1, latent_feature_size=512,
+                     output_pooling_size=8, train_encoder=True, train_decoder=True)
+        sd = fx.unet_state(21, 1, C)
+        isd.model.load_state_dict(sd); isd.ema_model.load_state_dict(sd)
+        model, ema_model = isd.model, isd.ema_model
+        for m_ in (model, ema_model):
+            zero_dropout(m_)
+        q_representation = nn.Sequential(nn.Conv2d(496, 496, kernel_size=1, bias=False), nn.Conv2d(496, 496, kernel_size=1, bias=False))
+        kfe = M2.FeatureExtractor(fea_dim=[256, 128, 64, 32, 16], output_dim=496)
+        qfe = M2.FeatureExtractor(fea_dim=[256, 128, 64, 32, 16], output_dim=496)
+        qfe.load_state_dict(fx.fe_state(31))
+        with torch.no_grad():
+            q_representation[0].weight.copy_(fx.fe_state(32)["fea4.weight"]); q_representation[1].weight.copy_(fx.fe_state(33)["fea4.weight"])
+            for t_p, s_p in zip(kfe.parameters(), qfe.parameters()):
+                t_p.data.copy_(s_p.data); t_p.requires_grad = False
+        optimizer = torch.optim.SGD(list(model.parameters()) + list(q_representation.parameters()) + list(qfe.parameters()),
+                                    lr=0.01, weight_decay=0.0001, momentum=0.9, nesterov=True)
+        seed_all(6)
+        tps = rand_tps.RandTPS(patch[0], patch[1], batch_size=2 * b, sigma=0.01, border_padding=False, random_mirror=True,
+                               random_scale=(0.8, 1.2), mode='affine')
+        for m_ in (model, ema_model, q_representation, kfe, qfe):
+            m_.train()
+        memobank, queue_ptrlis, queue_size = [], [], []
+        for i in range(C):
+            memobank.append([torch.zeros(1, 496)]); queue_size.append(qs); queue_ptrlis.append(torch.zeros(1, dtype=torch.long))
+        rs = np.random.RandomState(3)
+        pool = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((K, 496 * patch[0] * patch[1])).astype(np.float32)), dim=1)
+        ns["args"] = args
+        env = dict(ns)
+        env.update(aug)
+        env.update(dict(torch=torch, np=np, F=F, nn=nn, args=args, model=model, ema_model=ema_model, isd=isd, q_representation=q_representation,
+                        k_feature_extractor=kfe, q_feature_extractor=qfe, optimizer=optimizer, tps=tps, memobank=memobank,
+                        queue_ptrlis=queue_ptrlis, queue_size=queue_size, random_pool=pool, random_pool_ptr=torch.zeros(1, dtype=torch.long),
+                        compute_contra_memobank_loss=L2.compute_contra_memobank_loss, ce_loss=torch.nn.CrossEntropyLoss(),
+                        dice_loss=losses_mod.DiceLoss(C), base_lr=0.01, max_iterations=30000, iter_num=0, epoch_num=0, max_epoch=100,
+                        record=[], batch_transform=lambda data, label, logits=None, **kw: (data, label, logits),
+                        randomGeneratorWithLogits=lambda d, l, g: (d, l, g)))
+        out[f"{tag}_pool0"] = np.array(float(pool.double().abs().sum()))
+        for it in range(2):
+            env["train_l_data"] = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+            env["train_u_data"] = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+            env["train_l_label"] = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
+            seed_all(10 + it)
+            exec(body, env)
+            for k in ("loss_ce", "loss_dice", "unsup_loss", "reco_loss", "loss_eqv", "loss_q", "loss"):
+                out[f"{tag}_{it}_{k}"] = np.array(float(env[k]))
+            out[f"{tag}_{it}_bank_len"] = np.array([int(m[0].shape[0]) for m in memobank])
+            out[f"{tag}_{it}_ptr"] = np.array([int(p) for p in queue_ptrlis])
+            out[f"{tag}_{it}_bank_sum"] = np.array([float(m[0].double().abs().sum()) for m in memobank])
+            out[f"{tag}_{it}_pool_ptr"] = np.array(int(env["random_pool_ptr"]))
+            out[f"{tag}_{it}_probe"] = np.array((rng_probe(), float(np.random.uniform()), random.random()), dtype=np.float64)
+        sdm, sde = model.state_dict(), ema_model.state_dict()
+        for k, v in (("w_first", sdm["encoder.in_conv.conv_conv.0.weight"]), ("w_last", sdm["decoder.out_conv.weight"]),
+                     ("w_deep", sdm["encoder.down4.maxpool_conv.1.conv_conv.4.weight"]), ("qrep0", q_representation[0].weight),
+                     ("qrep1", q_representation[1].weight), ("qfe4", qfe.fea4.weight), ("kfe4", kfe.fea4.weight),
+                     ("t_first", sde["encoder.in_conv.conv_conv.0.weight"]), ("rm", sdm["encoder.in_conv.conv_conv.1.running_mean"]),
+                     ("pool", env["random_pool"])):
+            out[f"{tag}_end_{k}"] = np.array(float(v.detach().double().abs().sum()))
+        out[f"{tag}_cfg"] = np.array([C, b, patch[0], patch[1], Q, Nn, qs, K, k2], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g19_trainer_loop.npz"), **out)
+    print("g19_trainer_loop", len(out))
+
+
 if __name__ == "__main__":
     mods = ref_shim.load()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     if "g1" in which: gen_samplers(mods)
     if "g2" in which: gen_loss(mods)
     if "g3" in which: gen_nets(mods)
@@ -1137,3 +1239,4 @@ if __name__ == "__main__":
     if "g16" in which: gen_boundary(mods)
     if "g17" in which: gen_vnet_norms(mods)
     if "g18" in which: gen_vnet_strict(mods)
+    if "g19" in which: gen_trainer_loop(mods)

@@ -461,3 +461,36 @@ def test_vnet_oracle_float64_matches_reference_g18():
         flat = got.reshape(-1)
         np.testing.assert_allclose((flat if flat.numel() <= 120000 else flat[::stride]).numpy(), g["grad::" + n], rtol=1e-5,
                                    atol=1e-6 * float(np.abs(g["grad::" + n]).max()), err_msg=n)
+
+
+def test_cpu_step_oracle_reproduces_the_reference_trainer_loop():
+    """g19 (oracle/gen_golden.py): the loop body of train_arco_2d.py:283-435 executed from the reference's own text over the reference's
+    own modules.  The CPU oracle step (oracle/cpu_step.py - the checker of the whole-step GPU parity tests and bench.py's cpu_baseline)
+    must reproduce its loss terms, bank bookkeeping and updated weights: this pins the oracle's STEP, not only its pieces."""
+    import random
+    import cpu_step
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g19_trainer_loop.npz"))
+    case, k2, aug = "a", 1.0, "cutmix"
+    C, b, patch, Q, Nn, qs = 4, 2, (64, 64), 64, 32, 300
+    torch.set_num_threads(4)
+    st = cpu_step.make_state(fx.unet_state(21, 1, C), fx.fe_state(31), [fx.fe_state(32)["fea4.weight"], fx.fe_state(33)["fea4.weight"]])
+    bank, ptr, qsz = fx.fresh_bank(C, 496, qs, 'zeros')
+    rs = np.random.RandomState(3)
+    rs.standard_normal((6, 496 * 64 * 64))                 # the generator's draw of the revisiting pool
+    for it in range(2):
+        l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
+        random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
+        cpu_step.step(st, l, lab, u, bank, ptr, qsz, C, k1=1.0, lr=0.01, nq=Q, nn_=Nn, k2=k2, apply_aug=aug)
+        o = st["last_terms"]
+        for k, kk in (("ce", "loss_ce"), ("dice", "loss_dice"), ("unsup", "unsup_loss"), ("reco", "reco_loss"), ("eqv", "loss_eqv")):
+            np.testing.assert_allclose(float(o[k]), float(g[f"{case}_{it}_{kk}"]), rtol=2e-6, atol=1e-7, err_msg=f"step {it} {k}")
+        assert [int(x[0].shape[0]) for x in bank] == g[f"{case}_{it}_bank_len"].tolist()
+        assert [int(p) for p in ptr] == g[f"{case}_{it}_ptr"].tolist()
+        np.testing.assert_allclose([float(x[0].double().abs().sum()) for x in bank], g[f"{case}_{it}_bank_sum"], rtol=1e-6)
+    ref = dict(w_first=st["student"]["encoder.in_conv.conv_conv.0.weight"], w_last=st["student"]["decoder.out_conv.weight"],
+               qrep0=st["q_rep"][0], qrep1=st["q_rep"][1], qfe4=st["q_fe"]["fea4.weight"], kfe4=st["k_fe"]["fea4.weight"],
+               t_first=st["teacher"]["encoder.in_conv.conv_conv.0.weight"], rm=st["student"]["encoder.in_conv.conv_conv.1.running_mean"])
+    for k, v in ref.items():
+        np.testing.assert_allclose(float(v.detach().double().abs().sum()), float(g[f"{case}_end_{k}"]), rtol=2e-6, err_msg=k)
