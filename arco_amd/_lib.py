@@ -93,6 +93,7 @@ _SIGS = {
     "arco_s2d3": [_P, _L, _I, _I, _I, _I, _I, _P, _L, _I, _P],
     "arco_trilinear_fwd": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "arco_trilinear_bwd": [_P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "arco_conv1x1_upres_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I],
     "arco_conv3d_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "arco_conv3d_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P],
     "arco_gather_upcat_rows3d": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],

@@ -5,6 +5,7 @@
 // flat-buffer SGD-Nesterov and EMA (train_arco_2d.py:248,306-308,432; model_2D.py:176-182).
 // All kernels: float4 per lane along the channel axis, grid-stride over pixels.
 #include "common.h"
+#include "igemm_args.h"
 
 __device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
   uint32_t s = v * 747796405u + 2891336453u;
@@ -567,12 +568,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
 }
 
 // ---- bilinear resize, align_corners=True (torch upsample_bilinear2d index math in fp32)
-__device__ __forceinline__ void ac_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
-  const float src = scale * (float)o;
-  i0 = (int)src; if (i0 > in_size - 1) i0 = in_size - 1;
-  i1 = i0 < in_size - 1 ? i0 + 1 : i0;
-  l1 = src - (float)i0;
-}
+// (ac_src: igemm_args.h)
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ X, long ldx, int NB, int Hi, int Wi,
                                                           int C, int Ho, int Wo, float* __restrict__ Y, long ldy) {
   const int q4 = C / 4;
@@ -821,8 +817,7 @@ __global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restr
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      o[e] = hz * (hy * (hx * v000[e] + lx * v001[e]) + ly * (hx * v010[e] + lx * v011[e])) +
-             lz * (hy * (hx * v100[e] + lx * v101[e]) + ly * (hx * v110[e] + lx * v111[e]));
+      o[e] = tl_blend1(v000[e], v001[e], v010[e], v011[e], v100[e], v101[e], v110[e], v111[e], hx, lx, hy, ly, hz, lz);
     *reinterpret_cast<f32x4*>(Y + (((n * Do + zo) * Ho + yo) * (long)Wo + xo) * ldy + c) = o;
   }
 }
@@ -900,8 +895,7 @@ __global__ __launch_bounds__(256) void gather_upcat_rows3d_kernel(const float* _
     f32x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      r[e] = hz * (hy * (hx * v000[e] + lx * v001[e]) + ly * (hx * v010[e] + lx * v011[e])) +
-             lz * (hy * (hx * v100[e] + lx * v101[e]) + ly * (hx * v110[e] + lx * v111[e]));
+      r[e] = tl_blend1(v000[e], v001[e], v010[e], v011[e], v100[e], v101[e], v110[e], v111[e], hx, lx, hy, ly, hz, lz);
     *reinterpret_cast<f32x4*>(o + c) = r;
   }
   const TH* h = hi + p * ldhi;

@@ -262,7 +262,44 @@ __global__ __launch_bounds__(512) void gemm_sp_kernel(IgemmArgs a) {
         const int v = tile0 + j * G8;
         const int mblk = v / a.n_nblocks;
         const long m0 = (long)mblk * BM; const int n0 = (v - mblk * a.n_nblocks) * BN;
-        {      // (gemm_sp_dispatch only takes 16-byte-aligned outputs / residuals with N % 4 == 0: pieces are whole or absent)
+        if (a.Rup) {
+          // residual = trilinear(align_corners) sample of the low-resolution tensor at this lane's four voxels: the index math and
+          // the lerp expression of trilinear_fwd_kernel (elementwise.hip), so that out == conv + trilinear(...) bit for bit
+          const float sd = a.oD > 1 ? (float)(a.uD - 1) / (float)(a.oD - 1) : 0.f, sh = a.oH > 1 ? (float)(a.uH - 1) / (float)(a.oH - 1) : 0.f,
+                      sw = a.oW > 1 ? (float)(a.uW - 1) / (float)(a.oW - 1) : 0.f;
+#pragma unroll
+          for (int at = 0; at < A_T; ++at) {
+            const long m = m0 + (wm * A_T + at) * 16 + li;
+            const bool mok = m < a.M;
+            long r = mok ? m : 0;
+            const int xo = (int)(r % a.oW); r /= a.oW; const int yo = (int)(r % a.oH); r /= a.oH; const int zo = (int)(r % a.oD); const long n = r / a.oD;
+            int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+            ac_src(zo, sd, a.uD, z0, z1, lz); ac_src(yo, sh, a.uH, y0, y1, ly); ac_src(xo, sw, a.uW, x0, x1, lx);
+            const float hz = 1.f - lz, hy = 1.f - ly, hx = 1.f - lx;
+            const float* b = a.Rup + (n * a.uD) * (long)a.uH * a.uW * a.ldrup;
+#define TLP(zz, yy, xx) (b + (((long)(zz) * a.uH + (yy)) * a.uW + (xx)) * a.ldrup)
+            const float *p000 = TLP(z0, y0, x0), *p001 = TLP(z0, y0, x1), *p010 = TLP(z0, y1, x0), *p011 = TLP(z0, y1, x1);
+            const float *p100 = TLP(z1, y0, x0), *p101 = TLP(z1, y0, x1), *p110 = TLP(z1, y1, x0), *p111 = TLP(z1, y1, x1);
+#undef TLP
+#pragma unroll
+            for (int ct = 0; ct < C_T; ++ct) {
+              const int nb = n0 + (wn * C_T + ct) * 16 + 4 * g;
+              const int nc = nb < a.N ? nb : 0;
+              const f32x4 v000 = *reinterpret_cast<const f32x4*>(p000 + nc), v001 = *reinterpret_cast<const f32x4*>(p001 + nc);
+              const f32x4 v010 = *reinterpret_cast<const f32x4*>(p010 + nc), v011 = *reinterpret_cast<const f32x4*>(p011 + nc);
+              const f32x4 v100 = *reinterpret_cast<const f32x4*>(p100 + nc), v101 = *reinterpret_cast<const f32x4*>(p101 + nc);
+              const f32x4 v110 = *reinterpret_cast<const f32x4*>(p110 + nc), v111 = *reinterpret_cast<const f32x4*>(p111 + nc);
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                o[e] = tl_blend1(v000[e], v001[e], v010[e], v011[e], v100[e], v101[e], v110[e], v111[e], hx, lx, hy, ly, hz, lz);
+              f32x4 bv = f32x4{0, 0, 0, 0};
+              if (a.bias && nb < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + nb);
+              const f32x4 out = (acc[at][ct] + bv) + o;
+              if (mok && nb < a.N) *reinterpret_cast<f32x4*>(a.C + m * a.ldc + nb) = out;
+            }
+          }
+        } else {      // (gemm_sp_dispatch only takes 16-byte-aligned outputs / residuals with N % 4 == 0: pieces are whole or absent)
           // 16-byte pieces, whole or absent: the residual loads of all 16 sub-tiles are issued back to back (clamped address
           // where the piece is outside the matrix), then added and stored - one memory round trip per tile, not sixteen
 #pragma unroll
@@ -363,6 +400,8 @@ int gemm_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   if ((a.N & 3) != 0 || (a.ldc & 3) != 0 || (reinterpret_cast<uintptr_t>(a.C) & 15) != 0) return -1;
   if (a.R && ((a.ldr & 3) != 0 || (reinterpret_cast<uintptr_t>(a.R) & 15) != 0)) return -1;
   if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) return -1;
+  if (a.Rup && (a.R || (a.ldrup & 3) != 0 || (reinterpret_cast<uintptr_t>(a.Rup) & 15) != 0 ||
+                a.M % ((long)a.oD * a.oH * a.oW) != 0)) return -1;
   if (a.Npad < 64 || a.Kpad < 32) return -1;
   const int mblocks = (int)((a.M + BM - 1) / BM), nblocks = (a.Npad + BN - 1) / BN;
   const long tiles = (long)mblocks * nblocks;

@@ -1987,6 +1987,25 @@ int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, fl
                          1, 0, stream);
 }
 
+// out[voxel][0..N) = W . in[voxel] + trilinear_align_corners(lo)[voxel]: FeatureExtractor_3d's fea_i over cat(up(x), f_i) with the
+// wide block of the weights pushed under the upsample (model_3D.py:46-58) - the 1x1x1 GEMM over the high-resolution map f_i with the
+// upsampled low-resolution product sampled in its epilogue instead of being written and read back (gemm_sp.hip).  Split-bf16 mode
+// only; ARCO_ERR_UNSUPPORTED when the pipelined kernel does not take the shape (the caller then upsamples separately).
+int arco_conv1x1_upres_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out, const float* lo,
+                           long ld_lo, int NV, int uD, int uH, int uW, int oD, int oH, int oW, void* stream) {
+  ARCO_CHECK_ARG(in && Wp && out && lo && K > 0 && N > 0 && NV > 0 && uD > 0 && uH > 0 && uW > 0 && oD > 0 && oH > 0 && oW > 0);
+  IgemmArgs a{};
+  a.A = in; a.lda = ld_in; a.Wp = Wp; a.N = N; a.K = K;
+  a.Npad = (N + 15) / 16 * 16;
+  a.C = out; a.ldc = ld_out;
+  a.NB = NV * oD; a.H = oH; a.W = oW; a.M = (long)NV * oD * oH * oW; a.D3 = oD;
+  a.stat_groups = 1; a.mma = 3;
+  a.Kg = (K + 31) / 32 * 2; a.Kpad = a.Kg * 16;
+  a.Rup = lo; a.ldrup = ld_lo; a.uD = uD; a.uH = uH; a.uW = uW; a.oD = oD; a.oH = oH; a.oW = oW;
+  const int r = gemm_sp_dispatch(a, as_stream(stream), nullptr);
+  return r == -1 ? ARCO_ERR_UNSUPPORTED : r;
+}
+
 // 3-D generalisation: NV volumes of D3 planes of H x W; taps in {1, 9 (per plane), 27 (3x3x3, pad 1)}
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,

@@ -20,7 +20,35 @@ struct IgemmArgs {
                                      // 3: split-bf16; 4: f16 activation STORAGE (A / C are f16 tensors, conv_h.hip)
   int Kg;                            // mma == 3: 16-k groups per packed weight row (= ceil32(K) / 16)
   int batch; long batchA, batchW, batchC;   // TAPS==1 batched GEMM: blockIdx.z = problem, operands at + z * stride (floats)
+  // gemm_sp.hip only: the residual is the TRILINEAR (align_corners) upsample of a low-resolution tensor, sampled in the epilogue -
+  // FeatureExtractor_3d's `fea_i(cat(up(x), f_i)) + cat(up(x), f_i)` with the wide block pushed under the upsample
+  // (model_3D.py:46-58; arco_amd/model_3D.py forward_lowres2): Rup [NV, uD, uH, uW] rows of N channels -> output rows [NV, oD, oH, oW]
+  const float* Rup; long ldrup; int uD, uH, uW, oD, oH, oW;
 };
+
+// The 8-corner trilinear blend as ONE fixed chain of multiplies and fused multiply-adds: every kernel that interpolates (the resize
+// kernel, the row gather of the row-sparse head, the GEMM epilogue of gemm_sp.hip) evaluates exactly this chain, so their results
+// agree bit for bit whatever the surrounding code lets the compiler contract (the plain expression `hz * (...) + lz * (...)` left
+// the choice of which product of each sum becomes the fma to the instruction scheduler: the fused epilogue differed from the resize
+// kernel in 1-2 ulp on 80 % of the elements)
+__device__ __forceinline__ float tl_blend1(float v000, float v001, float v010, float v011, float v100, float v101, float v110, float v111,
+                                           float hx, float lx, float hy, float ly, float hz, float lz) {
+  const float a0 = __builtin_fmaf(lx, v001, hx * v000), a1 = __builtin_fmaf(lx, v011, hx * v010);
+  const float a2 = __builtin_fmaf(lx, v101, hx * v100), a3 = __builtin_fmaf(lx, v111, hx * v110);
+  const float b0 = __builtin_fmaf(ly, a1, hy * a0), b1 = __builtin_fmaf(ly, a3, hy * a2);
+  return __builtin_fmaf(lz, b1, hz * b0);
+}
+
+// align_corners source index / weight (torch upsample index math in fp32; shared by the resize kernels and the fused epilogue)
+// (contraction off: `src - i0` must subtract from the ROUNDED product, as torch's CPU kernel does - left to -ffp-contract=fast the
+//  compiler fused it into fma(scale, o, -i0) in some kernels and not in others: interpolation weights one ulp apart)
+__device__ __forceinline__ void ac_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+#pragma clang fp contract(off)
+  const float src = scale * (float)o;
+  i0 = (int)src; if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 < in_size - 1 ? i0 + 1 : i0;
+  l1 = src - (float)i0;
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

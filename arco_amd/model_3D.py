@@ -39,7 +39,7 @@ class FeatureExtractor_3d(nn.Module):
             n = c + int(f[i].shape[1])
             w_lo, w_hi = ops.fold_residual(fea.weight, c)                    # (W + I)[:, :c], (W + I)[:, c:] in one launch
             lo = ops.conv(x, w_lo)
-            x = ops.conv(f[i], w_hi, None, residual=ops.trilinear(lo, f[i].shape[-3:]))
+            x = ops.conv_upres(f[i], w_hi, lo)                                   # one launch: the upsample lives in the GEMM's epilogue
         return x, f[3], f[4]
 
     def forward(self, fea_list):

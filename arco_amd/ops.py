@@ -1100,6 +1100,71 @@ def gemm_weight(conv):
     return w.permute(0, 2, 3, 4, 1).reshape(co, 8 * ci, 1, 1, 1), b
 
 
+class ConvUpResFn(torch.autograd.Function):
+    """y = conv1x1x1(x; W) + trilinear_align_corners(lo -> x's size): FeatureExtractor_3d's `fea_i(cat(up(x), f_i)) + cat(up(x), f_i)`
+    with the wide block of the weights evaluated below the upsample (model_3D.py:46-58; arco_amd/model_3D.py forward_lowres2).
+    Forward: ONE launch - the upsampled low-resolution product is sampled in the GEMM's epilogue (arco_conv1x1_upres_fwd) instead of
+    being written by a resize kernel and read back as the residual (2 x 450 MB at the LA size); where the pipelined kernel does
+    not take the shape the two-launch route runs - the results are bit-identical.  Backward: the conv's data and weight gradients,
+    and the resize adjoint of the SAME incoming gradient for `lo`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, lo):
+        L.require_gpu(x, weight, lo)
+        xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
+        co = int(weight.shape[0])
+        lor, ldlo = rows_view(lo)
+        ud, uh, uw = (int(v) for v in lo.shape[2:])
+        od, oh, ow = (int(v) for v in x.shape[2:])
+        wp = pack_weight(weight, 1, 0)
+        spw = getattr(wp, "_arco_split", None)
+        y = None
+        if UPRES_FUSE and CONV_MMA == 3 and spw is not None and x.dtype == torch.float32 and lo.dtype == torch.float32 and int(lo.shape[1]) == co:
+            y = new_act_nd(nv, co, (od, oh, ow), x.device)
+            rc = getattr(L.load(), "arco_conv1x1_upres_fwd")(L.ptr(xr), ld, ci, L.ptr(spw), co, L.ptr(y), co, L.ptr(lor), ldlo, nv, ud, uh, uw,
+                                                             od, oh, ow, L.stream())
+            if rc == -3:
+                y = None                                   # shape not taken by the pipelined kernel
+            elif rc != 0:
+                raise RuntimeError(f"arco_amd: arco_conv1x1_upres_fwd failed with code {rc}")
+        if y is None:
+            up = new_act_nd(nv, co, (od, oh, ow), x.device)
+            L.call("arco_trilinear_fwd", L.ptr(lor), ldlo, nv, ud, uh, uw, co, od, oh, ow, L.ptr(up), co)
+            upr, ldu = rows_view(up)
+            y, _ = conv_raw(xr, ld, ci, wp, co, nv, h, w, 1, residual=upr, ld_res=ldu, d3=d3, sp=sp)
+        ctx.save_for_backward(x, weight)
+        ctx.dims = (nv, co, ud, uh, uw, od, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        nv, co, ud, uh, uw, od, oh, ow = ctx.dims
+        dyr, ldy, _, d3, h, w, _, sp = _geom_nd(dy)
+        xr, ldx = rows_view(x)
+        ci = int(x.shape[1])
+        dx = dw = dlo = None
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(dyr, ldy, co, xr, ldx, ci, 1, nv, h, w, weight, d3=d3, keep=(dy, x))
+        if ctx.needs_input_grad[0]:
+            wd = pack_weight(weight, 1, 1)
+            dx, _ = conv_raw(dyr, ldy, co, wd, ci, nv, h, w, 1, grad=True, d3=d3, sp=sp)
+        if ctx.needs_input_grad[2]:
+            dlo = new_act_nd(nv, co, (ud, uh, uw), dy.device)
+            L.call("arco_trilinear_bwd", L.ptr(dyr), ldy, nv, ud, uh, uw, co, od, oh, ow, L.ptr(dlo), co)
+        return dx, dw, dlo
+
+
+UPRES_FUSE = True      # A/B switch of ConvUpResFn's one-launch route
+
+
+def conv_upres(x, weight, lo):
+    """conv1x1x1(x; weight) + trilinear(lo -> x's size)  (see ConvUpResFn)."""
+    if tuple(int(v) for v in lo.shape[2:]) == tuple(int(v) for v in x.shape[2:]) or x.dim() != 5 or _is_half(x):
+        return conv(x, weight, None, residual=trilinear(lo, x.shape[-3:]))
+    return ConvUpResFn.apply(x, weight, lo)
+
+
 def conv(x, weight, bias=None, residual=False, bias_grad_zero=False):
     """bias_grad_zero=True: the caller normalises the result with a train-mode BatchNorm, so the bias gradient is
     analytically zero and is returned as exact zeros instead of a reduction over the output gradient."""

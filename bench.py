@@ -431,6 +431,27 @@ def sub_record(name, steps):
         return {"sub": name, "error": repr(e)}
 
 
+def forced_dist_record(steps=20):
+    """The headline step with ARCO_FORCE_DIST=1 (a one-rank `nccl` group: every exchange of arco_amd/dist.py issued through RCCL
+    and ProcessGroupNCCL's stream inside the two-stream, graph-replayed step): the per-step cost of the collective plumbing at
+    N = 1.  No scaling claim - a one-GPU box cannot make one."""
+    try:
+        env = dict(os.environ, ARCO_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "5", "--no_subs", "--no_cpu_baseline",
+                              "--k2_0_steps", "0", "--sustain_s", "0"], env=env, capture_output=True, text=True, timeout=600)
+        for ln in reversed(out.stdout.splitlines()):
+            if ln.startswith("{") and '"metric"' in ln:
+                r = json.loads(ln)
+                return {"sub": "forced_dist_world1", "ms_per_step": r["ms_per_step"], "steps_per_s": r["value"], "steps": steps,
+                        "note": "ARCO_FORCE_DIST=1: one-rank nccl group, all of dist.py's collectives issued every step (two gradient "
+                                "buckets, counter all-gather, tail-key broadcast, prototype all-reduce, percentile sums)"}
+        return {"sub": "forced_dist_world1", "error": (out.stderr or out.stdout)[-400:]}
+    except Exception as e:
+        return {"sub": "forced_dist_world1", "error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -610,7 +631,7 @@ def main():
             del stepper
             batches.clear()
             torch.cuda.empty_cache()
-            out["configs"] = [sub_record(n, a.sub_steps) for n in SUBS]
+            out["configs"] = [sub_record(n, a.sub_steps) for n in SUBS] + [forced_dist_record()]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -130,6 +130,13 @@ int arco_conv_sp_set(int on);
  * smallest 128 x 128 tile count the kernel takes (default 2048, ARCO_GEMM_SP_TILES).  Outputs are bit-identical either way.  Returns the
  * previous `on`. */
 int arco_gemm_sp_set(int on, long min_tiles);
+/* out = W . in + trilinear_align_corners(lo): the 1x1x1 conv over a high-resolution feature map with the upsampled low-resolution
+ * product as residual, sampled in the GEMM's epilogue (FeatureExtractor_3d, model_3D.py:46-58: `fea_i(cat(up(x), f_i)) + cat(...)` with
+ * the wide weight block evaluated below the upsample).  Wp: split-bf16 pack.  Returns ARCO_ERR_UNSUPPORTED (-3) when the pipelined
+ * kernel does not take the shape - the caller then upsamples with arco_trilinear_fwd and passes the result as arco_conv3d_fwd's residual;
+ * both routes give bit-identical outputs. */
+int arco_conv1x1_upres_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out, const float* lo,
+                           long ld_lo, int NV, int uD, int uH, int uW, int oD, int oH, int oW, void* stream);
 /* out = conv(in) (+bias)(+residual); optional per-channel (sum, sumsq) block partials for train-mode BN. */
 int arco_conv_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                   const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,

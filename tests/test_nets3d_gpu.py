@@ -601,3 +601,38 @@ def test_vnet_gradients_strict_vs_float64_reference():
     print(f"worst HIP deviation {worst[w_name]:.2e} at {w_name} (fp32 reference there {ref32[w_name]:.2e}); worst fp32 reference "
           f"deviation {ref_worst:.2e}; median HIP {float(np.median(list(worst.values()))):.2e} / reference "
           f"{float(np.median([ref32[k] for k in worst])):.2e}")
+
+
+def test_conv_with_upsampled_residual_in_the_epilogue_is_bit_identical():
+    """ops.conv_upres (FeatureExtractor_3d's high-resolution 1x1x1 GEMM with the trilinear upsample of the low-resolution product
+    sampled in the GEMM's epilogue: model_3D.py:46-58, csrc/gemm_sp.hip) against the two-launch route (arco_trilinear_fwd, then the
+    GEMM with a residual operand): outputs bit-identical, all three gradients identical, on an LA-shaped level and on a ragged one."""
+    from arco_amd import ops, _lib as L
+    prev = ops.CONV_MMA
+    ops.CONV_MMA = 3
+    torch.manual_seed(5)
+    try:
+        for (nv, ci, co, lo_sp, hi_sp) in ((2, 32, 224, (14, 14, 10), (28, 28, 20)), (1, 20, 100, (5, 7, 6), (10, 13, 11)), (4, 32, 224, (28, 28, 20), (56, 56, 40))):
+            x = torch.randn(nv, ci, *hi_sp, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+            lo = torch.randn(nv, co, *lo_sp, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+            w = torch.randn(co, ci, 1, 1, 1, device="cuda") / ci ** 0.5
+            probe = torch.randn(nv, co, *hi_sp, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+            res = []
+            for fuse in (False, True):
+                L.query("arco_gemm_sp_set", 1, 1)              # the pipelined kernel takes the launch whatever its tile count
+                ops._cfg_cache.clear()
+                ops.UPRES_FUSE = fuse
+                xs, los, ws = (t.clone().requires_grad_(True) for t in (x, lo, w))
+                y = ops.conv_upres(xs, ws, los)
+                (y * probe).sum().backward()
+                res.append((y.detach().clone(), xs.grad.clone(), los.grad.clone(), ws.grad.clone()))
+            for a_, b_ in zip(*res):
+                assert torch.equal(a_, b_)
+            ref = torch.nn.functional.conv3d(x.double().cpu(), w.double().cpu()) + torch.nn.functional.interpolate(
+                lo.double().cpu(), size=hi_sp, mode="trilinear", align_corners=True)
+            np.testing.assert_allclose(res[1][0].cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    finally:
+        ops.UPRES_FUSE = True
+        L.query("arco_gemm_sp_set", 1, 2048)
+        ops._cfg_cache.clear()
+        ops.CONV_MMA = prev
