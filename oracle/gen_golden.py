@@ -1214,6 +1214,81 @@ def gen_trainer_loop(mods):
                      ("pool", env["random_pool"])):
             out[f"{tag}_end_{k}"] = np.array(float(v.detach().double().abs().sum()))
         out[f"{tag}_cfg"] = np.array([C, b, patch[0], patch[1], Q, Nn, qs, K, k2], dtype=np.float64)
+    # ---- the volume trainer: train_arco_3d.py's loop body (:259-400) the same way.  C = 4 (the trainer's own default) so that the
+    # 5-D banks fill; three iterations: iteration 0 optimises `unsup + supervised + loss_eqv` (:393), later ones the contrastive
+    # objective (:391).  batch_transform / transform are the reference's own (identities in augment_3d.py:133-226).
+    rand_tps3 = importlib.import_module("tps.rand_tps_3d")
+    M3, L3 = mods["model_3D"], mods["loss_helper"]
+    path3 = os.path.join(ref_shim.REF, "train_arco_3d.py")
+    ns3, _ = _pull_functions(path3, {"compute_unsupervised_loss", "label_onehot", "get_revisiting_loss", "_dequeue_and_enqueue"})
+    aug3, _ = _pull_functions(os.path.join(ref_shim.REF, "augment_3d.py"),
+                              {"generate_cutout_mask_3d", "generate_class_mask", "generate_unsup_data_3d", "transform", "batch_transform"})
+    body3 = _loop_block(path3, "ema_model(train_u_data)", "iter_num+=1")
+    tag = "v"
+    C, b, patch, Q, Nn, qs, K = 4, 2, (32, 32, 32), 48, 16, 200, 4
+    args = types.SimpleNamespace(patch_size=list(patch), apply_aug="cutmix", k1=1.0, k2=1.0, k3=1.0, k4=0.5, topk=2, K=K,
+                                 strong_threshold=0.97, strong_threshold_u2pl=0.97, weak_threshold=0.7, func="asmc",
+                                 num_queries=Q, num_negatives=Nn, num_classes=C)
+    seed_all(5)
+    isd = M3.ISD_3d(K=K, m=0.99, Ts=0.01, Tt=0.1, num_classes=C, latent_pooling_size=1, latent_feature_size=128, output_pooling_size=4,
+                    train_encoder=True, train_decoder=True)
+    sd = fx.vnet_state(52, 1, C)
+    isd.model.load_state_dict(sd); isd.ema_model.load_state_dict(sd)
+    model, ema_model = isd.model, isd.ema_model
+    for m_ in (model, ema_model):
+        zero_dropout(m_)
+        m_.has_dropout = False
+    q_representation = nn.Sequential(nn.Conv3d(16, 16, kernel_size=1, bias=False), nn.Conv3d(16, 16, kernel_size=1, bias=False))
+    rsq = np.random.RandomState(62)
+    with torch.no_grad():
+        for layer in q_representation:
+            layer.weight.copy_(torch.from_numpy((rsq.standard_normal((16, 16, 1, 1, 1)) / 4).astype(np.float32)))
+    kfe = M3.FeatureExtractor_3d(fea_dim=[128, 64, 32, 16, 16], output_dim=16)
+    qfe = M3.FeatureExtractor_3d(fea_dim=[128, 64, 32, 16, 16], output_dim=16)
+    qfe.load_state_dict(fx.fe_state(61, (128, 64, 32, 16, 16), 16, nd=3))
+    with torch.no_grad():
+        for t_p, s_p in zip(kfe.parameters(), qfe.parameters()):
+            t_p.data.copy_(s_p.data); t_p.requires_grad = False
+    optimizer = torch.optim.SGD(list(model.parameters()) + list(q_representation.parameters()) + list(qfe.parameters()),
+                                lr=0.01, weight_decay=0.0001, momentum=0.9, nesterov=True)
+    seed_all(6)
+    tps = rand_tps3.RandTPS(patch[0], patch[1], patch[2], batch_size=2 * b, sigma=0.01, border_padding=False, random_mirror=True,
+                            random_scale=(0.8, 1.2), mode='affine')
+    for m_ in (model, ema_model, q_representation, kfe, qfe):
+        m_.train()
+    seed_all(7)
+    memobank, queue_ptrlis, queue_size = [], [], []
+    for i in range(C):
+        memobank.append([torch.randn(1, 16)]); queue_size.append(qs); queue_ptrlis.append(torch.zeros(1, dtype=torch.long))      # :144-151
+    out[f"{tag}_bank0"] = np.stack([m[0].numpy()[0] for m in memobank])
+    rs = np.random.RandomState(13)
+    pool = torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((K, 16 * patch[0] * patch[1] * patch[2])).astype(np.float32)), dim=1)
+    ns3["args"] = args
+    env = dict(ns3)
+    env.update(aug3)
+    env.update(dict(torch=torch, np=np, F=F, nn=nn, args=args, model=model, ema_model=ema_model, isd=isd, q_representation=q_representation,
+                    k_feature_extractor=kfe, q_feature_extractor=qfe, optimizer=optimizer, tps=tps, memobank=memobank,
+                    queue_ptrlis=queue_ptrlis, queue_size=queue_size, random_pool=pool, random_pool_ptr=torch.zeros(1, dtype=torch.long),
+                    compute_contra_memobank_loss=L3.compute_contra_memobank_loss, ce_loss=torch.nn.CrossEntropyLoss(),
+                    dice_loss=losses_mod.DiceLoss(C), base_lr=0.01, max_iterations=30000, iter_num=0, epoch_num=0, max_epoch=100, record=[]))
+    for it in range(3):
+        env["train_l_data"] = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        env["train_u_data"] = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        env["train_l_label"] = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
+        seed_all(10 + it)
+        exec(body3, env)
+        for k in ("loss_ce", "loss_dice", "unsup_loss", "reco_loss", "loss_eqv", "loss_q", "loss"):
+            out[f"{tag}_{it}_{k}"] = np.array(float(env[k]))
+        out[f"{tag}_{it}_bank_len"] = np.array([int(m[0].shape[0]) for m in memobank])
+        out[f"{tag}_{it}_ptr"] = np.array([int(p) for p in queue_ptrlis])
+        out[f"{tag}_{it}_bank_sum"] = np.array([float(m[0].double().abs().sum()) for m in memobank])
+        out[f"{tag}_{it}_probe"] = np.array((rng_probe(), float(np.random.uniform()), random.random()), dtype=np.float64)
+    sdm = model.state_dict()
+    for k, v in (("w_first", sdm["block_one.conv.0.weight"]), ("w_out", sdm["out_conv.weight"]), ("qrep0", q_representation[0].weight),
+                 ("qfe4", qfe.fea4.weight), ("kfe4", kfe.fea4.weight), ("t_first", ema_model.state_dict()["block_one.conv.0.weight"]),
+                 ("rm", sdm["block_one.conv.1.running_mean"])):
+        out[f"{tag}_end_{k}"] = np.array(float(v.detach().double().abs().sum()))
+    out[f"{tag}_cfg"] = np.array([C, b, *patch, Q, Nn, qs, K], dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "g19_trainer_loop.npz"), **out)
     print("g19_trainer_loop", len(out))
 

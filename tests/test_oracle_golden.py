@@ -494,3 +494,45 @@ def test_cpu_step_oracle_reproduces_the_reference_trainer_loop():
                t_first=st["teacher"]["encoder.in_conv.conv_conv.0.weight"], rm=st["student"]["encoder.in_conv.conv_conv.1.running_mean"])
     for k, v in ref.items():
         np.testing.assert_allclose(float(v.detach().double().abs().sum()), float(g[f"{case}_end_{k}"]), rtol=2e-6, err_msg=k)
+
+
+def test_cpu_step3d_oracle_reproduces_the_reference_volume_trainer_loop():
+    """g19 'v': the loop body of train_arco_3d.py:259-400 executed from the reference's text over the reference's modules (V-Net,
+    FeatureExtractor_3d, the 5-D loss, the slice-wise RandTPS): three iterations - iteration 0 with the equivariance objective,
+    then the contrastive one; C = 4, banks fill and truncate.  oracle/cpu_step3d.py (the checker of the 3-D whole-step GPU parity
+    tests) must reproduce every term, the bank bookkeeping and the generator consumption."""
+    import random
+    import cpu_step3d
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g19_trainer_loop.npz"))
+    C, b, patch, Q, Nn, qs, K = 4, 2, (32, 32, 32), 48, 16, 200, 4
+    torch.set_num_threads(4)
+    rsq = np.random.RandomState(62)
+    qrep = [torch.from_numpy((rsq.standard_normal((16, 16, 1, 1, 1)) / 4).astype(np.float32)) for _ in range(2)]
+    st = cpu_step3d.make_state(fx.vnet_state(52, 1, C), fx.fe_state(61, (128, 64, 32, 16, 16), 16, nd=3), qrep, max_iterations=30000)
+    bank = [[torch.from_numpy(g["v_bank0"][c:c + 1].copy())] for c in range(C)]
+    ptr = [torch.zeros(1, dtype=torch.long) for _ in range(C)]
+    rs = np.random.RandomState(13)
+    pool = dict(rows=torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((K, 16 * 32 ** 3)).astype(np.float32)), dim=1),
+                ptr=torch.zeros(1, dtype=torch.long))
+    for it in range(3):
+        l = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        u = torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32))
+        lab = torch.from_numpy(fx.blob_labels(rs, b, patch, C))
+        random.seed(10 + it); np.random.seed(10 + it); torch.manual_seed(10 + it)
+        cpu_step3d.step(st, l, lab, u, bank, ptr, [qs] * C, n_cls=C, epoch_num=0, max_epoch=100, k1=1.0, k3=1.0, k4=0.5, func="asmc",
+                        nq=Q, nn_=Nn, apply_aug="cutmix", pool=pool, topk=2)
+        o = st["last_terms"]
+        # iterations 0 and 1 strictly (identical decisions: measured 0 .. 1e-6); iteration 2 starts from weights two fp32 updates
+        # apart in summation order (the oracle's V-Net is its own restatement): a voxel on a threshold may flip - 1e-3, banks +-2
+        strict = it < 2
+        for k, kk in (("ce", "loss_ce"), ("dice", "loss_dice"), ("unsup", "unsup_loss"), ("reco", "reco_loss"), ("eqv", "loss_eqv"), ("loss_q", "loss_q")):
+            np.testing.assert_allclose(float(o[k]), float(g[f"v_{it}_{kk}"]), rtol=2e-5 if strict else 1e-3, atol=1e-6, err_msg=f"step {it} {k}")
+        lens = [int(x[0].shape[0]) for x in bank]
+        if strict:
+            assert lens == g[f"v_{it}_bank_len"].tolist(), it
+            assert [int(p) for p in ptr] == g[f"v_{it}_ptr"].tolist(), it
+            np.testing.assert_allclose([float(x[0].double().abs().sum()) for x in bank], g[f"v_{it}_bank_sum"], rtol=1e-5)
+            probe = (int(torch.randint(1 << 30, (1,))), float(np.random.uniform()), random.random())
+            np.testing.assert_allclose(probe, g[f"v_{it}_probe"], rtol=0, atol=0)
+        else:
+            assert max(abs(a - b_) for a, b_ in zip(lens, g[f"v_{it}_bank_len"].tolist())) <= 2
