@@ -40,6 +40,8 @@ __device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& x, const bf16x8
 }
 }  // namespace
 
+template <bool UPRES>      // UPRES: the residual is the trilinear upsample of a.Rup, sampled in the epilogue (its own instantiation:
+                           // in one kernel the sampling code cost the plain GEMM 92 bytes of scratch in its main loop)
 __global__ __launch_bounds__(512) void gemm_sp_kernel(IgemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned* const S = reinterpret_cast<unsigned*>(smem);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm_sp_kernel(IgemmArgs a) {
         const int v = tile0 + j * G8;
         const int mblk = v / a.n_nblocks;
         const long m0 = (long)mblk * BM; const int n0 = (v - mblk * a.n_nblocks) * BN;
-        if (a.Rup) {
+        if constexpr (UPRES) {
           // residual = trilinear(align_corners) sample of the low-resolution tensor at this lane's four voxels: the index math and
           // the lerp expression of trilinear_fwd_kernel (elementwise.hip), so that out == conv + trilinear(...) bit for bit
           const float sd = a.oD > 1 ? (float)(a.uD - 1) / (float)(a.oD - 1) : 0.f, sh = a.oH > 1 ? (float)(a.uH - 1) / (float)(a.oH - 1) : 0.f,
@@ -415,11 +417,13 @@ int gemm_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
     int dev = 0; hipDeviceProp_t p;
     (void)hipGetDevice(&dev);
     n_cu = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_DW * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_DW * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_DW * 4);
   }
   IgemmArgs b = a;
   b.n_mblocks = mblocks; b.n_nblocks = nblocks;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
-  hipLaunchKernelGGL(gemm_sp_kernel, dim3(grid), dim3(512), 2 * BUF_DW * 4, st, b);
+  if (a.Rup) hipLaunchKernelGGL(gemm_sp_kernel<true>, dim3(grid), dim3(512), 2 * BUF_DW * 4, st, b);
+  else hipLaunchKernelGGL(gemm_sp_kernel<false>, dim3(grid), dim3(512), 2 * BUF_DW * 4, st, b);
   return arco_launch_status();
 }

@@ -59,7 +59,32 @@ typedef unsigned int u32x2_ma __attribute__((ext_vector_type(2), may_alias));
 typedef unsigned int u32x4_ma __attribute__((ext_vector_type(4), may_alias));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 lds_bf16x8(const void* p) { return __builtin_bit_cast(bf16x8, u32x4(*reinterpret_cast<const u32x4_ma*>(p))); }
+// x = b0 + b1 + b2 exactly, b_i bf16 (RNE remainders): the split of an fp32 operand into its three bf16 MFMA terms.
+// A packed-pair form written at the instruction level (-DARCO_SPLIT_PACKED: per PAIR of elements one v_cvt_pk_bf16_f32 per term - its
+// result IS the packed LDS word -, two bit operations to widen a term back to fp32, one v_pk_add_f32 for the remainder: 10 VALU
+// instructions per pair where the element-wise C++ form compiles to 14) is 21-23 % faster as pure VALU work (tools/micro/split_rate.hip:
+// 53 vs 67 ns per f32x4 piece and wave) and bit-identical - and changes nothing where it matters: same box, alternating, the dense
+// GEMM 160.4 vs 159.4 TFLOP/s, the headline step 11.17 / 11.56 vs 11.08 / 11.21 ms (tools/debug/ab_split.sh, round 5).  The
+// kernels that split are bound by on-chip operand traffic and rendezvous, not by the loaders' instruction count
+// (profiles/r05_notes.md section 2).  Kept behind the macro; the element-wise form stays the default.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = cvt_pk_bf16(x0, x1);
+  const f32x2_t x = {x0, x1};
+  const f32x2_t f0 = {__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h0 & 0xffff0000u)};
+  const f32x2_t r1 = x - f0;
+  h1 = cvt_pk_bf16(r1[0], r1[1]);
+  const f32x2_t f1 = {__builtin_bit_cast(float, h1 << 16), __builtin_bit_cast(float, h1 & 0xffff0000u)};
+  const f32x2_t r2 = r1 - f1;
+  h2 = cvt_pk_bf16(r2[0], r2[1]);
+}
 __device__ __forceinline__ void split3_bf16x4(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+#ifndef ARCO_SPLIT_PACKED           // default: the element-wise form of rounds 2-4 (see the note above split3_pair)
   unsigned short h[3][4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -74,6 +99,12 @@ __device__ __forceinline__ void split3_bf16x4(f32x4 v, u32x2& p0, u32x2& p1, u32
   p0 = u32x2{(unsigned)h[0][0] | ((unsigned)h[0][1] << 16), (unsigned)h[0][2] | ((unsigned)h[0][3] << 16)};
   p1 = u32x2{(unsigned)h[1][0] | ((unsigned)h[1][1] << 16), (unsigned)h[1][2] | ((unsigned)h[1][3] << 16)};
   p2 = u32x2{(unsigned)h[2][0] | ((unsigned)h[2][1] << 16), (unsigned)h[2][2] | ((unsigned)h[2][3] << 16)};
+  return;
+#endif
+  unsigned a0, a1, a2, b0, b1, b2;
+  split3_pair(v[0], v[1], a0, a1, a2);
+  split3_pair(v[2], v[3], b0, b1, b2);
+  p0 = u32x2{a0, b0}; p1 = u32x2{a1, b1}; p2 = u32x2{a2, b2};
 }
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
