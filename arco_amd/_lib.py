@@ -102,6 +102,11 @@ _SIGS = {
     "arco_gather_upcat_rows3d_h": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "arco_cast_rows_f2h": [_P, _L, _I, _P, _L, _F, _P, _L, _P],
     "arco_zero_rows_h": [_P, _L, _I, _P, _L, _P],
+    "arco_det_absmax": [_P, _L, _I, _L, _P, _P],
+    "arco_det_scatter_rows": [_P, _L, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P],
+    "arco_det_finish_rows": [_P, _P, _L, _P, _L, _I, _P, _F, _P, _L, _P],
+    "arco_det_clear_rows": [_P, _P, _L, _P, _L, _I, _P],
+    "arco_corner_rows3d": [_P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "arco_fold_residual": [_P, _I, _I, _P, _P, _P],
     "arco_unfold_residual": [_P, _P, _I, _I, _P, _P],
     "arco_combine_terms": [_P, _P, _I, _P, _P],

@@ -13,6 +13,8 @@ accumulation); the backward scatters dX4 rows back into x3p / f4 and the weight 
 GEMMs over the anchor rows only.  This removes ~3.3 TFLOP/step of dense fp32 GEMM work at
 BASELINE config 2 without changing any result.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -246,6 +248,29 @@ def _row_grad_buffer_h(ptr, shape, dev):
     return dense, done_dense
 
 
+# Order-independent row scatter (csrc/det_scatter.hip): fixed-point int64 accumulation instead of fp32 atomics - the gradient of the
+# row-sparse 3-D head is bit-reproducible, which f16 activation storage needs to be reproducible at all (the ulp of an fp32 atomic's
+# arrival order decides f16 roundings downstream; profiles/r05_notes.md section 7).  ARCO_DET_SCATTER=0: the fp32 atomics.
+DET_SCATTER = int(os.environ.get("ARCO_DET_SCATTER", "1"))
+_ACC64 = {}
+
+
+def _det_scatter_rows(src, ld_src, C, div, idx, w, n_e, dst, ld_dst):
+    """dst[idx[e]] = sum over e of w[e] * src[e // div] (C channels), dst rows zero before; src: [n_e // div, >= C] fp32 view."""
+    dev = src.device
+    rows = dst.numel() // ld_dst
+    key = (dev.index, rows, C)
+    acc = _ACC64.get(key)
+    if acc is None:
+        acc = _ACC64[key] = torch.zeros((rows, C), dtype=torch.int64, device=dev)
+    mb = torch.empty(1, dtype=torch.int32, device=dev)
+    L.call("arco_det_absmax", L.ptr(src), ld_src, C, n_e // div, L.ptr(mb))
+    L.call("arco_det_scatter_rows", L.ptr(src), ld_src, C, div, None, L.ptr(idx), None if w is None else L.ptr(w), n_e,
+           L.ptr(acc), C, L.ptr(mb))
+    L.call("arco_det_finish_rows", None, L.ptr(idx), n_e, L.ptr(acc), C, C, L.ptr(mb), 1.0, L.ptr(dst), ld_dst)
+    L.call("arco_det_clear_rows", None, L.ptr(idx), n_e, L.ptr(acc), C, C)
+
+
 class LazyHead3Fn(torch.autograd.Function):
     """Three-level row-sparse head: fea2 (the 64 x 64 level), fea3 and fea4 are all evaluated only where the anchors need
     them - the 4 neighbours at 128 x 128 of every anchor and the 4 neighbours at 64 x 64 of each of those (16 n rows of
@@ -411,7 +436,10 @@ class LazyHead3dFn(torch.autograd.Function):
         dX4 = _gemm_t(dh0, w4)
         dX3p = dX4[:, :k3].contiguous()
         df4, fin4 = (_row_grad_buffer_h if ctx.fhalf[1] else _row_grad_buffer)(ctx.fptrs[1], s4, dev)
-        L.call("arco_scatter_add_rows", L.ptr(dX4[:, k3:]), k3 + c4, c4, None, L.ptr(pix), n, None, 1.0, L.ptr(df4), c4)
+        if DET_SCATTER:
+            _det_scatter_rows(dX4[:, k3:], k3 + c4, c4, 1, pix, None, n, df4, c4)
+        else:
+            L.call("arco_scatter_add_rows", L.ptr(dX4[:, k3:]), k3 + c4, c4, None, L.ptr(pix), n, None, 1.0, L.ptr(df4), c4)
         r = fin4(pix, n)
         if ctx.fhalf[1]:
             df4 = r
@@ -421,8 +449,15 @@ class LazyHead3dFn(torch.autograd.Function):
         c2, c3 = int(s2[1]), int(s3[1])
         dx2p = torch.zeros((s2[0], *s2[2:], c2), dtype=torch.float32, device=dev)
         df3, fin3 = (_row_grad_buffer_h if ctx.fhalf[0] else _row_grad_buffer)(ctx.fptrs[0], s3, dev)
-        L.call("arco_scatter_upcat_rows3d", L.ptr(dX3), k3, L.ptr(pix), n, L.ptr(dx2p), c2, c2, s2[2], s2[3], s2[4],
-               L.ptr(df3), c3, c3, s3[2], s3[3], s3[4])
+        if DET_SCATTER:
+            idx8 = torch.empty(8 * n, dtype=torch.int64, device=dev)
+            w8 = torch.empty(8 * n, dtype=torch.float32, device=dev)
+            L.call("arco_corner_rows3d", L.ptr(pix), n, s2[2], s2[3], s2[4], s3[2], s3[3], s3[4], L.ptr(idx8), L.ptr(w8))
+            _det_scatter_rows(dX3, k3, c2, 8, idx8, w8, 8 * n, dx2p, c2)
+            _det_scatter_rows(dX3[:, c2:], k3, c3, 1, pix, None, n, df3, c3)
+        else:
+            L.call("arco_scatter_upcat_rows3d", L.ptr(dX3), k3, L.ptr(pix), n, L.ptr(dx2p), c2, c2, s2[2], s2[3], s2[4],
+                   L.ptr(df3), c3, c3, s3[2], s3[3], s3[4])
         r = fin3(pix, n)
         if ctx.fhalf[0]:
             df3 = r

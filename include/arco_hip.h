@@ -241,6 +241,22 @@ int arco_gather_upcat_rows3d_h(const float* lo, long ldlo, int Clo, int Di, int 
 int arco_cast_rows_f2h(const float* src, long ld_src, int C, const int64_t* idx, long n, float scale, void* dst, long ld_dst,
                        void* stream);
 int arco_zero_rows_h(void* dst, long ld, int C, const int64_t* idx, long n, void* stream);
+/* Order-independent form of the row-scatter adjoints above (csrc/det_scatter.hip): fp32 atomics sum in arrival order (one ulp of
+ * run-to-run difference, as in torch's own upsample backward on the GPU that the reference runs: model_3D.py:52-55); these
+ * accumulate fixed-point int64 (2^44 units for the largest |source element|, arco_det_absmax) - bit-reproducible.
+ *   arco_det_absmax:        maxbits[0] = max bits(|X[r][c]|) over [n, C]  (>= 0x7f800000: a non-finite element)
+ *   arco_det_scatter_rows:  acc[r(e)][c] += fix(w[e] * src[e / div][c]),  r(e) = list ? list[idx[e]] : idx[e],  e < n_e  (w nullable = 1)
+ *   arco_det_finish_rows:   dst[r(e)][c]  = alpha * fp32(acc[r(e)][c])    (nan when the source was non-finite)
+ *   arco_det_clear_rows:    acc[r(e)][c]  = 0                             (acc: persistent, zero between uses)
+ *   arco_corner_rows3d:     idx8[8j+k], w8[8j+k] = low-resolution row and weight of corner k of sampled voxel pix[j]            */
+int arco_det_absmax(const float* X, long ld, int C, long n, unsigned* maxbits, void* stream);
+int arco_det_scatter_rows(const float* src, long ld_src, int C, int div, const int32_t* list, const int64_t* idx, const float* w,
+                          long n_e, long long* acc, long ld_acc, const unsigned* maxbits, void* stream);
+int arco_det_finish_rows(const int32_t* list, const int64_t* idx, long n_e, const long long* acc, long ld_acc, int C,
+                         const unsigned* maxbits, float alpha, float* dst, long ld_dst, void* stream);
+int arco_det_clear_rows(const int32_t* list, const int64_t* idx, long n_e, long long* acc, long ld_acc, int C, void* stream);
+int arco_corner_rows3d(const int64_t* pix, long n, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int64_t* idx8, float* w8,
+                       void* stream);
 /* glue kernels replacing chains of tensor-library launches in the step (no reference counterpart: the reference's
  * autograd does these as separate zeros / add / copy / mul kernels, train_arco_2d.py:426-431, model_2D.py:43-50):
  * arco_zero_rows: rows idx[] of a [rows, ld] buffer zeroed over C channels (re-arms a persistent gradient buffer);

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../arco_amd/csrc"
 make -j8 > /dev/null
 mkdir -p ../../build/var_$name
 objs=""
-for s in loss_front igemm conv_sp gemm_sp conv_h elementwise glue sampler_host augment; do
+for s in loss_front igemm conv_sp gemm_sp conv_h elementwise det_scatter glue sampler_host augment; do
   if [[ " $srcs " == *" $s.hip "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-value $flags -c $s.hip -o ../../build/var_$name/$s.o
     objs="$objs ../../build/var_$name/$s.o"
