@@ -5,6 +5,8 @@ memory (rows of C floats per pixel); a channel slice of such a tensor is consume
 in place through its row stride.  PyTorch only allocates memory and chains the
 autograd graph - every arithmetic op below is a hand-written gfx950 kernel.
 """
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -170,9 +172,24 @@ def _taps(weight):
 WEIGHT_EPOCH = 0
 
 
-_plans = []
-_PLAN_BY_PTR = {}       # data_ptr of a plan-owned GEMM-form weight W2 -> {mode: (plan, buf, sbuf, hbuf)} (the tensor object that
-                        # reaches pack_weight is an autograd output sharing W2's storage: attributes do not travel, addresses do)
+_plans = weakref.WeakSet()
+_PLAN_BY_PTR = {}       # data_ptr of a plan-owned GEMM-form weight W2 -> {mode: (plan flag, buf, sbuf, hbuf)} (the tensor object that
+                        # reaches pack_weight is an autograd output sharing W2's storage: attributes do not travel, addresses do).
+                        # The entries hold the plan's validity FLAG, not the plan, and leave with the plan (weakref.finalize below):
+                        # a dropped stepper's W2 / pack buffers are freed and its addresses cannot serve a later tensor
+
+
+class _PlanFlag:
+    __slots__ = ("valid",)
+
+    def __init__(self):
+        self.valid = False
+
+
+def _forget_plan_ptrs(pairs):
+    for ptr, ent in pairs:
+        if _PLAN_BY_PTR.get(ptr) is ent:
+            del _PLAN_BY_PTR[ptr]
 
 
 def bump_weight_epoch():
@@ -188,12 +205,22 @@ class PackPlan:
     one pack launch per layer per forward.  The owner calls refresh() whenever the weights changed (optimiser
     step / EMA update); pack_weight() then serves the plan's buffers."""
 
+    @property
+    def valid(self):
+        return self._flag.valid
+
+    @valid.setter
+    def valid(self, v):
+        self._flag.valid = bool(v)
+
     def __init__(self, modules, with_dgrad, half=None):
         """half: one flag per top-level module - True: the module runs on f16 activations (ops.ACT_HALF: the V-Net body), its
         Conv3d weights get the f16 pack ONLY (the one-channel first layer keeps the fp32 pack its kernel reads); False / None:
         fp32 activations (heads), the fp32 / split-bf16 packs."""
         import struct
         recs, self.entries = [], []
+        self._flag = _PlanFlag()
+        by_ptr = []
         dev = None
         total = 0
         tops = modules if isinstance(modules, (list, tuple)) else [modules]
@@ -236,13 +263,14 @@ class PackPlan:
                             kp32 = (k + 31) // 32 * 32
                             sbuf = torch.empty((1, n, kp32 * 3 // 2), dtype=torch.float32, device=dev)
                             recs.append((w, sbuf, n2, k2, g, (gm << 3) | mode | 2, n, kp32, total)); total += n * kp32
-                    ent[mode] = (self, buf, sbuf, hbuf)
+                    ent[mode] = (self._flag, buf, sbuf, hbuf)
                 bias8 = None
                 if up and m.bias is not None:
                     bias8 = torch.empty(8 * co_, dtype=torch.float32, device=dev)
                     recs.append((m.bias, bias8, 1, 8 * co_, co_, 4 << 3, 1, 8 * co_, total)); total += 8 * co_
                 ent["shape"] = (n2, k2)      # (the lookup checks it: an address match alone must not hand out another weight's packs)
                 _PLAN_BY_PTR[w2.data_ptr()] = ent
+                by_ptr.append((w2.data_ptr(), ent))
                 self.gemm_entries.append((w, w2, bias8))
                 w._arco_gemm = (self, w2, bias8)
                 continue
@@ -276,7 +304,8 @@ class PackPlan:
                 self.entries.append((w, mode, buf, sbuf, hbuf))
         self.total, self.n = total, len(recs)
         self.valid = False
-        _plans.append(self)
+        _plans.add(self)
+        weakref.finalize(self, _forget_plan_ptrs, by_ptr)
         if self.n:
             raw = b"".join(struct.pack("<QQiiiiiiq", w.data_ptr(), b.data_ptr(), co, ci, taps, mode, npad, kpad, first)
                            for (w, b, co, ci, taps, mode, npad, kpad, first) in recs)

@@ -636,3 +636,22 @@ def test_conv_with_upsampled_residual_in_the_epilogue_is_bit_identical():
         L.query("arco_gemm_sp_set", 1, 2048)
         ops._cfg_cache.clear()
         ops.CONV_MMA = prev
+
+
+def test_pack_plan_registry_entries_leave_with_the_plan():
+    """ops._PLAN_BY_PTR maps the address of a plan-owned GEMM-form weight to the plan's pack buffers (the tensor that reaches
+    pack_weight is an autograd output sharing that storage).  The entries must not keep a dropped plan's buffers alive, and a
+    recycled address must not serve a later tensor."""
+    import gc
+    from arco_amd import ops
+    conv = torch.nn.ConvTranspose3d(32, 16, 2, stride=2).cuda()
+    before = set(ops._PLAN_BY_PTR)
+    plan = ops.PackPlan([conv], True)
+    plan.refresh()
+    mine = set(ops._PLAN_BY_PTR) - before
+    assert len(mine) == 1 and plan in ops._plans
+    w2, b8 = ops.gemm_weight(conv)
+    assert ops._plan_by_ptr(w2.detach() if w2.requires_grad else w2) is not None
+    del plan, w2, b8, conv
+    gc.collect()
+    assert not (mine & set(ops._PLAN_BY_PTR))

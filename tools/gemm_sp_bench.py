@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from arco_amd import ops, _lib as L
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+PMC = len(sys.argv) > 1 and sys.argv[1] == "pmc"          # under rocprofv3 --pmc: the first shape only, 3 launches per kernel
+reps = 3 if PMC else (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
 ops.CONV_MMA = 3
 dev = "cuda:0"
 torch.manual_seed(0)
@@ -22,7 +23,7 @@ def run(x, w, res, M, K, N):
     wp = ops.pack_weight(w, 1, 0)
     out, _ = ops.conv_raw(x, K, K, wp, N, 1, 1, M, 1, residual=res, ld_res=N if res is not None else 0)
     return out
-for label, M, K, N, has_res in SHAPES:
+for label, M, K, N, has_res in (SHAPES[:1] if PMC else SHAPES):
     x = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev))
     w = (torch.randn(N, K, 1, 1, device=dev) / K ** 0.5).requires_grad_(False)
     res = torch.randn(M, N, device=dev) if has_res else None
