@@ -124,6 +124,27 @@ __global__ __launch_bounds__(256) void corner_rows3d_kernel(const int64_t* __res
       }
 }
 
+// 2-D counterpart (bilinear, align_corners: the adjoint of gather_upcat_rows, elementwise.hip): four corners y, x with x fastest
+__global__ __launch_bounds__(256) void corner_rows2d_kernel(const int64_t* __restrict__ pix, long n, int Hi, int Wi, int Ho, int Wo,
+                                                           int64_t* __restrict__ idx4, float* __restrict__ w4) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const long p = pix[j];
+  const long img = p / ((long)Ho * Wo); const int rem = (int)(p - img * (long)Ho * Wo);
+  const int yo = rem / Wo, xo = rem - yo * Wo;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  int yy[2], xx[2]; float ly, lx;
+  ac_src(yo, sh, Hi, yy[0], yy[1], ly); ac_src(xo, sw, Wi, xx[0], xx[1], lx);
+  const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      idx4[4 * j + b * 2 + d] = (img * Hi + yy[b]) * (long)Wi + xx[d];
+      w4[4 * j + b * 2 + d] = mul_np(wy[b], wx[d]);
+    }
+}
+
 extern "C" {
 
 int arco_det_absmax(const float* X, long ld, int C, long n, unsigned* maxbits, void* stream) {
@@ -166,6 +187,13 @@ int arco_corner_rows3d(const int64_t* pix, long n, int Di, int Hi, int Wi, int D
   if (n == 0) return ARCO_OK;
   hipLaunchKernelGGL(corner_rows3d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), pix, n, Di, Hi, Wi, Do, Ho, Wo,
                      idx8, w8);
+  return arco_launch_status();
+}
+
+int arco_corner_rows2d(const int64_t* pix, long n, int Hi, int Wi, int Ho, int Wo, int64_t* idx4, float* w4, void* stream) {
+  ARCO_CHECK_ARG(pix && idx4 && w4 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(corner_rows2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), pix, n, Hi, Wi, Ho, Wo, idx4, w4);
   return arco_launch_status();
 }
 

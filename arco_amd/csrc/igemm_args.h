@@ -43,7 +43,9 @@ __device__ __forceinline__ float tl_blend1(float v000, float v001, float v010, f
 // (contraction off: `src - i0` must subtract from the ROUNDED product, as torch's CPU kernel does - left to -ffp-contract=fast the
 //  compiler fused it into fma(scale, o, -i0) in some kernels and not in others: interpolation weights one ulp apart)
 __device__ __forceinline__ void ac_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+#ifndef ARCO_AC_FAST               // (A/B only: the pre-round-5 behaviour)
 #pragma clang fp contract(off)
+#endif
   const float src = scale * (float)o;
   i0 = (int)src; if (i0 > in_size - 1) i0 = in_size - 1;
   i1 = i0 < in_size - 1 ? i0 + 1 : i0;

@@ -72,8 +72,7 @@ class LazyHeadFn(torch.autograd.Function):
         dX = _gemm_t(dh0, w4)
         dlo = torch.zeros((nb, hi_h, hi_w, clo), dtype=torch.float32, device=da.device)
         dhi = torch.zeros((nb, ho, wo, chi), dtype=torch.float32, device=da.device)
-        L.call("arco_scatter_upcat_rows", L.ptr(dX), clo + chi, L.ptr(pix), int(pix.shape[0]), L.ptr(dlo), clo, clo,
-               hi_h, hi_w, L.ptr(dhi), chi, chi, ho, wo)
+        _scatter_upcat2d(dX, clo + chi, pix, int(pix.shape[0]), dlo, clo, hi_h, hi_w, dhi, chi, ho, wo)
         return dlo.permute(0, 3, 1, 2), dhi.permute(0, 3, 1, 2), dw4, dw1, dw2, None
 
 
@@ -142,16 +141,14 @@ class LazyHead2Fn(torch.autograd.Function):
         dX4 = _gemm_t(dh0, w4)
         dX3p = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
         df4 = torch.zeros((nb, h4, w4_, c4), dtype=torch.float32, device=dev)
-        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX4), k3 + c4, k3, L.ptr(lylx), L.ptr(pix), n, L.ptr(dX3p), k3,
-               L.ptr(df4), c4, c4)
+        _lerp4_cat_rows_bwd(dX4, k3 + c4, k3, lylx, pix, n, dX3p, df4, c4)
         dw3 = _wgrad(dX3p, X3, w3)
         # d(fea3(x)+x)/dx: W3^T dy + dy  (residual fused in the dgrad GEMM epilogue)
         y, _ = ops.conv_raw(dX3p, k3, k3, ops.pack_weight(w3, 1, 1), k3, 1, 1, 4 * n, 1, residual=dX3p, ld_res=k3)
         dX3 = y.permute(0, 2, 3, 1).reshape(4 * n, k3)
         dx2p = torch.zeros((nb, h2, w2_, c2), dtype=torch.float32, device=dev)
         df3 = torch.zeros((nb, h3, w3_, c3), dtype=torch.float32, device=dev)
-        L.call("arco_scatter_upcat_rows", L.ptr(dX3), k3, L.ptr(nb4), 4 * n, L.ptr(dx2p), c2, c2, h2, w2_, L.ptr(df3), c3,
-               c3, h3, w3_)
+        _scatter_upcat2d(dX3, k3, nb4, 4 * n, dx2p, c2, h2, w2_, df3, c3, h3, w3_)
         return (dx2p.permute(0, 3, 1, 2), df3.permute(0, 3, 1, 2), df4.permute(0, 3, 1, 2), dw3, dw4, dw1, dw2, None)
 
 
@@ -250,7 +247,8 @@ def _row_grad_buffer_h(ptr, shape, dev):
 
 # Order-independent row scatter (csrc/det_scatter.hip): fixed-point int64 accumulation instead of fp32 atomics - the gradient of the
 # row-sparse 3-D head is bit-reproducible, which f16 activation storage needs to be reproducible at all (the ulp of an fp32 atomic's
-# arrival order decides f16 roundings downstream; profiles/r05_notes.md section 7).  ARCO_DET_SCATTER=0: the fp32 atomics.
+# arrival order decides f16 roundings downstream; profiles/r05_notes.md section 7).  ARCO_DET_SCATTER = 0: fp32 atomics everywhere;
+# 1 (default): the 3-D head order-independent; 2: the 2-D heads too (17 more small launches on the 2-D step's critical path).
 DET_SCATTER = int(os.environ.get("ARCO_DET_SCATTER", "1"))
 _ACC64 = {}
 
@@ -269,6 +267,28 @@ def _det_scatter_rows(src, ld_src, C, div, idx, w, n_e, dst, ld_dst):
            L.ptr(acc), C, L.ptr(mb))
     L.call("arco_det_finish_rows", None, L.ptr(idx), n_e, L.ptr(acc), C, C, L.ptr(mb), 1.0, L.ptr(dst), ld_dst)
     L.call("arco_det_clear_rows", None, L.ptr(idx), n_e, L.ptr(acc), C, C)
+
+
+def _scatter_upcat2d(dX, ldx, pix, n, dlo, clo, hi_h, hi_w, dhi, chi, ho, wo):
+    """adjoint of arco_gather_upcat_rows: dlo += bilinear corners of dX[:, :clo], dhi[pix] += dX[:, clo:]"""
+    if DET_SCATTER >= 2:
+        dev = dX.device
+        idx4 = torch.empty(4 * n, dtype=torch.int64, device=dev)
+        w4 = torch.empty(4 * n, dtype=torch.float32, device=dev)
+        L.call("arco_corner_rows2d", L.ptr(pix), n, hi_h, hi_w, ho, wo, L.ptr(idx4), L.ptr(w4))
+        _det_scatter_rows(dX, ldx, clo, 4, idx4, w4, 4 * n, dlo, clo)
+        _det_scatter_rows(dX[:, clo:], ldx, chi, 1, pix, None, n, dhi, chi)
+    else:
+        L.call("arco_scatter_upcat_rows", L.ptr(dX), ldx, L.ptr(pix), n, L.ptr(dlo), clo, clo, hi_h, hi_w, L.ptr(dhi), chi, chi, ho, wo)
+
+
+def _lerp4_cat_rows_bwd(dX, ldx, clo, lylx, pix, n, dV, dhi, chi):
+    """adjoint of arco_lerp4_cat_rows: the four weighted copies of dX[:, :clo] (plain stores) and dhi[pix] += dX[:, clo:]"""
+    if DET_SCATTER >= 2:
+        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX), ldx, clo, L.ptr(lylx), L.ptr(pix), n, L.ptr(dV), clo, L.ptr(dhi), chi, 0)
+        _det_scatter_rows(dX[:, clo:], ldx, chi, 1, pix, None, n, dhi, chi)
+    else:
+        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX), ldx, clo, L.ptr(lylx), L.ptr(pix), n, L.ptr(dV), clo, L.ptr(dhi), chi, chi)
 
 
 class LazyHead3Fn(torch.autograd.Function):
@@ -308,22 +328,19 @@ class LazyHead3Fn(torch.autograd.Function):
         dX4 = _gemm_t(dh0, w4)
         dX3p = torch.empty((4 * n, k3), dtype=torch.float32, device=dev)
         df4, fin4 = _row_grad_buffer(ctx.fptrs[2], (nb, c4, h4, w4_), dev)
-        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX4), k3 + c4, k3, L.ptr(lylx4), L.ptr(pix), n, L.ptr(dX3p), k3,
-               L.ptr(df4), c4, c4)
+        _lerp4_cat_rows_bwd(dX4, k3 + c4, k3, lylx4, pix, n, dX3p, df4, c4)
         fin4(pix, n)
         dw3 = _wgrad(dX3p, X3, w3)
         dX3 = _fea_rows(dX3p, w3, 1)
         dX2p = torch.empty((16 * n, k2), dtype=torch.float32, device=dev)
         df3, fin3 = _row_grad_buffer(ctx.fptrs[1], (nb, c3, h3, w3_), dev)
-        L.call("arco_lerp4_cat_rows_bwd", L.ptr(dX3), k3, k2, L.ptr(lylx3), L.ptr(nb4), 4 * n, L.ptr(dX2p), k2,
-               L.ptr(df3), c3, c3)
+        _lerp4_cat_rows_bwd(dX3, k3, k2, lylx3, nb4, 4 * n, dX2p, df3, c3)
         fin3(nb4, 4 * n)
         dw2 = _wgrad(dX2p, X2, w2)
         dX2 = _fea_rows(dX2p, w2, 1)
         dx1p = torch.zeros((nb, h1, w1_, c1), dtype=torch.float32, device=dev)
         df2, fin2 = _row_grad_buffer(ctx.fptrs[0], (nb, c2, h2, w2_), dev)
-        L.call("arco_scatter_upcat_rows", L.ptr(dX2), k2, L.ptr(nb16), 16 * n, L.ptr(dx1p), c1, c1, h1, w1_, L.ptr(df2), c2,
-               c2, h2, w2_)
+        _scatter_upcat2d(dX2, k2, nb16, 16 * n, dx1p, c1, h1, w1_, df2, c2, h2, w2_)
         fin2(nb16, 16 * n)
         return (dx1p.permute(0, 3, 1, 2), df2.permute(0, 3, 1, 2), df3.permute(0, 3, 1, 2), df4.permute(0, 3, 1, 2),
                 dw2, dw3, dw4, dw1, dwq2, None)

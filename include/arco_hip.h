@@ -257,6 +257,8 @@ int arco_det_finish_rows(const int32_t* list, const int64_t* idx, long n_e, cons
 int arco_det_clear_rows(const int32_t* list, const int64_t* idx, long n_e, long long* acc, long ld_acc, int C, void* stream);
 int arco_corner_rows3d(const int64_t* pix, long n, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int64_t* idx8, float* w8,
                        void* stream);
+/*   arco_corner_rows2d:     the bilinear counterpart (four corners; adjoint of arco_gather_upcat_rows, model_2D.py:43-50)              */
+int arco_corner_rows2d(const int64_t* pix, long n, int Hi, int Wi, int Ho, int Wo, int64_t* idx4, float* w4, void* stream);
 /* glue kernels replacing chains of tensor-library launches in the step (no reference counterpart: the reference's
  * autograd does these as separate zeros / add / copy / mul kernels, train_arco_2d.py:426-431, model_2D.py:43-50):
  * arco_zero_rows: rows idx[] of a [rows, ld] buffer zeroed over C channels (re-arms a persistent gradient buffer);

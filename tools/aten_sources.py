@@ -12,6 +12,7 @@ SKIP = ("aten::view", "aten::as_strided", "aten::permute", "aten::detach", "aten
         "aten::empty", "aten::_local_scalar_dense", "aten::is_pinned", "aten::_pin_memory", "aten::lift_fresh", "aten::record_stream",
         "aten::set_", "aten::resize_", "aten::is_same_size", "aten::sym_", "aten::stride", "aten::size", "aten::unbind", "aten::split")
 cnt = collections.Counter()
+byt = collections.Counter()      # bytes of the op's output(s): which of these launches are large
 
 class Rec(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -26,6 +27,8 @@ class Rec(TorchDispatchMode):
                         site = f"{fr.filename.split('arco_amd/')[-1]}:{fr.lineno} {fr.name}"
                         break
                 cnt[(name, site)] += 1
+                outs = out if isinstance(out, (tuple, list)) else [out]
+                byt[(name, site)] += sum(o.numel() * o.element_size() for o in outs if isinstance(o, torch.Tensor))
         return out
 
 k2 = os.environ.get("K2", "1")
@@ -42,5 +45,5 @@ with Rec():
         st.step(l, ll, u)
 torch.cuda.synchronize()
 for (name, site), n in sorted(cnt.items(), key=lambda kv: (kv[0][0], -kv[1])):
-    print(f"{n / N:6.1f} calls/step  {name:34s} {site}")
+    print(f"{n / N:6.1f} calls/step  {byt[(name, site)] / N / 1e6:9.2f} MB/step  {name:34s} {site}")
 print("total", sum(cnt.values()) / N)
