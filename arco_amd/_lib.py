@@ -108,6 +108,8 @@ _SIGS = {
     "arco_det_clear_rows": [_P, _P, _L, _P, _L, _I, _P],
     "arco_corner_rows3d": [_P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "arco_corner_rows2d": [_P, _L, _I, _I, _I, _I, _P, _P, _P],
+    "arco_row_nonzero": [_P, _L, _I, _L, _P, _P],
+    "arco_put_rows": [_P, _L, _I, _P, _L, _P, _L, _P],
     "arco_fold_residual": [_P, _I, _I, _P, _P, _P],
     "arco_unfold_residual": [_P, _P, _I, _I, _P, _P],
     "arco_combine_terms": [_P, _P, _I, _P, _P],

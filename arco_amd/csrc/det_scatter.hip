@@ -124,6 +124,36 @@ __global__ __launch_bounds__(256) void corner_rows3d_kernel(const int64_t* __res
       }
 }
 
+// flag[r] = 1 when row r of X [M, C] holds any element that is not +-0 (nan and inf count): the gradient of a dense per-pixel layer
+// whose loss reads a few sampled rows is zero everywhere else, and the 1x1 convolutions' backward (ops.ConvFn) then runs on the
+// flagged rows only.  One wave per 4 rows x 64 lanes of 16-byte loads; reads X once.
+__global__ __launch_bounds__(256) void row_nonzero_kernel(const float* __restrict__ X, long ld, int C, long M, unsigned char* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const long r = ((long)blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (r >= M) return;
+  const float* x = X + r * ld;
+  unsigned any = 0;
+  const int C4 = C & ~3;
+  for (int c = lane * 4; c < C4; c += 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + c);
+    any |= (v[0] | v[1] | v[2] | v[3]) & 0x7fffffffu;
+  }
+  for (int c = C4 + lane; c < C; c += 64) any |= __float_as_uint(x[c]) & 0x7fffffffu;
+  const unsigned long long b = __ballot(any != 0);
+  if (lane == 0) flag[r] = b ? 1 : 0;
+}
+// dst[idx[j]][0..C) = src[j][0..C)   (idx without repetitions: plain stores)
+__global__ __launch_bounds__(256) void put_rows_kernel(const float* __restrict__ src, long lds_, int C, const int64_t* __restrict__ idx, long n,
+                                                      float* __restrict__ dst, long ldd) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const float* s = src + j * lds_;
+  float* d = dst + idx[j] * ldd;
+  for (int c = lane * 4; c < (C & ~3); c += 256) *reinterpret_cast<f32x4*>(d + c) = *reinterpret_cast<const f32x4*>(s + c);
+  for (int c = (C & ~3) + lane; c < C; c += 64) d[c] = s[c];
+}
+
 // 2-D counterpart (bilinear, align_corners: the adjoint of gather_upcat_rows, elementwise.hip): four corners y, x with x fastest
 __global__ __launch_bounds__(256) void corner_rows2d_kernel(const int64_t* __restrict__ pix, long n, int Hi, int Wi, int Ho, int Wo,
                                                            int64_t* __restrict__ idx4, float* __restrict__ w4) {
@@ -194,6 +224,21 @@ int arco_corner_rows2d(const int64_t* pix, long n, int Hi, int Wi, int Ho, int W
   ARCO_CHECK_ARG(pix && idx4 && w4 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
   if (n == 0) return ARCO_OK;
   hipLaunchKernelGGL(corner_rows2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), pix, n, Hi, Wi, Ho, Wo, idx4, w4);
+  return arco_launch_status();
+}
+
+int arco_row_nonzero(const float* X, long ld, int C, long M, unsigned char* flag, void* stream) {
+  ARCO_CHECK_ARG(X && flag && C > 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (M == 0) return ARCO_OK;
+  hipLaunchKernelGGL(row_nonzero_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), X, ld, C, M, flag);
+  return arco_launch_status();
+}
+
+int arco_put_rows(const float* src, long ld_src, int C, const int64_t* idx, long n, float* dst, long ld_dst, void* stream) {
+  ARCO_CHECK_ARG(src && idx && dst && C > 0 && (ld_src & 3) == 0 && (ld_dst & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(put_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), src, ld_src, C, idx, n, dst, ld_dst);
   return arco_launch_status();
 }
 

@@ -601,6 +601,56 @@ def colsum(xr, ld, m, c):
     return out
 
 
+# Row-sparse backward of the dense per-pixel layers.  The reference's trainer calls FeatureExtractor and q_representation on whole
+# feature maps (model_2D.py:51-53, train_arco_2d.py:231-234, 324-326: [16 x 65 536] rows of 496 channels) and its loss reads `rep` at
+# <= num_queries sampled rows per class (loss_helper_3d.py:455-457): d loss / d rep is zero in every other row, and because these
+# layers are per-pixel so is every gradient down to the first resampling.  Autograd hands ConvFn.backward the dense tensor; one pass
+# over it finds the rows that hold anything (arco_row_nonzero), and when they are few the data gradient and the weight gradient run
+# on those rows alone: the same kernels on [n, C] instead of [M, C] (data-gradient rows bit-identical - a row's result does not depend
+# on the other rows; weight gradients differ by fp32 summation order only), the rest of dx is a memset.  Needs the count on the host
+# (one synchronisation per layer): eager backward only, never inside a graph capture.  ARCO_SPARSE_BWD=0: always dense.
+SPARSE_BWD = int(__import__('os').environ.get('ARCO_SPARSE_BWD', '1'))
+SPARSE_BWD_MIN_ROWS = 65536
+SPARSE_BWD_MIN_CH = 128          # the heads' widths (496 ... 384; 3-D 240 ... 128); the U-Net's own 1x1 convs stay below it
+SPARSE_BWD_MAX_FRAC = 0.125
+sparse_bwd_stats = {"sparse": 0, "dense": 0}      # how often each route was taken (tests, bench)
+
+
+def _conv1x1_backward_on_nonzero_rows(ctx, dy, dyr, ldy, co, xr, ldx, ci, x, weight):
+    M = int(dyr.shape[0])
+    dev = dyr.device
+    flag = torch.empty(M, dtype=torch.uint8, device=dev)
+    L.call("arco_row_nonzero", L.ptr(dyr), ldy, co, M, L.ptr(flag))
+    idx = torch.nonzero(flag).view(-1)                   # ascending row ids; synchronises (the count sizes the launches below)
+    n = int(idx.shape[0])
+    if n > SPARSE_BWD_MAX_FRAC * M:
+        sparse_bwd_stats["dense"] += 1
+        return None
+    sparse_bwd_stats["sparse"] += 1
+    n_pad = max(16, (n + 15) // 16 * 16)                 # whole 16-row MFMA tiles; the padding rows are zero
+    dyc = torch.zeros((n_pad, co), dtype=torch.float32, device=dev)
+    dx = dw = db = None
+    if n:
+        L.call("arco_gather_rows", L.ptr(dyr), ldy, co, None, L.ptr(idx), None, 0, n, L.ptr(dyc), co)
+    if ctx.needs_input_grad[1]:
+        xc = torch.zeros((n_pad, ci), dtype=torch.float32, device=dev)
+        if n:
+            L.call("arco_gather_rows", L.ptr(xr), ldx, ci, None, L.ptr(idx), None, 0, n, L.ptr(xc), ci)
+        dw = _wgrad(dyc, co, co, xc, ci, ci, 1, 1, 1, n_pad, weight, keep=(dyc, xc))
+    if ctx.needs_input_grad[0]:
+        wd = pack_weight(weight, 1, 1)
+        dxc, _ = conv_raw(dyc, co, co, wd, ci, 1, 1, n_pad, 1, grad=True, residual=dyc if ctx.residual else None,
+                          ld_res=co if ctx.residual else 0)
+        dxc_r, ldc = rows_view(dxc)
+        dx = torch.zeros((int(x.shape[0]), *[int(v) for v in x.shape[2:]], ci), dtype=torch.float32, device=dev).movedim(-1, 1)
+        if n:
+            dxr, lddx = rows_view(dx)
+            L.call("arco_put_rows", L.ptr(dxc_r), ldc, ci, L.ptr(idx), n, L.ptr(dxr), lddx)
+    if ctx.has_bias and ctx.needs_input_grad[2]:
+        db = _zeros_cached((co,), dev) if ctx.bias_grad_zero else colsum(dyc, co, n_pad, co)
+    return dx, dw, db, (dy if ctx.res_tensor and ctx.needs_input_grad[3] else None), None
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv(x) (+ bias) (+ x when residual) for 1x1 / 3x3 (2-D) and 1x1x1 / 3x3x3 (3-D) kernels.
     Reference: nn.Conv2d in unetWithArgs.py:72,139 / model_2D.py:25-33 / train_arco_2d.py:231-234;
@@ -635,6 +685,11 @@ class ConvFn(torch.autograd.Function):
         xr, ldx = rows_view(x)
         ci = int(x.shape[1])
         dx = dw = db = None
+        if taps == 1 and SPARSE_BWD and nv * d3 * h * w >= SPARSE_BWD_MIN_ROWS and co >= SPARSE_BWD_MIN_CH and ci >= SPARSE_BWD_MIN_CH and not _is_half(dy) \
+                and xr.dtype == torch.float32 and not torch.cuda.is_current_stream_capturing():
+            r = _conv1x1_backward_on_nonzero_rows(ctx, dy, dyr, ldy, co, xr, ldx, ci, x, weight)
+            if r is not None:
+                return r
         if ctx.needs_input_grad[1]:      # first: it forks to the side stream and runs beside the data gradient
             dw = _wgrad(dyr, ldy, co, xr, ldx, ci, taps, nv, h, w, weight, d3=d3, keep=(dy, x))
         if ctx.needs_input_grad[0]:

@@ -403,7 +403,9 @@ def run_sub(name, steps):
     while time.perf_counter() - t_pre < 2.5:
         run_steps(4)
         torch.cuda.synchronize()
+    sb0 = dict(ops.sparse_bwd_stats)
     ms = timed(run_steps, steps)
+    sb = {k: round((ops.sparse_bwd_stats[k] - sb0[k]) / max(1, steps), 2) for k in sb0}       # 1x1-conv backward calls per step by route
     mem = torch.cuda.max_memory_allocated() / 1e9
     if cfg["kind"] == "2d":
         T.TEACHER_SIDE = 0            # single-stream eager pass for the per-kernel timing (see main())
@@ -416,7 +418,9 @@ def run_sub(name, steps):
                       "steps": steps, "dtype": ("f16 activation storage + f16 MFMA (fp32 accumulate) in the V-Net; fp32 elsewhere" if cfg.get("act") == "f16" else
                                                 {"f32": "f32", "f32x3": "f32 (split-bf16 matrix-core mode, fp32-accurate)"}.get(cfg["mma"], "f32 storage, f16/bf16 MFMA operands")),
                       "flags": "trainer defaults" + (" + " + " ".join(cfg["extra"]) if cfg.get("extra") else "") + ("" if cfg["kind"] == "2d" else " (--eqv_pass 1)"),
-                      "peak_mem_gb": round(mem, 2), "loss_terms": terms, "roofline": roof, "whole_step": whole}))
+                      "peak_mem_gb": round(mem, 2), "loss_terms": terms,
+                      "wide_1x1_backward_calls_per_step": {"on_nonzero_rows": sb["sparse"], "dense": sb["dense"]},
+                      "roofline": roof, "whole_step": whole}))
 
 
 def sub_record(name, steps):

@@ -259,6 +259,13 @@ int arco_corner_rows3d(const int64_t* pix, long n, int Di, int Hi, int Wi, int D
                        void* stream);
 /*   arco_corner_rows2d:     the bilinear counterpart (four corners; adjoint of arco_gather_upcat_rows, model_2D.py:43-50)              */
 int arco_corner_rows2d(const int64_t* pix, long n, int Hi, int Wi, int Ho, int Wo, int64_t* idx4, float* w4, void* stream);
+/* Row-sparse backward of the dense per-pixel layers (nn.Conv2d(k=1) of FeatureExtractor / q_representation called on whole maps:
+ * model_2D.py:51-53, train_arco_2d.py:231-234, 324-326).  The loss reads `rep` at a few hundred sampled rows (loss_helper_3d.py:455-457),
+ * so d loss / d rep - and, the layers being per-pixel, every gradient down to the first resampling - is zero in all other rows:
+ *   arco_row_nonzero: flag[r] = any element of row r that is not +-0   (one pass over the gradient)
+ *   arco_put_rows:    dst[idx[j]] = src[j]  (idx unique: the compacted data gradient back into a zero tensor)                          */
+int arco_row_nonzero(const float* X, long ld, int C, long M, unsigned char* flag, void* stream);
+int arco_put_rows(const float* src, long ld_src, int C, const int64_t* idx, long n, float* dst, long ld_dst, void* stream);
 /* glue kernels replacing chains of tensor-library launches in the step (no reference counterpart: the reference's
  * autograd does these as separate zeros / add / copy / mul kernels, train_arco_2d.py:426-431, model_2D.py:43-50):
  * arco_zero_rows: rows idx[] of a [rows, ld] buffer zeroed over C channels (re-arms a persistent gradient buffer);

@@ -35,13 +35,21 @@ def _drop_off(m):
                                      # the loss's degenerate-batch path (loss_helper_3d.py:417-424: <= 1 valid class -> `0.0 * rep.sum()`):
                                      # every head parameter gets a ZERO gradient, and SGD still applies weight decay / momentum to it
                                      dict(dense_head=0, head_levels=3, dense_teacher=0, k2=0.0, apply_aug="none", zero_path=1),
-                                     dict(dense_head=1, k2=0.0, apply_aug="none", zero_path=1)])
+                                     dict(dense_head=1, k2=0.0, apply_aug="none", zero_path=1),
+                                     # the SHIPPED schedule against the oracle directly (every variant above runs
+                                     # --graphs 0 and reaches the default only through graph == eager and two-stream == single-stream):
+                                     # trainer-default graph capture + replay and the two-stream pass schedule; three warm-up steps on
+                                     # other data make every graph exist, the state is rolled back, the two compared steps REPLAY
+                                     dict(dense_head=0, head_levels=3, dense_teacher=0, k2=1.0, apply_aug="cutmix", graphs=1, warm=1),
+                                     dict(dense_head=0, head_levels=3, dense_teacher=0, k2=1.0, apply_aug="cutout", graphs=1, warm=1,
+                                          batch_transform=1)])
 def test_two_steps_vs_cpu_oracle(variant):
     from arco_amd import train_arco_2d as T
     b, patch, C, Q, Nn, qs = 2, (64, 64), 4, 64, 32, 300
     unet_sd, fe_sd = fx.unet_state(21, 1, C), fx.fe_state(31)
     variant = dict(variant)
     zero_path = bool(variant.pop("zero_path", 0))
+    warm = bool(variant.pop("warm", 0))
     if zero_path:       # both nets predict class 0 everywhere and the labels are all background: one valid class
         unet_sd["decoder.out_conv.weight"] = unet_sd["decoder.out_conv.weight"] * 0.0
         unet_sd["decoder.out_conv.bias"] = torch.tensor([6.0, 0.0, 0.0, 0.0])
@@ -69,6 +77,25 @@ def test_two_steps_vs_cpu_oracle(variant):
         st_g.q_representation[1].weight.copy_(qrep_w[1])
     for m in (st_g.model, st_g.ema_model):
         _drop_off(m)
+    if warm:
+        import test_configs_at_size_gpu as TC
+        assert args.graphs == 1 and T.TEACHER_SIDE >= 3
+        snap = TC._snapshot(st_g)
+        heads0 = [p.detach().clone() for m in (st_g.q_feature_extractor, st_g.q_representation) for p in m.parameters()]
+        wr = np.random.RandomState(99)
+        for w in range(3):
+            random.seed(50 + w); np.random.seed(50 + w); torch.manual_seed(50 + w)
+            st_g.step(torch.from_numpy(wr.uniform(size=(b, 1, *patch)).astype(np.float32)).cuda(),
+                      torch.from_numpy(fx.blob_labels(wr, b, patch, C)).cuda(),
+                      torch.from_numpy(wr.uniform(size=(b, 1, *patch)).astype(np.float32)).cuda())
+        torch.cuda.synchronize()
+        assert st_g.s_train_lu.captured == bool(st_g.args.graph_train) and len(st_g.t_fwd_lu.graphs) > 0      # the compared steps replay
+        TC._restore(st_g, snap)
+        with torch.no_grad():                           # (the rollback is complete: the heads are back at their seed values)
+            for p0, p in zip(heads0, [p for m in (st_g.q_feature_extractor, st_g.q_representation) for p in m.parameters()]):
+                assert torch.equal(p0, p)
+        if st_g.random_pool is not None:
+            raise AssertionError("warm variants do not roll the revisiting pool back")
     st_o = cpu_step.make_state(unet_sd, fe_sd, qrep_w)
     bank_o, ptr_o, qsz = fx.fresh_bank(C, 496, qs, 'zeros')
     pool_o = None
@@ -131,15 +158,19 @@ def test_two_steps_vs_cpu_oracle(variant):
                                        rtol=1e-6, atol=1e-9)
     # updated weights: student U-Net (by name), heads, teacher
     sd_g = st_g.model.state_dict()
-    worst = 0.0
+    worst, worst_key = 0.0, None
     for k, v in st_o["student"].items():
         if not v.requires_grad:
             continue
         ref = v.detach()
         err = float((sd_g[k].cpu() - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
-        worst = max(worst, err)
-    wtol = 1e-3 if all_same else 3e-2          # (a step that drew another warp optimised another equivariance term)
-    assert worst < wtol, worst
+        if err > worst:
+            worst, worst_key = err, k
+    # (behind batch_transform the two sides' INPUT images agree to ~1e-4 only - fp32 association of AdvMorph's eight grid compositions -
+    #  and the deepest BatchNorm sees 2 x 4 x 4 values per channel at this patch size: 1.1e-3 measured on one gamma, 2e-3 allowed;
+    #  a step that drew another warp optimised another equivariance term)
+    wtol = (2e-3 if bt else 1e-3) if all_same else 3e-2
+    assert worst < wtol, (worst, worst_key)
     for k, v in st_o["q_fe"].items():
         ref = v.detach()
         got = st_g.q_feature_extractor.state_dict()[k].cpu()
