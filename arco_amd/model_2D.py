@@ -77,11 +77,33 @@ class FeatureExtractor(nn.Module):
             x = ops.conv(f[i], w_hi, None, residual=ops.bilinear(lo, f[i].shape[-2:]))
         return x, f[3], f[4]
 
-    def forward(self, fea_list):
+    def forward_reference_order(self, fea_list):
+        """model_2D.py:43-53 literally: upsample, concatenate, convolve at every level (the [B, 496, 256, 256] concatenation and a
+        1 M-row 496 x 496 GEMM at the last one).  Kept as the comparison target of the tests."""
         x, f4 = self.forward_lowres(fea_list)
         x = ops.bilinear(x, f4.shape[-2:])
         x = torch.cat((x, f4), dim=1)
         return ops.conv(x, self.fea4.weight, None, residual=False)         # fea4(x)
+
+    def forward(self, fea_list):
+        """The dense representation [B, output_dim, H, W] (model_2D.py:43-53) with every 1x1 convolution pushed BELOW its upsample
+        (forward_lowres2's identity: a bias-free 1x1 conv acts per pixel, bilinear interpolation per channel, so they commute):
+            x <- up((W_i + I)[:, :c] . x) + (W_i + I)[:, c:] . f_i        (levels 1-3),      rep = up(W_4[:, :c] . x) + W_4[:, c:] . f_4.
+        The wide block of every level runs on 4x fewer pixels and no concatenation is materialised: at config 2 the last level is a
+        [262 144 x 480 x 496] GEMM + a K = 16 GEMM with the upsampled product as its residual operand instead of a 2 GB concatenation
+        and a [1 048 576 x 496 x 496] GEMM (516 -> 141 GFLOP; the same factor in the backward).  Values differ from the reference
+        order by fp32 rounding only (tests/test_nets_gpu.py, tests/test_head_gpu.py)."""
+        f = [ops.to_channels_last(t) for t in fea_list]
+        x = ops.conv(f[0], self.fea0.weight, None, residual=True)
+        for i, fea in enumerate((self.fea1, self.fea2, self.fea3), start=1):
+            c = int(x.shape[1])
+            w_lo, w_hi = ops.fold_residual(fea.weight, c)                            # (W + I)[:, :c], (W + I)[:, c:]
+            lo = ops.conv(x, w_lo)                                                   # at the low resolution
+            x = ops.conv(f[i], w_hi, None, residual=ops.bilinear(lo, f[i].shape[-2:]))
+        c = int(x.shape[1])
+        w = self.fea4.weight                                                          # no residual at the last level
+        lo = ops.conv(x, w[:, :c].contiguous())
+        return ops.conv(f[4], w[:, c:].contiguous(), None, residual=ops.bilinear(lo, f[4].shape[-2:]))
 
 
 def create_model(ema=False, num_classes=4, train_encoder=True, train_decoder=True, in_chns=1):

@@ -116,6 +116,29 @@ def test_feature_extractor_vs_golden(golden, tag, dims, od):
             np.testing.assert_allclose(f.grad.double().abs().sum().item(), g[tag + f"_dx{i}_sum"][1], rtol=2e-3)
 
 
+def test_feature_extractor_commuted_forward_equals_the_reference_order():
+    """FeatureExtractor.forward evaluates model_2D.py:43-53 with every 1x1 convolution below its upsample (no concatenation, the wide
+    blocks on 4x fewer pixels); forward_reference_order is the literal order.  Same values and gradients up to fp32 rounding."""
+    from arco_amd.model_2D import FeatureExtractor
+    dims, od, sp = (256, 128, 64, 32, 16), 496, 64
+    fe = FeatureExtractor(fea_dim=list(dims), output_dim=od).cuda()
+    fe.load_state_dict(fx.fe_state(31, dims, od, nd=2), strict=True)
+    res = []
+    for fwd in (fe.forward, fe.forward_reference_order):
+        fl = [fx.image_batch(40 + i, 2, c, (sp >> (4 - i), sp >> (4 - i))).cuda().requires_grad_(True) for i, c in enumerate(dims)]
+        fe.zero_grad(set_to_none=True)
+        y = fwd(fl)
+        (y * probe_like(y, 3)).sum().backward()
+        res.append((y.detach(), [f.grad for f in fl], {n: p.grad.clone() for n, p in fe.named_parameters()}))
+    (y0, dx0, g0), (y1, dx1, g1) = res
+    sc = float(y1.abs().max())
+    assert float((y0 - y1).abs().max()) <= 2e-6 * sc
+    for a, b in zip(dx0, dx1):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    for n in g0:
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-5 * float(g1[n].abs().max()), n
+
+
 @pytest.mark.parametrize("nb,H,W,grads,sp", [(4, 64, 96, True, 0), (4, 64, 96, True, 1), (8, 256, 256, False, 1)])
 def test_bn_groups_equal_separate_passes(nb, H, W, grads, sp):
     """`with ops.bn_groups(2)`: one pass over cat(xa, xb) == a pass over xa then a pass over xb (outputs, every
