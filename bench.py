@@ -456,6 +456,29 @@ def forced_dist_record(steps=20):
         return {"sub": "forced_dist_world1", "error": repr(e)}
 
 
+def dropin_user_record(steps=6):
+    """A reference-style USER of the drop-in boundary at the headline size, in a child process: tests/dropin_user.py (this
+    repository's own form of the reference trainer's sequence of calls; `dropin/` first on sys.path binds arco_amd through the
+    reference's own import statements) with everything such a trainer builds itself in plain torch - nn.Conv2d q_representation,
+    torch.optim.SGD, CPU-side entropy percentiles and bank bookkeeping, no graphs / plans / row-sparse head.  What the boundary's
+    user gets per step, as opposed to ArcoStep2D (the headline) and to ArcoStep2D in the dense dataflow (`dropin_dense_dataflow`)."""
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK")}
+        script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "dropin_user.py")
+        out = subprocess.run([sys.executable, script, "time", str(steps)], env=env, capture_output=True, text=True, timeout=600)
+        for ln in reversed(out.stdout.splitlines()):
+            if ln.startswith("DROPIN_USER_TIME "):
+                r = json.loads(ln[len("DROPIN_USER_TIME "):])
+                return {"sub": "dropin_user_step", "ms_per_step": r["ms_per_step"], "steps_per_s": round(1e3 / r["ms_per_step"], 3), "steps": steps,
+                        "peak_mem_gb": r["peak_mem_gb"], "loss_terms": {k: round(v, 5) for k, v in r["last"].items() if k.startswith(("loss", "reco", "unsup"))},
+                        "workload": "the headline workload (BASELINE.json configs[1]) driven by a reference-style user of dropin/: dense "
+                                    "496-channel maps, torch nn.Conv2d q_representation and torch.optim.SGD, three student passes, "
+                                    "CPU-side percentiles, eager"}
+        return {"sub": "dropin_user_step", "error": (out.stderr or out.stdout)[-400:]}
+    except Exception as e:
+        return {"sub": "dropin_user_step", "error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -635,7 +658,7 @@ def main():
             del stepper
             batches.clear()
             torch.cuda.empty_cache()
-            out["configs"] = [sub_record(n, a.sub_steps) for n in SUBS] + [forced_dist_record()]
+            out["configs"] = [sub_record(n, a.sub_steps) for n in SUBS] + [forced_dist_record(), dropin_user_record()]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

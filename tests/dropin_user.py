@@ -130,7 +130,10 @@ def step(S, l, lab_l, u, cfg):
     rep_l, rep_u = S["q_rep"](S["q_fe"](fm_l)), S["q_rep"](S["q_fe"](fm_u))
     rep_lt, rep_ut = S["k_fe"](tfm_l), S["k_fe"](tfm_u)
     rep_all, pred_all = torch.cat((rep_l, rep_u)), torch.cat((pred_l, pred_u))
-    loss_q, keys = pool_distance_loss(S["pool"], rep_u, rep_ut, cfg["topk"])
+    if cfg["k4"]:
+        loss_q, keys = pool_distance_loss(S["pool"], rep_u, rep_ut, cfg["topk"])
+    else:                                                # (timing mode: the revisiting term is opt-in in the trainers, off at the headline)
+        loss_q, keys = torch.zeros((), device=DEV), None
     ce = F.cross_entropy(pred_l, lab_l.long())
     dice = S["dice"](torch.softmax(pred_l, dim=1), lab_l.unsqueeze(1))
     unsup = confidence_weighted_ce(pred_u, lab_u, conf_u, 0.97)
@@ -142,10 +145,11 @@ def step(S, l, lab_l, u, cfg):
     reco = compute_contra_memobank_loss(rep_all, oh_l.long(), oh_u.long(), pt_l, pt_u, low, high, B["memobank"], B["ptr"], B["size"],
                                         torch.cat((rep_lt, rep_ut)).detach(), delta_n=0.97, func="smc",
                                         num_queries=cfg["Q"], num_negatives=cfg["Nn"])[-1]
-    with torch.no_grad():                                # pool update (a ring of K rows)
-        n = keys.shape[0]
-        S["pool"][S["pool_ptr"]:S["pool_ptr"] + n] = keys
-        S["pool_ptr"] = (S["pool_ptr"] + n) % cfg["K"]
+    if keys is not None:
+        with torch.no_grad():                            # pool update (a ring of K rows)
+            n = keys.shape[0]
+            S["pool"][S["pool_ptr"]:S["pool_ptr"] + n] = keys
+            S["pool_ptr"] = (S["pool_ptr"] + n) % cfg["K"]
     labels = torch.cat((lab_l, lab_u)); conf = torch.cat((torch.full_like(lab_l, 255).float(), conf_u))
     mask = ((labels != 0) & (conf >= 0.7)).float().unsqueeze(1)
     eqv = equivariance(S, torch.cat((l, u_mix)), mask, pred_all)
@@ -163,8 +167,39 @@ def step(S, l, lab_l, u, cfg):
                 banks_on_gpu=all(m[0].is_cuda for m in B["memobank"]))
 
 
+def time_at_headline_size(steps=6):
+    """`python tests/dropin_user.py time`: the same user at BASELINE.json configs[1] size (8 + 8 images of 256 x 256, 256 queries, 512
+    negatives, 4096-key banks; revisiting term off as in the trainers' default) - milliseconds per step of a reference-style trainer
+    over the drop-in modules, torch's own q_representation / SGD and the CPU-side bank bookkeeping included (bench.py sub-record)."""
+    import time
+    C, b, patch = 4, 8, (256, 256)
+    cfg = dict(k1=1.0, k2=1.0, k3=1.0, k4=0.0, topk=3, K=2, Q=256, Nn=512, mix="cutmix")
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    rs = np.random.RandomState(3)
+    S = build(C, b, patch, 4096, 2, rs)
+    batches = []
+    for it in range(3):
+        batches.append((torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32)).to(DEV),
+                        torch.from_numpy(fx.blob_labels(rs, b, patch, C)).to(DEV),
+                        torch.from_numpy(rs.uniform(size=(b, 1, *patch)).astype(np.float32)).to(DEV)))
+    for it in range(3):
+        l, lab, u = batches[it % 3]
+        step(S, l, lab, u, cfg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        l, lab, u = batches[it % 3]
+        out = step(S, l, lab, u, cfg)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print("DROPIN_USER_TIME " + json.dumps(dict(ms_per_step=round(ms, 2), steps=steps, last=out, model_file=sys.modules["model_2D"].__file__,
+                                                peak_mem_gb=round(torch.cuda.max_memory_allocated() / 1e9, 2))))
+
+
 def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "a"
+    if case == "time":
+        return time_at_headline_size(int(sys.argv[2]) if len(sys.argv) > 2 else 6)
     k2, mix = {"a": (1.0, "cutmix"), "b": (0.0, "cutout")}[case]
     C, b, patch, Q, Nn, qs, K = 4, 2, (64, 64), 64, 32, 300, 6
     cfg = dict(k1=1.0, k2=k2, k3=1.0, k4=0.5, topk=3, K=K, Q=Q, Nn=Nn, mix=mix)
