@@ -78,3 +78,54 @@ def test_dropin_user_3d_matches_the_reference_volume_loop():
     assert max(got["steps"][-1]["bank_len"]) == 200                      # a bank met the truncation
     for k, v in got["end"].items():
         np.testing.assert_allclose(v, float(g[f"v_end_{k}"]), rtol=2e-3, err_msg=k)
+
+
+def test_star_imported_nn_builds_q_representation_on_the_hip_path():
+    """The reference trainers get `nn` from their star imports and build q_representation with it (train_arco_2d.py:231-234,
+    train_arco_3d.py:206-209).  dropin/ exports arco_amd.nn_dropin.nn there: torch.nn with 1x1 Conv2d / Conv3d through ops.conv.
+    Same module surface; values and gradients equal torch's own convolution up to fp32 summation order; anything that is not a plain
+    1x1 convolution of an fp32 GPU tensor takes torch's forward."""
+    code = r'''
+import sys, json
+sys.path.insert(0, sys.argv[1])
+import torch
+from model_2D import *
+from loss_helper_3d import *
+tnn = torch.nn
+out = {}
+out["cls"] = [nn.Conv2d.__name__, nn.Conv2d.__module__, issubclass(nn.Conv2d, tnn.Conv2d), nn.Sequential is tnn.Sequential,
+              nn.functional is tnn.functional, nn.KLDivLoss is tnn.KLDivLoss]
+torch.manual_seed(0)
+q = nn.Sequential(nn.Conv2d(496, 496, kernel_size=1, bias=False), nn.Conv2d(496, 496, kernel_size=1, bias=False)).cuda()
+r = tnn.Sequential(tnn.Conv2d(496, 496, kernel_size=1, bias=False), tnn.Conv2d(496, 496, kernel_size=1, bias=False)).cuda()
+r.load_state_dict(q.state_dict())                       # same keys
+out["keys"] = sorted(q.state_dict().keys())
+x = torch.randn(2, 496, 96, 80, device="cuda")
+dy = torch.zeros(2, 496, 96, 80, device="cuda")
+dy[:, :, ::7, ::9] = torch.randn(2, 496, 14, 9, device="cuda")          # few rows: the backward takes the row route or the dense one
+res = []
+for m in (q, r):
+    xx = x.clone().requires_grad_(True)
+    y = m(xx)
+    y.backward(dy)
+    res.append((y.detach(), xx.grad, [p.grad for p in m.parameters()]))
+rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+out["fwd"] = rel(res[0][0], res[1][0]); out["dx"] = rel(res[0][1], res[1][1])
+out["dw"] = max(rel(a, b) for a, b in zip(res[0][2], res[1][2]))
+# not a plain 1x1 convolution: torch's own forward, bit for bit
+c3 = nn.Conv2d(16, 16, 3, padding=1).cuda(); t3 = tnn.Conv2d(16, 16, 3, padding=1).cuda(); t3.load_state_dict(c3.state_dict())
+xi = torch.randn(1, 16, 20, 20, device="cuda")
+out["c3_same"] = bool(torch.equal(c3(xi), t3(xi)))
+c1 = nn.Conv2d(32, 32, 1); out["cpu_same"] = bool(torch.equal(c1(torch.ones(1, 32, 4, 4)), tnn.functional.conv2d(torch.ones(1, 32, 4, 4), c1.weight, c1.bias)))
+v = nn.Sequential(nn.Conv3d(16, 16, kernel_size=1, bias=False)).cuda(); tv = tnn.Conv3d(16, 16, 1, bias=False).cuda(); tv.load_state_dict(v[0].state_dict())
+xv = torch.randn(1, 16, 12, 10, 8, device="cuda")
+out["v"] = rel(v(xv), tv(xv))
+print("NNDROP " + json.dumps(out))
+'''
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "dropin")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("NNDROP ")][-1][len("NNDROP "):])
+    assert out["cls"] == ["Conv2d", "arco_amd.nn_dropin", True, True, True, True] and out["keys"] == ["0.weight", "1.weight"]
+    assert out["fwd"] <= 2e-5 and out["dx"] <= 2e-5 and out["dw"] <= 1e-4 and out["v"] <= 1e-5, out
+    assert out["c3_same"] and out["cpu_same"]
