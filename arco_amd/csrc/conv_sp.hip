@@ -492,6 +492,9 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
       okm2[set] = m_valid & ~bad;
       // WAVE-UNIFORM choice (every wave must issue exactly NA load instructions: the vmcnt waits count them)
       const bool border = !real || d.y0 == 0 || d.y0 + TH == a.H || d.x0 == 0 || d.x0 + 16 == a.W || d.c * 16 + 16 > a.K;
+#ifdef RW_NO_LOAD          // (timing-only ablation builds, tools/debug/rw_abl.sh: never in the shipped library)
+      if (true) { (void)gbase; } else
+#endif
       if (!border) {
 #pragma unroll
         for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(voff[it]), "s"(gbase) : "memory");
@@ -512,7 +515,11 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
       for (int it = 0; it < NA; ++it) {
         const f32x4 v = ((okm >> it) & 1u) ? ra[set][it] : f32x4{0, 0, 0, 0};
         u32x2 p0, p1, p2;
+#ifdef RW_NO_SPLIT
+        p0 = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}; p1 = u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])}; p2 = p0;
+#else
         split3_bf16x4(v, p0, p1, p2);
+#endif
         if (ldsA[it] >= 0) {
           unsigned* d = buf + ldsA[it];
           *reinterpret_cast<u32x2_ma*>(d) = p0; *reinterpret_cast<u32x2_ma*>(d + 8) = p1; *reinterpret_cast<u32x2_ma*>(d + 16) = p2;
@@ -601,6 +608,10 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
       for (int at = 0; at < A_T; ++at) {
 #pragma unroll
         for (int ct = 0; ct < C_T; ++ct) {                  // D = W . X^T; small terms first
+#ifdef RW_NO_MFMA
+          asm volatile("" :: "v"(fb[P][ct][0]), "v"(fb[P][ct][1]), "v"(fb[P][ct][2]), "v"(fa[at][0]), "v"(fa[at][1]), "v"(fa[at][2]));
+          continue;
+#endif
           mfma_acc(acc[at][ct], fb[P][ct][0], fa[at][2]);
           mfma_acc(acc[at][ct], fb[P][ct][2], fa[at][0]);
           mfma_acc(acc[at][ct], fb[P][ct][1], fa[at][1]);
@@ -639,6 +650,9 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
         f32x4 v = acc[at][ct] + bv;
         if (n < a.N) {                                       // (N = 4 / 8 / 12 of the 16-wide block: the other lane groups idle)
           if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + pix * a.ldr + n);
+#ifdef RW_NO_STORE
+          if (v[0] == 1.2345e30f)
+#endif
           *reinterpret_cast<f32x4*>(a.C + pix * a.ldc + n) = v;
         }
 #pragma unroll
