@@ -166,3 +166,34 @@ def test_star_imports_do_not_rebind_what_the_trainer_imported_before(stmts):
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("SHADOWED")][-1]
     assert line.strip() == "SHADOWED", line
+
+
+def test_star_imported_nn_is_torch_nn_with_two_subclasses():
+    """The `nn` the reference trainers receive through `from model_2D import *` / `from loss_helper_3d import *` (they never import
+    torch.nn; train_arco_2d.py:158,231-234,419): torch.nn itself, except Conv2d / Conv3d subclasses whose GPU 1x1 forward takes the HIP path
+    (arco_amd/nn_dropin.py).  On a CPU-only host every call falls through to torch's own forward, bit for bit."""
+    code = r'''
+import sys, json
+sys.path.insert(0, sys.argv[1])
+import torch
+from model_2D import *
+from loss_helper_3d import *
+tnn = torch.nn
+q = nn.Sequential(nn.Conv2d(32, 32, kernel_size=1, bias=False), nn.Conv2d(32, 32, kernel_size=1, bias=False))
+x = torch.randn(2, 32, 5, 7)
+y = q(x)
+ref = tnn.functional.conv2d(tnn.functional.conv2d(x, q[0].weight), q[1].weight)
+v = nn.Conv3d(16, 16, kernel_size=1, bias=False)
+print("NN " + json.dumps(dict(name=[type(q[0]).__name__, type(v).__name__], sub=[isinstance(q[0], tnn.Conv2d), isinstance(v, tnn.Conv3d)],
+      same=bool(torch.equal(y, ref)), keys=sorted(q.state_dict()), rest=[nn.Sequential is tnn.Sequential, nn.KLDivLoss is tnn.KLDivLoss,
+      nn.functional.normalize is tnn.functional.normalize, nn.Module is tnn.Module, nn.BatchNorm2d is tnn.BatchNorm2d],
+      module=type(q[0]).__module__, repr=repr(q[0]))))
+'''
+    for flag, mod in (("1", "arco_amd.nn_dropin"), ("0", "torch.nn.modules.conv")):
+        env = dict({k: v for k, v in os.environ.items() if k != "PYTHONPATH"}, ARCO_DROPIN_NN=flag)
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "dropin")], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("NN ")][-1][3:])
+        assert out["name"] == ["Conv2d", "Conv3d"] and out["sub"] == [True, True] and out["same"] and out["keys"] == ["0.weight", "1.weight"]
+        assert all(out["rest"]) and out["module"] == mod
+        assert out["repr"] == "Conv2d(32, 32, kernel_size=(1, 1), stride=(1, 1), bias=False)"
