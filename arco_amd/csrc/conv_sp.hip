@@ -619,6 +619,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
           mfma_acc(acc[at][ct], fb[P][ct][1], fa[at][0]);
           mfma_acc(acc[at][ct], fb[P][ct][0], fa[at][0]);
         }
+#ifndef RW_NO_FRAG
         if (S < 4 || more) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) fa[at][pl] = lds_bf16x8(An + laneA + aoff[(S + 1) % 5] + at * 18 * 24 + 8 * pl);
@@ -626,6 +627,9 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
 #pragma unroll
         for (int k = at * BPA; k < (at + 1) * BPA && k < C_T * 3; ++k)
           fb[Q][k / 3][k % 3] = lds_bf16x8(Wb + laneB + (k / 3) * 16 * 24 + 8 * (k % 3));
+#else
+        (void)An; (void)Wb;
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     };
