@@ -19,6 +19,19 @@ def test_two_ranks_stay_identical():
     assert "DDP_OK" in out.stdout
 
 
+def test_two_ranks_f16_volume_step_with_an_overflow_on_one_rank():
+    """the f16 loss-scale guard under data parallelism - tools/ddp_check3d.py: six 3-D steps with --act_dtype f16 on
+    two ranks, an inf forced into ONE rank's V-Net gradient at step 3.  The guard writes only flat_g[:heads_start] (the heads' bucket is
+    inside an asynchronous all-reduce), the flag is all-reduced with MIN: both ranks skip that V-Net update, both halve the loss scale,
+    weights / teacher / heads / banks stay bit-identical across ranks."""
+    env = dict(os.environ, ARCO_DIST_BACKEND="gloo", ARCO_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "tools", "ddp_check3d.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "DDP3D_OK" in out.stdout
+
+
 def test_forced_one_rank_nccl_group_equals_the_plain_step_and_stays_reproducible():
     """ARCO_FORCE_DIST=1: a one-rank `nccl` group, every exchange of arco_amd/dist.py issued through RCCL /
     ProcessGroupNCCL inside the default two-stream, graph-replayed step at the headline size.  The run must (i) issue the step's
