@@ -655,3 +655,34 @@ def test_pack_plan_registry_entries_leave_with_the_plan():
     del plan, w2, b8, conv
     gc.collect()
     assert not (mine & set(ops._PLAN_BY_PTR))
+
+
+def test_feature_extractor_3d_commuted_forward_equals_the_reference_order():
+    """FeatureExtractor_3d.forward evaluates model_3D.py:43-58 with every 1x1x1 convolution below its trilinear upsample (no
+    concatenation; wide blocks on 8x fewer voxels); forward_reference_order is the literal order.  Values and gradients agree to fp32
+    rounding; the reference's golden vectors hold either way (test_vnet_and_fe3d_vs_reference_golden)."""
+    from arco_amd.model_3D import FeatureExtractor_3d
+    dims, od = (128, 64, 32, 16, 16), 16
+    fe = FeatureExtractor_3d(fea_dim=list(dims), output_dim=od).cuda()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in fe.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) / p.shape[1] ** 0.5).cuda())
+    sizes = [(4, 4, 2), (8, 8, 4), (16, 16, 8), (32, 32, 16), (32, 32, 16)]
+    base = [torch.randn((2, c, *sz), generator=g) for c, sz in zip(dims, sizes)]
+    probe = None
+    res = []
+    for fwd in (fe.forward, fe.forward_reference_order):
+        fl = [t.clone().cuda().requires_grad_(True) for t in base]
+        fe.zero_grad(set_to_none=True)
+        y = fwd(fl)
+        if probe is None:
+            probe = torch.randn(y.shape, generator=g).cuda()
+        (y * probe).sum().backward()
+        res.append((y.detach(), [f.grad for f in fl], {n: p.grad.clone() for n, p in fe.named_parameters()}))
+    (y0, dx0, g0), (y1, dx1, g1) = res
+    assert y0.shape == y1.shape and float((y0 - y1).abs().max()) <= 3e-6 * float(y1.abs().max())
+    for a, b in zip(dx0, dx1):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    for n in g0:
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * float(g1[n].abs().max()), n
