@@ -9,6 +9,8 @@ with `nn.Conv3d(16, 16, 1)`).  The `dropin/` modules therefore export THIS names
 split-bf16 GEMM kernels; backward on the non-zero rows of the incoming gradient when the loss touched few rows) and everything else
 through `torch.nn`'s own forward.  Same class name, parameters, `state_dict` keys, `isinstance(m, torch.nn.Conv2d)`; fp32-accurate
 results (torch's convolution differs from it by summation order, as two torch backends do).  `ARCO_DROPIN_NN=0`: plain `torch.nn`.
+Not supported on the accelerated route: double backward (`create_graph=True` through the convolution) - `ops.ConvFn` is a first-order
+autograd function; a trainer that needs it sets `ARCO_DROPIN_NN=0`.
 At the headline size a reference-style user's step spends 32 of 76 ms in torch's own 1x1 convolutions of q_representation (11 forward,
 21 in their dense backward); through this namespace: see `bench.py` sub-record `dropin_user_step`."""
 import os

@@ -117,6 +117,16 @@ c3 = nn.Conv2d(16, 16, 3, padding=1).cuda(); t3 = tnn.Conv2d(16, 16, 3, padding=
 xi = torch.randn(1, 16, 20, 20, device="cuda")
 out["c3_same"] = bool(torch.equal(c3(xi), t3(xi)))
 c1 = nn.Conv2d(32, 32, 1); out["cpu_same"] = bool(torch.equal(c1(torch.ones(1, 32, 4, 4)), tnn.functional.conv2d(torch.ones(1, 32, 4, 4), c1.weight, c1.bias)))
+# ragged sizes, a bias, NCHW-contiguous input, no_grad, an input that needs no gradient
+cb = nn.Conv2d(48, 32, kernel_size=1).cuda(); tb = tnn.Conv2d(48, 32, 1).cuda(); tb.load_state_dict(cb.state_dict())
+xo = torch.randn(3, 48, 7, 5, device="cuda")
+with torch.no_grad():
+    out["odd_nograd"] = rel(cb(xo), tb(xo))
+yb, yt = cb(xo), tb(xo)
+go = torch.randn_like(yt)
+yb.backward(go); yt.backward(go)
+out["odd"] = max(rel(yb.detach(), yt.detach()), rel(cb.weight.grad, tb.weight.grad), rel(cb.bias.grad, tb.bias.grad))
+out["odd_shape"] = [list(yb.shape), list(yt.shape)]
 v = nn.Sequential(nn.Conv3d(16, 16, kernel_size=1, bias=False)).cuda(); tv = tnn.Conv3d(16, 16, 1, bias=False).cuda(); tv.load_state_dict(v[0].state_dict())
 xv = torch.randn(1, 16, 12, 10, 8, device="cuda")
 out["v"] = rel(v(xv), tv(xv))
@@ -129,3 +139,4 @@ print("NNDROP " + json.dumps(out))
     assert out["cls"] == ["Conv2d", "arco_amd.nn_dropin", True, True, True, True] and out["keys"] == ["0.weight", "1.weight"]
     assert out["fwd"] <= 2e-5 and out["dx"] <= 2e-5 and out["dw"] <= 1e-4 and out["v"] <= 1e-5, out
     assert out["c3_same"] and out["cpu_same"]
+    assert out["odd_nograd"] <= 2e-5 and out["odd"] <= 1e-4 and out["odd_shape"][0] == out["odd_shape"][1], out
