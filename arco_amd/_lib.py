@@ -96,6 +96,8 @@ _SIGS = {
     "arco_conv1x1_upres_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I],
     "arco_conv3d_fwd": [_P, _L, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "arco_conv3d_wgrad": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P],
+    "arco_conv3d_fwd_pro": [_P, _L, _I, _P, _I, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "arco_conv3d_wgrad_pro": [_P, _L, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "arco_gather_upcat_rows3d": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "arco_scatter_upcat_rows3d": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P],
     "arco_zero_rows": [_P, _L, _I, _P, _L, _P],
@@ -140,6 +142,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_conv_config": ([_I, _I, _I, _I, _I, _I, _L, _P], _I),
     "arco_conv_config_mma": ([_I, _I, _I, _I, _I, _I, _L, _I], _I),
     "arco_conv_split_ok": ([_I, _I, _I, _I, _I, _I, _L], _I),
+    "arco_conv_pro_ok": ([_I, _I, _I, _I, _I, _I, _I, _L, _I, _I], _I),
     "arco_conv_sp_set": ([_I], _I),
     "arco_gemm_sp_set": ([_I, _L], _I),
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
@@ -184,6 +187,18 @@ def load():
 
 def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class ActPro(ctypes.Structure):
+    """include/arco_hip.h ArcoActPro: the consumer-side activation descriptor of arco_conv3d_fwd_pro / arco_conv3d_wgrad_pro."""
+    _fields_ = [("mean", _P), ("istd", _P), ("gamma", _P), ("beta", _P), ("slope", _F), ("groups", _I),
+                ("drop_mode", _I), ("p", _F), ("seed", _U64), ("seed_dev", _P)]
+
+
+def act_pro(mean, istd, gamma, beta, slope, groups, drop_mode, p, seed, seed_dev):
+    d = ActPro(mean.data_ptr(), istd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(slope), int(groups), int(drop_mode),
+               float(p), int(seed), None if seed_dev is None else seed_dev.data_ptr())
+    return ctypes.byref(d)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

@@ -40,6 +40,24 @@ __device__ __forceinline__ f32x8 ld8p(const float* p) {      // eight per-channe
 }
 __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- the stateless dropout mask (nn.Dropout / nn.Dropout3d of the blocks, unetWithArgs.py:43, vnetWithArgs.py:195,238)
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+  uint32_t s = v * 747796405u + 2891336453u;
+  uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+// keep-decision of the dropout mask for element index e (stateless: recomputed in backward)
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
+  const uint32_t h = pcg_hash((uint32_t)e ^ pcg_hash((uint32_t)(e >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+// the same decision for element indices below 2^32 with the seed half hashed once per launch (drop_key32): the loaders of the
+// convolution kernels evaluate it per staged element
+__device__ __forceinline__ uint32_t drop_key32(uint64_t seed) { return pcg_hash((uint32_t)seed) ^ (uint32_t)(seed >> 32); }
+__device__ __forceinline__ bool drop_keep32(uint32_t key, uint32_t e, float p) {
+  return (float)(pcg_hash(e ^ key) >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
 // bit layout of the per-pixel class code (C <= 21)
 #define ARCO_MAXC 21
 #define ARCO_BIT_LV(c) (c)

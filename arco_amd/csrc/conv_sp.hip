@@ -73,11 +73,12 @@ __device__ __forceinline__ void mfma_first(f32x4& c, const bf16x8& x, const bf16
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(x), "v"(y));
 }
 
-template <int A_T, int C_T>
+template <int A_T, int C_T, bool PRO = false>
 __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
   using G = SpGeom<A_T, C_T>;
   constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT, NB = G::NBI;
   constexpr int NA4 = (NA + 3) / 4;                              // activation pieces split + written per staging step
+  constexpr int NL = NA + (PRO ? 4 : 0);     // VMEM loads per chunk and wave: the activation pieces (+ the four parameter quads of a consumer-side activation)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned* const As = reinterpret_cast<unsigned*>(smem);
   unsigned* const Bs = As + 2 * G::A_DW;
@@ -106,16 +107,18 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
 
   // chunk descriptors (tile ordinal j of this workgroup, 16-channel chunk c), advanced incrementally: the divisions of the
   // tile decode run once per tile, not once per load
-  struct Desc { int j, c, img, y0, x0, nblk, mblk; };
+  struct Desc { int j, c, img, y0, x0, nblk, mblk, grp; };
+  const int ipg = PRO ? a.NB / (a.pro.groups > 1 ? a.pro.groups : 1) : 1;      // images per BatchNorm group of the producing layer
   auto decode = [&](Desc& d) {
     const int v = tile0 + d.j * G8;
     d.mblk = v / a.n_nblocks; d.nblk = v - d.mblk * a.n_nblocks;
     d.img = d.mblk / tiles_img;
+    d.grp = PRO ? d.img / ipg : 0;
     const int r = d.mblk - d.img * tiles_img, ty = r / tiles_x;
     d.y0 = ty * TH; d.x0 = (r - ty * tiles_x) * 16;
   };
   auto advance = [&](Desc& d) { if (++d.c == nchunks) { d.c = 0; ++d.j; decode(d); } };
-  Desc d0{0, 0, 0, 0, 0, 0, 0};
+  Desc d0{0, 0, 0, 0, 0, 0, 0, 0};
   decode(d0);
 
   if (producer) {
@@ -126,13 +129,14 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     const int qA = tid & 3;
     // per-thread geometry of the NA activation pieces, fixed for the launch (see conv3x3_rw_kernel): LDS offset, byte offset
     // from the halo origin, masks of the pieces on the tile's top / bottom halo row and left / right halo column
-    int ldsA[NA]; unsigned voff[NA];
+    int ldsA[NA]; unsigned voff[NA]; int poff[NA];
     unsigned m_valid = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int row = (tid + it * 256) >> 2;
       const int hy = row / 18, hx = row - hy * 18;
       const bool valid = row < G::AROWS;
+      poff[it] = hy * a.W + hx;                    // (PRO: pixel offset from the halo origin, for the dropout element index)
       ldsA[it] = valid ? row * 24 + qA * 2 : -1;
       voff[it] = valid ? (unsigned)(((hy * a.W + hx) * (int)a.lda + qA * 4) * 4) : 0u;
       m_valid |= valid ? (1u << it) : 0u;
@@ -159,6 +163,25 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     // Two register sets, loaded TWO chunks ahead (set = parity of the chunk the data belongs to): with 32-channel blocks
     // a chunk lasts ~2 us, less than an HBM miss under load.
     f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
+    // consumer-side activation (see conv3x3_rw_kernel): four parameter quads per chunk behind its activation loads, NL loads per chunk
+    f32x4 rp[2][4]; unsigned ebase2[2] = {0, 0};
+    const float* const pm_ = PRO ? uniform_ptr(a.pro.mean) : nullptr; const float* const pi_ = PRO ? uniform_ptr(a.pro.istd) : nullptr;
+    const float* const pg_ = PRO ? uniform_ptr(a.pro.gamma) : nullptr; const float* const pb_ = PRO ? uniform_ptr(a.pro.beta) : nullptr;
+    const bool pdrop = PRO && a.pro.drop_mode == 1;
+    uint32_t dkey = 0; float keep_scale = 1.f;
+    u32x2 salt = {0u, 0u};        // the per-replay dropout salt of a graph-captured pass: the kernel's OLDEST counted load (an asm load as
+    if (PRO && pdrop && a.pro.seed_dev) {     // the activations': a load hipcc knows of would drain the DMA queue in front of its use)
+      const float* sp_ = uniform_ptr(reinterpret_cast<const float*>(a.pro.seed_dev));
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(salt) : "v"(0u), "s"(sp_) : "memory");
+    }
+    auto drop_setup = [&]() {     // behind the first vmcnt wait of the prologue
+      if (PRO && pdrop) {
+        asm volatile("" : "+v"(salt)::"memory");
+        const unsigned long long sv = ((unsigned long long)salt[1] << 32) | salt[0];
+        const unsigned long long sd = a.pro.seed_dev ? a.pro.seed ^ (sv * 0x9E3779B97F4A7C15ull) : a.pro.seed;
+        dkey = drop_key32(sd); keep_scale = 1.0f / (1.0f - a.pro.p);
+      }
+    };
     auto load_A = [&](const Desc& d, bool real, int set) {
       // scalar base of the halo origin + the per-piece byte offsets: a tile costs a few scalar instructions and one mask
       // expression, not ~20 VALU instructions per piece; out-of-image pieces load the tile's first pixel and are zeroed at
@@ -180,13 +203,31 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
           asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(o), "s"(gbase) : "memory");
         }
       }
+      if constexpr (PRO) {
+        const int ch = d.c * 16 + qA * 4;
+        const unsigned po = (unsigned)(((real ? d.grp : 0) * a.K + ch) * 4), pa = (unsigned)(ch * 4);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rp[set][0]) : "v"(po), "s"(pm_) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rp[set][1]) : "v"(po), "s"(pi_) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rp[set][2]) : "v"(pa), "s"(pg_) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rp[set][3]) : "v"(pa), "s"(pb_) : "memory");
+        ebase2[set] = (unsigned)((((d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.K) + ch);
+      }
     };
     auto ra_fence = [&](int set) {
 #pragma unroll
       for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[set][it])::"memory");
+      if constexpr (PRO) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(rp[set][j])::"memory");
+      }
     };
     auto store_A = [&](unsigned* buf, int it, int set) {    // split piece `it` into its three bf16 planes (zero outside the image)
-      const f32x4 v = ((okm2[set] >> it) & 1u) ? ra[set][it] : f32x4{0, 0, 0, 0};
+      f32x4 v = ra[set][it];
+      if constexpr (PRO) {
+        v = pro_bn_lrelu(v, ProQuad{rp[set][0], rp[set][1], rp[set][2], rp[set][3]}, a.pro.slope);
+        if (pdrop) v = pro_dropout(v, dkey, ebase2[set] + (unsigned)poff[it] * (unsigned)a.K, a.pro.p, keep_scale);
+      }
+      v = ((okm2[set] >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
       u32x2 p0, p1, p2;
       split3_bf16x4(v, p0, p1, p2);
       if (ldsA[it] >= 0) {
@@ -210,13 +251,14 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     load_A(d0, true, 0);
     refill(0, d0); refill(1, d0); refill(2, d0);
     wait_vm<3 * NB>();                // chunk 0's activations (the DMA behind them stays in flight)
+    drop_setup();
     ra_fence(0);
 #pragma unroll
     for (int it = 0; it < NA; ++it) store_A(As, it, 0);
     refill(3, d0);
     load_A(d1, total_gc > 1, 1);      // (every wave issues every instruction, real or not: the counts below are exact)
     load_A(d2, total_gc > 2, 0);
-    wait_vm<NA>();                    // chunk 1's activations (split from step 0 on) and with them slots 0-3
+    wait_vm<NL>();                    // chunk 1's activations (split from step 0 on) and with them slots 0-3
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();
 
@@ -229,7 +271,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
         // VMEM instructions younger than what this barrier needs; order per chunk:
         // s0 R4 | s1 R0' | s2 R1' | s3 R2' | s4 R3' A+3   (the last chunks issue the same instructions on dummy addresses).
         // The activations split at steps 0-3 were loaded two chunks ago: older than anything these waits leave in flight.
-        constexpr int NS = S <= 2 ? NA + 2 * NB : 2 * NB;
+        constexpr int NS = S <= 2 ? NL + 2 * NB : 2 * NB;
         wait_vm<NS>();
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();
@@ -414,10 +456,11 @@ struct RwGeom {
   static size_t lds_bytes(int nchunks) { return (size_t)(2 * A_DW + nchunks * WCH_DW + BIAS_DW) * 4; }
 };
 
-template <int A_T, int C_T>
+template <int A_T, int C_T, bool PRO = false>
 __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
   using G = RwGeom<A_T, C_T>;
   constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT;
+  constexpr int NL = NA + (PRO ? 4 : 0);     // VMEM loads per chunk and wave: the activation pieces (+ the four parameter quads of a consumer-side activation)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned* const As = reinterpret_cast<unsigned*>(smem);
   const int nchunks = (a.K + 15) >> 4;                        // (K = 4 / 8 / 12: one chunk, the missing channels read as zero)
@@ -436,15 +479,17 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
   const int total_gc = my_tiles * nchunks;
   if (my_tiles == 0) return;
   const bool has_stats = a.stat_sum != nullptr;
-  struct Desc { int j, c, img, y0, x0, mblk; };
+  struct Desc { int j, c, img, y0, x0, mblk, grp; };
+  const int ipg = PRO ? a.NB / (a.pro.groups > 1 ? a.pro.groups : 1) : 1;      // images per BatchNorm group of the producing layer
   auto decode = [&](Desc& d) {
     d.mblk = tile0 + d.j * G8;
     d.img = d.mblk / tiles_img;
+    d.grp = PRO ? d.img / ipg : 0;
     const int r = d.mblk - d.img * tiles_img, ty = r / tiles_x;
     d.y0 = ty * TH; d.x0 = (r - ty * tiles_x) * 16;
   };
   auto advance = [&](Desc& d) { if (++d.c == nchunks) { d.c = 0; ++d.j; decode(d); } };
-  Desc d0{0, 0, 0, 0, 0, 0};
+  Desc d0{0, 0, 0, 0, 0, 0, 0};
   decode(d0);
 
   if (producer) {
@@ -467,13 +512,14 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
     // bottom halo row and left / right halo column.  A tile then costs a handful of scalar instructions (base address, which
     // image borders it touches) and ONE mask expression - no per-piece coordinate arithmetic (round 2: ~20 VALU instructions
     // per piece, 2300 cycles per tile next to the MFMA waves of the same SIMDs).
-    int ldsA[NA]; unsigned voff[NA];
+    int ldsA[NA]; unsigned voff[NA]; int poff[NA];
     unsigned m_valid = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int row = (tid + it * 256) >> 2;
       const int hy = row / 18, hx = row - hy * 18;
       const bool valid = row < G::AROWS;
+      poff[it] = hy * a.W + hx;                    // (PRO: pixel offset from the halo origin, for the dropout element index)
       ldsA[it] = valid ? row * 24 + qA * 2 : -1;
       voff[it] = valid ? (unsigned)(((hy * a.W + hx) * (int)a.lda + qA * 4) * 4) : 0u;
       m_valid |= valid ? (1u << it) : 0u;
@@ -482,6 +528,26 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
     }
     const unsigned safe_off = (unsigned)(((a.W + 1) * (int)a.lda + qA * 4) * 4);      // the tile's first pixel: always inside the tensor
     f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
+    // consumer-side activation: the four parameter quads of the chunk's channels travel with its activation loads (same asm
+    // loads, same vmcnt accounting: NL instructions per chunk), the element index base of the dropout mask with the register set
+    f32x4 rp[2][4]; unsigned ebase2[2] = {0, 0};
+    const float* const pm_ = PRO ? uniform_ptr(a.pro.mean) : nullptr; const float* const pi_ = PRO ? uniform_ptr(a.pro.istd) : nullptr;
+    const float* const pg_ = PRO ? uniform_ptr(a.pro.gamma) : nullptr; const float* const pb_ = PRO ? uniform_ptr(a.pro.beta) : nullptr;
+    const bool pdrop = PRO && a.pro.drop_mode == 1;
+    uint32_t dkey = 0; float keep_scale = 1.f;
+    u32x2 salt = {0u, 0u};        // the per-replay dropout salt of a graph-captured pass: the kernel's OLDEST counted load (an asm load as
+    if (PRO && pdrop && a.pro.seed_dev) {     // the activations': a load hipcc knows of would drain the DMA queue in front of its use)
+      const float* sp_ = uniform_ptr(reinterpret_cast<const float*>(a.pro.seed_dev));
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(salt) : "v"(0u), "s"(sp_) : "memory");
+    }
+    auto drop_setup = [&]() {     // behind the first vmcnt wait of the prologue
+      if (PRO && pdrop) {
+        asm volatile("" : "+v"(salt)::"memory");
+        const unsigned long long sv = ((unsigned long long)salt[1] << 32) | salt[0];
+        const unsigned long long sd = a.pro.seed_dev ? a.pro.seed ^ (sv * 0x9E3779B97F4A7C15ull) : a.pro.seed;
+        dkey = drop_key32(sd); keep_scale = 1.0f / (1.0f - a.pro.p);
+      }
+    };
     auto load_A = [&](const Desc& d, bool real, int set) {
       // (scalar) base of the halo origin; out-of-image pieces load the tile's first pixel instead and are zeroed at the split
       // (a descriptor past the workgroup's last chunk - real == false, the loads are dummies that keep the vmcnt counts
@@ -506,14 +572,35 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
           asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(o), "s"(gbase) : "memory");
         }
       }
+      if constexpr (PRO) {
+        const int ch = d.c * 16 + qA * 4;
+        const unsigned po = (unsigned)(((real ? d.grp : 0) * a.K + (ch < a.K ? ch : 0)) * 4), pa = (unsigned)((ch < a.K ? ch : 0) * 4);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rp[set][0]) : "v"(po), "s"(pm_) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rp[set][1]) : "v"(po), "s"(pi_) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rp[set][2]) : "v"(pa), "s"(pg_) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rp[set][3]) : "v"(pa), "s"(pb_) : "memory");
+        // element index of channel `ch` of the halo origin (pixel (y0 - 1, x0 - 1)); pieces outside the image are masked anyway
+        ebase2[set] = (unsigned)((((d.img * a.H + d.y0 - 1) * a.W + d.x0 - 1) * a.K) + ch);
+      }
     };
     auto store_all = [&](unsigned* buf, int set) {
 #pragma unroll
       for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[set][it])::"memory");
+      ProQuad pq;
+      if constexpr (PRO) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(rp[set][j])::"memory");
+        pq = ProQuad{rp[set][0], rp[set][1], rp[set][2], rp[set][3]};
+      }
       const unsigned okm = okm2[set];
 #pragma unroll
       for (int it = 0; it < NA; ++it) {
-        const f32x4 v = ((okm >> it) & 1u) ? ra[set][it] : f32x4{0, 0, 0, 0};
+        f32x4 v = ra[set][it];
+        if constexpr (PRO) {
+          v = pro_bn_lrelu(v, pq, a.pro.slope);
+          if (pdrop) v = pro_dropout(v, dkey, ebase2[set] + (unsigned)poff[it] * (unsigned)a.K, a.pro.p, keep_scale);
+        }
+        v = ((okm >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
         u32x2 p0, p1, p2;
 #ifdef RW_NO_SPLIT
         p0 = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}; p1 = u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])}; p2 = p0;
@@ -531,12 +618,13 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
     // chunk 1 is split into buffer 1 while the consumers run steps 0-3 of chunk 0 - exactly what every later chunk does.
     load_A(d0, true, 0);
     load_A(d1, total_gc > 1, 1);
-    wait_vm<NA>();                     // chunk 0 and, older in the queue, the weight DMA (only chunk 1's loads are younger)
+    wait_vm<NL>();                     // chunk 0 and, older in the queue, the weight DMA (only chunk 1's loads are younger)
+    drop_setup();
     store_all(As, 0);
     load_A(d2, total_gc > 2, 0);
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();      // B0: weights, bias, buffer 0
-    wait_vm<NA>();                     // chunk 1 (only chunk 2's loads are younger)
+    wait_vm<NL>();                     // chunk 1 (only chunk 2's loads are younger)
     store_all(As + G::A_DW, 1);
     load_A(d3, total_gc > 3, 1);
     // barrier k (k = 0 .. total_gc - 1; the consumer passes it at the head of step 4 of chunk k): buffer k & 1 is free,
@@ -545,14 +633,14 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
     for (int k = 0; k < total_gc; k += 2) {          // two chunks per trip: the register sets keep their roles at the loop edge
       wait_lgkm0();
       __builtin_amdgcn_s_barrier();
-      wait_vm<NA>();                   // chunk k + 2 has landed (only the loads of chunk k + 3 are younger)
+      wait_vm<NL>();                   // chunk k + 2 has landed (only the loads of chunk k + 3 are younger)
       store_all(As, 0);
       load_A(dn, k + 4 < total_gc, 0);
       advance(dn);
       if (k + 1 < total_gc) {
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();
-        wait_vm<NA>();
+        wait_vm<NL>();
         store_all(As + G::A_DW, 1);
         load_A(dn, k + 5 < total_gc, 1);
         advance(dn);
@@ -696,13 +784,21 @@ static int launch_rw(const IgemmArgs& a, hipStream_t st, int* q) {
   const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
   if (q) { q[0] = 4 * mblocks; q[1] = 9350000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
   if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
-  auto kern = conv3x3_rw_kernel<A_T, C_T>;
   const size_t lds = G::lds_bytes((a.K + 15) >> 4);
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   IgemmArgs b = a;
   b.n_mblocks = mblocks; b.n_nblocks = 1;
   const int cus = conv_sp_cus();
+  if (a.pro.mean) {           // consumer-side activation of the input (the block's first BatchNorm + LeakyReLU + dropout)
+    if ((a.K & 15) != 0) return ARCO_ERR_UNSUPPORTED;
+    auto kern = conv3x3_rw_kernel<A_T, C_T, true>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3(512), lds, st, b);
+    return arco_launch_status();
+  }
+  auto kern = conv3x3_rw_kernel<A_T, C_T>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3(512), lds, st, b);
   return arco_launch_status();
 }
@@ -713,12 +809,19 @@ static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
   const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
   if (q) { q[0] = 4 * mblocks; q[1] = 9300000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }      // 4 stat slabs per tile
   if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
-  auto kern = conv3x3_sp_kernel<A_T, C_T>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
   IgemmArgs b = a;
   b.n_mblocks = mblocks; b.n_nblocks = a.Npad / G::BN;
   const int total = mblocks * b.n_nblocks, cus = conv_sp_cus();
+  if (a.pro.mean) {           // consumer-side activation of the input (the block's first BatchNorm + LeakyReLU + dropout)
+    auto kern = conv3x3_sp_kernel<A_T, C_T, true>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), G::LDS_BYTES, st, b);
+    return arco_launch_status();
+  }
+  auto kern = conv3x3_sp_kernel<A_T, C_T>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), G::LDS_BYTES, st, b);
   return arco_launch_status();
 }

@@ -7,16 +7,7 @@
 #include "common.h"
 #include "igemm_args.h"
 
-__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
-  uint32_t s = v * 747796405u + 2891336453u;
-  uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
-  return (w >> 22u) ^ w;
-}
-// keep-decision of the dropout mask for element index e (stateless: recomputed in backward)
-__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
-  const uint32_t h = pcg_hash((uint32_t)e ^ pcg_hash((uint32_t)(e >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
-  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
-}
+// (pcg_hash / drop_keep: common.h - the consumer-side activation of the convolution loaders draws the same masks)
 
 // ---- BN statistics finalize: block partial (sum, sumsq) -> mean, istd, running stats.
 //      One 64-lane wave per channel; fp64 tree over the partial slabs.

@@ -1065,6 +1065,8 @@ struct WgradArgs {
   int CoutPad, CinPad, n_tiles;
   int mma;             // 0 fp32 MFMA; 2: bf16 operands (halo kernels, 3x3x3 only), fp32 accumulate
   int abl;             // ablation bits for tools/micro/wgrad_abl.py (0 in the product): 1 no MFMA phase, 2 no staging, 4 no global loads
+  ArcoActPro pro;      // pro.mean != nullptr: Ain holds the pre-activation z of the producing conv; the loader applies BN + LeakyReLU + dropout
+                       // (wgrad_split_kernel, 3x3: the weight gradient of a block's second convolution reads z1, not a stored activation)
 };
 
 constexpr int WGRAD1_PAD = 8;
@@ -1458,7 +1460,7 @@ __global__ __launch_bounds__(256) void wgrad_halo2_kernel(WgradArgs a) {
 #ifndef ARCO_WG_CSX
 #define ARCO_WG_CSX (ARCO_WG_SWZ ? 136 : 124)
 #endif
-template <int CO_B, int CI_B>
+template <int CO_B, int CI_B, bool PRO = false>
 __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
   constexpr int QZ = CO_B / 4, QA = CI_B / 4;
   constexpr int ZU = 32 * QZ, XU = 50 * QA;                 // staging units (4 pixels x 4 channels)
@@ -1480,9 +1482,22 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
   f32x4 pz[NZU][4], px_[NXU][4];
+  // consumer-side activation of the input operand (PRO): validity bits and pixel origin of the fetched tile, the parameter quads of
+  // this thread's channels for the BatchNorm group of the tile being staged (reloaded when the group changes: at most once per launch
+  // and workgroup - tiles are walked in image order)
+  unsigned xok = 0; int f_img = 0, f_y0 = 0, f_x0 = 0, pgrp = -1;
+  ProQuad pq[NXU];
+  const int ipg = PRO ? a.NB / (a.pro.groups > 1 ? a.pro.groups : 1) : 1;
+  const bool pdrop = PRO && a.pro.drop_mode == 1;
+  uint32_t dkey = 0; float keep_scale = 1.f;
+  if (PRO && pdrop) {
+    const unsigned long long sd = a.pro.seed_dev ? a.pro.seed ^ (a.pro.seed_dev[0] * 0x9E3779B97F4A7C15ull) : a.pro.seed;
+    dkey = drop_key32(sd); keep_scale = 1.0f / (1.0f - a.pro.p);
+  }
   auto fetch = [&](int t) {
     int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; const int img = tt / tiles_y;
     const int y0 = ty * 8, x0 = tx * 16;
+    if (PRO) { f_img = img; f_y0 = y0; f_x0 = x0; xok = 0; }
     const int pl = a.taps == 27 ? img % a.D3 + dpl : 0;
     const bool plane_ok = pl >= 0 && pl < a.D3;
 #pragma unroll
@@ -1505,8 +1520,10 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
       for (int j = 0; j < 4; ++j) {
         const int x = x0 - 1 + 4 * hg + j;
         f32x4 v = f32x4{0, 0, 0, 0};
-        if (u < XU && y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok && c < a.Cin)
+        if (u < XU && y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok && c < a.Cin) {
           v = *reinterpret_cast<const f32x4*>(a.Ain + (((long)(img + dpl) * a.H + y) * a.W + x) * a.lda + c);
+          if (PRO) xok |= 1u << (i * 4 + j);
+        }
         px_[i][j] = v;
       }
     }
@@ -1533,6 +1550,33 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
     for (int i = 0; i < NZU; ++i) {
       const int u = tid + i * 256, pg = u / QZ, q = u % QZ, r = pg >> 2, cg = pg & 3;
       if (u < ZU) stage(pz[i], Zs, CO_B, 4 * q, CSZ, r * 8 + cg * 2);
+    }
+    if constexpr (PRO) {        // a = dropout(lrelu(BN(z))) on the fetched quads (zero padding stays zero), as bn_act_fwd_kernel computes it
+      const int grp = f_img / ipg;
+      if (grp != pgrp) {
+        pgrp = grp;
+#pragma unroll
+        for (int i = 0; i < NXU; ++i) {
+          const int u = tid + i * 256, q = u % QA;
+          int c = ci0 + 4 * q; if (c + 4 > a.Cin) c = 0;
+          pq[i].mu = *reinterpret_cast<const f32x4*>(a.pro.mean + (long)grp * a.Cin + c);
+          pq[i].is = *reinterpret_cast<const f32x4*>(a.pro.istd + (long)grp * a.Cin + c);
+          pq[i].ga = *reinterpret_cast<const f32x4*>(a.pro.gamma + c);
+          pq[i].be = *reinterpret_cast<const f32x4*>(a.pro.beta + c);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NXU; ++i) {
+        const int u = tid + i * 256, pg = u / QA, q = u % QA, hr = pg / 5, hg = pg % 5;
+        const int y = f_y0 + hr - 1, c = ci0 + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int x = f_x0 - 1 + 4 * hg + j;
+          f32x4 v = pro_bn_lrelu(px_[i][j], pq[i], a.pro.slope);
+          if (pdrop) v = pro_dropout(v, dkey, (uint32_t)(((f_img * a.H + y) * a.W + x) * a.Cin + c), a.pro.p, keep_scale);
+          px_[i][j] = ((xok >> (i * 4 + j)) & 1u) ? v : f32x4{0, 0, 0, 0};
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < NXU; ++i) {
@@ -2006,10 +2050,44 @@ int arco_conv1x1_upres_fwd(const float* in, long ld_in, int K, const float* Wp, 
   return r == -1 ? ARCO_ERR_UNSUPPORTED : r;
 }
 
-// 3-D generalisation: NV volumes of D3 planes of H x W; taps in {1, 9 (per plane), 27 (3x3x3, pad 1)}
+// 1 when arco_conv3d_fwd_pro / arco_conv3d_wgrad_pro take a convolution of this shape with a consumer-side activation on its input
+// (the pipelined split-bf16 3x3 kernels of conv_sp.hip and wgrad_split_kernel); else the caller materialises the activation
+int arco_conv_pro_ok(int taps, int NV, int D3, int H, int W, int Cin, int Cout, long ld_in, int mma, int groups) {
+  if (taps != 9 || D3 != 1 || mma != 3 || groups < 1 || NV % groups != 0 || (Cin & 15) != 0 || (Cout & 3) != 0 || (ld_in & 3) != 0) return 0;
+  if ((long)NV * H * W * Cin >= (1l << 31)) return 0;          // 32-bit element indices of the dropout mask
+  IgemmArgs a{};
+  a.NB = NV; a.H = H; a.W = W; a.M = (long)NV * H * W; a.D3 = 1;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in; a.mma = 3;
+  a.Kg = (Cin + 31) / 32 * 2; a.stat_groups = 1;
+  int q[3] = {0, 0, 0};
+  return conv_sp_dispatch(a, nullptr, q) == ARCO_OK ? 1 : 0;
+}
+
+static int conv3d_fwd_impl(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                           const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                           int NV, int D3, int H, int W, int stat_groups, int mma, const ArcoActPro* pro, void* stream);
 int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
                     const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
                     int NV, int D3, int H, int W, int stat_groups, int mma, void* stream) {
+  return conv3d_fwd_impl(in, ld_in, K, Wp, N, out, ld_out, bias, residual, ld_res, stat_sum, stat_sq, taps, NV, D3, H, W, stat_groups, mma,
+                         nullptr, stream);
+}
+// ... with a consumer-side activation: `in` is the pre-activation z of the producing convolution, pro its BatchNorm statistics /
+// affine parameters / LeakyReLU slope / dropout (unetWithArgs.py:36-44: the Conv-BN-LeakyReLU-Dropout in front of a block's second conv)
+int arco_conv3d_fwd_pro(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                        const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                        int NV, int D3, int H, int W, int stat_groups, int mma, const ArcoActPro* pro, void* stream) {
+  ARCO_CHECK_ARG(pro && pro->mean && pro->istd && pro->gamma && pro->beta && pro->groups >= 1 && (pro->drop_mode == 0 || pro->drop_mode == 1) &&
+                 pro->p >= 0.f && pro->p < 1.f);
+  if (!arco_conv_pro_ok(taps, NV, D3, H, W, K, N, ld_in, mma, pro->groups)) return ARCO_ERR_UNSUPPORTED;
+  return conv3d_fwd_impl(in, ld_in, K, Wp, N, out, ld_out, bias, residual, ld_res, stat_sum, stat_sq, taps, NV, D3, H, W, stat_groups, mma,
+                         pro, stream);
+}
+
+// 3-D generalisation: NV volumes of D3 planes of H x W; taps in {1, 9 (per plane), 27 (3x3x3, pad 1)}
+static int conv3d_fwd_impl(const float* in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                           const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                           int NV, int D3, int H, int W, int stat_groups, int mma, const ArcoActPro* pro, void* stream) {
   const int NB = NV * D3;
   ARCO_CHECK_ARG(in && Wp && out && K > 0 && N > 0 && NB > 0 && H > 0 && W > 0 && D3 > 0 && mma >= 0 && mma <= 4);
   IgemmArgs a{};
@@ -2025,6 +2103,11 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
     a.Kpad = taps == 1 ? a.Kg * 16 : (K + 15) / 16 * 16;
   }
   ARCO_CHECK_ARG(NV % a.stat_groups == 0);
+  if (pro) {            // (arco_conv_pro_ok has vouched for the shape: the launch below lands in conv_sp_dispatch)
+    a.pro = *pro;
+    const int r = conv_sp_dispatch(a, as_stream(stream), nullptr);
+    return r == -1 ? ARCO_ERR_UNSUPPORTED : r;
+  }
   if (mma == 4) {       // f16 activation storage: `out` (and `in`, unless this is the one-channel fp32 volume of the first layer) are f16
     if (taps == 27 && image_conv3d_eligible(a)) return launch_image_conv3d<3>(a, as_stream(stream), nullptr);
     a.Kpad = (K + 31) / 32 * 32;
@@ -2055,8 +2138,23 @@ int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long
   return arco_conv3d_wgrad(dZ, ld_dz, Cout, in, ld_in, Cin, taps, NB, 1, H, W, ws, dW, accumulate, 0, stream);
 }
 
+static int conv3d_wgrad_impl(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
+                             int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, const ArcoActPro* pro, void* stream);
 int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
                       int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, void* stream) {
+  return conv3d_wgrad_impl(dZ, ld_dz, Cout, in, ld_in, Cin, taps, NV, D3, H, W, ws, dW, accumulate, mma, nullptr, stream);
+}
+// ... where `in` is the pre-activation z of the producing convolution (see arco_conv3d_fwd_pro): dW = dZ^T . act(z)
+int arco_conv3d_wgrad_pro(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
+                          int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, const ArcoActPro* pro, void* stream) {
+  ARCO_CHECK_ARG(pro && pro->mean && pro->istd && pro->gamma && pro->beta && pro->groups >= 1 && (pro->drop_mode == 0 || pro->drop_mode == 1) &&
+                 pro->p >= 0.f && pro->p < 1.f);
+  if (!arco_conv_pro_ok(taps, NV, D3, H, W, Cin, Cout, ld_in, mma, pro->groups) || (ld_dz & 3) != 0) return ARCO_ERR_UNSUPPORTED;
+  return conv3d_wgrad_impl(dZ, ld_dz, Cout, in, ld_in, Cin, taps, NV, D3, H, W, ws, dW, accumulate, mma, pro, stream);
+}
+
+static int conv3d_wgrad_impl(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NV,
+                             int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, const ArcoActPro* pro, void* stream) {
   const int NB = NV * D3;
   ARCO_CHECK_ARG(dZ && in && ws && dW && (taps == 1 || taps == 9 || taps == 27) && mma >= 0 && mma <= 4);
   if (mma == 4 && !(taps >= 9 && Cin == 1))      // f16 activation storage (dZ and in are f16; the first layer's input volume is fp32)
@@ -2067,6 +2165,7 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
   a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.partial = ws;
   static const int abl = getenv("ARCO_WGRAD_ABL") ? atoi(getenv("ARCO_WGRAD_ABL")) : 0;
   a.abl = abl;
+  if (pro) a.pro = *pro;
   const int co_b = Cout >= 64 ? 64 : (Cout > 16 ? 32 : 16), ci_b = Cin >= 64 ? 64 : (Cin > 16 ? 32 : 16);
   a.CoutPad = (Cout + co_b - 1) / co_b * co_b; a.CinPad = (Cin + ci_b - 1) / ci_b * ci_b;
   a.n_tiles = taps >= 9 ? NB * ((H + 7) / 8) * ((W + 15) / 16) : (int)((a.M + 127) / 128);
@@ -2122,8 +2221,14 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
       if (sh < rd && (COB / 16) * (CIB / 16) < 4) sh = rd;                                        \
       static bool attr_s = false;                                                                 \
       if (sh > 64 * 1024 && !attr_s) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<COB, CIB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_s = true; } \
+      if (a.pro.mean) {                                                                           \
+        static bool attr_p = false;                                                               \
+        if (sh > 64 * 1024 && !attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<COB, CIB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_p = true; } \
+        hipLaunchKernelGGL((wgrad_split_kernel<COB, CIB, true>), hgrid, dim3(256), sh, st, a);    \
+      } else                                                                                      \
       hipLaunchKernelGGL((wgrad_split_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);            \
     } while (0)
+    if (pro && !split) return ARCO_ERR_UNSUPPORTED;
     if (split) {
       if (hco == 32 && hci == 32) WS(32, 32);
       else if (hco == 32 && hci == 16) WS(32, 16);

@@ -3,6 +3,15 @@
 #pragma once
 #include "common.h"
 
+// include/arco_hip.h: ArcoActPro (the C-ABI descriptor of a consumer-side activation); repeated here for the kernels
+struct ArcoActPro {
+  const float* mean; const float* istd; const float* gamma; const float* beta;   // [groups][K] statistics, [K] affine parameters
+  float slope;                       // LeakyReLU slope (0: ReLU)
+  int groups;                        // BatchNorm groups of the producing layer: images [g*NB/G, (g+1)*NB/G) use statistics row g
+  int drop_mode; float p;            // 0: none; 1: nn.Dropout(p) with the stateless mask of bn_act_fwd_kernel
+  unsigned long long seed; const unsigned long long* seed_dev;
+};
+
 struct IgemmArgs {
   const float* A; long lda;
   const float* Wp; int Npad, Kpad, N, K;
@@ -24,7 +33,30 @@ struct IgemmArgs {
   // FeatureExtractor_3d's `fea_i(cat(up(x), f_i)) + cat(up(x), f_i)` with the wide block pushed under the upsample
   // (model_3D.py:46-58; arco_amd/model_3D.py forward_lowres2): Rup [NV, uD, uH, uW] rows of N channels -> output rows [NV, oD, oH, oW]
   const float* Rup; long ldrup; int uD, uH, uW, oD, oH, oW;
+  // Consumer-side activation (pro.mean != nullptr): A holds the PRE-activation z of the producing convolution, and the loader forms
+  // a = dropout(lrelu((z - mean) * istd * gamma + beta)) element by element while it stages the tile - the BatchNorm-apply pass
+  // between the two convolutions of a block (unetWithArgs.py:36-44, vnetWithArgs.py:16-25) and its HBM round trip are gone.
+  // The arithmetic is bn_act_fwd_kernel's, operation for operation: the staged values are bit-identical to the tensor that pass wrote.
+  ArcoActPro pro;
 };
+
+// the per-channel parameters of four consecutive channels and the prologue applied to one staged quad
+struct ProQuad { f32x4 mu, is, ga, be; };
+__device__ __forceinline__ f32x4 pro_bn_lrelu(f32x4 z, const ProQuad& q, float slope) {
+  f32x4 y;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = (z[e] - q.mu[e]) * q.is[e] * q.ga[e] + q.be[e];
+    y[e] = v >= 0.f ? v : v * slope;
+  }
+  return y;
+}
+// nn.Dropout on the quad at element index e0 .. e0 + 3 (element = pixel * C + channel, as bn_act_fwd_kernel counts)
+__device__ __forceinline__ f32x4 pro_dropout(f32x4 y, uint32_t key, uint32_t e0, float p, float keep_scale) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = drop_keep32(key, e0 + (uint32_t)e, p) ? y[e] * keep_scale : 0.f;
+  return y;
+}
 
 // The 8-corner trilinear blend as ONE fixed chain of multiplies and fused multiply-adds: every kernel that interpolates (the resize
 // kernel, the row gather of the row-sparse head, the GEMM epilogue of gemm_sp.hip) evaluates exactly this chain, so their results

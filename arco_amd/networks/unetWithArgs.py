@@ -51,6 +51,11 @@ class ConvBlock(nn.Module):
     def forward(self, x, pool=False):
         """pool=True (train mode): (block output, its 2x2 max-pool) - the pooling rides on the last BN / activation pass."""
         s = self.conv_conv
+        if self.training:
+            # both stages as one node: the first stage's activation is formed in the second convolution's loader (ops.ConvBlockFn)
+            y = ops.conv_block(x, s[0], s[1], s[2], s[3].p, s[4], s[5], s[6], cat_room=self.cat_room, pool=pool)
+            if y is not None:
+                return y
         x = _stage(x, s[0], s[1], s[2], s[3].p, self.training)
         return _stage(x, s[4], s[5], s[6], 0.0, self.training, cat_room=self.cat_room, pool=pool)
 

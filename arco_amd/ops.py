@@ -442,17 +442,26 @@ def use_half(x, taps, ci):
 
 
 def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1, sp=None,
-             stat_groups=1, grad=False, half=False):
+             stat_groups=1, grad=False, half=False, pro=None, out=None):
     """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out channels-last, stat slabs or None).
     2-D: nb images of h x w -> out [nb,n,h,w].  3-D (d3 > 1): nb volumes of d3 planes -> out [nb,n,d3,h,w].
-    half: f16 activation storage - out (and xr, unless k == 1) are f16, wp is the f16 pack (k == 1: the fp32 pack)."""
+    half: f16 activation storage - out (and xr, unless k == 1) are f16, wp is the f16 pack (k == 1: the fp32 pack).
+    pro: an _lib.act_pro descriptor - xr is the PRE-activation of the producing layer, activated in the loader (the caller has
+    asked pro_ok).  out: write into this channels-last tensor (may be a channel slice of a wider buffer)."""
     odt = torch.float16 if half else torch.float32
-    if sp is not None:
+    outr = None
+    if out is not None:
+        outr, ld_out = rows_view(out)
+        if outr.data_ptr() != out.data_ptr():
+            raise RuntimeError("arco_amd: conv_raw(out=...) needs a channels-last tensor (or channel slice) with 16-byte aligned rows")
+    elif sp is not None:
         out = new_act_nd(nb, n, sp, xr.device, odt)    # keeps the caller's rank (a 3-D volume may have depth 1)
     elif d3 > 1:
         out = new_act_nd(nb, n, (d3, h, w), xr.device, odt)
     else:
         out = new_act(nb, n, h, w, xr.device)
+    if outr is None:
+        outr, ld_out = out, n
     mma = 0
     if half:
         if residual is not None or (d3 <= 1 and sp is None):
@@ -484,15 +493,21 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         if rec["n"] % PROFILE_EVERY == 1 % PROFILE_EVERY:
             prof = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             prof[0].record()
-    L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(out), n, L.ptr(bias), L.ptr(residual), ld_res,
-           L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1, mma)
+    if pro is not None:
+        if mma != 3:
+            raise RuntimeError("arco_amd: a consumer-side activation needs the split-bf16 kernels (ops.pro_ok)")
+        L.call("arco_conv3d_fwd_pro", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(outr), ld_out, L.ptr(bias), L.ptr(residual), ld_res,
+               L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1, mma, pro)
+    else:
+        L.call("arco_conv3d_fwd", L.ptr(xr), ld, k, L.ptr(wp), n, L.ptr(outr), ld_out, L.ptr(bias), L.ptr(residual), ld_res,
+               L.ptr(ssum), L.ptr(ssq), taps, nb, d3, h, w, stat_groups if stats else 1, mma)
     if prof is not None:
         prof[1].record()
         PROFILE[cfg]["timed"].append((prof[0], prof[1], 2.0 * taps * nb * d3 * h * w * n * k, (taps, nb * d3 * h * w, n, k)))
     return out, (ssum, ssq, nmb)
 
 
-def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
+def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1, pro=None):
     ws = torch.empty(L.query("arco_wgrad_ws_floats", co, ci, taps, nb * d3 * h * w), dtype=torch.float32,
                      device=dzr.device)
 
@@ -510,8 +525,12 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1):
             mma = 4
         else:
             mma = 3 if (CONV_MMA == 3 and taps in (9, 27)) else (2 if (CONV_MMA in (1, 2) and taps == 27) else 0)
-        L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
-               accumulate, mma)
+        if pro is not None:
+            L.call("arco_conv3d_wgrad_pro", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
+                   accumulate, mma, pro)
+        else:
+            L.call("arco_conv3d_wgrad", L.ptr(dzr), ldz, co, L.ptr(xr), ldx, ci, taps, nb, d3, h, w, L.ptr(ws), L.ptr(out),
+                   accumulate, mma)
         if prof is not None:
             prof[1].record()
             rec["timed"].append((prof[0], prof[1], flop, (taps, nb * d3 * h * w, co, ci)))
@@ -538,17 +557,17 @@ WGRAD_SIDE = int(_WGRAD_SIDE_ENV) if _WGRAD_SIDE_ENV is not None else 0
 _side = {"stream": None, "keep": [], "dirty": False}
 
 
-def _wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1, keep=()):
+def _wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1, keep=(), pro=None):
     view = getattr(like, "_arco_grad_view", None)
     if not (WGRAD_SIDE and view is not None and like.grad is not None and like.grad.data_ptr() == view.data_ptr()):
-        return conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=d3)
+        return conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=d3, pro=pro)
     cur = torch.cuda.current_stream()
     if _side["stream"] is None:
         _side["stream"] = torch.cuda.Stream()
     sd = _side["stream"]
     sd.wait_stream(cur)                                  # fork: behind everything queued so far (dZ is complete)
     with torch.cuda.stream(sd):
-        out = conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=d3)
+        out = conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=d3, pro=pro)
     _side["keep"].append((dzr, xr) + tuple(keep))
     if not _side["dirty"]:
         # joined at the end of THIS backward pass whoever runs it (loss.backward(), autograd.grad inside a graph capture, a
@@ -843,6 +862,155 @@ class ConvBnActFn(torch.autograd.Function):
             else:
                 db = _zeros_cached((co,), da.device)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
+BLOCK_FUSE = int(__import__('os').environ.get('ARCO_BLOCK_FUSE', '1'))    # A/B switch: 0 = every stage writes its activation (rounds 1-5)
+block_fuse_stats = {"fused": 0, "unfused": 0}       # how often conv_block took each route (tests, bench)
+
+
+def pro_ok(taps, nv, d3, h, w, ci, co, ld, groups):
+    """Does a convolution of this shape take its input as a pre-activation + consumer-side activation (arco_conv_pro_ok)?"""
+    key = ("pro", taps, nv, d3, h, w, ci, co, ld, groups, CONV_MMA)
+    r = _cfg_cache.get(key)
+    if r is None:
+        r = _cfg_cache[key] = bool(CONV_MMA == 3 and L.query("arco_conv_pro_ok", taps, nv, d3, h, w, ci, co, ld, 3, groups)
+                                   and _split_ok(taps, nv * d3, h, w, ci, co, ld))
+    return r
+
+
+def _finalize_bn(ssum, ssq, nmb, co, m, eps, momentum, running_mean, running_var, nbt, G, dev):
+    mean = torch.empty(G * co, dtype=torch.float32, device=dev)      # [G][co]
+    istd = torch.empty(G * co, dtype=torch.float32, device=dev)
+    d0, dbuf = _defer_args(running_mean, running_var, co, G, momentum)
+    L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
+           L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G, d0, L.ptr(dbuf))
+    return mean, istd
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """A whole ConvBlock of the U-Net (unetWithArgs.py:31-47: conv3x3 - BN - LeakyReLU - Dropout(p) - conv3x3 - BN - LeakyReLU) as ONE
+    autograd node whose first stage never writes its activation: conv1 stores z1 (+ BN partial statistics), the statistics are
+    finalised, and conv2 reads z1 through the consumer-side activation of its loader (arco_conv3d_fwd_pro).  Backward: the second
+    stage as ConvBnActFn's, with the weight gradient of conv2 reading z1 the same way (arco_conv3d_wgrad_pro); the first stage's
+    BatchNorm backward recomputes its activation from z1 as it always did.  Results are bit-identical to two ConvBnActFn stages
+    (tests/test_block_fuse_gpu.py); per block and pass one launch and two of the five HBM crossings of z1 / a1 are gone."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, rm1, rv1, nbt1, w2, b2, g2, be2, rm2, rv2, nbt2, slope1, p1, slope2, mom1, eps1, mom2, eps2,
+                cat_room=0, pool=False):
+        global _LAST_CAT_BUF
+        L.require_gpu(x, w1, w2)
+        xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
+        cm, co = int(w1.shape[0]), int(w2.shape[0])
+        m = nv * h * w
+        G = BN_GROUPS
+        if G > 1 and nv % G != 0:
+            raise RuntimeError(f"arco_amd: bn_groups({G}) needs a batch that is a multiple of {G}, got {nv}")
+        dev = x.device
+        # stage 1: z1 = conv1(x) + b1, statistics
+        z1, (s1, q1, nmb1) = conv_raw(xr, ld, ci, pack_weight(w1, 9, 0), cm, nv, h, w, 9, bias=b1, stats=True, stat_groups=G)
+        mean1, istd1 = _finalize_bn(s1, q1, nmb1, cm, m, eps1, mom1, rm1, rv1, nbt1, G, dev)
+        seed1 = _next_seed() if p1 > 0 else 0
+        seed_dev = SEED_DEV if (p1 > 0 and torch.cuda.is_current_stream_capturing()) else None
+        z1r, ldz1 = rows_view(z1)
+        pro = L.act_pro(mean1, istd1, g1, be1, slope1, G, 1 if p1 > 0 else 0, p1, seed1, seed_dev)
+        # stage 2: z2 = conv2(act(z1)) + b2 with the activation applied in the loader
+        z2, (s2, q2, nmb2) = conv_raw(z1r, ldz1, cm, pack_weight(w2, 9, 0), co, nv, h, w, 9, bias=b2, stats=True, stat_groups=G, pro=pro)
+        mean2, istd2 = _finalize_bn(s2, q2, nmb2, co, m, eps2, mom2, rm2, rv2, nbt2, G, dev)
+        if cat_room:
+            buf = new_act_nd(nv, co + int(cat_room), sp, dev)
+            a, ld_a = buf[:, :co], co + int(cat_room)
+            _LAST_CAT_BUF = buf
+        else:
+            a, ld_a = new_act_nd(nv, co, sp, dev), co
+        z2r, ldz2 = rows_view(z2)
+        ctx.pool, ctx.groups = bool(pool), G
+        ctx.cfg = (float(slope1), float(p1), seed1, float(slope2))
+        ctx.seed_dev = seed_dev
+        ctx.params = (b1, b2)
+        if pool:
+            pooled = new_act(nv, co, h // 2, w // 2, dev)
+            L.call("arco_bn_act_pool_fwd", L.ptr(z2r), ldz2, nv, h, w, co, L.ptr(mean2), L.ptr(istd2), L.ptr(g2), L.ptr(be2),
+                   float(slope2), L.ptr(a), ld_a, L.ptr(pooled), co, G)
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(x, w1, z1, mean1, istd1, g1, be1, w2, z2, mean2, istd2, g2, be2, a)
+            return a, pooled
+        _bn_apply(z2r, ldz2, m, co, mean2, istd2, g2, be2, slope2, 0, 0.0, 0, h * w, a, ld_a, G)
+        ctx.save_for_backward(x, w1, z1, mean1, istd1, g1, be1, w2, z2, mean2, istd2, g2, be2)
+        return a
+
+    @staticmethod
+    def backward(ctx, da, dpool=None):
+        if ctx.pool:
+            x, w1, z1, mean1, istd1, g1, be1, w2, z2, mean2, istd2, g2, be2, a = ctx.saved_tensors
+        else:
+            x, w1, z1, mean1, istd1, g1, be1, w2, z2, mean2, istd2, g2, be2 = ctx.saved_tensors
+        slope1, p1, seed1, slope2 = ctx.cfg
+        b1, b2 = ctx.params
+        G = ctx.groups
+        xr, ldx, nv, d3, h, w, ci, sp = _geom_nd(x)
+        cm, co = int(w1.shape[0]), int(w2.shape[0])
+        dev = x.device
+        if ctx.pool and dpool is not None:       # d a = d skip + maxpool2_bwd(d pooled), summed inside the pooling backward
+            ar, lda_ = rows_view(a)
+            dpr, ldp = rows_view(dpool)
+            dsum = new_act(nv, co, h, w, dev)
+            if da is None:
+                L.call("arco_maxpool2_bwd", L.ptr(ar), lda_, nv, h, w, co, L.ptr(dpr), ldp, L.ptr(dsum), co)
+            else:
+                sr, lds = rows_view(da)
+                L.call("arco_maxpool2_bwd_add", L.ptr(ar), lda_, nv, h, w, co, L.ptr(dpr), ldp, L.ptr(sr), lds, L.ptr(dsum), co)
+            da = dsum
+        # ---- stage 2
+        dz2, dg2, dbe2 = _bn_backward(da, z2, mean2, istd2, g2, be2, slope2, 0, 0.0, 0, h * w, None, G)
+        dz2r, lddz2 = rows_view(dz2)
+        z1r, ldz1 = rows_view(z1)
+        dw2 = None
+        if ctx.needs_input_grad[8]:
+            pro = L.act_pro(mean1, istd1, g1, be1, slope1, G, 1 if p1 > 0 else 0, p1, seed1, ctx.seed_dev)
+            dw2 = _wgrad(dz2r, lddz2, co, z1r, ldz1, cm, 9, nv, h, w, w2, keep=(dz2, z1, mean1, istd1), pro=pro)
+        da1, _ = conv_raw(dz2r, lddz2, co, pack_weight(w2, 9, 1), cm, nv, h, w, 9, grad=True)
+        # ---- stage 1 (its activation is recomputed from z1 inside the BatchNorm backward kernels)
+        dz1, dg1, dbe1 = _bn_backward(da1, z1, mean1, istd1, g1, be1, slope1, 1 if p1 > 0 else 0, p1, seed1, h * w, ctx.seed_dev, G)
+        dz1r, lddz1 = rows_view(dz1)
+        dw1 = dx = None
+        if ctx.needs_input_grad[1]:
+            dw1 = _wgrad(dz1r, lddz1, cm, xr, ldx, ci, 9, nv, h, w, w1, keep=(dz1, x))
+        if ctx.needs_input_grad[0]:
+            dx, _ = conv_raw(dz1r, lddz1, cm, pack_weight(w1, 9, 1), ci, nv, h, w, 9, grad=True)
+        # conv biases under train-mode BN: analytically zero gradients (see ConvBnActFn.backward)
+        dbs = []
+        for b, cn, need in ((b1, cm, ctx.needs_input_grad[2]), (b2, co, ctx.needs_input_grad[9])):
+            db = None
+            if b is not None and need:
+                view = getattr(b, "_arco_grad_view", None)
+                if view is not None and b.grad is not None and b.grad.data_ptr() == view.data_ptr():
+                    b._arco_mark()
+                else:
+                    db = _zeros_cached((cn,), dev)
+            dbs.append(db)
+        return (dx, dw1, dbs[0], dg1, dbe1, None, None, None, dw2, dbs[1], dg2, dbe2, None, None, None) + (None,) * 9
+
+
+def conv_block(x, conv1, bn1, act1, p1, conv2, bn2, act2, cat_room=0, pool=False):
+    """The train-mode ConvBlock: ConvBlockFn when both convolutions run on the pipelined kernels (ops.pro_ok), else None (the
+    caller runs the two stages separately)."""
+    global _LAST_CAT_BUF
+    if not BLOCK_FUSE or x.dim() != 4 or x.dtype != torch.float32:
+        return None
+    xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
+    cm, co = int(conv1.weight.shape[0]), int(conv2.weight.shape[0])
+    if _taps(conv1.weight) != 9 or _taps(conv2.weight) != 9 or not pro_ok(9, nv, 1, h, w, cm, co, cm, BN_GROUPS):
+        block_fuse_stats["unfused"] += 1
+        return None
+    block_fuse_stats["fused"] += 1
+    y = ConvBlockFn.apply(x, conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
+                          conv2.weight, conv2.bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
+                          getattr(act1, "negative_slope", 0.0), float(p1), getattr(act2, "negative_slope", 0.0),
+                          bn1.momentum, bn1.eps, bn2.momentum, bn2.eps, cat_room, pool)
+    if cat_room:
+        (y[0] if pool else y)._arco_cat_buf, _LAST_CAT_BUF = _LAST_CAT_BUF, None
+    return y
 
 
 class BnActFn(torch.autograd.Function):

@@ -152,6 +152,30 @@ int arco_conv3d_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, lo
                       int D3, int H, int W, float* ws, float* dW, int accumulate,
                       int mma /* 0 exact fp32; != 0: 3x3x3 halo kernels with bf16 MFMA operands, fp32 accumulate */, void* stream);
 long arco_wgrad_ws_floats(int Cout, int Cin, int taps, long M);
+
+/* ---- Consumer-side activation: a block's first Conv-BN-LeakyReLU-Dropout stage (unetWithArgs.py:36-44: conv_conv[0..3]) without the
+ * BatchNorm-apply pass.  The producing convolution writes its PRE-activation z (and the BN partial statistics); the block's second
+ * convolution - and, in the backward pass, the weight gradient of that second convolution - form
+ *     a = dropout(lrelu((z - mean) * istd * gamma + beta))
+ * element by element in their loaders while they stage z for the matrix cores (conv_sp.hip producer waves, wgrad_split_kernel): the
+ * activation never exists in HBM (2 of the 4 HBM crossings of every such activation, and one launch per stage, are gone).  The
+ * arithmetic is arco_bn_act_fwd's operation for operation: results are bit-identical to the two-pass route.                        */
+typedef struct ArcoActPro {
+  const float* mean; const float* istd;   /* [groups][K] batch statistics of the producing layer (arco_bn_finalize)                 */
+  const float* gamma; const float* beta;  /* [K] nn.BatchNorm2d weight / bias                                                       */
+  float slope;                            /* nn.LeakyReLU negative_slope (0: ReLU)                                                   */
+  int groups;                             /* BatchNorm groups: images [g*NV/G, (g+1)*NV/G) use statistics row g                     */
+  int drop_mode; float p;                 /* 0: none; 1: nn.Dropout(p), the stateless mask of arco_bn_act_fwd (element = pixel*K + k) */
+  unsigned long long seed; const unsigned long long* seed_dev;   /* as arco_bn_act_fwd (seed_dev: per-replay salt of a HIP graph)    */
+} ArcoActPro;
+/* 1 when the two entry points below take the shape (3x3, split-bf16 mode 3, the pipelined kernels); else the caller runs
+ * arco_bn_act_fwd and the plain entry points */
+int arco_conv_pro_ok(int taps, int NV, int D3, int H, int W, int Cin, int Cout, long ld_in, int mma, int groups);
+int arco_conv3d_fwd_pro(const float* z_in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
+                        const float* bias, const float* residual, long ld_res, float* stat_sum, float* stat_sq, int taps,
+                        int NV, int D3, int H, int W, int stat_groups, int mma, const ArcoActPro* pro, void* stream);
+int arco_conv3d_wgrad_pro(const float* dZ, long ld_dz, int Cout, const float* z_in, long ld_in, int Cin, int taps, int NV,
+                          int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, const ArcoActPro* pro, void* stream);
 /* dW[co][ci][tap] (+)= sum_pix dZ[pix][co] * in[pix+tap][ci]   (torch weight layout)                      */
 int arco_conv_wgrad(const float* dZ, long ld_dz, int Cout, const float* in, long ld_in, int Cin, int taps, int NB,
                     int H, int W, float* ws, float* dW, int accumulate, void* stream);
