@@ -22,6 +22,19 @@ static inline int arco_launch_status() {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// "has this kernel's dynamic-LDS limit been raised on the CURRENT device?" - one bit per device in a per-kernel mask.
+// hipFuncSetAttribute acts on the current device's copy of the kernel, and one process may drive several devices (a reference
+// trainer wraps the drop-in modules in nn.DataParallel, train_arco_2d.py:227-240): a process-wide flag would leave the second
+// device at the 64 KB default and its first launch would fail.  (Benign race: two threads may both set the attribute.)
+static inline bool arco_first_on_device(unsigned long long& mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+  const unsigned long long bit = 1ull << dev;
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 // four consecutive channels of an activation row as fp32, from fp32 or f16 storage (the *_h entry points: f16 activation storage)
@@ -46,16 +59,20 @@ __device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
   uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
   return (w >> 22u) ^ w;
 }
-// keep-decision of the dropout mask for element index e (stateless: recomputed in backward)
+// keep-decision of the dropout mask for element index e (stateless: recomputed in backward).  Round 6: SIXTEEN random bits per element, two
+// elements per hash - the mask is also drawn inside the convolution loaders (consumer-side activation, igemm_args.h), where the hash is
+// most of the cost; the drop probability is p rounded to a multiple of 2^-16 (|p' - p| < 8e-6; the survivors keep the scale 1 / (1 - p))
+__device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, float p) {
-  const uint32_t h = pcg_hash((uint32_t)e ^ pcg_hash((uint32_t)(e >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
-  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+  const uint64_t e2 = e >> 1;
+  const uint32_t h = pcg_hash((uint32_t)e2 ^ pcg_hash((uint32_t)(e2 >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  return ((e & 1) ? (h >> 16) : (h & 0xffffu)) >= drop_thr16(p);
 }
-// the same decision for element indices below 2^32 with the seed half hashed once per launch (drop_key32): the loaders of the
-// convolution kernels evaluate it per staged element
+// the same decisions for the four elements e0 .. e0 + 3 (e0 % 4 == 0, e0 < 2^33) with the seed half hashed once per launch (drop_key32)
 __device__ __forceinline__ uint32_t drop_key32(uint64_t seed) { return pcg_hash((uint32_t)seed) ^ (uint32_t)(seed >> 32); }
-__device__ __forceinline__ bool drop_keep32(uint32_t key, uint32_t e, float p) {
-  return (float)(pcg_hash(e ^ key) >> 8) * (1.0f / 16777216.0f) >= p;
+__device__ __forceinline__ void drop_keep_quad(uint32_t key, uint32_t e0, uint32_t thr, bool (&keep)[4]) {
+  const uint32_t h0 = pcg_hash((e0 >> 1) ^ key), h1 = pcg_hash(((e0 >> 1) + 1u) ^ key);
+  keep[0] = (h0 & 0xffffu) >= thr; keep[1] = (h0 >> 16) >= thr; keep[2] = (h1 & 0xffffu) >= thr; keep[3] = (h1 >> 16) >= thr;
 }
 
 // bit layout of the per-pixel class code (C <= 21)

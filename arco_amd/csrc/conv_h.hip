@@ -315,8 +315,8 @@ static int launch_hconv(const IgemmArgs& a, hipStream_t st, int* q) {
   const size_t red = (size_t)2 * WM * BN * sizeof(float);
   if (sh < red) sh = red;
   auto kern = hconv_kernel<TAPS, BM, BN, WM, WN, DEPTH, FLAT>;
-  static bool attr_set = false;
-  if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (sh > 64 * 1024 && arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
   IgemmArgs b = a;
   b.n_mblocks = mblocks;
   b.n_nblocks = (a.Npad + BN - 1) / BN;
@@ -561,8 +561,8 @@ static int launch_hconv_rw(const IgemmArgs& a, hipStream_t st, int* q) {
   const int nseg = (a.D3 + S - 1) / S;
   const long units = cols * nseg;
   auto kern = hconv_rw_kernel<NC, C_T, TH>;
-  static bool attr_set = false;
-  if (G::LDS_BYTES > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (G::LDS_BYTES > 64 * 1024 && arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); }
   IgemmArgs b = a;
   b.n_mblocks = (int)(a.NB * tiles);
   const long grid = slots < units ? slots : units;
@@ -760,8 +760,8 @@ static void launch_hwgrad(const HWgradArgs& a, dim3 grid, hipStream_t st) {
   const size_t rd = (size_t)4 * CO_T * CI_T * 4 * 64 * 4;
   if (sh < rd) sh = rd;
   auto kern = hwgrad_kernel<CO_T, CI_T, NT>;
-  static bool attr_set = false;
-  if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (sh > 64 * 1024 && arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
   hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, a);
 }
 

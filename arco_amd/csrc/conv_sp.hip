@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     const float* const pm_ = PRO ? uniform_ptr(a.pro.mean) : nullptr; const float* const pi_ = PRO ? uniform_ptr(a.pro.istd) : nullptr;
     const float* const pg_ = PRO ? uniform_ptr(a.pro.gamma) : nullptr; const float* const pb_ = PRO ? uniform_ptr(a.pro.beta) : nullptr;
     const bool pdrop = PRO && a.pro.drop_mode == 1;
-    uint32_t dkey = 0; float keep_scale = 1.f;
+    uint32_t dkey = 0, dthr = 0; float keep_scale = 1.f;
     u32x2 salt = {0u, 0u};        // the per-replay dropout salt of a graph-captured pass: the kernel's OLDEST counted load (an asm load as
     if (PRO && pdrop && a.pro.seed_dev) {     // the activations': a load hipcc knows of would drain the DMA queue in front of its use)
       const float* sp_ = uniform_ptr(reinterpret_cast<const float*>(a.pro.seed_dev));
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
         asm volatile("" : "+v"(salt)::"memory");
         const unsigned long long sv = ((unsigned long long)salt[1] << 32) | salt[0];
         const unsigned long long sd = a.pro.seed_dev ? a.pro.seed ^ (sv * 0x9E3779B97F4A7C15ull) : a.pro.seed;
-        dkey = drop_key32(sd); keep_scale = 1.0f / (1.0f - a.pro.p);
+        dkey = drop_key32(sd); dthr = drop_thr16(a.pro.p); keep_scale = 1.0f / (1.0f - a.pro.p);
       }
     };
     auto load_A = [&](const Desc& d, bool real, int set) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
       f32x4 v = ra[set][it];
       if constexpr (PRO) {
         v = pro_bn_lrelu(v, ProQuad{rp[set][0], rp[set][1], rp[set][2], rp[set][3]}, a.pro.slope);
-        if (pdrop) v = pro_dropout(v, dkey, ebase2[set] + (unsigned)poff[it] * (unsigned)a.K, a.pro.p, keep_scale);
+        if (pdrop) v = pro_dropout(v, dkey, ebase2[set] + (unsigned)poff[it] * (unsigned)a.K, dthr, keep_scale);
       }
       v = ((okm2[set] >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
       u32x2 p0, p1, p2;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
     const float* const pm_ = PRO ? uniform_ptr(a.pro.mean) : nullptr; const float* const pi_ = PRO ? uniform_ptr(a.pro.istd) : nullptr;
     const float* const pg_ = PRO ? uniform_ptr(a.pro.gamma) : nullptr; const float* const pb_ = PRO ? uniform_ptr(a.pro.beta) : nullptr;
     const bool pdrop = PRO && a.pro.drop_mode == 1;
-    uint32_t dkey = 0; float keep_scale = 1.f;
+    uint32_t dkey = 0, dthr = 0; float keep_scale = 1.f;
     u32x2 salt = {0u, 0u};        // the per-replay dropout salt of a graph-captured pass: the kernel's OLDEST counted load (an asm load as
     if (PRO && pdrop && a.pro.seed_dev) {     // the activations': a load hipcc knows of would drain the DMA queue in front of its use)
       const float* sp_ = uniform_ptr(reinterpret_cast<const float*>(a.pro.seed_dev));
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
         asm volatile("" : "+v"(salt)::"memory");
         const unsigned long long sv = ((unsigned long long)salt[1] << 32) | salt[0];
         const unsigned long long sd = a.pro.seed_dev ? a.pro.seed ^ (sv * 0x9E3779B97F4A7C15ull) : a.pro.seed;
-        dkey = drop_key32(sd); keep_scale = 1.0f / (1.0f - a.pro.p);
+        dkey = drop_key32(sd); dthr = drop_thr16(a.pro.p); keep_scale = 1.0f / (1.0f - a.pro.p);
       }
     };
     auto load_A = [&](const Desc& d, bool real, int set) {
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
         f32x4 v = ra[set][it];
         if constexpr (PRO) {
           v = pro_bn_lrelu(v, pq, a.pro.slope);
-          if (pdrop) v = pro_dropout(v, dkey, ebase2[set] + (unsigned)poff[it] * (unsigned)a.K, a.pro.p, keep_scale);
+          if (pdrop) v = pro_dropout(v, dkey, ebase2[set] + (unsigned)poff[it] * (unsigned)a.K, dthr, keep_scale);
         }
         v = ((okm >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
         u32x2 p0, p1, p2;
@@ -791,14 +791,14 @@ static int launch_rw(const IgemmArgs& a, hipStream_t st, int* q) {
   if (a.pro.mean) {           // consumer-side activation of the input (the block's first BatchNorm + LeakyReLU + dropout)
     if ((a.K & 15) != 0) return ARCO_ERR_UNSUPPORTED;
     auto kern = conv3x3_rw_kernel<A_T, C_T, true>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static unsigned long long attr_set = 0;
+    if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3(512), lds, st, b);
     return arco_launch_status();
   }
   auto kern = conv3x3_rw_kernel<A_T, C_T>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
   hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3(512), lds, st, b);
   return arco_launch_status();
 }
@@ -814,14 +814,14 @@ static int launch_sp(const IgemmArgs& a, hipStream_t st, int* q) {
   const int total = mblocks * b.n_nblocks, cus = conv_sp_cus();
   if (a.pro.mean) {           // consumer-side activation of the input (the block's first BatchNorm + LeakyReLU + dropout)
     auto kern = conv3x3_sp_kernel<A_T, C_T, true>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
+    static unsigned long long attr_set = 0;
+    if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); }
     hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), G::LDS_BYTES, st, b);
     return arco_launch_status();
   }
   auto kern = conv3x3_sp_kernel<A_T, C_T>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); }
   hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), G::LDS_BYTES, st, b);
   return arco_launch_status();
 }
@@ -1001,8 +1001,8 @@ int conv3d_rw_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   if (S > a.D3) S = a.D3;
   const int nseg = (a.D3 + S - 1) / S;
   const long units = cols * nseg;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_rw16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_rw16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES); }
   IgemmArgs b = a;
   b.n_mblocks = (int)(a.NB * tiles);
   hipLaunchKernelGGL(conv3d_rw16_kernel, dim3((unsigned)(slots < units ? slots : units)), dim3(G::NT), G::LDS_BYTES, st, b, S, nseg);

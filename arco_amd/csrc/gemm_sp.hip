@@ -417,6 +417,9 @@ int gemm_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
     int dev = 0; hipDeviceProp_t p;
     (void)hipGetDevice(&dev);
     n_cu = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256;
+  }
+  static unsigned long long attr_set = 0;       // (one bit per device: a process may drive several, common.h)
+  if (arco_first_on_device(attr_set)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_DW * 4);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_DW * 4);
   }

@@ -481,8 +481,8 @@ static int launch_igemm_v(const IgemmArgs& a, hipStream_t st, int* n_mblocks_out
   const size_t red = (size_t)2 * WAVES_M * BN * sizeof(float);
   if (sh < red) sh = red;
   auto kern = igemm_kernel<TAPS, BM, BN, WAVES_M, WAVES_N, KC, DB, VEC, DEPTH, FLAT, MMA>;
-  static bool attr_set = false;      // once per instantiation (never inside a stream capture after warm-up)
-  if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
+  static unsigned long long attr_set = 0;      // once per instantiation (never inside a stream capture after warm-up)
+  if (sh > 64 * 1024 && arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
   IgemmArgs b = a;
   b.n_mblocks = mblocks;
   b.n_nblocks = (a.Npad + BN - 1) / BN;
@@ -724,8 +724,8 @@ static int launch_halo(const IgemmArgs& a, hipStream_t st, int* q) {
   const long blocks = bpg * n_grp;
   if (q) { q[0] = (int)blocks; q[1] = 9 * 1000000 + 900000 + CIN * 1000 + COUT; q[2] = CIN * 100 + 10; return ARCO_OK; }
   auto kern = conv3x3_halo_kernel<CIN, COUT, TW>;
-  static bool attr_set = false;
-  if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; }
+  static unsigned long long attr_set = 0;
+  if (sh > 64 * 1024 && arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); }
   IgemmArgs b = a; b.n_mblocks = (int)blocks; b.n_nblocks = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), sh, st, b);
   return arco_launch_status();
@@ -1489,10 +1489,10 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
   ProQuad pq[NXU];
   const int ipg = PRO ? a.NB / (a.pro.groups > 1 ? a.pro.groups : 1) : 1;
   const bool pdrop = PRO && a.pro.drop_mode == 1;
-  uint32_t dkey = 0; float keep_scale = 1.f;
+  uint32_t dkey = 0, dthr = 0; float keep_scale = 1.f;
   if (PRO && pdrop) {
     const unsigned long long sd = a.pro.seed_dev ? a.pro.seed ^ (a.pro.seed_dev[0] * 0x9E3779B97F4A7C15ull) : a.pro.seed;
-    dkey = drop_key32(sd); keep_scale = 1.0f / (1.0f - a.pro.p);
+    dkey = drop_key32(sd); dthr = drop_thr16(a.pro.p); keep_scale = 1.0f / (1.0f - a.pro.p);
   }
   auto fetch = [&](int t) {
     int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; const int img = tt / tiles_y;
@@ -1568,12 +1568,11 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < NXU; ++i) {
         const int u = tid + i * 256, pg = u / QA, q = u % QA, hr = pg / 5, hg = pg % 5;
-        const int y = f_y0 + hr - 1, c = ci0 + 4 * q;
+        const uint32_t e0 = (uint32_t)(((f_img * a.H + f_y0 + hr - 1) * a.W + f_x0 - 1 + 4 * hg) * a.Cin + ci0 + 4 * q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int x = f_x0 - 1 + 4 * hg + j;
           f32x4 v = pro_bn_lrelu(px_[i][j], pq[i], a.pro.slope);
-          if (pdrop) v = pro_dropout(v, dkey, (uint32_t)(((f_img * a.H + y) * a.W + x) * a.Cin + c), a.pro.p, keep_scale);
+          if (pdrop) v = pro_dropout(v, dkey, e0 + (uint32_t)(j * a.Cin), dthr, keep_scale);
           px_[i][j] = ((xok >> (i * 4 + j)) & 1u) ? v : f32x4{0, 0, 0, 0};
         }
       }
@@ -2204,12 +2203,12 @@ static int conv3d_wgrad_impl(const float* dZ, long ld_dz, int Cout, const float*
       size_t sh = (size_t)(128 * LZ + (flat ? 128 + 2 * (W + 2) + 2 : 180) * LA) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4;  \
       if (sh < rd && (COB / 16) * (CIB / 16) < 4) sh = rd;                                        \
       if (flat && a.mma == 2) {                                                                   \
-        static bool attr_set2 = false;                                                            \
-        if (!attr_set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo2_kernel<COB, CIB, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 * LZ + (128 + 2 * IGEMM_FLAT_WPMAX + 2) * LA) * 4); attr_set2 = true; } \
+        static unsigned long long attr_set2 = 0;                                                            \
+        if (arco_first_on_device(attr_set2)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo2_kernel<COB, CIB, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 * LZ + (128 + 2 * IGEMM_FLAT_WPMAX + 2) * LA) * 4); } \
         hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB, true, 2>), hgrid, dim3(256), sh, st, a); \
       } else if (flat) {                                                                          \
-        static bool attr_set = false;                                                             \
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo2_kernel<COB, CIB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 * LZ + (128 + 2 * IGEMM_FLAT_WPMAX + 2) * LA) * 4); attr_set = true; } \
+        static unsigned long long attr_set = 0;                                                             \
+        if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo2_kernel<COB, CIB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (128 * LZ + (128 + 2 * IGEMM_FLAT_WPMAX + 2) * LA) * 4); } \
         hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB, true>), hgrid, dim3(256), sh, st, a);    \
       } else if (a.mma == 2) hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB, false, 2>), hgrid, dim3(256), sh, st, a); \
       else hipLaunchKernelGGL((wgrad_halo2_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);       \
@@ -2219,11 +2218,11 @@ static int conv3d_wgrad_impl(const float* dZ, long ld_dz, int Cout, const float*
     do {                                                                                          \
       size_t sh = (size_t)(3 * COB * ARCO_WG_CSZ + 3 * CIB * ARCO_WG_CSX) * 4; const size_t rd = (size_t)4 * 9 * 256 * 4; \
       if (sh < rd && (COB / 16) * (CIB / 16) < 4) sh = rd;                                        \
-      static bool attr_s = false;                                                                 \
-      if (sh > 64 * 1024 && !attr_s) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<COB, CIB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_s = true; } \
+      static unsigned long long attr_s = 0;                                                                 \
+      if (sh > 64 * 1024 && arco_first_on_device(attr_s)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<COB, CIB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); } \
       if (a.pro.mean) {                                                                           \
-        static bool attr_p = false;                                                               \
-        if (sh > 64 * 1024 && !attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<COB, CIB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_p = true; } \
+        static unsigned long long attr_p = 0;                                                               \
+        if (sh > 64 * 1024 && arco_first_on_device(attr_p)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<COB, CIB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); } \
         hipLaunchKernelGGL((wgrad_split_kernel<COB, CIB, true>), hgrid, dim3(256), sh, st, a);    \
       } else                                                                                      \
       hipLaunchKernelGGL((wgrad_split_kernel<COB, CIB>), hgrid, dim3(256), sh, st, a);            \
@@ -2259,13 +2258,13 @@ static int conv3d_wgrad_impl(const float* dZ, long ld_dz, int Cout, const float*
         long ch2 = 512 / yzq; if (ch2 < 1) ch2 = 1; if (ch2 > a.n_tiles) ch2 = a.n_tiles;
         if (ch2 * cop * cip <= arco_wgrad_ws_floats(Cout, Cin, taps, a.M)) chq = ch2;
         constexpr int shq = 64 * (2 * (128 + WGRAD1_PAD)) * 4;
-        static bool attr_q = false;
-        if (!attr_q) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_q_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, shq); attr_q = true; }
+        static unsigned long long attr_q = 0;
+        if (arco_first_on_device(attr_q)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_q_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, shq); }
         hipLaunchKernelGGL(wgrad_q_kernel<64>, dim3((unsigned)chq, cop / 128, cip / 128), dim3(256), shq, st, a);
       } else {
         constexpr int shq = 128 * (2 * (128 + WGRAD1_PAD)) * 4;
-        static bool attr_q = false;
-        if (!attr_q) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_q_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, shq); attr_q = true; }
+        static unsigned long long attr_q = 0;
+        if (arco_first_on_device(attr_q)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_q_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, shq); }
         hipLaunchKernelGGL(wgrad_q_kernel<128>, dim3((unsigned)chq, cop / 128, cip / 128), dim3(256), shq, st, a);
       }
       launch_wgrad_reduce(st, ws, (int)chq, taps, a.CoutPad, a.CinPad, Cout, Cin, dW, accumulate);
@@ -2282,8 +2281,8 @@ static int conv3d_wgrad_impl(const float* dZ, long ld_dz, int Cout, const float*
     size_t sh = (size_t)128 * (LZ + LA) * 4; const size_t rd = (size_t)4 * COB * CIB * 4;         \
     if (sh < rd) sh = rd;                                                                         \
     auto kern = wgrad_kernel<COB, CIB>;                                                           \
-    static bool attr_set = false;   /* once per instantiation: not legal inside a stream capture */ \
-    if (sh > 64 * 1024 && !attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set = true; } \
+    static unsigned long long attr_set = 0;   /* once per instantiation: not legal inside a stream capture */ \
+    if (sh > 64 * 1024 && arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); } \
     hipLaunchKernelGGL(kern, grid, dim3(256), sh, st, a);                                         \
   } while (0)
   if (co_b == 64 && ci_b == 64) WG(64, 64);

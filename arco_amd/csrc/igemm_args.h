@@ -52,9 +52,11 @@ __device__ __forceinline__ f32x4 pro_bn_lrelu(f32x4 z, const ProQuad& q, float s
   return y;
 }
 // nn.Dropout on the quad at element index e0 .. e0 + 3 (element = pixel * C + channel, as bn_act_fwd_kernel counts)
-__device__ __forceinline__ f32x4 pro_dropout(f32x4 y, uint32_t key, uint32_t e0, float p, float keep_scale) {
+__device__ __forceinline__ f32x4 pro_dropout(f32x4 y, uint32_t key, uint32_t e0, uint32_t thr, float keep_scale) {
+  bool keep[4];
+  drop_keep_quad(key, e0, thr, keep);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) y[e] = drop_keep32(key, e0 + (uint32_t)e, p) ? y[e] * keep_scale : 0.f;
+  for (int e = 0; e < 4; ++e) y[e] = keep[e] ? y[e] * keep_scale : 0.f;
   return y;
 }
 

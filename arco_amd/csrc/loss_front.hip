@@ -860,10 +860,9 @@ int arco_nce_fused(const float* S, long ld, const int* lens, const int* prow, in
   for (int e = 0; e < E; ++e) { ARCO_CHECK_ARG(t.len[e] > 0 && t.len[e] <= ld); if (t.len[e] > Lmax) Lmax = t.len[e]; }
   const size_t sh = (size_t)((Lmax + 1) / 2) * sizeof(uint32_t);
   ARCO_CHECK_ARG(sh <= (size_t)(160 * 1024 - 512));
-  static bool attr_set = false;
-  if (sh > 48 * 1024 && !attr_set) {
+  static unsigned long long attr_set = 0;
+  if (sh > 48 * 1024 && arco_first_on_device(attr_set)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    attr_set = true;
   }
   hipLaunchKernelGGL(infonce_fused_kernel, dim3((unsigned)Q, (unsigned)E), dim3(256), sh, as_stream(stream), S, ld, t, idx_all,
                      idx_off, idx_stride, Q, Nn, An, Pn_all, Dp, 1.0f / temp, W, gpos, loss_q);

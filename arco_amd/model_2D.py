@@ -103,7 +103,7 @@ class FeatureExtractor(nn.Module):
         c = int(x.shape[1])
         w = self.fea4.weight                                                          # no residual at the last level
         lo = ops.conv(x, w[:, :c].contiguous())
-        return ops.conv(f[4], w[:, c:].contiguous(), None, residual=ops.bilinear(lo, f[4].shape[-2:]))
+        return ops.boundary(ops.conv(f[4], w[:, c:].contiguous(), None, residual=ops.bilinear(lo, f[4].shape[-2:])))
 
 
 def create_model(ema=False, num_classes=4, train_encoder=True, train_decoder=True, in_chns=1):

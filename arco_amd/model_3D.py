@@ -66,8 +66,8 @@ class FeatureExtractor_3d(nn.Module):
         w = self.fea4.weight                                                      # no residual at the last level
         lo = ops.conv(x, w[:, :c].contiguous())
         if tuple(f[4].shape[2:]) == tuple(lo.shape[2:]):                          # (f3 and f4 share the full resolution: the resize is the identity)
-            return ops.conv(f[4], w[:, c:].contiguous(), None, residual=lo)
-        return ops.conv_upres(f[4], w[:, c:].contiguous(), lo)
+            return ops.boundary(ops.conv(f[4], w[:, c:].contiguous(), None, residual=lo))
+        return ops.boundary(ops.conv_upres(f[4], w[:, c:].contiguous(), lo))
 
 
 def create_model_3d(ema=False, num_classes=4):

@@ -9,6 +9,9 @@ with `nn.Conv3d(16, 16, 1)`).  The `dropin/` modules therefore export THIS names
 split-bf16 GEMM kernels; backward on the non-zero rows of the incoming gradient when the loss touched few rows) and everything else
 through `torch.nn`'s own forward.  Same class name, parameters, `state_dict` keys, `isinstance(m, torch.nn.Conv2d)`; fp32-accurate
 results (torch's convolution differs from it by summation order, as two torch backends do).  `ARCO_DROPIN_NN=0`: plain `torch.nn`.
+The outputs are channels-last in memory (logical NCHW / NCDHW) and are handed out as `ops.BoundaryTensor`: the reference's
+`rep_u.view(rep_u.shape[0], -1)` (`train_arco_2d.py:127`) works on them and flattens in (c, h, w) order as on torch's own convolution
+output (it copies where torch's would alias); `tests/test_dropin_user_gpu.py::test_literal_reference_statements_on_the_dropin_nn`.
 Not supported on the accelerated route: double backward (`create_graph=True` through the convolution) - `ops.ConvFn` is a first-order
 autograd function; a trainer that needs it sets `ARCO_DROPIN_NN=0`.
 At the headline size a reference-style user's step spends 32 of 76 ms in torch's own 1x1 convolutions of q_representation (11 forward,
@@ -35,7 +38,7 @@ class Conv2d(_tnn.Conv2d):
 
     def forward(self, x):
         if _plain_1x1(self, x, 2):
-            return ops.conv(ops.to_channels_last(x), self.weight, self.bias)
+            return ops.boundary(ops.conv(ops.to_channels_last(x), self.weight, self.bias))
         return super().forward(x)
 
 
@@ -44,7 +47,7 @@ class Conv3d(_tnn.Conv3d):
 
     def forward(self, x):
         if _plain_1x1(self, x, 3):
-            return ops.conv(ops.to_channels_last(x), self.weight, self.bias)
+            return ops.boundary(ops.conv(ops.to_channels_last(x), self.weight, self.bias))
         return super().forward(x)
 
 

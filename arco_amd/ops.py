@@ -16,6 +16,13 @@ _drop_gen = None
 SEED_DEV = None     # device uint64 salt for dropout masks of graph-captured forwards (graphs.py)
 PROFILE = None       # bench.py sets a dict: kernel instantiation id -> {n, flop, timed: [(ev0, ev1, flop, (taps, M, N, K))]}
 _cfg_cache = {}
+WORK = None          # bench.py sets {"bytes": 0.0, "flop": 0.0, "launches": 0}: ALGORITHMIC HBM bytes (each operand once) and FLOP of every
+                     # launch of the convolution / weight-gradient / BatchNorm / pooling / resize families, summed over a step (step_roofline)
+
+
+def _work(nbytes, flop=0.0, launches=1):
+    if WORK is not None and not torch.cuda.is_current_stream_capturing():
+        WORK["bytes"] += float(nbytes); WORK["flop"] += float(flop); WORK["launches"] += launches
 BN_GROUPS = 1         # see bn_groups()
 POOL_FUSE = int(__import__('os').environ.get('ARCO_POOL_FUSE', '1'))             # A/B switch: 0 = separate max-pool pass in the U-Net encoder
 CONV_MMA = int(__import__('os').environ.get('ARCO_CONV_MMA', '3'))          # MFMA mode of the convolutions / GEMMs (forward and data gradient; --conv_mma of the trainers):
@@ -479,6 +486,10 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         nmb = L.query("arco_conv_mblocks_mma", taps, nb * d3, h, w, k, n, ld, stat_groups, mma)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
+    if WORK is not None:
+        esz = 2 if half else 4
+        mpix = nb * d3 * h * w
+        _work(mpix * (k + n) * esz + taps * n * k * 4 + (mpix * n * esz if residual is not None else 0), 2.0 * taps * mpix * n * k)
     prof = cfg = None
     if PROFILE is not None and not torch.cuda.is_current_stream_capturing():
         # every launch is counted; every PROFILE_EVERY-th one is bracketed by HIP events on the launch stream
@@ -513,6 +524,9 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1, pro=None):
 
     def compute(out, accumulate):
         prof = None
+        if WORK is not None:
+            mpix = nb * d3 * h * w
+            _work(mpix * (co + ci) * (2 if _is_half(dzr) else 4) + taps * co * ci * 4, 2.0 * taps * mpix * co * ci, 2)      # + the slab reduction
         if PROFILE is not None and not torch.cuda.is_current_stream_capturing():
             flop = 2.0 * taps * nb * d3 * h * w * co * ci
             rec = PROFILE.setdefault(("wgrad", taps, co, ci), {"n": 0, "flop": 0.0, "timed": []})
@@ -725,6 +739,7 @@ class ConvFn(torch.autograd.Function):
 
 def _bn_apply(zr, ldz, m, co, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, out, ld_out=None, groups=1):
     seed_dev = SEED_DEV if (p > 0 and torch.cuda.is_current_stream_capturing()) else None
+    _work(2 * m * co * (2 if _is_half(zr) else 4))
     L.call("arco_bn_act_fwd_h" if _is_half(zr) else "arco_bn_act_fwd", L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd),
            L.ptr(gamma), L.ptr(beta), float(slope), int(drop_mode), float(p), seed, P, L.ptr(out), co if ld_out is None else ld_out,
            L.ptr(seed_dev), groups)
@@ -757,6 +772,7 @@ def _bn_backward(da, z, mean, istd, gamma, beta, slope, drop_mode, p, seed, P, s
             db_t = dbeta = torch.empty_like(beta)
     else:
         dg_t = db_t = None
+    _work(5 * m * co * (2 if half else 4), 0.0, 3)     # reduce: dA, Z; apply: dA, Z -> dZ (algorithmic: dA, Z -> dZ would be 3)
     L.call("arco_bn_act_bwd_h" if half else "arco_bn_act_bwd", L.ptr(dar), ldd, L.ptr(zr), ldz, m, co, L.ptr(mean), L.ptr(istd),
            L.ptr(gamma), L.ptr(beta), slope, drop_mode, p, seed, P, L.ptr(ws), L.ptr(dg_t), L.ptr(db_t), acc, L.ptr(dz), co,
            L.ptr(seed_dev), groups)
@@ -784,11 +800,7 @@ class ConvBnActFn(torch.autograd.Function):
             raise RuntimeError(f"arco_amd: bn_groups({G}) needs a batch that is a multiple of {G}, got {nv}")
         z, (ssum, ssq, nmb) = conv_raw(xr, ld, ci, wp, co, nv, h, w, taps, bias=bias, stats=True, d3=d3, sp=sp,
                                        stat_groups=G, half=half)
-        mean = torch.empty(G * co, dtype=torch.float32, device=x.device)      # [G][co]
-        istd = torch.empty(G * co, dtype=torch.float32, device=x.device)
-        d0, dbuf = _defer_args(running_mean, running_var, co, G, momentum)
-        L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
-               L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G, d0, L.ptr(dbuf))
+        mean, istd = _finalize_bn(ssum, ssq, nmb, co, m, eps, momentum, running_mean, running_var, nbt, G, x.device)
         seed = _next_seed() if p > 0 else 0
         if cat_room:        # leave room behind the channels for a later in-place channel concat (ops.upcat)
             buf = new_act_nd(nv, co + int(cat_room), sp, x.device)
@@ -805,6 +817,7 @@ class ConvBnActFn(torch.autograd.Function):
             if p > 0 or d3 != 1:
                 raise RuntimeError("arco_amd: conv_bn_act(pool=True) is the 2-D, dropout-free last stage of a ConvBlock")
             pooled = new_act(nv, co, h // 2, w // 2, x.device)
+            _work((2 * m + m // 4) * co * 4)
             L.call("arco_bn_act_pool_fwd", L.ptr(zr), ldz, nv, h, w, co, L.ptr(mean), L.ptr(istd), L.ptr(gamma), L.ptr(beta),
                    float(slope), L.ptr(a), ld_a, L.ptr(pooled), co, G)
             ctx.seed_dev = None
@@ -829,6 +842,7 @@ class ConvBnActFn(torch.autograd.Function):
             ar, lda_ = rows_view(a)
             dpr, ldp = rows_view(dpool)
             dsum = new_act(nv, co, h, w, x.device)
+            _work((nv * h * w * (3 if da is not None else 2) + nv * h * w // 4) * co * 4)
             if da is None:
                 L.call("arco_maxpool2_bwd", L.ptr(ar), lda_, nv, h, w, co, L.ptr(dpr), ldp, L.ptr(dsum), co)
             else:
@@ -882,6 +896,7 @@ def _finalize_bn(ssum, ssq, nmb, co, m, eps, momentum, running_mean, running_var
     mean = torch.empty(G * co, dtype=torch.float32, device=dev)      # [G][co]
     istd = torch.empty(G * co, dtype=torch.float32, device=dev)
     d0, dbuf = _defer_args(running_mean, running_var, co, G, momentum)
+    _work(2 * co * nmb * 4)
     L.call("arco_bn_finalize", L.ptr(ssum), L.ptr(ssq), nmb, co, m, float(eps), float(momentum), L.ptr(mean),
            L.ptr(istd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), G, d0, L.ptr(dbuf))
     return mean, istd
@@ -930,6 +945,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.params = (b1, b2)
         if pool:
             pooled = new_act(nv, co, h // 2, w // 2, dev)
+            _work((2 * m + m // 4) * co * 4)
             L.call("arco_bn_act_pool_fwd", L.ptr(z2r), ldz2, nv, h, w, co, L.ptr(mean2), L.ptr(istd2), L.ptr(g2), L.ptr(be2),
                    float(slope2), L.ptr(a), ld_a, L.ptr(pooled), co, G)
             ctx.set_materialize_grads(False)
@@ -955,6 +971,7 @@ class ConvBlockFn(torch.autograd.Function):
             ar, lda_ = rows_view(a)
             dpr, ldp = rows_view(dpool)
             dsum = new_act(nv, co, h, w, dev)
+            _work((nv * h * w * (3 if da is not None else 2) + nv * h * w // 4) * co * 4)
             if da is None:
                 L.call("arco_maxpool2_bwd", L.ptr(ar), lda_, nv, h, w, co, L.ptr(dpr), ldp, L.ptr(dsum), co)
             else:
@@ -1289,6 +1306,7 @@ class BilinearFn(torch.autograd.Function):
     def forward(ctx, x, ho, wo):
         xr, ld, nb, c, h, w = _geom(x)
         y = new_act(nb, c, ho, wo, x.device)
+        _work(nb * c * (h * w + ho * wo) * 4)
         L.call("arco_bilinear_fwd", L.ptr(xr), ld, nb, h, w, c, ho, wo, L.ptr(y), c)
         ctx.dims = (nb, c, h, w, ho, wo)
         return y
@@ -1298,6 +1316,7 @@ class BilinearFn(torch.autograd.Function):
         nb, c, h, w, ho, wo = ctx.dims
         dyr, ldy = rows_view(dy)
         dx = new_act(nb, c, h, w, dy.device)
+        _work(nb * c * (h * w + ho * wo) * 4)
         L.call("arco_bilinear_bwd", L.ptr(dyr), ldy, nb, h, w, c, ho, wo, L.ptr(dx), c, 0)
         return dx, None, None
 
@@ -1449,6 +1468,7 @@ class UpCatFn(torch.autograd.Function):
         xr, ld, nb, c, h, w = _geom(x)
         c2, ho, wo = int(skip.shape[1]), int(skip.shape[2]), int(skip.shape[3])
         ctot = int(buf.shape[1])
+        _work(nb * c * (h * w + ho * wo) * 4)
         L.call("arco_bilinear_fwd", L.ptr(xr), ld, nb, h, w, c, ho, wo, L.ptr(buf[:, c2:]), ctot)
         ctx.dims = (nb, c, h, w, ho, wo, c2)
         return buf
@@ -1458,6 +1478,7 @@ class UpCatFn(torch.autograd.Function):
         nb, c, h, w, ho, wo, c2 = ctx.dims
         dr, ldd = rows_view(dbuf)
         dx = new_act(nb, c, h, w, dbuf.device)
+        _work(nb * c * (h * w + ho * wo) * 4)
         L.call("arco_bilinear_bwd", L.ptr(dr[:, c2:]), ldd, nb, h, w, c, ho, wo, L.ptr(dx), c, 0)
         return dx, dbuf[:, :c2], None
 
@@ -1598,6 +1619,28 @@ def maxpool2_skip(x):
 
 def bilinear(x, size):
     return BilinearFn.apply(x, int(size[0]), int(size[1]))
+
+
+class BoundaryTensor(torch.Tensor):
+    """A channels-last activation as the drop-in boundary hands it to REFERENCE code.  The reference flattens such outputs with
+    `rep_u.view(rep_u.shape[0], -1)` (train_arco_2d.py:127,129,400; train_arco_3d.py:124,126,363) - legal on the NCHW-contiguous
+    result of torch's own convolution, a RuntimeError on channels-last strides.  On this subclass `.view` falls back to `.reshape`
+    when the strides do not allow a view: the statement then yields exactly the (c, h, w) flattening it yields in the reference,
+    at the price of the copy `.reshape` makes.  Everything else is torch.Tensor's own behaviour (the subclass survives slicing,
+    `.detach()`, arithmetic; autograd is unaffected)."""
+
+    def view(self, *shape, **kw):
+        try:
+            return super().view(*shape, **kw)
+        except RuntimeError:
+            if kw or (len(shape) == 1 and isinstance(shape[0], torch.dtype)):
+                raise
+            return self.reshape(*shape)
+
+
+def boundary(t):
+    """Mark a channels-last output that leaves the package through a reference-named module (see BoundaryTensor)."""
+    return t.as_subclass(BoundaryTensor) if type(t) is torch.Tensor else t
 
 
 def to_channels_last(x):

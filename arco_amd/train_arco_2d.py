@@ -318,6 +318,8 @@ class ArcoStep2D:
         with torch.no_grad():                                            # :284-286
             pred_u0, _, _ = self.t_fwd_u0(u_data)
             pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
+            if self.keep_debug:      # tests: the teacher's decisions before the mixing (cutout writes -1 into the labels in place)
+                dbg_pseudo = (pseudo_labels.clone(), pseudo_logits.clone())
         u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
         cj2_u = u_aug
         if bt:      # :299-304: two independent strong augmentations of the mixed unlabeled batch
@@ -367,6 +369,9 @@ class ArcoStep2D:
             prob_l_t = glue.softmax(pred_l_t)
             prob_u_t = glue.softmax(pred_u_t)
             low_mask_all, high_mask_all = glue.entropy_masks(pred_u, l_label, u_aug_label, alpha_t)
+            if self.keep_debug:      # the step's gradient-free decision inputs (oracle/cpu_step.py `force=`)
+                self.decisions = dict(pseudo_labels=dbg_pseudo[0], pseudo_logits=dbg_pseudo[1], low=low_mask_all, high=high_mask_all,
+                                      prob_l_t=prob_l_t, prob_u_t=prob_u_t)
         prof = self.profile_loss
         ev = ev2 = ev3 = None
         if prof:
@@ -675,7 +680,15 @@ def train(args, snapshot_path):
             u_img = u_next['image'].to(dev, non_blocking=True)
         loss, reco = stepper.step(l_img, l_lab, u_img, it // iters_per_epoch, max_epoch)
         if rank == 0:
-            logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))
+            if "loss_q" in stepper.last_terms:                          # --revisit 1: the reference's logged total (:426,457)
+                logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))
+            else:
+                # the reference's logged `loss` also carries k4*loss_q, the revisiting term (:126-136,334,425) - a constant w.r.t. every
+                # parameter (no gradient path: weights, banks and every other logged value are unaffected) that needs the dense
+                # 496-channel representations of both nets; by default it is NOT computed, and the log line says so instead of
+                # printing a total that silently differs from the reference's (--revisit 1 computes and adds it)
+                logging.info('iteration %d : loss : %f (without the gradient-free revisiting term k4*loss_q, k4 = %g: --revisit 1 adds it), '
+                             'reco_loss: %f' % (stepper.iter_num, loss.item(), args.k4, reco.item()))
             if stepper.iter_num % 1000 == 0:                           # :462-470
                 path = os.path.join(snapshot_path, 'iter_' + str(stepper.iter_num) + '.pth')
                 # parameters are views into the optimiser's flat buffer: save private copies, not the shared storage

@@ -483,7 +483,11 @@ def train(args, snapshot_path):
             u_img = u_next['image'].to(dev, non_blocking=True)
         loss, reco = stepper.step(l_img, l_lab, u_img, it // iters_per_epoch, max_epoch)
         if rank == 0:
-            logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))
+            if getattr(args, "revisit", 0):
+                logging.info('iteration %d : loss : %f, reco_loss: %f' % (stepper.iter_num, loss.item(), reco.item()))
+            else:      # (see train_arco_2d.train: the gradient-free revisiting term of the reference's logged total is opt-in)
+                logging.info('iteration %d : loss : %f (without the gradient-free revisiting term k4*loss_q, k4 = %g: --revisit 1 adds it), '
+                             'reco_loss: %f' % (stepper.iter_num, loss.item(), args.k4, reco.item()))
             if stepper.iter_num % 1000 == 0:                           # :441-449
                 path = os.path.join(snapshot_path, 'iter_' + str(stepper.iter_num) + '.pth')
                 # parameters are views into the optimiser's flat buffer: save private copies, not the shared storage

@@ -142,8 +142,13 @@ def cpu_baseline_child():
     cpu_step.timed_sample(b=1, patch=(64, 64), k2=1.0, bt=True)          # warm the thread pool / allocator
     secs, threads = cpu_step.timed_sample(b=2, steps=3, k2=1.0, bt=True)
     loss_ms = cpu_loss_only(threads)
+    # ... and the same step on ALL physical cores (SURVEY 8d asks for them): one step, reported beside the headline
+    secs_all = None
+    if physical > threads and "ARCO_CPU_THREADS" not in os.environ:
+        torch.set_num_threads(physical)
+        secs_all, _ = cpu_step.timed_sample(b=2, steps=1, k2=1.0, bt=True)
     print(json.dumps({"secs": secs, "threads": threads, "steps": 3, "physical_cores": physical, "logical_cpus": logical,
-                      "cpu_model": model, "loss_only_ms": loss_ms}))
+                      "cpu_model": model, "loss_only_ms": loss_ms, "secs_all_cores": secs_all}))
 
 
 def cpu_baseline():
@@ -159,6 +164,12 @@ def cpu_baseline():
     return {"value": round(1.0 / (4.0 * secs), 5), "unit": "steps/s (16-image steps)", "cores": threads, "kind": "port",
             "physical_cores": r.get("physical_cores"), "logical_cpus": r.get("logical_cpus"), "cpu_model": r.get("cpu_model"),
             "loss_only_ms": round(r.get("loss_only_ms", float("nan")), 1),
+            "all_physical_cores": (None if not r.get("secs_all_cores") else
+                                   {"cores": r.get("physical_cores"), "value": round(1.0 / (4.0 * r["secs_all_cores"]), 5),
+                                    "seconds_per_4_image_step": round(r["secs_all_cores"], 2),
+                                    "note": "one oracle step with one torch thread per physical core (slower than the 32-thread figure on "
+                                            "these two-socket hosts: torch's intra-op pool loses to cross-socket traffic); `value` above "
+                                            "is the FASTEST thread count, so the GPU / CPU ratio is not flattered"}),
             "loss_only_note": "oracle compute_contra_memobank_loss fwd + bwd alone at --batch_size 2 (4 images, D = 496, full 4096-key "
                               "queues, 256 x 512 samples per class); the GPU twin is contrastive_loss_ms_per_step at 16 images",
             "sample": f"{r.get('steps', 1)} chained full oracle steps at --batch_size 2 (4 images, 256x256, C=4, D=496, cutmix, "
@@ -233,6 +244,7 @@ def roofline_from_profile(prof, n_steps, step_ms):
     the UN-instrumented product run: shares and the whole-step figure are quoted against it."""
     if not prof:
         return None, None
+    prof = {c: v for c, v in prof.items() if c != "__work__"}
     avg = {c: sum(s_.elapsed_time(e_) for s_, e_, _, _ in v["timed"]) / max(1, len(v["timed"])) for c, v in prof.items()}
     tot = {c: avg[c] * v["n"] for c, v in prof.items()}
     is3 = lambda c: (not isinstance(c, tuple)) and c % 100000000 // 1000000 == 9
@@ -275,6 +287,10 @@ def roofline_from_profile(prof, n_steps, step_ms):
         by_shape = {f"{shp[0]}x{shp[1]}x{shp[2]}x{shp[3]}": round(table[shp] / conv_algorithmic_bytes(*shp, k_mma), 4)
                     for shp in sorted({l_[3] for l_ in launches}) if shp in table}
     roof = {**head, "traffic": traffic, "traffic_over_algorithmic": ratio, "traffic_over_algorithmic_by_shape": by_shape,
+            "traffic_source": ("table: HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 units) measured ONCE per launch shape in separate "
+                               "rocprofv3 --pmc passes (tools/pmc_conv*.py; summaries profiles/r0N_pmc_*_traffic.md, newest profiles/r05_pmc_traffic.md) "
+                               "and averaged here over the launches timed in THIS run - bench.py itself collects no counters (a --pmc pass "
+                               "cannot run inside this process)"),
             "peak_note": {0: "fp32 MFMA peak", 3: "dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32-accurate product); the native fp32 MFMA peak is 157.3"}.get(k_mma, "dense f16/bf16 MFMA peak"),
             "kernel": _kernel_name(cfg), "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(rec["n"] / n_steps, 1),
             "launches_timed": len(launches), "avg_flop_per_launch": avg_flop,
@@ -330,11 +346,36 @@ def eager_profile(stepper, run_steps, n_steps):
     run_steps(2)
     torch.cuda.synchronize()
     ops.PROFILE, ops.PROFILE_EVERY = {}, 5
+    ops.WORK = {"bytes": 0.0, "flop": 0.0, "launches": 0}
     run_steps(n_steps)
     torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
+    work, ops.WORK = ops.WORK, None
     graphs.set_enabled(stepper, prev)
+    prof["__work__"] = {k: v / n_steps for k, v in work.items()}
     return prof
+
+
+def step_roofline(work, step_ms, split=True):
+    """The WHOLE step against both rooflines: the algorithmic HBM bytes (every operand of a launch counted once) and
+    the FLOP of every launch of the convolution / weight-gradient / BatchNorm / pooling / resize families of one step (ops.WORK, counted
+    in the eager pass - the same launches the graphs replay), divided by the step time of the un-instrumented run."""
+    if not work:
+        return None
+    peak_f = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    gbs = work["bytes"] / (step_ms * 1e-3) / 1e9
+    tf = work["flop"] / (step_ms * 1e-3) / 1e12
+    t_hbm, t_mfma = work["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3, work["flop"] / (peak_f * 1e12) * 1e3
+    return {"algorithmic_bytes_per_step": work["bytes"], "flop_per_step": work["flop"], "launches_counted": round(work["launches"], 1),
+            "ms_per_step": round(step_ms, 3),
+            "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+            "mfma": {"achieved": round(tf, 2), "peak": round(peak_f, 1), "unit": "TFLOP/s", "frac": round(tf / peak_f, 4)},
+            "lower_bound_ms": {"hbm": round(t_hbm, 3), "mfma": round(t_mfma, 3), "max": round(max(t_hbm, t_mfma), 3)},
+            "frac_of_lower_bound": round(max(t_hbm, t_mfma) / step_ms, 4),
+            "note": "bytes: inputs + outputs + weights of every counted launch once (what a perfectly cached kernel must move); the BatchNorm "
+                    "backward counts its two passes (5 tensor crossings); loss front end, glue, augmentation and optimiser launches "
+                    "(< 10 % of the kernel time) are not counted.  The step is a dependent chain of ~800 launches on two streams: "
+                    "frac_of_lower_bound is the whole-step roofline fraction"}
 
 
 def timed(run_steps, n):
@@ -594,13 +635,17 @@ def main():
     stepper.loss_events = []
     _graphs.set_enabled(stepper, prev_flags)
     T.TEACHER_SIDE = side_mode
+    ranks_seen = 1
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        one = torch.ones(1, dtype=torch.float64, device=dev)       # every rank contributes 1 over RCCL: the record proves the collective saw N ranks
+        torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
     step_ms = dt / a.steps * 1e3
 
-    sustained = k2_0 = roof = whole = None
+    sustained = k2_0 = roof = whole = step_roof = None
     if world == 1:
         if a.sustain_s > 0:              # clocks settle lower under sustained load: a >= 3 s figure beside the K-step one
             n_s = max(a.steps, int(a.sustain_s * 1e3 / step_ms) + 1)
@@ -619,6 +664,7 @@ def main():
         prof = eager_profile(stepper, run, 3)
         T.TEACHER_SIDE = side_mode
         roof, whole = roofline_from_profile(prof, 3, step_ms)
+        step_roof = step_roofline(prof.get("__work__"), step_ms, split=a.conv_mma == "f32x3")
 
     if rank == 0:
         out = {
@@ -647,6 +693,8 @@ def main():
             "contrastive_loss_segments_ms": {"masks_counts": loss_seg[0], "lists_prototypes_keys_banks": loss_seg[1],
                                              "anchors_head_infonce": loss_seg[2]},
             "roofline": roof,
+            "step_roofline": step_roof,
+            "ranks_seen": ranks_seen,
         }
         if whole is not None:
             out["whole_step"] = whole

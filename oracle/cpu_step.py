@@ -47,10 +47,28 @@ def batch_transform(data, label, logits, apply_augmentation, morph_velocity=None
 
 def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20.0, k1=0.01, lr=0.01,
          delta_n=0.97, func='smc', nq=256, nn_=512, k2=0.0, tps_sigma=0.01, weak_threshold=0.7, apply_aug='none', pool=None, k4=1.0, topk=5,
-         bt=False, morph_velocity=None):
+         bt=False, morph_velocity=None, force=None):
+    """force (round 6, as cpu_step3d.step): the step's gradient-free DECISION inputs as another implementation computed them
+    (pseudo_labels / pseudo_logits before the mixing, low / high entropy masks, teacher probabilities).  Each is compared with this
+    function's own value (agreement counts in st["agree"]) and then used in its place, so that every threshold / arg-max decision of
+    the step - 10^5 pixels at 256 x 256, each a hair-trigger for the sampler arguments and through them the CPU generator stream -
+    is taken on identical numbers and everything continuous downstream can be compared strictly."""
+    agree = {}
+
+    def forced(name, mine):
+        if force is None or name not in force:
+            return mine
+        other = force[name].to(mine.dtype)
+        if mine.is_floating_point():
+            agree[name] = dict(max_abs_diff=float((other - mine).abs().max()), n_diff=int((other != mine).sum()), n=mine.numel())
+        else:
+            agree[name] = dict(n_diff=int((other != mine).sum()), n=mine.numel())
+        return other
+    st["agree"] = agree
     with torch.no_grad():
         pred_u0, _, _ = orc.unet_forward(u_data, st["teacher"], track=True)
         pseudo_logits, pseudo_labels = torch.max(torch.softmax(pred_u0, 1), 1)
+        pseudo_logits, pseudo_labels = forced("pseudo_logits", pseudo_logits), forced("pseudo_labels", pseudo_labels)
         if apply_aug in ('cutout', 'cutmix', 'classmix'):      # train_arco_2d.py:296-297 (generate_unsup_data)
             mixed = orc.generate_unsup_data(u_data.numpy(), pseudo_labels.numpy().copy(), pseudo_logits.numpy(), apply_aug)
             u_data, pseudo_labels, pseudo_logits = (torch.from_numpy(v) for v in mixed)
@@ -80,6 +98,7 @@ def step(st, l_data, l_label, u_data, memobank, ptrs, qsize, n_cls=4, alpha_t=20
         label_u = orc.label_onehot(pseudo_labels, n_cls).long()
         low, high, _ = orc.entropy_masks(pred_u, l_label, pseudo_labels, alpha_t)
         pl, pu = torch.softmax(pred_l_t, 1), torch.softmax(pred_u_t, 1)
+        low, high, pl, pu = forced("low", low), forced("high", high), forced("prob_l_t", pl), forced("prob_u_t", pu)
     _, reco = orc.compute_contra_memobank_loss(rep, label_l, label_u, pl, pu, low, high, memobank, ptrs, qsize, rep_t,
                                                delta_n=delta_n, func=func, num_queries=nq, num_negatives=nn_)
     ce, dice = orc.supervised_loss(pred_l, l_label, n_cls)

@@ -10,6 +10,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -140,3 +141,38 @@ print("NNDROP " + json.dumps(out))
     assert out["fwd"] <= 2e-5 and out["dx"] <= 2e-5 and out["dw"] <= 1e-4 and out["v"] <= 1e-5, out
     assert out["c3_same"] and out["cpu_same"]
     assert out["odd_nograd"] <= 2e-5 and out["odd"] <= 1e-4 and out["odd_shape"][0] == out["odd_shape"][1], out
+
+
+def test_literal_reference_statements_on_the_dropin_nn():
+    """The statements the reference trainers apply to q_representation and its output, literally: the module built from the
+    star-imported `nn` (train_arco_2d.py:231-234), wrapped in nn.DataParallel (:240), its output sliced and flattened with `.view`
+    (:127, 129, 400 - a RuntimeError on a plain channels-last tensor), normalised, and differentiated.  The accelerated 1x1 path must
+    be the one that ran, and the flattening order must be torch's (c, h, w)."""
+    import torch.nn.functional as F
+    from arco_amd import ops
+    from arco_amd.nn_dropin import nn
+    torch.manual_seed(0)
+    q_representation = nn.Sequential(nn.Conv2d(496, 496, kernel_size=1, bias=False), nn.Conv2d(496, 496, kernel_size=1, bias=False))
+    q_representation = torch.nn.DataParallel(q_representation.cuda())
+    x = torch.randn(4, 496, 32, 32, device="cuda")
+    rep_all = q_representation(x)
+    assert isinstance(rep_all, ops.BoundaryTensor) and rep_all.stride(1) == 1          # the HIP GEMM path, channels-last memory
+    rep_u = rep_all[2:]
+    rep_u = rep_u.view(rep_u.shape[0], -1)                                            # train_arco_2d.py:127
+    rep_u = torch.nn.functional.normalize(rep_u, dim=-1)                              # :128
+    with torch.no_grad():
+        w0, w1 = [m.weight for m in q_representation.module]
+        ref = F.conv2d(F.conv2d(x, w0), w1)[2:]
+        ref = F.normalize(ref.reshape(ref.shape[0], -1), dim=-1)
+    assert rep_u.shape == ref.shape
+    np.testing.assert_allclose(rep_u.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-3, atol=1e-6)
+    random_pool = F.normalize(torch.randn(6, rep_u.shape[1], device="cuda"), dim=1)
+    dist_t = 2 - 2 * torch.einsum('bc,kc->bk', [rep_u, random_pool])                  # :130
+    dist_t.sum().backward()
+    g = [m.weight.grad for m in q_representation.module]
+    assert all(t is not None and torch.isfinite(t).all() and float(t.abs().max()) > 0 for t in g)
+    # 3-D twin (train_arco_3d.py:206-209, 124)
+    q3 = nn.Sequential(nn.Conv3d(16, 16, 1), nn.Conv3d(16, 16, 1)).cuda()
+    y3 = q3(torch.randn(2, 16, 8, 16, 16, device="cuda"))
+    assert isinstance(y3, ops.BoundaryTensor)
+    assert y3[1:].view(1, -1).shape == (1, 16 * 8 * 16 * 16)

@@ -272,3 +272,77 @@ def test_pass_concurrency_3d_equals_the_single_stream_step(side_mode):
                 np.testing.assert_allclose(vb.cpu().numpy(), va.cpu().numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
     finally:
         T3.PASS_SIDE = prev
+
+
+def test_three_steps_3d_free_running_chain_is_reported():
+    """The same three 3-D steps as `sparse_c4` above, FREE-RUNNING: the HIP step and the CPU oracle start from equal
+    state once and are never re-synchronised, and the oracle takes its own gradient-free decisions (no `force=`).  The docs argue that
+    such a chain cannot be held to 1e-3 (V-Net gradients are conditioned like ReLU-flip counts, one flipped threshold voxel shifts
+    every later draw of the host generator); this test turns the argument into numbers: per step the relative deviation of every loss
+    term, whether the two sides still draw the same samples, and the largest parameter deviation - printed, written to
+    gpurun_out/r06_free_chain3d.json when that directory exists, and held only to loose sanity bounds (supervised / unsupervised
+    terms within 5 %, everything finite).  The re-synced variants above stay the 1e-3 parity gate."""
+    import json
+    import os
+    from arco_amd import ops, train_arco_3d as T3
+    C, b, patch, Q, Nn, qs, lr = 4, 2, (32, 32, 32), 48, 16, 200, 0.01
+    vnet_sd = _state(C)
+    fe_sd = fx.fe_state(61, FEA, 16, nd=3)
+    qrep_w = [_qrep_w(71), _qrep_w(72)]
+    argv = ["--batch_size", str(b), "--queue_size", str(qs), "--synthetic", "1", "--num_classes", str(C), "--num_queries", str(Q),
+            "--num_negatives", str(Nn), "--k1", "1.0", "--base_lr", str(lr), "--dense_head", "0", "--eqv_pass", "1", "--apply_aug", "cutmix",
+            "--func", "asmc", "--graphs", "0", "--strong_threshold", "0.3"]
+    args = T3.build_parser().parse_args(argv)
+    args.patch_size = list(patch)
+    random.seed(3); np.random.seed(3); torch.manual_seed(3)
+    st_g = T3.ArcoStep3D(args, "cuda:0")
+    st_g.model.load_state_dict(vnet_sd, strict=True)
+    st_g.ema_model.load_state_dict(vnet_sd, strict=True)
+    st_g.q_feature_extractor.load_state_dict(fe_sd, strict=True)
+    st_g.k_feature_extractor.load_state_dict(fe_sd, strict=True)
+    with torch.no_grad():
+        st_g.q_representation[0].weight.copy_(qrep_w[0])
+        st_g.q_representation[1].weight.copy_(qrep_w[1])
+    for m in (st_g.model, st_g.ema_model):
+        _drop_off(m)
+    ops.bump_weight_epoch()
+    st_o = cpu_step3d.make_state(vnet_sd, fe_sd, qrep_w, base_lr=lr, max_iterations=args.max_iterations)
+    bank_o = [[m[0].detach().cpu().clone()] for m in st_g.memobank]
+    ptr_o = [torch.zeros(1, dtype=torch.long) for _ in range(C)]
+    qsz = list(st_g.queue_size)
+    rs = np.random.RandomState(13)
+
+    def gens():
+        ns = np.random.get_state()
+        return (random.getstate(), ns[1].tobytes(), ns[2:], torch.get_rng_state().numpy().tobytes())
+
+    random.seed(10); np.random.seed(10); torch.manual_seed(10)
+    g_state = o_state = (random.getstate(), np.random.get_state(), torch.get_rng_state())
+    report = []
+    for it in range(3):
+        l, lab, u = _volumes(rs, b, patch, C)
+        random.setstate(g_state[0]); np.random.set_state(g_state[1]); torch.set_rng_state(g_state[2])
+        st_g.step(l.cuda(), lab.cuda(), u.cuda())
+        g_state, g_cmp = (random.getstate(), np.random.get_state(), torch.get_rng_state()), gens()
+        random.setstate(o_state[0]); np.random.set_state(o_state[1]); torch.set_rng_state(o_state[2])
+        cpu_step3d.step(st_o, l, lab, u, bank_o, ptr_o, qsz, n_cls=C, k1=1.0, k3=args.k3, k4=args.k4, delta_n=args.strong_threshold_u2pl,
+                        strong_threshold=args.strong_threshold, weak_threshold=args.weak_threshold, func="asmc", nq=Q, nn_=Nn,
+                        tps_sigma=args.tps_sigma, apply_aug="cutmix", eqv_pass=True, pool=None, topk=5, force=None)
+        o_state, o_cmp = (random.getstate(), np.random.get_state(), torch.get_rng_state()), gens()
+        to, tg = st_o["last_terms"], st_g.last_terms
+        rel = {k: abs(float(tg[k]) - to[k]) / max(abs(to[k]), 1e-6) for k in ("ce", "dice", "unsup", "reco", "eqv")}
+        sd_g = st_g.model.state_dict()
+        wdev = max(float((sd_g[k].cpu() - v.detach()).abs().max()) / max(1e-6, float(v.detach().abs().max()))
+                   for k, v in st_o["student"].items() if v.requires_grad)
+        report.append(dict(step=it, rel_dev=rel, same_host_draws=bool(g_cmp == o_cmp), max_rel_param_dev=wdev,
+                           bank_lengths_equal=[int(x[0].shape[0]) for x in bank_o] == [int(m[0].shape[0]) for m in st_g.memobank]))
+        for k in ("ce", "dice", "unsup"):
+            assert rel[k] < 5e-2, (it, k, rel)
+        assert all(np.isfinite(list(rel.values())))
+    print("free-running 3-D chain, HIP vs CPU oracle:")
+    for r in report:
+        print("  ", json.dumps(r))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r06_free_chain3d.json"), "w") as f:
+            json.dump(report, f, indent=1)
