@@ -31,6 +31,10 @@ CONV_MMA = int(__import__('os').environ.get('ARCO_CONV_MMA', '3'))          # MF
                       #    (error per product <= 2^-23, the size of one fp32 rounding; csrc/igemm.hip, MMA = 3);
                       # 0 ("f32"): the native fp32 MFMA (bitwise an fma chain);
                       # 1 / 2 ("f16" / "bf16"): the 3x3x3 convolutions round their operands to f16 / bf16 (BASELINE configs[4])
+HEAD_MMA = 0         # 1 / 2: every 1x1 / 1x1x1 GEMM on fp32 tensors (FeatureExtractor_3d, q_representation, the row-sparse heads: model_3D.py:37-63,
+                     # train_arco_3d.py:206-209) rounds its operands to f16 / bf16 in registers (v_mfma_f32_16x16x16_f16, fp32 accumulate; gradient
+                     # operands bf16 for range) - the "contrastive" half of BASELINE configs[4]'s "fp16 MFMA conv + contrastive"; set by
+                     # train_arco_3d --act_dtype f16 (--head_mma).  0: the GEMMs follow CONV_MMA
 PROFILE_EVERY = 1    # time every n-th conv launch of an instantiation (bench.py: 7, prime vs the per-step launch counts)
 ACT_HALF = False     # f16 ACTIVATION STORAGE of the volume path (--act_dtype f16 of train_arco_3d, BASELINE configs[4]): the V-Net's
                      # first layer writes f16 and every operator below follows its input's dtype (csrc/conv_h.hip, the *_h entry points);
@@ -474,6 +478,8 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         if residual is not None or (d3 <= 1 and sp is None):
             raise RuntimeError("arco_amd: f16 activation storage covers the volume path's convolutions without a residual operand")
         mma = 4
+    elif HEAD_MMA and taps == 1 and pro is None:
+        mma = 2 if grad else HEAD_MMA                     # (wp is the fp32 pack: the operands are rounded in registers)
     elif CONV_MMA == 3:
         sp_ = getattr(wp, "_arco_split", None)
         if sp_ is not None and _split_ok(taps, nb * d3, h, w, k, n, ld):

@@ -175,6 +175,7 @@ class ArcoStep2D:
         if mma not in ("f32", "f32x3"):      # no silent fp32 run under a reduced-precision label (the modes exist in 3-D only)
             raise ValueError(f"--conv_mma {mma}: the 2-D step computes in f32x3 or f32; f16 / bf16 operands are a 3-D trainer mode")
         ops.CONV_MMA = {"f32": 0, "f32x3": 3}[mma]
+        ops.HEAD_MMA = 0                 # (a 3-D trainer of this process may have set the heads' reduced-precision mode)
         self.random_pool = None
         if getattr(args, "revisit", 0):
             # random_pool (:156-159) is drawn before the models are created, like the reference (same CPU-generator order)

@@ -46,6 +46,10 @@ def build_parser():
                    help="f16: the V-Net's activations and activation gradients are stored as f16 (BASELINE configs[4], 'fp16 MFMA "
                         "conv'): f16 matrix cores with fp32 accumulation, fp32 weights / BatchNorm statistics / loss / optimizer; "
                         "heads and losses stay fp32 (--conv_mma applies to them)")
+    p.add_argument('--head_mma', type=str, default='auto', choices=['auto', 'f32x3', 'f16', 'bf16'],
+                   help="matrix-core operands of the heads' GEMMs (FeatureExtractor_3d, q_representation, the row-sparse heads).  auto: f16 "
+                        "with --act_dtype f16 (BASELINE configs[4] 'fp16 MFMA conv + contrastive': operands rounded to f16 in registers, "
+                        "fp32 accumulate, gradient operands bf16; the full-resolution maps are read as stored f16 rows), else --conv_mma's mode")
     p.add_argument('--loss_scale', type=float, default=16384.0,
                    help='--act_dtype f16: gradients enter the f16 region multiplied by this power of two')
     p.add_argument('--eqv_pass', type=int, default=1,
@@ -64,6 +68,8 @@ class ArcoStep3D:
         C = args.num_classes
         ops.CONV_MMA = {"f32": 0, "f16": 1, "bf16": 2, "f32x3": 3}[getattr(args, "conv_mma", "f32x3")]
         ops.ACT_HALF = getattr(args, "act_dtype", "f32") == "f16"          # before the PackPlans: they carry the f16 packs
+        hm = getattr(args, "head_mma", "auto")
+        ops.HEAD_MMA = {"auto": 1 if ops.ACT_HALF else 0, "f32x3": 0, "f16": 1, "bf16": 2}[hm]
         ops.LOSS_SCALE = float(getattr(args, "loss_scale", 16384.0))
         self.memobank, self.queue_ptrlis, self.queue_size = [], [], []
         for i in range(C):                                                # :144-151

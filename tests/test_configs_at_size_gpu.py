@@ -450,7 +450,7 @@ def test_cfg3_cfg5_default_volume_step_is_reproducible_at_full_size(shape):
         print(shape, "worst relative gradient difference over 40 executions:", worst)
         assert worst <= 1e-5, worst
     finally:
-        ops.ACT_HALF = False
+        ops.ACT_HALF = False; ops.HEAD_MMA = 0
         ops.LOSS_SCALE = 16384.0
         torch.cuda.empty_cache()
 
@@ -472,6 +472,9 @@ def test_cfg5_lits_f16_step_at_full_size_tracks_fp32():
             extra = ["--eqv_pass", "0", "--strong_threshold", "0.55"] + (["--act_dtype", "f16"] if mode == "f16s" else [])
             st = _make3d(extra, patch=sp, b=1, mma={"f32": "f32", "f16": "f16", "f16s": "f32x3"}[mode])
             assert ops.CONV_MMA == {"f32": 0, "f16": 1, "f16s": 3}[mode] and ops.ACT_HALF == (mode == "f16s")
+            # round 6: with f16 activation storage the heads' GEMMs (FeatureExtractor_3d, q_representation, row-sparse
+            # heads) run on f16 MFMA operands too - "fp16 MFMA conv + contrastive" - inside the same 1e-2 budget
+            assert ops.HEAD_MMA == (1 if mode == "f16s" else 0)
             _drop_off(st)
             st.keep_debug = True
             terms = []
@@ -488,7 +491,7 @@ def test_cfg5_lits_f16_step_at_full_size_tracks_fp32():
             torch.cuda.empty_cache()
     finally:
         ops.CONV_MMA = 3
-        ops.ACT_HALF = False
+        ops.ACT_HALF = False; ops.HEAD_MMA = 0
     for mode in ("f16", "f16s"):
         assert np.all(np.isfinite(out[mode]))
         np.testing.assert_allclose(out[mode][0, :2], out["f32"][0, :2], rtol=1e-2)      # first step, same weights: CE / Dice at 1e-2

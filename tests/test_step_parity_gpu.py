@@ -552,7 +552,7 @@ def test_cfg1_step_vs_cpu_oracle_at_256(schedule):
         for k in ("pseudo_logits", "prob_l_t", "prob_u_t"):
             assert ag[k]["max_abs_diff"] < 1e-3, (it, k, ag[k])
         for k in ("pseudo_labels", "low", "high"):
-            assert ag[k]["n_diff"] <= max(2, 1e-4 * ag[k]["n"]), (it, k, ag[k])
+            assert ag[k]["n_diff"] <= max(2, 1e-3 * ag[k]["n"]), (it, k, ag[k])
         assert gen_g == _generators(), f"step {it}: the two sides consumed the host generators differently (a sampled index differs)"
         to, tg = st_o["last_terms"], st_g.last_terms
         for k in ("ce", "dice", "unsup", "reco", "eqv"):
