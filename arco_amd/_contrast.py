@@ -28,6 +28,7 @@ from . import _lib as L
 from . import samplers
 
 GROUPED = True      # all classes of the InfoNCE loop per launch (False: the per-class launch sequence; tests compare the two)
+NCE_FUSED = int(__import__('os').environ.get('ARCO_NCE_FUSED', '1'))     # round 6: score GEMM with the softmax-CE in its epilogue (0: the staged route of rounds 2-5; tests compare the two)
 EPS = 1e-8          # torch.cosine_similarity eps
 DELTA_P = 0.3       # current_class_threshold      (loss_helper_3d.py:316)
 LOW_RANK, HIGH_RANK = 3, 20                        # (loss_helper_3d.py:318)
@@ -436,6 +437,37 @@ def _infonce_grouped(pl, A_all, memobank, temp, need_grad):
     n = E * Q
     An = torch.empty((n, Dp), dtype=torch.float32, device=dev)
     invA = torch.empty(n, dtype=torch.float32, device=dev)
+    if NCE_FUSED and D % 4 == 0 and temp >= 0.05 and all(b.is_contiguous() and b.data_ptr() % 16 == 0 for b in banks):
+        # Round 6: the score GEMM with the softmax-CE in its epilogue (include/arco_hip.h, arco_nce_score) - five launches, no score
+        # matrix, no normalised copy of the banks.  (temp < 0.05: exp((cos - 1) / T) may underflow for every negative of a row;
+        # the staged route below shifts by the row's actual maximum)
+        proto = pl.proto.contiguous()
+        nP = int(proto.shape[0])
+        Pn = torch.empty((nP, Dp), dtype=torch.float32, device=dev)
+        M = torch.empty((n, Lp), dtype=torch.int16, device=dev)
+        L.call("arco_nce_prep", L.ptr(A_det), n, L.ptr(proto), nP, D, Dp, EPS, L.ptr(An), L.ptr(invA), L.ptr(Pn), lens_c, E,
+               L.ptr(pl.idx_all), Q, pl.idx_stride, Q, Nn, Lp, L.ptr(M))
+        n_lt = int(L.query("arco_nce_score_ltiles", Lp))
+        Wu = torch.empty((E, Q, Lp), dtype=torch.float32, device=dev)
+        Zp = torch.empty((n, n_lt), dtype=torch.float32, device=dev)
+        Bt = torch.empty((E, Dp, Lp), dtype=torch.float32, device=dev) if need_grad else None
+        L.call("arco_nce_score", L.ptr(An), Dp, D, bank_ptrs, lens_c, E, Lp, Q, L.ptr(M), float(temp), EPS, L.ptr(Wu), L.ptr(Zp), L.ptr(Bt))
+        gpos = torch.empty(n, dtype=torch.float32, device=dev)
+        gscale = torch.empty(n, dtype=torch.float32, device=dev)
+        loss_q = torch.empty(n, dtype=torch.float32, device=dev)
+        loss_acc = torch.empty(1, dtype=torch.float32, device=dev)
+        L.call("arco_nce_finish", L.ptr(An), L.ptr(Pn), prow, E, Q, Dp, L.ptr(Zp), Lp, float(temp), 1.0 / (Q * pl.valid_seg),
+               L.ptr(gpos), L.ptr(gscale), L.ptr(loss_q), L.ptr(loss_acc))
+        dA_all = None
+        if need_grad:
+            splits = max(1, min(16, Lp // 256))
+            ws = torch.empty((E, splits, Q, Dp), dtype=torch.float32, device=dev) if splits > 1 else None
+            G = torch.empty((n, Dp), dtype=torch.float32, device=dev)
+            L.call("arco_gemm_batched", L.ptr(Wu), Lp, Lp, L.ptr(Bt), Dp, L.ptr(G), Dp, Q, E, Q * Lp, Dp * Lp, Q * Dp, splits, L.ptr(ws))
+            dA_all = torch.empty((n, D), dtype=torch.float32, device=dev)
+            L.call("arco_nce_anchor_grad_scaled", L.ptr(G), L.ptr(An), L.ptr(Pn), prow, E, L.ptr(gpos), L.ptr(invA), L.ptr(gscale), Q, D, Dp,
+                   EPS, 1.0 / (Q * pl.valid_seg), L.ptr(dA_all), D)
+        return loss_acc[0], dA_all
     L.call("arco_normalize_rows_pad", L.ptr(A_det), D, n, D, Dp, EPS, L.ptr(An), Dp, L.ptr(invA))
     proto = pl.proto.contiguous()
     Pn = torch.empty((int(proto.shape[0]), Dp), dtype=torch.float32, device=dev)

@@ -34,6 +34,10 @@ _SIGS = {
     "arco_gemm_batched": [_P, _L, _I, _P, _I, _P, _L, _L, _I, _L, _L, _L, _I, _P, _P],
     "arco_nce_fused": [_P, _L, _P, _P, _I, _P, _L, _L, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P],
     "arco_nce_anchor_grad": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _F, _P, _L, _P],
+    "arco_nce_prep": [_P, _L, _P, _L, _I, _I, _F, _P, _P, _P, _P, _I, _P, _L, _L, _I, _I, _L, _P, _P],
+    "arco_nce_score": [_P, _I, _I, _P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _P, _P],
+    "arco_nce_finish": [_P, _P, _P, _I, _I, _I, _P, _L, _F, _F, _P, _P, _P, _P, _P],
+    "arco_nce_anchor_grad_scaled": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _L, _P],
     "arco_anchor_pix": [_P, _L, _P, _I, _P, _L, _I, _P, _P],
     "arco_scatter_add_rows": [_P, _L, _I, _P, _P, _L, _P, _F, _P, _L, _P],
     "arco_sum_scale": [_P, _I, _F, _P, _I, _P],
@@ -136,6 +140,7 @@ _SIGS = {
 _QUERIES = {   # plain host helpers returning sizes
     "arco_proto_ws_floats": ([_L, _I, _I], _L),
     "arco_nce_max_len": ([], _L),
+    "arco_nce_score_ltiles": ([_L], _L),
     "arco_jitter_desc_bytes": ([], _L),
     "arco_conv_mblocks": ([_I, _I, _I, _I, _I, _I, _L, _I], _I),
     "arco_conv_mblocks_mma": ([_I, _I, _I, _I, _I, _I, _L, _I, _I], _I),

@@ -548,24 +548,256 @@ __global__ __launch_bounds__(256) void infonce_anchor_grad_batched_kernel(const 
                                                                          const float* __restrict__ Pn_all, NceTable t,
                                                                          const float* __restrict__ gpos, const float* __restrict__ inv,
                                                                          int Q, long n_rows, int D, int Dp, float eps, float scale,
-                                                                         float* __restrict__ dA, long ldd) {
+                                                                         float* __restrict__ dA, long ldd, const float* __restrict__ gscale = nullptr) {
+  // gscale != null: G holds the UNNORMALISED weighted bank sums of arco_nce_score; row r's softmax normalisation 1 / (T Z) is applied here
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_rows) return;
   const float* Pn = Pn_all + (long)t.prow[r / Q] * Dp;
-  const float gp = gpos[r], iv = inv[r];
+  const float gp = gpos[r], iv = inv[r], gs = gscale ? gscale[r] : 1.0f;
   float dot = 0.f;
   for (int d = lane; d < Dp; d += 64) {
-    const float g = G[r * Dp + d] + gp * Pn[d];
+    const float g = G[r * Dp + d] * gs + gp * Pn[d];
     dot += g * An[r * Dp + d];
   }
   dot = wave_sum(dot);
   const bool clamped = iv >= 1.0f / eps;
   for (int d = lane; d < D; d += 64) {
-    const float g = G[r * Dp + d] + gp * Pn[d];
+    const float g = G[r * Dp + d] * gs + gp * Pn[d];
     const float v = clamped ? g * iv : iv * (g - An[r * Dp + d] * dot);
     dA[r * ldd + d] = v * scale;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: the pixel-feature x memory-bank score as an MFMA GEMM with the temperature-scaled, multiplicity-weighted softmax-CE in
+// its epilogue (loss_helper_3d.py:503-509) - no S[E,Q,Lp] round trip, the bank normalisation folded into the B staging.
+//   arco_nce_prep     one launch: anchors and prototypes normalised (rows of An / Pn, inv norms) and, per (entry, query), the 16-bit
+//                     multiplicity row M[e][q][0..Lp) of its Nn sampled negatives
+//   arco_nce_score    grid (q-tile of 64, bank-row tile of 128, entry): S = An . bank^T on the fp32 matrix cores
+//                     (v_mfma_f32_16x16x4_f32, K chunks of 16 double-buffered in LDS); the B staging accumulates every bank row's
+//                     sum of squares, so the epilogue has 1 / max(||b_l||, eps) without a normalised copy of the bank;
+//                     epilogue: Wu[q][l] = M[q][l] * exp((s - 1) / T) * inv||b_l||  (cosines are <= 1: a fixed shift, no running
+//                     maximum, any summation order) and the partial row sums Zp[row][l-tile] of M * exp((s - 1) / T).
+//                     The q-tile-0 workgroups also write the raw bank transposed (Bt [E][Dp][Lp]) - the operand the anchor-gradient
+//                     GEMM takes - from the chunks they stage anyway.
+//   arco_nce_finish   per row: Z = sum of the partials + exp((pos - 1) / T), loss = log Z - (pos - 1) / T,
+//                     gpos = (exp((pos - 1) / T) / Z - 1) / T, gscale = 1 / (T Z); the step's loss sum (fixed order) in the same launch
+// The anchor gradient is then Gu = Wu . bank (arco_gemm_batched on Bt) and arco_nce_anchor_grad with gscale:
+// G = gscale * Gu + gpos * Pn.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct NceIdx { const int64_t* idx_all; long idx_off, idx_stride; };
+
+__global__ __launch_bounds__(256) void nce_prep_kernel(const float* __restrict__ A, long n_a, const float* __restrict__ P, long n_p, int D, int Dp,
+                                                      float eps, float* __restrict__ An, float* __restrict__ invA, float* __restrict__ Pn,
+                                                      NceTable t, NceIdx ix, int Q, int Nn, long Lp, unsigned short* __restrict__ M) {
+  extern __shared__ uint32_t cnt[];                  // multiplicity blocks: Lp / 2 words
+  const long nrow_blocks = (n_a + n_p + 3) / 4;
+  if ((long)blockIdx.x < nrow_blocks) {              // ---- four rows per block: anchors first, then the prototypes
+    const int lane = threadIdx.x & 63;
+    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n_a + n_p) return;
+    const bool isa = j < n_a;
+    const float* s = isa ? A + j * (long)D : P + (j - n_a) * (long)D;
+    float* y = isa ? An + j * (long)Dp : Pn + (j - n_a) * (long)Dp;
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) { const float v = s[d]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float iv = 1.0f / fmaxf(sqrtf(ss), eps);
+    if (lane == 0 && isa) invA[j] = iv;
+    for (int d = lane; d < Dp; d += 64) y[d] = d < D ? s[d] * iv : 0.f;
+    return;
+  }
+  // ---- one (entry, query) per block: multiplicities of its sampled negatives, 16-bit counters two per word
+  const long r = (long)blockIdx.x - nrow_blocks;
+  const int e = (int)(r / Q), q = (int)(r - (long)e * Q);
+  const long L = t.len[e];
+  for (long k = threadIdx.x; k < Lp / 2; k += 256) cnt[k] = 0u;
+  __syncthreads();
+  const int64_t* idx = ix.idx_all + (long)e * ix.idx_stride + ix.idx_off + (long)q * Nn;
+  for (int i = threadIdx.x; i < Nn; i += 256) {
+    long k = idx[i];
+    if (k < 0) k += L;
+    atomicAdd(&cnt[k >> 1], 1u << (16 * (int)(k & 1)));
+  }
+  __syncthreads();
+  uint32_t* out = reinterpret_cast<uint32_t*>(M + r * Lp);
+  for (long k = threadIdx.x; k < Lp / 2; k += 256) out[k] = cnt[k];
+}
+
+constexpr int NS_BM = 64, NS_BN = 128, NS_KC = 16, NS_LDK = NS_KC + 4;
+__global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict__ An, int Dp, int D, NceTable t, long Lp, int Q,
+                                                       const unsigned short* __restrict__ M, float inv_temp, float eps,
+                                                       float* __restrict__ Wu, float* __restrict__ Zp, int n_ltiles,
+                                                       float* __restrict__ Bt) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (NS_BM + NS_BN) * NS_LDK];
+  __shared__ float ssq[NS_BN][4];
+  __shared__ float invb[NS_BN];
+  __shared__ float zred[2][NS_BM];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;                    // 2 x 2 waves: 32 queries x 64 bank rows each
+  const int e = blockIdx.z, q0 = blockIdx.x * NS_BM, l0 = blockIdx.y * NS_BN;
+  const long L = t.len[e];
+  const float* bank = t.bank[e];
+  constexpr int BUF = (NS_BM + NS_BN) * NS_LDK;
+  // staging geometry: thread -> (row, quad) of the A tile (one piece) and of the B tile (two pieces)
+  const int qd = tid & 3, ar = tid >> 2;                    // A: rows 0..63
+  const long arow = (long)e * Q + q0 + ar;
+  const bool a_ok = q0 + ar < Q;
+  const float* a_src = An + arow * Dp + 4 * qd;
+  const float* b_src[2]; bool b_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long l = l0 + ar + 64 * i;
+    b_ok[i] = l < L;
+    b_src[i] = bank + l * (long)D + 4 * qd;
+  }
+  const int nchunks = Dp / NS_KC;
+  f32x4 ra, rb[2];
+  float ss[2] = {0.f, 0.f};
+  auto load_chunk = [&](int c) {
+    const int k = c * NS_KC + 4 * qd;
+    ra = (a_ok) ? *reinterpret_cast<const f32x4*>(a_src + c * NS_KC) : f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rb[i] = (b_ok[i] && k < D) ? *reinterpret_cast<const f32x4*>(b_src[i] + c * NS_KC) : f32x4{0, 0, 0, 0};
+  };
+  auto store_chunk = [&](float* buf) {
+    *reinterpret_cast<f32x4*>(&buf[ar * NS_LDK + 4 * qd]) = ra;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(&buf[(NS_BM + ar + 64 * i) * NS_LDK + 4 * qd]) = rb[i];
+      ss[i] += (rb[i][0] * rb[i][0] + rb[i][1] * rb[i][1]) + (rb[i][2] * rb[i][2] + rb[i][3] * rb[i][3]);     // the bank row's sum of squares, this quad's share
+    }
+  };
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  auto compute = [&](const float* buf) {
+    const float* As = buf; const float* Bs = buf + NS_BM * NS_LDK;
+    f32x4 af[2], bf[4];
+#pragma unroll
+    for (int at = 0; at < 2; ++at) af[at] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + at) * 16 + li) * NS_LDK + 4 * g]);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bf[ct] = *reinterpret_cast<const f32x4*>(&Bs[((wn * 4 + ct) * 16 + li) * NS_LDK + 4 * g]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int at = 0; at < 2; ++at)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[at][j], bf[ct][j], acc[at][ct], 0, 0, 0);
+  };
+  // the q-tile-0 workgroups write the transposed raw bank from the staged chunk: Bt[e][k][l0 .. l0 + 127] (pad rows / columns zero)
+  const bool write_bt = Bt != nullptr && blockIdx.x == 0;
+  auto emit_bt = [&](const float* buf, int c) {
+    // thread = (k, segment of 8 bank rows); the rows are read in an order rotated by the segment index: with rows 20 dwords apart eight
+    // rows share a bank, and unrotated all 16 segments of a wave instruction would hit it together
+    const float* Bs = buf + NS_BM * NS_LDK;
+    const int k = tid >> 4, sg = tid & 15, seg = sg * 8;
+    float* dst = Bt + ((long)e * Dp + c * NS_KC + k) * Lp + l0 + seg;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int uu = (u + sg) & 7;
+      if (l0 + seg + uu < Lp) dst[uu] = Bs[(seg + uu) * NS_LDK + k];
+    }
+  };
+  load_chunk(0);
+  store_chunk(smem);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    float* cur = smem + (c & 1) * BUF;
+    float* nxt = smem + ((c + 1) & 1) * BUF;
+    const bool more = c + 1 < nchunks;
+    if (more) load_chunk(c + 1);
+    compute(cur);
+    if (write_bt) emit_bt(cur, c);
+    if (more) store_chunk(nxt);
+    __syncthreads();
+  }
+  // bank-row inverse norms: four quad partials per row, summed in a fixed order
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ssq[ar + 64 * i][qd] = ss[i];
+  __syncthreads();
+  if (tid < NS_BN) {
+    const float s2 = (ssq[tid][0] + ssq[tid][1]) + (ssq[tid][2] + ssq[tid][3]);
+    invb[tid] = 1.0f / fmaxf(sqrtf(s2), eps);
+  }
+  __syncthreads();
+  // epilogue: lane (li, g) of tile (at, ct) holds S[q = 4g + r][l = li]
+  float zrow[2][4];
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zrow[at][r] = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int ll = (wn * 4 + ct) * 16 + li;
+    const long l = l0 + ll;
+    const float ib = invb[ll];
+#pragma unroll
+    for (int at = 0; at < 2; ++at)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + (wm * 2 + at) * 16 + 4 * g + r;
+        if (q < Q && l < Lp) {
+          const long row = (long)e * Q + q;
+          const unsigned mk = l < L ? (unsigned)M[row * Lp + l] : 0u;
+          float w = 0.f;
+          if (mk) {
+            const float ex = (float)mk * expf((acc[at][ct][r] * ib - 1.0f) * inv_temp);
+            zrow[at][r] += ex;
+            w = ex * ib;
+          }
+          Wu[row * Lp + l] = w;
+        }
+      }
+  }
+  // partial row sums of this 128-row bank tile: 16 lanes (li) of a row group, then the two wave columns, fixed order
+#pragma unroll
+  for (int at = 0; at < 2; ++at)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = zrow[at][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (li == 0) zred[wn][(wm * 2 + at) * 16 + 4 * g + r] = v;
+    }
+  __syncthreads();
+  if (tid < NS_BM && q0 + tid < Q) Zp[((long)e * Q + q0 + tid) * n_ltiles + blockIdx.y] = zred[0][tid] + zred[1][tid];
+}
+
+__global__ __launch_bounds__(256) void nce_finish_kernel(const float* __restrict__ An, const float* __restrict__ Pn_all, NceTable t, int Q, long n_rows,
+                                                        int Dp, const float* __restrict__ Zp, int n_ltiles, float inv_temp, float scale,
+                                                        float* __restrict__ gpos, float* __restrict__ gscale, float* __restrict__ loss_q,
+                                                        float* __restrict__ loss_sum) {
+  // ONE block: rows strided over the four waves (n_rows = E * Q <= a few thousand), then the fixed-order loss sum
+  __shared__ double part[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (long r = w; r < n_rows; r += 4) {
+    const float* a = An + r * Dp;
+    const float* p = Pn_all + (long)t.prow[r / Q] * Dp;
+    float dp = 0.f;
+    for (int d = lane; d < Dp; d += 64) dp += a[d] * p[d];
+    dp = wave_sum(dp);
+    double z = 0.0;
+    for (int k = lane; k < n_ltiles; k += 64) z += (double)Zp[r * n_ltiles + k];
+    z = wave_sum_d(z);
+    const float epos = expf((dp - 1.0f) * inv_temp);
+    const double tot = z + (double)epos;
+    const float lq = (float)log(tot) - (dp - 1.0f) * inv_temp;
+    if (lane == 0) {
+      loss_q[r] = lq;
+      gpos[r] = ((float)((double)epos / tot) - 1.0f) * inv_temp;
+      gscale[r] = (float)((double)inv_temp / tot);
+    }
+    acc += (double)lq;                   // (every lane holds the same value: no reduction needed)
+  }
+  if (lane == 0) part[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_sum[0] = (float)(((part[0] + part[1]) + (part[2] + part[3])) * (double)scale);
 }
 
 // out[e*Q + q] = lists[k_e][ idx_e[q] ]  (global pixel id of every sampled anchor, entries back to back)
@@ -875,6 +1107,59 @@ int arco_nce_anchor_grad(const float* G, const float* An, const float* Pn_all, c
   const long n = (long)E * Q;
   hipLaunchKernelGGL(infonce_anchor_grad_batched_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), G, An, Pn_all,
                      t, gpos, inv, Q, n, D, Dp, eps, scale, dA, ld_dA);
+  return arco_launch_status();
+}
+// ---- round 6: score GEMM with the softmax-CE in its epilogue (see nce_score_kernel) ---------------------------------------------
+// A [n_a = E*Q][D] sampled anchors, P [n_p][D] prototypes -> An [n_a][Dp], invA [n_a], Pn [n_p][Dp]; M [E*Q][Lp] uint16 multiplicities
+// of each query's Nn sampled negatives (indices as in arco_nce_fused).  Lp % 16 == 0, Lp <= arco_nce_max_len().
+int arco_nce_prep(const float* A, long n_a, const float* P, long n_p, int D, int Dp, float eps, float* An, float* invA, float* Pn,
+                  const int* lens, int E, const int64_t* idx_all, long idx_off, long idx_stride, int Q, int Nn, long Lp, void* M,
+                  void* stream) {
+  NceTable t;
+  ARCO_CHECK_ARG(fill_table(t, nullptr, lens, nullptr, E) == ARCO_OK && A && P && An && invA && Pn && M && idx_all && n_a == (long)E * Q &&
+                 n_p > 0 && D > 0 && Dp >= D && Q > 0 && Nn > 0 && Nn < 65536 && Lp > 0 && (Lp & 15) == 0 && Lp <= arco_nce_max_len());
+  for (int e = 0; e < E; ++e) ARCO_CHECK_ARG(t.len[e] > 0 && t.len[e] <= Lp);
+  const size_t sh = (size_t)Lp * 2;
+  static unsigned long long attr_set = 0;
+  if (sh > 48 * 1024 && arco_first_on_device(attr_set))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nce_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+  const long blocks = (n_a + n_p + 3) / 4 + n_a;
+  NceIdx ix{idx_all, idx_off, idx_stride};
+  hipLaunchKernelGGL(nce_prep_kernel, dim3((unsigned)blocks), dim3(256), sh, as_stream(stream), A, n_a, P, n_p, D, Dp, eps, An, invA, Pn, t, ix,
+                     Q, Nn, Lp, reinterpret_cast<unsigned short*>(M));
+  return arco_launch_status();
+}
+long arco_nce_score_ltiles(long Lp) { return (Lp + NS_BN - 1) / NS_BN; }
+// Wu [E][Q][Lp], Zp [E*Q][arco_nce_score_ltiles(Lp)], Bt [E][Dp][Lp] (nullable: no gradient wanted); banks: raw [len][D] rows, D % 4 == 0
+int arco_nce_score(const float* An, int Dp, int D, const void* const* banks, const int* lens, int E, long Lp, int Q, const void* M,
+                   float temp, float eps, float* Wu, float* Zp, float* Bt, void* stream) {
+  NceTable t;
+  ARCO_CHECK_ARG(fill_table(t, banks, lens, nullptr, E) == ARCO_OK && An && M && Wu && Zp && Q > 0 && D > 0 && (D & 3) == 0 && Dp >= D &&
+                 (Dp & 15) == 0 && Lp > 0 && (Lp & 15) == 0 && temp > 0.f);
+  for (int e = 0; e < E; ++e) ARCO_CHECK_ARG(t.bank[e] && t.len[e] > 0 && t.len[e] <= Lp && (reinterpret_cast<uintptr_t>(t.bank[e]) & 15) == 0);
+  const int n_lt = (int)arco_nce_score_ltiles(Lp);
+  hipLaunchKernelGGL(nce_score_kernel, dim3((unsigned)((Q + NS_BM - 1) / NS_BM), (unsigned)n_lt, (unsigned)E), dim3(256), 0, as_stream(stream),
+                     An, Dp, D, t, Lp, Q, reinterpret_cast<const unsigned short*>(M), 1.0f / temp, eps, Wu, Zp, n_lt, Bt);
+  return arco_launch_status();
+}
+// per row: loss_q, gpos, gscale; loss_sum[0] = scale * sum of loss_q (fixed order)
+int arco_nce_finish(const float* An, const float* Pn_all, const int* prow, int E, int Q, int Dp, const float* Zp, long Lp, float temp,
+                    float scale, float* gpos, float* gscale, float* loss_q, float* loss_sum, void* stream) {
+  NceTable t;
+  ARCO_CHECK_ARG(fill_table(t, nullptr, nullptr, prow, E) == ARCO_OK && An && Pn_all && Zp && gpos && gscale && loss_q && loss_sum && Q > 0 && temp > 0.f);
+  hipLaunchKernelGGL(nce_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), An, Pn_all, t, Q, (long)E * Q, Dp, Zp,
+                     (int)arco_nce_score_ltiles(Lp), 1.0f / temp, scale, gpos, gscale, loss_q, loss_sum);
+  return arco_launch_status();
+}
+// arco_nce_anchor_grad on the unnormalised weighted bank sums of arco_nce_score: G_row = gscale[row] * Gu_row + gpos[row] * Pn
+int arco_nce_anchor_grad_scaled(const float* Gu, const float* An, const float* Pn_all, const int* prow, int E, const float* gpos,
+                                const float* inv, const float* gscale, int Q, int D, int Dp, float eps, float scale, float* dA, long ld_dA,
+                                void* stream) {
+  NceTable t;
+  ARCO_CHECK_ARG(fill_table(t, nullptr, nullptr, prow, E) == ARCO_OK && Q > 0 && D > 0 && Dp >= D && gscale);
+  const long n = (long)E * Q;
+  hipLaunchKernelGGL(infonce_anchor_grad_batched_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), Gu, An, Pn_all,
+                     t, gpos, inv, Q, n, D, Dp, eps, scale, dA, ld_dA, gscale);
   return arco_launch_status();
 }
 // out[e*Q + q] = lists[k[e]][idx_all[e*idx_stride + q]]: pixel ids of the sampled anchors (loss_helper_3d.py:455-457)

@@ -148,7 +148,7 @@ class ArcoStep3D:
         a step later, the memory banks - silently and for good).  All on the device, no host synchronisation in the step:
         `ok` = every V-Net gradient finite (on every rank); non-finite values are replaced by zeros and the V-Net's gradient is multiplied
         by ok, so an overflowed step leaves the V-Net with weight decay and momentum only instead of poisoning the run (the heads' fp32
-        gradients do not pass through the f16 region and are applied).
+        gradients do not pass through the f16 backward; they are guarded behind their all-reduce: _guard_heads_and_publish).
         The flag is copied to pinned memory and read at the START of the next step (long complete by then): an overflow halves
         the loss scale (floor 1), 500 clean steps double it again up to --loss_scale (dynamic loss scaling)."""
         gv = self.optimizer.flat_g[:self.heads_start]
@@ -164,10 +164,22 @@ class ArcoStep3D:
         # finite), and under data parallelism their bucket flat_g[heads_start:] is already inside an asynchronous all-reduce
         # started by dist.mark_heads_done's backward hook - nothing may write it before allreduce_grads has waited.
         gv.mul_(okf)
-        ok = okf > 0
+        return okf > 0
+
+    def _guard_heads_and_publish(self, ok):
+        """Second half of the guard, AFTER allreduce_grads has waited for the heads' bucket: an f16 forward overflow (an inf
+        in a feature-map row or in the loss) makes the heads' fp32 gradients NaN although they never pass through the f16 backward.
+        The reduced bucket is identical on every rank, so every rank takes the same decision without another collective: non-finite
+        values -> zeros, the bucket multiplied by its own finite flag, and the flag folded into the overflow flag that drives the
+        dynamic loss scale (copied to pinned memory, read at the start of the next step)."""
+        gh = self.optimizer.flat_g[self.heads_start:]
+        okh = torch.isfinite(gh).all()
+        torch.nan_to_num_(gh, nan=0.0, posinf=0.0, neginf=0.0)
+        gh.mul_(okh.to(torch.float32))
+        ok = ok.view(1) & okh.view(1)
         if self._ovf_host is None:
             self._ovf_host = torch.ones(1, dtype=torch.bool).pin_memory()
-        self._ovf_host.copy_(ok.view(1), non_blocking=True)
+        self._ovf_host.copy_(ok, non_blocking=True)
         self._ovf_event = torch.cuda.Event()
         self._ovf_event.record()
 
@@ -400,8 +412,10 @@ class ArcoStep3D:
         if zero_path and not first:      # `0 * rep.sum()` (loss_helper.py:588-595): zero gradients for every head parameter
             self.optimizer.touch_from(self.heads_start)
         if ops.ACT_HALF:       # the V-Net's parameter gradients carry the loss scale of the f16 region
-            self._unscale_and_guard()
+            ok_vnet = self._unscale_and_guard()
         adist.allreduce_grads(self.optimizer)
+        if ops.ACT_HALF:
+            self._guard_heads_and_publish(ok_vnet)
         self.optimizer.step()
         self.isd._momentum_update_key_encoder()
         lr_ = a.base_lr * (1.0 - self.iter_num / a.max_iterations) ** 0.9

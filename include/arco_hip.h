@@ -89,6 +89,26 @@ int arco_nce_fused(const float* S, long ld, const int* lens, const int* prow, in
 /* dA[e*Q+q][0..D) = scale * d loss / d anchor through the cosine normalisation, all entries                            */
 int arco_nce_anchor_grad(const float* G, const float* An, const float* Pn_all, const int* prow, int E, const float* gpos,
                          const float* inv, int Q, int D, int Dp, float eps, float scale, float* dA, long ld_dA, void* stream);
+/* ---- L6, round 6: the score GEMM with the temperature-scaled softmax-CE in its EPILOGUE (north_star's wording; loss_helper_3d.py:503-509:
+ *   logits = cat(pos, cosine(anchor, negatives)) / T; F.cross_entropy(logits, 0)) - no score matrix in HBM, the bank normalisation
+ *   folded into the GEMM's B staging.  Five launches replace nine (2 x normalize_rows_pad, nce_normalize_banks, gemm_batched, nce_fused,
+ *   sum_scale | gemm_batched + slab sum, nce_anchor_grad):
+ *   arco_nce_prep    anchors / prototypes normalised (An, invA, Pn) + per (entry, query) the uint16 multiplicity row M[e*Q+q][0..Lp)
+ *   arco_nce_score   S = An . bank^T on the matrix cores per (64 queries, 128 bank rows, entry); the B staging accumulates each bank
+ *                    row's sum of squares; epilogue Wu = M * exp((cos - 1)/T) / ||b||, partial row sums Zp; Bt = the raw bank transposed
+ *   arco_nce_finish  loss_q = log Z - (pos - 1)/T with Z = sum Zp + exp((pos - 1)/T); gpos, gscale = 1/(T Z); the loss sum
+ *   then arco_gemm_batched(Wu, Bt) and arco_nce_anchor_grad_scaled.  Same results as the staged route to fp32 rounding.         */
+int arco_nce_prep(const float* A, long n_a, const float* P, long n_p, int D, int Dp, float eps, float* An, float* invA, float* Pn,
+                  const int* lens, int E, const int64_t* idx_all, long idx_off, long idx_stride, int Q, int Nn, long Lp, void* M,
+                  void* stream);
+long arco_nce_score_ltiles(long Lp);
+int arco_nce_score(const float* An, int Dp, int D, const void* const* banks, const int* lens, int E, long Lp, int Q, const void* M,
+                   float temp, float eps, float* Wu, float* Zp, float* Bt, void* stream);
+int arco_nce_finish(const float* An, const float* Pn_all, const int* prow, int E, int Q, int Dp, const float* Zp, long Lp, float temp,
+                    float scale, float* gpos, float* gscale, float* loss_q, float* loss_sum, void* stream);
+int arco_nce_anchor_grad_scaled(const float* Gu, const float* An, const float* Pn_all, const int* prow, int E, const float* gpos,
+                                const float* inv, const float* gscale, int Q, int D, int Dp, float eps, float scale, float* dA, long ld_dA,
+                                void* stream);
 /* out[e*Q+q] = lists[k[e]][idx_all[e*idx_stride + q]]: pixel id of every sampled anchor (loss_helper_3d.py:455-457)     */
 int arco_anchor_pix(const int32_t* lists, long n_pix, const int* k, int E, const int64_t* idx_all, long idx_stride, int Q,
                     int64_t* out, void* stream);

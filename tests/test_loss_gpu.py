@@ -227,3 +227,42 @@ def test_grouped_infonce_equals_per_class_launches(cfg):
     for b1, b2 in zip(out[True][1], out[False][1]):
         assert torch.equal(b1, b2)
     assert abs(out[True][0][-1][1]) > 1e-3
+
+
+@pytest.mark.parametrize("cfg", [dict(b=2, n_cls=4, feat=64, spatial=(32, 32), Q=64, Nn=32, qs=300),
+                                 dict(b=2, n_cls=4, feat=496, spatial=(64, 64), Q=256, Nn=512, qs=4096),
+                                 dict(b=1, n_cls=19, feat=496, spatial=(32, 48), Q=32, Nn=64, qs=100),
+                                 dict(b=1, n_cls=2, feat=16, spatial=(8, 12, 10), Q=48, Nn=16, qs=40)])
+def test_score_gemm_with_softmax_ce_epilogue_equals_the_staged_route(cfg):
+    """Round 6 (north_star: "contrastive score as an MFMA GEMM with fused temperature-scaled softmax-CE"; loss_helper_3d.py:503-509):
+    arco_nce_prep / arco_nce_score / arco_nce_finish (no score matrix, no normalised bank copy, five launches) against the staged
+    grouped route (normalised banks, score GEMM, arco_nce_fused) on chained steps with growing, ragged banks - incl. the headline's
+    D = 496, 256 x 512 samples, 4096-key queues: loss 2e-6, gradient 1e-4 of its scale, identical banks and sampled indices."""
+    from arco_amd import _contrast as C_
+    from arco_amd.loss_helper_3d import compute_contra_memobank_loss
+    inp = to_dev(fx.loss_inputs(13, b=cfg["b"], n_cls=cfg["n_cls"], feat=cfg["feat"], spatial=cfg["spatial"]))
+    out = {}
+    prev = C_.NCE_FUSED
+    try:
+        for fused in (1, 0):
+            C_.NCE_FUSED = fused
+            bank, ptr, qs = fx.fresh_bank(cfg["n_cls"], cfg["feat"], cfg["qs"], 'zeros')
+            res = []
+            for s in range(4):
+                seed_all(60 + s)
+                r = inp["rep"].clone().requires_grad_(True)
+                nk, loss = compute_contra_memobank_loss(r, inp["label_l"], inp["label_u"], inp["prob_l"], inp["prob_u"], inp["low_mask"],
+                                                        inp["high_mask"], bank, ptr, qs, inp["rep_teacher"], func='smc',
+                                                        num_queries=cfg["Q"], num_negatives=cfg["Nn"], delta_n=0.97)
+                loss.backward()
+                res.append((nk, float(loss.detach()), r.grad.clone()))
+            out[fused] = (res, [b[0].clone() for b in bank])
+    finally:
+        C_.NCE_FUSED = prev
+    for (nk1, l1, g1), (nk2, l2, g2) in zip(out[1][0], out[0][0]):
+        assert nk1 == nk2 and abs(l1 - l2) <= 2e-6 * max(1.0, abs(l2)), (l1, l2)
+        scale = float(g2.abs().max())
+        assert float((g1 - g2).abs().max()) <= 1e-4 * scale, (float((g1 - g2).abs().max()), scale)
+    for b1, b2 in zip(out[1][1], out[0][1]):
+        assert torch.equal(b1, b2)
+    assert abs(out[1][0][-1][1]) > 1e-3

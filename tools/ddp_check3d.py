@@ -33,9 +33,10 @@ def guard():
         if rank == 1:
             g[7] = float("inf")                      # an overflowed V-Net gradient on this rank only
         state["heads_before"] = g[st.heads_start:].clone()       # (snapshot: the bucket may still be reducing - read only)
-    real_guard()
+    ok = real_guard()
     if state["i"] == OVF_STEP:
         state["vnet_after"] = g[:st.heads_start].clone()
+    return ok
 
 
 st._unscale_and_guard = guard
