@@ -451,12 +451,14 @@ def _infonce_grouped(pl, A_all, memobank, temp, need_grad):
         Wu = torch.empty((E, Q, Lp), dtype=torch.float32, device=dev)
         Zp = torch.empty((n, n_lt), dtype=torch.float32, device=dev)
         Bt = torch.empty((E, Dp, Lp), dtype=torch.float32, device=dev) if need_grad else None
-        L.call("arco_nce_score", L.ptr(An), Dp, D, bank_ptrs, lens_c, E, Lp, Q, L.ptr(M), float(temp), EPS, L.ptr(Wu), L.ptr(Zp), L.ptr(Bt))
+        pos = torch.empty(n, dtype=torch.float32, device=dev)
+        L.call("arco_nce_score", L.ptr(An), Dp, D, bank_ptrs, lens_c, prow, E, Lp, Q, L.ptr(M), L.ptr(Pn), float(temp), EPS, L.ptr(Wu),
+               L.ptr(Zp), L.ptr(pos), L.ptr(Bt))
         gpos = torch.empty(n, dtype=torch.float32, device=dev)
         gscale = torch.empty(n, dtype=torch.float32, device=dev)
         loss_q = torch.empty(n, dtype=torch.float32, device=dev)
         loss_acc = torch.empty(1, dtype=torch.float32, device=dev)
-        L.call("arco_nce_finish", L.ptr(An), L.ptr(Pn), prow, E, Q, Dp, L.ptr(Zp), Lp, float(temp), 1.0 / (Q * pl.valid_seg),
+        L.call("arco_nce_finish", L.ptr(pos), n, L.ptr(Zp), Lp, float(temp), 1.0 / (Q * pl.valid_seg),
                L.ptr(gpos), L.ptr(gscale), L.ptr(loss_q), L.ptr(loss_acc))
         dA_all = None
         if need_grad:

@@ -35,8 +35,8 @@ _SIGS = {
     "arco_nce_fused": [_P, _L, _P, _P, _I, _P, _L, _L, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P],
     "arco_nce_anchor_grad": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _F, _P, _L, _P],
     "arco_nce_prep": [_P, _L, _P, _L, _I, _I, _F, _P, _P, _P, _P, _I, _P, _L, _L, _I, _I, _L, _P, _P],
-    "arco_nce_score": [_P, _I, _I, _P, _P, _I, _L, _I, _P, _F, _F, _P, _P, _P, _P],
-    "arco_nce_finish": [_P, _P, _P, _I, _I, _I, _P, _L, _F, _F, _P, _P, _P, _P, _P],
+    "arco_nce_score": [_P, _I, _I, _P, _P, _P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P],
+    "arco_nce_finish": [_P, _L, _P, _L, _F, _F, _P, _P, _P, _P, _P],
     "arco_nce_anchor_grad_scaled": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _F, _P, _L, _P],
     "arco_anchor_pix": [_P, _L, _P, _I, _P, _L, _I, _P, _P],
     "arco_scatter_add_rows": [_P, _L, _I, _P, _P, _L, _P, _F, _P, _L, _P],

@@ -629,11 +629,12 @@ constexpr int NS_BM = 64, NS_BN = 128, NS_KC = 16, NS_LDK = NS_KC + 4;
 __global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict__ An, int Dp, int D, NceTable t, long Lp, int Q,
                                                        const unsigned short* __restrict__ M, float inv_temp, float eps,
                                                        float* __restrict__ Wu, float* __restrict__ Zp, int n_ltiles,
-                                                       float* __restrict__ Bt) {
+                                                       float* __restrict__ Bt, const float* __restrict__ Pn_all, float* __restrict__ pos) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (NS_BM + NS_BN) * NS_LDK];
   __shared__ float ssq[NS_BN][4];
   __shared__ float invb[NS_BN];
   __shared__ float zred[2][NS_BM];
+  __shared__ float pred[NS_BM][4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;                    // 2 x 2 waves: 32 queries x 64 bank rows each
   const int e = blockIdx.z, q0 = blockIdx.x * NS_BM, l0 = blockIdx.y * NS_BN;
@@ -653,20 +654,28 @@ __global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict_
     b_src[i] = bank + l * (long)D + 4 * qd;
   }
   const int nchunks = Dp / NS_KC;
-  f32x4 ra, rb[2];
-  float ss[2] = {0.f, 0.f};
-  auto load_chunk = [&](int c) {
+  f32x4 ra[2], rb[2][2], rp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};      // two register sets: the global loads run TWO chunks ahead of the MFMAs
+  float ss[2] = {0.f, 0.f}, pdot = 0.f;
+  // the bank-tile-0 workgroups also form the positive logits pos[q] = An[q] . Pn[prow] from the anchor chunks they stage
+  const bool want_pos = blockIdx.y == 0;
+  const float* p_src = Pn_all + (long)t.prow[e] * Dp + 4 * qd;
+  auto load_chunk = [&](int c, auto SET_) {
+    constexpr int S = decltype(SET_)::value;
     const int k = c * NS_KC + 4 * qd;
-    ra = (a_ok) ? *reinterpret_cast<const f32x4*>(a_src + c * NS_KC) : f32x4{0, 0, 0, 0};
+    ra[S] = (a_ok) ? *reinterpret_cast<const f32x4*>(a_src + c * NS_KC) : f32x4{0, 0, 0, 0};
+    if (want_pos) rp[S] = *reinterpret_cast<const f32x4*>(p_src + c * NS_KC);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rb[i] = (b_ok[i] && k < D) ? *reinterpret_cast<const f32x4*>(b_src[i] + c * NS_KC) : f32x4{0, 0, 0, 0};
+    for (int i = 0; i < 2; ++i) rb[S][i] = (b_ok[i] && k < D) ? *reinterpret_cast<const f32x4*>(b_src[i] + c * NS_KC) : f32x4{0, 0, 0, 0};
   };
-  auto store_chunk = [&](float* buf) {
-    *reinterpret_cast<f32x4*>(&buf[ar * NS_LDK + 4 * qd]) = ra;
+  auto store_chunk = [&](float* buf, auto SET_) {
+    constexpr int S = decltype(SET_)::value;
+    *reinterpret_cast<f32x4*>(&buf[ar * NS_LDK + 4 * qd]) = ra[S];
+    if (want_pos) pdot += (ra[S][0] * rp[S][0] + ra[S][1] * rp[S][1]) + (ra[S][2] * rp[S][2] + ra[S][3] * rp[S][3]);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<f32x4*>(&buf[(NS_BM + ar + 64 * i) * NS_LDK + 4 * qd]) = rb[i];
-      ss[i] += (rb[i][0] * rb[i][0] + rb[i][1] * rb[i][1]) + (rb[i][2] * rb[i][2] + rb[i][3] * rb[i][3]);     // the bank row's sum of squares, this quad's share
+      const f32x4 v = rb[S][i];
+      *reinterpret_cast<f32x4*>(&buf[(NS_BM + ar + 64 * i) * NS_LDK + 4 * qd]) = v;
+      ss[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);     // the bank row's sum of squares, this quad's share
     }
   };
   f32x4 acc[2][4];
@@ -689,41 +698,55 @@ __global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict_
         for (int ct = 0; ct < 4; ++ct)
           acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[at][j], bf[ct][j], acc[at][ct], 0, 0, 0);
   };
-  // the q-tile-0 workgroups write the transposed raw bank from the staged chunk: Bt[e][k][l0 .. l0 + 127] (pad rows / columns zero)
-  const bool write_bt = Bt != nullptr && blockIdx.x == 0;
+  // The transposed raw bank Bt[e][k][l0 .. l0 + 127] (the anchor-gradient GEMM's operand) is written from the staged chunks, the 16 k of a
+  // chunk dealt in quads over the q-tile workgroups of this bank tile (quad j by workgroup j % gridDim.x): a thread reads the four k of one
+  // bank row with one conflict-free ds_read_b128 and stores them to four Bt rows - 64 consecutive l per wave instruction, 256-byte runs.
+  // (A first version let the q-tile-0 workgroups write everything with 4-byte stores in 32-byte runs: 45 of the kernel's 107 us.)
+  const bool write_bt = Bt != nullptr;
   auto emit_bt = [&](const float* buf, int c) {
-    // thread = (k, segment of 8 bank rows); the rows are read in an order rotated by the segment index: with rows 20 dwords apart eight
-    // rows share a bank, and unrotated all 16 segments of a wave instruction would hit it together
+    if (tid >= NS_BN) return;
     const float* Bs = buf + NS_BM * NS_LDK;
-    const int k = tid >> 4, sg = tid & 15, seg = sg * 8;
-    float* dst = Bt + ((long)e * Dp + c * NS_KC + k) * Lp + l0 + seg;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int uu = (u + sg) & 7;
-      if (l0 + seg + uu < Lp) dst[uu] = Bs[(seg + uu) * NS_LDK + k];
+    for (int j = 0; j < 4; ++j) {
+      if (j % (int)gridDim.x != (int)blockIdx.x) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[tid * NS_LDK + 4 * j]);
+      if (l0 + tid < Lp) {
+        float* dst = Bt + ((long)e * Dp + c * NS_KC + 4 * j) * Lp + l0 + tid;
+        dst[0] = v[0]; dst[Lp] = v[1]; dst[2 * Lp] = v[2]; dst[3 * Lp] = v[3];
+      }
     }
   };
-  load_chunk(0);
-  store_chunk(smem);
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+  load_chunk(0, S0{});
+  if (nchunks > 1) load_chunk(1, S1{});
+  store_chunk(smem, S0{});
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
+  // chunk c is computed from LDS buffer c & 1 while chunk c + 1 (in registers since the previous trip) is written to the other buffer and
+  // the loads of chunk c + 2 are in flight; two chunks per trip keep the register sets compile-time
+  auto trip = [&](int c, auto SETN_) {           // SETN: register set of chunk c + 1 (= (c + 1) & 1); chunk c + 2 reuses chunk c's set
+    constexpr int SN = decltype(SETN_)::value;
     float* cur = smem + (c & 1) * BUF;
     float* nxt = smem + ((c + 1) & 1) * BUF;
-    const bool more = c + 1 < nchunks;
-    if (more) load_chunk(c + 1);
+    if (c + 2 < nchunks) load_chunk(c + 2, std::integral_constant<int, SN ^ 1>{});
     compute(cur);
     if (write_bt) emit_bt(cur, c);
-    if (more) store_chunk(nxt);
+    if (c + 1 < nchunks) store_chunk(nxt, SETN_);
     __syncthreads();
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    trip(c, S1{});
+    if (c + 1 < nchunks) trip(c + 1, S0{});
   }
   // bank-row inverse norms: four quad partials per row, summed in a fixed order
 #pragma unroll
   for (int i = 0; i < 2; ++i) ssq[ar + 64 * i][qd] = ss[i];
+  if (want_pos) pred[ar][qd] = pdot;
   __syncthreads();
   if (tid < NS_BN) {
     const float s2 = (ssq[tid][0] + ssq[tid][1]) + (ssq[tid][2] + ssq[tid][3]);
     invb[tid] = 1.0f / fmaxf(sqrtf(s2), eps);
   }
+  if (want_pos && tid < NS_BM && q0 + tid < Q) pos[(long)e * Q + q0 + tid] = (pred[tid][0] + pred[tid][1]) + (pred[tid][2] + pred[tid][3]);
   __syncthreads();
   // epilogue: lane (li, g) of tile (at, ct) holds S[q = 4g + r][l = li]
   float zrow[2][4];
@@ -768,36 +791,37 @@ __global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict_
   if (tid < NS_BM && q0 + tid < Q) Zp[((long)e * Q + q0 + tid) * n_ltiles + blockIdx.y] = zred[0][tid] + zred[1][tid];
 }
 
-__global__ __launch_bounds__(256) void nce_finish_kernel(const float* __restrict__ An, const float* __restrict__ Pn_all, NceTable t, int Q, long n_rows,
-                                                        int Dp, const float* __restrict__ Zp, int n_ltiles, float inv_temp, float scale,
-                                                        float* __restrict__ gpos, float* __restrict__ gscale, float* __restrict__ loss_q,
-                                                        float* __restrict__ loss_sum) {
-  // ONE block: rows strided over the four waves (n_rows = E * Q <= a few thousand), then the fixed-order loss sum
-  __shared__ double part[4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void nce_finish_kernel(const float* __restrict__ pos, long n_rows, const float* __restrict__ Zp, int n_ltiles,
+                                                         float inv_temp, float scale, float* __restrict__ gpos, float* __restrict__ gscale,
+                                                         float* __restrict__ loss_q, float* __restrict__ loss_sum) {
+  // ONE block, one thread per row (n_rows = E * Q, strided beyond 1024), then the loss sum in a fixed order
+  __shared__ double part[1024];
   double acc = 0.0;
-  for (long r = w; r < n_rows; r += 4) {
-    const float* a = An + r * Dp;
-    const float* p = Pn_all + (long)t.prow[r / Q] * Dp;
-    float dp = 0.f;
-    for (int d = lane; d < Dp; d += 64) dp += a[d] * p[d];
-    dp = wave_sum(dp);
+  for (long r = threadIdx.x; r < n_rows; r += 1024) {
     double z = 0.0;
-    for (int k = lane; k < n_ltiles; k += 64) z += (double)Zp[r * n_ltiles + k];
-    z = wave_sum_d(z);
-    const float epos = expf((dp - 1.0f) * inv_temp);
-    const double tot = z + (double)epos;
-    const float lq = (float)log(tot) - (dp - 1.0f) * inv_temp;
-    if (lane == 0) {
-      loss_q[r] = lq;
-      gpos[r] = ((float)((double)epos / tot) - 1.0f) * inv_temp;
-      gscale[r] = (float)((double)inv_temp / tot);
+    const float* zr = Zp + r * n_ltiles;
+    int k = 0;
+    for (; k + 3 < n_ltiles && ((reinterpret_cast<uintptr_t>(zr) & 15) == 0); k += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(zr + k);
+      z += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
     }
-    acc += (double)lq;                   // (every lane holds the same value: no reduction needed)
+    for (; k < n_ltiles; ++k) z += (double)zr[k];
+    const float dp = pos[r];
+    const float epos = expf((dp - 1.0f) * inv_temp);
+    const float tot = (float)(z + (double)epos);
+    const float lq = logf(tot) - (dp - 1.0f) * inv_temp;
+    loss_q[r] = lq;
+    gpos[r] = (epos / tot - 1.0f) * inv_temp;
+    gscale[r] = inv_temp / tot;
+    acc += (double)lq;
   }
-  if (lane == 0) part[w] = acc;
+  part[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) loss_sum[0] = (float)(((part[0] + part[1]) + (part[2] + part[3])) * (double)scale);
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_sum[0] = (float)(part[0] * (double)scale);
 }
 
 // out[e*Q + q] = lists[k_e][ idx_e[q] ]  (global pixel id of every sampled anchor, entries back to back)
@@ -1130,24 +1154,24 @@ int arco_nce_prep(const float* A, long n_a, const float* P, long n_p, int D, int
   return arco_launch_status();
 }
 long arco_nce_score_ltiles(long Lp) { return (Lp + NS_BN - 1) / NS_BN; }
-// Wu [E][Q][Lp], Zp [E*Q][arco_nce_score_ltiles(Lp)], Bt [E][Dp][Lp] (nullable: no gradient wanted); banks: raw [len][D] rows, D % 4 == 0
-int arco_nce_score(const float* An, int Dp, int D, const void* const* banks, const int* lens, int E, long Lp, int Q, const void* M,
-                   float temp, float eps, float* Wu, float* Zp, float* Bt, void* stream) {
+// Wu [E][Q][Lp], Zp [E*Q][arco_nce_score_ltiles(Lp)], pos [E*Q] (= An . Pn[prow[e]]), Bt [E][Dp][Lp] (nullable: no gradient wanted);
+// banks: raw [len][D] rows, D % 4 == 0
+int arco_nce_score(const float* An, int Dp, int D, const void* const* banks, const int* lens, const int* prow, int E, long Lp, int Q,
+                   const void* M, const float* Pn_all, float temp, float eps, float* Wu, float* Zp, float* pos, float* Bt, void* stream) {
   NceTable t;
-  ARCO_CHECK_ARG(fill_table(t, banks, lens, nullptr, E) == ARCO_OK && An && M && Wu && Zp && Q > 0 && D > 0 && (D & 3) == 0 && Dp >= D &&
+  ARCO_CHECK_ARG(fill_table(t, banks, lens, prow, E) == ARCO_OK && An && M && Wu && Zp && Pn_all && pos && Q > 0 && D > 0 && (D & 3) == 0 && Dp >= D &&
                  (Dp & 15) == 0 && Lp > 0 && (Lp & 15) == 0 && temp > 0.f);
   for (int e = 0; e < E; ++e) ARCO_CHECK_ARG(t.bank[e] && t.len[e] > 0 && t.len[e] <= Lp && (reinterpret_cast<uintptr_t>(t.bank[e]) & 15) == 0);
   const int n_lt = (int)arco_nce_score_ltiles(Lp);
   hipLaunchKernelGGL(nce_score_kernel, dim3((unsigned)((Q + NS_BM - 1) / NS_BM), (unsigned)n_lt, (unsigned)E), dim3(256), 0, as_stream(stream),
-                     An, Dp, D, t, Lp, Q, reinterpret_cast<const unsigned short*>(M), 1.0f / temp, eps, Wu, Zp, n_lt, Bt);
+                     An, Dp, D, t, Lp, Q, reinterpret_cast<const unsigned short*>(M), 1.0f / temp, eps, Wu, Zp, n_lt, Bt, Pn_all, pos);
   return arco_launch_status();
 }
-// per row: loss_q, gpos, gscale; loss_sum[0] = scale * sum of loss_q (fixed order)
-int arco_nce_finish(const float* An, const float* Pn_all, const int* prow, int E, int Q, int Dp, const float* Zp, long Lp, float temp,
-                    float scale, float* gpos, float* gscale, float* loss_q, float* loss_sum, void* stream) {
-  NceTable t;
-  ARCO_CHECK_ARG(fill_table(t, nullptr, nullptr, prow, E) == ARCO_OK && An && Pn_all && Zp && gpos && gscale && loss_q && loss_sum && Q > 0 && temp > 0.f);
-  hipLaunchKernelGGL(nce_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), An, Pn_all, t, Q, (long)E * Q, Dp, Zp,
+// per row (pos, Zp from arco_nce_score): loss_q, gpos, gscale; loss_sum[0] = scale * sum of loss_q (fixed order)
+int arco_nce_finish(const float* pos, long n_rows, const float* Zp, long Lp, float temp, float scale, float* gpos, float* gscale,
+                    float* loss_q, float* loss_sum, void* stream) {
+  ARCO_CHECK_ARG(pos && Zp && gpos && gscale && loss_q && loss_sum && n_rows > 0 && temp > 0.f);
+  hipLaunchKernelGGL(nce_finish_kernel, dim3(1), dim3(1024), 0, as_stream(stream), pos, n_rows, Zp,
                      (int)arco_nce_score_ltiles(Lp), 1.0f / temp, scale, gpos, gscale, loss_q, loss_sum);
   return arco_launch_status();
 }

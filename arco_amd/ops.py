@@ -504,6 +504,8 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
         cfg = _cfg_cache.get(key)
         if cfg is None:        # kernel instantiation id + 1e8 * matrix-core mode
             cfg = _cfg_cache[key] = L.query("arco_conv_config_mma", *key) + 100000000 * mma
+        if pro is not None:
+            cfg += 50000000          # the PRO instantiation (consumer-side activation in the loader) is a kernel of its own in the records
         rec = PROFILE.setdefault(cfg, {"n": 0, "flop": 0.0, "timed": []})
         rec["n"] += 1
         rec["flop"] += 2.0 * taps * nb * d3 * h * w * n * k
@@ -1642,6 +1644,19 @@ class BoundaryTensor(torch.Tensor):
             if kw or (len(shape) == 1 and isinstance(shape[0], torch.dtype)):
                 raise
             return self.reshape(*shape)
+
+    # The subclass survives only the operations that hand the SAME channels-last map on (batch slicing / indexing, detach, narrow):
+    # everything else returns plain tensors, so the Python-level dispatch below is paid by the first operation on a boundary
+    # output and not by the whole graph behind it (a reference-style user's step runs hundreds of torch ops downstream)
+    _KEEP = frozenset(("__getitem__", "detach", "narrow", "requires_grad_", "contiguous"))
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **(kwargs or {}))
+        if getattr(func, "__name__", "") in cls._KEEP and type(out) is torch.Tensor and out.dim() >= 3:
+            return out.as_subclass(cls)
+        return out
 
 
 def boundary(t):

@@ -211,6 +211,8 @@ def _kernel_name(key):
     if isinstance(key, tuple):
         return f"wgrad<taps={key[1]},co={key[2]},ci={key[3]}> (weight gradient, fp32 MFMA 16x16x4)"
     mma, key = key // 100000000, key % 100000000
+    if key >= 50000000:          # ops.conv_raw: the PRO instantiation of the pipelined 3x3 kernels
+        return _kernel_name(mma * 100000000 + key - 50000000).replace("> (", ",PRO> (consumer-side BatchNorm + LeakyReLU + dropout of the producing layer applied in the loader; ", 1)
     if mma == 4 and key // 1000000 == 27:
         return "conv3d_image_kernel<3> (one-channel fp32 volume -> 16 channels, f16 output; the 27 taps are the reduction dimension)"
     if mma == 4 and 9400000 <= key < 9500000:
@@ -247,7 +249,7 @@ def roofline_from_profile(prof, n_steps, step_ms):
     prof = {c: v for c, v in prof.items() if c != "__work__"}
     avg = {c: sum(s_.elapsed_time(e_) for s_, e_, _, _ in v["timed"]) / max(1, len(v["timed"])) for c, v in prof.items()}
     tot = {c: avg[c] * v["n"] for c, v in prof.items()}
-    is3 = lambda c: (not isinstance(c, tuple)) and c % 100000000 // 1000000 == 9
+    is3 = lambda c: (not isinstance(c, tuple)) and c % 50000000 // 1000000 == 9
     cand = {c: t for c, t in tot.items() if is3(c)} or tot
     cfg = max(cand, key=cand.get)
     rec = prof[cfg]

@@ -95,17 +95,18 @@ int arco_nce_anchor_grad(const float* G, const float* An, const float* Pn_all, c
  *   sum_scale | gemm_batched + slab sum, nce_anchor_grad):
  *   arco_nce_prep    anchors / prototypes normalised (An, invA, Pn) + per (entry, query) the uint16 multiplicity row M[e*Q+q][0..Lp)
  *   arco_nce_score   S = An . bank^T on the matrix cores per (64 queries, 128 bank rows, entry); the B staging accumulates each bank
- *                    row's sum of squares; epilogue Wu = M * exp((cos - 1)/T) / ||b||, partial row sums Zp; Bt = the raw bank transposed
+ *                    row's sum of squares; epilogue Wu = M * exp((cos - 1)/T) / ||b||, partial row sums Zp; pos = An . Pn[prow];
+ *                    Bt = the raw bank transposed (the operand of the anchor-gradient GEMM)
  *   arco_nce_finish  loss_q = log Z - (pos - 1)/T with Z = sum Zp + exp((pos - 1)/T); gpos, gscale = 1/(T Z); the loss sum
  *   then arco_gemm_batched(Wu, Bt) and arco_nce_anchor_grad_scaled.  Same results as the staged route to fp32 rounding.         */
 int arco_nce_prep(const float* A, long n_a, const float* P, long n_p, int D, int Dp, float eps, float* An, float* invA, float* Pn,
                   const int* lens, int E, const int64_t* idx_all, long idx_off, long idx_stride, int Q, int Nn, long Lp, void* M,
                   void* stream);
 long arco_nce_score_ltiles(long Lp);
-int arco_nce_score(const float* An, int Dp, int D, const void* const* banks, const int* lens, int E, long Lp, int Q, const void* M,
-                   float temp, float eps, float* Wu, float* Zp, float* Bt, void* stream);
-int arco_nce_finish(const float* An, const float* Pn_all, const int* prow, int E, int Q, int Dp, const float* Zp, long Lp, float temp,
-                    float scale, float* gpos, float* gscale, float* loss_q, float* loss_sum, void* stream);
+int arco_nce_score(const float* An, int Dp, int D, const void* const* banks, const int* lens, const int* prow, int E, long Lp, int Q,
+                   const void* M, const float* Pn_all, float temp, float eps, float* Wu, float* Zp, float* pos, float* Bt, void* stream);
+int arco_nce_finish(const float* pos, long n_rows, const float* Zp, long Lp, float temp, float scale, float* gpos, float* gscale,
+                    float* loss_q, float* loss_sum, void* stream);
 int arco_nce_anchor_grad_scaled(const float* Gu, const float* An, const float* Pn_all, const int* prow, int E, const float* gpos,
                                 const float* inv, const float* gscale, int Q, int D, int Dp, float eps, float scale, float* dA, long ld_dA,
                                 void* stream);
