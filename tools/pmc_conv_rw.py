@@ -17,3 +17,18 @@ for nb, ci, co, s in [(16, 16, 16, 256), (16, 32, 16, 256), (16, 16, 4, 256), (1
         xr, ld = ops.rows_view(x)
         ops.conv_raw(xr, ld, ci, wp, co, nb, s, s, 9, stats=True, stat_groups=2 if nb == 16 else 1)
 torch.cuda.synchronize()
+# round 6: the PRO instantiation (consumer-side BatchNorm + LeakyReLU + dropout of the producing layer in the loader): same launch
+# classes, input = the producing layer's pre-activation; 16->16 with dropout 0.05 (encoder in_conv), 32->16 without (decoder up4)
+for nb, ci, co, s, p in [(16, 16, 16, 256, 0.05), (16, 32, 16, 256, 0.0)]:
+    w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
+    wp = ops.pack_weight(w, 9, 0)
+    mean, istd = torch.randn(2 * ci, device="cuda") * 0.1, torch.rand(2 * ci, device="cuda") + 0.5
+    gamma, beta = torch.randn(ci, device="cuda"), torch.randn(ci, device="cuda") * 0.1
+    xs = [torch.randn(nb, s, s, ci, device="cuda").permute(0, 3, 1, 2) for _ in range(5)]
+    assert ops.pro_ok(9, nb, 1, s, s, ci, co, ci, 2)
+    for x in xs:
+        big.add_(1.0)
+        xr, ld = ops.rows_view(x)
+        pro = L.act_pro(mean, istd, gamma, beta, 0.01, 2, 1 if p > 0 else 0, p, 12345, None)
+        ops.conv_raw(xr, ld, ci, wp, co, nb, s, s, 9, stats=True, stat_groups=2, pro=pro)
+torch.cuda.synchronize()
