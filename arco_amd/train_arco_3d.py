@@ -45,7 +45,7 @@ def build_parser():
     p.add_argument('--act_dtype', type=str, default='f32', choices=['f32', 'f16'],
                    help="f16: the V-Net's activations and activation gradients are stored as f16 (BASELINE configs[4], 'fp16 MFMA "
                         "conv'): f16 matrix cores with fp32 accumulation, fp32 weights / BatchNorm statistics / loss / optimizer; "
-                        "heads and losses stay fp32 (--conv_mma applies to them)")
+                        "the heads keep fp32 tensors, their GEMM operands follow --head_mma")
     p.add_argument('--head_mma', type=str, default='auto', choices=['auto', 'f32x3', 'f16', 'bf16'],
                    help="matrix-core operands of the heads' GEMMs (FeatureExtractor_3d, q_representation, the row-sparse heads).  auto: f16 "
                         "with --act_dtype f16 (BASELINE configs[4] 'fp16 MFMA conv + contrastive': operands rounded to f16 in registers, "
