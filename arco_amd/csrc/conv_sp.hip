@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
     // a chunk lasts ~2 us, less than an HBM miss under load.
     f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
     // consumer-side activation (see conv3x3_rw_kernel): four parameter quads per chunk behind its activation loads, NL loads per chunk
-    f32x4 rp[2][4]; unsigned ebase2[2] = {0, 0};
+    f32x4 rp[2][4]; unsigned ebase2[2] = {0, 0}; bool bord2[2] = {true, true};
     const float* const pm_ = PRO ? uniform_ptr(a.pro.mean) : nullptr; const float* const pi_ = PRO ? uniform_ptr(a.pro.istd) : nullptr;
     const float* const pg_ = PRO ? uniform_ptr(a.pro.gamma) : nullptr; const float* const pb_ = PRO ? uniform_ptr(a.pro.beta) : nullptr;
     const bool pdrop = PRO && a.pro.drop_mode == 1;
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
       const unsigned okm = m_valid & ~bad;
       okm2[set] = okm;
       const bool border = !real || d.y0 == 0 || d.y0 + TH == a.H || d.x0 == 0 || d.x0 + 16 == a.W;     // wave-uniform: NA loads per wave either way
+      if constexpr (PRO) bord2[set] = border;
       if (!border) {
 #pragma unroll
         for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(voff[it]), "s"(gbase) : "memory");
@@ -226,8 +227,10 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
       if constexpr (PRO) {
         v = pro_bn_lrelu(v, ProQuad{rp[set][0], rp[set][1], rp[set][2], rp[set][3]}, a.pro.slope);
         if (pdrop) v = pro_dropout(v, dkey, ebase2[set] + (unsigned)poff[it] * (unsigned)a.K, dthr, keep_scale);
+        if (bord2[set]) v = pro_mask(v, okm2[set] >> it);       // (interior tiles: every staged piece is inside the image - wave-uniform)
+      } else {
+        v = ((okm2[set] >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
       }
-      v = ((okm2[set] >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
       u32x2 p0, p1, p2;
       split3_bf16x4(v, p0, p1, p2);
       if (ldsA[it] >= 0) {
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
     f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
     // consumer-side activation: the four parameter quads of the chunk's channels travel with its activation loads (same asm
     // loads, same vmcnt accounting: NL instructions per chunk), the element index base of the dropout mask with the register set
-    f32x4 rp[2][4]; unsigned ebase2[2] = {0, 0};
+    f32x4 rp[2][4]; unsigned ebase2[2] = {0, 0}; bool bord2[2] = {true, true};
     const float* const pm_ = PRO ? uniform_ptr(a.pro.mean) : nullptr; const float* const pi_ = PRO ? uniform_ptr(a.pro.istd) : nullptr;
     const float* const pg_ = PRO ? uniform_ptr(a.pro.gamma) : nullptr; const float* const pb_ = PRO ? uniform_ptr(a.pro.beta) : nullptr;
     const bool pdrop = PRO && a.pro.drop_mode == 1;
@@ -558,6 +561,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
       okm2[set] = m_valid & ~bad;
       // WAVE-UNIFORM choice (every wave must issue exactly NA load instructions: the vmcnt waits count them)
       const bool border = !real || d.y0 == 0 || d.y0 + TH == a.H || d.x0 == 0 || d.x0 + 16 == a.W || d.c * 16 + 16 > a.K;
+      if constexpr (PRO) bord2[set] = border;
 #ifdef RW_NO_LOAD          // (timing-only ablation builds, tools/debug/rw_abl.sh: never in the shipped library)
       if (true) { (void)gbase; } else
 #endif
@@ -599,8 +603,10 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
         if constexpr (PRO) {
           v = pro_bn_lrelu(v, pq, a.pro.slope);
           if (pdrop) v = pro_dropout(v, dkey, ebase2[set] + (unsigned)poff[it] * (unsigned)a.K, dthr, keep_scale);
+          if (bord2[set]) v = pro_mask(v, okm >> it);        // (interior tiles: every staged piece is inside the image - wave-uniform)
+        } else {
+          v = ((okm >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
         }
-        v = ((okm >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
         u32x2 p0, p1, p2;
 #ifdef RW_NO_SPLIT
         p0 = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}; p1 = u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])}; p2 = p0;

@@ -51,6 +51,16 @@ __device__ __forceinline__ f32x4 pro_bn_lrelu(f32x4 z, const ProQuad& q, float s
   }
   return y;
 }
+// v where keep != 0, +0.0 elsewhere - as a bitwise AND with an all-ones / all-zeros word.  Written `keep ? v : 0` behind the prologue
+// arithmetic, hipcc sinks that arithmetic into per-element branches (wgrad_split_kernel<16,16,PRO>: 111 us against 72 us for either
+// the arithmetic or the select alone, tools/micro/wgrad_pro_bench.py); the AND keeps the loader straight-line
+__device__ __forceinline__ f32x4 pro_mask(f32x4 v, unsigned keep) {
+  // (whole-vector bit casts: `__builtin_bit_cast(unsigned, v[e])` on a vector ELEMENT reads element 0 for every e with this clang)
+  typedef unsigned int pm_u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned m = 0u - (keep & 1u);
+  const pm_u32x4 u = __builtin_bit_cast(pm_u32x4, v) & pm_u32x4{m, m, m, m};
+  return __builtin_bit_cast(f32x4, u);
+}
 // nn.Dropout on the quad at element index e0 .. e0 + 3 (element = pixel * C + channel, as bn_act_fwd_kernel counts)
 __device__ __forceinline__ f32x4 pro_dropout(f32x4 y, uint32_t key, uint32_t e0, uint32_t thr, float keep_scale) {
   bool keep[4];
