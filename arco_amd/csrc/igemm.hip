@@ -1482,10 +1482,10 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
   f32x4 pz[NZU][4], px_[NXU][4];
-  // consumer-side activation of the input operand (PRO): validity bits and pixel origin of the fetched tile, the parameter quads of
+  // consumer-side activation of the input operand (PRO): pixel origin of the fetched tile, the parameter quads of
   // this thread's channels for the BatchNorm group of the tile being staged (reloaded when the group changes: at most once per launch
   // and workgroup - tiles are walked in image order)
-  unsigned xok = 0; int f_img = 0, f_y0 = 0, f_x0 = 0, pgrp = -1;
+  int f_img = 0, f_y0 = 0, f_x0 = 0, pgrp = -1;
   ProQuad pq[NXU];
   const int ipg = PRO ? a.NB / (a.pro.groups > 1 ? a.pro.groups : 1) : 1;
   const bool pdrop = PRO && a.pro.drop_mode == 1;
@@ -1497,7 +1497,7 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
   auto fetch = [&](int t) {
     int tt = t; const int tx = tt % tiles_x; tt /= tiles_x; const int ty = tt % tiles_y; const int img = tt / tiles_y;
     const int y0 = ty * 8, x0 = tx * 16;
-    if (PRO) { f_img = img; f_y0 = y0; f_x0 = x0; xok = 0; }
+    if (PRO) { f_img = img; f_y0 = y0; f_x0 = x0; }
     const int pl = a.taps == 27 ? img % a.D3 + dpl : 0;
     const bool plane_ok = pl >= 0 && pl < a.D3;
 #pragma unroll
@@ -1522,7 +1522,6 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
         f32x4 v = f32x4{0, 0, 0, 0};
         if (u < XU && y >= 0 && y < a.H && x >= 0 && x < a.W && plane_ok && c < a.Cin) {
           v = *reinterpret_cast<const f32x4*>(a.Ain + (((long)(img + dpl) * a.H + y) * a.W + x) * a.lda + c);
-          if (PRO) xok |= 1u << (i * 4 + j);
         }
         px_[i][j] = v;
       }
@@ -1585,11 +1584,14 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
         for (int i = 0; i < NXU; ++i) {
           const int u = tid + i * 256, pg = u / QA, q = u % QA, hr = pg / 5, hg = pg % 5;
           const uint32_t e0 = (uint32_t)(((f_img * a.H + f_y0 + hr - 1) * a.W + f_x0 - 1 + 4 * hg) * a.Cin + ci0 + 4 * q);
+          const int y = f_y0 + hr - 1;
+          const bool rok = u < XU && y >= 0 && y < a.H && ci0 + 4 * q < a.Cin;      // (validity recomputed here, on border tiles only: no mask carried from fetch)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
+            const int x = f_x0 - 1 + 4 * hg + j;
             f32x4 v = pro_bn_lrelu(px_[i][j], pq[i], a.pro.slope);
             if (pdrop) v = pro_dropout(v, dkey, e0 + (uint32_t)(j * a.Cin), dthr, keep_scale);
-            px_[i][j] = pro_mask(v, xok >> (i * 4 + j));
+            px_[i][j] = pro_mask(v, (rok && x >= 0 && x < a.W) ? 1u : 0u);
           }
         }
       }

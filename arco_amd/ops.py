@@ -657,6 +657,32 @@ SPARSE_BWD_MAX_FRAC = 0.125
 sparse_bwd_stats = {"sparse": 0, "dense": 0}      # how often each route was taken (tests, bench)
 
 
+# A layer whose incoming gradient keeps turning out DENSE stops paying for the probe (one pass over dy + one host synchronisation per
+# backward): after SPARSE_BWD_GIVE_UP dense verdicts in a row the probe is skipped for SPARSE_BWD_RETRY backward calls of that
+# weight, then tried again.  The verdict lives on the weight tensor object.
+SPARSE_BWD_GIVE_UP, SPARSE_BWD_RETRY = 3, 64
+
+
+def _sparse_probe_due(weight):
+    st = getattr(weight, "_arco_sparse_probe", None)
+    if st is None or st[1] <= 0:
+        return True
+    st[1] -= 1
+    return False
+
+
+def _sparse_probe_result(weight, was_sparse):
+    try:
+        st = getattr(weight, "_arco_sparse_probe", None)
+        if st is None:
+            st = weight._arco_sparse_probe = [0, 0]          # [dense verdicts in a row, backward calls to skip]
+        st[0] = 0 if was_sparse else st[0] + 1
+        if st[0] >= SPARSE_BWD_GIVE_UP:
+            st[0], st[1] = 0, SPARSE_BWD_RETRY
+    except AttributeError:
+        pass
+
+
 def _conv1x1_backward_on_nonzero_rows(ctx, dy, dyr, ldy, co, xr, ldx, ci, x, weight):
     M = int(dyr.shape[0])
     dev = dyr.device
@@ -727,8 +753,9 @@ class ConvFn(torch.autograd.Function):
         ci = int(x.shape[1])
         dx = dw = db = None
         if taps == 1 and SPARSE_BWD and nv * d3 * h * w >= SPARSE_BWD_MIN_ROWS and co >= SPARSE_BWD_MIN_CH and ci >= SPARSE_BWD_MIN_CH and not _is_half(dy) \
-                and xr.dtype == torch.float32 and not torch.cuda.is_current_stream_capturing():
+                and xr.dtype == torch.float32 and not torch.cuda.is_current_stream_capturing() and _sparse_probe_due(weight):
             r = _conv1x1_backward_on_nonzero_rows(ctx, dy, dyr, ldy, co, xr, ldx, ci, x, weight)
+            _sparse_probe_result(weight, r is not None)
             if r is not None:
                 return r
         if ctx.needs_input_grad[1]:      # first: it forks to the side stream and runs beside the data gradient
