@@ -625,56 +625,72 @@ __global__ __launch_bounds__(256) void nce_prep_kernel(const float* __restrict__
   for (long k = threadIdx.x; k < Lp / 2; k += 256) out[k] = cnt[k];
 }
 
-constexpr int NS_BM = 64, NS_BN = 128, NS_KC = 16, NS_LDK = NS_KC + 4;
+constexpr int NS_BM = 64, NS_BN = 128, NS_KC = 16, NS_LDK = NS_KC + 4;      // (NS_KC = 32 measured: 80 vs 77 us - the chunk depth is not what bounds the kernel)
+constexpr int NS_Q = NS_KC / 4;                       // 16-byte pieces per staged row and chunk
+constexpr int NS_RPT = 256 / NS_Q;                    // rows covered by one sweep of the 256 staging threads
+constexpr int NS_NA = NS_BM / NS_RPT, NS_NB = NS_BN / NS_RPT;
 __global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict__ An, int Dp, int D, NceTable t, long Lp, int Q,
                                                        const unsigned short* __restrict__ M, float inv_temp, float eps,
                                                        float* __restrict__ Wu, float* __restrict__ Zp, int n_ltiles,
                                                        float* __restrict__ Bt, const float* __restrict__ Pn_all, float* __restrict__ pos) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (NS_BM + NS_BN) * NS_LDK];
-  __shared__ float ssq[NS_BN][4];
+  __shared__ float ssq[NS_BN][NS_Q];
   __shared__ float invb[NS_BN];
   __shared__ float zred[2][NS_BM];
-  __shared__ float pred[NS_BM][4];
+  __shared__ float pred[NS_BM][NS_Q];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;                    // 2 x 2 waves: 32 queries x 64 bank rows each
   const int e = blockIdx.z, q0 = blockIdx.x * NS_BM, l0 = blockIdx.y * NS_BN;
   const long L = t.len[e];
   const float* bank = t.bank[e];
   constexpr int BUF = (NS_BM + NS_BN) * NS_LDK;
-  // staging geometry: thread -> (row, quad) of the A tile (one piece) and of the B tile (two pieces)
-  const int qd = tid & 3, ar = tid >> 2;                    // A: rows 0..63
-  const long arow = (long)e * Q + q0 + ar;
-  const bool a_ok = q0 + ar < Q;
-  const float* a_src = An + arow * Dp + 4 * qd;
-  const float* b_src[2]; bool b_ok[2];
+  // staging geometry: thread -> (row, quad); NS_NA pieces of the A tile and NS_NB of the B tile per chunk
+  const int qd = tid % NS_Q, ar = tid / NS_Q;
+  const float* a_src[NS_NA]; bool a_ok[NS_NA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const long l = l0 + ar + 64 * i;
+  for (int i = 0; i < NS_NA; ++i) {
+    const int r = ar + NS_RPT * i;
+    a_ok[i] = q0 + r < Q;
+    a_src[i] = An + ((long)e * Q + q0 + r) * Dp + 4 * qd;
+  }
+  const float* b_src[NS_NB]; bool b_ok[NS_NB];
+#pragma unroll
+  for (int i = 0; i < NS_NB; ++i) {
+    const long l = l0 + ar + NS_RPT * i;
     b_ok[i] = l < L;
     b_src[i] = bank + l * (long)D + 4 * qd;
   }
-  const int nchunks = Dp / NS_KC;
-  f32x4 ra[2], rb[2][2], rp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};      // two register sets: the global loads run TWO chunks ahead of the MFMAs
-  float ss[2] = {0.f, 0.f}, pdot = 0.f;
+  const int nchunks = (Dp + NS_KC - 1) / NS_KC;
+  f32x4 ra[2][NS_NA], rb[2][NS_NB], rp[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};      // two register sets: the global loads run TWO chunks ahead of the MFMAs
+  float ss[NS_NB], pdot[NS_NA];
+#pragma unroll
+  for (int i = 0; i < NS_NB; ++i) ss[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NS_NA; ++i) pdot[i] = 0.f;
   // the bank-tile-0 workgroups also form the positive logits pos[q] = An[q] . Pn[prow] from the anchor chunks they stage
   const bool want_pos = blockIdx.y == 0;
   const float* p_src = Pn_all + (long)t.prow[e] * Dp + 4 * qd;
   auto load_chunk = [&](int c, auto SET_) {
     constexpr int S = decltype(SET_)::value;
     const int k = c * NS_KC + 4 * qd;
-    ra[S] = (a_ok) ? *reinterpret_cast<const f32x4*>(a_src + c * NS_KC) : f32x4{0, 0, 0, 0};
-    if (want_pos) rp[S] = *reinterpret_cast<const f32x4*>(p_src + c * NS_KC);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rb[S][i] = (b_ok[i] && k < D) ? *reinterpret_cast<const f32x4*>(b_src[i] + c * NS_KC) : f32x4{0, 0, 0, 0};
+    for (int i = 0; i < NS_NA; ++i) ra[S][i] = (a_ok[i] && k < Dp) ? *reinterpret_cast<const f32x4*>(a_src[i] + c * NS_KC) : f32x4{0, 0, 0, 0};
+    if (want_pos) rp[S] = k < Dp ? *reinterpret_cast<const f32x4*>(p_src + c * NS_KC) : f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NS_NB; ++i) rb[S][i] = (b_ok[i] && k < D) ? *reinterpret_cast<const f32x4*>(b_src[i] + c * NS_KC) : f32x4{0, 0, 0, 0};
   };
   auto store_chunk = [&](float* buf, auto SET_) {
     constexpr int S = decltype(SET_)::value;
-    *reinterpret_cast<f32x4*>(&buf[ar * NS_LDK + 4 * qd]) = ra[S];
-    if (want_pos) pdot += (ra[S][0] * rp[S][0] + ra[S][1] * rp[S][1]) + (ra[S][2] * rp[S][2] + ra[S][3] * rp[S][3]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NS_NA; ++i) {
+      const f32x4 v = ra[S][i];
+      *reinterpret_cast<f32x4*>(&buf[(ar + NS_RPT * i) * NS_LDK + 4 * qd]) = v;
+      if (want_pos) pdot[i] += (v[0] * rp[S][0] + v[1] * rp[S][1]) + (v[2] * rp[S][2] + v[3] * rp[S][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < NS_NB; ++i) {
       const f32x4 v = rb[S][i];
-      *reinterpret_cast<f32x4*>(&buf[(NS_BM + ar + 64 * i) * NS_LDK + 4 * qd]) = v;
+      *reinterpret_cast<f32x4*>(&buf[(NS_BM + ar + NS_RPT * i) * NS_LDK + 4 * qd]) = v;
       ss[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);     // the bank row's sum of squares, this quad's share
     }
   };
@@ -685,21 +701,24 @@ __global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
   auto compute = [&](const float* buf) {
     const float* As = buf; const float* Bs = buf + NS_BM * NS_LDK;
-    f32x4 af[2], bf[4];
 #pragma unroll
-    for (int at = 0; at < 2; ++at) af[at] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + at) * 16 + li) * NS_LDK + 4 * g]);
+    for (int kk = 0; kk < NS_KC / 16; ++kk) {
+      f32x4 af[2], bf[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bf[ct] = *reinterpret_cast<const f32x4*>(&Bs[((wn * 4 + ct) * 16 + li) * NS_LDK + 4 * g]);
+      for (int at = 0; at < 2; ++at) af[at] = *reinterpret_cast<const f32x4*>(&As[((wm * 2 + at) * 16 + li) * NS_LDK + kk * 16 + 4 * g]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int ct = 0; ct < 4; ++ct) bf[ct] = *reinterpret_cast<const f32x4*>(&Bs[((wn * 4 + ct) * 16 + li) * NS_LDK + kk * 16 + 4 * g]);
 #pragma unroll
-      for (int at = 0; at < 2; ++at)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[at][j], bf[ct][j], acc[at][ct], 0, 0, 0);
+        for (int at = 0; at < 2; ++at)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[at][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[at][j], bf[ct][j], acc[at][ct], 0, 0, 0);
+    }
   };
-  // The transposed raw bank Bt[e][k][l0 .. l0 + 127] (the anchor-gradient GEMM's operand) is written from the staged chunks, the 16 k of a
-  // chunk dealt in quads over the q-tile workgroups of this bank tile (quad j by workgroup j % gridDim.x): a thread reads the four k of one
+  // The transposed raw bank Bt[e][k][l0 .. l0 + 127] (the anchor-gradient GEMM's operand) is written from the staged chunks, the k quads of a
+  // chunk dealt over the q-tile workgroups of this bank tile (quad j by workgroup j % gridDim.x): a thread reads the four k of one
   // bank row with one conflict-free ds_read_b128 and stores them to four Bt rows - 64 consecutive l per wave instruction, 256-byte runs.
   // (A first version let the q-tile-0 workgroups write everything with 4-byte stores in 32-byte runs: 45 of the kernel's 107 us.)
   const bool write_bt = Bt != nullptr;
@@ -707,11 +726,13 @@ __global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict_
     if (tid >= NS_BN) return;
     const float* Bs = buf + NS_BM * NS_LDK;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NS_Q; ++j) {
       if (j % (int)gridDim.x != (int)blockIdx.x) continue;
+      const int k = c * NS_KC + 4 * j;
+      if (k >= Dp) continue;
       const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[tid * NS_LDK + 4 * j]);
       if (l0 + tid < Lp) {
-        float* dst = Bt + ((long)e * Dp + c * NS_KC + 4 * j) * Lp + l0 + tid;
+        float* dst = Bt + ((long)e * Dp + k) * Lp + l0 + tid;
         dst[0] = v[0]; dst[Lp] = v[1]; dst[2 * Lp] = v[2]; dst[3 * Lp] = v[3];
       }
     }
@@ -737,16 +758,26 @@ __global__ __launch_bounds__(256) void nce_score_kernel(const float* __restrict_
     trip(c, S1{});
     if (c + 1 < nchunks) trip(c + 1, S0{});
   }
-  // bank-row inverse norms: four quad partials per row, summed in a fixed order
+  // bank-row inverse norms / positive logits: the quad partials of a row, summed in a fixed order
 #pragma unroll
-  for (int i = 0; i < 2; ++i) ssq[ar + 64 * i][qd] = ss[i];
-  if (want_pos) pred[ar][qd] = pdot;
+  for (int i = 0; i < NS_NB; ++i) ssq[ar + NS_RPT * i][qd] = ss[i];
+  if (want_pos) {
+#pragma unroll
+    for (int i = 0; i < NS_NA; ++i) pred[ar + NS_RPT * i][qd] = pdot[i];
+  }
   __syncthreads();
   if (tid < NS_BN) {
-    const float s2 = (ssq[tid][0] + ssq[tid][1]) + (ssq[tid][2] + ssq[tid][3]);
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS_Q; ++j) s2 += ssq[tid][j];
     invb[tid] = 1.0f / fmaxf(sqrtf(s2), eps);
   }
-  if (want_pos && tid < NS_BM && q0 + tid < Q) pos[(long)e * Q + q0 + tid] = (pred[tid][0] + pred[tid][1]) + (pred[tid][2] + pred[tid][3]);
+  if (want_pos && tid < NS_BM && q0 + tid < Q) {
+    float pv = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS_Q; ++j) pv += pred[tid][j];
+    pos[(long)e * Q + q0 + tid] = pv;
+  }
   __syncthreads();
   // epilogue: lane (li, g) of tile (at, ct) holds S[q = 4g + r][l = li]
   float zrow[2][4];
