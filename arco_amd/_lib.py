@@ -149,6 +149,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_conv_split_ok": ([_I, _I, _I, _I, _I, _I, _L], _I),
     "arco_conv_pro_ok": ([_I, _I, _I, _I, _I, _I, _I, _L, _I, _I], _I),
     "arco_conv_sp_set": ([_I], _I),
+    "arco_conv3d_fl_set": ([_I], _I),
     "arco_gemm_sp_set": ([_I, _L], _I),
     "arco_wgrad_ws_floats": ([_I, _I, _I, _L], _L),
     "arco_chan_stats_blocks": ([_L], _I),

@@ -957,6 +957,10 @@ static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb
     const int r = conv3d_rw_dispatch(a, st, nmb);
     if (r != -1) return r;
   }
+  if (taps == 27 && a.mma == 3) {     // the 32 .. 256-channel levels: pipelined flat-tile kernel over 3 K virtual channels (conv3d_fl.hip)
+    const int r = conv3d_fl_dispatch(a, st, nmb);
+    if (r != -1) return r;
+  }
   if (taps == 27) return dispatch_spatial<3>(a, st, nmb);   // 3x3x3: planes of H x W, depth taps looped in the kernel
   if (taps == 9 && a.mma == 3) {     // 2-D levels with enough tiles: the software-pipelined kernels of conv_sp.hip
     const int r = conv_sp_dispatch(a, st, nmb);

@@ -168,6 +168,8 @@ __device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
 int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
 // conv_sp.hip: the resident-weights 3x3x3 kernel of the 16 -> 16 full-resolution level (split-bf16); -1 when the shape is not taken
 int conv3d_rw_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
+// conv3d_fl.hip: the pipelined flat-tile 3x3x3 kernel of the V-Net levels below full resolution (-1: shape not taken)
+int conv3d_fl_dispatch(const IgemmArgs& a, hipStream_t st, int* q);
 
 // gemm_sp.hip: the software-pipelined split-bf16 1x1 GEMM (wide, many-tile launches without BN statistics); -1 when the shape is not taken
 int gemm_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q);

@@ -351,6 +351,13 @@ def conv_sp_set(on):
     return prev
 
 
+def conv3d_fl_set(on):
+    """Switch the pipelined flat-tile 3x3x3 kernel (csrc/conv3d_fl.hip) on / off (A/B runs, tests); returns the previous setting."""
+    prev = L.query("arco_conv3d_fl_set", int(on))
+    _cfg_cache.clear()
+    return prev
+
+
 def _split_ok(taps, nbd, h, w, k, n, ld):
     key = ("split", taps, nbd, h, w, k, n, ld)
     r = _cfg_cache.get(key)

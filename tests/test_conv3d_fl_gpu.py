@@ -1,0 +1,88 @@
+"""csrc/conv3d_fl.hip - the software-pipelined flat-tile 3x3x3 convolution of the V-Net levels below full resolution
+(vnetWithArgs.py:5-31: Conv3d(k=3, pad=1) of ConvBlock at 32 / 64 / 128 / 256 channels) - against igemm_kernel<9,..,FLAT,DEPTH=3>
+(bit-identical: the same products in the same order) and an fp64 torch convolution (-m gpu)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(x):
+    return x.cuda().contiguous(memory_format=torch.channels_last_3d)
+
+
+# LA-patch levels (planes 56x40, 28x20, 14x10, 7x5), one and several volumes, several tiles per workgroup (nv=6 at 56x40: 336 planes),
+# a 16-multiple width (48) and a one-chunk-per-slice K (16 -> 32), two BatchNorm groups, every tile shape the cost model picks
+SHAPES = [dict(nv=1, ci=32, co=32, sp=(6, 56, 40)), dict(nv=6, ci=32, co=32, sp=(56, 56, 40), groups=2),
+          dict(nv=2, ci=64, co=64, sp=(28, 28, 20), groups=2), dict(nv=4, ci=128, co=128, sp=(14, 14, 10)),
+          dict(nv=4, ci=256, co=256, sp=(7, 7, 5)), dict(nv=1, ci=16, co=32, sp=(3, 9, 48)), dict(nv=2, ci=48, co=96, sp=(5, 12, 61)),
+          dict(nv=1, ci=64, co=32, sp=(2, 20, 20)), dict(nv=3, ci=32, co=64, sp=(2, 5, 3))]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_pipelined_3x3x3_kernel_equals_igemm_kernel(shape):
+    from arco_amd import _lib as L, ops
+    nv, ci, co, (d3, h, w) = shape["nv"], shape["ci"], shape["co"], shape["sp"]
+    groups = shape.get("groups", 1)
+    g = torch.Generator().manual_seed(ci * 1000 + co + h)
+    x = _cl(torch.randn(nv, ci, d3, h, w, generator=g))
+    wt = (torch.randn(co, ci, 3, 3, 3, generator=g) / (5.2 * ci ** 0.5)).cuda()
+    bias = torch.randn(co, generator=g).cuda()
+    prev_mma = ops.CONV_MMA
+    ops.CONV_MMA = 3
+    prev = ops.conv3d_fl_set(1)
+    res = {}
+    try:
+        wp = ops.pack_weight(wt, 27, 0)
+        xr, ldx = ops.rows_view(x)
+        for on in (0, 1):
+            ops.conv3d_fl_set(on)
+            cfg = L.query("arco_conv_config_mma", 27, nv * d3, h, w, ci, co, ldx, 3)
+            assert (9700000 <= cfg < 9800000) == bool(on), cfg
+            out, (ssum, ssq, nmb) = ops.conv_raw(xr, ldx, ci, wp, co, nv, h, w, 27, bias=bias, stats=True, d3=d3, stat_groups=groups)
+            assert ssum.shape == (co, nmb) and nmb % groups == 0
+            res[on] = (out.clone(), ssum.double().view(co, groups, -1).sum(2), ssq.double().view(co, groups, -1).sum(2))
+    finally:
+        ops.conv3d_fl_set(prev)
+        ops.CONV_MMA = prev_mma
+    assert torch.equal(res[0][0], res[1][0])
+    ref = F.conv3d(x.double(), wt.double(), bias.double(), padding=1)
+    assert float((res[1][0].double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    for k in (1, 2):
+        assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-5)
+    refg = ref.view(groups, nv // groups, co, -1)
+    assert torch.allclose(res[1][1].t(), refg.sum((1, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(res[1][2].t(), (refg * refg).sum((1, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("cfg", [44, 24, 14, 42, 22, 12])
+def test_every_tile_shape_of_the_pipelined_3x3x3_kernel(cfg, monkeypatch):
+    """ARCO_CONV3D_FL_CFG is read once per process: the tile shapes are forced through a child interpreter."""
+    import os, subprocess, sys
+    code = r'''
+import torch, torch.nn.functional as F
+from arco_amd import ops
+ops.CONV_MMA = 3
+g = torch.Generator().manual_seed(5)
+for (nv, ci, co, sp) in ((2, 64, 64, (9, 28, 20)), (1, 32, 128, (4, 14, 10)), (3, 16, 64, (3, 7, 5))):
+    x = torch.randn(nv, ci, *sp, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    wt = (torch.randn(co, ci, 3, 3, 3, generator=g) / (5.2 * ci ** 0.5)).cuda()
+    b = torch.randn(co, generator=g).cuda()
+    xg = x.clone().requires_grad_(True)
+    y = ops.conv(xg, wt, b)
+    gy = torch.randn(y.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    y.backward(gy)
+    ops.conv3d_fl_set(0)
+    xg0 = x.clone().requires_grad_(True)
+    y0 = ops.conv(xg0, wt, b); y0.backward(gy)
+    ops.conv3d_fl_set(1)
+    assert torch.equal(y, y0) and torch.equal(xg.grad, xg0.grad)
+    ref = F.conv3d(x.double(), wt.double(), b.double(), padding=1)
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+print("OK")
+'''
+    env = dict(os.environ, ARCO_CONV3D_FL_CFG=str(cfg))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
