@@ -227,6 +227,12 @@ def _kernel_name(key):
         return f"conv3x3_image_kernel<Cin={key % 100000 // 1000}> (few-channel input: the taps are the reduction dimension; {MMA_NAMES[mma]})"
     if 9500000 <= key < 9700000:        # flat-position tiles of the 3x3x3 kernels (narrow planes)
         return f"igemm_kernel<9,{(key - 9500000) // 1000},{key % 1000},...,FLAT,MMA={mma}> ({MMA_NAMES[mma]} implicit GEMM, 3x3x3 depth taps looped)"
+    if 9270000 <= key < 9300000:        # conv3d_fl.hip: the pipelined flat-tile 3x3x3 kernels
+        form = {7: ("conv3d_fl_kernel", "one rendezvous per tap-pair step, LDS-DMA weight ring"),
+                8: ("conv3d_dw_kernel", "depth-walking columns, three accumulator sets"),
+                9: ("conv3d_fc_kernel", "one rendezvous per 16-channel chunk, double-buffered chunk weights")}[key // 10000 % 10]
+        return (f"{form[0]}<A_T={key % 10000 // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; 3x3x3 as a 3x3 over 3 K virtual channels on flat "
+                f"tiles, persistent workgroups of 4 MFMA + 4 loader waves, {form[1]})")
     if 9450000 <= key < 9500000:
         return f"conv3d_rw16_kernel ({MMA_NAMES[mma]}; 3x3x3 16 -> 16: persistent workgroups, 27 taps' weights resident in LDS, ring of three input planes along the depth axis)"
     if 9350000 <= key < 9400000:

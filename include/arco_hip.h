@@ -146,7 +146,7 @@ int arco_conv_config_mma(int taps, int NB, int H, int W, int Cin, int Cout, long
  * or ARCO_CONV_SP=0 in the environment for off) lets the eligible wide 2-D shapes take it, 0 keeps every shape on
  * igemm_kernel.  Returns the previous setting.  Tile counts differ: query arco_conv_mblocks_mma after switching.   */
 int arco_conv_sp_set(int on);
-/* A/B switch of the software-pipelined flat-tile 3x3x3 kernel (conv3d_fl.hip; ids 9.7e6 + A_T*1e3 + BN: the 32 .. 256-channel levels of
+/* A/B switch of the software-pipelined flat-tile 3x3x3 kernel (conv3d_fl.hip; ids 9.27e6 / 9.28e6 / 9.29e6 + A_T*1e3 + BN for its per-step, depth-walking and per-chunk forms: the 32 .. 256-channel levels of
  * the V-Net, vnetWithArgs.py:5-31): on = 0 (or ARCO_CONV3D_FL=0) keeps every 3x3x3 launch on igemm_kernel.  Outputs are bit-identical
  * either way; tile counts differ (query arco_conv_mblocks_mma after switching).  Returns the previous setting. */
 int arco_conv3d_fl_set(int on);

@@ -39,7 +39,7 @@ def test_pipelined_3x3x3_kernel_equals_igemm_kernel(shape):
         for on in (0, 1):
             ops.conv3d_fl_set(on)
             cfg = L.query("arco_conv_config_mma", 27, nv * d3, h, w, ci, co, ldx, 3)
-            assert (9700000 <= cfg < 9800000) == bool(on), cfg
+            assert (9270000 <= cfg < 9300000) == bool(on), cfg      # conv3d_fl_kernel 9.27e6, conv3d_dw_kernel 9.28e6, conv3d_fc_kernel 9.29e6
             out, (ssum, ssq, nmb) = ops.conv_raw(xr, ldx, ci, wp, co, nv, h, w, 27, bias=bias, stats=True, d3=d3, stat_groups=groups)
             assert ssum.shape == (co, nmb) and nmb % groups == 0
             res[on] = (out.clone(), ssum.double().view(co, groups, -1).sum(2), ssq.double().view(co, groups, -1).sum(2))
@@ -56,7 +56,7 @@ def test_pipelined_3x3x3_kernel_equals_igemm_kernel(shape):
     assert torch.allclose(res[1][2].t(), (refg * refg).sum((1, 3)), rtol=1e-4, atol=1e-2)
 
 
-@pytest.mark.parametrize("cfg", [44, 24, 14, 42, 22, 12])
+@pytest.mark.parametrize("cfg", [44, 34, 24, 14, 42, 32, 22, 12, 92, 93, 124, 114, 142, 132, 122, 112])
 def test_every_tile_shape_of_the_pipelined_3x3x3_kernel(cfg, monkeypatch):
     """ARCO_CONV3D_FL_CFG is read once per process: the tile shapes are forced through a child interpreter."""
     import os, subprocess, sys

@@ -18,8 +18,10 @@ def timeit(fn, reps=20):
 
 
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-for ci, co, sp in ((32, 32, (56, 56, 40)), (64, 64, (28, 28, 20)), (128, 128, (14, 14, 10)), (256, 256, (7, 7, 5)),
-                   (32, 32, (80, 80, 48)), (64, 64, (40, 40, 24))):
+SHAPES = ((32, 32, (56, 56, 40)), (64, 64, (28, 28, 20)), (128, 128, (14, 14, 10)), (256, 256, (7, 7, 5)), (32, 32, (80, 80, 48)), (64, 64, (40, 40, 24)))
+if os.environ.get('FL_SHAPES'):
+    SHAPES = SHAPES[:int(os.environ['FL_SHAPES'])]
+for ci, co, sp in SHAPES:
     d3, h, w = sp
     x = torch.randn(nv, d3, h, w, ci, device="cuda").permute(0, 4, 1, 2, 3)
     wt = torch.randn(co, ci, 3, 3, 3, device="cuda") * 0.05
