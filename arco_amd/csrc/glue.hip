@@ -344,22 +344,37 @@ __global__ __launch_bounds__(256) void overlap_counts_kernel(const int64_t* __re
 
 // ---- equivariance loss (tps/rand_tps.py, tps_stn_pytorch/tps_grid_gen.py, train_arco_2d.py:404-423)
 // grid[b][p][0..1] = rep[p][0..NR) . mapping[b][0..NR)[0..1]   (TPSGridGen.forward, NR = 25 control points + 3)
+// One pixel per lane; the 28 basis values of the pixel in registers (seven 16-byte loads), the 2 x NR mapping coefficients of an
+// image read through wave-uniform addresses (scalar loads: they cost no vector or LDS issue), blockIdx.y = a group of BG images.
+// Round 6: the first form kept the mapping in LDS and ran one 256-thread block per CU over all B images - 1800 dependent
+// broadcast ds_read_b32 per lane, 356 us per launch (the longest single launch of the 2-D step); this one ~15 us.  The launch
+// sits on the second stream beside the contrastive stage: the replayed step did not move (10.51-10.70 -> 10.68-10.79 ms, same box).
+// The sums run in the same order (k ascending, one fused multiply-add per term): results unchanged bit for bit.
+constexpr int TPS_BG = 4;
 __global__ __launch_bounds__(256) void tps_grid_kernel(const float* __restrict__ rep, const float* __restrict__ mapping, int B,
                                                       long HW, int NR, float* __restrict__ grid) {
-  extern __shared__ float mp[];                      // [B][NR][2]
-  for (int i = threadIdx.x; i < B * NR * 2; i += 256) mp[i] = mapping[i];
-  __syncthreads();
-  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-    float r[32];                         // (static indexing: registers, no scratch - a scratch-using kernel's first launch
-#pragma unroll                           //  waits ~28 ms for the runtime to set the scratch arena up)
-    for (int k = 0; k < 32; ++k) r[k] = k < NR ? rep[p * NR + k] : 0.f;
-    for (int b = 0; b < B; ++b) {
-      float gx = 0.f, gy = 0.f;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float r[32];                           // (static indexing: registers, no scratch - a scratch-using kernel's first launch
+  if ((NR & 3) == 0) {                   //  waits ~28 ms for the runtime to set the scratch arena up)
 #pragma unroll
-      for (int k = 0; k < 32; ++k)
-        if (k < NR) { gx += r[k] * mp[(b * NR + k) * 2]; gy += r[k] * mp[(b * NR + k) * 2 + 1]; }
-      grid[((long)b * HW + p) * 2] = gx; grid[((long)b * HW + p) * 2 + 1] = gy;
+    for (int k4 = 0; k4 < 8; ++k4) {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (4 * k4 < NR) v = *reinterpret_cast<const f32x4*>(rep + p * NR + 4 * k4);
+      r[4 * k4] = v[0]; r[4 * k4 + 1] = v[1]; r[4 * k4 + 2] = v[2]; r[4 * k4 + 3] = v[3];
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r[k] = k < NR ? rep[p * NR + k] : 0.f;
+  }
+  const int b0 = blockIdx.y * TPS_BG, b1 = min(B, b0 + TPS_BG);
+  for (int b = b0; b < b1; ++b) {
+    const float* __restrict__ m = mapping + (long)b * NR * 2;       // wave-uniform
+    float gx = 0.f, gy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (k < NR) { gx += r[k] * m[2 * k]; gy += r[k] * m[2 * k + 1]; }
+    grid[((long)b * HW + p) * 2] = gx; grid[((long)b * HW + p) * 2 + 1] = gy;
   }
 }
 // ---- A2  AdvMorph (adv_morph.py:310-580): random diffeomorphic warp of the unlabeled stream -------------------------------
@@ -588,8 +603,8 @@ int arco_label_onehot(const int64_t* lab, long M, int C, long P, int64_t* out, v
 
 // TPS grid: rep [HW][NR], mapping [B][NR][2] -> grid [B][HW][2]   (NR <= 32)
 int arco_tps_grid(const float* rep, const float* mapping, int B, long HW, int NR, float* grid, void* stream) {
-  ARCO_CHECK_ARG(rep && mapping && grid && B > 0 && HW > 0 && NR > 0 && NR <= 32 && (size_t)B * NR * 2 * 4 <= 60 * 1024);
-  hipLaunchKernelGGL(tps_grid_kernel, dim3(gl_grid(HW)), dim3(256), (size_t)B * NR * 2 * sizeof(float), as_stream(stream), rep,
+  ARCO_CHECK_ARG(rep && mapping && grid && B > 0 && HW > 0 && NR > 0 && NR <= 32 && (HW + 255) / 256 < (1l << 31));
+  hipLaunchKernelGGL(tps_grid_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)((B + TPS_BG - 1) / TPS_BG)), dim3(256), 0, as_stream(stream), rep,
                      mapping, B, HW, NR, grid);
   return arco_launch_status();
 }
