@@ -40,3 +40,23 @@ def test_loss_slab_counts():
     assert got == {1: 512, 2: 256, 3: 256, 4: 128, 5: 128, 7: 128, 8: 64, 9: 64, 16: 64, 64: 64}
     for b, n in got.items():
         assert n * b >= 512 or b >= 8
+
+
+def test_3x3x3_launch_shapes_of_the_la_levels():
+    """Which kernel and tile shape the library picks for the V-Net's 3x3x3 convolutions at the LA patch (vnetWithArgs.py:5-31;
+    csrc/conv3d_fl.hip: the fitted launch cost model on a 256-CU device - the default without a GPU), and how many BatchNorm
+    partial-sum slabs per channel the caller has to provide.  ids: 9.45e6 conv3d_rw16_kernel, 9.27e6 + A_T*1e3 + BN conv3d_fl_kernel
+    (per-step rendezvous), 9.29e6 + ... conv3d_fc_kernel (per-chunk rendezvous); slabs = 4 per flat tile of 64 A_T positions.
+    (The query describes a launch by its plane count only: the choice cannot depend on the depth.)"""
+    levels = ((16, (112, 112, 80)), (32, (56, 56, 40)), (64, (28, 28, 20)), (128, (14, 14, 10)), (256, (7, 7, 5)))
+    want = {2: (9450016, 9293032, 9273064, 9292032, 9291032), 4: (9450016, 9294032, 9292064, 9293032, 9291032)}
+    for nv, ids in want.items():
+        for (c, (d, h, w)), cfg in zip(levels, ids):
+            assert int(L.query("arco_conv_config_mma", 27, nv * d, h, w, c, c, c, 3)) == cfg, (nv, c)
+            nmb = int(L.query("arco_conv_mblocks_mma", 27, nv * d, h, w, c, c, c, 1, 3))
+            if 9270000 <= cfg < 9300000:
+                a_t = cfg % 10000 // 1000
+                assert nmb == 4 * nv * d * -(-(h * (w + 2)) // (64 * a_t)), (nv, c, nmb)
+    # shapes the pipelined kernels do not take stay on igemm_kernel: planes wider than 61 pixels, N not a multiple of 32
+    assert int(L.query("arco_conv_config_mma", 27, 64, 80, 80, 32, 32, 32, 3)) < 9270000
+    assert not 9270000 <= int(L.query("arco_conv_config_mma", 27, 64, 28, 20, 32, 48, 32, 3)) < 9300000
