@@ -19,8 +19,7 @@
 //                    are summed once per launch.  Slabs [chunk][tap][CoutPad][CinPad] as in igemm.hip -> wgrad_reduce.
 //   hconv_rw_kernel  the resident-weights form of hconv_kernel for the 16-channel full-resolution level (further down).
 //   cast kernels     the fp32 <-> f16 boundary of the V-Net (outputs up, gradients down with the loss scale).
-#include "igemm_args.h"
-#include <stdlib.h>
+#include "sp_util.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -570,6 +569,322 @@ static int launch_hconv_rw(const IgemmArgs& a, hipStream_t st, int* q) {
   return arco_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// hconv_fc_kernel<A_T, C_T>: the f16-storage counterpart of conv3d_fc_kernel (conv3d_fl.hip; round 6) for the 3x3x3 levels
+// below full resolution - the 3x3x3 convolution as a 3x3 over 3 K virtual channels on flat tiles of 64 A_T positions, persistent
+// workgroups of 4 MFMA + 4 loader waves, one rendezvous per 16-channel chunk.  With f16 storage a product is ONE
+// v_mfma_f32_16x16x32_f16 (six in the split-bf16 mode), so a chunk is 5 A_T C_T MFMAs per wave: the kernel lives or dies by what
+// surrounds them.  hconv_kernel staged every chunk through registers between two __syncthreads() (phase-serialised: 0.14 of the f16
+// peak).  Here the loader waves only ISSUE: activation tiles and weights both go HBM -> LDS by LDS-DMA (an f16 tile needs no
+// conversion; positions that are padding, and planes outside the volume, are fetched from a zero row), into rings of four chunk
+// buffers filled two chunks ahead behind counted s_waitcnt vmcnt(N).  Same products in the same order as hconv_kernel: bit-identical.
+// LDS: [4][A rows][8] A + [4][10][BN][8] weights + bias (A_T = 4, C_T = 4: 49.2 + 81.9 KB).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) unsigned int hconv_fc_zero_row[16];
+
+template <int A_T, int C_T>
+struct HFcGeom {
+  static constexpr int BM = 64 * A_T, WPMAX = 63, AROWS = BM + 2 * WPMAX + 2, BN = C_T * 16, NBUF = 4;
+  static constexpr int NA = (AROWS * 2 + 255) / 256;            // LDS-DMA instructions per thread and chunk: activation pieces (2 per row)
+  static constexpr int NW = (10 * BN * 2 + 255) / 256;          // ... weight pieces
+  static constexpr int WBUF_DW = NW * 256 * 4;
+  static constexpr int BIAS_DW = 256;
+  static constexpr int A_DW = NA * 256 * 4;                     // whole wave-instructions (every loader wave issues all NA of them)
+  static constexpr size_t LDS_BYTES = (size_t)(NBUF * (A_DW + WBUF_DW) + BIAS_DW) * 4;
+};
+
+__device__ __forceinline__ void mfma_acc_h(f32x4& c, const h8& x, const h8& y) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(x), "v"(y));
+}
+
+template <int A_T, int C_T>
+__global__ __launch_bounds__(512) void hconv_fc_kernel(IgemmArgs a) {
+  using G = HFcGeom<A_T, C_T>;
+  constexpr int BM = G::BM, BN = G::BN, NA = G::NA, NW = G::NW, NBUF = G::NBUF;
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_f[];
+  const int Wp = a.W + 2, npos = a.H * Wp, per_plane = (npos + BM - 1) / BM;
+  const int arows = BM + 2 * Wp + 2;
+  constexpr int A_DW = G::A_DW;
+  unsigned* const As = smem_f;                                  // [NBUF][A_DW]: rows of 16 channels = 8 dwords
+  unsigned* const Ws = As + NBUF * A_DW;                        // [NBUF][5 steps][tapL][BN][8]
+  float* const bias_s = reinterpret_cast<float*>(Ws + NBUF * G::WBUF_DW);
+  const _Float16* const Ag = reinterpret_cast<const _Float16*>(a.A);
+  const _Float16* const Wg = reinterpret_cast<const _Float16*>(a.Wp);
+  _Float16* const Cg = reinterpret_cast<_Float16*>(a.C);
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+  const bool producer = threadIdx.x >= 256;
+  const int nk = a.K >> 4, nvc = 3 * nk;
+  const int total_tiles = a.n_mblocks * a.n_nblocks;
+  const bool xcd_map = (gridDim.x & 7) == 0;
+  const int G8 = xcd_map ? (int)gridDim.x >> 3 : (int)gridDim.x;
+  const int T8 = xcd_map ? (total_tiles + 7) >> 3 : total_tiles;
+  const int tile0 = xcd_map ? ((int)blockIdx.x & 7) * T8 + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int tile_end_x = xcd_map ? min(total_tiles, (((int)blockIdx.x & 7) + 1) * T8) : total_tiles;
+  const int my_tiles = tile0 < tile_end_x ? (tile_end_x - tile0 + G8 - 1) / G8 : 0;
+  const int total_gc = my_tiles * nvc;
+  if (my_tiles == 0) return;
+  const bool has_stats = a.stat_sum != nullptr;
+  struct Desc { int j, vc, dz, kc, img, f0, nblk, mblk, pl; };
+  auto decode = [&](Desc& d) {
+    const int v = tile0 + d.j * G8;
+    d.mblk = v / a.n_nblocks; d.nblk = v - d.mblk * a.n_nblocks;
+    d.img = d.mblk / per_plane;
+    d.f0 = (d.mblk - d.img * per_plane) * BM;
+    d.pl = d.img % a.D3;
+  };
+  auto advance = [&](Desc& d) {
+    ++d.vc;
+    if (++d.kc == nk) { d.kc = 0; ++d.dz; }
+    if (d.vc == nvc) { d.vc = 0; d.dz = 0; d.kc = 0; ++d.j; decode(d); }
+  };
+  Desc d0{0, 0, 0, 0, 0, 0, 0, 0, 0};
+  decode(d0);
+
+  if (producer) {
+    // ================================================================ loader waves: LDS-DMA only
+    const float inv_wp = 1.0f / (float)Wp;
+    const long plane_el = (long)a.H * a.W * a.lda;       // f16 elements per plane
+    const _Float16* const zrow = reinterpret_cast<const _Float16*>(hconv_fc_zero_row);
+    // activation piece i of this thread: staged row (tid + i * 256) >> 1, half = channel octet; its source offset (elements within the
+    // plane) and whether it is a pixel belong to the TILE (tile_geom at a tile's first chunk)
+    int aoffs[NA]; unsigned okm_t = 0;
+    auto tile_geom = [&](const Desc& d) {
+      okm_t = 0;
+#pragma unroll
+      for (int it = 0; it < NA; ++it) {
+        const int idx = tid + it * 256, row = idx >> 1, half = idx & 1;
+        const int pidx = d.f0 + row - 1;
+        const int py = (int)(((float)pidx + 0.5f) * inv_wp), px = pidx - py * Wp;
+        const bool ok = row < arows && pidx >= 0 && py >= 1 && py <= a.H && px >= 1 && px <= a.W;
+        aoffs[it] = ok ? ((py - 1) * a.W + px - 1) * (int)a.lda + half * 8 : 0;
+        okm_t |= ok ? (1u << it) : 0u;
+      }
+    };
+    int woff[NW]; bool wz[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int p = (i * 4 + wid) * 64 + lane;
+      const int half = p & 1, n = (p >> 1) % BN, t10 = p / (2 * BN);      // t10 = 2 s + tapL
+      wz[i] = t10 >= 9;
+      woff[i] = t10 < 9 ? (t10 * a.Npad + n) * a.Kpad + half * 8 : 0;
+    }
+    const long wslice = (long)9 * a.Npad * a.Kpad;
+    auto load_chunk = [&](const Desc& d, bool real, int buf) {      // NW + NA LDS-DMA instructions per wave, real or not (exact vmcnt counts)
+      const _Float16* wb = Wg + d.dz * wslice + (long)d.nblk * BN * a.Kpad + d.kc * 16;
+      unsigned* const wdst = Ws + buf * G::WBUF_DW;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const _Float16* src = wz[i] ? zrow + (lane & 1) * 8 : wb + woff[i];
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(wdst + (i * 4 + wid) * 256), 16, 0, 0);
+      }
+      if (d.vc == 0) tile_geom(d);
+      const int pz = d.pl + d.dz - 1;
+      const bool pok = real && pz >= 0 && pz < a.D3;
+      const _Float16* ab = Ag + (long)(pok ? d.img + d.dz - 1 : 0) * plane_el + d.kc * 16;
+      unsigned* const adst = As + buf * A_DW;
+#pragma unroll
+      for (int it = 0; it < NA; ++it) {
+        const _Float16* src = (pok && ((okm_t >> it) & 1u)) ? ab + aoffs[it] : zrow + (lane & 1) * 8;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(adst + (it * 4 + wid) * 256), 16, 0, 0);
+      }
+    };
+    constexpr int NC = NW + NA;
+    for (int i = tid; i < G::BIAS_DW; i += 256) bias_s[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
+    Desc dl = d0;                                   // the chunk whose DMA is issued next
+    load_chunk(dl, true, 0); advance(dl);
+    load_chunk(dl, total_gc > 1, 1); advance(dl);
+    load_chunk(dl, total_gc > 2, 2); advance(dl);
+    wait_vm<2 * NC>();                              // chunk 0 has landed
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();                   // B0
+    // barrier k (the consumers pass it at the head of step 4 of chunk k): chunk k + 1 is complete in LDS; behind it the DMA of
+    // chunk k + 3 goes into the buffers chunk k - 1 used
+    for (int k = 0; k < total_gc; ++k) {
+      wait_vm<NC>();                                // chunk k + 1 (only chunk k + 2's DMA is younger)
+      __builtin_amdgcn_s_barrier();
+      load_chunk(dl, k + 3 < total_gc, (k + 3) & 3); advance(dl);
+    }
+    wait_vm<0>();
+    return;
+  }
+
+  // ================================================================== MFMA waves
+  const int tl = g >> 1;
+  int aoff[5];
+#pragma unroll
+  for (int s_ = 0; s_ < 5; ++s_) {
+    const int tap = 2 * s_ + tl > 8 ? 8 : 2 * s_ + tl;
+    aoff[s_] = ((tap / 3) * Wp + tap % 3) * 8;
+  }
+  const int laneA = (wid * A_T * 16 + li) * 8 + (g & 1) * 4;
+  const int laneB = (tl * BN + li) * 8 + (g & 1) * 4;              // within a step's [tapL][n] block
+  h8 fa[A_T], fb[2][C_T];
+  f32x4 acc[A_T][C_T];
+#pragma unroll
+  for (int i = 0; i < A_T; ++i)
+#pragma unroll
+    for (int j = 0; j < C_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  __builtin_amdgcn_s_barrier();        // B0
+#pragma unroll
+  for (int at = 0; at < A_T; ++at) fa[at] = lds_h8(As + laneA + aoff[0] + at * 16 * 8);
+#pragma unroll
+  for (int ct = 0; ct < C_T; ++ct) fb[0][ct] = lds_h8(Ws + laneB + ct * 16 * 8);
+
+  auto chunk = [&](auto CP_, int gc, bool more) {
+    constexpr int CP = decltype(CP_)::value;               // B set of step 0 (5 steps per chunk: alternates per chunk)
+    const unsigned* Acur = As + (gc & 3) * A_DW;
+    const unsigned* Anxt = As + ((gc + 1) & 3) * A_DW;
+    const unsigned* Wc = Ws + (gc & 3) * G::WBUF_DW;
+    const unsigned* Wn = Ws + ((gc + 1) & 3) * G::WBUF_DW;
+    auto step = [&](auto S_) {
+      constexpr int S = decltype(S_)::value;
+      constexpr int P = (CP + S) & 1, Q = P ^ 1;
+      if (S == 4) {                    // the one rendezvous of the chunk: the next chunk is complete in LDS
+        wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+      }
+      constexpr int BPA = (C_T + A_T - 1) / A_T;            // next-step B reads per pixel tile
+      const unsigned* An = S < 4 ? Acur : Anxt;
+      const unsigned* Wb = (S < 4 ? Wc : Wn) + ((S + 1) % 5) * (2 * BN * 8);
+#pragma unroll
+      for (int at = 0; at < A_T; ++at) {
+#pragma unroll
+        for (int ct = 0; ct < C_T; ++ct) mfma_acc_h(acc[at][ct], fb[P][ct], fa[at]);      // D = W . X^T
+        if (S < 4 || more) fa[at] = lds_h8(An + laneA + aoff[(S + 1) % 5] + at * 16 * 8);
+#pragma unroll
+        for (int k = at * BPA; k < (at + 1) * BPA && k < C_T; ++k) fb[Q][k] = lds_h8(Wb + laneB + k * 16 * 8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+  };
+
+  const float inv_wp = 1.0f / (float)Wp;
+  auto tile_end = [&]() {              // bias, round to f16, 8-byte stores, BN partial statistics of the rounded values (one slab per wave)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const int n0 = d0.nblk * BN;
+    long pix[A_T];
+#pragma unroll
+    for (int at = 0; at < A_T; ++at) {
+      const int f = d0.f0 + (wid * A_T + at) * 16 + li;
+      const int y = (int)(((float)f + 0.5f) * inv_wp), xq = f - y * Wp;
+      pix[at] = (y < a.H && xq >= 1 && xq <= a.W) ? ((long)d0.img * a.H + y) * a.W + xq - 1 : -1;
+    }
+    float s1[C_T][4], s2[C_T][4];
+#pragma unroll
+    for (int ct = 0; ct < C_T; ++ct) {
+      const int n = n0 + ct * 16 + 4 * g;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; }
+#pragma unroll
+      for (int at = 0; at < A_T; ++at) {
+        if (pix[at] >= 0) {
+          const f32x4 v = acc[at][ct] + bv;
+          const h4 hv = __builtin_convertvector(v, h4);
+          *reinterpret_cast<h4*>(Cg + pix[at] * a.ldc + n) = hv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float x = (float)hv[r]; s1[ct][r] += x; s2[ct][r] += x * x; }
+        }
+        acc[at][ct] = f32x4{0, 0, 0, 0};
+      }
+    }
+    if (has_stats) {
+      const long slab = (long)d0.mblk * 4 + wid, nslab = (long)a.n_mblocks * 4;
+#pragma unroll
+      for (int ct = 0; ct < C_T; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v1 = row16_sum(s1[ct][r]), v2 = row16_sum(s2[ct][r]);
+          if (li == 0) {
+            a.stat_sum[(n0 + ct * 16 + 4 * g + r) * nslab + slab] = v1;
+            a.stat_sq[(n0 + ct * 16 + 4 * g + r) * nslab + slab] = v2;
+          }
+        }
+    }
+  };
+  for (int gc = 0; gc < total_gc; gc += 2) {
+    chunk(std::integral_constant<int, 0>{}, gc, gc + 1 < total_gc);
+    if (d0.vc + 1 == nvc) tile_end();
+    advance(d0);
+    if (gc + 1 < total_gc) {
+      chunk(std::integral_constant<int, 1>{}, gc + 1, gc + 2 < total_gc);
+      if (d0.vc + 1 == nvc) tile_end();
+      advance(d0);
+    }
+  }
+}
+
+template <int A_T, int C_T>
+static int launch_hfc(const IgemmArgs& a, hipStream_t st, int* q) {
+  using G = HFcGeom<A_T, C_T>;
+  const int mblocks = a.NB * ((a.H * (a.W + 2) + G::BM - 1) / G::BM);
+  if (q) { q[0] = 4 * mblocks; q[1] = 9260000 + A_T * 1000 + G::BN; q[2] = 1631; return ARCO_OK; }
+  if (a.D3 < 1 || a.NB % a.D3 != 0) return ARCO_ERR_ARG;
+  const size_t lds = G::LDS_BYTES;
+  static_assert(G::LDS_BYTES <= 160 * 1024, "LDS");
+  IgemmArgs b = a;
+  b.n_mblocks = mblocks; b.n_nblocks = a.Npad / G::BN;
+  const int total = mblocks * b.n_nblocks, cus = conv_sp_cus();
+  auto kern = hconv_fc_kernel<A_T, C_T>;
+  static unsigned long long attr_set = 0;
+  if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, b);
+  return arco_launch_status();
+}
+
+// -1: shape not taken.  A/B: ARCO_HCONV_FC=0 off; ARCO_HCONV_FC_CFG=<A_T><C_T> forces a tile shape.  arco_conv3d_fl_set(0) switches it off too.
+extern "C" int arco_conv3d_fl_set(int on);
+static int hconv_fc_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
+  static const int on = getenv("ARCO_HCONV_FC") ? atoi(getenv("ARCO_HCONV_FC")) : 1;
+  static const int forced = getenv("ARCO_HCONV_FC_CFG") ? atoi(getenv("ARCO_HCONV_FC_CFG")) : 0;
+  if (!on) return -1;
+  { const int cur = arco_conv3d_fl_set(1); if (!cur) { arco_conv3d_fl_set(0); return -1; } }
+  if ((a.K & 15) != 0 || a.K < 16 || (a.N & 31) != 0 || a.N != a.Npad || a.N > 256 || a.W + 2 > 63 || (a.lda & 7) != 0 || (a.ldc & 3) != 0) return -1;
+  if ((long)a.H * a.W * a.lda >= (1l << 30)) return -1;
+  // the 32-channel level on planes whose width is a multiple of 16 stays on hconv_kernel<9,256,32> (rectangular 16 x 16 tiles,
+  // measured 53 against 63 us at 80 x 80 x 48 x 2 volumes)
+  if (!forced && (a.W & 15) == 0 && a.Npad <= 32) return -1;
+  int best = forced;
+  if (!best) {
+    // Launch model (fit of tools/micro/fl_bench.py HALF=1, profiles/r06_notes.md section 9): with one MFMA per product these launches
+    // are bound by the L2 -> LDS stream (every tile re-reads the 27 taps' weights: 20 KB of weights against 3-10 KB of activations per
+    // chunk), ~5.9 TB/s over the chip: time = LDS-DMA bytes of all rounds / 5.9 TB/s (a partly filled last round counts as a full
+    // one), or the MFMA / rendezvous path if that is longer, + 1.9 us of epilogue per round
+    double bc = 1e300;
+    const int cand[8] = {44, 34, 24, 14, 42, 32, 22, 12};
+    const int cus = conv_sp_cus();
+    for (int i = 0; i < 8; ++i) {
+      const int a_t = cand[i] / 10, c_t = cand[i] % 10;
+      if ((a.N % (16 * c_t)) != 0) continue;
+      const long tiles = (long)a.NB * ((a.H * (a.W + 2) + 64 * a_t - 1) / (64 * a_t)) * (a.Npad / (16 * c_t));
+      const long rounds = (tiles + cus - 1) / cus;
+      const double chunks = 3.0 * (a.K >> 4);
+      const double bytes = (64.0 * a_t + 2.0 * (a.W + 2) + 2.0) * 32.0 + 10.0 * 16 * c_t * 32.0;
+      const double eff_tiles = tiles <= cus ? (double)tiles : (double)rounds * cus;
+      const double t_bw = eff_tiles * chunks * bytes / 5.9e6;
+      const double t_mfma = (double)rounds * chunks * (5.0 * a_t * c_t * 0.008 + 0.10);
+      const double c = (t_bw > t_mfma ? t_bw : t_mfma) + 1.9 * rounds;
+      if (c < bc * 0.999) { bc = c; best = cand[i]; }
+    }
+  }
+  switch (best) {
+    case 44: if ((a.N & 63) == 0) return launch_hfc<4, 4>(a, st, q); break;
+    case 34: if ((a.N & 63) == 0) return launch_hfc<3, 4>(a, st, q); break;
+    case 24: if ((a.N & 63) == 0) return launch_hfc<2, 4>(a, st, q); break;
+    case 14: if ((a.N & 63) == 0) return launch_hfc<1, 4>(a, st, q); break;
+    case 42: return launch_hfc<4, 2>(a, st, q);
+    case 32: return launch_hfc<3, 2>(a, st, q);
+    case 22: return launch_hfc<2, 2>(a, st, q);
+    case 12: return launch_hfc<1, 2>(a, st, q);
+  }
+  return -1;
+}
+
 // entry of the f16-storage convolutions (called from arco_conv3d_fwd with mma == 4).  a.Kpad = ceil32(K) (the f16 pack)
 int hconv_dispatch(const IgemmArgs& a, int taps, hipStream_t st, int* q) {
   if ((taps != 1 && ((a.K & 7) != 0 || (a.lda & 7) != 0)) || a.R != nullptr) return ARCO_ERR_UNSUPPORTED;
@@ -580,6 +895,7 @@ int hconv_dispatch(const IgemmArgs& a, int taps, hipStream_t st, int* q) {
       if (a.K == 16) return ((mode & 4) && a.H % 16 == 0) ? launch_hconv_rw<1, 1, 16>(a, st, q) : launch_hconv_rw<1, 1, 8>(a, st, q);
       return launch_hconv_rw<2, 2, 16>(a, st, q);
     }
+    { const int r = hconv_fc_dispatch(a, st, q); if (r != -1) return r; }      // the pipelined flat-tile form (32 .. 256 channels)
     if ((a.W & 15) != 0 && a.W + 2 <= HFLAT_WPMAX) return hconv_dispatch3<true>(a, st, q);
     return hconv_dispatch3<false>(a, st, q);
   }

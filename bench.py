@@ -218,6 +218,9 @@ def _kernel_name(key):
     if mma == 4 and 9400000 <= key < 9500000:
         return (f"hconv_rw_kernel<TH={(key - 9400000) // 1000},N={key % 1000}> (f16 activation storage; persistent workgroups, all 27 taps' weights "
                 "resident in LDS, ring of three input planes walked along the depth axis)")
+    if mma == 4 and 9260000 <= key < 9270000:
+        return (f"hconv_fc_kernel<A_T={key % 10000 // 1000},C_T={key % 1000 // 16}> (f16 activation storage, v_mfma_f32_16x16x32_f16; 3x3x3 as a 3x3 over 3 K "
+                "virtual channels on flat tiles, 4 MFMA + 4 LDS-DMA loader waves, one rendezvous per 16-channel chunk)")
     if mma == 4 and not (9700000 <= key < 9900000):
         flat = 9500000 <= key < 9700000
         base = key - (9500000 if flat else (key // 1000000) * 1000000)

@@ -86,3 +86,42 @@ print("OK")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+# f16 activation storage (BASELINE.json configs[4]): hconv_fc_kernel against hconv_kernel - LiTS-patch levels (planes 40x24, 20x12, 10x6; the
+# 32-channel 80x48 level stays on hconv_kernel's rectangular tiles), the LA ones, one and two volumes, two BatchNorm groups
+H_SHAPES = [dict(nv=1, ci=32, co=32, sp=(9, 80, 40)), dict(nv=2, ci=64, co=64, sp=(40, 40, 24), groups=2), dict(nv=2, ci=128, co=128, sp=(20, 20, 12)),
+            dict(nv=2, ci=256, co=256, sp=(10, 10, 6), groups=2), dict(nv=1, ci=32, co=64, sp=(5, 56, 40)), dict(nv=3, ci=16, co=32, sp=(3, 7, 5)),
+            dict(nv=1, ci=48, co=96, sp=(2, 12, 61))]
+
+
+@pytest.mark.parametrize("shape", H_SHAPES)
+def test_pipelined_f16_3x3x3_kernel_equals_hconv_kernel(shape):
+    from arco_amd import _lib as L, ops
+    nv, ci, co, (d3, h, w) = shape["nv"], shape["ci"], shape["co"], shape["sp"]
+    groups = shape.get("groups", 1)
+    g = torch.Generator().manual_seed(ci * 1000 + co + h)
+    x = _cl(torch.randn(nv, ci, d3, h, w, generator=g).half())
+    wt = (torch.randn(co, ci, 3, 3, 3, generator=g) / (5.2 * ci ** 0.5)).half().float().cuda()
+    bias = torch.randn(co, generator=g).cuda()
+    prev = ops.conv3d_fl_set(1)
+    res = {}
+    try:
+        wp = ops.pack_weight(wt, 27, 0, half=True)
+        xr, ldx = ops.rows_view(x)
+        for on in (0, 1):
+            ops.conv3d_fl_set(on)
+            cfg = L.query("arco_conv_config_mma", 27, nv * d3, h, w, ci, co, ldx, 4)
+            assert (9260000 <= cfg < 9270000) == bool(on), cfg
+            out, (ssum, ssq, nmb) = ops.conv_raw(xr, ldx, ci, wp, co, nv, h, w, 27, bias=bias, stats=True, d3=d3, stat_groups=groups, half=True)
+            assert out.dtype == torch.float16 and ssum.shape == (co, nmb) and nmb % groups == 0
+            res[on] = (out.clone(), ssum.double().view(co, groups, -1).sum(2), ssq.double().view(co, groups, -1).sum(2))
+    finally:
+        ops.conv3d_fl_set(prev)
+    assert torch.equal(res[0][0], res[1][0])
+    ref = F.conv3d(x.double(), wt.double(), bias.double(), padding=1)
+    assert float((res[1][0].double() - ref).abs().max() / ref.abs().max()) < 1e-3          # one f16 rounding of the stored result
+    for k in (1, 2):
+        assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-4)
+    got = res[1][0].double().view(groups, nv // groups, co, -1)
+    assert torch.allclose(res[1][1].t(), got.sum((1, 3)), rtol=1e-4, atol=1e-2)             # statistics of the ROUNDED outputs
