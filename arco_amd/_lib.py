@@ -144,6 +144,7 @@ _QUERIES = {   # plain host helpers returning sizes
     "arco_jitter_desc_bytes": ([], _L),
     "arco_conv_mblocks": ([_I, _I, _I, _I, _I, _I, _L, _I], _I),
     "arco_conv_mblocks_mma": ([_I, _I, _I, _I, _I, _I, _L, _I, _I], _I),
+    "arco_conv_mblocks_pro": ([_I, _I, _I, _I, _I, _I, _L, _I, _I, _I], _I),
     "arco_conv_config": ([_I, _I, _I, _I, _I, _I, _L, _P], _I),
     "arco_conv_config_mma": ([_I, _I, _I, _I, _I, _I, _L, _I], _I),
     "arco_conv_split_ok": ([_I, _I, _I, _I, _I, _I, _L], _I),

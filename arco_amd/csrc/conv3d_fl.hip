@@ -375,10 +375,15 @@ struct FcGeom {
   static constexpr int NA_IT = (AROWS * 4 + 255) / 256;
   static constexpr int BIAS_DW = 256;
   static int a_dw(int Wp) { return (BM + 2 * Wp + 2) * 24; }
-  static size_t lds_bytes(int Wp) { return (size_t)(2 * a_dw(Wp) + 2 * WBUF_DW + BIAS_DW) * 4; }
+  // pro_dw: the statistics / affine parameters of a consumer-side activation ([groups][K] mean and istd, [K] gamma and beta)
+  static size_t lds_bytes(int Wp, int pro_dw = 0) { return (size_t)(2 * a_dw(Wp) + 2 * WBUF_DW + BIAS_DW + pro_dw) * 4; }
 };
 
-template <int A_T, int C_T>
+// PRO (consumer-side activation, igemm_args.h): the input is the PRE-activation z of the producing convolution; the loader waves apply
+// ReLU(BatchNorm(z)) - bn_act_fwd_kernel's arithmetic, operation for operation - to every staged piece before the bf16 split, with the
+// statistics and affine parameters read from LDS (copied there once per launch).  Positions that are padding stay zero (the mask is applied
+// behind the activation).  The gradient-free passes of the V-Net run their stage -> stage links this way (ops.conv_block3d_nograd).
+template <int A_T, int C_T, bool PRO = false>
 __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
   using G = FcGeom<A_T, C_T>;
   constexpr int BM = G::BM, BN = G::BN, NA = G::NA_IT, NW = G::NW;
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
   unsigned* const As = reinterpret_cast<unsigned*>(smem);
   unsigned* const Ws = As + 2 * A_DW;
   float* const bias_s = reinterpret_cast<float*>(Ws + 2 * G::WBUF_DW);
+  float* const pro_s = bias_s + G::BIAS_DW;                      // PRO: [groups][K] mean, [groups][K] istd, [K] gamma, [K] beta
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
   const bool producer = threadIdx.x >= 256;
   const int nk = a.K >> 4, nvc = 3 * nk;
@@ -402,6 +408,8 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
   const int total_gc = my_tiles * nvc;
   if (my_tiles == 0) return;
   const bool has_stats = a.stat_sum != nullptr;
+  const int pgroups = PRO ? (a.pro.groups > 1 ? a.pro.groups : 1) : 1;
+  const int ppg = PRO ? a.NB / pgroups : 1;                       // planes per BatchNorm group of the producing layer
   struct Desc { int j, vc, dz, kc, img, f0, nblk, mblk, pl; };
   auto decode = [&](Desc& d) {
     const int v = tile0 + d.j * G8;
@@ -420,6 +428,13 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
 
   if (producer) {
     // ================================================================ producer waves
+    if constexpr (PRO) {               // the producing layer's statistics and parameters -> LDS, before any counted load is issued
+      const int gk = pgroups * a.K;
+      for (int i = tid; i < 2 * gk + 2 * a.K; i += 256)
+        pro_s[i] = i < gk ? a.pro.mean[i] : (i < 2 * gk ? a.pro.istd[i - gk] : (i < 2 * gk + a.K ? a.pro.gamma[i - 2 * gk] : a.pro.beta[i - 2 * gk - a.K]));
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();    // (PRO only, both roles: every loader thread reads quads other threads have written)
+    }
     Desc d1 = d0; advance(d1);
     Desc d2 = d1; advance(d2);
     Desc d3 = d2; advance(d3);
@@ -458,21 +473,33 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
     const float* const zrow = reinterpret_cast<const float*>(conv3d_fl_zero_row);
 
     f32x4 ra[2][NA]; unsigned okm2[2] = {0, 0};
+    int pch2[2] = {0, 0}, pgr2[2] = {0, 0};         // PRO: first channel of the thread's quad and BatchNorm group of the chunk in each register set
     auto load_A = [&](const Desc& d, bool real, int set) {
       if (d.vc == 0) tile_geom(d);
       const int pz = d.pl + d.dz - 1;
       const bool pok = real && pz >= 0 && pz < a.D3;
       const float* gbase = uniform_ptr(a.A + (long)(pok ? d.img + d.dz - 1 : 0) * plane_dw + d.kc * 16);
       okm2[set] = pok ? okm_t : 0u;
+      if constexpr (PRO) { pch2[set] = d.kc * 16 + qA * 4; pgr2[set] = real ? d.img / ppg : 0; }
 #pragma unroll
       for (int it = 0; it < NA; ++it) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[set][it]) : "v"(voff[it]), "s"(gbase) : "memory");
     };
     auto store_all = [&](unsigned* buf, int set) {
 #pragma unroll
       for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(ra[set][it])::"memory");
+      ProQuad pq;
+      if constexpr (PRO) {
+        const int gk = pgroups * a.K;
+        pq.mu = *reinterpret_cast<const f32x4*>(pro_s + pgr2[set] * a.K + pch2[set]);
+        pq.is = *reinterpret_cast<const f32x4*>(pro_s + gk + pgr2[set] * a.K + pch2[set]);
+        pq.ga = *reinterpret_cast<const f32x4*>(pro_s + 2 * gk + pch2[set]);
+        pq.be = *reinterpret_cast<const f32x4*>(pro_s + 2 * gk + a.K + pch2[set]);
+      }
 #pragma unroll
       for (int it = 0; it < NA; ++it) {
-        const f32x4 v = ((okm2[set] >> it) & 1u) ? ra[set][it] : f32x4{0, 0, 0, 0};
+        f32x4 v = ra[set][it];
+        if constexpr (PRO) v = pro_mask(pro_bn_lrelu(v, pq, a.pro.slope), okm2[set] >> it);
+        else v = ((okm2[set] >> it) & 1u) ? v : f32x4{0, 0, 0, 0};
         u32x2 q0, q1, q2;
         split3_bf16x4(v, q0, q1, q2);
         if (ldsA[it] >= 0) {
@@ -547,6 +574,7 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
   for (int i = 0; i < A_T; ++i)
 #pragma unroll
     for (int j = 0; j < C_T; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  if constexpr (PRO) __builtin_amdgcn_s_barrier();      // the loaders' parameter copy
   __builtin_amdgcn_s_barrier();        // B0
 #pragma unroll
   for (int at = 0; at < A_T; ++at)
@@ -657,17 +685,26 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
   }
 }
 
+static int fc_pro_dw(const IgemmArgs& a) { return a.pro.mean ? (2 * (a.pro.groups > 1 ? a.pro.groups : 1) + 2) * a.K : 0; }
 template <int A_T, int C_T>
 static int launch_fc(const IgemmArgs& a, hipStream_t st, int* q) {
   using G = FcGeom<A_T, C_T>;
   const int mblocks = a.NB * ((a.H * (a.W + 2) + G::BM - 1) / G::BM);
   if (q) { q[0] = 4 * mblocks; q[1] = 9290000 + A_T * 1000 + G::BN; q[2] = 1630; return ARCO_OK; }
   if (a.D3 < 1 || a.NB % a.D3 != 0) return ARCO_ERR_ARG;
-  const size_t lds = G::lds_bytes(a.W + 2);
+  const size_t lds = G::lds_bytes(a.W + 2, fc_pro_dw(a));
   if (lds > 160 * 1024) return ARCO_ERR_UNSUPPORTED;
   IgemmArgs b = a;
   b.n_mblocks = mblocks; b.n_nblocks = a.Npad / G::BN;
   const int total = mblocks * b.n_nblocks, cus = conv_sp_cus();
+  if (a.pro.mean) {           // consumer-side activation of the input
+    if (a.pro.drop_mode != 0 || a.NB % (a.pro.groups > 1 ? a.pro.groups : 1) != 0) return ARCO_ERR_UNSUPPORTED;
+    auto kern = conv3d_fc_kernel<A_T, C_T, true>;
+    static unsigned long long attr_set = 0;
+    if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, b);
+    return arco_launch_status();
+  }
   auto kern = conv3d_fc_kernel<A_T, C_T>;
   static unsigned long long attr_set = 0;
   if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
@@ -675,7 +712,7 @@ static int launch_fc(const IgemmArgs& a, hipStream_t st, int* q) {
   return arco_launch_status();
 }
 template <int A_T, int C_T>
-static bool fc_fits(const IgemmArgs& a) { return FcGeom<A_T, C_T>::lds_bytes(a.W + 2) <= 160 * 1024; }
+static bool fc_fits(const IgemmArgs& a) { return FcGeom<A_T, C_T>::lds_bytes(a.W + 2, fc_pro_dw(a)) <= 160 * 1024; }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Depth-walking form for the 32-channel-wide output blocks (conv3d_dw_kernel<A_T>, 16 C_T = 32 output channels per workgroup).
@@ -1078,7 +1115,8 @@ int conv3d_fl_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   // profiles/r06_notes.md section 7): ARCO_CONV3D_DW = 0 (default) off, 1 the 32-channel layers, 2 every layer it can take
   // (n-blocks of 32); ARCO_CONV3D_FL_CFG = 92 / 93 / 94 forces it with 128- / 192- / 256-position tiles
   static const int dw = getenv("ARCO_CONV3D_DW") ? atoi(getenv("ARCO_CONV3D_DW")) : 0;
-  if (forced == 94 || forced == 93 || forced == 92 || (!forced && dw && (a.N == 32 || dw >= 2))) {
+  if (a.pro.mean && forced && forced < 100) return -1;
+  if (!a.pro.mean && (forced == 94 || forced == 93 || forced == 92 || (!forced && dw && (a.N == 32 || dw >= 2)))) {
     const int a_t = forced ? forced - 90 : 2;
     return a_t == 4 ? launch_dw<4>(a, st, q) : (a_t == 3 ? launch_dw<3>(a, st, q) : launch_dw<2>(a, st, q));
   }
@@ -1088,18 +1126,18 @@ int conv3d_fl_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   if (!best) {
     double bc = 1e300;
     const int cand[8] = {44, 34, 24, 14, 42, 32, 22, 12};
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8 && !a.pro.mean; ++i) {          // (a consumer-side activation: the per-chunk form only)
       const int a_t = cand[i] / 10, c_t = cand[i] % 10;
       if ((a.N % (16 * c_t)) != 0) continue;
       const double c = fl_cost(a, a_t, c_t, false);
       if (c < bc * 0.999) { bc = c; best = cand[i]; }
     }
-    if (fc) {
+    if (fc || a.pro.mean) {
       const int cand2[6] = {124, 114, 142, 132, 122, 112};
       for (int i = 0; i < 6; ++i) {
         const int a_t = (cand2[i] / 10) % 10, c_t = cand2[i] % 10;
         if ((a.N % (16 * c_t)) != 0) continue;
-        if ((size_t)(2 * (64 * a_t + 2 * (a.W + 2) + 2) * 96 + 2 * ((10 * 16 * c_t * 6 + 255) / 256) * 4096 + 1024) > 160 * 1024) continue;
+        if ((size_t)(2 * (64 * a_t + 2 * (a.W + 2) + 2) * 96 + 2 * ((10 * 16 * c_t * 6 + 255) / 256) * 4096 + 1024 + 4 * fc_pro_dw(a)) > 160 * 1024) continue;
         const double c = fl_cost(a, a_t, c_t, true);
         if (c < bc * 0.999) { bc = c; best = cand2[i]; }
       }

@@ -1920,6 +1920,21 @@ int arco_conv_mblocks_mma(int taps, int NB, int H, int W, int Cin, int Cout, lon
   return q[0];
 }
 
+// ... for a launch through arco_conv3d_fwd_pro (consumer-side activation with pro_groups BatchNorm groups): the 3x3x3 kernels choose their
+// tile shape among the forms that have the activation in their loaders, so the slab count can differ from the plain launch's
+int arco_conv_mblocks_pro(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups, int mma, int pro_groups) {
+  if (taps != 27) return arco_conv_mblocks_mma(taps, NB, H, W, Cin, Cout, ld_in, stat_groups, mma);
+  if (mma != 3) return ARCO_ERR_UNSUPPORTED;
+  IgemmArgs a{};
+  a.NB = NB; a.H = H; a.W = W; a.M = (long)NB * H * W; a.D3 = 1;
+  a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in; a.ldc = Cout; a.mma = 3;
+  a.Kg = (Cin + 31) / 32 * 2; a.stat_groups = stat_groups > 1 ? stat_groups : 1;
+  static const float one = 1.f;
+  a.pro.mean = a.pro.istd = a.pro.gamma = a.pro.beta = &one; a.pro.groups = pro_groups > 1 ? pro_groups : 1;
+  int q[3] = {0, 0, 0};
+  return conv3d_fl_dispatch(a, nullptr, q) == ARCO_OK ? q[0] : ARCO_ERR_UNSUPPORTED;
+}
+
 // which igemm_kernel<TAPS,BM,BN,..> instantiation a launch uses: returns TAPS*1e6 + BM*1e3 + BN (kernel-tap form:
 // 9 for both 3x3 and 3x3x3); *kc_depth_db = KC*100 + DEPTH*10 + DB
 int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int* kc_depth_db) {
@@ -2075,6 +2090,17 @@ int arco_conv1x1_upres_fwd(const float* in, long ld_in, int K, const float* Wp, 
 // 1 when arco_conv3d_fwd_pro / arco_conv3d_wgrad_pro take a convolution of this shape with a consumer-side activation on its input
 // (the pipelined split-bf16 3x3 kernels of conv_sp.hip and wgrad_split_kernel); else the caller materialises the activation
 int arco_conv_pro_ok(int taps, int NV, int D3, int H, int W, int Cin, int Cout, long ld_in, int mma, int groups) {
+  if (taps == 27) {       // 3x3x3: conv3d_fc_kernel's loaders (conv3d_fl.hip; BatchNorm + ReLU / LeakyReLU, no dropout), gradient-free passes
+    if (mma != 3 || groups < 1 || NV % groups != 0 || D3 < 1 || (Cin & 15) != 0 || (ld_in & 3) != 0) return 0;
+    IgemmArgs a{};
+    a.NB = NV * D3; a.H = H; a.W = W; a.M = (long)a.NB * H * W; a.D3 = D3;
+    a.N = Cout; a.Npad = (Cout + 15) / 16 * 16; a.K = Cin; a.Kpad = (Cin + 15) / 16 * 16; a.lda = ld_in; a.ldc = Cout; a.mma = 3;
+    a.Kg = (Cin + 31) / 32 * 2; a.stat_groups = 1;
+    static const float one = 1.f;
+    a.pro.mean = a.pro.istd = a.pro.gamma = a.pro.beta = &one; a.pro.groups = groups;      // (query only: never dereferenced)
+    int q[3] = {0, 0, 0};
+    return conv3d_fl_dispatch(a, nullptr, q) == ARCO_OK ? 1 : 0;
+  }
   if (taps != 9 || D3 != 1 || mma != 3 || groups < 1 || NV % groups != 0 || (Cin & 15) != 0 || (Cout & 3) != 0 || (ld_in & 3) != 0) return 0;
   if ((long)NV * H * W * Cin >= (1l << 31)) return 0;          // 32-bit element indices of the dropout mask
   IgemmArgs a{};
@@ -2125,6 +2151,11 @@ static int conv3d_fwd_impl(const float* in, long ld_in, int K, const float* Wp, 
     a.Kpad = taps == 1 ? a.Kg * 16 : (K + 15) / 16 * 16;
   }
   ARCO_CHECK_ARG(NV % a.stat_groups == 0);
+  if (pro && taps == 27) {      // (arco_conv_pro_ok has vouched for the shape: conv3d_fc_kernel<.., PRO>)
+    a.pro = *pro;
+    const int r = conv3d_fl_dispatch(a, as_stream(stream), nullptr);
+    return r == -1 ? ARCO_ERR_UNSUPPORTED : r;
+  }
   if (pro) {            // (arco_conv_pro_ok has vouched for the shape: the launch below lands in conv_sp_dispatch)
     a.pro = *pro;
     const int r = conv_sp_dispatch(a, as_stream(stream), nullptr);

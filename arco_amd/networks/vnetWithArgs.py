@@ -87,6 +87,10 @@ class ConvBlock(nn.Module):
         self.per = 2 if normalization == 'none' else 3
 
     def forward(self, x):
+        if self.training and self.per == 3 and self.n_stages >= 2 and isinstance(self.conv[1], nn.BatchNorm3d):
+            stages = [(self.conv[3 * i], self.conv[3 * i + 1]) for i in range(self.n_stages)]
+            if ops.block3d_fusable(x, stages):       # gradient-free pass: only the last stage's activation is written
+                return ops.conv_block3d_nograd(x, stages)
         for i in range(self.n_stages):
             conv = self.conv[self.per * i]
             x = _stage(x, conv, self.conv[self.per * i + 1] if self.per == 3 else None, self.training)

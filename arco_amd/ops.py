@@ -460,7 +460,7 @@ def use_half(x, taps, ci):
 
 
 def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=0, stats=False, d3=1, sp=None,
-             stat_groups=1, grad=False, half=False, pro=None, out=None):
+             stat_groups=1, grad=False, half=False, pro=None, out=None, pro_groups=1):
     """out[pix][0..n) = conv(x)(+bias)(+residual); returns (out channels-last, stat slabs or None).
     2-D: nb images of h x w -> out [nb,n,h,w].  3-D (d3 > 1): nb volumes of d3 planes -> out [nb,n,d3,h,w].
     half: f16 activation storage - out (and xr, unless k == 1) are f16, wp is the f16 pack (k == 1: the fp32 pack).
@@ -496,7 +496,10 @@ def conv_raw(xr, ld, k, wp, n, nb, h, w, taps, bias=None, residual=None, ld_res=
     ssum = ssq = None
     nmb = 0
     if stats:
-        nmb = L.query("arco_conv_mblocks_mma", taps, nb * d3, h, w, k, n, ld, stat_groups, mma)
+        if pro is not None and taps == 27:       # the 3x3x3 forms with the activation in their loaders tile differently
+            nmb = L.query("arco_conv_mblocks_pro", taps, nb * d3, h, w, k, n, ld, stat_groups, mma, pro_groups)
+        else:
+            nmb = L.query("arco_conv_mblocks_mma", taps, nb * d3, h, w, k, n, ld, stat_groups, mma)
         ssum = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
         ssq = torch.empty((n, nmb), dtype=torch.float32, device=xr.device)
     if WORK is not None:
@@ -920,6 +923,59 @@ class ConvBnActFn(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
+def conv_block3d_nograd(x, stages):
+    """A V-Net ConvBlock (vnetWithArgs.py:5-31: n_stages x [Conv3d(3, pad 1) - BatchNorm3d(train) - ReLU]) in a GRADIENT-FREE pass (the
+    teacher's forwards, the warped student pass of the equivariance term): only the last stage writes its activation.  Stage i + 1 reads
+    stage i's pre-activation z_i through the consumer-side activation of conv3d_fc_kernel's loaders (arco_conv3d_fwd_pro; the arithmetic
+    is bn_act_fwd_kernel's: results bit-identical to the staged route, tests/test_block_fuse_gpu.py) - one launch and one write + read of
+    the activation less per link.  stages: [(conv, bn), ...]; the caller has checked block3d_fusable."""
+    L.require_gpu(x)
+    xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
+    G = BN_GROUPS
+    if G > 1 and nv % G != 0:
+        raise RuntimeError(f"arco_amd: bn_groups({G}) needs a batch that is a multiple of {G}, got {nv}")
+    m = nv * d3 * h * w
+    pro = None
+    zr, ldz, k = xr, ld, ci
+    for conv, bn in stages:
+        co = int(conv.weight.shape[0])
+        z, (ssum, ssq, nmb) = conv_raw(zr, ldz, k, pack_weight(conv.weight, 27, 0), co, nv, h, w, 27, bias=conv.bias, stats=True, d3=d3, sp=sp,
+                                       stat_groups=G, pro=pro, pro_groups=G)
+        mean, istd = _finalize_bn(ssum, ssq, nmb, co, m, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked, G, x.device)
+        zr, ldz = rows_view(z)
+        k = co
+        pro = L.act_pro(mean, istd, bn.weight, bn.bias, 0.0, G, 0, 0.0, 0, None)
+        last = (z, mean, istd, bn, co)
+    z, mean, istd, bn, co = last
+    a = new_act_nd(nv, co, sp, x.device)
+    _bn_apply(zr, ldz, m, co, mean, istd, bn.weight, bn.bias, 0.0, 0, 0.0, 0, d3 * h * w, a, co, G)
+    block_fuse_stats["fused3d"] = block_fuse_stats.get("fused3d", 0) + len(stages) - 1
+    return a
+
+
+def block3d_fusable(x, stages):
+    """Can conv_block3d_nograd run this block?  fp32 activations, the split-bf16 mode, no gradient, at least two stages, and every
+    stage -> stage link a shape conv3d_fc_kernel's loaders take (arco_conv_pro_ok)."""
+    if not BLOCK_FUSE3D or torch.is_grad_enabled() or len(stages) < 2 or CONV_MMA != 3 or x.dtype != torch.float32 or x.dim() != 5 or not x.is_cuda:
+        return False
+    xr, ld, nv, d3, h, w, ci, sp = _geom_nd(x)
+    G = BN_GROUPS
+    if G > 1 and nv % G != 0:
+        return False
+    k = int(stages[0][0].weight.shape[0])
+    if not _split_ok(27, nv * d3, h, w, ci, k, ld):
+        return False
+    for conv, _ in stages[1:]:
+        co = int(conv.weight.shape[0])
+        if not pro_ok(27, nv, d3, h, w, k, co, k, G):
+            return False
+        k = co
+    return True
+
+
+# A/B switch of conv_block3d_nograd; OFF by default: measured level with the staged route (the loaders' prologue costs what the apply
+# pass of these small tensors costs: tools/micro/fl_pro_bench.py, profiles/r06_notes.md section 10; LA step 24.9-25.0 -> 25.1-25.2 ms)
+BLOCK_FUSE3D = int(__import__('os').environ.get('ARCO_BLOCK_FUSE3D', '0'))
 BLOCK_FUSE = int(__import__('os').environ.get('ARCO_BLOCK_FUSE', '1'))    # A/B switch: 0 = every stage writes its activation (rounds 1-5)
 block_fuse_stats = {"fused": 0, "unfused": 0}       # how often conv_block took each route (tests, bench)
 

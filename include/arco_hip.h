@@ -138,6 +138,7 @@ int arco_gemm_splitk(const float* in, long ld_in, int K, const float* Wp, int N,
                      int splits, float* ws, void* stream);
 int arco_conv_mblocks(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups);
 int arco_conv_mblocks_mma(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups, int mma);   /* ... for a launch in matrix-core mode mma (arco_conv3d_fwd) */
+int arco_conv_mblocks_pro(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int stat_groups, int mma, int pro_groups);   /* ... for a launch through arco_conv3d_fwd_pro (3x3x3: the forms with the activation in their loaders tile differently) */
 /* which kernel instantiation a launch uses: igemm_kernel<TAPS,BM,BN,..> -> TAPS*1e6 + BM*1e3 + BN;
  * conv3x3_halo_kernel<CIN,COUT,..> -> 9.9e6 + CIN*1e3 + COUT */
 int arco_conv_config(int taps, int NB, int H, int W, int Cin, int Cout, long ld_in, int* kc_depth_db);

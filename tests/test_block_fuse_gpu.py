@@ -154,3 +154,39 @@ def test_whole_unet_fused_equals_unfused():
     assert nb_ == 0 and na >= 3, (na, nb_)
     for i, (u, v) in enumerate(zip(a, b)):
         assert torch.equal(u, v), (i, float((u.float() - v.float()).abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [dict(n=2, c=32, sp=(9, 28, 20), nv=2, groups=1), dict(n=3, c=64, sp=(7, 14, 10), nv=4, groups=2),
+                                 dict(n=3, c=128, sp=(5, 7, 5), nv=2, groups=2), dict(n=2, c=32, sp=(12, 56, 40), nv=2, groups=2)])
+def test_vnet_convblock_gradient_free_pass_fuses_its_stage_links(cfg):
+    """vnetWithArgs.py:5-31 in a gradient-free pass (the teacher's forwards, the warped student pass): stage i + 1 reads stage i's
+    pre-activation through conv3d_fc_kernel's loaders (ops.conv_block3d_nograd) - output and running statistics bit-identical to the
+    staged route; with gradients enabled the block takes the staged route.  (Opt-in, ops.BLOCK_FUSE3D: measured level with the staged route.)"""
+    from arco_amd import ops
+    from arco_amd.networks.vnetWithArgs import ConvBlock
+    torch.manual_seed(cfg["c"] + cfg["n"])
+    blk = ConvBlock(cfg["n"], cfg["c"], cfg["c"], normalization='batchnorm').cuda().train()
+    x = torch.randn(cfg["nv"], cfg["c"], *cfg["sp"], device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    state0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    prev, prev_mma = ops.BLOCK_FUSE3D, ops.CONV_MMA
+    ops.CONV_MMA = 3
+    out, states, fused = {}, {}, {}
+    try:
+        for on in (0, 1):
+            ops.BLOCK_FUSE3D = on
+            blk.load_state_dict(state0)
+            n0 = ops.block_fuse_stats.get("fused3d", 0)
+            with torch.no_grad(), ops.bn_groups(cfg["groups"]):
+                out[on] = blk(x).clone()
+            fused[on] = ops.block_fuse_stats.get("fused3d", 0) - n0
+            states[on] = {k: v.clone() for k, v in blk.state_dict().items()}
+        ops.BLOCK_FUSE3D = 1
+        n0 = ops.block_fuse_stats.get("fused3d", 0)
+        y = blk(x.clone().requires_grad_(True))              # gradients enabled: staged route
+        assert ops.block_fuse_stats.get("fused3d", 0) == n0 and y.requires_grad
+    finally:
+        ops.BLOCK_FUSE3D, ops.CONV_MMA = prev, prev_mma
+    assert fused == {0: 0, 1: cfg["n"] - 1}
+    assert torch.equal(out[0], out[1])
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
