@@ -584,6 +584,9 @@ def conv_wgrad(dzr, ldz, co, xr, ldx, ci, taps, nb, h, w, like, d3=1, pro=None):
 # to a co-resident weight-gradient workgroup than the tails give back); the 3-D LA step gains 3 % only with EAGER student passes
 # (30.1 -> 29.2 ms: two queues hide host launch time), nothing under the default graph replay (30.1-30.6 both ways; LiTS f16
 # 20.5 vs 20.7).  Hence: off by default, kept as a knob (ARCO_WGRAD_SIDE=1..3).
+# Round 6: with the pipelined 3x3x3 kernels the LA step gains 0.3-0.5 ms from mode 3 under graph replay (24.9 / 24.8 / 25.7 -> 24.6 / 24.4 / 25.2 ms,
+# same box, alternating; LiTS-f16 level, the 2-D step 11.0-11.2 -> 12.2-12.3): the 3-D trainer's constructor sets 3, the 2-D trainer's 0,
+# unless ARCO_WGRAD_SIDE is given.
 _WGRAD_SIDE_ENV = __import__('os').environ.get('ARCO_WGRAD_SIDE')
 WGRAD_SIDE = int(_WGRAD_SIDE_ENV) if _WGRAD_SIDE_ENV is not None else 0
 _side = {"stream": None, "keep": [], "dirty": False}

@@ -176,6 +176,8 @@ class ArcoStep2D:
             raise ValueError(f"--conv_mma {mma}: the 2-D step computes in f32x3 or f32; f16 / bf16 operands are a 3-D trainer mode")
         ops.CONV_MMA = {"f32": 0, "f32x3": 3}[mma]
         ops.HEAD_MMA = 0                 # (a 3-D trainer of this process may have set the heads' reduced-precision mode)
+        if ops._WGRAD_SIDE_ENV is None:
+            ops.WGRAD_SIDE = 0           # (... and the side-stream weight gradients: 11.0-11.2 -> 12.2-12.3 ms on this step)
         self.random_pool = None
         if getattr(args, "revisit", 0):
             # random_pool (:156-159) is drawn before the models are created, like the reference (same CPU-generator order)

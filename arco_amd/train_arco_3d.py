@@ -121,6 +121,8 @@ class ArcoStep3D:
         self.plans = [plan_s] + [pl for pr in pairs for pl in pr.plans] + self.k_fe_ema.plans
         self.iter_num = 0
         self._side, self._tps_pending = None, False
+        if ops._WGRAD_SIDE_ENV is None:        # weight gradients on the side stream behind their data gradient: -0.3 .. -0.5 ms on the LA step with
+            ops.WGRAD_SIDE = 3                 # round 6's 3x3x3 kernels (level on LiTS-f16; the 2-D step loses 1 ms with it: train_arco_2d resets it)
         self._ovf_host, self._ovf_event, self.overflow_steps, self._clean_steps = None, None, 0, 0     # f16 overflow guard
         self.keep_debug = False          # tests: keep the last step's plan and anchor rows (self.debug)
         use_graphs = bool(getattr(args, "graphs", 1))

@@ -274,6 +274,45 @@ def test_pass_concurrency_3d_equals_the_single_stream_step(side_mode):
         T3.PASS_SIDE = prev
 
 
+@pytest.mark.parametrize("graphs", [0, 1])
+def test_weight_gradients_on_the_side_stream_3d_equal_the_single_stream_step(graphs):
+    """ops.WGRAD_SIDE = 3 (the 3-D trainer's default since round 6: every layer's weight gradient forks behind its data gradient and
+    runs beside the next layer's BatchNorm backward; joined before the optimiser) against 0 (everything on one stream), three steps
+    from equal state, eager and graph-replayed student passes: the same kernels on the same operands - weights bit-identical."""
+    from arco_amd import ops, train_arco_3d as T3
+    prev = ops.WGRAD_SIDE
+    try:
+        sts = []
+        for mode in (0, 3):
+            random.seed(4); np.random.seed(4); torch.manual_seed(4)
+            args = T3.build_parser().parse_args(["--batch_size", "1", "--queue_size", "200", "--synthetic", "1", "--num_classes", "4",
+                                                 "--num_queries", "48", "--num_negatives", "16", "--k1", "1.0", "--graph_train", str(graphs)])
+            args.patch_size = [32, 32, 32]
+            st = T3.ArcoStep3D(args, "cuda:0")
+            assert ops.WGRAD_SIDE == 3                     # the constructor's default (ARCO_WGRAD_SIDE unset)
+            for m in (st.model, st.ema_model):
+                _drop_off(m)
+            sts.append(st)
+        st_a, st_b = sts
+        with torch.no_grad():
+            st_b.optimizer.flat_p.copy_(st_a.optimizer.flat_p)
+            for md, ms in ((st_b.model, st_a.model), (st_b.ema_model, st_a.ema_model), (st_b.k_feature_extractor, st_a.k_feature_extractor)):
+                for (kd, vd), (ks, vs) in zip(md.state_dict().items(), ms.state_dict().items()):
+                    vd.copy_(vs)
+        ops.bump_weight_epoch()
+        for it in range(3):
+            l, ll = T3.synthetic_volume_batch(1, (32, 32, 32), 4, 10 + it, "cuda:0")
+            u, _ = T3.synthetic_volume_batch(1, (32, 32, 32), 4, 20 + it, "cuda:0")
+            for st, mode in ((st_a, 0), (st_b, 3)):
+                ops.WGRAD_SIDE = mode
+                random.seed(60 + it); np.random.seed(60 + it); torch.manual_seed(60 + it)
+                st.step(l, ll, u)
+                torch.cuda.synchronize()
+            assert torch.equal(st_a.optimizer.flat_p, st_b.optimizer.flat_p), it
+    finally:
+        ops.WGRAD_SIDE = prev
+
+
 def test_three_steps_3d_free_running_chain_is_reported():
     """The same three 3-D steps as `sparse_c4` above, FREE-RUNNING: the HIP step and the CPU oracle start from equal
     state once and are never re-synchronised, and the oracle takes its own gradient-free decisions (no `force=`).  The docs argue that
