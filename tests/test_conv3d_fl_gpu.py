@@ -125,3 +125,33 @@ def test_pipelined_f16_3x3x3_kernel_equals_hconv_kernel(shape):
         assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-4)
     got = res[1][0].double().view(groups, nv // groups, co, -1)
     assert torch.allclose(res[1][1].t(), got.sum((1, 3)), rtol=1e-4, atol=1e-2)             # statistics of the ROUNDED outputs
+
+
+@pytest.mark.parametrize("c,sp", [(32, (56, 56, 40)), (64, (28, 28, 20)), (128, (14, 14, 10)), (256, (7, 7, 5))])
+def test_la_levels_direct_sums_and_linearity(c, sp):
+    """The V-Net's 3x3x3 levels at the LA patch (4 volumes, BASELINE.json configs[2]) held to properties that do not go through any
+    other kernel of this library: exact direct sums at the eight corners (zero padding on every face), one edge and one interior voxel,
+    linearity, and invariance of a volume's output to what the other volumes of the launch hold (no tile reads across volumes)."""
+    from arco_amd import ops
+    prev_mma = ops.CONV_MMA
+    ops.CONV_MMA = 3
+    try:
+        g = torch.Generator(device="cuda").manual_seed(c)
+        d, h, w = sp
+        x1 = torch.randn((4, d, h, w, c), device="cuda", generator=g).permute(0, 4, 1, 2, 3)
+        x2 = torch.randn((4, d, h, w, c), device="cuda", generator=g).permute(0, 4, 1, 2, 3)
+        wt = torch.randn((c, c, 3, 3, 3), device="cuda", generator=g) / (27 * c) ** 0.5
+        with torch.no_grad():
+            y1, y2 = ops.conv(x1, wt, None), ops.conv(x2, wt, None)
+            y12 = ops.conv((0.5 * x1 + x2).contiguous(memory_format=torch.channels_last_3d), wt, None)
+            assert float(((0.5 * y1 + y2) - y12).abs().max()) < 2e-5 * float(y12.abs().max()) + 1e-6
+            xm = x1.clone(); xm[1:] = x2[1:]
+            ym = ops.conv(xm.contiguous(memory_format=torch.channels_last_3d), wt, None)
+            assert torch.equal(ym[0], y1[0]) and torch.equal(ym[1:], y2[1:])
+            xp = torch.nn.functional.pad(x1[3:].double(), (1, 1, 1, 1, 1, 1))
+            pts = [(a, b, e) for a in (0, d - 1) for b in (0, h - 1) for e in (0, w - 1)] + [(d // 2, 0, w // 2), (d // 2, h // 2, w // 2)]
+            for (a, b, e) in pts:
+                ref = (wt.double() * xp[0, :, a:a + 3, b:b + 3, e:e + 3].unsqueeze(0)).sum(dim=(1, 2, 3, 4))
+                assert float((y1[3, :, a, b, e].double() - ref).abs().max()) < 3e-6 * float(ref.abs().max()) + 1e-6, (a, b, e)
+    finally:
+        ops.CONV_MMA = prev_mma
