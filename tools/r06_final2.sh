@@ -1,11 +1,8 @@
 #!/bin/bash
-# on the GPU box: the round's final evidence after the 3x3x3 kernel work -> gpurun_out/r06d_*
+# on the GPU box: the round's final evidence (last commit) -> gpurun_out/r06e_*
 root=$(pwd); o=$root/gpurun_out; export TMPDIR=/tmp; mkdir -p $o
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $o/r06d_tests.log
-python -c "import __graft_entry__ as g; g.smoke()" >> $o/r06d_tests.log 2>&1
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $o/r06d_bench.json 2> $o/r06d_bench.err
-bash tools/prof_run3d.sh r06d > $o/r06d_prof3d.txt 2>&1
-bash tools/prof_run3d.sh r06d_lits "SHAPE=1 160 160 96" ACT_DTYPE=f16 > $o/r06d_prof3d_lits.txt 2>&1
-bash tools/prof_run.sh r06d 40 > $o/r06d_prof2d.txt 2>&1
-bash tools/prof_bench.sh r06d > $o/r06d_prof_bench.txt 2>&1
-cat $o/r06d_tests.log; tail -c 300 $o/r06d_bench.json; head -3 $o/r06d_prof3d.txt | cut -c1-160; head -3 $o/r06d_prof3d_lits.txt | cut -c1-160; head -3 $o/r06d_prof2d.txt | cut -c1-160; tail -3 $o/r06d_prof_bench.txt | cut -c1-200
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $o/r06e_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" >> $o/r06e_tests.log 2>&1
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $o/r06e_bench.json 2> $o/r06e_bench.err
+bash tools/prof_run3d.sh r06e > $o/r06e_prof3d.txt 2>&1
+cat $o/r06e_tests.log; tail -c 300 $o/r06e_bench.json; head -3 $o/r06e_prof3d.txt | cut -c1-160; head -3 $o/r06e_prof3d_lits.txt | cut -c1-160; head -3 $o/r06e_prof2d.txt | cut -c1-160; tail -3 $o/r06e_prof_bench.txt | cut -c1-200
