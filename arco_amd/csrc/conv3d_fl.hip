@@ -1133,10 +1133,11 @@ int conv3d_fl_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
       if (c < bc * 0.999) { bc = c; best = cand[i]; }
     }
     if (fc || a.pro.mean) {
-      const int cand2[6] = {124, 114, 142, 132, 122, 112};
-      for (int i = 0; i < 6; ++i) {
+      const int cand2[7] = {124, 114, 152, 142, 132, 122, 112};
+      for (int i = 0; i < 7; ++i) {
         const int a_t = (cand2[i] / 10) % 10, c_t = cand2[i] % 10;
-        if ((a.N % (16 * c_t)) != 0) continue;
+        static const int no5 = getenv("ARCO_CONV3D_FL_NO5") ? atoi(getenv("ARCO_CONV3D_FL_NO5")) : 0;      // A/B: without the 320-position tiles
+        if ((a.N % (16 * c_t)) != 0 || (no5 && a_t == 5)) continue;
         if ((size_t)(2 * (64 * a_t + 2 * (a.W + 2) + 2) * 96 + 2 * ((10 * 16 * c_t * 6 + 255) / 256) * 4096 + 1024 + 4 * fc_pro_dw(a)) > 160 * 1024) continue;
         const double c = fl_cost(a, a_t, c_t, true);
         if (c < bc * 0.999) { bc = c; best = cand2[i]; }
@@ -1146,6 +1147,7 @@ int conv3d_fl_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   switch (best) {
     case 124: if ((a.N & 63) == 0 && fc_fits<2, 4>(a)) return launch_fc<2, 4>(a, st, q); break;
     case 114: if ((a.N & 63) == 0 && fc_fits<1, 4>(a)) return launch_fc<1, 4>(a, st, q); break;
+    case 152: if (fc_fits<5, 2>(a)) return launch_fc<5, 2>(a, st, q); break;
     case 142: if (fc_fits<4, 2>(a)) return launch_fc<4, 2>(a, st, q); break;
     case 132: if (fc_fits<3, 2>(a)) return launch_fc<3, 2>(a, st, q); break;
     case 122: if (fc_fits<2, 2>(a)) return launch_fc<2, 2>(a, st, q); break;
