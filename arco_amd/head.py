@@ -250,23 +250,43 @@ def _row_grad_buffer_h(ptr, shape, dev):
 # arrival order decides f16 roundings downstream; profiles/r05_notes.md section 7).  ARCO_DET_SCATTER = 0: fp32 atomics everywhere;
 # 1 (default): the 3-D head order-independent; 2: the 2-D heads too (17 more small launches on the 2-D step's critical path).
 DET_SCATTER = int(os.environ.get("ARCO_DET_SCATTER", "1"))
+# The fixed-point accumulators of the order-independent scatter: one int64 buffer of the destination's size per (device, rows, channels),
+# kept between steps (zero between uses: every call clears exactly the rows it touched) - 315 MB for the LiTS-shaped full-resolution map,
+# 80 MB for its half-resolution one (a trainer uses two).  Nothing evicts them behind the caller's back - captured HIP graphs hold their
+# addresses; release_det_buffers() frees them once no graph that used them will be replayed.  A buffer first created inside a capture
+# lives in that graph's pool, which is why the trainers run their first steps eagerly.  Resolution: values are scaled to the launch-wide largest magnitude, so a contribution below 2^-45 of that
+# maximum is dropped - far below one fp32 ulp of any sum the maximum takes part in, not of a row that only holds tiny values.
 _ACC64 = {}
+
+
+def _det_acc(dev, rows, C):
+    key = (dev.index, rows, C)
+    acc = _ACC64.get(key)
+    if acc is None:
+        acc = _ACC64[key] = torch.zeros((rows, C), dtype=torch.int64, device=dev)
+    return acc
+
+
+def release_det_buffers():
+    """Free the int64 accumulators of the order-independent scatter (they are re-created, zeroed, on the next use)."""
+    _ACC64.clear()
 
 
 def _det_scatter_rows(src, ld_src, C, div, idx, w, n_e, dst, ld_dst):
     """dst[idx[e]] = sum over e of w[e] * src[e // div] (C channels), dst rows zero before; src: [n_e // div, >= C] fp32 view."""
     dev = src.device
     rows = dst.numel() // ld_dst
-    key = (dev.index, rows, C)
-    acc = _ACC64.get(key)
-    if acc is None:
-        acc = _ACC64[key] = torch.zeros((rows, C), dtype=torch.int64, device=dev)
+    acc = _det_acc(dev, rows, C)
     mb = torch.empty(1, dtype=torch.int32, device=dev)
-    L.call("arco_det_absmax", L.ptr(src), ld_src, C, n_e // div, L.ptr(mb))
-    L.call("arco_det_scatter_rows", L.ptr(src), ld_src, C, div, None, L.ptr(idx), None if w is None else L.ptr(w), n_e,
-           L.ptr(acc), C, L.ptr(mb))
-    L.call("arco_det_finish_rows", None, L.ptr(idx), n_e, L.ptr(acc), C, C, L.ptr(mb), 1.0, L.ptr(dst), ld_dst)
-    L.call("arco_det_clear_rows", None, L.ptr(idx), n_e, L.ptr(acc), C, C)
+    try:
+        L.call("arco_det_absmax", L.ptr(src), ld_src, C, n_e // div, L.ptr(mb))
+        L.call("arco_det_scatter_rows", L.ptr(src), ld_src, C, div, None, L.ptr(idx), None if w is None else L.ptr(w), n_e,
+               L.ptr(acc), C, L.ptr(mb))
+        L.call("arco_det_finish_rows", None, L.ptr(idx), n_e, L.ptr(acc), C, C, L.ptr(mb), 1.0, L.ptr(dst), ld_dst)
+        L.call("arco_det_clear_rows", None, L.ptr(idx), n_e, L.ptr(acc), C, C)
+    except Exception:
+        _ACC64.pop((dev.index, rows, C), None)      # "zero between uses" may no longer hold: the next call starts from a fresh buffer
+        raise
 
 
 def _scatter_upcat2d(dX, ldx, pix, n, dlo, clo, hi_h, hi_w, dhi, chi, ho, wo):
