@@ -2202,6 +2202,7 @@ int arco_conv3d_wgrad_pro(const float* dZ, long ld_dz, int Cout, const float* in
                           int D3, int H, int W, float* ws, float* dW, int accumulate, int mma, const ArcoActPro* pro, void* stream) {
   ARCO_CHECK_ARG(pro && pro->mean && pro->istd && pro->gamma && pro->beta && pro->groups >= 1 && (pro->drop_mode == 0 || pro->drop_mode == 1) &&
                  pro->p >= 0.f && pro->p < 1.f);
+  if (taps != 9) return ARCO_ERR_UNSUPPORTED;        // (the 3x3x3 consumer-side activation exists in the forward kernel only: gradient-free passes)
   if (!arco_conv_pro_ok(taps, NV, D3, H, W, Cin, Cout, ld_in, mma, pro->groups) || (ld_dz & 3) != 0) return ARCO_ERR_UNSUPPORTED;
   return conv3d_wgrad_impl(dZ, ld_dz, Cout, in, ld_in, Cin, taps, NV, D3, H, W, ws, dW, accumulate, mma, pro, stream);
 }

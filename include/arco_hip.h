@@ -194,7 +194,9 @@ typedef struct ArcoActPro {
   int drop_mode; float p;                 /* 0: none; 1: nn.Dropout(p), the stateless mask of arco_bn_act_fwd (element = pixel*K + k) */
   unsigned long long seed; const unsigned long long* seed_dev;   /* as arco_bn_act_fwd (seed_dev: per-replay salt of a HIP graph)    */
 } ArcoActPro;
-/* 1 when the two entry points below take the shape (3x3, split-bf16 mode 3, the pipelined kernels); else the caller runs
+/* 1 when the entry points below take the shape (taps = 9: 3x3, split-bf16 mode 3, the pipelined kernels - forward and weight gradient;
+ * taps = 27: the V-Net's 3x3x3 stage -> stage links (vnetWithArgs.py:5-31; conv3d_fc_kernel's loaders, BatchNorm + ReLU, no dropout) -
+ * FORWARD ONLY, for gradient-free passes, with the BatchNorm slab count from arco_conv_mblocks_pro); else the caller runs
  * arco_bn_act_fwd and the plain entry points */
 int arco_conv_pro_ok(int taps, int NV, int D3, int H, int W, int Cin, int Cout, long ld_in, int mma, int groups);
 int arco_conv3d_fwd_pro(const float* z_in, long ld_in, int K, const float* Wp, int N, float* out, long ld_out,
