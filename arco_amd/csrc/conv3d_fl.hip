@@ -1,6 +1,8 @@
 // Software-pipelined split-bf16 3x3x3 convolution for the V-Net levels below full resolution (ConvBlock / the stages of the
 // up path, vnetWithArgs.py:5-31, 222-262: 32 -> 32 on 56 x 40 planes, 64 -> 64 on 28 x 20, 128 -> 128 on 14 x 10, 256 -> 256 on
 // 7 x 5 at the LA patch; forward and, with flipped + transposed packed weights, the data gradient).
+// (-DARCO_FC_CLOCK: a DIAGNOSTIC build of conv3d_fc_kernel with s_memtime stamps into a buffer of their own - tools/micro/fc_clock.py; never in the
+//  shipped library.)
 //
 // Same arithmetic as igemm_kernel<9,...,FLAT,DEPTH=3,MMA=3> (igemm.hip), operation for operation - the outputs are bit-identical,
 // asserted in tests/test_conv3d_fl_gpu.py - in the execution structure of conv3x3_sp_kernel (conv_sp.hip):
@@ -23,6 +25,9 @@
 #include "sp_util.h"
 
 __device__ __attribute__((aligned(64))) unsigned int conv3d_fl_zero_row[32];      // zero-initialised: the "tap 9" weights of a slice
+#ifdef ARCO_FC_CLOCK
+__device__ unsigned long long* arco_fc_clock_buf = nullptr;       // (diagnostic build: stamps go to a buffer of their own)
+#endif
 
 template <int A_T, int C_T>
 struct FlGeom {
@@ -533,16 +538,38 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
     store_all(As + A_DW, 1);
     load_A(d3, total_gc > 3, 1);
     Desc dn = d3; advance(dn);         // chunk k + 4
+#ifdef ARCO_FC_CLOCK
+    unsigned long long pc_bar = 0, pc_dma = 0, pc_store = 0, pc_load = 0, pc_wait = 0;
+#endif
     Desc dw_ = d2;                     // chunk k + 2 (its weights)
     for (int k = 0; k < total_gc; k += 2) {          // two chunks per trip: the register sets keep their roles at the loop edge
       wait_lgkm0();
+#ifdef ARCO_FC_CLOCK
+      const unsigned long long pb0 = __builtin_amdgcn_s_memtime();
+#endif
       __builtin_amdgcn_s_barrier();    // barrier k
+#ifdef ARCO_FC_CLOCK
+      const unsigned long long pb1 = __builtin_amdgcn_s_memtime();
+#endif
       load_W(dw_, 0); advance(dw_);    // chunk k + 2's weights into the buffer chunk k has finished with
       wait_vm<NL + NW>();              // chunk k + 2's activations (loaded two chunks ago; after the first trip they have landed long before)
+#ifdef ARCO_FC_CLOCK
+      const unsigned long long pb2 = __builtin_amdgcn_s_memtime();
+#endif
       store_all(As, 0);
+#ifdef ARCO_FC_CLOCK
+      const unsigned long long pb3 = __builtin_amdgcn_s_memtime();
+#endif
       load_A(dn, k + 4 < total_gc, 0);
       advance(dn);
+#ifdef ARCO_FC_CLOCK
+      const unsigned long long pb4 = __builtin_amdgcn_s_memtime();
+#endif
       wait_vm<NL>();                   // the weight burst has landed (and chunk k + 3's activations); only chunk k + 4's loads are younger
+#ifdef ARCO_FC_CLOCK
+      { const unsigned long long pb5 = __builtin_amdgcn_s_memtime();
+        pc_bar += pb1 - pb0; pc_dma += pb2 - pb1; pc_store += pb3 - pb2; pc_load += pb4 - pb3; pc_wait += pb5 - pb4; }
+#endif
       if (k + 1 < total_gc) {
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();  // barrier k + 1
@@ -555,6 +582,12 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
       }
     }
     wait_vm<0>();
+#ifdef ARCO_FC_CLOCK
+    if (!PRO && threadIdx.x == 256 && arco_fc_clock_buf && blockIdx.x < 512) {      // (even chunks only: half of the intervals)
+      unsigned long long* o = arco_fc_clock_buf + 8 * 512 + 8 * blockIdx.x;
+      o[0] = pc_bar; o[1] = pc_dma; o[2] = pc_store; o[3] = pc_load; o[4] = pc_wait; o[5] = (unsigned long long)((total_gc + 1) / 2);
+    }
+#endif
     return;
   }
 
@@ -585,6 +618,9 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) fb[0][ct][pl] = lds_bf16x8(Ws + laneB + ct * 16 * 24 + 8 * pl);
 
+#ifdef ARCO_FC_CLOCK
+  unsigned long long clk_bar = 0, clk_epi = 0, clk_e1 = 0, clk_e2 = 0;
+#endif
   auto chunk = [&](auto CP_, int gc, bool more) {
     constexpr int CP = decltype(CP_)::value;               // B set of step 0 (5 steps per chunk: alternates per chunk)
     const unsigned* Acur = As + (gc & 1) * A_DW;
@@ -596,7 +632,13 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
       constexpr int P = (CP + S) & 1, Q = P ^ 1;
       if (S == 4) {                    // the one rendezvous of the chunk: the next chunk is complete, this one's buffers are free
         wait_lgkm0();
+#ifdef ARCO_FC_CLOCK
+        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef ARCO_FC_CLOCK
+        clk_bar += __builtin_amdgcn_s_memtime() - tb0;
+#endif
       }
       constexpr int BPA = (C_T * 3 + A_T - 1) / A_T;        // next-step B reads per pixel tile
       const unsigned* An = S < 4 ? Acur : Anxt;
@@ -631,6 +673,9 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
 
   const float inv_wp = 1.0f / (float)Wp;
   auto tile_end = [&]() {
+#ifdef ARCO_FC_CLOCK
+    const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     const int n0 = d0.nblk * BN;
     long pix[A_T];
@@ -640,6 +685,10 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
       const int y = (int)(((float)f + 0.5f) * inv_wp), xq = f - y * Wp;
       pix[at] = (y < a.H && xq >= 1 && xq <= a.W) ? ((long)d0.img * a.H + y) * a.W + xq - 1 : -1;
     }
+#ifdef ARCO_FC_CLOCK
+    const unsigned long long te1 = __builtin_amdgcn_s_memtime();
+    clk_e1 += te1 - te0;
+#endif
     float s1[C_T][4], s2[C_T][4];
 #pragma unroll
     for (int ct = 0; ct < C_T; ++ct) {
@@ -659,6 +708,10 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
         acc[at][ct] = f32x4{0, 0, 0, 0};
       }
     }
+#ifdef ARCO_FC_CLOCK
+    const unsigned long long te2 = __builtin_amdgcn_s_memtime();
+    clk_e2 += te2 - te1;
+#endif
     if (has_stats) {
       const long slab = (long)d0.mblk * 4 + wid, nslab = (long)a.n_mblocks * 4;
 #pragma unroll
@@ -672,7 +725,13 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
           }
         }
     }
+#ifdef ARCO_FC_CLOCK
+    clk_epi += __builtin_amdgcn_s_memtime() - te0;
+#endif
   };
+#ifdef ARCO_FC_CLOCK          // DIAGNOSTIC build only (tools/micro/fc_clock.py): the in-kernel clock under the kernel's own load
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int gc = 0; gc < total_gc; gc += 2) {
     chunk(std::integral_constant<int, 0>{}, gc, gc + 1 < total_gc);
     if (d0.vc + 1 == nvc) tile_end();
@@ -683,7 +742,19 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
       advance(d0);
     }
   }
+#ifdef ARCO_FC_CLOCK
+  if (!PRO && threadIdx.x == 0 && arco_fc_clock_buf && blockIdx.x < 512) {
+    unsigned long long* o = arco_fc_clock_buf + 8 * blockIdx.x;
+    o[0] = __builtin_amdgcn_s_memtime() - clk_t0; o[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    o[2] = (unsigned long long)total_gc * 30 * A_T * C_T; o[3] = (unsigned long long)my_tiles;
+    o[4] = clk_bar; o[5] = clk_epi; o[6] = (unsigned long long)total_gc; o[7] = (clk_e1 << 32) | (clk_e2 & 0xffffffffull);
+  }
+#endif
 }
+
+#ifdef ARCO_FC_CLOCK
+extern "C" void arco_fc_clock_buffer(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(arco_fc_clock_buf), &p, sizeof(p)); }
+#endif
 
 static int fc_pro_dw(const IgemmArgs& a) { return a.pro.mean ? (2 * (a.pro.groups > 1 ? a.pro.groups : 1) + 2) * a.K : 0; }
 template <int A_T, int C_T>
@@ -1092,10 +1163,10 @@ extern "C" int arco_conv3d_fl_set(int on) { const int prev = conv3d_fl_flag(); c
 
 // Time of a launch with tiles of 64 A_T positions x 16 C_T channels, in microseconds, from a fit of the per-level measurements
 // (tools/micro/fl_bench.py at 2 and 4 volumes, profiles/r06_notes.md section 7): the persistent workgroups run ceil(tiles / CUs)
-// tiles one after another; a tile is 3 K / 16 chunks of 30 A_T C_T MFMAs per wave (10.7 ns each at the clock the chip holds under this
-// load, 9.5 ns with four weight fragments per activation fragment) plus the rendezvous of a chunk (five at 0.136 us in the per-step
-// form, one at 0.30 us in the per-chunk form) plus 1.9 us of epilogue and pipeline restart.  Reproduces the measured times to
-// 0-8 %, and their order except among shapes within 3 %.
+// tiles one after another; a tile is 3 K / 16 chunks of 30 A_T C_T MFMAs per wave (10.7 ns each in these 20-launch bursts, 9.5 ns with four
+// weight fragments per activation fragment; sustained launches run ~15 % faster at the same ranking: tools/micro/fc_clock.py) plus the
+// rendezvous of a chunk (five at 0.136 us in the per-step form, one at 0.30 us in the per-chunk form) plus 1.9 us of epilogue and launch
+// share.  Reproduces the measured times to 0-8 %, and their order except among shapes within 3 %.
 static double fl_cost(const IgemmArgs& a, int a_t, int c_t, bool per_chunk) {
   const long tiles = (long)a.NB * ((a.H * (a.W + 2) + 64 * a_t - 1) / (64 * a_t)) * (a.Npad / (16 * c_t));
   const long rounds = (tiles + conv_sp_cus() - 1) / conv_sp_cus();
