@@ -129,7 +129,40 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h0, un
   const f32x2_t r2 = r1 - f1;
   h2 = cvt_pk_bf16(r2[0], r2[1]);
 }
+// The ACTIVATION split (round 6): the same exact three-term decomposition with fewer vector instructions.  t0 = bf16(x) by the hardware's
+// round-to-nearest conversion of a PAIR (v_cvt_pk_bf16_f32: its result is the packed LDS word of plane 0); r1 = x - t0 (exact); t1 = the upper
+// 16 bits of r1 (truncation: one v_and); t2 = r1 - t1 (exact, at most 8 significant bits: a bf16 value as it stands); x = t0 + t1 + t2 bit for bit.
+// Eleven full-rate instructions per pair of elements (22 per 16-byte piece) where the all-round-to-nearest form (-DARCO_SPLIT_RNE: rounds 2-5; still
+// what the weight pack kernels do) compiles to ~34.  The loader waves of the pipelined kernels share their SIMD's vector issue port with an MFMA wave
+// and were the side the rendezvous waited for (tools/micro/fc_clock.py, profiles/r06_notes.md section 13).  Rounding the FIRST term keeps the
+// remainders zero-mean: truncating it too (-DARCO_SPLIT_TRUNC0, measured) biases every dropped cross product the same way, the bias adds up over K,
+// and the whole V-Net's gradients moved from 0.4 % to 0.9 % (worst tensor 1.4 % -> 9 %) off the float64 reference through extra ReLU flips.
+// |t1| <= 2^-8 |x|, |t2| < 2^-15 |x|: the three dropped cross products are bounded by 2^-23 + 2^-24 of |x||w| (all-RNE: 2^-23), zero-mean.
+__device__ __forceinline__ unsigned perm_hi16(unsigned hi, unsigned lo) {      // {hi[31:16], lo[31:16]}
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+__device__ __forceinline__ void split3_pair_rt(float x0, float x1, unsigned& h0, unsigned& h1, unsigned& h2) {
+#ifdef ARCO_SPLIT_TRUNC0
+  h0 = perm_hi16(__float_as_uint(x1), __float_as_uint(x0));
+#else
+  h0 = cvt_pk_bf16(x0, x1);
+#endif
+  const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h0 & 0xffff0000u);
+  const unsigned u0 = __float_as_uint(r0) & 0xffff0000u, u1 = __float_as_uint(r1) & 0xffff0000u;
+  h1 = perm_hi16(u1, u0);
+  h2 = perm_hi16(__float_as_uint(r1 - __uint_as_float(u1)), __float_as_uint(r0 - __uint_as_float(u0)));
+}
 __device__ __forceinline__ void split3_bf16x4(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+#ifndef ARCO_SPLIT_RNE
+  {
+    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    unsigned a0, a1, a2, c0, c1, c2;
+    split3_pair_rt(x0, x1, a0, a1, a2);
+    split3_pair_rt(x2, x3, c0, c1, c2);
+    p0 = u32x2{a0, c0}; p1 = u32x2{a1, c1}; p2 = u32x2{a2, c2};
+    return;
+  }
+#endif
 #ifndef ARCO_SPLIT_PACKED           // default: the element-wise form of rounds 2-4 (see the note above split3_pair)
   unsigned short h[3][4];
 #pragma unroll

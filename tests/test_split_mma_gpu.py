@@ -200,3 +200,32 @@ def test_pipelined_gemm_is_bit_identical_to_the_implicit_gemm_kernel():
         L.query("arco_gemm_sp_set", 1, 2048)
         ops._cfg_cache.clear()
         ops.CONV_MMA = prev_mma
+
+
+@pytest.mark.parametrize("shape", [dict(nb=16, c=16, sp=(256, 256)), dict(nb=16, c=64, sp=(64, 64)), dict(nb=4, c=32, sp=(128, 128)),
+                                   dict(nb=2, c=32, sp=(12, 56, 40)), dict(nb=2, c=64, sp=(9, 28, 20)), dict(nb=1, c=16, sp=(8, 32, 32)),
+                                   dict(nb=1, c=496, sp=(64, 64), k=1)])
+def test_activation_split_is_an_exact_decomposition_through_the_kernels(shape):
+    """The loaders split every activation into three bf16 terms (round 6: the first by round-to-nearest, the second by truncation, the
+    third the exact rest - igemm_args.h).  x = t0 + t1 + t2 must hold bit for bit: a convolution whose weights are the identity on the
+    centre tap (1, 0, 0 in the weight terms) accumulates exactly (t2 + t1) + t0 per output and has to hand the input back unchanged -
+    on six decades of magnitudes, exact zeros and negative values, through the pipelined 2-D kernels (resident weights, LDS-DMA ring),
+    the 3x3x3 flat-tile and plane-ring kernels and the wide 1x1 GEMM."""
+    from arco_amd import ops
+    rs = np.random.RandomState(shape["c"])
+    nd, k = len(shape["sp"]), shape.get("k", 3)
+    x = rs.standard_normal((shape["nb"], shape["c"], *shape["sp"])).astype(np.float32)
+    x = x * (10.0 ** rs.uniform(-3, 3, size=x.shape)).astype(np.float32)
+    x[rs.uniform(size=x.shape) < 0.1] = 0.0
+    wt = np.zeros((shape["c"], shape["c"]) + (k,) * nd, dtype=np.float32)
+    idx = (np.arange(shape["c"]), np.arange(shape["c"])) + (k // 2,) * nd
+    wt[idx] = 1.0
+    prev = ops.CONV_MMA
+    ops.CONV_MMA = 3
+    try:
+        xg = _cl(torch.from_numpy(x))
+        with torch.no_grad():
+            y = ops.conv(xg, torch.from_numpy(wt).cuda(), None)
+    finally:
+        ops.CONV_MMA = prev
+    assert torch.equal(y, xg)
