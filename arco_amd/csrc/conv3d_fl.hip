@@ -371,9 +371,11 @@ static int launch_fl(const IgemmArgs& a, hipStream_t st, int* q) {
 // Outputs bit-identical to conv3d_fl_kernel and igemm_kernel (the same products in the same order).
 // LDS: [2][arows][24] A planes + [2][10][BN][24] weights + bias.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int A_T, int C_T>
+// NCW = MFMA waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD, 12 waves with the loaders: one wave's epilogue, rendezvous waits and LDS
+// latencies run under the other's MFMAs; 170 registers per wave)
+template <int A_T, int C_T, int NCW = 4>
 struct FcGeom {
-  static constexpr int BM = 64 * A_T, WPMAX = 63, AROWS = BM + 2 * WPMAX + 2, BN = C_T * 16;
+  static constexpr int BM = NCW * 16 * A_T, WPMAX = 63, AROWS = BM + 2 * WPMAX + 2, BN = C_T * 16;
   static constexpr int WCH_DW = 10 * BN * 24;                   // one chunk of weights: 5 steps x [tapL][n][24]
   static constexpr int NW = (10 * BN * 6 + 255) / 256;          // LDS-DMA instructions per thread and chunk
   static constexpr int WBUF_DW = NW * 256 * 4;
@@ -388,9 +390,9 @@ struct FcGeom {
 // ReLU(BatchNorm(z)) - bn_act_fwd_kernel's arithmetic, operation for operation - to every staged piece before the bf16 split, with the
 // statistics and affine parameters read from LDS (copied there once per launch).  Positions that are padding stay zero (the mask is applied
 // behind the activation).  The gradient-free passes of the V-Net run their stage -> stage links this way (ops.conv_block3d_nograd).
-template <int A_T, int C_T, bool PRO = false>
-__global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
-  using G = FcGeom<A_T, C_T>;
+template <int A_T, int C_T, bool PRO = false, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64) void conv3d_fc_kernel(IgemmArgs a) {
+  using G = FcGeom<A_T, C_T, NCW>;
   constexpr int BM = G::BM, BN = G::BN, NA = G::NA_IT, NW = G::NW;
   constexpr int NL = NA;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -400,8 +402,8 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
   unsigned* const Ws = As + 2 * A_DW;
   float* const bias_s = reinterpret_cast<float*>(Ws + 2 * G::WBUF_DW);
   float* const pro_s = bias_s + G::BIAS_DW;                      // PRO: [groups][K] mean, [groups][K] istd, [K] gamma, [K] beta
-  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
-  const bool producer = threadIdx.x >= 256;
+  const bool producer = threadIdx.x >= NCW * 64;              // waves 0 .. NCW-1: MFMA; the last four: loaders
+  const int tid = producer ? (int)threadIdx.x - NCW * 64 : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
   const int nk = a.K >> 4, nvc = 3 * nk;
   const int total_tiles = a.n_mblocks * a.n_nblocks;
   const bool xcd_map = (gridDim.x & 7) == 0;
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
     }
     wait_vm<0>();
 #ifdef ARCO_FC_CLOCK
-    if (!PRO && threadIdx.x == 256 && arco_fc_clock_buf && blockIdx.x < 512) {      // (even chunks only: half of the intervals)
+    if (!PRO && threadIdx.x == NCW * 64 && arco_fc_clock_buf && blockIdx.x < 512) {      // (even chunks only: half of the intervals)
       unsigned long long* o = arco_fc_clock_buf + 8 * 512 + 8 * blockIdx.x;
       o[0] = pc_bar; o[1] = pc_dma; o[2] = pc_store; o[3] = pc_load; o[4] = pc_wait; o[5] = (unsigned long long)((total_gc + 1) / 2);
     }
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(512) void conv3d_fc_kernel(IgemmArgs a) {
     clk_e2 += te2 - te1;
 #endif
     if (has_stats) {
-      const long slab = (long)d0.mblk * 4 + wid, nslab = (long)a.n_mblocks * 4;
+      const long slab = (long)d0.mblk * NCW + wid, nslab = (long)a.n_mblocks * NCW;
 #pragma unroll
       for (int ct = 0; ct < C_T; ++ct)
 #pragma unroll
@@ -757,11 +759,11 @@ extern "C" void arco_fc_clock_buffer(unsigned long long* p) { (void)hipMemcpyToS
 #endif
 
 static int fc_pro_dw(const IgemmArgs& a) { return a.pro.mean ? (2 * (a.pro.groups > 1 ? a.pro.groups : 1) + 2) * a.K : 0; }
-template <int A_T, int C_T>
+template <int A_T, int C_T, int NCW = 4>
 static int launch_fc(const IgemmArgs& a, hipStream_t st, int* q) {
-  using G = FcGeom<A_T, C_T>;
+  using G = FcGeom<A_T, C_T, NCW>;
   const int mblocks = a.NB * ((a.H * (a.W + 2) + G::BM - 1) / G::BM);
-  if (q) { q[0] = 4 * mblocks; q[1] = 9290000 + A_T * 1000 + G::BN; q[2] = 1630; return ARCO_OK; }
+  if (q) { q[0] = NCW * mblocks; q[1] = 9290000 + (A_T + (NCW == 8 ? 5 : 0)) * 1000 + G::BN; q[2] = 1630; return ARCO_OK; }      // one stat slab per MFMA wave and tile
   if (a.D3 < 1 || a.NB % a.D3 != 0) return ARCO_ERR_ARG;
   const size_t lds = G::lds_bytes(a.W + 2, fc_pro_dw(a));
   if (lds > 160 * 1024) return ARCO_ERR_UNSUPPORTED;
@@ -769,21 +771,22 @@ static int launch_fc(const IgemmArgs& a, hipStream_t st, int* q) {
   b.n_mblocks = mblocks; b.n_nblocks = a.Npad / G::BN;
   const int total = mblocks * b.n_nblocks, cus = conv_sp_cus();
   if (a.pro.mean) {           // consumer-side activation of the input
+    if (NCW != 4) return ARCO_ERR_UNSUPPORTED;
     if (a.pro.drop_mode != 0 || a.NB % (a.pro.groups > 1 ? a.pro.groups : 1) != 0) return ARCO_ERR_UNSUPPORTED;
-    auto kern = conv3d_fc_kernel<A_T, C_T, true>;
+    auto kern = conv3d_fc_kernel<A_T, C_T, true, 4>;
     static unsigned long long attr_set = 0;
     if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, b);
     return arco_launch_status();
   }
-  auto kern = conv3d_fc_kernel<A_T, C_T>;
+  auto kern = conv3d_fc_kernel<A_T, C_T, false, NCW>;
   static unsigned long long attr_set = 0;
   if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, b);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3((NCW + 4) * 64), lds, st, b);
   return arco_launch_status();
 }
-template <int A_T, int C_T>
-static bool fc_fits(const IgemmArgs& a) { return FcGeom<A_T, C_T>::lds_bytes(a.W + 2, fc_pro_dw(a)) <= 160 * 1024; }
+template <int A_T, int C_T, int NCW = 4>
+static bool fc_fits(const IgemmArgs& a) { return FcGeom<A_T, C_T, NCW>::lds_bytes(a.W + 2, fc_pro_dw(a)) <= 160 * 1024; }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Depth-walking form for the 32-channel-wide output blocks (conv3d_dw_kernel<A_T>, 16 C_T = 32 output channels per workgroup).
@@ -1218,6 +1221,10 @@ int conv3d_fl_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   switch (best) {
     case 124: if ((a.N & 63) == 0 && fc_fits<2, 4>(a)) return launch_fc<2, 4>(a, st, q); break;
     case 114: if ((a.N & 63) == 0 && fc_fits<1, 4>(a)) return launch_fc<1, 4>(a, st, q); break;
+    case 222: if (!a.pro.mean && fc_fits<2, 2, 8>(a)) return launch_fc<2, 2, 8>(a, st, q); break;      // eight MFMA waves
+    case 232: if (!a.pro.mean && fc_fits<3, 2, 8>(a)) return launch_fc<3, 2, 8>(a, st, q); break;
+    case 212: if (!a.pro.mean && fc_fits<1, 2, 8>(a)) return launch_fc<1, 2, 8>(a, st, q); break;
+    case 214: if (!a.pro.mean && (a.N & 63) == 0 && fc_fits<1, 4, 8>(a)) return launch_fc<1, 4, 8>(a, st, q); break;
     case 152: if (fc_fits<5, 2>(a)) return launch_fc<5, 2>(a, st, q); break;
     case 142: if (fc_fits<4, 2>(a)) return launch_fc<4, 2>(a, st, q); break;
     case 132: if (fc_fits<3, 2>(a)) return launch_fc<3, 2>(a, st, q); break;

@@ -234,8 +234,10 @@ def _kernel_name(key):
         form = {7: ("conv3d_fl_kernel", "one rendezvous per tap-pair step, LDS-DMA weight ring"),
                 8: ("conv3d_dw_kernel", "depth-walking columns, three accumulator sets"),
                 9: ("conv3d_fc_kernel", "one rendezvous per 16-channel chunk, double-buffered chunk weights")}[key // 10000 % 10]
-        return (f"{form[0]}<A_T={key % 10000 // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; 3x3x3 as a 3x3 over 3 K virtual channels on flat "
-                f"tiles, persistent workgroups of 4 MFMA + 4 loader waves, {form[1]})")
+        a_t = key % 10000 // 1000
+        ncw = 8 if a_t > 5 else 4          # (conv3d_fc_kernel with eight MFMA waves: ids A_T + 5)
+        return (f"{form[0]}<A_T={a_t - 5 if a_t > 5 else a_t},C_T={key % 1000 // 16}{',NCW=8' if ncw == 8 else ''}> ({MMA_NAMES[mma]}; 3x3x3 as a 3x3 over 3 K virtual channels on flat "
+                f"tiles, persistent workgroups of {ncw} MFMA + 4 loader waves, {form[1]})")
     if 9450000 <= key < 9500000:
         return f"conv3d_rw16_kernel ({MMA_NAMES[mma]}; 3x3x3 16 -> 16: persistent workgroups, 27 taps' weights resident in LDS, ring of three input planes along the depth axis)"
     if 9350000 <= key < 9400000:

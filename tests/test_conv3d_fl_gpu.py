@@ -56,7 +56,7 @@ def test_pipelined_3x3x3_kernel_equals_igemm_kernel(shape):
     assert torch.allclose(res[1][2].t(), (refg * refg).sum((1, 3)), rtol=1e-4, atol=1e-2)
 
 
-@pytest.mark.parametrize("cfg", [44, 34, 24, 14, 42, 32, 22, 12, 92, 93, 124, 114, 152, 142, 132, 122, 112])
+@pytest.mark.parametrize("cfg", [44, 34, 24, 14, 42, 32, 22, 12, 92, 93, 124, 114, 152, 142, 132, 122, 112, 222, 232, 212, 214])
 def test_every_tile_shape_of_the_pipelined_3x3x3_kernel(cfg, monkeypatch):
     """ARCO_CONV3D_FL_CFG is read once per process: the tile shapes are forced through a child interpreter."""
     import os, subprocess, sys
