@@ -405,9 +405,11 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(IgemmArgs a) {
 // B groups, used alternately by consecutive steps.  Producers as in conv3x3_sp_kernel (asm loads two chunks ahead, split
 // to bf16 planes), a whole chunk time per tile.  LDS: [2][AROWS][24] A planes + [nchunks][10][BN][24] weights + bias.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int A_T, int C_T>
+// NCW = MFMA waves per workgroup: 4 (one per SIMD, A_T MFMA tiles of 16 pixels each) or 8 (two per SIMD, twelve waves with the loaders: one wave's
+// epilogue and LDS latencies under the other's MFMAs; the tile - NCW A_T rows x 16 columns - and the LDS image are the same)
+template <int A_T, int C_T, int NCW = 4>
 struct RwGeom {
-  static constexpr int TH = 4 * A_T, AROWS = (TH + 2) * 18, BN = C_T * 16;
+  static constexpr int TH = NCW * A_T, AROWS = (TH + 2) * 18, BN = C_T * 16;
   static constexpr int A_DW = AROWS * 24;
   static constexpr int WCH_DW = 10 * BN * 24;                   // one chunk of weights: 9 taps + the zero tap
   static constexpr int NA_IT = (AROWS * 4 + 255) / 256;
@@ -415,9 +417,9 @@ struct RwGeom {
   static size_t lds_bytes(int nchunks) { return (size_t)(2 * A_DW + nchunks * WCH_DW + BIAS_DW) * 4; }
 };
 
-template <int A_T, int C_T, bool PRO = false>
-__global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
-  using G = RwGeom<A_T, C_T>;
+template <int A_T, int C_T, bool PRO = false, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64) void conv3x3_rw_kernel(IgemmArgs a) {
+  using G = RwGeom<A_T, C_T, NCW>;
   constexpr int TH = G::TH, BN = G::BN, NA = G::NA_IT;
   constexpr int NL = NA + (PRO ? 4 : 0);     // VMEM loads per chunk and wave: the activation pieces (+ the four parameter quads of a consumer-side activation)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -425,8 +427,8 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
   const int nchunks = (a.K + 15) >> 4;                        // (K = 4 / 8 / 12: one chunk, the missing channels read as zero)
   unsigned* const Ws = As + 2 * G::A_DW;
   float* const bias_s = reinterpret_cast<float*>(Ws + nchunks * G::WCH_DW);
-  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
-  const bool producer = threadIdx.x >= 256;
+  const bool producer = threadIdx.x >= NCW * 64;              // waves 0 .. NCW-1: MFMA; the last four: loaders
+  const int tid = producer ? (int)threadIdx.x - NCW * 64 : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
   const int tiles_x = a.W >> 4, tiles_y = a.H / TH, tiles_img = tiles_x * tiles_y;
   const int total_tiles = a.n_mblocks;                        // (one N-block: N == BN)
   const bool xcd_map = (gridDim.x & 7) == 0;
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
       }
     }
     if (has_stats) {
-      const long slab = (long)d0.mblk * 4 + wid, nslab = (long)a.n_mblocks * 4;
+      const long slab = (long)d0.mblk * NCW + wid, nslab = (long)a.n_mblocks * NCW;
 #pragma unroll
       for (int ct = 0; ct < C_T; ++ct)
 #pragma unroll
@@ -740,11 +742,11 @@ __global__ __launch_bounds__(512) void conv3x3_rw_kernel(IgemmArgs a) {
   }
 }
 
-template <int A_T, int C_T>
+template <int A_T, int C_T, int NCW = 4>
 static int launch_rw(const IgemmArgs& a, hipStream_t st, int* q) {
-  using G = RwGeom<A_T, C_T>;
+  using G = RwGeom<A_T, C_T, NCW>;
   const int mblocks = a.NB * (a.H / G::TH) * (a.W / 16);
-  if (q) { q[0] = 4 * mblocks; q[1] = 9350000 + A_T * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }
+  if (q) { q[0] = NCW * mblocks; q[1] = 9350000 + (G::TH / 4) * 1000 + G::BN; q[2] = 1610; return ARCO_OK; }      // (id by tile height: <4,1,NCW=8> is <8,1>'s tile)
   if ((a.ldc & 3) != 0 || (a.R && (a.ldr & 3) != 0)) return ARCO_ERR_UNSUPPORTED;
   const size_t lds = G::lds_bytes((a.K + 15) >> 4);
   IgemmArgs b = a;
@@ -752,16 +754,16 @@ static int launch_rw(const IgemmArgs& a, hipStream_t st, int* q) {
   const int cus = conv_sp_cus();
   if (a.pro.mean) {           // consumer-side activation of the input (the block's first BatchNorm + LeakyReLU + dropout)
     if ((a.K & 15) != 0) return ARCO_ERR_UNSUPPORTED;
-    auto kern = conv3x3_rw_kernel<A_T, C_T, true>;
+    auto kern = conv3x3_rw_kernel<A_T, C_T, true, NCW>;
     static unsigned long long attr_set = 0;
     if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3(512), lds, st, b);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3((NCW + 4) * 64), lds, st, b);
     return arco_launch_status();
   }
-  auto kern = conv3x3_rw_kernel<A_T, C_T>;
+  auto kern = conv3x3_rw_kernel<A_T, C_T, false, NCW>;
   static unsigned long long attr_set = 0;
   if (arco_first_on_device(attr_set)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3(512), lds, st, b);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(mblocks < cus ? mblocks : cus)), dim3((NCW + 4) * 64), lds, st, b);
   return arco_launch_status();
 }
 
@@ -997,12 +999,21 @@ int conv_sp_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   // one 16-wide output block from at most 32 inputs: also the few-channel ends of the network (the 16 -> 4 logits layer, its
   // 4 -> 16 data gradient) - HBM-bound launches, the idle MFMA columns / zero channels cost nothing
   if (rw && a.Npad == 16 && (a.N & 3) == 0 && (a.N == 16 || narrow) && a.K <= 32 && (a.K & 3) == 0 && ((a.K & 15) == 0 || (a.K < 16 && narrow)) &&
-      (a.H & 31) == 0 && (long)a.NB * (a.H / 32) * (a.W / 16) >= min_tiles)
+      (a.H & 31) == 0 && (long)a.NB * (a.H / 32) * (a.W / 16) >= min_tiles) {
+    // eight MFMA waves (two per SIMD) on the same 32 x 16 tiles (round 6): a one-chunk tile (K <= 16) is 240 MFMAs against an epilogue of the same
+    // order, and the second wave's MFMAs run under it - tools/micro/rw_bench.py (inputs from HBM): 52.5 -> 49.2 us at 16 -> 16 @256^2 x16, 47.3 -> 43.7 at
+    // 16 -> 4, 40.7 -> 38.2 at 4 -> 16, 40.2 -> 38.9 at 32 -> 32 @128^2 (<2,2,8>), 81 -> 82-87 at 32 -> 16 (two chunks per tile).  In bench.py's event-timed
+    // pass the family averages 43.4 us with four waves, 41.7 with eight at K <= 16, 40.3 with eight everywhere (roofline.frac 0.313 / 0.327 / 0.340);
+    // the replayed step 10.57 / 10.48 / 10.52 ms (five alternations, one box).  ARCO_CONV_RW8 = 0: four waves, 1: eight at K <= 16, 2 (default): eight
+    static const int rw8 = getenv("ARCO_CONV_RW8") ? atoi(getenv("ARCO_CONV_RW8")) : 2;
+    if (rw8 == 2 || (rw8 == 1 && a.K <= 16)) return launch_rw<4, 1, 8>(a, st, q);
     return launch_rw<8, 1>(a, st, q);
+  }
   if ((a.K & 15) != 0 || a.K < 16 || (a.N & 15) != 0 || a.N != a.Npad || a.N > 256) return -1;
   if (a.N < min_n) return -1;
   if (rw && a.K <= 32 && a.N == 32) {                           // shallow levels: resident weights, one rendezvous per chunk
-    if ((a.H & 15) == 0 && (long)a.NB * (a.H / 16) * (a.W / 16) >= min_tiles) return launch_rw<4, 2>(a, st, q);
+    static const int rw8b = getenv("ARCO_CONV_RW8") ? atoi(getenv("ARCO_CONV_RW8")) : 2;
+    if ((a.H & 15) == 0 && (long)a.NB * (a.H / 16) * (a.W / 16) >= min_tiles) return rw8b == 2 ? launch_rw<2, 2, 8>(a, st, q) : launch_rw<4, 2>(a, st, q);
   }
   if ((a.N & 63) == 0) return dispatch_rows<4>(a, st, q, min_tiles);
   if ((a.N & 31) == 0) return dispatch_rows<2>(a, st, q, min_tiles);
