@@ -241,8 +241,11 @@ def _kernel_name(key):
     if 9450000 <= key < 9500000:
         return f"conv3d_rw16_kernel ({MMA_NAMES[mma]}; 3x3x3 16 -> 16: persistent workgroups, 27 taps' weights resident in LDS, ring of three input planes along the depth axis)"
     if 9350000 <= key < 9400000:
-        return (f"conv3x3_rw_kernel<A_T={(key - 9350000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, {4 * ((key - 9350000) // 1000)} x 16-pixel tiles, "
-                "4 or 8 MFMA + 4 loader waves (ARCO_CONV_RW8), weights resident in LDS)")
+        th = 4 * ((key - 9350000) // 1000)            # the id names the tile height; the instantiation depends on ARCO_CONV_RW8 (csrc/conv_sp.hip, default 2)
+        rw8 = int(os.environ.get("ARCO_CONV_RW8", "2"))
+        inst = f"A_T={th // 8},C_T={key % 1000 // 16},NCW=8" if rw8 == 2 else f"A_T={th // 4},C_T={key % 1000 // 16}"
+        return (f"conv3x3_rw_kernel<{inst}> ({MMA_NAMES[mma]}; persistent workgroups, {th} x 16-pixel tiles, "
+                f"{'8' if rw8 == 2 else '4 (8 at K <= 16)' if rw8 == 1 else '4'} MFMA + 4 loader waves, weights resident in LDS)")
     if 9300000 <= key < 9350000:
         return f"conv3x3_sp_kernel<A_T={(key - 9300000) // 1000},C_T={key % 1000 // 16}> ({MMA_NAMES[mma]}; persistent workgroups, 4 MFMA + 4 loader waves, LDS-DMA weight ring)"
     if key >= 9900000:
