@@ -308,6 +308,58 @@ def test_surface_metrics_analytic():
     np.testing.assert_allclose(metrics.cal_dice(np.array([0, 1, 1, 2]), np.array([0, 1, 2, 2]), 3), [2 / 3, 2 / 3])
 
 
+def _brute_surface_distances(a, b, spacing):
+    """Directed surface distances with no scipy: a voxel is on the border when it is set and one of its 2*ndim face
+    neighbours is unset or outside the array (binary_erosion's border_value = 0); the distance is the minimum over
+    the other border's voxels, in physical units."""
+    def border(x):
+        pad = np.pad(x, 1, constant_values=False)
+        core = np.ones_like(x)
+        for ax in range(x.ndim):
+            for sh in (-1, 1):
+                sl = [slice(1, -1)] * x.ndim
+                sl[ax] = slice(1 + sh, x.shape[ax] + 1 + sh)
+                core &= pad[tuple(sl)]
+        return x & ~core
+    pa = np.argwhere(border(a)) * np.asarray(spacing, np.float64)
+    pb = np.argwhere(border(b)) * np.asarray(spacing, np.float64)
+    d = np.sqrt(((pa[:, None, :] - pb[None, :, :]) ** 2).sum(-1))
+    return d.min(axis=1)
+
+
+@pytest.mark.parametrize("seed,shape,spacing", [(0, (14, 12, 10), None), (1, (12, 12, 12), (1.0, 0.5, 2.5)),
+                                                (2, (24, 20), None), (3, (9, 16, 11), (0.8, 0.8, 3.0))])
+def test_surface_metrics_vs_brute_force(seed, shape, spacing):
+    """hd95 / asd against an O(n^2) restatement that shares no code with scipy.ndimage: random blobs with holes,
+    objects touching the array border, anisotropic voxel spacing."""
+    from arco_amd.utils import metrics
+    rng = np.random.default_rng(seed)
+    def blob():
+        x = rng.random(shape) < 0.08
+        for _ in range(2):                                             # grow the seeds into blobs
+            pad = np.pad(x, 1)
+            g = x.copy()
+            for ax in range(x.ndim):
+                for sh in (-1, 1):
+                    sl = [slice(1, -1)] * x.ndim
+                    sl[ax] = slice(1 + sh, x.shape[ax] + 1 + sh)
+                    g |= pad[tuple(sl)]
+            x = g
+        return x & (rng.random(shape) < 0.97)                          # pinholes: interior borders
+    a, b = blob(), blob()
+    assert a.any() and b.any() and not a.all() and not b.all()
+    sp = spacing if spacing is not None else (1.0,) * len(shape)
+    d1, d2 = _brute_surface_distances(a, b, sp), _brute_surface_distances(b, a, sp)
+    got = metrics.binary._surface_distances(a, b, spacing, 1)
+    np.testing.assert_allclose(np.sort(got), np.sort(d1), rtol=0, atol=1e-9)
+    assert abs(metrics.binary.hd95(a, b, voxelspacing=spacing) - np.percentile(np.hstack((d1, d2)), 95)) < 1e-9
+    assert abs(metrics.binary.asd(a, b, voxelspacing=spacing) - d1.mean()) < 1e-9
+    assert abs(metrics.binary.asd(b, a, voxelspacing=spacing) - d2.mean()) < 1e-9
+    if spacing is None:
+        hd, asd = orc.surface_metrics(a, b)
+        assert abs(hd - np.percentile(np.hstack((d1, d2)), 95)) < 1e-9 and abs(asd - d1.mean()) < 1e-9
+
+
 @pytest.mark.parametrize("tag", sorted(fx.MIX_CASES))
 def test_mix_oracle_vs_reference(tag):
     """generate_unsup_data(_3d) of the oracle vs the reference functions' outputs (g7): bit-exact tensors and the
