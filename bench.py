@@ -313,7 +313,7 @@ def roofline_from_profile(prof, n_steps, step_ms):
                     for shp in sorted({l_[3] for l_ in launches}) if shp in table}
     roof = {**head, "traffic": traffic, "traffic_over_algorithmic": ratio, "traffic_over_algorithmic_by_shape": by_shape,
             "traffic_source": ("table: HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 units) measured ONCE per launch shape in separate "
-                               "rocprofv3 --pmc passes (tools/pmc_conv*.py; summaries profiles/r0N_pmc_*_traffic.md, newest profiles/r05_pmc_traffic.md) "
+                               "rocprofv3 --pmc passes (tools/pmc_conv*.py; summaries profiles/r0N_pmc_*_traffic.md, newest profiles/r06_pmc_traffic.md, re-measured at the last commit for the eight-MFMA-wave instantiation) "
                                "and averaged here over the launches timed in THIS run - bench.py itself collects no counters (a --pmc pass "
                                "cannot run inside this process)"),
             "peak_note": {0: "fp32 MFMA peak", 3: "dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32-accurate product); the native fp32 MFMA peak is 157.3"}.get(k_mma, "dense f16/bf16 MFMA peak"),
