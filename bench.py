@@ -685,11 +685,13 @@ def main():
             k2_0 = {"ms_per_step": round(ms0, 3), "steps_per_s": round(1e3 / ms0, 3), "steps": a.k2_0_steps,
                     "note": "--k2 0: the north-star path alone (contrastive + supervised + unsupervised terms), no "
                             "equivariance pass; round 1's headline configuration"}
-        T.TEACHER_SIDE = 0            # single-stream eager pass: per-kernel HIP-event timing (see above)
-        prof = eager_profile(stepper, run, 3)
-        T.TEACHER_SIDE = side_mode
-        roof, whole = roofline_from_profile(prof, 3, step_ms)
-        step_roof = step_roofline(prof.get("__work__"), step_ms, split=a.conv_mma == "f32x3")
+    # the roofline objects at every N: each rank runs the same instrumented eager steps (they contain the step's collectives, so
+    # all ranks take part); rank 0's launches are the ones reported
+    T.TEACHER_SIDE = 0            # single-stream eager pass: per-kernel HIP-event timing (see above)
+    prof = eager_profile(stepper, run, 3)
+    T.TEACHER_SIDE = side_mode
+    roof, whole = roofline_from_profile(prof, 3, step_ms)
+    step_roof = step_roofline(prof.get("__work__"), step_ms, split=a.conv_mma == "f32x3")
 
     if rank == 0:
         out = {
