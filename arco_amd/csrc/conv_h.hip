@@ -856,9 +856,12 @@ static int hconv_fc_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
     // chunk), ~5.9 TB/s over the chip: time = LDS-DMA bytes of all rounds / 5.9 TB/s (a partly filled last round counts as a full
     // one), or the MFMA / rendezvous path if that is longer, + 1.9 us of epilogue per round
     double bc = 1e300;
-    const int cand[8] = {44, 34, 24, 14, 42, 32, 22, 12};
+    // (A_T = 5 / 6 with 64-wide blocks, round 6: a chunk's 20 KB of weights serve 320 / 384 positions - the stream per position drops
+    //  from 148 to 90 B at 40 x 24 planes; ARCO_HCONV_FC_BIG=0 leaves them out)
+    static const int big = getenv("ARCO_HCONV_FC_BIG") ? atoi(getenv("ARCO_HCONV_FC_BIG")) : 1;
+    const int cand[10] = {64, 54, 44, 34, 24, 14, 42, 32, 22, 12};      // (<6,2> / <5,2> exist for ARCO_HCONV_FC_CFG only: 58-69 us against hconv_kernel's 53 at 80 x 80 x 48)
     const int cus = conv_sp_cus();
-    for (int i = 0; i < 8; ++i) {
+    for (int i = big ? 0 : 2; i < 10; ++i) {
       const int a_t = cand[i] / 10, c_t = cand[i] % 10;
       if ((a.N % (16 * c_t)) != 0) continue;
       const long tiles = (long)a.NB * ((a.H * (a.W + 2) + 64 * a_t - 1) / (64 * a_t)) * (a.Npad / (16 * c_t));
@@ -873,10 +876,14 @@ static int hconv_fc_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
     }
   }
   switch (best) {
+    case 64: if ((a.N & 63) == 0) return launch_hfc<6, 4>(a, st, q); break;
+    case 54: if ((a.N & 63) == 0) return launch_hfc<5, 4>(a, st, q); break;
     case 44: if ((a.N & 63) == 0) return launch_hfc<4, 4>(a, st, q); break;
     case 34: if ((a.N & 63) == 0) return launch_hfc<3, 4>(a, st, q); break;
     case 24: if ((a.N & 63) == 0) return launch_hfc<2, 4>(a, st, q); break;
     case 14: if ((a.N & 63) == 0) return launch_hfc<1, 4>(a, st, q); break;
+    case 62: return launch_hfc<6, 2>(a, st, q);
+    case 52: return launch_hfc<5, 2>(a, st, q);
     case 42: return launch_hfc<4, 2>(a, st, q);
     case 32: return launch_hfc<3, 2>(a, st, q);
     case 22: return launch_hfc<2, 2>(a, st, q);

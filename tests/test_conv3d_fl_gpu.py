@@ -127,6 +127,40 @@ def test_pipelined_f16_3x3x3_kernel_equals_hconv_kernel(shape):
     assert torch.allclose(res[1][1].t(), got.sum((1, 3)), rtol=1e-4, atol=1e-2)             # statistics of the ROUNDED outputs
 
 
+@pytest.mark.parametrize("cfg", [64, 54, 62, 52, 44, 34, 24, 14, 42, 32, 22, 12])
+def test_every_tile_shape_of_the_pipelined_f16_kernel(cfg):
+    """ARCO_HCONV_FC_CFG is read once per process: hconv_fc_kernel's tile shapes forced through a child interpreter, outputs and
+    BatchNorm partial sums against hconv_kernel (two BatchNorm groups, a ragged last tile, planes narrower than a tile)."""
+    import os, subprocess, sys
+    code = r'''
+import torch
+from arco_amd import ops, _lib as L
+g = torch.Generator().manual_seed(7)
+for (nv, ci, co, sp, groups) in ((2, 64, 64, (9, 40, 24), 2), (1, 64, 128, (4, 20, 12), 1), (3, 16, 64, (3, 7, 5), 1), (2, 32, 64, (2, 33, 45), 1)):
+    d3, h, w = sp
+    x = torch.randn(nv, ci, *sp, generator=g).half().cuda().contiguous(memory_format=torch.channels_last_3d)
+    wt = (torch.randn(co, ci, 3, 3, 3, generator=g) / (5.2 * ci ** 0.5)).half().float().cuda()
+    b = torch.randn(co, generator=g).cuda()
+    wp = ops.pack_weight(wt, 27, 0, half=True)
+    xr, ldx = ops.rows_view(x)
+    res = {}
+    for on in (0, 1):
+        ops.conv3d_fl_set(on)
+        cfg = L.query("arco_conv_config_mma", 27, nv * d3, h, w, ci, co, ldx, 4)
+        assert (9260000 <= cfg < 9270000) == bool(on), cfg
+        out, (ssum, ssq, nmb) = ops.conv_raw(xr, ldx, ci, wp, co, nv, h, w, 27, bias=b, stats=True, d3=d3, stat_groups=groups, half=True)
+        res[on] = (out.clone(), ssum.double().view(co, groups, -1).sum(2), ssq.double().view(co, groups, -1).sum(2))
+    ops.conv3d_fl_set(1)
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-4) and torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-4)
+print("OK")
+'''
+    env = dict(os.environ, ARCO_HCONV_FC_CFG=str(cfg))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("c,sp", [(32, (56, 56, 40)), (64, (28, 28, 20)), (128, (14, 14, 10)), (256, (7, 7, 5))])
 def test_la_levels_direct_sums_and_linearity(c, sp):
     """The V-Net's 3x3x3 levels at the LA patch (4 volumes, BASELINE.json configs[2]) held to properties that do not go through any
