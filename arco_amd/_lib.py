@@ -106,6 +106,9 @@ _SIGS = {
     "arco_scatter_upcat_rows3d": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P],
     "arco_zero_rows": [_P, _L, _I, _P, _L, _P],
     "arco_gather_upcat_rows3d_h": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    "arco_lerp8_cat_rows3d": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    "arco_lerp8_cat_rows3d_h": [_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    "arco_lerp8_rows3d_bwd": [_P, _L, _I, _P, _L, _P, _L, _P],
     "arco_cast_rows_f2h": [_P, _L, _I, _P, _L, _F, _P, _L, _P],
     "arco_zero_rows_h": [_P, _L, _I, _P, _L, _P],
     "arco_det_absmax": [_P, _L, _I, _L, _P, _P],

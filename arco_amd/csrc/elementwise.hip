@@ -892,6 +892,63 @@ __global__ __launch_bounds__(256) void gather_upcat_rows3d_kernel(const float* _
   const TH* h = hi + p * ldhi;
   for (int c = lane * 4; c < Chi; c += 256) *reinterpret_cast<f32x4*>(o + Clo + c) = ld4f(h + c);
 }
+// ---- the level below, lazily too (head.LazyHead3dL3Fn): V holds the eight corner rows of every sampled voxel (rows 8 j + k, corner order
+// z, y, x with x fastest - arco_corner_rows3d), each already evaluated through its own layer;
+// X[j][0..Clo) = their trilinear blend in the gather's index / lerp arithmetic (-> the values the dense map would have handed to
+// gather_upcat_rows3d_kernel, up to the rounding of the rows themselves), X[j][Clo..Clo+Chi) = hi[pix[j]]
+template <typename TH>
+__global__ __launch_bounds__(256) void lerp8_cat_rows3d_kernel(const float* __restrict__ V, long ldv, int Clo, int Di, int Hi, int Wi,
+                                                              const TH* __restrict__ hi, long ldhi, int Chi, int Do, int Ho, int Wo,
+                                                              const int64_t* __restrict__ pix, long n, float* __restrict__ X, long ldx) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const long p = pix[j];
+  const long vol = (long)Do * Ho * Wo;
+  const long img = p / vol; long rem = p - img * vol;
+  const int zo = (int)(rem / ((long)Ho * Wo)); rem -= (long)zo * Ho * Wo;
+  const int yo = (int)(rem / Wo), xo = (int)(rem - (long)yo * Wo);
+  const float sd = Do > 1 ? (float)(Di - 1) / (float)(Do - 1) : 0.f, sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f,
+              sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+  ac_src(zo, sd, Di, z0, z1, lz); ac_src(yo, sh, Hi, y0, y1, ly); ac_src(xo, sw, Wi, x0, x1, lx);
+  const float hz = 1.f - lz, hy = 1.f - ly, hx = 1.f - lx;
+  const float* v = V + (8 * j) * ldv;
+  float* o = X + j * ldx;
+  for (int c = lane * 4; c < Clo; c += 256) {
+    f32x4 q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = *reinterpret_cast<const f32x4*>(v + k * ldv + c);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = tl_blend1(q[0][e], q[1][e], q[2][e], q[3][e], q[4][e], q[5][e], q[6][e], q[7][e], hx, lx, hy, ly, hz, lz);
+    *reinterpret_cast<f32x4*>(o + c) = r;
+  }
+  const TH* h = hi + p * ldhi;
+  for (int c = lane * 4; c < Chi; c += 256) *reinterpret_cast<f32x4*>(o + Clo + c) = ld4f(h + c);
+}
+// adjoint of the blend: dV[8 j + k] = w8[8 j + k] * dX[j][0..Clo)   (w8: arco_corner_rows3d's weights; plain stores)
+__global__ __launch_bounds__(256) void lerp8_rows3d_bwd_kernel(const float* __restrict__ dX, long ldx, int Clo, const float* __restrict__ w8,
+                                                              long n, float* __restrict__ dV, long ldv) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  const float* g = dX + j * ldx;
+  float* v = dV + (8 * j) * ldv;
+  float wk[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) wk[k] = w8[8 * j + k];
+  for (int c = lane * 4; c < Clo; c += 256) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(g + c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) asm("v_mul_f32 %0, %1, %2" : "=v"(r[e]) : "v"(d[e]), "v"(wk[k]));      // (never a packed multiply: see lerp4_cat_rows_bwd_kernel)
+      *reinterpret_cast<f32x4*>(v + k * ldv + c) = r;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void scatter_upcat_rows3d_kernel(const float* __restrict__ dX, long ldx, const int64_t* __restrict__ pix, long n,
                                                                   float* __restrict__ dlo, long ldlo, int Clo, int Di, int Hi, int Wi,
                                                                   float* __restrict__ dhi, long ldhi, int Chi, int Do, int Ho, int Wo) {
@@ -1410,6 +1467,29 @@ int arco_gather_upcat_rows3d_h(const float* lo, long ldlo, int Clo, int Di, int 
   if (n == 0) return ARCO_OK;
   hipLaunchKernelGGL(gather_upcat_rows3d_kernel<_Float16>, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), lo, ldlo, Clo, Di, Hi, Wi,
                      reinterpret_cast<const _Float16*>(hi), ldhi, Chi, Do, Ho, Wo, pix, n, X, ldx);
+  return arco_launch_status();
+}
+// rows of cat(trilinear blend of eight already-evaluated corner rows, hi[pix]) and the blend's adjoint (three-level 3-D head)
+int arco_lerp8_cat_rows3d(const float* V, long ldv, int Clo, int Di, int Hi, int Wi, const float* hi, long ldhi, int Chi,
+                          int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream) {
+  ARCO_CHECK_ARG((Clo & 3) == 0 && (Chi & 3) == 0 && (ldv & 3) == 0 && (ldhi & 3) == 0 && (ldx & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(lerp8_cat_rows3d_kernel<float>, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), V, ldv, Clo, Di, Hi, Wi,
+                     hi, ldhi, Chi, Do, Ho, Wo, pix, n, X, ldx);
+  return arco_launch_status();
+}
+int arco_lerp8_cat_rows3d_h(const float* V, long ldv, int Clo, int Di, int Hi, int Wi, const void* hi, long ldhi, int Chi,
+                            int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream) {
+  ARCO_CHECK_ARG((Clo & 3) == 0 && (Chi & 3) == 0 && (ldv & 3) == 0 && (ldhi & 3) == 0 && (ldx & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(lerp8_cat_rows3d_kernel<_Float16>, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), V, ldv, Clo, Di, Hi, Wi,
+                     reinterpret_cast<const _Float16*>(hi), ldhi, Chi, Do, Ho, Wo, pix, n, X, ldx);
+  return arco_launch_status();
+}
+int arco_lerp8_rows3d_bwd(const float* dX, long ldx, int Clo, const float* w8, long n, float* dV, long ldv, void* stream) {
+  ARCO_CHECK_ARG((Clo & 3) == 0 && (ldv & 3) == 0 && (ldx & 3) == 0);
+  if (n == 0) return ARCO_OK;
+  hipLaunchKernelGGL(lerp8_rows3d_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), dX, ldx, Clo, w8, n, dV, ldv);
   return arco_launch_status();
 }
 int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, long n, float* dlo, long ldlo, int Clo, int Di,

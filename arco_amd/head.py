@@ -540,6 +540,157 @@ class LazyTeacher3D:
         return _rows3d_forward(self.x2p, self.f3, self.f4, self.w3, self.w4, pix)[2]
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# The 3-D head with the 56x56x40 level lazy too (round 6).  Above that level everything is per-voxel, so a sampled voxel needs
+# exactly its EIGHT trilinear corners of x2p = fea2(cat(up(x1p), f2)) + cat(...): 8 n rows of 224 channels instead of the dense
+# 501 760-row map (450 MB at the LA size: the step's longest GEMM launch writes it, its prototype sums, its resize adjoint, its
+# data and weight gradients read it - for ~1 % of its rows).  x1p = fea1(...)+... [B,192,28,28,20] stays dense.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _rows3d_l3_forward(x1p, f2, f3, f4, w2, w3, w4, pix):
+    """corner rows idx8 (at f2's resolution) of every sampled voxel; X2 = cat(trilinear(x1p), f2) on them; X2p = fea2(X2)+X2;
+    X3 = cat(trilinear blend of X2p's eight rows, f3[pix]); then as _rows3d_forward.  Returns (X2, X3, X4, idx8, w8, fea4(X4))."""
+    dev = pix.device
+    lo, ldlo = rows_view(x1p)
+    r2, ld2 = rows_view(f2)
+    r3, ld3 = rows_view(f3)
+    r4, ld4 = rows_view(f4)
+    nb, c1, d1, h1, w1_ = (int(v) for v in x1p.shape)
+    c2, d2, h2, w2_ = (int(v) for v in f2.shape[1:])
+    c3, d3, h3, w3_ = (int(v) for v in f3.shape[1:])
+    c4 = int(f4.shape[1])
+    n = int(pix.shape[0])
+    k2 = c1 + c2
+    k3 = k2 + c3
+    idx8 = torch.empty(8 * n, dtype=torch.int64, device=dev)
+    w8 = torch.empty(8 * n, dtype=torch.float32, device=dev)
+    L.call("arco_corner_rows3d", L.ptr(pix), n, d2, h2, w2_, d3, h3, w3_, L.ptr(idx8), L.ptr(w8))
+    X2 = torch.empty((8 * n, k2), dtype=torch.float32, device=dev)
+    L.call("arco_gather_upcat_rows3d_h" if r2.dtype == torch.float16 else "arco_gather_upcat_rows3d",
+           L.ptr(lo), ldlo, c1, d1, h1, w1_, L.ptr(r2), ld2, c2, d2, h2, w2_, L.ptr(idx8), 8 * n, L.ptr(X2), k2)
+    X2p = _fea_rows(X2, w2, 0)
+    X3 = torch.empty((n, k3), dtype=torch.float32, device=dev)
+    L.call("arco_lerp8_cat_rows3d_h" if r3.dtype == torch.float16 else "arco_lerp8_cat_rows3d",
+           L.ptr(X2p), k2, k2, d2, h2, w2_, L.ptr(r3), ld3, c3, d3, h3, w3_, L.ptr(pix), n, L.ptr(X3), k3)
+    y3, _ = ops.conv_raw(X3, k3, k3, ops.pack_weight(w3, 1, 0), k3, 1, 1, n, 1, residual=X3, ld_res=k3)
+    X4 = torch.empty((n, k3 + c4), dtype=torch.float32, device=dev)
+    X4[:, :k3] = y3.permute(0, 2, 3, 1).reshape(n, k3)
+    L.call("arco_gather_rows_h" if r4.dtype == torch.float16 else "arco_gather_rows",
+           L.ptr(r4), ld4, c4, None, L.ptr(pix), None, 0, n, L.ptr(X4[:, k3:]), k3 + c4)
+    return X2, X3, X4, idx8, w8, _gemm(X4, w4)
+
+
+class LazyHead3dL3Fn(torch.autograd.Function):
+    """Row-sparse student head of the 3-D step with fea2 evaluated on rows too (model_3D.py:46-58, train_arco_3d.py:289-296): inputs
+    x1p = fea1(.)+. [B,192,28,28,20] (dense), f2 [B,32,56,56,40], f3, f4 [B,16,112,112,80].  The gradient becomes dense again from the
+    28x28x20 level down (48 MB); f2's, f3's and f4's are row scatters (order-independent by default, DET_SCATTER)."""
+
+    @staticmethod
+    def forward(ctx, x1p, f2, f3, f4, w2, w3, w4, w1, wq2, pix):
+        X2, X3, X4, idx8, w8, h0 = _rows3d_l3_forward(x1p, f2, f3, f4, w2, w3, w4, pix)
+        h1 = _gemm(h0, w1)
+        a = _gemm(h1, wq2)
+        ctx.save_for_backward(X2, X3, X4, h0, h1, w2, w3, w4, w1, wq2, pix, idx8, w8)
+        ctx.shapes = (tuple(x1p.shape), tuple(f2.shape), tuple(f3.shape), tuple(f4.shape))
+        ctx.fptrs = (f2.data_ptr(), f3.data_ptr(), f4.data_ptr())
+        ctx.fhalf = (f2.dtype == torch.float16, f3.dtype == torch.float16, f4.dtype == torch.float16)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        X2, X3, X4, h0, h1, w2, w3, w4, w1, wq2, pix, idx8, w8 = ctx.saved_tensors
+        s1, s2, s3, s4 = ctx.shapes
+        dev = da.device
+        n = int(pix.shape[0])
+        k2, k3 = int(X2.shape[1]), int(X3.shape[1])
+        c1, c2, c3, c4 = int(s1[1]), int(s2[1]), int(s3[1]), int(s4[1])
+        da = da.contiguous()
+        dwq2 = _wgrad(da, h1, wq2)
+        dh1 = _gemm_t(da, wq2)
+        dw1 = _wgrad(dh1, h0, w1)
+        dh0 = _gemm_t(dh1, w1)
+        dw4 = _wgrad(dh0, X4, w4)
+        dX4 = _gemm_t(dh0, w4)
+        dX3p = dX4[:, :k3].contiguous()
+
+        def scatter(src, ld_src, C, idx, n_e, ptr, shape, half):
+            buf, fin = (_row_grad_buffer_h if half else _row_grad_buffer)(ptr, shape, dev)
+            if DET_SCATTER:
+                _det_scatter_rows(src, ld_src, C, 1, idx, None, n_e, buf, C)
+            else:
+                L.call("arco_scatter_add_rows", L.ptr(src), ld_src, C, None, L.ptr(idx), n_e, None, 1.0, L.ptr(buf), C)
+            r = fin(idx, n_e)
+            return r if half else buf
+        df4 = scatter(dX4[:, k3:], k3 + c4, c4, pix, n, ctx.fptrs[2], s4, ctx.fhalf[2])
+        dw3 = _wgrad(dX3p, X3, w3)
+        y, _ = ops.conv_raw(dX3p, k3, k3, ops.pack_weight(w3, 1, 1), k3, 1, 1, n, 1, residual=dX3p, ld_res=k3)
+        dX3 = y.permute(0, 2, 3, 1).reshape(n, k3)
+        df3 = scatter(dX3[:, k2:], k3, c3, pix, n, ctx.fptrs[1], s3, ctx.fhalf[1])
+        dX2p = torch.empty((8 * n, k2), dtype=torch.float32, device=dev)
+        L.call("arco_lerp8_rows3d_bwd", L.ptr(dX3), k3, k2, L.ptr(w8), n, L.ptr(dX2p), k2)
+        dw2 = _wgrad(dX2p, X2, w2)
+        dX2 = _fea_rows(dX2p, w2, 1)
+        df2 = scatter(dX2[:, c1:], k2, c2, idx8, 8 * n, ctx.fptrs[0], s2, ctx.fhalf[0])
+        dx1p = torch.zeros((s1[0], *s1[2:], c1), dtype=torch.float32, device=dev)
+        if DET_SCATTER:
+            idx64 = torch.empty(64 * n, dtype=torch.int64, device=dev)
+            w64 = torch.empty(64 * n, dtype=torch.float32, device=dev)
+            L.call("arco_corner_rows3d", L.ptr(idx8), 8 * n, s1[2], s1[3], s1[4], s2[2], s2[3], s2[4], L.ptr(idx64), L.ptr(w64))
+            _det_scatter_rows(dX2, k2, c1, 8, idx64, w64, 64 * n, dx1p, c1)
+        else:       # (the fp32-atomic adjoint of the gather: lo part only - dhi = a scratch row sink of the right shape)
+            sink = torch.zeros((s2[0], *s2[2:], c2), dtype=torch.float32, device=dev)
+            L.call("arco_scatter_upcat_rows3d", L.ptr(dX2), k2, L.ptr(idx8), 8 * n, L.ptr(dx1p), c1, c1, s1[2], s1[3], s1[4],
+                   L.ptr(sink), c2, c2, s2[2], s2[3], s2[4])
+        return (dx1p.movedim(-1, 1), df2.movedim(-1, 1), df3.movedim(-1, 1), df4.movedim(-1, 1), dw2, dw3, dw4, dw1, dwq2, None)
+
+
+def lazy_head3d_l3(x1p, f2, f3, f4, fea2_weight, fea3_weight, fea4_weight, q1_weight, q2_weight, pix):
+    return LazyHead3dL3Fn.apply(x1p, f2, f3, f4, fea2_weight, fea3_weight, fea4_weight, q1_weight, q2_weight, pix)
+
+
+class LazyTeacher3DL3:
+    """Teacher side with the 56x56x40 level lazy too: prototype_c = W4 . cat((W3+I) . cat((W2+I) . cat(S(x1p; w''), S(f2; w')), S(f3; w)),
+    S(f4; w)) with S(t; w) = the class-weighted row sums of t and the class mask w pushed through the trilinear adjoint once (w', the
+    56x56x40 level) and twice (w'', the 28x28x20 level); key rows evaluated at the key voxels only."""
+
+    def __init__(self, x1p, f2, f3, f4, w2, w3, w4):
+        self.x1p, self.f2, self.f3, self.f4, self.w2, self.w3, self.w4 = x1p, f2, f3, f4, w2, w3, w4
+
+    @torch.no_grad()
+    def prototypes(self, pl):
+        r1, ld1 = rows_view(self.x1p)
+        r2, ld2 = rows_view(self.f2)
+        r3, ld3 = rows_view(self.f3)
+        r4, ld4 = rows_view(self.f4)
+        nb, c1, d1, h1, w1_ = (int(v) for v in self.x1p.shape)
+        c2, d2, h2, w2_ = (int(v) for v in self.f2.shape[1:])
+        c3, d3, h3, w3_ = (int(v) for v in self.f3.shape[1:])
+        c4 = int(self.f4.shape[1])
+        C, k2 = pl.C, c1 + c2
+        k3 = k2 + c3
+        wm, Cp = _class_weights(pl)
+        n2, n1 = nb * d2 * h2 * w2_, nb * d1 * h1 * w1_
+        wl2 = torch.empty((n2, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_trilinear_bwd", L.ptr(wm), Cp, nb, d2, h2, w2_, Cp, d3, h3, w3_, L.ptr(wl2), Cp)
+        wl1 = torch.empty((n1, Cp), dtype=torch.float32, device=pl.dev)
+        L.call("arco_trilinear_bwd", L.ptr(wl2), Cp, nb, d1, h1, w1_, Cp, d2, h2, w2_, L.ptr(wl1), Cp)
+        R = _ceil(C, 16)
+        S2 = torch.zeros((R, k2), dtype=torch.float32, device=pl.dev)
+        _wsum(r1, ld1, wl1, Cp, n1, C, c1, pl.totals, S2, k2)
+        _wsum(r2, ld2, wl2, Cp, n2, C, c2, pl.totals, S2[:, c1:], k2)
+        S3 = torch.zeros((R, k3), dtype=torch.float32, device=pl.dev)
+        S3[:, :k2] = _fea_rows(S2, self.w2, 0)
+        _wsum(r3, ld3, wm, Cp, pl.n_pix, C, c3, pl.totals, S3[:, k2:], k3)
+        y3, _ = ops.conv_raw(S3, k3, k3, ops.pack_weight(self.w3, 1, 0), k3, 1, 1, R, 1, residual=S3, ld_res=k3)
+        S4 = torch.zeros((R, k3 + c4), dtype=torch.float32, device=pl.dev)
+        S4[:, :k3] = y3.permute(0, 2, 3, 1).reshape(R, k3)
+        _wsum(r4, ld4, wm, Cp, pl.n_pix, C, c4, pl.totals, S4[:, k3:], k3 + c4)
+        return _gemm(S4, self.w4)[:C].contiguous()
+
+    @torch.no_grad()
+    def rows(self, pix):
+        return _rows3d_l3_forward(self.x1p, self.f2, self.f3, self.f4, self.w2, self.w3, self.w4, pix)[5]
+
+
 class LazyTeacher2DL2:
     """Two-level lazy teacher (default of the 2-D step): also fea3 is never evaluated densely.
     prototype_c = W4 . cat((W3+I) . mean_c(cat(up(x2p), f3)), mean_c(f4)), the class mask being pushed through

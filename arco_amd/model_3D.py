@@ -42,6 +42,16 @@ class FeatureExtractor_3d(nn.Module):
             x = ops.conv_upres(f[i], w_hi, lo)                                   # one launch: the upsample lives in the GEMM's epilogue
         return x, f[3], f[4]
 
+    def forward_lowres1(self, fea_list):
+        """Up to fea1 (the 28x28x20 level): (fea1(x)+x, f2, f3, f4) for the three-level row-sparse head (arco_amd.head.LazyHead3dL3Fn):
+        fea2's 224-channel map at 56x56x40 - 450 MB at the LA size, of which a step reads ~1 % of the rows - is not evaluated densely."""
+        f = [ops.to_channels_last(t) for t in fea_list]
+        x = ops.conv(f[0], self.fea0.weight, None, residual=True)
+        c = int(x.shape[1])
+        w_lo, w_hi = ops.fold_residual(self.fea1.weight, c)
+        x = ops.conv_upres(f[1], w_hi, ops.conv(x, w_lo))
+        return x, f[2], f[3], f[4]
+
     def forward_reference_order(self, fea_list):
         """model_3D.py:43-58 literally: upsample, concatenate, convolve at every level.  Kept as the comparison target of the tests."""
         f = [ops.to_channels_last(t) for t in fea_list]

@@ -32,6 +32,9 @@ from .train_arco_2d import build_parser as _build_parser_2d
 # starts as soon as the host has drawn the warp - beside that low-occupancy stretch instead of beside the backward pass.
 PASS_SIDE = min(3, int(os.environ.get("ARCO_TEACHER_SIDE", "4")))
 LISTS_SIDE = int(os.environ.get("ARCO_LISTS_SIDE", "1"))
+# lazy levels of the row-sparse heads: 2 = fea3 / fea4 on rows over the dense 56x56x40 map of fea2 (rounds 2-5), 3 = fea2 on rows too - the
+# 224-channel map at 56x56x40 (450 MB at the LA size) is never written (head.LazyHead3dL3Fn, round 6)
+HEAD_LEVELS = int(os.environ.get("ARCO_HEAD3D_LEVELS", "3"))
 FM_ROWS_HALF = int(os.environ.get("ARCO_FM_ROWS_HALF", "1"))     # --act_dtype f16: heads read the full-resolution maps as f16 (ops.fm_rows_half)
 FEA_DIM_3D = [128, 64, 32, 16, 16]
 REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
@@ -213,6 +216,12 @@ class ArcoStep3D:
             if isinstance(v, graphs.GraphedTrain):
                 v.captured = False
 
+    @staticmethod
+    def _lazy_teacher(kfe, fm_t):
+        if HEAD_LEVELS == 3:
+            return head.LazyTeacher3DL3(*kfe.forward_lowres1(fm_t), kfe.fea2.weight, kfe.fea3.weight, kfe.fea4.weight)
+        return head.LazyTeacher3D(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
+
     def q_rep(self, x):
         x = ops.conv(x, self.q_representation[0].weight)
         return ops.conv(x, self.q_representation[1].weight)
@@ -254,7 +263,7 @@ class ArcoStep3D:
                     t_done = t_side.record_event()
                     if PASS_SIDE >= 3 and not getattr(a, "dense_head", 0):   # :292-293 (the teacher's heads: joined before the row lists)
                         kfe = self.k_feature_extractor
-                        lazy_t_side = head.LazyTeacher3D(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
+                        lazy_t_side = self._lazy_teacher(kfe, fm_t)
             with ops.bn_groups(2), fm_ctx():
                 pred_all, _, fm_s = self.s_train_lu(lu)                  # :283-284
             if t_side is not None:
@@ -308,12 +317,12 @@ class ArcoStep3D:
             elif lazy_t_side is not None:
                 rep_all_teacher, lazy_t = None, lazy_t_side
             else:       # teacher rows are only needed as class means (prototypes) and <= queue_size keys per class
-                rep_all_teacher, lazy_t = None, head.LazyTeacher3D(*kfe.forward_lowres2(fm_t), kfe.fea3.weight, kfe.fea4.weight)
+                rep_all_teacher, lazy_t = None, self._lazy_teacher(kfe, fm_t)
         fm_s = adist.mark_heads_done(fm_s, self.optimizer, self.heads_start)     # data parallel: heads' gradient bucket reduced early
         if dense:
             rep_all = self.q_rep(qfe(fm_s))                              # :289-296,301
         else:
-            x2p, f3, f4 = qfe.forward_lowres2(fm_s)
+            s_maps = qfe.forward_lowres1(fm_s) if HEAD_LEVELS == 3 else qfe.forward_lowres2(fm_s)
         if lists_done is not None:
             torch.cuda.current_stream().wait_event(lists_done)
         else:
@@ -386,8 +395,12 @@ class ArcoStep3D:
             A_all = C_.GatherRowsFn.apply(rep_all, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
         else:
-            A_all = head.lazy_head3d(x2p, f3, f4, qfe.fea3.weight, qfe.fea4.weight, self.q_representation[0].weight,
-                                     self.q_representation[1].weight, plan.anchor_pix)
+            if HEAD_LEVELS == 3:
+                A_all = head.lazy_head3d_l3(*s_maps, qfe.fea2.weight, qfe.fea3.weight, qfe.fea4.weight, self.q_representation[0].weight,
+                                            self.q_representation[1].weight, plan.anchor_pix)
+            else:
+                A_all = head.lazy_head3d(*s_maps, qfe.fea3.weight, qfe.fea4.weight, self.q_representation[0].weight,
+                                         self.q_representation[1].weight, plan.anchor_pix)
             reco_loss, _ = C_.contrast_infonce(plan, A_all, self.memobank, temp=0.5)
         if self.keep_debug and plan.valid_seg > 1 and plan.entries:
             self.debug = dict(plan=plan, A_all=A_all.detach(), banks=[m[0] for m in self.memobank])

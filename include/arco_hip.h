@@ -290,6 +290,14 @@ int arco_scatter_upcat_rows3d(const float* dX, long ldx, const int64_t* pix, lon
  * f16 buffer, times the loss scale, saturated at +-65504 (arco_cast_f2h on the touched rows only); arco_zero_rows for f16       */
 int arco_gather_upcat_rows3d_h(const float* lo, long ldlo, int Clo, int Di, int Hi, int Wi, const void* hi, long ldhi, int Chi,
                                int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
+/* The level below evaluated lazily too (arco_amd/head.py LazyHead3dL3Fn; model_3D.py:46-58 one level further down): V = the eight
+ * corner rows (8 j + k, arco_corner_rows3d's order) of every sampled voxel, each already through its own layer; X[j] = cat(their
+ * trilinear blend in the gather's arithmetic, hi[pix[j]]); _bwd: dV[8 j + k] = w8[8 j + k] * dX[j][0..Clo)                        */
+int arco_lerp8_cat_rows3d(const float* V, long ldv, int Clo, int Di, int Hi, int Wi, const float* hi, long ldhi, int Chi,
+                          int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
+int arco_lerp8_cat_rows3d_h(const float* V, long ldv, int Clo, int Di, int Hi, int Wi, const void* hi, long ldhi, int Chi,
+                            int Do, int Ho, int Wo, const int64_t* pix, long n, float* X, long ldx, void* stream);
+int arco_lerp8_rows3d_bwd(const float* dX, long ldx, int Clo, const float* w8, long n, float* dV, long ldv, void* stream);
 int arco_cast_rows_f2h(const float* src, long ld_src, int C, const int64_t* idx, long n, float scale, void* dst, long ld_dst,
                        void* stream);
 int arco_zero_rows_h(void* dst, long ld, int C, const int64_t* idx, long n, void* stream);

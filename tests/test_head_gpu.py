@@ -57,3 +57,70 @@ def test_lazy_teacher_matches_dense_teacher(levels):
         assert x.shape == y.shape
         np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(p_s.numpy(), p_d.numpy(), rtol=1e-3, atol=1e-4)      # (float-atomics scatters: one of 3.2 M weights was seen 7.5e-5 off)
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_three_level_3d_head_and_teacher_match_the_two_level_ones_on_the_dense_map(half):
+    """head.LazyHead3dL3Fn / LazyTeacher3DL3 (fea2 evaluated on the eight corner rows of every sampled voxel; model_3D.py:46-58 one level
+    further down than head.LazyHead3dFn) against the two-level head fed the DENSE x2p = fea2(cat(up(x1p), f2)) + cat(...) built with
+    autograd-capable ops in the reference's order: anchors' rows, every gradient (x1p, f2, f3, f4, fea2 / fea3 / fea4 / q_representation
+    weights), the teacher's prototypes and key rows.  half: f3 / f4 read as stored f16 (ops.fm_rows_half)."""
+    from arco_amd import head, ops, _contrast as C_
+    import fixture_inputs as fx
+    dev = "cuda:0"
+    rs = np.random.RandomState(11)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last_3d)
+    nb, c1, c2, c3, c4 = 2, 192, 32, 16, 16
+    sp1, sp2, sp3 = (4, 5, 3), (8, 10, 6), (16, 20, 12)
+    k2, k3 = c1 + c2, c1 + c2 + c3
+    rnd = lambda *s: torch.from_numpy(rs.standard_normal(s).astype(np.float32)).to(dev)
+    x1p, f2 = cl(rnd(nb, c1, *sp1)), cl(rnd(nb, c2, *sp2))
+    f3, f4 = cl(rnd(nb, c3, *sp3)), cl(rnd(nb, c4, *sp3))
+    if half:
+        f3, f4 = cl(f3.half()), cl(f4.half())
+    w2 = rnd(k2, k2, 1, 1, 1) / np.sqrt(k2)
+    w3 = rnd(k3, k3, 1, 1, 1) / np.sqrt(k3)
+    w4 = rnd(16, k3 + c4, 1, 1, 1) / np.sqrt(k3 + c4)
+    w1, wq = rnd(16, 16, 1, 1, 1) / 4, rnd(16, 16, 1, 1, 1) / 4
+    n_vox = nb * sp3[0] * sp3[1] * sp3[2]
+    pix = torch.from_numpy(rs.randint(0, n_vox, size=200)).to(dev)
+    pix[5] = pix[2]; pix[60] = pix[2]; pix[0] = 0; pix[1] = n_vox - 1          # repeated voxels, the two extreme corners
+    da = rnd(200, 16) * 1e-2
+    prev_scale = ops.LOSS_SCALE
+    ops.LOSS_SCALE = 256.0
+    try:
+        res = {}
+        for mode in ("l3", "l2"):
+            lv = [t.clone().requires_grad_(True) for t in (x1p, f2, w2, w3, w4, w1, wq)]
+            f3l, f4l = f3.clone().requires_grad_(True), f4.clone().requires_grad_(True)
+            if mode == "l3":
+                a = head.lazy_head3d_l3(lv[0], lv[1], f3l, f4l, lv[2], lv[3], lv[4], lv[5], lv[6], pix)
+            else:
+                X2 = torch.cat((ops.trilinear(lv[0], sp2), lv[1]), dim=1)
+                x2p = ops.conv(X2, lv[2], None, residual=True)
+                a = head.lazy_head3d(x2p, f3l, f4l, lv[3], lv[4], lv[5], lv[6], pix)
+            a.backward(da)
+            res[mode] = [a.detach()] + [t.grad for t in lv] + [f3l.grad, f4l.grad]
+        names = ["rows", "dx1p", "df2", "dw2", "dw3", "dw4", "dw1", "dwq", "df3", "df4"]
+        for nme, x, y in zip(names, res["l3"], res["l2"]):
+            assert x.shape == y.shape and x.dtype == y.dtype, nme
+            tol = 2.0 ** -9 if (half and nme in ("df3", "df4")) else 2e-5        # (f16 gradients: one rounding of sums that differ in the last fp32 bits)
+            err = float((x.float() - y.float()).abs().max()) / max(1e-20, float(y.float().abs().max()))
+            assert err <= tol, (nme, err)
+        assert float(res["l3"][2].abs().max()) > 0 and float(res["l3"][1].abs().max()) > 0
+        # untouched f2 rows stay exactly zero (row-sparse gradient)
+        touched = int((res["l3"][2].movedim(1, -1).reshape(-1, c2).abs().sum(1) > 0).sum())
+        assert 0 < touched <= 8 * 200
+        # teacher
+        inp = {k: v.to(dev) for k, v in fx.loss_inputs(9, b=1, n_cls=3, feat=16, spatial=sp3).items()}
+        pl = C_.contrast_masks(inp["label_l"], inp["label_u"], inp["prob_l"], inp["prob_u"], inp["low_mask"], inp["high_mask"], 0.97)
+        with torch.no_grad():
+            x2p = ops.conv(torch.cat((ops.trilinear(x1p, sp2), f2), dim=1), w2, None, residual=True)
+        t3 = head.LazyTeacher3DL3(x1p, f2, f3, f4, w2, w3, w4)
+        t2 = head.LazyTeacher3D(x2p, f3, f4, w3, w4)
+        p3, p2 = t3.prototypes(pl), t2.prototypes(pl)
+        assert p3.shape == p2.shape and float((p3 - p2).abs().max()) <= 2e-5 * float(p2.abs().max())
+        r3, r2 = t3.rows(pix), t2.rows(pix)
+        assert float((r3 - r2).abs().max()) <= 2e-5 * float(r2.abs().max())
+    finally:
+        ops.LOSS_SCALE = prev_scale
