@@ -1012,15 +1012,49 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 
 // one launch packs every conv weight of a model: desc[i] = {src, dst, Cout, Cin, taps, mode, Npad, Kpad, first}
 struct PackDesc { const float* src; float* dst; int Cout, Cin, taps, mode, Npad, Kpad; long first; };
-__global__ void pack_many_kernel(const PackDesc* __restrict__ desc, int n_desc, long total) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int lo = 0, hi = n_desc - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].first <= i) lo = mid; else hi = mid - 1; }
-    const PackDesc d = desc[lo];
-    const long j = i - d.first;
+// One launch for every weight of a network.  grid = (chunks, descriptors): block (x, y) works on descriptor y only - no search.
+//  * taps > 1 (the 3x3 / 3x3x3 weights, ~95 % of the elements): 16 (n) x 16 (k) x taps tiles through LDS.  The torch layout has the
+//    tap index fastest, the packed layout the k index: element-wise each wave load touched 64 different 128-byte lines for 256 useful
+//    bytes (every weight is packed up to four times per step: plain / split, forward / transposed) - 127-132 us per launch for the
+//    V-Net's 38 MB at 0.7 TB/s (profiles/r06_notes.md section 18).  A tile reads sixteen contiguous runs of 16 x taps floats and
+//    writes, per tap, sixteen runs of 16 consecutive k.
+//  * taps == 1 and the GEMM forms of the k2 s2 convolutions (mode >> 3): element-wise, 4096 elements per block step.
+__global__ __launch_bounds__(256) void pack_many_kernel(const PackDesc* __restrict__ desc, int n_desc, long total) {
+  __shared__ float tile[16 * (16 * 27 + 1)];
+  const PackDesc d = desc[blockIdx.y];
+  const int gm = d.mode >> 3;
+  if (gm == 0 && d.taps > 1 && d.taps <= 27 && (d.Npad & 15) == 0 && (d.Kpad & 15) == 0) {
+    const int T = d.taps, run = 16 * T, rs = run + 1;          // LDS row stride (odd distance between the rows of a tile)
+    const int kt = d.Kpad >> 4, n_tiles = (d.Npad >> 4) * kt;
+    const bool tr = (d.mode & 1) != 0;
+    // logical source matrix [A][B][T] (T fastest): forward A = n (< Cout), B = k (< Cin); transposed A = k (< Cout), B = n (< Cin)
+    const int An = d.Cout, Bn = d.Cin;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+      const int n0 = (t / kt) * 16, k0 = (t - (t / kt) * kt) * 16;
+      const int a0 = tr ? k0 : n0, b0 = tr ? n0 : k0;
+      __syncthreads();
+      for (int e = threadIdx.x; e < 16 * run; e += 256) {        // row = a - a0, off = (b - b0) * T + tap: contiguous in the source
+        const int row = e / run, off = e - row * run;
+        const int a = a0 + row, b = b0 + off / T;
+        tile[row * rs + off] = (a < An && b < Bn) ? d.src[((long)a * Bn + b0) * T + off] : 0.f;
+      }
+      __syncthreads();
+      const int nl = threadIdx.x >> 4, kl = threadIdx.x & 15;
+      const int n = n0 + nl, k = k0 + kl;
+      for (int tap = 0; tap < T; ++tap) {
+        const float v = tr ? tile[kl * rs + nl * T + (T - 1 - tap)] : tile[nl * rs + kl * T + tap];
+        const long r = (long)tap * d.Npad + n;
+        if (d.mode & 4) reinterpret_cast<_Float16*>(d.dst)[r * d.Kpad + k] = (_Float16)v;
+        else if (d.mode & 2) store_split3(v, reinterpret_cast<unsigned short*>(d.dst), r, k, d.Kpad);
+        else d.dst[r * d.Kpad + k] = v;
+      }
+    }
+    return;
+  }
+  const long n_el = (long)(gm ? 1 : d.taps) * d.Npad * d.Kpad;
+  for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n_el; j += (long)gridDim.x * 256) {
     const int k = j % d.Kpad; const long r = j / d.Kpad; const int n = r % d.Npad; const int tap = r / d.Npad;
     float v = 0.f;
-    const int gm = d.mode >> 3;
     if (gm) {
       // GEMM form of a k2 s2 (transposed) convolution, gathered straight from the torch layout (round 4: the V-Net's
       // DownsamplingConvBlock / UpsamplingDeconvBlock rebuilt and re-packed their [N][K] weights at every forward: ~130
@@ -2004,8 +2038,8 @@ int arco_conv3d_fwd(const float* in, long ld_in, int K, const float* Wp, int N, 
 long arco_pack_desc_bytes() { return (long)sizeof(PackDesc); }
 int arco_pack_many(const void* desc, int n_desc, long total, void* stream) {
   if (n_desc <= 0 || total <= 0) return ARCO_OK;
-  long g = (total + 255) / 256; if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), (const PackDesc*)desc, n_desc, total);
+  // (the descriptors live in device memory: the x extent is a bound - 256 tiles cover a 256 x 256 weight, element-wise blocks stride)
+  hipLaunchKernelGGL(pack_many_kernel, dim3(256, (unsigned)n_desc), dim3(256), 0, as_stream(stream), (const PackDesc*)desc, n_desc, total);
   return arco_launch_status();
 }
 

@@ -698,3 +698,44 @@ def test_feature_extractor_3d_commuted_forward_equals_the_reference_order():
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
     for n in g0:
         assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * float(g1[n].abs().max()), n
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_pack_plan_buffers_equal_the_single_weight_packer(half):
+    """arco_pack_many (one launch per network: 16 x 16 x taps tiles through LDS for the 3x3 / 3x3x3 weights, element-wise for the 1x1 ones
+    and the GEMM forms of the k2 s2 convolutions) against arco_pack_conv_weight on every entry: plain, split-bf16 and f16 packs,
+    forward and transposed, channel counts that are not multiples of 16 (ragged tiles), 2-D and 3-D."""
+    from arco_amd import ops
+    prev_mma, prev_half = ops.CONV_MMA, ops.ACT_HALF
+    ops.CONV_MMA = 3
+    try:
+        g = torch.Generator().manual_seed(4)
+        mods = [torch.nn.Conv3d(16, 32, 3, padding=1), torch.nn.Conv3d(40, 24, 3, padding=1), torch.nn.Conv3d(256, 256, 3, padding=1),
+                torch.nn.Conv3d(64, 16, 1), torch.nn.Conv3d(8, 8, 3, padding=1)]
+        if not half:
+            mods += [torch.nn.Conv2d(16, 16, 3, padding=1), torch.nn.Conv2d(20, 4, 3, padding=1), torch.nn.Conv2d(4, 36, 3, padding=1),
+                     torch.nn.Conv2d(496, 32, 1)]
+        mods = [m.cuda() for m in mods]
+        with torch.no_grad():
+            for m in mods:
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g).cuda())
+        ops.ACT_HALF = half
+        plan = ops.PackPlan(mods, True)
+        plan.refresh()
+        torch.cuda.synchronize()
+        n_checked = 0
+        for w, mode, buf, sbuf, hbuf in plan.entries:
+            co, ci, taps = int(w.shape[0]), int(w.shape[1]), ops._taps(w)
+            wd = w.detach().contiguous()
+            if buf is not None:
+                assert torch.equal(buf, ops._pack_now(wd, co, ci, taps, mode, False)), (tuple(w.shape), mode, "plain")
+                n_checked += 1
+            if sbuf is not None:
+                assert torch.equal(sbuf.view(torch.int32), ops._pack_now(wd, co, ci, taps, mode, True).view(torch.int32)), (tuple(w.shape), mode, "split")
+                n_checked += 1
+            if hbuf is not None:
+                assert torch.equal(hbuf, ops._pack_now(wd, co, ci, taps, mode, False, half=True)), (tuple(w.shape), mode, "half")
+                n_checked += 1
+        assert n_checked >= (8 if half else 24), n_checked
+    finally:
+        ops.CONV_MMA, ops.ACT_HALF = prev_mma, prev_half
