@@ -892,6 +892,93 @@ static int hconv_fc_dispatch(const IgemmArgs& a, hipStream_t st, int* q) {
   return -1;
 }
 
+// Streaming narrow 1x1x1 convolutions on f16 storage (see conv1x1_narrow_out_kernel in igemm.hip): the V-Net's out_conv and its data
+// gradient over the full-resolution f16 map (157 MB at the LiTS size) ran 115 us on 256 x 16 GEMM tiles; fp32 FMAs of the exact
+// f16 x f16 products, one rounding to f16 at the store - as the MFMA route (fp32 accumulation), in a different summation order.
+template <int Q>
+__global__ __launch_bounds__(256) void hconv1x1_narrow_out_kernel(IgemmArgs a) {
+  const _Float16* const Ag = reinterpret_cast<const _Float16*>(a.A);
+  const _Float16* const Wg = reinterpret_cast<const _Float16*>(a.Wp);
+  _Float16* const Cg = reinterpret_cast<_Float16*>(a.C);
+  const int lq = threadIdx.x % Q;
+  float w[4][8], bs[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    bs[n] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int k = 8 * lq + e; w[n][e] = (n < a.N && k < a.K) ? (float)Wg[(long)n * a.Kpad + k] : 0.f; }
+  }
+  const long rstride = (long)gridDim.x * (256 / Q);
+  for (long row = (long)blockIdx.x * (256 / Q) + threadIdx.x / Q; row < a.M; row += rstride) {
+    const h8 x = *reinterpret_cast<const h8*>(Ag + row * a.lda + 8 * lq);
+    float p[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float acc = (float)x[0] * w[n][0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) acc = fmaf((float)x[e], w[n][e], acc);
+      p[n] = acc;
+    }
+#pragma unroll
+    for (int off = 1; off < Q; off <<= 1)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) p[n] += __shfl_xor(p[n], off);
+    if (lq == 0) {
+      _Float16* o = Cg + row * a.ldc;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) if (n < a.N) o[n] = (_Float16)(p[n] + bs[n]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void hconv1x1_narrow_in_kernel(IgemmArgs a) {
+  const _Float16* const Ag = reinterpret_cast<const _Float16*>(a.A);
+  const _Float16* const Wg = reinterpret_cast<const _Float16*>(a.Wp);
+  _Float16* const Cg = reinterpret_cast<_Float16*>(a.C);
+  const int Q = a.N >> 3, lq = threadIdx.x % Q;
+  float w[4][8], bq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bq[e] = a.bias ? a.bias[8 * lq + e] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k][e] = k < a.K ? (float)Wg[(long)(8 * lq + e) * a.Kpad + k] : 0.f;
+  }
+  const long rstride = (long)gridDim.x * (256 / Q);
+  for (long row = (long)blockIdx.x * (256 / Q) + threadIdx.x / Q; row < a.M; row += rstride) {
+    const _Float16* x = Ag + row * a.lda;
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = bq[e];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < a.K) { const float xv = (float)x[k];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = fmaf(xv, w[k][e], y[e]); }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)y[e];
+    *reinterpret_cast<h8*>(Cg + row * a.ldc + 8 * lq) = o;
+  }
+}
+static int hconv1x1_stream_dispatch(const IgemmArgs& a, hipStream_t st) {
+  static const int on = getenv("ARCO_CONV1X1_STREAM") ? atoi(getenv("ARCO_CONV1X1_STREAM")) : 1;
+  if (!on || a.stat_sum || a.R || a.pro.mean || a.Rup || a.ksplit > 1 || a.batch > 1 || a.M < 65536) return -1;
+  long blocks;
+  if (a.N >= 1 && a.N <= 4 && (a.K == 8 || a.K == 16 || a.K == 32) && (a.lda & 7) == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0) {
+    const int Q = a.K / 8;
+    blocks = (a.M + (256 / Q) * 8 - 1) / ((256 / Q) * 8); if (blocks > 16384) blocks = 16384;
+    if (Q == 1) hipLaunchKernelGGL(hconv1x1_narrow_out_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (Q == 2) hipLaunchKernelGGL(hconv1x1_narrow_out_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(hconv1x1_narrow_out_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return arco_launch_status();
+  }
+  if (a.K >= 1 && a.K <= 4 && (a.N == 8 || a.N == 16 || a.N == 32) && (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0) {
+    const int Q = a.N / 8;
+    blocks = (a.M + (256 / Q) * 8 - 1) / ((256 / Q) * 8); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(hconv1x1_narrow_in_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return arco_launch_status();
+  }
+  return -1;
+}
+
 // entry of the f16-storage convolutions (called from arco_conv3d_fwd with mma == 4).  a.Kpad = ceil32(K) (the f16 pack)
 int hconv_dispatch(const IgemmArgs& a, int taps, hipStream_t st, int* q) {
   if ((taps != 1 && ((a.K & 7) != 0 || (a.lda & 7) != 0)) || a.R != nullptr) return ARCO_ERR_UNSUPPORTED;
@@ -907,6 +994,7 @@ int hconv_dispatch(const IgemmArgs& a, int taps, hipStream_t st, int* q) {
     return hconv_dispatch3<false>(a, st, q);
   }
   if (taps == 1) {
+    if (!q) { const int r = hconv1x1_stream_dispatch(a, st); if (r != -1) return r; }
     if (a.Npad <= 16) return launch_hconv<1, 256, 16, 4, 1, 1, false>(a, st, q);
     if (a.Npad <= 32) return launch_hconv<1, 128, 32, 4, 1, 1, false>(a, st, q);
     if (a.M * (long)a.Npad <= 4096l * 1024) {

@@ -913,7 +913,109 @@ static int launch_image_conv(const IgemmArgs& a, hipStream_t st, int* q) {
   hipLaunchKernelGGL(conv3x3_image_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
   return arco_launch_status();
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Streaming 1x1(x1) convolutions with a handful of channels on one side (round 6).  The V-Net's out_conv (16 -> classes,
+// vnetWithArgs.py:182) and its data gradient (classes -> 16) run over the FULL-resolution map: 128 MB (LA) per launch for
+// 0.06 GFLOP.  As GEMMs on 256 x 16 tiles (N padded 2 -> 16, K padded 16 -> 32, operands staged and split through LDS) they ran
+// 85 us / 204 us - 1.5 / 0.6 TB/s; they are streams.  fp32 FMAs in a fixed order (deterministic; values differ from the MFMA
+// route by fp32 rounding of a 16-term sum).
+//   narrow-out (Q = K / 4 lanes per row, N <= 4): lane (row, quad) multiplies its input quad with its 4 N weights, the Q partial
+//     sums meet in an xor butterfly, lane quad 0 writes the row's N outputs.  Weights: the split-bf16 pack (mma 3), summed back
+//     to the exact fp32 value (the three terms are an exact decomposition), or the plain fp32 pack.
+//   narrow-in (K <= 4, N = 4 Q outputs, plain fp32 pack): lane (row, quad) reads the row's K inputs and writes one 16-byte quad.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(256) void conv1x1_narrow_out_kernel(IgemmArgs a) {
+  const int lq = threadIdx.x % Q;
+  float w[4][4], bs[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    bs[n] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * lq + e;
+      float v = 0.f;
+      if (n < a.N && k < a.K) {
+        if (a.mma == 3) {
+          const unsigned short* wp = reinterpret_cast<const unsigned short*>(a.Wp) + ((long)n * a.Kg + (k >> 4)) * 48 + (k & 15);
+          const float b0 = __uint_as_float((unsigned)wp[0] << 16), b1 = __uint_as_float((unsigned)wp[16] << 16), b2 = __uint_as_float((unsigned)wp[32] << 16);
+          v = (b0 + b1) + b2;
+        } else {
+          v = a.Wp[(long)n * a.Kpad + k];
+        }
+      }
+      w[n][e] = v;
+    }
+  }
+  const long rstride = (long)gridDim.x * (256 / Q);
+  for (long row = (long)blockIdx.x * (256 / Q) + threadIdx.x / Q; row < a.M; row += rstride) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a.A + row * a.lda + 4 * lq);
+    float p[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) p[n] = fmaf(x[3], w[n][3], fmaf(x[2], w[n][2], fmaf(x[1], w[n][1], x[0] * w[n][0])));
+#pragma unroll
+    for (int off = 1; off < Q; off <<= 1)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) p[n] += __shfl_xor(p[n], off);
+    if (lq == 0) {
+      float* o = a.C + row * a.ldc;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) if (n < a.N) o[n] = p[n] + bs[n];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void conv1x1_narrow_in_kernel(IgemmArgs a) {
+  const int Q = a.N >> 2, lq = threadIdx.x % Q;
+  f32x4 w[4], bq = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[k][e] = k < a.K ? a.Wp[(long)(4 * lq + e) * a.Kpad + k] : 0.f;
+  if (a.bias) bq = *reinterpret_cast<const f32x4*>(a.bias + 4 * lq);
+  const long rstride = (long)gridDim.x * (256 / Q);
+  for (long row = (long)blockIdx.x * (256 / Q) + threadIdx.x / Q; row < a.M; row += rstride) {
+    const float* x = a.A + row * a.lda;
+    f32x4 y = bq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < a.K) { const float xv = x[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = fmaf(xv, w[k][e], y[e]); }
+    if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + row * a.ldr + 4 * lq);
+    *reinterpret_cast<f32x4*>(a.C + row * a.ldc + 4 * lq) = y;
+  }
+}
+// -1: not taken.  ARCO_CONV1X1_STREAM=0: off (A/B)
+static int conv1x1_stream_dispatch(const IgemmArgs& a, hipStream_t st) {
+  static const int on = getenv("ARCO_CONV1X1_STREAM") ? atoi(getenv("ARCO_CONV1X1_STREAM")) : 1;
+  if (!on || a.stat_sum || a.pro.mean || a.Rup || a.ksplit > 1 || a.batch > 1 || a.M < 65536 || (a.mma != 3 && a.mma != 0)) return -1;
+  const long rows_per_block_min = 8;
+  if (!a.R && a.N >= 1 && a.N <= 4 && (a.K == 4 || a.K == 8 || a.K == 16 || a.K == 32) && (a.lda & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(a.A) & 15) == 0) {
+    const int Q = a.K / 4;
+    long blocks = (a.M + (256 / Q) * rows_per_block_min - 1) / ((256 / Q) * rows_per_block_min);
+    if (blocks > 16384) blocks = 16384;
+    switch (Q) {
+      case 1: hipLaunchKernelGGL(conv1x1_narrow_out_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 2: hipLaunchKernelGGL(conv1x1_narrow_out_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 4: hipLaunchKernelGGL(conv1x1_narrow_out_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL(conv1x1_narrow_out_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+    }
+    return arco_launch_status();
+  }
+  if (a.mma == 0 && a.K >= 1 && a.K <= 4 && (a.N == 4 || a.N == 8 || a.N == 16 || a.N == 32) && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) &&
+      (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 && (!a.R || (reinterpret_cast<uintptr_t>(a.R) & 15) == 0) &&
+      (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0)) {
+    const int Q = a.N / 4;
+    long blocks = (a.M + (256 / Q) * rows_per_block_min - 1) / ((256 / Q) * rows_per_block_min);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(conv1x1_narrow_in_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return arco_launch_status();
+  }
+  return -1;
+}
+
 static int dispatch_igemm(const IgemmArgs& a, int taps, hipStream_t st, int* nmb) {
+  if (taps == 1 && !nmb) { const int r = conv1x1_stream_dispatch(a, st); if (r != -1) return r; }
   if (taps == 1 && a.mma == 3) {      // split-bf16 GEMMs: K chunks of 32
     if (!nmb) {                       // the wide many-tile GEMMs: the software-pipelined kernel of gemm_sp.hip (launches only: the
       const int r = gemm_sp_dispatch(a, st, nullptr);      // tile queries describe igemm_kernel, which every statistics launch uses)

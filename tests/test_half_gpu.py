@@ -76,7 +76,9 @@ def test_conv3x3x3_f16_storage_forward_backward(ci, co, D, H, W):
 
 
 @pytest.mark.parametrize("ci,co,M", [(128, 32, (6, 10, 12)), (256, 64, (5, 6, 6)), (32, 128, (8, 12, 16)), (16, 2, (8, 16, 16)),
-                                     (1024, 256, (3, 5, 3)), (256, 1024, (3, 5, 3))])
+                                     (1024, 256, (3, 5, 3)), (256, 1024, (3, 5, 3)),
+                                     # >= 65 536 rows with <= 4 channels on one side: the streaming kernels (hconv1x1_narrow_out / _in)
+                                     (16, 2, (48, 40, 36)), (16, 4, (40, 40, 44)), (32, 2, (36, 40, 24)), (8, 4, (48, 48, 32))])
 def test_conv1x1x1_f16_storage_forward_backward(ci, co, M):
     from arco_amd import ops
     dev = "cuda:0"

@@ -739,3 +739,35 @@ def test_pack_plan_buffers_equal_the_single_weight_packer(half):
         assert n_checked >= (8 if half else 24), n_checked
     finally:
         ops.CONV_MMA, ops.ACT_HALF = prev_mma, prev_half
+
+
+@pytest.mark.parametrize("ci,co", [(16, 2), (16, 4), (32, 3), (8, 1), (4, 4)])
+def test_streaming_narrow_1x1_convolutions_match_fp64(ci, co):
+    """conv1x1_narrow_out_kernel / conv1x1_narrow_in_kernel (the V-Net's out_conv 16 -> classes, vnetWithArgs.py:182, and its data gradient
+    at full resolution as streams instead of padded GEMM tiles): forward, data gradient and weight / bias gradients against float64,
+    in the split-bf16 mode the trainers run and in the plain fp32 mode; a non-dense input (channel slice) and a launch below the
+    streaming threshold take the GEMM route and must agree with it."""
+    from arco_amd import ops
+    _cl = lambda t: t.contiguous(memory_format=torch.channels_last_3d)
+    prev = ops.CONV_MMA
+    try:
+        for mma in (3, 0):
+            ops.CONV_MMA = mma
+            ops._cfg_cache.clear()
+            g = torch.Generator().manual_seed(ci * 10 + co + mma)
+            for sp in ((48, 40, 36), (8, 8, 8)):                     # 69 120 rows x 1 volume (streamed), 512 rows (GEMM tiles)
+                x = _cl(torch.randn(1, ci, *sp, generator=g).cuda()).requires_grad_(True)
+                w = (torch.randn(co, ci, 1, 1, 1, generator=g) / ci ** 0.5).cuda().requires_grad_(True)
+                b = torch.randn(co, generator=g).cuda().requires_grad_(True)
+                y = ops.conv(x, w, b)
+                gy = _cl(torch.randn(y.shape, generator=g).cuda())
+                y.backward(gy)
+                xd, wd, bd = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+                yd = torch.nn.functional.conv3d(xd, wd, bd)
+                yd.backward(gy.double().cpu())
+                for name, got, ref in (("y", y, yd), ("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", b.grad, bd.grad)):
+                    err = float((got.detach().double().cpu() - ref.detach()).abs().max()) / max(1e-30, float(ref.detach().abs().max()))
+                    assert err < 3e-6, (name, mma, sp, err)
+    finally:
+        ops.CONV_MMA = prev
+        ops._cfg_cache.clear()
