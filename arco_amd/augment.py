@@ -83,7 +83,30 @@ def generate_class_mask(pseudo_labels):
     return table[t.clamp(0, 63)] * (t >= 0)
 
 
-def _mix(data, target, logits, mode):
+def draw_boxes(B, spatial):
+    """The host draws of the cutout / cutmix strategies (one half-area box per image, augment.py:229-245) as the descriptor table of
+    arco_mix_unsup - drawn apart from the mixing so that a trainer can mix the IMAGES (which need the boxes only) before the teacher
+    pass that produces the pseudo-labels has finished, and the labels / logits afterwards, with the same boxes (_mix(..., desc=))."""
+    desc = np.zeros((B, 8), dtype=np.int32)
+    desc[:, 5] = 1
+    for i in range(B):
+        box = _cutout_box(list(spatial), ratio=2)
+        desc[i, :len(box)] = box
+    return desc
+
+
+def mix_images(data, mode, desc):
+    """new_data of generate_unsup_data(_3d) alone, for boxes drawn by draw_boxes (cutout / cutmix: the image mix does not read the
+    pseudo-labels)."""
+    assert mode in ("cutout", "cutmix")
+    B = int(data.shape[0])
+    sp = tuple(int(v) for v in data.shape[2:])
+    dummy_t = torch.zeros((B,) + sp, dtype=torch.int64, device=data.device)
+    dummy_l = torch.zeros((B,) + sp, dtype=torch.float32, device=data.device)
+    return _mix(data, dummy_t, dummy_l, mode, desc=desc)[0]
+
+
+def _mix(data, target, logits, mode, desc=None):
     L.require_gpu(data, target, logits)
     if mode not in _MODES:                                   # reference: mask of ones -> the inputs unchanged
         return data, target.long(), logits
@@ -93,17 +116,17 @@ def _mix(data, target, logits, mode):
     data = data.to(torch.float32).contiguous()
     logits = logits.to(torch.float32).contiguous()
     tgt = target.to(torch.int64).contiguous()
-    desc = np.zeros((B, 8), dtype=np.int32)
-    desc[:, 5] = 1
-    if mode == "classmix":
+    if desc is not None:
+        assert mode != "classmix" and desc.shape == (B, 8)
+    elif mode == "classmix":
+        desc = np.zeros((B, 8), dtype=np.int32)
+        desc[:, 5] = 1
         sets = _label_sets(tgt)
         for i in range(B):
             sel = _select_half(sets[i])
             desc[i, 6], desc[i, 7] = np.uint32(sel & 0xFFFFFFFF).astype(np.int32), np.uint32(sel >> 32).astype(np.int32)
     else:
-        for i in range(B):
-            box = _cutout_box(list(sp), ratio=2)
-            desc[i, :len(box)] = box
+        desc = draw_boxes(B, sp)
     odata, otarget, ologits = torch.empty_like(data), torch.empty_like(tgt), torch.empty_like(logits)
     L.call("arco_mix_unsup", L.ptr(data), Cimg, L.ptr(tgt), L.ptr(logits), B, H, W, Z, desc.ctypes.data_as(ctypes.c_void_p), _MODES[mode], L.ptr(odata),
            L.ptr(otarget), L.ptr(ologits))
@@ -121,10 +144,10 @@ def generate_unsup_data(data, target, logits, mode='cutout'):
     return _mix(data, target, logits, mode)
 
 
-def generate_unsup_data_3d(data, target, logits, mode='cutout'):
-    """Volume variant (augment_3d.py:228-257): the box is 10 slices deep along the last axis."""
+def generate_unsup_data_3d(data, target, logits, mode='cutout', desc=None):
+    """Volume variant (augment_3d.py:228-257): the box is 10 slices deep along the last axis.  desc: boxes drawn earlier (draw_boxes)."""
     assert data.dim() == 5, data.shape
-    return _mix(data, target, logits, mode)
+    return _mix(data, target, logits, mode, desc=desc)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

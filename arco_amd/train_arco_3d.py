@@ -35,6 +35,10 @@ LISTS_SIDE = int(os.environ.get("ARCO_LISTS_SIDE", "1"))
 # lazy levels of the row-sparse heads: 2 = fea3 / fea4 on rows over the dense 56x56x40 map of fea2 (rounds 2-5), 3 = fea2 on rows too - the
 # 224-channel map at 56x56x40 (450 MB at the LA size) is never written (head.LazyHead3dL3Fn, round 6)
 HEAD_LEVELS = int(os.environ.get("ARCO_HEAD3D_LEVELS", "3"))
+# ARCO_U0_SIDE=1: the teacher's first pass beside the grouped student pass (cutout / cutmix; see ArcoStep3D.step).  Opt-in: measured level
+# (LA 21.2-21.3 -> 21.3-21.4 ms, LiTS-f16 13.7 -> 13.6-13.7) - the teacher's two passes stay serial on the second stream, which is then the
+# longer one; running them beside each other as well needs their BatchNorm running-statistics updates deferred (profiles/r06_notes.md section 20)
+U0_SIDE = int(os.environ.get("ARCO_U0_SIDE", "0"))
 FM_ROWS_HALF = int(os.environ.get("ARCO_FM_ROWS_HALF", "1"))     # --act_dtype f16: heads read the full-resolution maps as f16 (ops.fm_rows_half)
 FEA_DIM_3D = [128, 64, 32, 16, 16]
 REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
@@ -238,13 +242,30 @@ class ArcoStep3D:
         # f16 row-sparse gradients) - no dense cast of a full-resolution map in either direction (ops.fm_rows_half)
         rows_half = ops.ACT_HALF and FM_ROWS_HALF and not getattr(a, "dense_head", 0) and self.random_pool is None
         fm_ctx = ops.fm_rows_half if rows_half else contextlib.nullcontext
-        with torch.no_grad(), ops.logits_only():                         # :260-262
-            pred_u0, _, _ = self.t_fwd_u0(u_data)
-            pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
-        if self.keep_debug:      # tests: the teacher's decisions before the mixing (cutout writes -1 into the labels in place)
-            dbg_pseudo = (pseudo_labels.clone(), pseudo_logits.clone())
-        # :268-278: the mixing strategy of --apply_aug on the GPU (train_arco_3d.py:270-271); the PIL transforms are identity
-        u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data_3d(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
+        # (opt-in, U0_SIDE) The teacher's first pass (pseudo-labels, :260-262) runs ALONE at the head of the step (2.2 of 20.8 ms at the LA size).
+        # With cutout / cutmix the mixed IMAGES need only the boxes - host draws -, not the pseudo-labels: the boxes are drawn at the
+        # reference's point of the generator order, the images are mixed at once, the grouped student pass starts on this stream while
+        # the teacher's first pass and, behind it on the same (second) stream, its grouped pass run beside it; labels and logits are
+        # mixed with the same boxes once the teacher is done.  classmix (its masks are the pseudo-labels') keeps the serial order.
+        u0_side = (U0_SIDE and PASS_SIDE >= 1 and a.apply_aug in ("cutout", "cutmix") and self.batched_passes
+                   and l_data.shape == u_data.shape)
+        if u0_side:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            mix_desc = augment.draw_boxes(int(u_data.shape[0]), tuple(int(v) for v in u_data.shape[2:]))
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side), torch.no_grad(), ops.logits_only():      # :260-262
+                pred_u0, _, _ = self.t_fwd_u0(u_data)
+                pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
+            u_aug = augment.mix_images(u_data, a.apply_aug, mix_desc)
+        else:
+            with torch.no_grad(), ops.logits_only():                         # :260-262
+                pred_u0, _, _ = self.t_fwd_u0(u_data)
+                pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
+            if self.keep_debug:      # tests: the teacher's decisions before the mixing (cutout writes -1 into the labels in place)
+                dbg_pseudo = (pseudo_labels.clone(), pseudo_logits.clone())
+            # :268-278: the mixing strategy of --apply_aug on the GPU (train_arco_3d.py:270-271); the PIL transforms are identity
+            u_aug, u_aug_label, u_aug_logits = augment.generate_unsup_data_3d(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug)
         self.k_fe_ema.update(0.99)                                      # :279-281
         batched = self.batched_passes and l_data.shape == u_aug.shape
         lazy_t_side = None
@@ -268,6 +289,10 @@ class ArcoStep3D:
                 pred_all, _, fm_s = self.s_train_lu(lu)                  # :283-284
             if t_side is not None:
                 torch.cuda.current_stream().wait_event(t_done)
+            if u0_side:          # (t_done lies behind the teacher's first pass on the same stream)
+                if self.keep_debug:
+                    dbg_pseudo = (pseudo_labels.clone(), pseudo_logits.clone())
+                _, u_aug_label, u_aug_logits = augment.generate_unsup_data_3d(u_data, pseudo_labels, pseudo_logits, mode=a.apply_aug, desc=mix_desc)
             pred_l, pred_u = ops.split_batch(pred_all, nb_l)
             if PASS_SIDE >= 3:     # the warped pass's inputs (volumes, mixed labels, the grouped pass's logits) exist from here on
                 self._fwd_ready = torch.cuda.current_stream().record_event()
