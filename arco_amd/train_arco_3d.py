@@ -39,6 +39,12 @@ HEAD_LEVELS = int(os.environ.get("ARCO_HEAD3D_LEVELS", "3"))
 # (LA 21.2-21.3 -> 21.3-21.4 ms, LiTS-f16 13.7 -> 13.6-13.7) - the teacher's two passes stay serial on the second stream, which is then the
 # longer one; running them beside each other as well needs their BatchNorm running-statistics updates deferred (profiles/r06_notes.md section 20)
 U0_SIDE = int(os.environ.get("ARCO_U0_SIDE", "0"))
+# T_MERGE (default; ARCO_T_MERGE=0: the serial order of rounds 2-5): the teacher's first pass and its grouped pass as ONE pass over
+# cat(u, l, u_aug) with three BatchNorm groups (running statistics updated group after group: u, l, u_aug - the reference's order,
+# train_arco_3d.py:260-262, 286-287), on the second stream beside the student's grouped pass.  Possible with cutout / cutmix, whose mixed
+# images need the host-drawn boxes only (classmix masks are the pseudo-labels': serial order).  LA 21.1-21.2 -> 20.3 ms, LiTS-f16 13.5-13.6 -> 13.2
+# on the same box (profiles/r06_notes.md section 20)
+T_MERGE = int(os.environ.get("ARCO_T_MERGE", "1"))
 FM_ROWS_HALF = int(os.environ.get("ARCO_FM_ROWS_HALF", "1"))     # --act_dtype f16: heads read the full-resolution maps as f16 (ops.fm_rows_half)
 FEA_DIM_3D = [128, 64, 32, 16, 16]
 REP_DIM_3D = 16                                  # train_arco_3d.py:148,207
@@ -145,6 +151,7 @@ class ArcoStep3D:
         self.s_train_lu = graphs.GraphedTrain(self.model, enabled=g_train)
         self.t_fwd_lu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u0 = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
+        self.t_fwd_ulu = graphs.GraphedForward(self.ema_model, enabled=use_graphs)      # T_MERGE: (u, l, u_aug) as one three-group pass
         self.t_fwd_l = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         self.t_fwd_u = graphs.GraphedForward(self.ema_model, enabled=use_graphs)
         # the warped student pass carries no gradient after iteration 0 (:390-393): replayed as one graph - its ~300 eager
@@ -247,9 +254,15 @@ class ArcoStep3D:
         # reference's point of the generator order, the images are mixed at once, the grouped student pass starts on this stream while
         # the teacher's first pass and, behind it on the same (second) stream, its grouped pass run beside it; labels and logits are
         # mixed with the same boxes once the teacher is done.  classmix (its masks are the pseudo-labels') keeps the serial order.
-        u0_side = (U0_SIDE and PASS_SIDE >= 1 and a.apply_aug in ("cutout", "cutmix") and self.batched_passes
+        u0_side = ((U0_SIDE or T_MERGE) and PASS_SIDE >= 1 and a.apply_aug in ("cutout", "cutmix") and self.batched_passes
                    and l_data.shape == u_data.shape)
-        if u0_side:
+        t_merge = bool(u0_side and T_MERGE)
+        if t_merge:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            mix_desc = augment.draw_boxes(int(u_data.shape[0]), tuple(int(v) for v in u_data.shape[2:]))
+            u_aug = augment.mix_images(u_data, a.apply_aug, mix_desc)
+        elif u0_side:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             mix_desc = augment.draw_boxes(int(u_data.shape[0]), tuple(int(v) for v in u_data.shape[2:]))
@@ -279,8 +292,15 @@ class ArcoStep3D:
                 t_side = self._side
                 t_side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(t_side), torch.no_grad():
-                    with ops.bn_groups(2), fm_ctx():
-                        pred_t, _, fm_t = self.t_fwd_lu(lu)              # :286-287
+                    if t_merge:
+                        nb_u = int(u_data.shape[0])
+                        with ops.bn_groups(3), fm_ctx():
+                            pred_ulu, _, fm_ulu = self.t_fwd_ulu(torch.cat((u_data, lu)))      # :260-262 and :286-287 in one pass
+                        pred_u0, pred_t, fm_t = pred_ulu[:nb_u], pred_ulu[nb_u:], [f[nb_u:] for f in fm_ulu]
+                        pseudo_logits, pseudo_labels = glue.softmax_max(pred_u0)
+                    else:
+                        with ops.bn_groups(2), fm_ctx():
+                            pred_t, _, fm_t = self.t_fwd_lu(lu)              # :286-287
                     t_done = t_side.record_event()
                     if PASS_SIDE >= 3 and not getattr(a, "dense_head", 0):   # :292-293 (the teacher's heads: joined before the row lists)
                         kfe = self.k_feature_extractor
