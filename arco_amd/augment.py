@@ -135,13 +135,13 @@ def _mix(data, target, logits, mode, desc=None):
     return odata, otarget, ologits
 
 
-def generate_unsup_data(data, target, logits, mode='cutout'):
+def generate_unsup_data(data, target, logits, mode='cutout', desc=None):
     """(new_data [b,c,H,W], new_target int64 [b,H,W], new_logits [b,H,W]) - augment.py:284-313.
     cutout: data, logits zeroed and target = -1 inside a random half-area rectangle per image; cutmix: that rectangle
     is filled from image (i+1) % b; classmix: a random half of image i's labels keep their pixels, the rest comes from
     image (i+1) % b.  Any other mode returns the inputs."""
     assert data.dim() == 4, data.shape
-    return _mix(data, target, logits, mode)
+    return _mix(data, target, logits, mode, desc=desc)          # desc: boxes drawn earlier (draw_boxes)
 
 
 def generate_unsup_data_3d(data, target, logits, mode='cutout', desc=None):
