@@ -60,3 +60,21 @@ def test_3x3x3_launch_shapes_of_the_la_levels():
     # shapes the pipelined kernels do not take stay on igemm_kernel: planes wider than 61 pixels, N not a multiple of 32
     assert int(L.query("arco_conv_config_mma", 27, 64, 80, 80, 32, 32, 32, 3)) < 9270000
     assert not 9270000 <= int(L.query("arco_conv_config_mma", 27, 64, 28, 20, 32, 48, 32, 3)) < 9300000
+
+
+def test_draw_boxes_consumes_the_generator_like_the_inline_mixing_loop():
+    """augment.draw_boxes (round 6: the boxes of cutout / cutmix drawn apart from the mixing, so that the image side can run before the
+    teacher's pseudo-labels exist) must leave numpy's generator where the reference's per-image generate_cutout_mask(_3d) calls leave it
+    (augment.py:229-245, 284-313) and return those boxes - 2-D and 3-D."""
+    import numpy as np
+    from arco_amd import augment
+    for sp in ((256, 256), (112, 112, 80), (64, 48)):
+        np.random.seed(17)
+        desc = augment.draw_boxes(5, sp)
+        after = np.random.randint(0, 1 << 30)
+        np.random.seed(17)
+        ref = [augment._cutout_box(list(sp), ratio=2) for _ in range(5)]
+        assert np.random.randint(0, 1 << 30) == after
+        assert desc.shape == (5, 8) and desc.dtype == np.int32
+        for i, box in enumerate(ref):
+            assert list(desc[i, :len(box)]) == box and desc[i, 5] == (box[5] if len(box) == 6 else 1)
